@@ -1,0 +1,188 @@
+/* lsdhip.h — C ABI of the MI355X-native LSD-SLAM dense hot path (liblsdhip.so).
+ *
+ * The reference (tum-vision/lsd_slam) has no plugin/FFI layer: the boundary of this path is the C++ class API
+ * consumed by SlamSystem.  Each entry point below names the reference interface it replaces
+ * (`C/` = lsd_slam_core/src/).  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ * The header-only C++ adapters in include/lsd_slam_hip.hpp put the reference's class signatures
+ * (lsd_slam::SE3Tracker::trackFrame, lsd_slam::DepthMap::updateKeyframe / createKeyFrame …) back on top of it.
+ *
+ * Conventions
+ *   - poses: double[7] = (qw,qx,qy,qz,tx,ty,tz) (Sophus::SE3d content), Sim3: double[8] with scale last.
+ *   - every call returns an int status: 0 ok, >0 algorithmic condition (1 = tracking diverged), <0 usage /
+ *     runtime error (LSDHIP_E_*).  Nothing throws across the boundary.
+ *   - a context owns one HIP stream; all calls on objects of one context are serialised on that stream and are
+ *     synchronous from the caller's point of view unless documented otherwise.  Different contexts may be
+ *     used concurrently from different host threads (C/SlamSystem.h:124-132: tracking and mapping threads).
+ *   - "host" pointers are ordinary host memory; "dev" pointers are device memory on the context's GPU.
+ */
+#ifndef LSDHIP_H
+#define LSDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSDHIP_PYRAMID_LEVELS 5 /* C/util/settings.h:98-106 */
+
+#define LSDHIP_OK 0
+#define LSDHIP_DIVERGED 1
+#define LSDHIP_E_ARG (-1)
+#define LSDHIP_E_HIP (-2)
+#define LSDHIP_E_STATE (-3)
+#define LSDHIP_E_CAPACITY (-4)
+
+typedef struct lsdhip_ctx lsdhip_ctx;
+typedef struct lsdhip_frame lsdhip_frame;
+typedef struct lsdhip_tracker lsdhip_tracker;
+typedef struct lsdhip_depthmap lsdhip_depthmap;
+
+/* The mutable globals of C/util/settings.cpp:77-88 that the hot path reads. */
+typedef struct lsdhip_params {
+  float minUseGrad;              /* 5  */
+  float cameraPixelNoise2;       /* 16 */
+  float depthSmoothingFactor;    /* 1  */
+  int allowNegativeIdepths;      /* 1  */
+  int useSubpixelStereo;         /* 1  */
+  int useAffineLightningEstimation; /* 1 (ROS cfg default 0, cfg/LSDParams.cfg:27) */
+} lsdhip_params;
+void lsdhip_default_params(lsdhip_params* p);
+
+/* DepthMapPixelHypothesis, C/DepthEstimation/DepthMapPixelHypothesis.h:43-60 (32-byte AoS exchange format). */
+typedef struct lsdhip_hypothesis {
+  uint8_t isValid;
+  uint8_t pad_[3];
+  int32_t blacklisted;
+  float nextStereoFrameMinID;
+  int32_t validity_counter;
+  float idepth, idepth_var, idepth_smoothed, idepth_var_smoothed;
+} lsdhip_hypothesis;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+/* Replaces the (w,h,K) constructor arguments shared by SE3Tracker (C/Tracking/SE3Tracker.cpp:46-94),
+ * DepthMap (C/DepthEstimation/DepthMap.cpp:41-83) and Frame (C/DataStructures/Frame.cpp:397-484).
+ * K = (fx, fy, cx, cy) of level 0; w and h must be multiples of 16 (C/SlamSystem.cpp:55-59). */
+int lsdhip_ctx_create(int device, int w, int h, const float K[4], const lsdhip_params* params, lsdhip_ctx** out);
+void lsdhip_ctx_destroy(lsdhip_ctx* ctx);
+void* lsdhip_ctx_stream(lsdhip_ctx* ctx);        /* hipStream_t of the context */
+int lsdhip_ctx_synchronize(lsdhip_ctx* ctx);
+const char* lsdhip_last_error(void);
+/* per-level intrinsics fx,fy,cx,cy,fxi,fyi,cxi,cyi (C/DataStructures/Frame.cpp:445-459) */
+int lsdhip_ctx_intrinsics(lsdhip_ctx* ctx, int level, float out[8]);
+
+/* ---- Frame ---------------------------------------------------------------------------------------- */
+/* Frame::Frame(id,w,h,K,timestamp,const unsigned char*) C/DataStructures/Frame.cpp:35-48 plus the lazy pyramid
+ * builders buildImage/buildGradients/buildMaxGradients (Frame.cpp:491-767), executed eagerly on the device. */
+int lsdhip_frame_create(lsdhip_ctx* ctx, int id, const uint8_t* gray_host, lsdhip_frame** out);
+int lsdhip_frame_create_from_device(lsdhip_ctx* ctx, int id, const uint8_t* gray_dev, lsdhip_frame** out);
+void lsdhip_frame_destroy(lsdhip_frame* f);
+int lsdhip_frame_id(lsdhip_frame* f);
+/* Frame::image/gradients/maxGradients/idepth/idepthVar(level) accessors (Frame.h:357-418), copied to host.
+ * what: 0 image, 1 gradients (4 floats per pixel: gx,gy,I,0), 2 maxGradients (level 0), 3 idepth, 4 idepthVar */
+int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float* out_host);
+/* Frame::setDepthFromGroundTruth (Frame.cpp:245-293) */
+int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_host, float cov_scale);
+/* raw level-0 idepth / idepthVar planes (what Frame::setDepth leaves behind, Frame.cpp:199-243) */
+int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* idepth_host, const float* idepthVar_host);
+/* Frame::refPixelWasGood() (Frame.h:421-437): level-1 mask, bytes 0xFF until the tracker writes 0/1.
+ * returns 1 and fills out_host if the mask exists, 0 if it was never created / was cleared. */
+int lsdhip_frame_get_wasgood(lsdhip_frame* f, uint8_t* out_host);
+int lsdhip_frame_set_wasgood(lsdhip_frame* f, const uint8_t* in_host);
+int lsdhip_frame_clear_wasgood(lsdhip_frame* f); /* Frame::clear_refPixelWasGood */
+/* FramePoseStruct::thisToParent_raw / trackingParent and Frame::initialTrackedResidual
+ * (written by trackFrame, SE3Tracker.cpp:482-484; read by DepthMap, DepthMap.cpp:1095-1101, :1918) */
+int lsdhip_frame_set_pose(lsdhip_frame* f, const double thisToParent_sim3[8], lsdhip_frame* trackingParent,
+                          float initialTrackedResidual);
+int lsdhip_frame_get_pose(lsdhip_frame* f, double thisToParent_sim3[8]);
+/* out: initialTrackedResidual, meanIdepth, numPoints, numFramesTrackedOnThis, numMappedOnThis,
+ *      numMappedOnThisTotal, depthHasBeenUpdatedFlag, reserved */
+int lsdhip_frame_stats(lsdhip_frame* f, float out[8]);
+int lsdhip_frame_set_counters(lsdhip_frame* f, int numFramesTrackedOnThis, int numMappedOnThis,
+                              int numMappedOnThisTotal, int depthHasBeenUpdatedFlag);
+/* TrackingReference::makePointCloud(level) (C/Tracking/TrackingReference.cpp:96-147) for the keyframe `kf`,
+ * in the reference's x-outer/y-inner order.  Any output pointer may be NULL.  Returns the number of points. */
+int lsdhip_ref_pointcloud(lsdhip_frame* kf, int level, float* pos3_host, float* colorAndVar2_host,
+                          float* grad2_host, int* idx_host);
+
+/* ---- SE3Tracker ----------------------------------------------------------------------------------- */
+typedef struct lsdhip_track_result {
+  double frameToReference[7]; /* return value of trackFrame (SE3Tracker.cpp:485) */
+  float pointUsage, lastGoodCount, lastBadCount, lastMeanRes, lastResidual;
+  float affineEstimation_a, affineEstimation_b;
+  int diverged, trackingWasGood;
+  int numEvaluations, numWarpUpdates; /* instrumentation: residual-kernel launches, LM outer iterations */
+} lsdhip_track_result;
+
+/* one fused evaluation K1+K2+K3 (calcResidualAndBuffers + calcWeightsAndResidual + calculateWarpUpdate) */
+typedef struct lsdhip_residual_record {
+  int warped_size;                /* buf_warped_size */
+  float goodCount, badCount, pointUsage, meanRes, retval;
+  float affine_a_lastIt, affine_b_lastIt;
+  float weightedError;            /* calcWeightsAndResidual[SSE] return value */
+  float A[36], b[6], lsError;     /* LGS6 after finish() */
+  double num_constraints;
+} lsdhip_residual_record;
+
+/* SE3Tracker::SE3Tracker (SE3Tracker.cpp:46-94); settings = DenseDepthTrackerSettings (settings.h:355-402) */
+int lsdhip_tracker_create(lsdhip_ctx* ctx, lsdhip_tracker** out);
+void lsdhip_tracker_destroy(lsdhip_tracker* t);
+int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int maxItsPerLvl[LSDHIP_PYRAMID_LEVELS]);
+/* SE3Tracker::trackFrame(TrackingReference*, Frame*, const SE3& frameToReference_initialEstimate)
+ * (SE3Tracker.cpp:280-486).  `keyframe` plays the role of reference->keyframe (its idepth planes must be set).
+ * Side effects as in the reference: frame mask refPixelWasGood, frame pose / trackingParent /
+ * initialTrackedResidual, keyframe numFramesTrackedOnThis++.  Returns LSDHIP_DIVERGED when diverged. */
+int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame,
+                         const double frameToReference_initialEstimate[7], lsdhip_track_result* out);
+/* K1+K2+K3 once, at a fixed referenceToFrame (float (qw,qx,qy,qz,tx,ty,tz)) — kernel-level parity hook. */
+int lsdhip_tracker_evaluate(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame,
+                            const float referenceToFrame[7], int level, float affine_a, float affine_b,
+                            lsdhip_residual_record* out);
+/* SE3Tracker::trackFrameOnPermaref (SE3Tracker.cpp:162-272) / checkPermaRefOverlap (:121-157) on an explicit
+ * level-4 point cloud (Frame::setPermaRef data, Frame.cpp:149-174). */
+int lsdhip_tracker_track_permaref(lsdhip_tracker* t, const float* pos3_host, const float* colorAndVar2_host, int n,
+                                  lsdhip_frame* frame, const double referenceToFrame[7], lsdhip_track_result* out);
+int lsdhip_tracker_check_overlap(lsdhip_tracker* t, const float* pos3_host, int n, const double referenceToFrame[7],
+                                 float* usage_out);
+
+/* ---- DepthMap ------------------------------------------------------------------------------------- */
+/* DepthMap::DepthMap (DepthMap.cpp:41-83) */
+int lsdhip_depth_create(lsdhip_ctx* ctx, lsdhip_depthmap** out);
+void lsdhip_depth_destroy(lsdhip_depthmap* dm);
+int lsdhip_depth_is_valid(lsdhip_depthmap* dm);          /* DepthMap::isValid */
+int lsdhip_depth_invalidate(lsdhip_depthmap* dm);        /* DepthMap::invalidate */
+int lsdhip_depth_reset(lsdhip_depthmap* dm);             /* DepthMap::reset (DepthMap.cpp:102-108) */
+int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf);      /* initializeFromGTDepth :965-1018 */
+int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf);  /* initializeRandomly :883-916 */
+int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame* kf); /* setFromExistingKF :920-962 */
+/* DepthMap::updateKeyframe(std::deque<std::shared_ptr<Frame>> referenceFrames) (DepthMap.cpp:1072-1213).
+ * refs[0] is the oldest, refs[n-1] the newest frame of the deque. */
+int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int n);
+/* DepthMap::createKeyFrame(Frame* new_keyframe) (DepthMap.cpp:1222-1327); rescale_out = rescaleFactor (:1294) */
+int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* new_keyframe, float* rescale_out);
+/* DepthMap::finalizeKeyFrame (DepthMap.cpp:1363-1395), incl. Frame::takeReActivationData */
+int lsdhip_depth_finalize(lsdhip_depthmap* dm);
+/* currentDepthMap <-> host in the reference's 32-byte AoS layout (debug / parity / drop-in users that read it) */
+int lsdhip_depth_download(lsdhip_depthmap* dm, lsdhip_hypothesis* out_host);
+int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const lsdhip_hypothesis* in_host, int reactivated);
+/* single stages for kernel-level parity: 0 observeDepth (refs/n as in update), 1 regularizeDepthMapFillHoles,
+ * 2 regularizeDepthMap(false,24), 3 regularizeDepthMap(true,24), 4 propagateDepth(refs[0] = new keyframe) */
+int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame** refs, int n);
+/* smoothed idepth / variance planes of the active keyframe (what setDepth produced), device to device —
+ * the payload the multi-GPU gather collects per keyframe. */
+int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* idepthVar_dev);
+/* timing fields DepthMap keeps public (DepthMap.h:86-93): msUpdate, msCreate, msFinalize, msObserve, msRegularize,
+ * msPropagate, msFillHoles, msSetDepth (exponential moving averages, ms) */
+int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);
+
+/* ---- measurement hooks ---------------------------------------------------------------------------- */
+/* Accumulated HIP-event time (ms) and launch count of the residual kernel on the context's stream since the last
+ * reset, plus the algorithmic bytes those launches moved; bench.py's roofline leg. */
+int lsdhip_prof_enable(lsdhip_ctx* ctx, int on);
+int lsdhip_prof_read(lsdhip_ctx* ctx, double* residual_ms, long long* residual_launches, double* residual_bytes);
+int lsdhip_prof_reset(lsdhip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSDHIP_H */

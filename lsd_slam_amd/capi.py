@@ -1,0 +1,124 @@
+"""ctypes binding of liblsdhip.so — exactly the entry points include/lsdhip.h declares.
+
+There is no CPU fallback: if the shared library is missing, or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsdhip.so")
+_lib = None
+
+HYP_DTYPE = np.dtype(
+    [("isValid", np.uint8), ("_pad", np.uint8, 3), ("blacklisted", np.int32), ("nextStereoFrameMinID", np.float32),
+     ("validity_counter", np.int32), ("idepth", np.float32), ("idepth_var", np.float32),
+     ("idepth_smoothed", np.float32), ("idepth_var_smoothed", np.float32)])
+assert HYP_DTYPE.itemsize == 32
+
+
+class Params(C.Structure):
+    _fields_ = [("minUseGrad", C.c_float), ("cameraPixelNoise2", C.c_float), ("depthSmoothingFactor", C.c_float),
+                ("allowNegativeIdepths", C.c_int), ("useSubpixelStereo", C.c_int),
+                ("useAffineLightningEstimation", C.c_int)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("frameToReference", C.c_double * 7), ("pointUsage", C.c_float), ("lastGoodCount", C.c_float),
+                ("lastBadCount", C.c_float), ("lastMeanRes", C.c_float), ("lastResidual", C.c_float),
+                ("affineEstimation_a", C.c_float), ("affineEstimation_b", C.c_float), ("diverged", C.c_int),
+                ("trackingWasGood", C.c_int), ("numEvaluations", C.c_int), ("numWarpUpdates", C.c_int)]
+
+
+class ResidualRecord(C.Structure):
+    _fields_ = [("warped_size", C.c_int), ("goodCount", C.c_float), ("badCount", C.c_float), ("pointUsage", C.c_float),
+                ("meanRes", C.c_float), ("retval", C.c_float), ("affine_a_lastIt", C.c_float),
+                ("affine_b_lastIt", C.c_float), ("weightedError", C.c_float), ("A", C.c_float * 36), ("b", C.c_float * 6),
+                ("lsError", C.c_float), ("num_constraints", C.c_double)]
+
+
+# every symbol declared in include/lsdhip.h: name -> (restype, argtypes)
+def _signatures():
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    pvp = C.POINTER(C.c_void_p)
+    return {
+        "lsdhip_default_params": (None, [C.POINTER(Params)]),
+        "lsdhip_ctx_create": (i, [i, i, i, vp, C.POINTER(Params), pvp]),
+        "lsdhip_ctx_destroy": (None, [vp]),
+        "lsdhip_ctx_stream": (vp, [vp]),
+        "lsdhip_ctx_synchronize": (i, [vp]),
+        "lsdhip_last_error": (C.c_char_p, []),
+        "lsdhip_ctx_intrinsics": (i, [vp, i, vp]),
+        "lsdhip_frame_create": (i, [vp, i, vp, pvp]),
+        "lsdhip_frame_create_from_device": (i, [vp, i, vp, pvp]),
+        "lsdhip_frame_destroy": (None, [vp]),
+        "lsdhip_frame_id": (i, [vp]),
+        "lsdhip_frame_download": (i, [vp, i, i, vp]),
+        "lsdhip_frame_set_depth_gt": (i, [vp, vp, f]),
+        "lsdhip_frame_set_depth_planes": (i, [vp, vp, vp]),
+        "lsdhip_frame_get_wasgood": (i, [vp, vp]),
+        "lsdhip_frame_set_wasgood": (i, [vp, vp]),
+        "lsdhip_frame_clear_wasgood": (i, [vp]),
+        "lsdhip_frame_set_pose": (i, [vp, vp, vp, f]),
+        "lsdhip_frame_get_pose": (i, [vp, vp]),
+        "lsdhip_frame_stats": (i, [vp, vp]),
+        "lsdhip_frame_set_counters": (i, [vp, i, i, i, i]),
+        "lsdhip_ref_pointcloud": (i, [vp, i, vp, vp, vp, vp]),
+        "lsdhip_tracker_create": (i, [vp, pvp]),
+        "lsdhip_tracker_destroy": (None, [vp]),
+        "lsdhip_tracker_set_max_its": (i, [vp, vp]),
+        "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),
+        "lsdhip_tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(ResidualRecord)]),
+        "lsdhip_tracker_track_permaref": (i, [vp, vp, vp, i, vp, vp, C.POINTER(TrackResult)]),
+        "lsdhip_tracker_check_overlap": (i, [vp, vp, i, vp, C.POINTER(C.c_float)]),
+        "lsdhip_depth_create": (i, [vp, pvp]),
+        "lsdhip_depth_destroy": (None, [vp]),
+        "lsdhip_depth_is_valid": (i, [vp]),
+        "lsdhip_depth_invalidate": (i, [vp]),
+        "lsdhip_depth_reset": (i, [vp]),
+        "lsdhip_depth_init_gt": (i, [vp, vp]),
+        "lsdhip_depth_init_random": (i, [vp, vp]),
+        "lsdhip_depth_set_from_existing": (i, [vp, vp]),
+        "lsdhip_depth_update": (i, [vp, pvp, i]),
+        "lsdhip_depth_create_keyframe": (i, [vp, vp, C.POINTER(C.c_float)]),
+        "lsdhip_depth_finalize": (i, [vp]),
+        "lsdhip_depth_download": (i, [vp, vp]),
+        "lsdhip_depth_upload": (i, [vp, vp, vp, i]),
+        "lsdhip_depth_stage": (i, [vp, i, pvp, i]),
+        "lsdhip_depth_copy_planes_dev": (i, [vp, vp, vp]),
+        "lsdhip_depth_timings": (i, [vp, vp]),
+        "lsdhip_prof_enable": (i, [vp, i]),
+        "lsdhip_prof_read": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+        "lsdhip_prof_reset": (i, [vp]),
+    }
+
+
+EXPORTED_SYMBOLS = sorted(_signatures().keys())
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("liblsdhip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` — "
+                           "there is no CPU fallback for the hot path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in _signatures().items():
+        fn = getattr(L, name)  # AttributeError if the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class LsdHipError(RuntimeError):
+    pass
+
+
+def check(rc, allow_positive=True):
+    if rc < 0 or (rc > 0 and not allow_positive):
+        msg = lib().lsdhip_last_error()
+        raise LsdHipError("liblsdhip call failed (%d): %s" % (rc, msg.decode() if msg else ""))
+    return rc

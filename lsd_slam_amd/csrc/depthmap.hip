@@ -1,0 +1,1290 @@
+// DepthMap on the device: semi-dense inverse-depth estimation kernels K4 (observe / doLineStereo / EKF update),
+// K5 (fill holes), K6 (regularise), K7 (propagate to a new keyframe), K8 (setDepth + rescale).  gfx950 only.
+//
+// Reference behaviour restated (C/ = lsd_slam_core/src/):
+//   DepthMap::observeDepthRow / observeDepthCreate / observeDepthUpdate   C/DepthEstimation/DepthMap.cpp:111-146, :237-473
+//   DepthMap::makeAndCheckEPL                                             :184-234
+//   DepthMap::doLineStereo                                                :1442-1972
+//   DepthMap::regularizeDepthMapFillHolesRow + buildRegIntegralBuffer     :656-754
+//   DepthMap::regularizeDepthMapRow<removeOcclusions>                     :758-848
+//   DepthMap::propagateDepth                                              :475-653
+//   DepthMap::updateKeyframe / createKeyFrame / finalizeKeyFrame          :1072-1213, :1222-1327, :1363-1395
+//   DepthMap::initializeFromGTDepth / initializeRandomly / setFromExistingKF  :883-1018
+//   Frame::setDepth / takeReActivationData / prepareForStereoWith         C/DataStructures/Frame.cpp:199-243, :107-145, :295-317
+//
+// HBM layout: the 32-byte AoS hypothesis of the reference becomes eight SoA planes (29 B/px).  The reference's
+// "memcpy current -> other, read other, write current" snapshot (64 B/px of copy traffic per pass) is replaced by a
+// ping-pong of the 1-byte validity plane only: K5 and K6 read every other field in place because neither of them
+// modifies a field that a neighbouring pixel reads.  The validity integral image of K5 is replaced by a direct 5x5
+// window sum (int32, exact — the integral is only ever used as that window difference).
+#include <chrono>
+#include <cstdlib>
+#include "lsdhip_internal.hpp"
+
+// ---- constants, C/util/settings.h:34-35, :50-174 ------------------------------------------------------------------
+#define DIVISION_EPS 1e-10f
+#define VALIDITY_COUNTER_MAX (5.0f)
+#define VALIDITY_COUNTER_MAX_VARIABLE (250.0f)
+#define VALIDITY_COUNTER_INC 5
+#define VALIDITY_COUNTER_DEC 5
+#define VALIDITY_COUNTER_INITIAL_OBSERVE 5
+#define VAL_SUM_MIN_FOR_CREATE (30)
+#define VAL_SUM_MIN_FOR_KEEP (24)
+#define VAL_SUM_MIN_FOR_UNBLACKLIST (100)
+#define MIN_BLACKLIST -1
+#define SUCC_VAR_INC_FAC (1.01f)
+#define FAIL_VAR_INC_FAC 1.1f
+#define MAX_VAR (0.5f * 0.5f)
+#define VAR_GT_INIT_INITIAL 0.01f * 0.01f
+#define VAR_RANDOM_INIT_INITIAL (0.5f * MAX_VAR)
+#define MIN_DEPTH 0.05f
+#define MAX_EPL_LENGTH_CROP 30.0f
+#define MIN_EPL_LENGTH_CROP (3.0f)
+#define GRADIENT_SAMPLE_DIST 1.0f
+#define SAMPLE_POINT_TO_BORDER 7
+#define MAX_ERROR_STEREO (1300.0f)
+#define MIN_DISTANCE_ERROR_STEREO (1.5f)
+#define STEREO_EPL_VAR_FAC 2.0f
+#define DIFF_FAC_SMOOTHING (1.0f * 1.0f)
+#define DIFF_FAC_OBSERVE (1.0f * 1.0f)
+#define DIFF_FAC_PROP_MERGE (1.0f * 1.0f)
+#define MIN_EPL_GRAD_SQUARED (2.0f * 2.0f)
+#define MIN_EPL_LENGTH_SQUARED (1.0f * 1.0f)
+#define MIN_EPL_ANGLE_SQUARED (0.3f * 0.3f)
+#define MAX_DIFF_CONSTANT (40.0f * 40.0f)
+#define MAX_DIFF_GRAD_MULT (0.5f * 0.5f)
+#define PROP_SLOT_CAP 8
+
+// UNZERO (settings.h:35) evaluates in double in the reference; the float form below returns the same float for every
+// float input (|val| is compared against 1e-10, the result is rounded to float either way).
+__device__ __forceinline__ float unzero(float val) {
+  return (float)(val < 0 ? (val > -1e-10 ? -1e-10 : (double)val) : (val < 1e-10 ? 1e-10 : (double)val));
+}
+
+// getInterpolatedElement, C/util/globalFuncs.h:43-61
+__device__ __forceinline__ float interp1(const float* __restrict__ mat, float x, float y, int width) {
+  int ix = (int)x;
+  int iy = (int)y;
+  float dx = x - ix;
+  float dy = y - iy;
+  float dxdy = dx * dy;
+  const float* bp = mat + ix + iy * width;
+  return dxdy * bp[1 + width] + (dy - dxdy) * bp[width] + (dx - dxdy) * bp[1] + (1 - dx - dy + dxdy) * bp[0];
+}
+
+struct ObserveArgs {
+  HypPlanes m;
+  const float* kfImage;
+  const float4* kfGrad;
+  const float* kfMaxGrad;
+  const StereoRef* refs;
+  const int* refByID;
+  int nByID, byIDOffset, nRefs;
+  int reactivated;
+  int w, h;
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+  float minUseGrad, cameraPixelNoise2;
+  int allowNegativeIdepths, useSubpixelStereo;
+  int kfNumFramesTrackedOnThis, kfNumMappedOnThis;
+};
+
+// DepthMap::doLineStereo (DepthMap.cpp:1442-1972).  Status codes as in the reference: >= 0 matching error,
+// -1 out of bounds, -2 ambiguous / negative, -3 error too large, -4 arithmetic.  The epipolar walk is capped at 1000
+// steps (the reference loop is unbounded; no finite input reaches the cap).
+__device__ float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, const float u, const float v, const float epxn,
+                                const float epyn, const float min_idepth, const float prior_idepth, float max_idepth,
+                                float& result_idepth, float& result_var, float& result_eplLength) {
+  const int width = a.w, height = a.h;
+  const float* __restrict__ kfImg = a.kfImage;
+  const float* __restrict__ refImg = rf.image;
+  float KinvP0 = a.fxi * u + a.cxi, KinvP1 = a.fyi * v + a.cyi, KinvP2 = 1.0f;
+  float pInf0 = (rf.K_otherToThis_R[0] * KinvP0 + rf.K_otherToThis_R[1] * KinvP1) + rf.K_otherToThis_R[2] * KinvP2;
+  float pInf1 = (rf.K_otherToThis_R[3] * KinvP0 + rf.K_otherToThis_R[4] * KinvP1) + rf.K_otherToThis_R[5] * KinvP2;
+  float pInf2 = (rf.K_otherToThis_R[6] * KinvP0 + rf.K_otherToThis_R[7] * KinvP1) + rf.K_otherToThis_R[8] * KinvP2;
+  float pReal2 = pInf2 / prior_idepth + rf.K_otherToThis_t[2];
+  float rescaleFactor = pReal2 * prior_idepth;
+
+  float firstX = u - 2 * epxn * rescaleFactor;
+  float firstY = v - 2 * epyn * rescaleFactor;
+  float lastX = u + 2 * epxn * rescaleFactor;
+  float lastY = v + 2 * epyn * rescaleFactor;
+  if (firstX <= 0 || firstX >= width - 2 || firstY <= 0 || firstY >= height - 2 || lastX <= 0 || lastX >= width - 2 ||
+      lastY <= 0 || lastY >= height - 2)
+    return -1;
+  if (!(rescaleFactor > 0.7f && rescaleFactor < 1.4f)) return -1;
+
+  float realVal_p1 = interp1(kfImg, u + epxn * rescaleFactor, v + epyn * rescaleFactor, width);
+  float realVal_m1 = interp1(kfImg, u - epxn * rescaleFactor, v - epyn * rescaleFactor, width);
+  float realVal = interp1(kfImg, u, v, width);
+  float realVal_m2 = interp1(kfImg, u - 2 * epxn * rescaleFactor, v - 2 * epyn * rescaleFactor, width);
+  float realVal_p2 = interp1(kfImg, u + 2 * epxn * rescaleFactor, v + 2 * epyn * rescaleFactor, width);
+
+  const float Kt0 = rf.K_otherToThis_t[0], Kt1 = rf.K_otherToThis_t[1], Kt2 = rf.K_otherToThis_t[2];
+  float pClose0 = pInf0 + Kt0 * max_idepth, pClose1 = pInf1 + Kt1 * max_idepth, pClose2 = pInf2 + Kt2 * max_idepth;
+  if (pClose2 < 0.001f) {
+    max_idepth = (0.001f - pInf2) / Kt2;
+    pClose0 = pInf0 + Kt0 * max_idepth; pClose1 = pInf1 + Kt1 * max_idepth; pClose2 = pInf2 + Kt2 * max_idepth;
+  }
+  pClose0 = pClose0 / pClose2; pClose1 = pClose1 / pClose2;
+
+  float pFar0 = pInf0 + Kt0 * min_idepth, pFar1 = pInf1 + Kt1 * min_idepth, pFar2 = pInf2 + Kt2 * min_idepth;
+  if (pFar2 < 0.001f || max_idepth < min_idepth) return -1;
+  pFar0 = pFar0 / pFar2; pFar1 = pFar1 / pFar2;
+
+  if (isnan((float)(pFar0 + pClose0))) return -4;
+
+  float incx = pClose0 - pFar0;
+  float incy = pClose1 - pFar1;
+  float eplLength = sqrtf(incx * incx + incy * incy);
+  if (eplLength == 0.0f || isinf(eplLength)) return -4;  // `!eplLength > 0 || isinf` of the reference (:1518)
+
+  if (eplLength > MAX_EPL_LENGTH_CROP) {
+    pClose0 = pFar0 + incx * MAX_EPL_LENGTH_CROP / eplLength;
+    pClose1 = pFar1 + incy * MAX_EPL_LENGTH_CROP / eplLength;
+  }
+  incx *= GRADIENT_SAMPLE_DIST / eplLength;
+  incy *= GRADIENT_SAMPLE_DIST / eplLength;
+
+  pFar0 -= incx; pFar1 -= incy;
+  pClose0 += incx; pClose1 += incy;
+
+  if (eplLength < MIN_EPL_LENGTH_CROP) {
+    float pad = (MIN_EPL_LENGTH_CROP - (eplLength)) / 2.0f;
+    pFar0 -= incx * pad; pFar1 -= incy * pad;
+    pClose0 += incx * pad; pClose1 += incy * pad;
+  }
+
+  if (pFar0 <= SAMPLE_POINT_TO_BORDER || pFar0 >= width - SAMPLE_POINT_TO_BORDER || pFar1 <= SAMPLE_POINT_TO_BORDER ||
+      pFar1 >= height - SAMPLE_POINT_TO_BORDER)
+    return -1;
+
+  if (pClose0 <= SAMPLE_POINT_TO_BORDER || pClose0 >= width - SAMPLE_POINT_TO_BORDER || pClose1 <= SAMPLE_POINT_TO_BORDER ||
+      pClose1 >= height - SAMPLE_POINT_TO_BORDER) {
+    if (pClose0 <= SAMPLE_POINT_TO_BORDER) {
+      float toAdd = (SAMPLE_POINT_TO_BORDER - pClose0) / incx;
+      pClose0 += toAdd * incx; pClose1 += toAdd * incy;
+    } else if (pClose0 >= width - SAMPLE_POINT_TO_BORDER) {
+      float toAdd = (width - SAMPLE_POINT_TO_BORDER - pClose0) / incx;
+      pClose0 += toAdd * incx; pClose1 += toAdd * incy;
+    }
+    if (pClose1 <= SAMPLE_POINT_TO_BORDER) {
+      float toAdd = (SAMPLE_POINT_TO_BORDER - pClose1) / incy;
+      pClose0 += toAdd * incx; pClose1 += toAdd * incy;
+    } else if (pClose1 >= height - SAMPLE_POINT_TO_BORDER) {
+      float toAdd = (height - SAMPLE_POINT_TO_BORDER - pClose1) / incy;
+      pClose0 += toAdd * incx; pClose1 += toAdd * incy;
+    }
+    float fincx = pClose0 - pFar0;
+    float fincy = pClose1 - pFar1;
+    float newEplLength = sqrtf(fincx * fincx + fincy * fincy);
+    if (pClose0 <= SAMPLE_POINT_TO_BORDER || pClose0 >= width - SAMPLE_POINT_TO_BORDER || pClose1 <= SAMPLE_POINT_TO_BORDER ||
+        pClose1 >= height - SAMPLE_POINT_TO_BORDER || newEplLength < 8.0f)
+      return -1;
+  }
+
+  float cpx = pFar0;
+  float cpy = pFar1;
+  float val_cp_m2 = interp1(refImg, cpx - 2.0f * incx, cpy - 2.0f * incy, width);
+  float val_cp_m1 = interp1(refImg, cpx - incx, cpy - incy, width);
+  float val_cp = interp1(refImg, cpx, cpy, width);
+  float val_cp_p1 = interp1(refImg, cpx + incx, cpy + incy, width);
+  float val_cp_p2;
+
+  int loopCounter = 0;
+  float best_match_x = -1;
+  float best_match_y = -1;
+  float best_match_err = INFINITY;          // `1e50` assigned to a float (:1658)
+  float second_best_match_err = INFINITY;
+  float best_match_errPre = NAN, best_match_errPost = NAN, best_match_DiffErrPre = NAN, best_match_DiffErrPost = NAN;
+  bool bestWasLastLoop = false;
+  float eeLast = -1;
+  float e1A = NAN, e1B = NAN, e2A = NAN, e2B = NAN, e3A = NAN, e3B = NAN, e4A = NAN, e4B = NAN, e5A = NAN, e5B = NAN;
+  int loopCBest = -1, loopCSecond = -1;
+  while ((((incx < 0) == (cpx > pClose0) && (incy < 0) == (cpy > pClose1)) || loopCounter == 0) && loopCounter < 1000) {
+    val_cp_p2 = interp1(refImg, cpx + 2 * incx, cpy + 2 * incy, width);
+    float ee = 0;
+    if (loopCounter % 2 == 0) {
+      e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
+      e2A = val_cp_p1 - realVal_p1; ee += e2A * e2A;
+      e3A = val_cp - realVal;       ee += e3A * e3A;
+      e4A = val_cp_m1 - realVal_m1; ee += e4A * e4A;
+      e5A = val_cp_m2 - realVal_m2; ee += e5A * e5A;
+    } else {
+      e1B = val_cp_p2 - realVal_p2; ee += e1B * e1B;
+      e2B = val_cp_p1 - realVal_p1; ee += e2B * e2B;
+      e3B = val_cp - realVal;       ee += e3B * e3B;
+      e4B = val_cp_m1 - realVal_m1; ee += e4B * e4B;
+      e5B = val_cp_m2 - realVal_m2; ee += e5B * e5B;
+    }
+    if (ee < best_match_err) {
+      second_best_match_err = best_match_err;
+      loopCSecond = loopCBest;
+      best_match_err = ee;
+      loopCBest = loopCounter;
+      best_match_errPre = eeLast;
+      best_match_DiffErrPre = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
+      best_match_errPost = -1;
+      best_match_DiffErrPost = -1;
+      best_match_x = cpx;
+      best_match_y = cpy;
+      bestWasLastLoop = true;
+    } else {
+      if (bestWasLastLoop) {
+        best_match_errPost = ee;
+        best_match_DiffErrPost = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
+        bestWasLastLoop = false;
+      }
+      if (ee < second_best_match_err) {
+        second_best_match_err = ee;
+        loopCSecond = loopCounter;
+      }
+    }
+    eeLast = ee;
+    val_cp_m2 = val_cp_m1; val_cp_m1 = val_cp; val_cp = val_cp_p1; val_cp_p1 = val_cp_p2;
+    cpx += incx;
+    cpy += incy;
+    loopCounter++;
+  }
+
+  if (best_match_err > 4.0f * (float)MAX_ERROR_STEREO) return -3;
+  if (abs(loopCBest - loopCSecond) > 1.0f && MIN_DISTANCE_ERROR_STEREO * best_match_err > second_best_match_err) return -2;
+
+  bool didSubpixel = false;
+  if (a.useSubpixelStereo) {
+    float gradPre_pre = -(best_match_errPre - best_match_DiffErrPre);
+    float gradPre_this = +(best_match_err - best_match_DiffErrPre);
+    float gradPost_this = -(best_match_err - best_match_DiffErrPost);
+    float gradPost_post = +(best_match_errPost - best_match_DiffErrPost);
+    bool interpPost = false;
+    bool interpPre = false;
+    if ((gradPost_this < 0) ^ (gradPre_this < 0)) {
+    } else if ((gradPre_pre < 0) ^ (gradPre_this < 0)) {
+      if ((gradPost_post < 0) ^ (gradPost_this < 0)) {
+      } else
+        interpPre = true;
+    } else if ((gradPost_post < 0) ^ (gradPost_this < 0)) {
+      interpPost = true;
+    }
+    if (interpPre) {
+      float d = gradPre_this / (gradPre_this - gradPre_pre);
+      best_match_x -= d * incx;
+      best_match_y -= d * incy;
+      best_match_err = best_match_err - 2 * d * gradPre_this - (gradPre_pre - gradPre_this) * d * d;
+      didSubpixel = true;
+    } else if (interpPost) {
+      float d = gradPost_this / (gradPost_this - gradPost_post);
+      best_match_x += d * incx;
+      best_match_y += d * incy;
+      best_match_err = best_match_err + 2 * d * gradPost_this + (gradPost_post - gradPost_this) * d * d;
+      didSubpixel = true;
+    }
+  }
+
+  float sampleDist = GRADIENT_SAMPLE_DIST * rescaleFactor;
+  float gradAlongLine = 0;
+  float tmp = realVal_p2 - realVal_p1; gradAlongLine += tmp * tmp;
+  tmp = realVal_p1 - realVal;          gradAlongLine += tmp * tmp;
+  tmp = realVal - realVal_m1;          gradAlongLine += tmp * tmp;
+  tmp = realVal_m1 - realVal_m2;       gradAlongLine += tmp * tmp;
+  gradAlongLine /= sampleDist * sampleDist;
+
+  if (best_match_err > (float)MAX_ERROR_STEREO + sqrtf(gradAlongLine) * 20) return -3;
+
+  float idnew_best_match;
+  float alpha;
+  if (incx * incx > incy * incy) {
+    float oldX = a.fxi * best_match_x + a.cxi;
+    float nominator = (oldX * rf.otherToThis_t[2] - rf.otherToThis_t[0]);
+    // Vector3f::dot — Eigen redux order x0 + (x1 + x2)
+    float dot0 = KinvP0 * rf.row0[0] + (KinvP1 * rf.row0[1] + KinvP2 * rf.row0[2]);
+    float dot2 = KinvP0 * rf.row2[0] + (KinvP1 * rf.row2[1] + KinvP2 * rf.row2[2]);
+    idnew_best_match = (dot0 - oldX * dot2) / nominator;
+    alpha = incx * a.fxi * (dot0 * rf.otherToThis_t[2] - dot2 * rf.otherToThis_t[0]) / (nominator * nominator);
+  } else {
+    float oldY = a.fyi * best_match_y + a.cyi;
+    float nominator = (oldY * rf.otherToThis_t[2] - rf.otherToThis_t[1]);
+    float dot1 = KinvP0 * rf.row1[0] + (KinvP1 * rf.row1[1] + KinvP2 * rf.row1[2]);
+    float dot2 = KinvP0 * rf.row2[0] + (KinvP1 * rf.row2[1] + KinvP2 * rf.row2[2]);
+    idnew_best_match = (dot1 - oldY * dot2) / nominator;
+    alpha = incy * a.fyi * (dot1 * rf.otherToThis_t[2] - dot2 * rf.otherToThis_t[1]) / (nominator * nominator);
+  }
+
+  if (idnew_best_match < 0) {
+    if (!a.allowNegativeIdepths) return -2;
+  }
+
+  float photoDispError = 4.0f * a.cameraPixelNoise2 / (gradAlongLine + DIVISION_EPS);
+  float trackingErrorFac = 0.25f * (1.0f + rf.initialTrackedResidual);
+  // getInterpolatedElement42 on the keyframe gradients (globalFuncs.h:95-109)
+  float gI0, gI1;
+  {
+    int ix = (int)u;
+    int iy = (int)v;
+    float dx = u - ix;
+    float dy = v - iy;
+    float dxdy = dx * dy;
+    const float4* bp = a.kfGrad + ix + iy * width;
+    float4 t00 = bp[0], t10 = bp[1], t01 = bp[width], t11 = bp[1 + width];
+    gI0 = dxdy * t11.x + (dy - dxdy) * t01.x + (dx - dxdy) * t10.x + (1 - dx - dy + dxdy) * t00.x;
+    gI1 = dxdy * t11.y + (dy - dxdy) * t01.y + (dx - dxdy) * t10.y + (1 - dx - dy + dxdy) * t00.y;
+  }
+  float geoDispError = (gI0 * epxn + gI1 * epyn) + DIVISION_EPS;
+  geoDispError = trackingErrorFac * trackingErrorFac * (gI0 * gI0 + gI1 * gI1) / (geoDispError * geoDispError);
+  result_var = alpha * alpha * ((didSubpixel ? 0.05f : 0.5f) * sampleDist * sampleDist + geoDispError + photoDispError);
+  result_idepth = idnew_best_match;
+  result_eplLength = eplLength;
+  return best_match_err;
+}
+
+// DepthMap::makeAndCheckEPL (DepthMap.cpp:184-234)
+__device__ __forceinline__ bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x, int y, float* pepx, float* pepy) {
+  int idx = x + y * a.w;
+  float epx = -a.fx * rf.thisToOther_t[0] + rf.thisToOther_t[2] * (x - a.cx);
+  float epy = -a.fy * rf.thisToOther_t[1] + rf.thisToOther_t[2] * (y - a.cy);
+  if (isnan(epx + epy)) return false;
+  float eplLengthSquared = epx * epx + epy * epy;
+  if (eplLengthSquared < MIN_EPL_LENGTH_SQUARED) return false;
+  float gx = a.kfImage[idx + 1] - a.kfImage[idx - 1];
+  float gy = a.kfImage[idx + a.w] - a.kfImage[idx - a.w];
+  float eplGradSquared = gx * epx + gy * epy;
+  eplGradSquared = eplGradSquared * eplGradSquared / eplLengthSquared;
+  if (eplGradSquared < MIN_EPL_GRAD_SQUARED) return false;
+  if (eplGradSquared / (gx * gx + gy * gy) < MIN_EPL_ANGLE_SQUARED) return false;
+  float fac = GRADIENT_SAMPLE_DIST / sqrtf(eplLengthSquared);
+  *pepx = epx * fac;
+  *pepy = epy * fac;
+  return true;
+}
+
+// K4: observeDepthRow over the whole map, one pixel per lane, hypothesis updated in place.
+__global__ __launch_bounds__(256) void k_observe(ObserveArgs a) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3) return;
+  const int idx = x + y * a.w;
+  const bool hasHypothesis = a.m.valid[idx] != 0;
+  const float maxGrad = a.kfMaxGrad[idx];
+  if (hasHypothesis && maxGrad < a.minUseGrad) { a.m.valid[idx] = 0; return; }
+  if (maxGrad < a.minUseGrad || a.m.blacklisted[idx] < MIN_BLACKLIST) return;
+
+  if (!hasHypothesis) {
+    // observeDepthCreate (DepthMap.cpp:237-292)
+    const StereoRef& rf = a.refs[a.reactivated ? a.nRefs - 1 : 0];
+    if (rf.parentIsKF && rf.wasGood != nullptr && !rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)]) return;
+    float epx, epy;
+    if (!make_and_check_epl(a, rf, x, y, &epx, &epy)) return;
+    float new_u = x, new_v = y;
+    float result_idepth = 0, result_var = 0, result_eplLength = 0;
+    float error = do_line_stereo(a, rf, new_u, new_v, epx, epy, 0.0f, 1.0f, 1.0f / MIN_DEPTH, result_idepth, result_var, result_eplLength);
+    if (error == -3 || error == -2) a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1;
+    if (error < 0 || result_var > MAX_VAR) return;
+    result_idepth = unzero(result_idepth);
+    a.m.valid[idx] = 1;
+    a.m.blacklisted[idx] = 0;
+    a.m.nextID[idx] = 0;
+    a.m.validity[idx] = VALIDITY_COUNTER_INITIAL_OBSERVE;
+    a.m.idepth[idx] = result_idepth;
+    a.m.var[idx] = result_var;
+    a.m.idepth_s[idx] = -1;
+    a.m.var_s[idx] = -1;
+    return;
+  }
+
+  // observeDepthUpdate (DepthMap.cpp:294-473)
+  int refIdx;
+  const float nextID = a.m.nextID[idx];
+  if (!a.reactivated) {
+    int rel = (int)nextID - a.byIDOffset;
+    if (rel >= a.nByID) return;
+    refIdx = rel < 0 ? 0 : a.refByID[rel];
+  } else
+    refIdx = a.nRefs - 1;
+  const StereoRef& rf = a.refs[refIdx];
+  if (rf.parentIsKF && rf.wasGood != nullptr && !rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)]) return;
+  float epx, epy;
+  if (!make_and_check_epl(a, rf, x, y, &epx, &epy)) return;
+
+  const float idepth_smoothed = a.m.idepth_s[idx];
+  const float var_smoothed = a.m.var_s[idx];
+  float sv = sqrtf(var_smoothed);
+  float min_idepth = idepth_smoothed - sv * STEREO_EPL_VAR_FAC;
+  float max_idepth = idepth_smoothed + sv * STEREO_EPL_VAR_FAC;
+  if (min_idepth < 0) min_idepth = 0;
+  if (max_idepth > 1 / MIN_DEPTH) max_idepth = 1 / MIN_DEPTH;
+
+  float result_idepth = 0, result_var = 0, result_eplLength = 0;
+  float error = do_line_stereo(a, rf, x, y, epx, epy, min_idepth, idepth_smoothed, max_idepth, result_idepth, result_var, result_eplLength);
+  float diff = result_idepth - idepth_smoothed;
+
+  if (error == -1) return;
+  if (error == -2) {
+    int vc = a.m.validity[idx] - VALIDITY_COUNTER_DEC;
+    if (vc < 0) vc = 0;
+    a.m.validity[idx] = vc;
+    a.m.nextID[idx] = 0;
+    float nv = a.m.var[idx] * FAIL_VAR_INC_FAC;
+    a.m.var[idx] = nv;
+    if (nv > MAX_VAR) { a.m.valid[idx] = 0; a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1; }
+    return;
+  }
+  if (error == -3 || error == -4) return;
+  if (DIFF_FAC_OBSERVE * diff * diff > result_var + var_smoothed) {
+    float nv = a.m.var[idx] * FAIL_VAR_INC_FAC;
+    a.m.var[idx] = nv;
+    if (nv > MAX_VAR) a.m.valid[idx] = 0;
+    return;
+  }
+  {
+    const float old_var = a.m.var[idx];
+    float id_var = old_var * SUCC_VAR_INC_FAC;
+    float w = result_var / (result_var + id_var);
+    float new_idepth = (1 - w) * result_idepth + w * a.m.idepth[idx];
+    a.m.idepth[idx] = unzero(new_idepth);
+    id_var = id_var * w;
+    if (id_var < old_var) a.m.var[idx] = id_var;
+    int vc = a.m.validity[idx] + VALIDITY_COUNTER_INC;
+    float absGrad = maxGrad;
+    if (vc > VALIDITY_COUNTER_MAX + absGrad * (VALIDITY_COUNTER_MAX_VARIABLE) / 255.0f)
+      vc = VALIDITY_COUNTER_MAX + absGrad * (VALIDITY_COUNTER_MAX_VARIABLE) / 255.0f;
+    a.m.validity[idx] = vc;
+    if (result_eplLength < MIN_EPL_LENGTH_CROP) {
+      float inc = a.kfNumFramesTrackedOnThis / (float)(a.kfNumMappedOnThis + 5);
+      if (inc < 3) inc = 3;
+      inc += ((int)(result_eplLength * 10000) % 2);
+      if (result_eplLength < 0.5 * MIN_EPL_LENGTH_CROP) inc *= 3;
+      a.m.nextID[idx] = rf.id + inc;
+    }
+  }
+}
+
+struct RegArgs {
+  HypPlanes m;
+  const uint8_t* validIn;   // snapshot plane (read)
+  uint8_t* validOut;        // new validity plane (written for every pixel)
+  const float* kfMaxGrad;
+  int w, h;
+  float minUseGrad, regDistVar;
+  int validityTH;
+};
+
+// K5: regularizeDepthMapFillHolesRow (DepthMap.cpp:656-703); 5x5 validity sum replaces the integral image.
+__global__ __launch_bounds__(256) void k_fill_holes(RegArgs a) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= a.w || y >= a.h) return;
+  const int idx = x + y * a.w;
+  const uint8_t wasValid = a.validIn[idx];
+  uint8_t nowValid = wasValid;
+  if (x >= 3 && x < a.w - 2 && y >= 3 && y < a.h - 2 && !wasValid && !(a.kfMaxGrad[idx] < a.minUseGrad)) {
+    int val = 0;
+    for (int yy = y - 2; yy <= y + 2; yy++)
+      for (int xx = x - 2; xx <= x + 2; xx++) {
+        int j = xx + yy * a.w;
+        if (a.validIn[j]) val += a.m.validity[j];
+      }
+    if ((a.m.blacklisted[idx] >= MIN_BLACKLIST && val > VAL_SUM_MIN_FOR_CREATE) || val > VAL_SUM_MIN_FOR_UNBLACKLIST) {
+      float sumIdepthObs = 0, sumIVarObs = 0;
+      for (int yy = y - 2; yy <= y + 2; yy++)
+        for (int xx = x - 2; xx <= x + 2; xx++) {
+          int j = xx + yy * a.w;
+          if (!a.validIn[j]) continue;
+          float sv = a.m.var[j];
+          sumIdepthObs += a.m.idepth[j] / sv;
+          sumIVarObs += 1.0f / sv;
+        }
+      float idepthObs = sumIdepthObs / sumIVarObs;
+      idepthObs = unzero(idepthObs);
+      nowValid = 1;
+      a.m.blacklisted[idx] = 0;
+      a.m.nextID[idx] = 0;
+      a.m.validity[idx] = 0;
+      a.m.idepth[idx] = idepthObs;
+      a.m.var[idx] = VAR_RANDOM_INIT_INITIAL;
+      a.m.idepth_s[idx] = -1;
+      a.m.var_s[idx] = -1;
+    }
+  }
+  a.validOut[idx] = nowValid;
+}
+
+// K6: regularizeDepthMapRow<removeOcclusions> (DepthMap.cpp:758-848)
+template <bool removeOcclusions>
+__global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= a.w || y >= a.h) return;
+  const int idx = x + y * a.w;
+  const uint8_t wasValid = a.validIn[idx];
+  uint8_t nowValid = wasValid;
+  if (x >= 2 && x < a.w - 2 && y >= 2 && y < a.h - 2 && wasValid) {
+    const float c_id = a.m.idepth[idx];
+    const float c_var = a.m.var[idx];
+    float sum = 0, val_sum = 0, sumIvar = 0;
+    int numOccluding = 0, numNotOccluding = 0;
+    for (int dx = -2; dx <= 2; dx++)
+      for (int dy = -2; dy <= 2; dy++) {
+        int j = idx + dx + dy * a.w;
+        if (!a.validIn[j]) continue;
+        float s_id = a.m.idepth[j];
+        float s_var = a.m.var[j];
+        float diff = s_id - c_id;
+        if (DIFF_FAC_SMOOTHING * diff * diff > s_var + c_var) {
+          if (removeOcclusions) { if (s_id > c_id) numOccluding++; }
+          continue;
+        }
+        val_sum += a.m.validity[j];
+        if (removeOcclusions) numNotOccluding++;
+        float distFac = (float)(dx * dx + dy * dy) * a.regDistVar;
+        float ivar = 1.0f / (s_var + distFac);
+        sum += s_id * ivar;
+        sumIvar += ivar;
+      }
+    if (val_sum < a.validityTH) {
+      nowValid = 0;
+      a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1;
+    } else if (removeOcclusions && numOccluding > numNotOccluding) {
+      nowValid = 0;
+    } else {
+      sum = sum / sumIvar;
+      sum = unzero(sum);
+      a.m.idepth_s[idx] = sum;
+      a.m.var_s[idx] = 1.0f / sumIvar;
+    }
+  }
+  a.validOut[idx] = nowValid;
+}
+
+// K8: Frame::setDepth (Frame.cpp:199-243) + per-workgroup (sum, count) partials for meanIdepth / numPoints
+__global__ __launch_bounds__(256) void k_set_depth(HypPlanes m, float* __restrict__ id0, float* __restrict__ var0, int n, double* __restrict__ partials) {
+  __shared__ double s_sum[256];
+  __shared__ int s_cnt[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double s = 0;
+  int c = 0;
+  if (i < n) {
+    float ids = m.idepth_s[i];
+    if (m.valid[i] && (double)ids >= -0.05) {
+      id0[i] = ids;
+      var0[i] = m.var_s[i];
+      s = ids;
+      c = 1;
+    } else {
+      id0[i] = -1.f;
+      var0[i] = -1.f;
+    }
+  }
+  s_sum[threadIdx.x] = s;
+  s_cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s_sum[0]; partials[2 * blockIdx.x + 1] = (double)s_cnt[0]; }
+}
+// sum of idepth_smoothed over valid pixels (createKeyFrame rescale, DepthMap.cpp:1286-1294)
+__global__ __launch_bounds__(256) void k_sum_valid_idepth(HypPlanes m, int n, double* __restrict__ partials) {
+  __shared__ double s_sum[256];
+  __shared__ int s_cnt[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double s = 0;
+  int c = 0;
+  if (i < n && m.valid[i]) { s = m.idepth_s[i]; c = 1; }
+  s_sum[threadIdx.x] = s;
+  s_cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s_sum[0]; partials[2 * blockIdx.x + 1] = (double)s_cnt[0]; }
+}
+__global__ __launch_bounds__(256) void k_reduce_pairs(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+  __shared__ double s_a[256], s_b[256];
+  double a = 0, b = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  s_a[threadIdx.x] = a;
+  s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = s_a[0]; out[1] = s_b[0]; }
+}
+// rescale (DepthMap.cpp:1296-1304)
+__global__ __launch_bounds__(256) void k_rescale(HypPlanes m, int n, float rescaleFactor, float rescaleFactor2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !m.valid[i]) return;
+  m.idepth[i] *= rescaleFactor;
+  m.idepth_s[i] *= rescaleFactor;
+  m.var[i] *= rescaleFactor2;
+  m.var_s[i] *= rescaleFactor2;
+}
+
+// ---- K7: propagateDepth (DepthMap.cpp:475-653) ---------------------------------------------------------------------
+struct PropArgs {
+  HypPlanes src;   // currentDepthMap (old keyframe)
+  HypPlanes dst;   // otherDepthMap (new keyframe)
+  const float* oldKFImage;
+  const float* newKFImage;
+  const float* newKFMaxGrad;
+  const uint8_t* trackingWasGood;  // level-1 mask of the new keyframe or nullptr
+  float4* cand;
+  int* slotCount;
+  int* slots;
+  int* flags;
+  int w, h;
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+  float R[9], t[3];
+  float minUseGrad;
+};
+// phase A: every valid source hypothesis computes its target pixel and candidate, and registers in the target's slot list
+__global__ __launch_bounds__(256) void k_prop_candidates(PropArgs a) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= a.w || y >= a.h) return;
+  const int idx = x + y * a.w;
+  if (!a.src.valid[idx]) return;
+  const float ids = a.src.idepth_s[idx];
+  float r0 = x * a.fxi + a.cxi, r1 = y * a.fyi + a.cyi, r2 = 1.0f;
+  float Rr0 = (a.R[0] * r0 + a.R[1] * r1) + a.R[2] * r2;
+  float Rr1 = (a.R[3] * r0 + a.R[4] * r1) + a.R[5] * r2;
+  float Rr2 = (a.R[6] * r0 + a.R[7] * r1) + a.R[8] * r2;
+  float pn0 = Rr0 / ids + a.t[0], pn1 = Rr1 / ids + a.t[1], pn2 = Rr2 / ids + a.t[2];
+  float new_idepth = 1.0f / pn2;
+  float u_new = pn0 * new_idepth * a.fx + a.cx;
+  float v_new = pn1 * new_idepth * a.fy + a.cy;
+  if (!(u_new > 2.1f && v_new > 2.1f && u_new < a.w - 3.1f && v_new < a.h - 3.1f)) return;
+  int newIDX = (int)(u_new + 0.5f) + ((int)(v_new + 0.5f)) * a.w;
+  float destAbsGrad = a.newKFMaxGrad[newIDX];
+  if (a.trackingWasGood != nullptr) {
+    if (!a.trackingWasGood[(x >> 1) + (a.w >> 1) * (y >> 1)] || destAbsGrad < a.minUseGrad) return;
+  } else {
+    float sourceColor = a.oldKFImage[idx];
+    float destColor = interp1(a.newKFImage, u_new, v_new, a.w);
+    float residual = destColor - sourceColor;
+    if (residual * residual / (MAX_DIFF_CONSTANT + MAX_DIFF_GRAD_MULT * destAbsGrad * destAbsGrad) > 1.0f || destAbsGrad < a.minUseGrad) return;
+  }
+  float idepth_ratio_4 = new_idepth / ids;
+  idepth_ratio_4 *= idepth_ratio_4;
+  idepth_ratio_4 *= idepth_ratio_4;
+  float new_var = idepth_ratio_4 * a.src.var[idx];
+  a.cand[idx] = make_float4(new_idepth, new_var, __int_as_float(a.src.validity[idx]), 0.f);
+  int pos = atomicAdd(&a.slotCount[newIDX], 1);
+  if (pos < PROP_SLOT_CAP) a.slots[(size_t)newIDX * PROP_SLOT_CAP + pos] = idx;
+  else atomicExch(&a.flags[0], 1);
+}
+// phase B: per target, replay its candidates in source order (row-major, as the reference's double loop visits them)
+__global__ __launch_bounds__(256) void k_prop_resolve(PropArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  int n = a.slotCount[i];
+  if (n > PROP_SLOT_CAP) n = PROP_SLOT_CAP;
+  int srcs[PROP_SLOT_CAP];
+  for (int k = 0; k < PROP_SLOT_CAP; k++) srcs[k] = (k < n) ? a.slots[(size_t)i * PROP_SLOT_CAP + k] : 0x7fffffff;
+  for (int p = 1; p < PROP_SLOT_CAP; p++) {  // insertion sort, ascending source index
+    int key = srcs[p];
+    int q = p - 1;
+    while (q >= 0 && srcs[q] > key) { srcs[q + 1] = srcs[q]; q--; }
+    srcs[q + 1] = key;
+  }
+  bool tValid = false;
+  float t_idepth = 0, t_var = 0;
+  int t_validity = 0;
+  for (int k = 0; k < n; k++) {
+    float4 c = a.cand[srcs[k]];
+    float new_idepth = c.x, new_var = c.y;
+    int src_validity = __float_as_int(c.z);
+    if (tValid) {
+      float diff = t_idepth - new_idepth;
+      if (DIFF_FAC_PROP_MERGE * diff * diff > new_var + t_var) {
+        if (new_idepth < t_idepth) continue;
+        else tValid = false;
+      }
+    }
+    if (!tValid) {
+      tValid = true;
+      t_idepth = new_idepth; t_var = new_var; t_validity = src_validity;
+    } else {
+      float w = new_var / (t_var + new_var);
+      float merged_new_idepth = w * t_idepth + (1.0f - w) * new_idepth;
+      int merged_validity = src_validity + t_validity;
+      if (merged_validity > VALIDITY_COUNTER_MAX + (VALIDITY_COUNTER_MAX_VARIABLE))
+        merged_validity = VALIDITY_COUNTER_MAX + (VALIDITY_COUNTER_MAX_VARIABLE);
+      float mv = 1.0f / (1.0f / t_var + 1.0f / new_var);
+      t_idepth = merged_new_idepth; t_var = mv; t_validity = merged_validity;
+    }
+  }
+  a.dst.valid[i] = tValid ? 1 : 0;
+  a.dst.blacklisted[i] = 0;
+  if (tValid) {
+    a.dst.nextID[i] = 0;
+    a.dst.validity[i] = t_validity;
+    a.dst.idepth[i] = t_idepth;
+    a.dst.var[i] = t_var;
+    a.dst.idepth_s[i] = -1;
+    a.dst.var_s[i] = -1;
+  }
+}
+
+// ---- initialisation / re-activation kernels ------------------------------------------------------------------------
+// initializeFromGTDepth (DepthMap.cpp:979-1014)
+__global__ __launch_bounds__(256) void k_init_gt(HypPlanes m, const float* __restrict__ idepth0, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = idepth0[i];
+  if (!isnan(v) && v > 0) {
+    m.valid[i] = 1; m.blacklisted[i] = 0; m.nextID[i] = 0; m.validity[i] = 20;
+    m.idepth[i] = v; m.idepth_s[i] = v; m.var[i] = VAR_GT_INIT_INITIAL; m.var_s[i] = VAR_GT_INIT_INITIAL;
+  } else {
+    m.valid[i] = 0; m.blacklisted[i] = 0;
+  }
+}
+// Frame::takeReActivationData (Frame.cpp:107-145)
+__global__ __launch_bounds__(256) void k_take_react(HypPlanes m, float* __restrict__ id, float* __restrict__ var, uint8_t* __restrict__ val, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (m.valid[i]) { id[i] = m.idepth[i]; var[i] = m.var[i]; val[i] = (uint8_t)m.validity[i]; }
+  else if (m.blacklisted[i] < MIN_BLACKLIST) var[i] = -2;
+  else var[i] = -1;
+}
+// setFromExistingKF (DepthMap.cpp:937-959)
+__global__ __launch_bounds__(256) void k_from_react(HypPlanes m, const float* __restrict__ id, const float* __restrict__ var, const uint8_t* __restrict__ val, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = var[i];
+  if (v > 0) {
+    m.valid[i] = 1; m.blacklisted[i] = 0; m.nextID[i] = 0; m.validity[i] = val[i];
+    m.idepth[i] = id[i]; m.var[i] = v; m.idepth_s[i] = -1; m.var_s[i] = -1;
+  } else {
+    m.valid[i] = 0;
+    m.blacklisted[i] = (v == -2) ? MIN_BLACKLIST - 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------------
+static int alloc_planes(HypPlanes& p, size_t n, void** base_out) {
+  char* base = nullptr;
+  size_t bytes = n * 29 + 8 * 256;
+  HIPCHK(hipMalloc((void**)&base, bytes));
+  HIPCHK(hipMemset(base, 0, bytes));
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  size_t off = 0;
+  p.blacklisted = (int32_t*)(base + off); off = up(off + n * 4);
+  p.nextID = (float*)(base + off); off = up(off + n * 4);
+  p.validity = (int32_t*)(base + off); off = up(off + n * 4);
+  p.idepth = (float*)(base + off); off = up(off + n * 4);
+  p.var = (float*)(base + off); off = up(off + n * 4);
+  p.idepth_s = (float*)(base + off); off = up(off + n * 4);
+  p.var_s = (float*)(base + off); off = up(off + n * 4);
+  p.valid = (uint8_t*)(base + off);
+  *base_out = base;
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_depth_create(lsdhip_ctx* c, lsdhip_depthmap** out) {
+  if (!c || !out) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  lsdhip_depthmap* dm = new lsdhip_depthmap();
+  dm->ctx = c;
+  size_t n = (size_t)c->w * c->h;
+  int rc = alloc_planes(dm->cur, n, &dm->bases[0]);
+  if (rc) return rc;
+  rc = alloc_planes(dm->oth, n, &dm->bases[1]);
+  if (rc) return rc;
+  HIPCHK(hipMalloc((void**)&dm->d_validSnap, n));
+  dm->bases[2] = dm->d_validSnap;
+  HIPCHK(hipMemset(dm->d_validSnap, 0, n));
+  HIPCHK(hipMalloc((void**)&dm->d_slotCount, n * 4));
+  HIPCHK(hipMalloc((void**)&dm->d_slots, n * 4 * PROP_SLOT_CAP));
+  HIPCHK(hipMalloc((void**)&dm->d_cand, n * 16));
+  HIPCHK(hipMalloc((void**)&dm->d_flags, 64));
+  int nb = (int)((n + 255) / 256);
+  HIPCHK(hipMalloc((void**)&dm->d_red, (size_t)(2 * nb + 16) * sizeof(double)));
+  HIPCHK(hipHostMalloc((void**)&dm->h_red, 16 * sizeof(double), hipHostMallocMapped));
+  *out = dm;
+  return LSDHIP_OK;
+}
+extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
+  if (!dm) return;
+  (void)hipSetDevice(dm->ctx->device);
+  (void)hipStreamSynchronize(dm->ctx->stream);
+  for (int i = 0; i < 3; i++) (void)hipFree(dm->bases[i]);  // plane pointers get swapped around; free the arenas
+  (void)hipFree(dm->d_slotCount);
+  (void)hipFree(dm->d_slots);
+  (void)hipFree(dm->d_cand);
+  (void)hipFree(dm->d_flags);
+  (void)hipFree(dm->d_red);
+  (void)hipHostFree(dm->h_red);
+  if (dm->d_refs) (void)hipFree(dm->d_refs);
+  if (dm->d_refByID) (void)hipFree(dm->d_refByID);
+  delete dm;
+}
+extern "C" int lsdhip_depth_is_valid(lsdhip_depthmap* dm) { return dm && dm->activeKeyFrame != nullptr; }
+extern "C" int lsdhip_depth_invalidate(lsdhip_depthmap* dm) { if (!dm) return LSDHIP_E_ARG; dm->activeKeyFrame = nullptr; return LSDHIP_OK; }
+extern "C" int lsdhip_depth_reset(lsdhip_depthmap* dm) {
+  if (!dm) return LSDHIP_E_ARG;
+  size_t n = (size_t)dm->ctx->w * dm->ctx->h;
+  HIPCHK(hipMemsetAsync(dm->cur.valid, 0, n, dm->ctx->stream));
+  HIPCHK(hipMemsetAsync(dm->oth.valid, 0, n, dm->ctx->stream));
+  return LSDHIP_OK;
+}
+
+// Frame::setDepth on the active keyframe: level-0 planes, idepth pyramid, meanIdepth / numPoints
+static int set_depth(lsdhip_depthmap* dm) {
+  lsdhip_ctx* c = dm->ctx;
+  lsdhip_frame* kf = dm->activeKeyFrame;
+  int n = c->w * c->h;
+  int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_set_depth, dim3(nb), dim3(256), 0, c->stream, dm->cur, kf->d_idepth[0], kf->d_idepthVar[0], n, dm->d_red + 16);
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nb, dm->h_red);
+  int rc = lsd_frame_build_idepth_pyramid(kf);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float sumIdepth = (float)dm->h_red[0];
+  int numIdepth = (int)dm->h_red[1];
+  kf->meanIdepth = sumIdepth / numIdepth;
+  kf->numPoints = numIdepth;
+  kf->depthHasBeenUpdatedFlag = true;
+  return LSDHIP_OK;
+}
+
+static RegArgs reg_args(lsdhip_depthmap* dm, int validityTH) {
+  lsdhip_ctx* c = dm->ctx;
+  RegArgs a;
+  a.m = dm->cur;
+  a.validIn = dm->cur.valid;
+  a.validOut = dm->d_validSnap;
+  a.kfMaxGrad = dm->activeKeyFrame->d_maxgrad;
+  a.w = c->w; a.h = c->h;
+  a.minUseGrad = c->params.minUseGrad;
+  a.regDistVar = 0.075f * 0.075f * c->params.depthSmoothingFactor * c->params.depthSmoothingFactor;  // REG_DIST_VAR
+  a.validityTH = validityTH;
+  return a;
+}
+static void swap_valid(lsdhip_depthmap* dm) { std::swap(dm->cur.valid, dm->d_validSnap); }
+
+static int fill_holes(lsdhip_depthmap* dm) {
+  lsdhip_ctx* c = dm->ctx;
+  RegArgs a = reg_args(dm, 0);
+  hipLaunchKernelGGL(k_fill_holes, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  swap_valid(dm);
+  return LSDHIP_OK;
+}
+static int regularize(lsdhip_depthmap* dm, bool removeOcclusions, int validityTH) {
+  lsdhip_ctx* c = dm->ctx;
+  RegArgs a = reg_args(dm, validityTH);
+  dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
+  if (removeOcclusions) hipLaunchKernelGGL(k_regularize<true>, grid, dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_regularize<false>, grid, dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  swap_valid(dm);
+  return LSDHIP_OK;
+}
+
+// Frame::prepareForStereoWith (Frame.cpp:295-317): Sim3 algebra in double, results cast to float
+static void prepare_stereo(lsdhip_depthmap* dm, lsdhip_frame* fr, StereoRef& s) {
+  lsdhip_ctx* c = dm->ctx;
+  const lsdm::Sim3dH& thisToOther = fr->thisToParent_raw;
+  lsdm::Sim3dH otherToThis = lsdm::sim3_inverse(thisToOther);
+  double Rd[9];
+  lsdm::quatd_to_rot(otherToThis.q, Rd);
+  float Rf[9];
+  for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
+  const float* K = c->K0;
+  float sc = (float)otherToThis.s;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float acc = K[i * 3 + 0] * Rf[0 * 3 + j];
+      acc += K[i * 3 + 1] * Rf[1 * 3 + j];
+      acc += K[i * 3 + 2] * Rf[2 * 3 + j];
+      s.K_otherToThis_R[i * 3 + j] = acc * sc;
+    }
+  for (int i = 0; i < 3; i++) s.otherToThis_t[i] = (float)otherToThis.t[i];
+  for (int i = 0; i < 3; i++) {
+    float acc = K[i * 3 + 0] * s.otherToThis_t[0];
+    acc += K[i * 3 + 1] * s.otherToThis_t[1];
+    acc += K[i * 3 + 2] * s.otherToThis_t[2];
+    s.K_otherToThis_t[i] = acc;
+  }
+  for (int i = 0; i < 3; i++) s.thisToOther_t[i] = (float)thisToOther.t[i];
+  double R2[9];
+  lsdm::quatd_to_rot(thisToOther.q, R2);
+  float R2f[9];
+  for (int i = 0; i < 9; i++) R2f[i] = (float)R2[i] * (float)thisToOther.s;
+  for (int i = 0; i < 3; i++) { s.row0[i] = R2f[i * 3 + 0]; s.row1[i] = R2f[i * 3 + 1]; s.row2[i] = R2f[i * 3 + 2]; }
+  s.image = fr->d_image[0];
+  s.parentIsKF = (fr->trackingParent == dm->activeKeyFrame) ? 1 : 0;
+  s.wasGood = fr->wasGoodValid ? fr->d_wasGood : nullptr;
+  s.id = fr->id;
+  s.initialTrackedResidual = fr->initialTrackedResidual;
+}
+
+static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
+  lsdhip_ctx* c = dm->ctx;
+  lsdhip_frame* kf = dm->activeKeyFrame;
+  if (n <= 0) { lsd_set_error("updateKeyframe: empty reference deque"); return LSDHIP_E_ARG; }
+  std::vector<StereoRef> hrefs(n);
+  std::vector<int> byID;
+  int offset = refs[0]->id;
+  for (int i = 0; i < n; i++) {
+    lsdhip_frame* fr = refs[i];
+    if (fr->trackingParentID != kf->id) {
+      // DepthMap.cpp:1099 needs getScaledCamToWorld() from the pose graph, which stays on the host side of the boundary
+      lsd_set_error("updateKeyframe: frame %d was tracked on keyframe %d, active keyframe is %d (pose-graph path is out of scope)",
+                    fr->id, fr->trackingParentID, kf->id);
+      return LSDHIP_E_STATE;
+    }
+    prepare_stereo(dm, fr, hrefs[i]);
+    while ((int)byID.size() + offset <= fr->id) byID.push_back(i);
+  }
+  if (n > dm->refs_capacity) {
+    if (dm->d_refs) HIPCHK(hipFree(dm->d_refs));
+    dm->refs_capacity = n > 64 ? n : 64;
+    HIPCHK(hipMalloc((void**)&dm->d_refs, sizeof(StereoRef) * dm->refs_capacity));
+  }
+  if ((int)byID.size() > dm->byid_capacity) {
+    if (dm->d_refByID) HIPCHK(hipFree(dm->d_refByID));
+    dm->byid_capacity = (int)byID.size() > 256 ? (int)byID.size() : 256;
+    HIPCHK(hipMalloc((void**)&dm->d_refByID, sizeof(int) * dm->byid_capacity));
+  }
+  HIPCHK(hipMemcpyAsync(dm->d_refs, hrefs.data(), sizeof(StereoRef) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->d_refByID, byID.data(), sizeof(int) * byID.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+
+  ObserveArgs a;
+  a.m = dm->cur;
+  a.kfImage = kf->d_image[0];
+  a.kfGrad = kf->d_grad[0];
+  a.kfMaxGrad = kf->d_maxgrad;
+  a.refs = dm->d_refs;
+  a.refByID = dm->d_refByID;
+  a.nByID = (int)byID.size();
+  a.byIDOffset = offset;
+  a.nRefs = n;
+  a.reactivated = dm->activeKeyFrameIsReactivated ? 1 : 0;
+  a.w = c->w; a.h = c->h;
+  const LevelIntr& in = c->intr[0];
+  a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
+  a.minUseGrad = c->params.minUseGrad;
+  a.cameraPixelNoise2 = c->params.cameraPixelNoise2;
+  a.allowNegativeIdepths = c->params.allowNegativeIdepths;
+  a.useSubpixelStereo = c->params.useSubpixelStereo;
+  a.kfNumFramesTrackedOnThis = kf->numFramesTrackedOnThis;
+  a.kfNumMappedOnThis = kf->numMappedOnThis;
+  hipLaunchKernelGGL(k_observe, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return LSDHIP_OK;
+}
+
+static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk) {
+  lsdhip_ctx* c = dm->ctx;
+  lsdhip_frame* old = dm->activeKeyFrame;
+  size_t n = (size_t)c->w * c->h;
+  PropArgs a;
+  a.src = dm->cur;
+  a.dst = dm->oth;
+  a.oldKFImage = old->d_image[0];
+  a.newKFImage = nk->d_image[0];
+  a.newKFMaxGrad = nk->d_maxgrad;
+  a.trackingWasGood = (nk->trackingParent == old && nk->wasGoodValid) ? nk->d_wasGood : nullptr;
+  a.cand = dm->d_cand;
+  a.slotCount = dm->d_slotCount;
+  a.slots = dm->d_slots;
+  a.flags = dm->d_flags;
+  a.w = c->w; a.h = c->h;
+  const LevelIntr& in = c->intr[0];
+  a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
+  a.minUseGrad = c->params.minUseGrad;
+  // oldToNew_SE3 = se3FromSim3(new_keyframe->pose->thisToParent_raw).inverse() (double), cast to float
+  lsdm::SE3dH newToOld;
+  newToOld.q = nk->thisToParent_raw.q;
+  for (int i = 0; i < 3; i++) newToOld.t[i] = nk->thisToParent_raw.t[i];
+  lsdm::SE3dH oldToNew = lsdm::se3d_inverse(newToOld);
+  double Rd[9];
+  lsdm::quatd_to_rot(oldToNew.q, Rd);
+  for (int i = 0; i < 9; i++) a.R[i] = (float)Rd[i];
+  for (int i = 0; i < 3; i++) a.t[i] = (float)oldToNew.t[i];
+
+  HIPCHK(hipMemsetAsync(dm->d_slotCount, 0, n * 4, c->stream));
+  HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, c->stream));
+  hipLaunchKernelGGL(k_prop_candidates, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_prop_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, dm->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (flag) {
+    lsd_set_error("propagateDepth: more than %d source hypotheses mapped to one target pixel", PROP_SLOT_CAP);
+    return LSDHIP_E_CAPACITY;
+  }
+  std::swap(dm->cur, dm->oth);
+  return LSDHIP_OK;
+}
+
+struct StageTimer {
+  hipEvent_t a, b;
+  lsdhip_ctx* c;
+  bool ok;
+  StageTimer(lsdhip_ctx* c_) : c(c_) { ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess; }
+  ~StageTimer() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+};
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+extern "C" int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf) {
+  if (!dm || !kf) return LSDHIP_E_ARG;
+  if (!kf->hasIDepth) { lsd_set_error("initializeFromGTDepth: frame has no depth"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  dm->activeKeyFrame = kf;
+  dm->activeKeyFrameIsReactivated = false;
+  int n = c->w * c->h;
+  hipLaunchKernelGGL(k_init_gt, dim3((n + 255) / 256), dim3(256), 0, c->stream, dm->cur, kf->d_idepth[0], n);
+  return set_depth(dm);
+}
+
+extern "C" int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf) {
+  if (!dm || !kf) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  dm->activeKeyFrame = kf;
+  dm->activeKeyFrameIsReactivated = false;
+  // initializeRandomly (DepthMap.cpp:883-916) draws from the C library's rand() in pixel order: a host-side init path.
+  int w = c->w, h = c->h;
+  size_t n = (size_t)w * h;
+  std::vector<float> mg(n);
+  HIPCHK(hipMemcpyAsync(mg.data(), kf->d_maxgrad, n * 4, hipMemcpyDeviceToHost, c->stream));
+  std::vector<lsdhip_hypothesis> hyp(n);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int rc = lsdhip_depth_download(dm, hyp.data());
+  if (rc) return rc;
+  for (int y = 1; y < h - 1; y++)
+    for (int x = 1; x < w - 1; x++) {
+      lsdhip_hypothesis& p = hyp[x + y * w];
+      if (mg[x + y * w] > c->params.minUseGrad) {
+        float idepth = 0.5f + 1.0f * ((rand() % 100001) / 100000.0f);
+        p.isValid = 1; p.blacklisted = 0; p.nextStereoFrameMinID = 0; p.validity_counter = 20;
+        p.idepth = idepth; p.idepth_smoothed = idepth; p.idepth_var = VAR_RANDOM_INIT_INITIAL; p.idepth_var_smoothed = VAR_RANDOM_INIT_INITIAL;
+      } else {
+        p.isValid = 0; p.blacklisted = 0;
+      }
+    }
+  rc = lsdhip_depth_upload(dm, kf, hyp.data(), 0);
+  if (rc) return rc;
+  return set_depth(dm);
+}
+
+extern "C" int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame* kf) {
+  if (!dm || !kf) return LSDHIP_E_ARG;
+  if (!kf->reActValid) { lsd_set_error("setFromExistingKF: frame %d has no re-activation data", kf->id); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  dm->activeKeyFrame = kf;
+  kf->numMappedOnThis = 0;
+  kf->numFramesTrackedOnThis = 0;
+  dm->activeKeyFrameIsReactivated = true;
+  int n = c->w * c->h;
+  hipLaunchKernelGGL(k_from_react, dim3((n + 255) / 256), dim3(256), 0, c->stream, dm->cur, kf->d_idepth_reAct, kf->d_idepthVar_reAct,
+                     kf->d_validity_reAct, n);
+  int rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+
+static float ema(float old, double sample) { return (float)(0.9 * old + 0.1 * sample); }
+
+extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
+  if (!dm || !refs || n <= 0) return LSDHIP_E_ARG;
+  if (!dm->activeKeyFrame) { lsd_set_error("updateKeyframe: depth map has no active keyframe"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  double t0 = now_ms();
+  int rc = observe(dm, refs, n);
+  if (rc) return rc;
+  rc = fill_holes(dm);
+  if (rc) return rc;
+  rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
+  if (rc) return rc;
+  lsdhip_frame* kf = dm->activeKeyFrame;
+  if (!kf->depthHasBeenUpdatedFlag) {
+    rc = set_depth(dm);
+    if (rc) return rc;
+  } else {
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);
+  kf->numMappedOnThis++;
+  kf->numMappedOnThisTotal++;
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* nk, float* rescale_out) {
+  if (!dm || !nk) return LSDHIP_E_ARG;
+  if (!dm->activeKeyFrame) { lsd_set_error("createKeyFrame: depth map has no active keyframe"); return LSDHIP_E_STATE; }
+  if (!nk->trackingParent) { lsd_set_error("createKeyFrame: new keyframe has no tracking parent"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  double t0 = now_ms();
+  lsdm::SE3dH newToOld;
+  newToOld.q = nk->thisToParent_raw.q;
+  for (int i = 0; i < 3; i++) newToOld.t[i] = nk->thisToParent_raw.t[i];
+  lsdm::SE3dH oldToNew = lsdm::se3d_inverse(newToOld);
+
+  int rc = propagate(dm, nk);
+  if (rc) return rc;
+  dm->msPropagate = ema(dm->msPropagate, now_ms() - t0);
+  dm->activeKeyFrame = nk;
+  dm->activeKeyFrameIsReactivated = false;
+  rc = regularize(dm, true, VAL_SUM_MIN_FOR_KEEP);
+  if (rc) return rc;
+  rc = fill_holes(dm);
+  if (rc) return rc;
+  rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
+  if (rc) return rc;
+
+  // make mean inverse depth be one (DepthMap.cpp:1285-1304)
+  int n = c->w * c->h;
+  int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_sum_valid_idepth, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, dm->d_red + 16);
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nb, dm->h_red);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float sumIdepth = (float)dm->h_red[0], numIdepth = (float)dm->h_red[1];
+  float rescaleFactor = numIdepth / sumIdepth;
+  float rescaleFactor2 = rescaleFactor * rescaleFactor;
+  hipLaunchKernelGGL(k_rescale, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, rescaleFactor, rescaleFactor2);
+  lsdm::SE3dH back = lsdm::se3d_inverse(oldToNew);
+  nk->thisToParent_raw.q = back.q;
+  for (int i = 0; i < 3; i++) nk->thisToParent_raw.t[i] = back.t[i];
+  nk->thisToParent_raw.s = rescaleFactor;
+  if (rescale_out) *rescale_out = rescaleFactor;
+  rc = set_depth(dm);
+  dm->msCreate = ema(dm->msCreate, now_ms() - t0);
+  return rc;
+}
+
+extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
+  if (!dm) return LSDHIP_E_ARG;
+  if (!dm->activeKeyFrame) { lsd_set_error("finalizeKeyFrame: depth map has no active keyframe"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  double t0 = now_ms();
+  int rc = fill_holes(dm);
+  if (rc) return rc;
+  rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
+  if (rc) return rc;
+  rc = set_depth(dm);
+  if (rc) return rc;
+  lsdhip_frame* kf = dm->activeKeyFrame;
+  size_t n = (size_t)c->w * c->h;
+  if (!kf->d_idepth_reAct) {
+    char* base = nullptr;
+    HIPCHK(hipMalloc((void**)&base, n * 9 + 512));
+    HIPCHK(hipMemsetAsync(base, 0, n * 9 + 512, c->stream));
+    kf->d_idepth_reAct = (float*)base;
+    kf->d_idepthVar_reAct = (float*)(base + (n * 4 + 255) / 256 * 256);
+    kf->d_validity_reAct = (uint8_t*)(base + 2 * ((n * 4 + 255) / 256 * 256));
+  }
+  hipLaunchKernelGGL(k_take_react, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dm->cur, kf->d_idepth_reAct,
+                     kf->d_idepthVar_reAct, kf->d_validity_reAct, (int)n);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  kf->reActValid = true;
+  dm->msFinalize = ema(dm->msFinalize, now_ms() - t0);
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_depth_download(lsdhip_depthmap* dm, lsdhip_hypothesis* out) {
+  if (!dm || !out) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  size_t n = (size_t)c->w * c->h;
+  std::vector<uint8_t> v(n);
+  std::vector<int32_t> bl(n), vc(n);
+  std::vector<float> nid(n), id(n), var(n), ids(n), vars(n);
+  HIPCHK(hipMemcpyAsync(v.data(), dm->cur.valid, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(bl.data(), dm->cur.blacklisted, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(vc.data(), dm->cur.validity, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(nid.data(), dm->cur.nextID, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(id.data(), dm->cur.idepth, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(var.data(), dm->cur.var, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(ids.data(), dm->cur.idepth_s, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(vars.data(), dm->cur.var_s, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < n; i++) {
+    lsdhip_hypothesis& h = out[i];
+    h.isValid = v[i]; h.pad_[0] = h.pad_[1] = h.pad_[2] = 0;
+    h.blacklisted = bl[i]; h.nextStereoFrameMinID = nid[i]; h.validity_counter = vc[i];
+    h.idepth = id[i]; h.idepth_var = var[i]; h.idepth_smoothed = ids[i]; h.idepth_var_smoothed = vars[i];
+  }
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const lsdhip_hypothesis* in, int reactivated) {
+  if (!dm || !kf || !in) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  size_t n = (size_t)c->w * c->h;
+  std::vector<uint8_t> v(n);
+  std::vector<int32_t> bl(n), vc(n);
+  std::vector<float> nid(n), id(n), var(n), ids(n), vars(n);
+  for (size_t i = 0; i < n; i++) {
+    const lsdhip_hypothesis& h = in[i];
+    v[i] = h.isValid ? 1 : 0; bl[i] = h.blacklisted; nid[i] = h.nextStereoFrameMinID; vc[i] = h.validity_counter;
+    id[i] = h.idepth; var[i] = h.idepth_var; ids[i] = h.idepth_smoothed; vars[i] = h.idepth_var_smoothed;
+  }
+  HIPCHK(hipMemcpyAsync(dm->cur.valid, v.data(), n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->cur.blacklisted, bl.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->cur.validity, vc.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->cur.nextID, nid.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->cur.idepth, id.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->cur.var, var.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->cur.idepth_s, ids.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dm->cur.var_s, vars.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  dm->activeKeyFrame = kf;
+  dm->activeKeyFrameIsReactivated = reactivated != 0;
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame** refs, int n) {
+  if (!dm) return LSDHIP_E_ARG;
+  if (!dm->activeKeyFrame) { lsd_set_error("depth stage: no active keyframe"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = dm->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  int rc = LSDHIP_E_ARG;
+  switch (stage) {
+    case 0: rc = observe(dm, refs, n); break;
+    case 1: rc = fill_holes(dm); break;
+    case 2: rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP); break;
+    case 3: rc = regularize(dm, true, VAL_SUM_MIN_FOR_KEEP); break;
+    case 4:
+      if (!refs || n < 1) return LSDHIP_E_ARG;
+      rc = propagate(dm, refs[0]);
+      if (rc == LSDHIP_OK) { dm->activeKeyFrame = refs[0]; dm->activeKeyFrameIsReactivated = false; }
+      break;
+    default: return LSDHIP_E_ARG;
+  }
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* var_dev) {
+  if (!dm || !idepth_dev || !var_dev) return LSDHIP_E_ARG;
+  if (!dm->activeKeyFrame || !dm->activeKeyFrame->hasIDepth) return LSDHIP_E_STATE;
+  lsdhip_ctx* c = dm->ctx;
+  size_t n = (size_t)c->w * c->h;
+  HIPCHK(hipMemcpyAsync(idepth_dev, dm->activeKeyFrame->d_idepth[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(var_dev, dm->activeKeyFrame->d_idepthVar[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]) {
+  if (!dm || !out) return LSDHIP_E_ARG;
+  out[0] = dm->msUpdate; out[1] = dm->msCreate; out[2] = dm->msFinalize; out[3] = dm->msObserve; out[4] = dm->msRegularize;
+  out[5] = dm->msPropagate; out[6] = dm->msFillHoles; out[7] = dm->msSetDepth;
+  return LSDHIP_OK;
+}

@@ -1,0 +1,595 @@
+// Context + device-resident Frame: image / gradient / maxGradient / inverse-depth pyramids (K-pyr-*), point-cloud
+// export (K0), ground-truth depth initialisation.  gfx950 only.
+//
+// Reference behaviour restated on the device:
+//   Frame::Frame                 C/DataStructures/Frame.cpp:35-48    uint8 -> float copy (no scaling)
+//   Frame::initialize            Frame.cpp:397-459                   per-level intrinsics
+//   Frame::buildImage            Frame.cpp:491-630                   2x2 box mean, SSE association (:532-544)
+//   Frame::buildGradients        Frame.cpp:643-680                   linear-index walk incl. row wrap
+//   Frame::buildMaxGradients     Frame.cpp:690-767                   |grad| + separable 3x3 max (linear-index ranges)
+//   Frame::buildIDepthAndIDepthVar Frame.cpp:775-877                 inverse-variance 2x2 pooling
+//   Frame::setDepthFromGroundTruth Frame.cpp:245-293
+//   TrackingReference::makePointCloud C/Tracking/TrackingReference.cpp:96-147
+// Unwritten pool memory of the reference is defined as 0 here (rows 0 / h-1 of gradients etc.).
+#include <mutex>
+#include "lsdhip_internal.hpp"
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------
+
+// One 16x16 level-0 tile per workgroup -> 8x8, 4x4, 2x2, 1x1 tiles of levels 1..4, all in one launch.
+// HBM traffic: 1 B/px read (uint8) + 4 B * (1 + 1/4 + 1/16 + 1/64 + 1/256) written.
+__global__ __launch_bounds__(256) void k_image_pyramid(const uint8_t* __restrict__ gray, float* __restrict__ i0,
+                                                        float* __restrict__ i1, float* __restrict__ i2,
+                                                        float* __restrict__ i3, float* __restrict__ i4, int w, int h) {
+  __shared__ float s0[16][17];
+  __shared__ float s1[8][9];
+  __shared__ float s2[4][5];
+  __shared__ float s3[2][3];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  {
+    int x = bx * 16 + tx, y = by * 16 + ty;
+    float v = (float)gray[y * w + x];
+    i0[y * w + x] = v;
+    s0[ty][tx] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int ax = tid & 7, ay = tid >> 3;
+    float c0 = s0[2 * ay][2 * ax] + s0[2 * ay + 1][2 * ax];          // (top + bottom) of the left column
+    float c1 = s0[2 * ay][2 * ax + 1] + s0[2 * ay + 1][2 * ax + 1];  // right column
+    float r = (c0 + c1) * 0.25f;
+    s1[ay][ax] = r;
+    i1[(by * 8 + ay) * (w >> 1) + bx * 8 + ax] = r;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    int ax = tid & 3, ay = tid >> 2;
+    float c0 = s1[2 * ay][2 * ax] + s1[2 * ay + 1][2 * ax];
+    float c1 = s1[2 * ay][2 * ax + 1] + s1[2 * ay + 1][2 * ax + 1];
+    float r = (c0 + c1) * 0.25f;
+    s2[ay][ax] = r;
+    i2[(by * 4 + ay) * (w >> 2) + bx * 4 + ax] = r;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    int ax = tid & 1, ay = tid >> 1;
+    float c0 = s2[2 * ay][2 * ax] + s2[2 * ay + 1][2 * ax];
+    float c1 = s2[2 * ay][2 * ax + 1] + s2[2 * ay + 1][2 * ax + 1];
+    float r = (c0 + c1) * 0.25f;
+    s3[ay][ax] = r;
+    i3[(by * 2 + ay) * (w >> 3) + bx * 2 + ax] = r;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float c0 = s3[0][0] + s3[1][0];
+    float c1 = s3[0][1] + s3[1][1];
+    i4[by * (w >> 4) + bx] = (c0 + c1) * 0.25f;
+  }
+}
+
+struct GradArgs {
+  const float* img[LSD_LEVELS];
+  float4* grad[LSD_LEVELS];
+  float* absgrad0;
+  int w[LSD_LEVELS], h[LSD_LEVELS];
+};
+
+// All five gradient planes in one launch (blockIdx.y = level).  4 B/px read (+ neighbours from L2), 16 B/px
+// written; level 0 additionally writes |grad| (4 B/px) for the maxGradients pass.
+__global__ __launch_bounds__(256) void k_gradients(GradArgs a) {
+  const int l = blockIdx.y;
+  const int w = a.w[l], h = a.h[l];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w * h) return;
+  const float* __restrict__ img = a.img[l];
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool inner = (i >= w) && (i < w * (h - 1));
+  if (inner) {
+    g.x = 0.5f * (img[i + 1] - img[i - 1]);
+    g.y = 0.5f * (img[i + w] - img[i - w]);
+    g.z = img[i];
+  }
+  a.grad[l][i] = g;
+  if (l == 0) a.absgrad0[i] = inner ? sqrtf(g.x * g.x + g.y * g.y) : 0.f;
+}
+
+// Separable 3x3 max of |grad| with the reference's linear-index validity ranges (see header comment).
+__global__ __launch_bounds__(256) void k_max_gradients(const float* __restrict__ absg, float* __restrict__ maxgrad, int w, int h) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = w * h;
+  if (i >= n) return;
+  const int lo = w + 1, hi = w * (h - 1) - 1;
+  auto vmax = [&](int j) -> float {
+    if (j < lo || j >= hi) return 0.f;
+    float g1 = absg[j - w];
+    float g2 = absg[j];
+    if (g1 < g2) g1 = g2;
+    float g3 = absg[j + w];
+    return (g1 < g3) ? g3 : g1;
+  };
+  float out = 0.f;
+  if (i >= lo && i < hi) {
+    float g1 = vmax(i - 1);
+    float g2 = vmax(i);
+    if (g1 < g2) g1 = g2;
+    float g3 = vmax(i + 1);
+    out = (g1 < g3) ? g3 : g1;
+  } else if (i == w || i == hi) {
+    out = absg[i];
+  }
+  maxgrad[i] = out;
+}
+
+// inverse-variance pooling of one 2x2 block, children in the order idx, idx+1, idx+sw, idx+sw+1
+__device__ __forceinline__ void pool4(const float id[4], const float var[4], float& oid, float& ovar) {
+  float idepthSumsSum = 0.f, ivarSumsSum = 0.f;
+  int num = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (var[k] > 0) {
+      float ivar = 1.0f / var[k];
+      ivarSumsSum += ivar;
+      idepthSumsSum += ivar * id[k];
+      num++;
+    }
+  }
+  if (num > 0) {
+    float depth = ivarSumsSum / idepthSumsSum;
+    oid = 1.0f / depth;
+    ovar = num / ivarSumsSum;
+  } else {
+    oid = -1.f;
+    ovar = -1.f;
+  }
+}
+
+struct DepthPyrArgs {
+  float* id[LSD_LEVELS];
+  float* var[LSD_LEVELS];
+  int w0;
+};
+
+// Levels 1..4 of (idepth, idepthVar) from level 0, one 16x16 level-0 tile per workgroup.
+__global__ __launch_bounds__(256) void k_idepth_pyramid(DepthPyrArgs a) {
+  __shared__ float sid[16][17], svar[16][17];
+  __shared__ float tid1[8][9], tvar1[8][9];
+  __shared__ float tid2[4][5], tvar2[4][5];
+  __shared__ float tid3[2][3], tvar3[2][3];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int w0 = a.w0;
+  {
+    int x = bx * 16 + tx, y = by * 16 + ty;
+    sid[ty][tx] = a.id[0][y * w0 + x];
+    svar[ty][tx] = a.var[0][y * w0 + x];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int ax = tid & 7, ay = tid >> 3;
+    float i4[4] = {sid[2 * ay][2 * ax], sid[2 * ay][2 * ax + 1], sid[2 * ay + 1][2 * ax], sid[2 * ay + 1][2 * ax + 1]};
+    float v4[4] = {svar[2 * ay][2 * ax], svar[2 * ay][2 * ax + 1], svar[2 * ay + 1][2 * ax], svar[2 * ay + 1][2 * ax + 1]};
+    float oi, ov;
+    pool4(i4, v4, oi, ov);
+    tid1[ay][ax] = oi; tvar1[ay][ax] = ov;
+    int o = (by * 8 + ay) * (w0 >> 1) + bx * 8 + ax;
+    a.id[1][o] = oi; a.var[1][o] = ov;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    int ax = tid & 3, ay = tid >> 2;
+    float i4[4] = {tid1[2 * ay][2 * ax], tid1[2 * ay][2 * ax + 1], tid1[2 * ay + 1][2 * ax], tid1[2 * ay + 1][2 * ax + 1]};
+    float v4[4] = {tvar1[2 * ay][2 * ax], tvar1[2 * ay][2 * ax + 1], tvar1[2 * ay + 1][2 * ax], tvar1[2 * ay + 1][2 * ax + 1]};
+    float oi, ov;
+    pool4(i4, v4, oi, ov);
+    tid2[ay][ax] = oi; tvar2[ay][ax] = ov;
+    int o = (by * 4 + ay) * (w0 >> 2) + bx * 4 + ax;
+    a.id[2][o] = oi; a.var[2][o] = ov;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    int ax = tid & 1, ay = tid >> 1;
+    float i4[4] = {tid2[2 * ay][2 * ax], tid2[2 * ay][2 * ax + 1], tid2[2 * ay + 1][2 * ax], tid2[2 * ay + 1][2 * ax + 1]};
+    float v4[4] = {tvar2[2 * ay][2 * ax], tvar2[2 * ay][2 * ax + 1], tvar2[2 * ay + 1][2 * ax], tvar2[2 * ay + 1][2 * ax + 1]};
+    float oi, ov;
+    pool4(i4, v4, oi, ov);
+    tid3[ay][ax] = oi; tvar3[ay][ax] = ov;
+    int o = (by * 2 + ay) * (w0 >> 3) + bx * 2 + ax;
+    a.id[3][o] = oi; a.var[3][o] = ov;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float i4[4] = {tid3[0][0], tid3[0][1], tid3[1][0], tid3[1][1]};
+    float v4[4] = {tvar3[0][0], tvar3[0][1], tvar3[1][0], tvar3[1][1]};
+    float oi, ov;
+    pool4(i4, v4, oi, ov);
+    int o = by * (w0 >> 4) + bx;
+    a.id[4][o] = oi; a.var[4][o] = ov;
+  }
+}
+
+// Frame::setDepthFromGroundTruth
+__global__ __launch_bounds__(256) void k_set_depth_gt(const float* __restrict__ depth, const float* __restrict__ maxgrad,
+                                                       float* __restrict__ id, float* __restrict__ var, int w, int h,
+                                                       float cov_scale, float minUseGrad) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w * h) return;
+  int x = i % w, y = i / w;
+  float d = depth[i];
+  if (x > 0 && x < w - 1 && y > 0 && y < h - 1 && maxgrad[i] >= minUseGrad && !isnan(d) && d > 0) {
+    id[i] = 1.0f / d;
+    var[i] = 0.01f * 0.01f * cov_scale;  // VAR_GT_INIT_INITIAL * cov_scale (C/util/settings.h:75)
+  } else {
+    id[i] = -1.f;
+    var[i] = -1.f;
+  }
+}
+
+// ---- K0: TrackingReference::makePointCloud, x outer / y inner, order preserving ------------------------------
+__global__ __launch_bounds__(256) void k_pc_count(const float* __restrict__ id, const float* __restrict__ var, int w, int h,
+                                                   int* __restrict__ colCount) {
+  int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= w) return;
+  int c = 0;
+  if (x >= 1 && x < w - 1)
+    for (int y = 1; y < h - 1; y++) {
+      int idx = x + y * w;
+      if (!(var[idx] <= 0 || id[idx] == 0)) c++;
+    }
+  colCount[x] = c;
+}
+__global__ void k_pc_scan(int* __restrict__ colCount, int w, int* __restrict__ total) {
+  // single thread exclusive scan over <= a few thousand columns (keyframe-rate export path, not the hot path)
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int acc = 0;
+    for (int x = 0; x < w; x++) { int c = colCount[x]; colCount[x] = acc; acc += c; }
+    *total = acc;
+  }
+}
+__global__ __launch_bounds__(256) void k_pc_write(const float* __restrict__ id, const float* __restrict__ var,
+                                                   const float* __restrict__ img, const float4* __restrict__ grad, int w, int h,
+                                                   float fxi, float fyi, float cxi, float cyi, const int* __restrict__ colOff,
+                                                   float* __restrict__ pos, float* __restrict__ colvar,
+                                                   float* __restrict__ gradOut, int* __restrict__ idxOut) {
+  int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < 1 || x >= w - 1) return;
+  int n = colOff[x];
+  for (int y = 1; y < h - 1; y++) {
+    int idx = x + y * w;
+    float v = var[idx], d = id[idx];
+    if (v <= 0 || d == 0) continue;
+    float inv = 1.0f / d;
+    pos[3 * n + 0] = inv * (fxi * x + cxi);
+    pos[3 * n + 1] = inv * (fyi * y + cyi);
+    pos[3 * n + 2] = inv * 1.0f;
+    float4 g = grad[idx];
+    gradOut[2 * n + 0] = g.x;
+    gradOut[2 * n + 1] = g.y;
+    colvar[2 * n + 0] = img[idx];
+    colvar[2 * n + 1] = v;
+    idxOut[n] = idx;
+    n++;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------
+extern "C" void lsdhip_default_params(lsdhip_params* p) {
+  p->minUseGrad = 5;
+  p->cameraPixelNoise2 = 4 * 4;
+  p->depthSmoothingFactor = 1;
+  p->allowNegativeIdepths = 1;
+  p->useSubpixelStereo = 1;
+  p->useAffineLightningEstimation = 1;
+}
+
+extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], const lsdhip_params* params, lsdhip_ctx** out) {
+  if (!out || !K || w <= 0 || h <= 0 || (w % 16) != 0 || (h % 16) != 0) {
+    lsd_set_error("lsdhip_ctx_create: image dimensions must be positive multiples of 16 (got %dx%d)", w, h);
+    return LSDHIP_E_ARG;
+  }
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    lsd_set_error("lsdhip_ctx_create: device %d not available (%d visible)", device, ndev);
+    return LSDHIP_E_HIP;
+  }
+  HIPCHK(hipSetDevice(device));
+  lsdhip_ctx* c = new lsdhip_ctx();
+  c->device = device;
+  c->w = w;
+  c->h = h;
+  if (params) c->params = *params; else lsdhip_default_params(&c->params);
+  // Frame::initialize (Frame.cpp:397-459)
+  float fx[LSD_LEVELS], fy[LSD_LEVELS], cx[LSD_LEVELS], cy[LSD_LEVELS];
+  fx[0] = K[0]; fy[0] = K[1]; cx[0] = K[2]; cy[0] = K[3];
+  for (int l = 0; l < LSD_LEVELS; l++) {
+    c->wl[l] = w >> l;
+    c->hl[l] = h >> l;
+    if (l > 0) {
+      fx[l] = fx[l - 1] * 0.5;
+      fy[l] = fy[l - 1] * 0.5;
+      cx[l] = (cx[0] + 0.5) / ((int)1 << l) - 0.5;
+      cy[l] = (cy[0] + 0.5) / ((int)1 << l) - 0.5;
+    }
+    float Kl[9] = {fx[l], 0.f, cx[l], 0.f, fy[l], cy[l], 0.f, 0.f, 1.f};
+    float Ki[9];
+    lsdm::inverse3_eigen(Kl, Ki);
+    c->intr[l] = {fx[l], fy[l], cx[l], cy[l], Ki[0], Ki[4], Ki[2], Ki[5]};
+    if (l == 0) { memcpy(c->K0, Kl, sizeof(Kl)); memcpy(c->K0inv, Ki, sizeof(Ki)); }
+  }
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&c->ev_a));
+  HIPCHK(hipEventCreate(&c->ev_b));
+  *out = c;
+  return LSDHIP_OK;
+}
+extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+extern "C" void* lsdhip_ctx_stream(lsdhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
+  if (!c) return LSDHIP_E_ARG;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_intrinsics(lsdhip_ctx* c, int level, float out[8]) {
+  if (!c || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
+  memcpy(out, &c->intr[level], sizeof(LevelIntr));
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_prof_enable(lsdhip_ctx* c, int on) { if (!c) return LSDHIP_E_ARG; c->prof_on = on != 0; return LSDHIP_OK; }
+extern "C" int lsdhip_prof_reset(lsdhip_ctx* c) {
+  if (!c) return LSDHIP_E_ARG;
+  c->prof_ms = 0; c->prof_bytes = 0; c->prof_launches = 0;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_prof_read(lsdhip_ctx* c, double* ms, long long* launches, double* bytes) {
+  if (!c) return LSDHIP_E_ARG;
+  if (ms) *ms = c->prof_ms;
+  if (launches) *launches = c->prof_launches;
+  if (bytes) *bytes = c->prof_bytes;
+  return LSDHIP_OK;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
+  lsdhip_frame* f = new lsdhip_frame();
+  f->ctx = c;
+  f->id = id;
+  f->thisToParent_raw.q = {1, 0, 0, 0};
+  f->thisToParent_raw.t[0] = f->thisToParent_raw.t[1] = f->thisToParent_raw.t[2] = 0;
+  f->thisToParent_raw.s = 1;
+  // one arena per frame: gray | image[l] | grad[l] | absgrad | maxgrad | idepth[l] | idepthVar[l] | wasGood
+  size_t off = 0, offs[64];
+  int k = 0;
+  auto take = [&](size_t bytes) { off = align_up(off, 256); offs[k++] = off; off += bytes; };
+  size_t n0 = (size_t)c->w * c->h;
+  take(n0);
+  for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
+  for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 16);
+  take(n0 * 4);
+  take(n0 * 4);
+  for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
+  for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
+  take((size_t)c->wl[1] * c->hl[1]);
+  char* base = nullptr;
+  hipError_t e = hipMalloc((void**)&base, align_up(off, 256));
+  if (e != hipSuccess) { lsd_set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); delete f; return LSDHIP_E_HIP; }
+  k = 0;
+  f->d_gray = (uint8_t*)(base + offs[k++]);
+  for (int l = 0; l < LSD_LEVELS; l++) f->d_image[l] = (float*)(base + offs[k++]);
+  for (int l = 0; l < LSD_LEVELS; l++) f->d_grad[l] = (float4*)(base + offs[k++]);
+  f->d_absgrad = (float*)(base + offs[k++]);
+  f->d_maxgrad = (float*)(base + offs[k++]);
+  for (int l = 0; l < LSD_LEVELS; l++) f->d_idepth[l] = (float*)(base + offs[k++]);
+  for (int l = 0; l < LSD_LEVELS; l++) f->d_idepthVar[l] = (float*)(base + offs[k++]);
+  f->d_wasGood = (uint8_t*)(base + offs[k++]);
+  *out = f;
+  return LSDHIP_OK;
+}
+
+int lsd_frame_build_pyramids(lsdhip_frame* f) {
+  lsdhip_ctx* c = f->ctx;
+  dim3 grid(c->w / 16, c->h / 16);
+  hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, c->stream, f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
+                     f->d_image[3], f->d_image[4], c->w, c->h);
+  GradArgs ga;
+  for (int l = 0; l < LSD_LEVELS; l++) { ga.img[l] = f->d_image[l]; ga.grad[l] = f->d_grad[l]; ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l]; }
+  ga.absgrad0 = f->d_absgrad;
+  int n0 = c->w * c->h;
+  hipLaunchKernelGGL(k_gradients, dim3((n0 + 255) / 256, LSD_LEVELS), dim3(256), 0, c->stream, ga);
+  hipLaunchKernelGGL(k_max_gradients, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, f->d_absgrad, f->d_maxgrad, c->w, c->h);
+  HIPCHK(hipGetLastError());
+  return LSDHIP_OK;
+}
+
+int lsd_frame_build_idepth_pyramid(lsdhip_frame* f) {
+  lsdhip_ctx* c = f->ctx;
+  DepthPyrArgs a;
+  for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = f->d_idepth[l]; a.var[l] = f->d_idepthVar[l]; }
+  a.w0 = c->w;
+  hipLaunchKernelGGL(k_idepth_pyramid, dim3(c->w / 16, c->h / 16), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  f->hasIDepth = true;
+  return LSDHIP_OK;
+}
+
+int lsd_frame_ensure_wasgood(lsdhip_frame* f) {
+  if (!f->wasGoodValid) {
+    HIPCHK(hipMemsetAsync(f->d_wasGood, 0xFF, (size_t)f->ctx->wl[1] * f->ctx->hl[1], f->ctx->stream));
+    f->wasGoodValid = true;
+  }
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint8_t* gray_dev, lsdhip_frame** out) {
+  if (!c || !gray_dev || !out) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  lsdhip_frame* f = nullptr;
+  int rc = frame_alloc(c, id, &f);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(f->d_gray, gray_dev, (size_t)c->w * c->h, hipMemcpyDeviceToDevice, c->stream));
+  rc = lsd_frame_build_pyramids(f);
+  if (rc) { lsdhip_frame_destroy(f); return rc; }
+  *out = f;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_host, lsdhip_frame** out) {
+  if (!c || !gray_host || !out) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  lsdhip_frame* f = nullptr;
+  int rc = frame_alloc(c, id, &f);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(f->d_gray, gray_host, (size_t)c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  rc = lsd_frame_build_pyramids(f);
+  if (rc) { lsdhip_frame_destroy(f); return rc; }
+  HIPCHK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
+  *out = f;
+  return LSDHIP_OK;
+}
+extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->ctx->device);
+  (void)hipStreamSynchronize(f->ctx->stream);
+  (void)hipFree(f->d_gray);  // arena base
+  if (f->d_idepth_reAct) (void)hipFree(f->d_idepth_reAct);
+  delete f;
+}
+extern "C" int lsdhip_frame_id(lsdhip_frame* f) { return f ? f->id : -1; }
+
+extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float* out) {
+  if (!f || !out || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = f->ctx;
+  size_t n = (size_t)c->wl[level] * c->hl[level];
+  const void* src = nullptr;
+  switch (what) {
+    case 0: src = f->d_image[level]; break;
+    case 1: src = f->d_grad[level]; n *= 4; break;
+    case 2: if (level != 0) return LSDHIP_E_ARG; src = f->d_maxgrad; break;
+    case 3: if (!f->hasIDepth) return LSDHIP_E_STATE; src = f->d_idepth[level]; break;
+    case 4: if (!f->hasIDepth) return LSDHIP_E_STATE; src = f->d_idepthVar[level]; break;
+    default: return LSDHIP_E_ARG;
+  }
+  HIPCHK(hipMemcpyAsync(out, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_host, float cov_scale) {
+  if (!f || !depth_host) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = f->ctx;
+  int n0 = c->w * c->h;
+  float* d_depth = nullptr;
+  HIPCHK(hipMalloc((void**)&d_depth, (size_t)n0 * 4));
+  HIPCHK(hipMemcpyAsync(d_depth, depth_host, (size_t)n0 * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_set_depth_gt, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, d_depth, f->d_maxgrad, f->d_idepth[0],
+                     f->d_idepthVar[0], c->w, c->h, cov_scale, c->params.minUseGrad);
+  int rc = lsd_frame_build_idepth_pyramid(f);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(d_depth));
+  return rc;
+}
+extern "C" int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* id, const float* var) {
+  if (!f || !id || !var) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = f->ctx;
+  size_t n0 = (size_t)c->w * c->h;
+  HIPCHK(hipMemcpyAsync(f->d_idepth[0], id, n0 * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(f->d_idepthVar[0], var, n0 * 4, hipMemcpyHostToDevice, c->stream));
+  int rc = lsd_frame_build_idepth_pyramid(f);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return rc;
+}
+extern "C" int lsdhip_frame_get_wasgood(lsdhip_frame* f, uint8_t* out) {
+  if (!f || !out) return LSDHIP_E_ARG;
+  if (!f->wasGoodValid) return 0;
+  lsdhip_ctx* c = f->ctx;
+  HIPCHK(hipMemcpyAsync(out, f->d_wasGood, (size_t)c->wl[1] * c->hl[1], hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 1;
+}
+extern "C" int lsdhip_frame_set_wasgood(lsdhip_frame* f, const uint8_t* in) {
+  if (!f || !in) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = f->ctx;
+  HIPCHK(hipMemcpyAsync(f->d_wasGood, in, (size_t)c->wl[1] * c->hl[1], hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  f->wasGoodValid = true;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_clear_wasgood(lsdhip_frame* f) {
+  if (!f) return LSDHIP_E_ARG;
+  f->wasGoodValid = false;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_set_pose(lsdhip_frame* f, const double s[8], lsdhip_frame* parent, float initialTrackedResidual) {
+  if (!f || !s) return LSDHIP_E_ARG;
+  f->thisToParent_raw.q = {s[0], s[1], s[2], s[3]};
+  f->thisToParent_raw.t[0] = s[4]; f->thisToParent_raw.t[1] = s[5]; f->thisToParent_raw.t[2] = s[6];
+  f->thisToParent_raw.s = s[7];
+  f->trackingParent = parent;
+  f->trackingParentID = parent ? parent->id : -1;
+  f->initialTrackedResidual = initialTrackedResidual;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_get_pose(lsdhip_frame* f, double s[8]) {
+  if (!f || !s) return LSDHIP_E_ARG;
+  s[0] = f->thisToParent_raw.q.w; s[1] = f->thisToParent_raw.q.x; s[2] = f->thisToParent_raw.q.y; s[3] = f->thisToParent_raw.q.z;
+  s[4] = f->thisToParent_raw.t[0]; s[5] = f->thisToParent_raw.t[1]; s[6] = f->thisToParent_raw.t[2];
+  s[7] = f->thisToParent_raw.s;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_stats(lsdhip_frame* f, float out[8]) {
+  if (!f || !out) return LSDHIP_E_ARG;
+  out[0] = f->initialTrackedResidual; out[1] = f->meanIdepth; out[2] = (float)f->numPoints;
+  out[3] = (float)f->numFramesTrackedOnThis; out[4] = (float)f->numMappedOnThis; out[5] = (float)f->numMappedOnThisTotal;
+  out[6] = f->depthHasBeenUpdatedFlag ? 1.f : 0.f; out[7] = 0.f;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_set_counters(lsdhip_frame* f, int a, int b, int c2, int flag) {
+  if (!f) return LSDHIP_E_ARG;
+  f->numFramesTrackedOnThis = a; f->numMappedOnThis = b; f->numMappedOnThisTotal = c2; f->depthHasBeenUpdatedFlag = flag != 0;
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_ref_pointcloud(lsdhip_frame* kf, int level, float* pos, float* colvar, float* grad, int* idx) {
+  if (!kf || level < 0 || level >= LSD_LEVELS) { lsd_set_error("lsdhip_ref_pointcloud: bad arguments"); return LSDHIP_E_ARG; }
+  if (!kf->hasIDepth) { lsd_set_error("lsdhip_ref_pointcloud: keyframe has no depth"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = kf->ctx;
+  int w = c->wl[level], h = c->hl[level];
+  size_t nmax = (size_t)w * h;
+  char* scratch = nullptr;
+  size_t bytes = (size_t)(w + 1) * 4 + nmax * (12 + 8 + 8 + 4) + 1024;
+  HIPCHK(hipMalloc((void**)&scratch, bytes));
+  int* d_col = (int*)scratch;
+  int* d_total = d_col + w;
+  float* d_pos = (float*)(scratch + align_up((size_t)(w + 1) * 4, 256));
+  float* d_cv = d_pos + nmax * 3;
+  float* d_gr = d_cv + nmax * 2;
+  int* d_idx = (int*)(d_gr + nmax * 2);
+  const LevelIntr& in = c->intr[level];
+  hipLaunchKernelGGL(k_pc_count, dim3((w + 255) / 256), dim3(256), 0, c->stream, kf->d_idepth[level], kf->d_idepthVar[level], w, h, d_col);
+  hipLaunchKernelGGL(k_pc_scan, dim3(1), dim3(64), 0, c->stream, d_col, w, d_total);
+  hipLaunchKernelGGL(k_pc_write, dim3((w + 255) / 256), dim3(256), 0, c->stream, kf->d_idepth[level], kf->d_idepthVar[level],
+                     kf->d_image[level], kf->d_grad[level], w, h, in.fxi, in.fyi, in.cxi, in.cyi, d_col, d_pos, d_cv, d_gr, d_idx);
+  int total = 0;
+  HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (pos) HIPCHK(hipMemcpy(pos, d_pos, (size_t)total * 12, hipMemcpyDeviceToHost));
+  if (colvar) HIPCHK(hipMemcpy(colvar, d_cv, (size_t)total * 8, hipMemcpyDeviceToHost));
+  if (grad) HIPCHK(hipMemcpy(grad, d_gr, (size_t)total * 8, hipMemcpyDeviceToHost));
+  if (idx) HIPCHK(hipMemcpy(idx, d_idx, (size_t)total * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(scratch));
+  return total;
+}

@@ -1,0 +1,340 @@
+"""Host-side mirror of the reference's class interface for the hot path, on top of the C ABI (include/lsdhip.h).
+
+Same names, argument meaning and error behaviour as the reference so that parity tests read like the reference's
+call sites (`C/` = lsd_slam_core/src/):
+
+    Frame(id, image, ctx)                          C/DataStructures/Frame.h:43
+    TrackingReference.importFrame(kf)              C/Tracking/TrackingReference.h:49
+    SE3Tracker.trackFrame(reference, frame, init)  C/Tracking/SE3Tracker.h:65-68
+    DepthMap.updateKeyframe / createKeyFrame / finalizeKeyFrame / initializeFromGTDepth …
+                                                   C/DepthEstimation/DepthMap.h:47-98
+
+Poses are numpy double[7] = (qw,qx,qy,qz,tx,ty,tz).  All per-pixel work happens in liblsdhip.so on the GPU; this
+file only marshals arguments (no numerical fallback of any kind).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import HYP_DTYPE, check
+
+IDENTITY = np.array([1.0, 0, 0, 0, 0, 0, 0])
+
+
+class Context:
+    """(w, h, K) + device + stream shared by Frame / SE3Tracker / DepthMap objects."""
+
+    def __init__(self, w, h, K, device=0, params=None):
+        self.L = capi.lib()
+        self.w, self.h = int(w), int(h)
+        self.K = np.ascontiguousarray(K, dtype=np.float32)
+        self.params = capi.Params()
+        self.L.lsdhip_default_params(C.byref(self.params))
+        if params:
+            for k, v in params.items():
+                setattr(self.params, k, v)
+        h_ = C.c_void_p()
+        check(self.L.lsdhip_ctx_create(device, self.w, self.h, self.K.ctypes.data, C.byref(self.params), C.byref(h_)),
+              allow_positive=False)
+        self.h_ = h_
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.lsdhip_ctx_destroy(self.h_)
+            self.h_ = None
+
+    def synchronize(self):
+        check(self.L.lsdhip_ctx_synchronize(self.h_))
+
+    def intrinsics(self, level):
+        out = np.zeros(8, np.float32)
+        check(self.L.lsdhip_ctx_intrinsics(self.h_, level, out.ctypes.data))
+        return out
+
+    def stream(self):
+        return self.L.lsdhip_ctx_stream(self.h_)
+
+    def prof_enable(self, on=True):
+        check(self.L.lsdhip_prof_enable(self.h_, int(on)))
+
+    def prof_reset(self):
+        check(self.L.lsdhip_prof_reset(self.h_))
+
+    def prof_read(self):
+        ms, n, b = C.c_double(), C.c_longlong(), C.c_double()
+        check(self.L.lsdhip_prof_read(self.h_, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+
+class Frame:
+    """Device-resident frame: pyramids are built on the GPU at construction."""
+
+    def __init__(self, ctx, id_, image=None, device_ptr=None):
+        self.ctx = ctx
+        self.L = ctx.L
+        h_ = C.c_void_p()
+        if device_ptr is not None:
+            check(self.L.lsdhip_frame_create_from_device(ctx.h_, id_, C.c_void_p(device_ptr), C.byref(h_)), False)
+        else:
+            img = np.ascontiguousarray(image, dtype=np.uint8)
+            if img.shape != (ctx.h, ctx.w):
+                raise ValueError("image must be %dx%d uint8" % (ctx.w, ctx.h))
+            check(self.L.lsdhip_frame_create(ctx.h_, id_, img.ctypes.data, C.byref(h_)), False)
+        self.h_ = h_
+        self._id = id_
+        self._parent = None
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "h_", None) and getattr(self.ctx, "h_", None):
+            self.L.lsdhip_frame_destroy(self.h_)
+        self.h_ = None
+
+    def id(self):
+        return self._id
+
+    def width(self, level=0):
+        return self.ctx.w >> level
+
+    def height(self, level=0):
+        return self.ctx.h >> level
+
+    def _plane(self, what, level):
+        shape = (self.height(level), self.width(level), 4) if what == 1 else (self.height(level), self.width(level))
+        out = np.zeros(shape, np.float32)
+        check(self.L.lsdhip_frame_download(self.h_, what, level, out.ctypes.data), False)
+        return out
+
+    def image(self, level=0):
+        return self._plane(0, level)
+
+    def gradients(self, level=0):
+        return self._plane(1, level)
+
+    def maxGradients(self, level=0):
+        return self._plane(2, level)
+
+    def idepth(self, level=0):
+        return self._plane(3, level)
+
+    def idepthVar(self, level=0):
+        return self._plane(4, level)
+
+    def setDepthFromGroundTruth(self, depth, cov_scale=1.0):
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        check(self.L.lsdhip_frame_set_depth_gt(self.h_, d.ctypes.data, cov_scale), False)
+
+    def setDepthPlanes(self, idepth, idepthVar):
+        a = np.ascontiguousarray(idepth, dtype=np.float32)
+        b = np.ascontiguousarray(idepthVar, dtype=np.float32)
+        check(self.L.lsdhip_frame_set_depth_planes(self.h_, a.ctypes.data, b.ctypes.data), False)
+
+    def refPixelWasGoodNoCreate(self):
+        out = np.zeros((self.height(1), self.width(1)), np.uint8)
+        rc = check(self.L.lsdhip_frame_get_wasgood(self.h_, out.ctypes.data))
+        return out if rc == 1 else None
+
+    def set_refPixelWasGood(self, m):
+        m = np.ascontiguousarray(m, dtype=np.uint8)
+        check(self.L.lsdhip_frame_set_wasgood(self.h_, m.ctypes.data), False)
+
+    def clear_refPixelWasGood(self):
+        check(self.L.lsdhip_frame_clear_wasgood(self.h_))
+
+    def setPose(self, thisToParent_sim3, trackingParent, initialTrackedResidual=0.0):
+        s = np.ascontiguousarray(thisToParent_sim3, dtype=np.float64)
+        self._parent = trackingParent
+        check(self.L.lsdhip_frame_set_pose(self.h_, s.ctypes.data, trackingParent.h_ if trackingParent else None,
+                                           initialTrackedResidual), False)
+
+    def thisToParent_raw(self):
+        out = np.zeros(8, np.float64)
+        check(self.L.lsdhip_frame_get_pose(self.h_, out.ctypes.data))
+        return out
+
+    def stats(self):
+        out = np.zeros(8, np.float32)
+        check(self.L.lsdhip_frame_stats(self.h_, out.ctypes.data))
+        keys = ["initialTrackedResidual", "meanIdepth", "numPoints", "numFramesTrackedOnThis", "numMappedOnThis",
+                "numMappedOnThisTotal", "depthHasBeenUpdatedFlag", "reserved"]
+        return dict(zip(keys, out.tolist()))
+
+    def setCounters(self, numFramesTrackedOnThis, numMappedOnThis, numMappedOnThisTotal, depthHasBeenUpdatedFlag):
+        check(self.L.lsdhip_frame_set_counters(self.h_, numFramesTrackedOnThis, numMappedOnThis, numMappedOnThisTotal,
+                                               int(depthHasBeenUpdatedFlag)))
+
+
+class TrackingReference:
+    """C/Tracking/TrackingReference.h — on the device the point cloud is generated on the fly inside the residual
+    kernel, so this object only remembers which keyframe it refers to; makePointCloud() exports the compacted arrays
+    in the reference's order for callers that want them (permaref, Sim3 tracker)."""
+
+    def __init__(self):
+        self.keyframe = None
+
+    def importFrame(self, kf):
+        self.keyframe = kf
+
+    def invalidate(self):
+        self.keyframe = None
+
+    def makePointCloud(self, level):
+        kf = self.keyframe
+        n_max = kf.width(level) * kf.height(level)
+        pos = np.zeros((n_max, 3), np.float32)
+        cv = np.zeros((n_max, 2), np.float32)
+        gr = np.zeros((n_max, 2), np.float32)
+        idx = np.zeros(n_max, np.int32)
+        n = check(kf.L.lsdhip_ref_pointcloud(kf.h_, level, pos.ctypes.data, cv.ctypes.data, gr.ctypes.data, idx.ctypes.data))
+        return pos[:n].copy(), cv[:n].copy(), gr[:n].copy(), idx[:n].copy()
+
+
+class SE3Tracker:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = ctx.L
+        h_ = C.c_void_p()
+        check(self.L.lsdhip_tracker_create(ctx.h_, C.byref(h_)), False)
+        self.h_ = h_
+        self.last = None
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "h_", None) and getattr(self.ctx, "h_", None):
+            self.L.lsdhip_tracker_destroy(self.h_)
+        self.h_ = None
+
+    def set_maxItsPerLvl(self, its):
+        its = np.ascontiguousarray(its, dtype=np.int32)
+        check(self.L.lsdhip_tracker_set_max_its(self.h_, its.ctypes.data))
+
+    def _publish(self, r):
+        self.last = r
+        self.pointUsage = r.pointUsage
+        self.lastGoodCount = r.lastGoodCount
+        self.lastBadCount = r.lastBadCount
+        self.lastMeanRes = r.lastMeanRes
+        self.lastResidual = r.lastResidual
+        self.affineEstimation_a = r.affineEstimation_a
+        self.affineEstimation_b = r.affineEstimation_b
+        self.diverged = bool(r.diverged)
+        self.trackingWasGood = bool(r.trackingWasGood)
+
+    def trackFrame(self, reference, frame, frameToReference_initialEstimate):
+        """Returns frameToReference (double[7]); identity when diverged, like the reference (SE3Tracker.cpp:324-329)."""
+        init = np.ascontiguousarray(frameToReference_initialEstimate, dtype=np.float64)
+        r = capi.TrackResult()
+        check(self.L.lsdhip_tracker_track(self.h_, reference.keyframe.h_, frame.h_, init.ctypes.data, C.byref(r)))
+        self._publish(r)
+        if not r.diverged:
+            frame._parent = reference.keyframe
+        return np.array(r.frameToReference)
+
+    def evaluate(self, reference, frame, referenceToFrame, level, a=1.0, b=0.0):
+        T = np.ascontiguousarray(referenceToFrame, dtype=np.float32)
+        r = capi.ResidualRecord()
+        check(self.L.lsdhip_tracker_evaluate(self.h_, reference.keyframe.h_, frame.h_, T.ctypes.data, level, a, b, C.byref(r)), False)
+        return r
+
+    def trackFrameOnPermaref(self, permaRef_pos, permaRef_colVar, frame, referenceToFrame):
+        pos = np.ascontiguousarray(permaRef_pos, np.float32)
+        cv = np.ascontiguousarray(permaRef_colVar, np.float32)
+        T = np.ascontiguousarray(referenceToFrame, np.float64)
+        r = capi.TrackResult()
+        check(self.L.lsdhip_tracker_track_permaref(self.h_, pos.ctypes.data, cv.ctypes.data, len(pos), frame.h_, T.ctypes.data, C.byref(r)))
+        self._publish(r)
+        return np.array(r.frameToReference)
+
+    def checkPermaRefOverlap(self, permaRef_pos, referenceToFrame):
+        pos = np.ascontiguousarray(permaRef_pos, np.float32)
+        T = np.ascontiguousarray(referenceToFrame, np.float64)
+        u = C.c_float()
+        check(self.L.lsdhip_tracker_check_overlap(self.h_, pos.ctypes.data, len(pos), T.ctypes.data, C.byref(u)), False)
+        self.pointUsage = u.value
+        return u.value
+
+
+class DepthMap:
+    STAGES = {"observe": 0, "fillholes": 1, "regularize": 2, "regularize_occ": 3, "propagate": 4}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = ctx.L
+        h_ = C.c_void_p()
+        check(self.L.lsdhip_depth_create(ctx.h_, C.byref(h_)), False)
+        self.h_ = h_
+        self._keep = []
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "h_", None) and getattr(self.ctx, "h_", None):
+            self.L.lsdhip_depth_destroy(self.h_)
+        self.h_ = None
+
+    def _arr(self, frames):
+        return (C.c_void_p * len(frames))(*[f.h_ for f in frames])
+
+    def isValid(self):
+        return bool(self.L.lsdhip_depth_is_valid(self.h_))
+
+    def invalidate(self):
+        check(self.L.lsdhip_depth_invalidate(self.h_))
+
+    def reset(self):
+        check(self.L.lsdhip_depth_reset(self.h_))
+
+    def initializeFromGTDepth(self, frame):
+        self._keep.append(frame)
+        check(self.L.lsdhip_depth_init_gt(self.h_, frame.h_), False)
+
+    def initializeRandomly(self, frame):
+        self._keep.append(frame)
+        check(self.L.lsdhip_depth_init_random(self.h_, frame.h_), False)
+
+    def setFromExistingKF(self, frame):
+        self._keep.append(frame)
+        check(self.L.lsdhip_depth_set_from_existing(self.h_, frame.h_), False)
+
+    def updateKeyframe(self, referenceFrames):
+        frames = list(referenceFrames)
+        check(self.L.lsdhip_depth_update(self.h_, self._arr(frames), len(frames)), False)
+
+    def createKeyFrame(self, new_keyframe):
+        self._keep.append(new_keyframe)
+        s = C.c_float()
+        check(self.L.lsdhip_depth_create_keyframe(self.h_, new_keyframe.h_, C.byref(s)), False)
+        return s.value
+
+    def finalizeKeyFrame(self):
+        check(self.L.lsdhip_depth_finalize(self.h_), False)
+
+    def currentDepthMap(self):
+        out = np.zeros((self.ctx.h, self.ctx.w), dtype=HYP_DTYPE)
+        check(self.L.lsdhip_depth_download(self.h_, out.ctypes.data), False)
+        return out
+
+    def setCurrentDepthMap(self, kf, hyp, reactivated=False):
+        self._keep.append(kf)
+        hyp = np.ascontiguousarray(hyp, dtype=HYP_DTYPE)
+        check(self.L.lsdhip_depth_upload(self.h_, kf.h_, hyp.ctypes.data, int(reactivated)), False)
+
+    def stage(self, name, frames=()):
+        frames = list(frames)
+        self._keep.extend(frames)
+        check(self.L.lsdhip_depth_stage(self.h_, self.STAGES[name], self._arr(frames) if frames else None, len(frames)), False)
+
+    def copyPlanesToDevice(self, idepth_ptr, var_ptr):
+        check(self.L.lsdhip_depth_copy_planes_dev(self.h_, C.c_void_p(idepth_ptr), C.c_void_p(var_ptr)), False)
+
+    def timings(self):
+        out = np.zeros(8, np.float32)
+        check(self.L.lsdhip_depth_timings(self.h_, out.ctypes.data))
+        keys = ["msUpdate", "msCreate", "msFinalize", "msObserve", "msRegularize", "msPropagate", "msFillHoles", "msSetDepth"]
+        return dict(zip(keys, out.tolist()))

@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU, and exports
+every symbol include/lsdhip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from lsd_slam_amd import build
+    return build.build()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "lsdhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lsdhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from lsd_slam_amd import capi
+    assert declared_symbols() == capi.EXPORTED_SYMBOLS
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    L = ctypes.CDLL(built_lib)
+    for name in declared_symbols():
+        assert hasattr(L, name), "liblsdhip.so does not export %s" % name
+
+
+def test_binding_loads_and_default_params(built_lib):
+    from lsd_slam_amd import capi
+    L = capi.lib()
+    p = capi.Params()
+    L.lsdhip_default_params(ctypes.byref(p))
+    # C/util/settings.cpp:80-88
+    assert (p.minUseGrad, p.cameraPixelNoise2, p.depthSmoothingFactor) == (5.0, 16.0, 1.0)
+    assert (p.allowNegativeIdepths, p.useSubpixelStereo, p.useAffineLightningEstimation) == (1, 1, 1)
+
+
+def test_hypothesis_layout_is_32_bytes():
+    from lsd_slam_amd import capi
+    from oracle import pyoracle
+    assert capi.HYP_DTYPE.itemsize == 32 and pyoracle.HYP_DTYPE == capi.HYP_DTYPE
+    assert capi.HYP_DTYPE.fields["idepth"][1] == 16 and capi.HYP_DTYPE.fields["blacklisted"][1] == 4
+
+
+def test_no_silent_cpu_fallback_without_gpu(built_lib):
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import lsd_slam_amd as la
+    from lsd_slam_amd import synth
+    with pytest.raises(la.LsdHipError):
+        la.Context(160, 128, synth.intrinsics(160, 128))
+
+
+def test_product_package_does_not_import_oracle():
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import lsd_slam_amd, lsd_slam_amd.slam, lsd_slam_amd.capi, lsd_slam_amd.synth; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'product imports oracle'") % ROOT
+    subprocess.check_call([sys.executable, "-c", code])
+    for fn in os.listdir(os.path.join(ROOT, "lsd_slam_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "lsd_slam_amd", fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+            assert "pyoracle" not in src and "liblsd_oracle" not in src, fn

@@ -1,0 +1,443 @@
+"""GPU parity tests proper: every hot-path stage of liblsdhip.so (called through the C ABI) against the CPU oracle on
+the same seeded inputs.  Bar: bit-exact for masks / integer state / per-pixel float results whose operation order
+is replicated; float32 reductions within 1e-5 of a float64 accumulation of the oracle's per-point float32 terms;
+function-level poses within the oracle's own scalar-vs-SSE spread."""
+import numpy as np
+import pytest
+
+from common import ODOMETRY_ITS, assert_bit_equal, pose_distance, sequence
+
+pytestmark = pytest.mark.gpu
+
+IDENT7 = np.array([1.0, 0, 0, 0, 0, 0, 0])
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import lsd_slam_amd as la
+    return la
+
+
+def make_pair(oracle, hip, w, h, n, seq_index=0):
+    frames, depth0, K, gt = sequence(w, h, n, seq_index)
+    ctx = hip.Context(w, h, K)
+    return frames, depth0, K, gt, ctx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K-pyr
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(160, 128), (640, 480)])
+def test_pyramids_bit_exact(oracle, hip, w, h):
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 2)
+    fo = oracle.Frame(0, frames[1], K)
+    fg = hip.Frame(ctx, 0, frames[1])
+    for lvl in range(5):
+        assert np.array_equal(ctx.intrinsics(lvl), fo.intrinsics(lvl)), "intrinsics level %d" % lvl
+        assert_bit_equal(fg.image(lvl), fo.plane("image", lvl), "image L%d" % lvl)
+        assert_bit_equal(fg.gradients(lvl), fo.plane("gradients", lvl), "gradients L%d" % lvl)
+    assert_bit_equal(fg.maxGradients(0), fo.plane("maxGradients", 0), "maxGradients")
+    # K-pyr-id + setDepthFromGroundTruth
+    fo.set_depth_gt(depth0)
+    fg.setDepthFromGroundTruth(depth0)
+    for lvl in range(5):
+        assert_bit_equal(fg.idepth(lvl), fo.plane("idepth", lvl), "idepth L%d" % lvl)
+        assert_bit_equal(fg.idepthVar(lvl), fo.plane("idepthVar", lvl), "idepthVar L%d" % lvl)
+
+
+def test_idepth_pyramid_ragged_validity(oracle, hip):
+    """inverse-variance pooling with random holes, negative idepths and tiny variances"""
+    w, h = 160, 128
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 1)
+    rng = np.random.default_rng(7)
+    idp = rng.uniform(-0.2, 2.0, (h, w)).astype(np.float32)
+    var = rng.uniform(1e-6, 0.25, (h, w)).astype(np.float32)
+    hole = rng.uniform(size=(h, w)) < 0.6
+    idp[hole] = -1
+    var[hole] = -1
+    idp[10:20, 10:20] = -1
+    var[10:20, 10:20] = -1      # fully empty 2x2 blocks
+    fo = oracle.Frame(0, frames[0], K)
+    fg = hip.Frame(ctx, 0, frames[0])
+    fo.set_depth_planes(idp, var)
+    fg.setDepthPlanes(idp, var)
+    for lvl in range(5):
+        assert_bit_equal(fg.idepth(lvl), fo.plane("idepth", lvl), "idepth L%d" % lvl)
+        assert_bit_equal(fg.idepthVar(lvl), fo.plane("idepthVar", lvl), "idepthVar L%d" % lvl)
+
+
+def test_pointcloud_order_and_bits(oracle, hip):
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 1)
+    fo = oracle.Frame(0, frames[0], K)
+    fg = hip.Frame(ctx, 0, frames[0])
+    fo.set_depth_gt(depth0)
+    fg.setDepthFromGroundTruth(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(fo)
+    rg = hip.TrackingReference()
+    rg.importFrame(fg)
+    for lvl in (4, 3, 2, 1, 0):
+        po, cvo, gro, io = ro.pointcloud(lvl)
+        pg, cvg, grg, ig = rg.makePointCloud(lvl)
+        assert len(po) == len(pg) and len(po) > 0
+        assert np.array_equal(io, ig)
+        assert_bit_equal(pg, po, "posData L%d" % lvl)
+        assert_bit_equal(cvg, cvo, "colorAndVarData L%d" % lvl)
+        assert_bit_equal(grg, gro, "gradData L%d" % lvl)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# residual kernel (K1+K2+K3) at fixed poses
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_terms64(oracle, tr):
+    """float64 accumulation of the oracle's per-point float32 terms in SSE operation order (exact reciprocal)."""
+    f32 = np.float32
+    x, y, z = tr.buffer("x"), tr.buffer("y"), tr.buffer("z")
+    gx, gy, r, wgt = tr.buffer("dx"), tr.buffer("dy"), tr.buffer("residual"), tr.buffer("weight_p")
+    n = (len(x) // 4) * 4
+    x, y, z, gx, gy, r, wgt = [a[:n] for a in (x, y, z, gx, gy, r, wgt)]
+    pz = f32(1.0) / z
+    J = [pz * gx, pz * gy, None, None, None, (x * gy) * pz - (y * gx) * pz]
+    pz2 = pz * pz
+    v1 = (x * gx) * pz2
+    v2 = (y * gy) * pz2
+    J[2] = f32(0) - (v1 + v2)
+    J[3] = f32(0) - ((v2 * y) + (gy + v1 * y))
+    J[4] = (gx + v1 * x) + v2 * x
+    A = np.zeros((6, 6))
+    Aabs = np.zeros((6, 6))
+    for i in range(6):
+        Jw = J[i] * wgt
+        for j in range(i, 6):
+            t = (Jw * J[j]).astype(np.float64)
+            A[i, j] = A[j, i] = t.sum()
+            Aabs[i, j] = Aabs[j, i] = np.abs(t).sum()
+    resw = r * wgt
+    b = np.array([-(resw * J[i]).astype(np.float64).sum() for i in range(6)])
+    babs = np.array([np.abs((resw * J[i]).astype(np.float64)).sum() for i in range(6)])
+    err = (resw * r).astype(np.float64).sum()
+    return A, Aabs, b, babs, err, n
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+def test_residual_kernel_fixed_pose(oracle, hip, w, h):
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4)
+    kfo = oracle.Frame(0, frames[0], K)
+    kfg = hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(kfo)
+    rg = hip.TrackingReference()
+    rg.importFrame(kfg)
+    tro = oracle.SE3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP)
+    trg = hip.SE3Tracker(ctx)
+    poses = [IDENT7.astype(np.float32),
+             oracle.se3_inv(gt[3]).astype(np.float32),
+             oracle.se3_exp(np.array([0.05, -0.03, 0.02, 0.01, -0.02, 0.03])).astype(np.float32),
+             oracle.se3_exp(np.array([0.9, 0.1, 0.0, 0.0, 0.35, 0.0])).astype(np.float32)]  # most points leave the image
+    for pi, T in enumerate(poses):
+        for lvl in (4, 3, 2, 1):
+            fo = oracle.Frame(3, frames[3], K)
+            fg = hip.Frame(ctx, 3, frames[3])
+            a, b = (1.0, 0.0) if pi % 2 == 0 else (1.03, -2.5)
+            r_o = tro.evaluate(ro, fo, T, lvl, a, b)
+            r_g = trg.evaluate(rg, fg, T, lvl, a, b)
+            tag = "pose %d level %d" % (pi, lvl)
+            # integer / mask outputs: exact
+            assert r_g.warped_size == r_o.warped_size, tag
+            assert r_g.goodCount == r_o.goodCount and r_g.badCount == r_o.badCount, tag
+            if lvl == 1:
+                assert_bit_equal(fg.refPixelWasGoodNoCreate(), fo.wasgood(), "refPixelWasGood " + tag)
+            else:
+                assert fg.refPixelWasGoodNoCreate() is None and fo.wasgood() is None
+            if r_o.warped_size < 8:
+                continue
+            assert r_g.num_constraints == r_o.num_constraints, tag
+            # reductions of K1
+            assert r_g.pointUsage == pytest.approx(r_o.pointUsage, rel=2e-5), tag
+            assert r_g.retval == pytest.approx(r_o.retval, rel=1e-4), tag
+            assert r_g.meanRes == pytest.approx(r_o.meanRes, rel=1e-3, abs=1e-4), tag
+            assert r_g.affine_a_lastIt == pytest.approx(r_o.affine_a_lastIt, rel=1e-4), tag
+            assert r_g.affine_b_lastIt == pytest.approx(r_o.affine_b_lastIt, rel=1e-3, abs=2e-3), tag
+            # K2 / K3 against a float64 accumulation of the oracle's per-point float32 terms
+            A64, Aabs, b64, babs, err64, n4 = _oracle_terms64(oracle, tro)
+            nc = r_o.num_constraints
+            Ag = np.array(r_g.A).reshape(6, 6).astype(np.float64) * nc
+            bg = np.array(r_g.b).astype(np.float64) * nc
+            assert np.all(np.abs(Ag - A64) <= 1e-5 * Aabs + 1e-12), tag
+            assert np.all(np.abs(bg - b64) <= 1e-5 * babs + 1e-12), tag
+            assert r_g.lsError * nc == pytest.approx(err64, rel=1e-5), tag
+            assert r_g.weightedError == pytest.approx(r_o.weightedError, rel=2e-5), tag
+            # and within float32-summation noise of the oracle's own float32 sums
+            assert np.allclose(np.array(r_g.A), np.array(r_o.A), rtol=2e-4, atol=1e-4 * np.abs(np.array(r_o.A)).max()), tag
+
+
+def test_trackframe_parity(oracle, hip):
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
+    kfo = oracle.Frame(0, frames[0], K)
+    kfg = hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(kfo)
+    rg = hip.TrackingReference()
+    rg.importFrame(kfg)
+    trg = hip.SE3Tracker(ctx)
+    trg.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr_sse = oracle.SE3Tracker(w, h, K, mode=oracle.SSE)
+    tr_sc = oracle.SE3Tracker(w, h, K, mode=oracle.SCALAR)
+    tr_sse.set_max_its(ODOMETRY_ITS)
+    tr_sc.set_max_its(ODOMETRY_ITS)
+    init = IDENT7.copy()
+    for i in range(1, 6):
+        fo = oracle.Frame(i, frames[i], K)
+        fo2 = oracle.Frame(i, frames[i], K)
+        fg = hip.Frame(ctx, i, frames[i])
+        r_sse = tr_sse.track(ro, fo, init)
+        r_sc = tr_sc.track(ro, fo2, init)
+        est = trg.trackFrame(rg, fg, init)
+        p_sse, p_sc = np.array(r_sse.frameToRef), np.array(r_sc.frameToRef)
+        spread = max(max(pose_distance(p_sse, p_sc, oracle)), 1e-5)
+        dt, dr = pose_distance(est, p_sse, oracle)
+        # within 10x the reference's own scalar-vs-SSE spread on this input (and an absolute 5e-4 floor)
+        assert max(dt, dr) <= max(10 * spread, 5e-4), (i, dt, dr, spread)
+        assert trg.diverged == bool(r_sse.diverged) and trg.trackingWasGood == bool(r_sse.trackingWasGood)
+        assert trg.lastResidual == pytest.approx(r_sse.lastResidual, rel=5e-2)
+        assert trg.pointUsage == pytest.approx(r_sse.pointUsage, rel=1e-3)
+        # frame side effects
+        so, sg = fo.stats(), fg.stats()
+        assert sg["initialTrackedResidual"] == pytest.approx(so["initialTrackedResidual"], rel=5e-2)
+        mg, mo = fg.refPixelWasGoodNoCreate(), fo.wasgood()
+        assert mg is not None and mo is not None
+        assert (mg != mo).mean() < 2e-3   # masks are those of the last evaluated pose; poses differ by ~1e-5
+        init = est
+    assert kfg.stats()["numFramesTrackedOnThis"] == kfo.stats()["numFramesTrackedOnThis"] == 5
+
+
+def test_trackframe_divergence_returns_identity(oracle, hip):
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 2)
+    kfo = oracle.Frame(0, frames[0], K)
+    kfg = hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(kfo)
+    rg = hip.TrackingReference()
+    rg.importFrame(kfg)
+    bad = oracle.se3_exp(np.array([5.0, 0, 0, 0, 0, 0]))   # keyframe entirely out of view
+    tro = oracle.SE3Tracker(w, h, K)
+    trg = hip.SE3Tracker(ctx)
+    r = tro.track(ro, oracle.Frame(1, frames[1], K), bad)
+    est = trg.trackFrame(rg, hip.Frame(ctx, 1, frames[1]), bad)
+    assert r.diverged and trg.diverged and not trg.trackingWasGood
+    assert np.array_equal(est, IDENT7)
+
+
+def test_permaref_paths(oracle, hip):
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4)
+    kfo = oracle.Frame(0, frames[0], K)
+    kfo.set_depth_gt(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(kfo)
+    pos, cv, _, _ = ro.pointcloud(4)
+    tro = oracle.SE3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP)
+    trg = hip.SE3Tracker(ctx)
+    fo = oracle.Frame(3, frames[3], K)
+    fg = hip.Frame(ctx, 3, frames[3])
+    T0 = oracle.se3_exp(np.array([0.01, 0.0, 0.0, 0, 0, 0.002]))
+    r = tro.track_permaref(pos, cv, fo, T0)
+    est = trg.trackFrameOnPermaref(pos, cv, fg, T0)
+    dt, dr = pose_distance(est, np.array(r.frameToRef), oracle)
+    assert max(dt, dr) < 2e-3, (dt, dr)
+    assert trg.trackingWasGood == bool(r.trackingWasGood)
+    u_o = tro.check_overlap(pos, kfo, T0)
+    u_g = trg.checkPermaRefOverlap(pos, T0)
+    assert u_g == pytest.approx(u_o, rel=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# depth map stages
+# ---------------------------------------------------------------------------------------------------------------
+def _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, sigma=0.1, seed=1):
+    kfo = oracle.Frame(0, frames[0], K)
+    kfg = hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    dmo = oracle.DepthMap(w, h, K)
+    dmg = hip.DepthMap(ctx)
+    dmo.init_gt(kfo)
+    dmg.initializeFromGTDepth(kfg)
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "initializeFromGTDepth")
+    hyp = dmo.get()
+    rng = np.random.default_rng(seed)
+    v = hyp["isValid"] > 0
+    noise = rng.normal(0, sigma, hyp.shape).astype(np.float32)
+    for k in ("idepth", "idepth_smoothed"):
+        hyp[k][v] += noise[v]
+    for k in ("idepth_var", "idepth_var_smoothed"):
+        hyp[k][v] = sigma ** 2
+    # ragged state: holes, blacklisted pixels, varied validity, scheduled skips
+    holes = rng.uniform(size=hyp.shape) < 0.15
+    hyp["isValid"][holes] = 0
+    hyp["blacklisted"][rng.uniform(size=hyp.shape) < 0.03] = -2
+    hyp["blacklisted"][rng.uniform(size=hyp.shape) < 0.03] = -1
+    hyp["validity_counter"] = rng.integers(0, 60, hyp.shape).astype(np.int32)
+    hyp["nextStereoFrameMinID"][rng.uniform(size=hyp.shape) < 0.2] = 4.0
+    dmo.set(kfo, hyp)
+    dmg.setCurrentDepthMap(kfg, hyp)
+    return kfo, kfg, dmo, dmg
+
+
+def assert_hyp_equal(g, o, what, float_exact=True, rtol=0.0):
+    assert_bit_equal(g["isValid"], o["isValid"], what + ": isValid")
+    assert_bit_equal(g["blacklisted"], o["blacklisted"], what + ": blacklisted")
+    v = o["isValid"] > 0
+    assert_bit_equal(g["validity_counter"][v], o["validity_counter"][v], what + ": validity_counter")
+    for k in ("nextStereoFrameMinID", "idepth", "idepth_var", "idepth_smoothed", "idepth_var_smoothed"):
+        if float_exact:
+            assert_bit_equal(g[k][v], o[k][v], what + ": " + k)
+        else:
+            assert np.allclose(g[k][v], o[k][v], rtol=rtol, atol=0), what + ": " + k
+
+
+def _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, ids, with_masks=True, seed=5):
+    rng = np.random.default_rng(seed)
+    fos, fgs = [], []
+    for i in ids:
+        fo = oracle.Frame(i, frames[i], K)
+        fg = hip.Frame(ctx, i, frames[i])
+        sim3 = np.concatenate([gt[i], [1.0]])
+        itr = float(0.3 + 0.1 * i)
+        fo.set_pose(sim3, kfo, itr)
+        fg.setPose(sim3, kfg, itr)
+        if with_masks:
+            m = (rng.uniform(size=(fo.h >> 1, fo.w >> 1)) < 0.9).astype(np.uint8)
+            fo.set_wasgood(m)
+            fg.set_refPixelWasGood(m)
+        fos.append(fo)
+        fgs.append(fg)
+    return fos, fgs
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+def test_depth_stages_bit_exact(oracle, hip, w, h):
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h)
+    kfo.set_counters(7, 3, 3, 0)
+    kfg.setCounters(7, 3, 3, 0)
+    fos, fgs = _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [3, 4, 6, 7])
+    # K4 with a multi-frame deque (oldest = 3, newest = 7, id 5 missing -> referenceFrameByID duplicates)
+    dmo.stage("observe", fos)
+    dmg.stage("observe", fgs)
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "observeDepth")
+    # K5
+    dmo.stage("fillholes")
+    dmg.stage("fillholes")
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "fillHoles")
+    # K6 both variants
+    dmo.stage("regularize")
+    dmg.stage("regularize")
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "regularize<false>")
+    dmo.stage("regularize_occ")
+    dmg.stage("regularize_occ")
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "regularize<true>")
+    # second observe pass: the update branch now sees smoothed values written by K6
+    dmo.stage("observe", fos[1:])
+    dmg.stage("observe", fgs[1:])
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "observeDepth (2nd)")
+
+
+def test_observe_reactivated_and_no_masks(oracle, hip):
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, seed=3)
+    hyp = dmo.get()
+    dmo.set(kfo, hyp, reactivated=True)
+    dmg.setCurrentDepthMap(kfg, hyp, reactivated=True)
+    fos, fgs = _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [2, 5], with_masks=False)
+    dmo.stage("observe", fos)
+    dmg.stage("observe", fgs)
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "observeDepth reactivated")
+
+
+def test_update_keyframe_end_to_end(oracle, hip):
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, seed=11)
+    for i in range(1, 6):
+        fos, fgs = _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [i], seed=i)
+        dmo.update(fos)
+        dmg.updateKeyframe(fgs)
+        assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "updateKeyframe %d" % i)
+    so, sg = kfo.stats(), kfg.stats()
+    assert sg["numMappedOnThis"] == so["numMappedOnThis"] == 5
+    # setDepth ran on the first update only (depthHasBeenUpdatedFlag, DepthMap.cpp:1150)
+    assert sg["depthHasBeenUpdatedFlag"] == so["depthHasBeenUpdatedFlag"] == 1
+    assert sg["numPoints"] == so["numPoints"]
+    assert sg["meanIdepth"] == pytest.approx(so["meanIdepth"], rel=1e-5)
+    for lvl in range(5):
+        assert_bit_equal(kfg.idepth(lvl), kfo.plane("idepth", lvl), "kf idepth L%d" % lvl)
+        assert_bit_equal(kfg.idepthVar(lvl), kfo.plane("idepthVar", lvl), "kf idepthVar L%d" % lvl)
+
+
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_propagate_and_create_keyframe(oracle, hip, use_mask):
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 10)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, sigma=0.05, seed=21)
+    dmo.stage("regularize")
+    dmg.stage("regularize")
+    fos, fgs = _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [9], with_masks=use_mask)
+    nko, nkg = fos[0], fgs[0]
+    # K7 alone
+    hyp0 = dmo.get()
+    dmo.stage("propagate", [nko])
+    dmg.stage("propagate", [nkg])
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "propagateDepth")
+    # full createKeyFrame from the same starting state
+    dmo.set(kfo, hyp0)
+    dmg.setCurrentDepthMap(kfg, hyp0)
+    s_o = dmo.create_keyframe(nko)
+    s_g = dmg.createKeyFrame(nkg)
+    assert s_g == pytest.approx(s_o, rel=2e-5)     # float32 sequential vs float64 tree sum of ~1e5 terms
+    go, gg = dmo.get(), dmg.currentDepthMap()
+    assert_hyp_equal(gg, go, "createKeyFrame", float_exact=False, rtol=1e-4)
+    po, pg = nko.pose(), nkg.thisToParent_raw()
+    assert np.allclose(pg[:7], po[:7], atol=1e-12) and pg[7] == pytest.approx(po[7], rel=2e-5)
+    assert nkg.stats()["numPoints"] == nko.stats()["numPoints"]
+
+
+def test_finalize_and_reactivation(oracle, hip):
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 3)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, seed=4)
+    dmo.finalize()
+    dmg.finalizeKeyFrame()
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "finalizeKeyFrame")
+    for lvl in range(5):
+        assert_bit_equal(kfg.idepth(lvl), kfo.plane("idepth", lvl), "finalize idepth L%d" % lvl)
+    # wipe and re-activate from the keyframe's own re-activation data (setFromExistingKF)
+    dmo.set_from_existing(kfo)
+    dmg.setFromExistingKF(kfg)
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "setFromExistingKF")
+
+
+def test_usage_errors_are_loud(hip):
+    frames, depth0, K, gt = sequence(160, 128, 2)
+    with pytest.raises(hip.LsdHipError):
+        hip.Context(150, 128, K)              # not a multiple of 16 (C/SlamSystem.cpp:55-59)
+    ctx = hip.Context(160, 128, K)
+    f = hip.Frame(ctx, 0, frames[0])
+    ref = hip.TrackingReference()
+    ref.importFrame(f)
+    tr = hip.SE3Tracker(ctx)
+    with pytest.raises(hip.LsdHipError):
+        tr.trackFrame(ref, hip.Frame(ctx, 1, frames[1]), IDENT7)   # keyframe without depth
+    dm = hip.DepthMap(ctx)
+    with pytest.raises(hip.LsdHipError):
+        dm.updateKeyframe([f])                # no active keyframe

@@ -1,0 +1,178 @@
+"""CPU tests of the oracle itself (no GPU): self-checks that catch restatement errors, the Sophus group-property
+tests the reference vendors (thirdparty/Sophus/sophus/test_se3.cpp:42-86, tests.hpp) applied to the minimal SE3, and
+agreement of the oracle's three tracker arithmetic paths."""
+import numpy as np
+import pytest
+
+from common import ODOMETRY_ITS, assert_bit_equal, pose_distance, sequence
+
+
+def test_se3_exp_log_roundtrip_sophus_elements(oracle):
+    # the tangent / group element list of thirdparty/Sophus/sophus/test_se3.cpp:42-86
+    tangents = [np.array(v, float) for v in [
+        [0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0], [0, 1, 0, 1, 0, 0], [0, -5, 10, 0, 0, 0], [-1, 1, 0, 0, 0, 1],
+        [20, -1, 0, -1, 1, 0], [30, 5, -1, 20, -1, 0]]]
+    omegas = [[0.2, 0.5, 0.0], [0.2, 0.5, -1.0], [0, 0, 0], [0, 0, 0.00001], [np.pi, 0, 0], [0.2, 0.5, 0.0]]
+    trans = [[0, 0, 0], [10, 0, 0], [0, 100, 5], [0, 0, 0], [4, -5, 0], [1e-6, 2e-6, 3e-6]]
+    elems = []
+    for om, t in zip(omegas, trans):
+        T = oracle.se3_exp(np.array([0, 0, 0] + om, float))
+        T[4:] = t
+        elems.append(T)
+    for T in elems:  # exp(log(T)) == T   (tests.hpp: expLogTest)
+        T2 = oracle.se3_exp(oracle.se3_log(T))
+        dt, dr = pose_distance(T, T2, oracle)
+        assert dt < 1e-8 and dr < 1e-8
+    for a in tangents:  # log(exp(a)) == a for |omega| < pi (tests.hpp: expMapTest)
+        if np.linalg.norm(a[3:]) < np.pi:
+            a2 = oracle.se3_log(oracle.se3_exp(a))
+            assert np.allclose(a, a2, atol=1e-9)
+    for A in elems:  # group law: (A*B)*B^-1 == A
+        for B in elems:
+            AB = oracle.se3_mul(A, B)
+            A2 = oracle.se3_mul(AB, oracle.se3_inv(B))
+            dt, dr = pose_distance(A, A2, oracle)
+            assert dt < 1e-6 and dr < 1e-9
+
+
+def test_ldlt6_solves_spd_system(oracle):
+    rng = np.random.default_rng(3)
+    L = oracle.lib()
+    for _ in range(20):
+        M = rng.standard_normal((6, 6)).astype(np.float32)
+        A = (M @ M.T + 6 * np.eye(6)).astype(np.float32)
+        b = rng.standard_normal(6).astype(np.float32)
+        x = np.zeros(6, np.float32)
+        L.orc_ldlt6_solve(np.ascontiguousarray(A.ravel()), b, x)
+        assert np.allclose(A.astype(np.float64) @ x, b, atol=2e-5)
+
+
+def test_image_pyramid_sse_and_scalar_association_agree(oracle):
+    # for uint8-sourced images both associations are exact => identical bits on every level
+    frames, depth0, K, _ = sequence(160, 128, 2)
+    fa = oracle.Frame(0, frames[0], K)
+    fb = oracle.Frame(0, frames[0], K)
+    fb.L.orc_frame_set_sse_pyramid(fb.h_, 0)
+    for lvl in range(5):
+        assert_bit_equal(fa.plane("image", lvl), fb.plane("image", lvl), "image level %d" % lvl)
+        assert_bit_equal(fa.plane("gradients", lvl), fb.plane("gradients", lvl), "gradients level %d" % lvl)
+
+
+def test_gradients_border_convention(oracle):
+    frames, _, K, _ = sequence(160, 128, 1)
+    f = oracle.Frame(0, frames[0], K)
+    g = f.plane("gradients", 0)
+    img = f.plane("image", 0)
+    assert np.all(g[0] == 0) and np.all(g[-1] == 0)          # rows 0 / h-1 never written (defined as 0)
+    assert np.all(g[1:-1, 1:-1, 2] == img[1:-1, 1:-1])
+    assert np.all(g[1:-1, 1:-1, 0] == 0.5 * (img[1:-1, 2:] - img[1:-1, :-2]))
+    assert np.all(g[1:-1, 1:-1, 1] == 0.5 * (img[2:, 1:-1] - img[:-2, 1:-1]))
+    # column 0 wraps across the row boundary in the linear walk (Frame.cpp:658-677)
+    assert g[5, 0, 0] == 0.5 * (img[5, 1] - img[4, -1])
+
+
+def test_jacobian_matches_finite_differences(oracle):
+    """-b of the normal equations is the gradient of the weighted cost: check against finite differences of the
+    weighted error along the 6 twist directions (SURVEY.md §8(c) self-check)."""
+    frames, depth0, K, gt = sequence(160, 128, 3)
+    kf = oracle.Frame(0, frames[0], K)
+    kf.set_depth_gt(depth0)
+    fr = oracle.Frame(1, frames[2], K)
+    ref = oracle.TrackingReference()
+    ref.import_frame(kf)
+    tr = oracle.SE3Tracker(160, 128, K, mode=oracle.SCALAR)
+    T0 = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)
+    r0 = tr.evaluate(ref, fr, T0, 1)
+    A = np.array(r0.A).reshape(6, 6)
+    b = np.array(r0.b)
+    assert np.allclose(A, A.T)
+    assert np.all(np.linalg.eigvalsh(A.astype(np.float64)) > 0)
+    # Gauss-Newton step must reduce the weighted error
+    inc = np.linalg.solve(A.astype(np.float64), -b.astype(np.float64))
+    T1 = oracle.se3_exp(inc)
+    r1 = tr.evaluate(ref, fr, T1.astype(np.float32), 1)
+    assert r1.weightedError < r0.weightedError
+
+
+def test_tracker_recovers_rendered_pose_and_paths_agree(oracle):
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 3)
+    kf = oracle.Frame(0, frames[0], K)
+    kf.set_depth_gt(depth0)
+    ref = oracle.TrackingReference()
+    ref.import_frame(kf)
+    est = {}
+    for mode in (oracle.SCALAR, oracle.SSE, oracle.SSE_EXACT_RCP):
+        tr = oracle.SE3Tracker(w, h, K, mode=mode)
+        tr.set_max_its(ODOMETRY_ITS)
+        fr = oracle.Frame(2, frames[2], K)
+        r = tr.track(ref, fr, np.array([1, 0, 0, 0, 0, 0, 0], float))
+        assert not r.diverged and r.trackingWasGood
+        est[mode] = np.array(r.frameToRef)
+        dt, dr = pose_distance(est[mode], gt[2], oracle)
+        assert dt < 1e-2 and dr < 5e-3, (dt, dr)  # small baseline: translation/rotation ambiguity of direct alignment
+    # the reference's own scalar-vs-SSE spread defines the function-level tolerance
+    dt, dr = pose_distance(est[oracle.SCALAR], est[oracle.SSE], oracle)
+    assert dt < 5e-4 and dr < 5e-4
+    dt, dr = pose_distance(est[oracle.SSE_EXACT_RCP], est[oracle.SSE], oracle)
+    assert dt < 5e-4 and dr < 5e-4
+
+
+def test_sse_tail_drop_and_constraint_count(oracle):
+    frames, depth0, K, _ = sequence(160, 128, 2)
+    kf = oracle.Frame(0, frames[0], K)
+    kf.set_depth_gt(depth0)
+    fr = oracle.Frame(1, frames[1], K)
+    ref = oracle.TrackingReference()
+    ref.import_frame(kf)
+    tr = oracle.SE3Tracker(160, 128, K, mode=oracle.SSE)
+    r = tr.evaluate(ref, fr, np.array([1, 0, 0, 0, 0, 0, 0], np.float32), 2)
+    assert r.num_constraints == 6 * (r.warped_size // 4)      # LGSX.h:385 quirk
+    w = tr.buffer("weight_p")
+    assert len(w) == r.warped_size
+
+
+def test_stereo_recovers_plane_depth(oracle):
+    """observe + regularise on a noisy initial map must pull inverse depths towards ground truth."""
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 8)
+    kf = oracle.Frame(0, frames[0], K)
+    kf.set_depth_gt(depth0)
+    dm = oracle.DepthMap(w, h, K)
+    dm.init_gt(kf)
+    hyp = dm.get()
+    rng = np.random.default_rng(1)
+    v = hyp["isValid"] > 0
+    noise = rng.normal(0, 0.1, hyp.shape).astype(np.float32)
+    for k in ("idepth", "idepth_smoothed"):
+        hyp[k][v] += noise[v]
+    for k in ("idepth_var", "idepth_var_smoothed"):
+        hyp[k][v] = 0.1 ** 2
+    dm.set(kf, hyp)
+    err0 = np.abs(hyp["idepth_smoothed"][v] - 1.0 / depth0[v]).mean()
+    for i in range(3, 8):
+        fr = oracle.Frame(i, frames[i], K)
+        fr.set_pose(np.concatenate([gt[i], [1.0]]), kf, 0.5)
+        dm.update([fr])
+    out = dm.get()
+    v2 = (out["isValid"] > 0) & v
+    err1 = np.abs(out["idepth_smoothed"][v2] - 1.0 / depth0[v2]).mean()
+    assert v2.sum() > 0.5 * v.sum()
+    assert err1 < 0.5 * err0, (err0, err1)
+
+
+def test_regulariser_idempotent_on_constant_map(oracle):
+    w, h = 160, 128
+    frames, depth0, K, _ = sequence(w, h, 1)
+    kf = oracle.Frame(0, frames[0], K)
+    kf.set_depth_planes(np.full((h, w), 0.5, np.float32), np.full((h, w), 0.01, np.float32))
+    dm = oracle.DepthMap(w, h, K)
+    dm.init_gt(kf)
+    dm.stage("regularize")
+    a = dm.get()
+    inner = a[2:-2, 2:-2]
+    assert np.all(inner["isValid"] == 1)
+    assert np.allclose(inner["idepth_smoothed"], 0.5, rtol=1e-6)
+    dm.stage("regularize")
+    b = dm.get()
+    assert_bit_equal(a["idepth_smoothed"], b["idepth_smoothed"], "idempotent")
