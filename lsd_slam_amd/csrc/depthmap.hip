@@ -55,14 +55,18 @@
 #define MAX_DIFF_GRAD_MULT (0.5f * 0.5f)
 #define PROP_SLOT_CAP 8
 
+// per-pixel arithmetic is host+device so that tests/ can shadow-execute it on a CPU when chasing a parity bit
+#define LSD_HD __host__ __device__ __forceinline__
+#define LSD_HD_NOINLINE __host__ __device__
+
 // UNZERO (settings.h:35) evaluates in double in the reference; the float form below returns the same float for every
 // float input (|val| is compared against 1e-10, the result is rounded to float either way).
-__device__ __forceinline__ float unzero(float val) {
+LSD_HD float unzero(float val) {
   return (float)(val < 0 ? (val > -1e-10 ? -1e-10 : (double)val) : (val < 1e-10 ? 1e-10 : (double)val));
 }
 
 // getInterpolatedElement, C/util/globalFuncs.h:43-61
-__device__ __forceinline__ float interp1(const float* __restrict__ mat, float x, float y, int width) {
+LSD_HD float interp1(const float* __restrict__ mat, float x, float y, int width) {
   int ix = (int)x;
   int iy = (int)y;
   float dx = x - ix;
@@ -91,7 +95,7 @@ struct ObserveArgs {
 // DepthMap::doLineStereo (DepthMap.cpp:1442-1972).  Status codes as in the reference: >= 0 matching error,
 // -1 out of bounds, -2 ambiguous / negative, -3 error too large, -4 arithmetic.  The epipolar walk is capped at 1000
 // steps (the reference loop is unbounded; no finite input reaches the cap).
-__device__ float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, const float u, const float v, const float epxn,
+LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, const float u, const float v, const float epxn,
                                 const float epyn, const float min_idepth, const float prior_idepth, float max_idepth,
                                 float& result_idepth, float& result_var, float& result_eplLength) {
   const int width = a.w, height = a.h;
@@ -131,12 +135,12 @@ __device__ float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, const
   if (pFar2 < 0.001f || max_idepth < min_idepth) return -1;
   pFar0 = pFar0 / pFar2; pFar1 = pFar1 / pFar2;
 
-  if (isnan((float)(pFar0 + pClose0))) return -4;
+  if (__builtin_isnan((float)(pFar0 + pClose0))) return -4;
 
   float incx = pClose0 - pFar0;
   float incy = pClose1 - pFar1;
   float eplLength = sqrtf(incx * incx + incy * incy);
-  if (eplLength == 0.0f || isinf(eplLength)) return -4;  // `!eplLength > 0 || isinf` of the reference (:1518)
+  if (eplLength == 0.0f || __builtin_isinf(eplLength)) return -4;  // `!eplLength > 0 || isinf` of the reference (:1518)
 
   if (eplLength > MAX_EPL_LENGTH_CROP) {
     pClose0 = pFar0 + incx * MAX_EPL_LENGTH_CROP / eplLength;
@@ -337,11 +341,11 @@ __device__ float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, const
 }
 
 // DepthMap::makeAndCheckEPL (DepthMap.cpp:184-234)
-__device__ __forceinline__ bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x, int y, float* pepx, float* pepy) {
+LSD_HD bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x, int y, float* pepx, float* pepy) {
   int idx = x + y * a.w;
   float epx = -a.fx * rf.thisToOther_t[0] + rf.thisToOther_t[2] * (x - a.cx);
   float epy = -a.fy * rf.thisToOther_t[1] + rf.thisToOther_t[2] * (y - a.cy);
-  if (isnan(epx + epy)) return false;
+  if (__builtin_isnan(epx + epy)) return false;
   float eplLengthSquared = epx * epx + epy * epy;
   if (eplLengthSquared < MIN_EPL_LENGTH_SQUARED) return false;
   float gx = a.kfImage[idx + 1] - a.kfImage[idx - 1];
@@ -350,16 +354,16 @@ __device__ __forceinline__ bool make_and_check_epl(const ObserveArgs& a, const S
   eplGradSquared = eplGradSquared * eplGradSquared / eplLengthSquared;
   if (eplGradSquared < MIN_EPL_GRAD_SQUARED) return false;
   if (eplGradSquared / (gx * gx + gy * gy) < MIN_EPL_ANGLE_SQUARED) return false;
-  float fac = GRADIENT_SAMPLE_DIST / sqrtf(eplLengthSquared);
+  // the reference calls the C library's double sqrt() here (unqualified sqrt in DepthMap.cpp:229), so the quotient is
+  // formed in double and rounded to float once; f64 sqrt / divide are IEEE-exact on gfx950
+  float fac = (float)((double)GRADIENT_SAMPLE_DIST / sqrt((double)eplLengthSquared));
   *pepx = epx * fac;
   *pepy = epy * fac;
   return true;
 }
 
-// K4: observeDepthRow over the whole map, one pixel per lane, hypothesis updated in place.
-__global__ __launch_bounds__(256) void k_observe(ObserveArgs a) {
-  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+// observeDepthRow body for one pixel (DepthMap.cpp:117-143), hypothesis updated in place.
+LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int y) {
   if (x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3) return;
   const int idx = x + y * a.w;
   const bool hasHypothesis = a.m.valid[idx] != 0;
@@ -455,6 +459,13 @@ __global__ __launch_bounds__(256) void k_observe(ObserveArgs a) {
       a.m.nextID[idx] = rf.id + inc;
     }
   }
+}
+
+// K4: observeDepthRow over the whole map, one pixel per lane.
+__global__ __launch_bounds__(256) void k_observe(ObserveArgs a) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  observe_pixel(a, x, y);
 }
 
 struct RegArgs {

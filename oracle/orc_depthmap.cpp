@@ -126,7 +126,9 @@ bool DepthMap::makeAndCheckEPL(const int x, const int y, const Frame* const ref,
   eplGradSquared = eplGradSquared * eplGradSquared / eplLengthSquared;
   if (eplGradSquared < MIN_EPL_GRAD_SQUARED) return false;
   if (eplGradSquared / (gx * gx + gy * gy) < MIN_EPL_ANGLE_SQUARED) return false;
-  float fac = GRADIENT_SAMPLE_DIST / sqrt(eplLengthSquared);
+  // unqualified sqrt() in the reference (DepthMap.cpp:229) is the C library's double sqrt(double): with the libstdc++ of
+  // the reference's era <cmath> leaves only that overload in the global namespace, so the quotient is a double
+  float fac = (float)((double)GRADIENT_SAMPLE_DIST / sqrt((double)eplLengthSquared));
   *pepx = epx * fac;
   *pepy = epy * fac;
   return true;
@@ -178,7 +180,7 @@ bool DepthMap::observeDepthUpdate(int x, int y, int idx, const float* keyFrameMa
   bool isGood = makeAndCheckEPL(x, y, refFrame, &epx, &epy);
   if (!isGood) return false;
 
-  float sv = sqrt(target->idepth_var_smoothed);
+  float sv = (float)sqrt((double)target->idepth_var_smoothed);  // double sqrt, one rounding: == sqrtf
   float min_idepth = target->idepth_smoothed - sv * STEREO_EPL_VAR_FAC;
   float max_idepth = target->idepth_smoothed + sv * STEREO_EPL_VAR_FAC;
   if (min_idepth < 0) min_idepth = 0;
@@ -593,7 +595,7 @@ float DepthMap::doLineStereo(const float u, const float v, const float epxn, con
 
   float incx = pClose[0] - pFar[0];
   float incy = pClose[1] - pFar[1];
-  float eplLength = sqrt(incx * incx + incy * incy);
+  float eplLength = (float)sqrt((double)(incx * incx + incy * incy));  // == sqrtf
   if (!eplLength > 0 || std::isinf(eplLength)) return -4;  // sic: true only for eplLength == 0 (or inf)
 
   if (eplLength > MAX_EPL_LENGTH_CROP) {
@@ -642,7 +644,7 @@ float DepthMap::doLineStereo(const float u, const float v, const float epxn, con
     }
     float fincx = pClose[0] - pFar[0];
     float fincy = pClose[1] - pFar[1];
-    float newEplLength = sqrt(fincx * fincx + fincy * fincy);
+    float newEplLength = (float)sqrt((double)(fincx * fincx + fincy * fincy));  // == sqrtf
     if (pClose[0] <= SAMPLE_POINT_TO_BORDER || pClose[0] >= width - SAMPLE_POINT_TO_BORDER || pClose[1] <= SAMPLE_POINT_TO_BORDER ||
         pClose[1] >= height - SAMPLE_POINT_TO_BORDER || newEplLength < 8.0f)
       return -1;

@@ -159,8 +159,10 @@ def test_residual_kernel_fixed_pose(oracle, hip, w, h):
             assert r_g.pointUsage == pytest.approx(r_o.pointUsage, rel=2e-5), tag
             assert r_g.retval == pytest.approx(r_o.retval, rel=1e-4), tag
             assert r_g.meanRes == pytest.approx(r_o.meanRes, rel=1e-3, abs=1e-4), tag
-            assert r_g.affine_a_lastIt == pytest.approx(r_o.affine_a_lastIt, rel=1e-4), tag
-            assert r_g.affine_b_lastIt == pytest.approx(r_o.affine_b_lastIt, rel=1e-3, abs=2e-3), tag
+            # the affine-lighting statistic is a difference of O(1e4 N) float32 sums (syy - sy^2/sw): ill-conditioned in
+            # the reference itself; b additionally multiplies the error of a by the mean intensity (~128)
+            assert r_g.affine_a_lastIt == pytest.approx(r_o.affine_a_lastIt, rel=5e-4), tag
+            assert r_g.affine_b_lastIt == pytest.approx(r_o.affine_b_lastIt, abs=0.08), tag
             # K2 / K3 against a float64 accumulation of the oracle's per-point float32 terms
             A64, Aabs, b64, babs, err64, n4 = _oracle_terms64(oracle, tro)
             nc = r_o.num_constraints
@@ -214,7 +216,8 @@ def test_trackframe_parity(oracle, hip):
         assert mg is not None and mo is not None
         assert (mg != mo).mean() < 2e-3   # masks are those of the last evaluated pose; poses differ by ~1e-5
         init = est
-    assert kfg.stats()["numFramesTrackedOnThis"] == kfo.stats()["numFramesTrackedOnThis"] == 5
+    assert kfg.stats()["numFramesTrackedOnThis"] == 5
+    assert kfo.stats()["numFramesTrackedOnThis"] == 10   # two oracle trackers (SSE + scalar) share the keyframe
 
 
 def test_trackframe_divergence_returns_identity(oracle, hip):
@@ -311,7 +314,10 @@ def _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, ids, with_masks=True,
     for i in ids:
         fo = oracle.Frame(i, frames[i], K)
         fg = hip.Frame(ctx, i, frames[i])
-        sim3 = np.concatenate([gt[i], [1.0]])
+        # GT pose composed with a small general twist: a pure in-plane translation + roll (the synthetic trajectory)
+        # leaves t_z = 0 and zero rotation off-diagonals, which would hide operation-order mismatches
+        twist = np.array([0.0, 0.0, 0.003, 0.0008, -0.0006, 0.0004]) * (1 + 0.1 * i)
+        sim3 = np.concatenate([oracle.se3_mul(gt[i], oracle.se3_exp(twist)), [1.0]])
         itr = float(0.3 + 0.1 * i)
         fo.set_pose(sim3, kfo, itr)
         fg.setPose(sim3, kfg, itr)
@@ -379,7 +385,8 @@ def test_update_keyframe_end_to_end(oracle, hip):
     # setDepth ran on the first update only (depthHasBeenUpdatedFlag, DepthMap.cpp:1150)
     assert sg["depthHasBeenUpdatedFlag"] == so["depthHasBeenUpdatedFlag"] == 1
     assert sg["numPoints"] == so["numPoints"]
-    assert sg["meanIdepth"] == pytest.approx(so["meanIdepth"], rel=1e-5)
+    # the reference accumulates sumIdepth sequentially in float32 (Frame.cpp:222); the device sums in float64
+    assert sg["meanIdepth"] == pytest.approx(so["meanIdepth"], rel=2e-4)
     for lvl in range(5):
         assert_bit_equal(kfg.idepth(lvl), kfo.plane("idepth", lvl), "kf idepth L%d" % lvl)
         assert_bit_equal(kfg.idepthVar(lvl), kfo.plane("idepthVar", lvl), "kf idepthVar L%d" % lvl)
