@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py — LSD-SLAM dense hot path on MI355X: tracked frames/sec (+ depth-map Mpixels/sec) at 640x480.
+
+One "step" = one frame of the full track+map loop of BASELINE.json configs[1]: device-resident uint8 frame ->
+image/gradient pyramids -> SE3Tracker::trackFrame against the current keyframe (5-level pyramid, LM over levels
+4..1) -> DepthMap::updateKeyframe([frame]) (observe/doLineStereo, fill holes, regularise, setDepth); every
+KF_EVERY-th frame finalizeKeyFrame + createKeyFrame (propagate, 2x regularise, fill holes, rescale) instead.
+Inputs (the rendered uint8 frames) are resident in HBM before the timed region starts.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank runs an independent sequence
+(weak scaling; BASELINE.json configs[3]) and the finished keyframes' inverse-depth planes are collected on rank 0 with
+an RCCL gather over xGMI — the only exchange step of the path.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+KF_EVERY = 10
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def cpu_baseline(frames, depth0, K, n_frames, w, h):
+    """The oracle's timing build (-O3, SSE tracker path, 4 mapping threads) on the same loop, bounded sample."""
+    from oracle import pyoracle as po
+    po.build()
+    L = po.lib(fast=True)
+    kf = po.Frame(0, frames[0], K, L=L)
+    kf.set_depth_gt(depth0)
+    dm = po.DepthMap(w, h, K, L=L, threads=4)
+    dm.init_gt(kf)
+    ref = po.TrackingReference(L=L)
+    ref.import_frame(kf)
+    tr = po.SE3Tracker(w, h, K, mode=po.SSE, L=L)
+    tr.set_max_its([5, 20, 50, 100, 0])
+    last = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    t_track = t_map = 0.0
+    n_upd = 0
+    since = 0
+    keep = [kf]
+    t_all = time.perf_counter()
+    for i in range(1, n_frames + 1):
+        t0 = time.perf_counter()
+        f = po.Frame(i, frames[i % len(frames)], K, L=L)
+        ref.import_frame(kf)
+        s = kf.stats()
+        kf.set_counters(int(s["numFramesTrackedOnThis"]), int(s["numMappedOnThis"]), int(s["numMappedOnThisTotal"]), 0)
+        r = tr.track(ref, f, last)
+        t1 = time.perf_counter()
+        t_track += t1 - t0
+        since += 1
+        if since >= KF_EVERY:
+            dm.finalize()
+            dm.create_keyframe(f)
+            kf = f
+            keep = [kf]
+            last = np.array([1.0, 0, 0, 0, 0, 0, 0])
+            since = 0
+        else:
+            dm.update([f])
+            f.clear_wasgood()
+            last = np.array(r.frameToRef)
+            n_upd += 1
+        t_map += time.perf_counter() - t1
+    total = time.perf_counter() - t_all
+    return {
+        "value": n_frames / total, "unit": "frames/s", "cores": 4, "kind": "port",
+        "sample": "%d frames of the same 640x480 track+map loop (oracle -O3 build: SSE tracker on 1 thread, depth map on 4 "
+                  "threads x 10-row chunks as the reference)" % n_frames,
+        "track_fps": n_frames / t_track, "depth_mpix_per_s": (w * h * n_upd) / t_map / 1e6 if t_map > 0 else None,
+        "seconds": total,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=250)
+    ap.add_argument("--no-roofline-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import lsd_slam_amd as la
+    from lsd_slam_amd import synth
+
+    w, h = args.width, args.height
+    n_seq = 50
+    frames, depth0, K, gt = synth.make_sequence(w, h, n_seq, seq_index=rank)
+    d_frames = torch.from_numpy(frames).cuda(local_rank)           # inputs resident in HBM
+    torch.cuda.synchronize()
+    ptr = lambda i: d_frames[i % n_seq].data_ptr()
+
+    ctx = la.Context(w, h, K, device=local_rank)
+    loop = la.SlamLoop(ctx, ptr(0), depth0, kf_every=KF_EVERY, device_frames=True)
+
+    # per-keyframe gather (RCCL over xGMI): smoothed idepth + variance planes of finished keyframes -> rank 0
+    from lsd_slam_amd.multigpu import KeyframeGather
+    kg = KeyframeGather((2, h, w), torch.device("cuda", local_rank))
+
+    def after_step():
+        if distributed and loop.new_keyframe:
+            kg.submit(lambda buf: loop.map.copyPlanesToDevice(buf[0].data_ptr(), buf[1].data_ptr()))
+
+    clock = time.perf_counter
+    fi = 0
+    for _ in range(args.warmup):
+        fi += 1
+        loop.step(ptr(fi), clock)
+        after_step()
+    kg.wait()
+
+    # timed region: exactly K steps between barrier + synchronize
+    loop.t_track = loop.t_map = 0.0
+    loop.n_track = loop.n_update = 0
+    loop.evaluations = 0
+    if not args.no_roofline_events:
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    t0 = clock()
+    for _ in range(args.steps):
+        fi += 1
+        loop.step(ptr(fi), clock)
+        after_step()
+    kg.wait()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = clock() - t0
+    ctx.prof_enable(False)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res_ms, res_launches, res_bytes = ctx.prof_read()
+    out = None
+    if rank == 0:
+        value = world * args.steps / elapsed
+        roofline = None
+        if res_launches > 0 and res_ms > 0:
+            achieved = (res_bytes / res_launches) / (res_ms / res_launches * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "k_residual (fused K0+K1+K2+K3)", "launches": int(res_launches),
+                        "avg_launch_us": res_ms / res_launches * 1e3,
+                        "algorithmic_bytes_per_launch": res_bytes / res_launches}
+        out = {
+            "metric": "tracked frames/sec (full track+map loop) at 640x480", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "640x480 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
+                                   "(BASELINE.json configs[1]); synthetic scene S1, GT-depth init, new keyframe every %d frames"
+                                   % KF_EVERY,
+                       "width": w, "height": h, "parallelism": "1 sequence per GPU, RCCL gather of keyframe depth planes"},
+            "track_fps": loop.n_track / loop.t_track if loop.t_track > 0 else None,
+            "depth_mpix_per_s": (w * h * loop.n_update) / loop.t_map / 1e6 if loop.t_map > 0 else None,
+            "lm_evaluations_per_frame": loop.evaluations / max(1, loop.n_track),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, depth0, K, args.cpu_frames, w, h)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

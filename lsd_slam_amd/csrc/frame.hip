@@ -333,6 +333,8 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->free_arenas) (void)hipFree(p);
+  for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   (void)hipStreamDestroy(c->stream);
@@ -386,8 +388,14 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
   take((size_t)c->wl[1] * c->hl[1]);
   char* base = nullptr;
-  hipError_t e = hipMalloc((void**)&base, align_up(off, 256));
-  if (e != hipSuccess) { lsd_set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); delete f; return LSDHIP_E_HIP; }
+  c->arena_bytes = align_up(off, 256);
+  if (!c->free_arenas.empty()) {
+    base = (char*)c->free_arenas.back();
+    c->free_arenas.pop_back();
+  } else {
+    hipError_t e = hipMalloc((void**)&base, c->arena_bytes);
+    if (e != hipSuccess) { lsd_set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); delete f; return LSDHIP_E_HIP; }
+  }
   k = 0;
   f->d_gray = (uint8_t*)(base + offs[k++]);
   for (int l = 0; l < LSD_LEVELS; l++) f->d_image[l] = (float*)(base + offs[k++]);
@@ -462,10 +470,19 @@ extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_ho
 }
 extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   if (!f) return;
-  (void)hipSetDevice(f->ctx->device);
-  (void)hipStreamSynchronize(f->ctx->stream);
-  (void)hipFree(f->d_gray);  // arena base
-  if (f->d_idepth_reAct) (void)hipFree(f->d_idepth_reAct);
+  lsdhip_ctx* c = f->ctx;
+  if (c->free_arenas.size() < 16) {
+    c->free_arenas.push_back(f->d_gray);  // arena base; reuse is ordered on the context's stream
+  } else {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(f->d_gray);
+  }
+  if (f->d_idepth_reAct) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(f->d_idepth_reAct);
+  }
   delete f;
 }
 extern "C" int lsdhip_frame_id(lsdhip_frame* f) { return f ? f->id : -1; }

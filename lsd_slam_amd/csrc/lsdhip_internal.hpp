@@ -25,28 +25,7 @@ void lsd_set_error(const char* fmt, ...);
     }                                                                                      \
   } while (0)
 
-// ---- host math (double/float quaternion poses; independent of oracle/) ---------------------------------
-namespace lsdm {
-struct Quatd { double w, x, y, z; };
-struct Quatf { float w, x, y, z; };
-struct SE3dH { Quatd q; double t[3]; };
-struct SE3fH { Quatf q; float t[3]; };
-struct Sim3dH { Quatd q; double t[3]; double s; };
-
-SE3dH se3d_from7(const double p[7]);
-void se3d_to7(const SE3dH& T, double p[7]);
-SE3dH se3d_inverse(const SE3dH& T);
-SE3fH se3f_from_d(const SE3dH& T);
-SE3dH se3d_from_f(const SE3fH& T);
-SE3fH se3f_inverse(const SE3fH& T);
-SE3fH se3f_mul(const SE3fH& a, const SE3fH& b);  // Sophus operator*: fastMultiply + normalize
-SE3fH se3f_exp(const float a[6]);                 // Sophus SE3Group<float>::exp
-void quatf_to_rot(const Quatf& q, float R[9]);    // row-major
-void quatd_to_rot(const Quatd& q, double R[9]);
-Sim3dH sim3_inverse(const Sim3dH& S);
-void ldlt6_solve(const float A[36], const float b[6], float x[6]);  // pivoted LDL^T like Eigen's A.ldlt().solve(b)
-void inverse3_eigen(const float K[9], float Kinv[9]);              // Eigen compute_inverse<3>
-}  // namespace lsdm
+#include "pose_math.hpp"  // lsdm:: pose algebra (host + device)
 
 // ---- device-visible parameter blocks --------------------------------------------------------------------
 struct LevelIntr { float fx, fy, cx, cy, fxi, fyi, cxi, cyi; };
@@ -61,31 +40,67 @@ enum {
   RS_B0 = RS_A0 + 21,  // 6 entries of J r w
   RS_ERR = RS_B0 + 6,  // sum w r^2 (LGS error)
   RS_NREF,         // number of valid reference points (numData[level])
-  RS_END
+  RS_END,
+  RS_TOP0 = RS_END // 3 slots (int bits): the workgroup's largest reference-order keys among in-image points
 };
+static_assert(RS_TOP0 + 3 <= RS_NUM, "record too small");
 static_assert(RS_END <= RS_NUM, "record too small");
 
-struct ResidualArgs {
-  // keyframe (reference) planes at this level
-  const float* kf_idepth;
+// One pyramid level of a tracking job, as the residual kernel sees it.
+struct TrackLevel {
+  const float* kf_idepth;    // keyframe (reference) planes at this level
   const float* kf_idepthVar;
   const float* kf_image;
-  // tracked frame texels (gx, gy, I, 0) at this level
-  const float4* fr_grad;
-  uint8_t* wasGood;      // level-1 mask or nullptr
-  // explicit point list instead of keyframe planes (permaref path); npts < 0 => dense keyframe grid
-  const float* pts_pos;     // 3 floats per point
-  const float* pts_colvar;  // 2 floats per point
+  const float4* fr_grad;     // tracked-frame texels (gx, gy, I, 0)
+  const float* pts_pos;      // explicit point list (permaref path) instead of keyframe planes; npts < 0 => dense grid
+  const float* pts_colvar;
   int npts;
   int w, h;
+  int nblocks;               // workgroups that have work at this level
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
-  float R[9];
-  float t[3];
-  float aff_a, aff_b;
+  float lambdaInitial, stepSizeMin, convergenceEps;
+  int maxIts;
+  float minWarped;           // MIN_GOODPERALL_PIXEL_ABSMIN * (width>>lvl) * (height>>lvl)
+  int writeMask;             // level == SE3TRACKING_MIN_LEVEL: write frame->refPixelWasGood
+};
+
+// Everything one trackFrame call needs, resident in HBM (uploaded once per call).
+struct TrackJob {
+  TrackLevel lv[LSD_LEVELS];
+  uint8_t* wasGood;
   float cameraPixelNoise2, var_weight, huber_half;
-  float* partials;       // [gridDim.x][RS_NUM]
-  float* out_record;     // RS_NUM floats, host-visible
-  int nblocks;
+  float lambdaSuccessFac, lambdaFailFac;
+  int useAffine;
+  int lastLevel;             // the LM loop runs levels state.level .. lastLevel
+  int evalOnly;              // 1: a step only finalises the sums of one evaluation (kernel-level parity hook / host LM)
+  int trackFrameSemantics;   // lastResidual bookkeeping of trackFrame (1) vs trackFrameOnPermaref (0)
+};
+
+// Levenberg-Marquardt state of a tracking job, resident in HBM, advanced by k_lm_step.
+struct TrackState {
+  lsdm::SE3fH T;             // last accepted referenceToFrame
+  lsdm::SE3fH Tn;            // pose being evaluated
+  float R[9], t[3];          // rotation matrix / translation of Tn (what the residual kernel reads)
+  float aff_a, aff_b, aff_a_lastIt, aff_b_lastIt;
+  float lastErr, LM_lambda, last_residual;
+  int level, iteration, incTry, phase;   // phase 0: first evaluation of a level, 1: trial evaluation
+  int pending;               // partial sums of an evaluation are waiting for their LM step
+  float A[36], b[6];         // normal equations of the last accepted evaluation (LGS6 after finish())
+  float inc[6];              // increment of the trial under evaluation
+  double bytes;              // algorithmic bytes moved by the evaluations so far (bench.py roofline leg)
+  int done, diverged;
+  int numEvaluations, numWarpUpdates;
+  float pointUsage, goodCount, badCount, meanRes;
+};
+
+// What the host reads back (pinned, device-mapped): written by k_lm_step when the job finishes (or every step in
+// evalOnly mode).
+struct TrackSummary {
+  int done, diverged, level, numEvaluations, numWarpUpdates, pad_[3];
+  float q[4], t[3];
+  float lastResidual, pointUsage, goodCount, badCount, meanRes, aff_a, aff_b, aff_a_lastIt, aff_b_lastIt;
+  float sums[RS_NUM];        // raw sums of the last evaluation (tail-drop corrected)
+  double bytes;              // algorithmic bytes of all evaluations of the job
 };
 
 struct lsdhip_ctx {
@@ -101,6 +116,11 @@ struct lsdhip_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   double prof_ms = 0, prof_bytes = 0;
   long long prof_launches = 0;
+  std::vector<hipEvent_t> prof_events;   // per-launch event pairs for the device-resident LM loop
+  // recycled frame arenas (the FrameMemory idea, C/DataStructures/FrameMemory.cpp:67-127, for device buffers);
+  // reuse is stream-ordered, so no synchronisation is needed when a frame dies
+  std::vector<void*> free_arenas;
+  size_t arena_bytes = 0;
 };
 
 struct lsdhip_frame {
@@ -145,12 +165,17 @@ struct lsdhip_tracker {
   float affineEstimation_a = 1, affineEstimation_b = 0, affineEstimation_a_lastIt = 1, affineEstimation_b_lastIt = 0;
   bool diverged = false, trackingWasGood = false;
   int numEvaluations = 0, numWarpUpdates = 0;
+  bool hostLM = false;            // debugging: run the LM control loop on the host, one evaluation per round trip
   // device scratch
-  float* d_partials = nullptr;   // [max_blocks][RS_NUM]
+  float* d_partials = nullptr;    // [max_blocks][RS_NUM]
   int max_blocks = 0;
-  float* h_record = nullptr;     // pinned, device-mapped: final RS_NUM sums
-  float* d_record = nullptr;     // device alias of h_record
-  float* d_pts = nullptr;        // permaref point upload
+  TrackJob* d_job = nullptr;
+  TrackState* d_state = nullptr;
+  TrackJob* h_job = nullptr;      // pinned staging
+  TrackState* h_state = nullptr;  // pinned staging
+  TrackSummary* h_summary = nullptr;  // pinned, device-mapped
+  TrackSummary* d_summary = nullptr;  // device alias of h_summary
+  float* d_pts = nullptr;         // permaref point upload
   int pts_capacity = 0;
 };
 

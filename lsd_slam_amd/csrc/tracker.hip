@@ -1,30 +1,56 @@
-// SE3Tracker on the device: one fused "residual kernel" per evaluation (K0 point generation + K1 warp/sample/mask +
-// K2 weights + K3 normal equations) followed by a one-workgroup finalize kernel; the Levenberg-Marquardt control loop
-// stays on the host exactly as in the reference.  gfx950 only.
+// SE3Tracker on the device.  gfx950 only.
+//
+// One evaluation = two launches on the context's stream:
+//   k_residual   fused K0 (point generation from the keyframe planes) + K1 (warp / bilinear sample / mask) + K2 (weights)
+//                + K3 (normal equations); 41 sums reduced wave (DPP) -> workgroup (LDS) -> partials[workgroup]
+//   k_lm_step    one workgroup: fixed-order sum of the partials, SSE tail-drop correction, and the Levenberg-Marquardt
+//                decision of SE3Tracker::trackFrame (accept / reject, lambda schedule, 6x6 LDL^T solve, SE3 exp,
+//                level change) — the pose never leaves HBM between evaluations.
+// The host enqueues a budget of (k_residual, k_lm_step) pairs back to back and synchronises once; pairs launched after
+// the job has finished return immediately.  A host-driven LM loop (one evaluation per round trip) is kept behind
+// lsdhip_tracker.hostLM for debugging and as the kernel-level parity hook (lsdhip_tracker_evaluate).
 //
 // Reference behaviour restated:
-//   TrackingReference::makePointCloud   C/Tracking/TrackingReference.cpp:128-138  (points generated on the fly from
-//                                        the keyframe's idepth / idepthVar / image planes, no compacted arrays)
+//   TrackingReference::makePointCloud   C/Tracking/TrackingReference.cpp:128-138
 //   SE3Tracker::calcResidualAndBuffers  C/Tracking/SE3Tracker.cpp:885-1029
 //   SE3Tracker::calcWeightsAndResidualSSE  :492-575   (op order of the SSE path; _mm_rcp_ps -> IEEE 1/x)
-//   SE3Tracker::calculateWarpUpdateSSE  :1033-1130 + LGS6::updateSSE C/Tracking/LGSX.h:328-386
-//   SE3Tracker::trackFrame              :280-486      (host)
+//   SE3Tracker::calculateWarpUpdateSSE  :1033-1130 + LGS6::updateSSE / finish  C/Tracking/LGSX.h:205-386
+//   SE3Tracker::trackFrame              :280-486
 //   SE3Tracker::trackFrameOnPermaref    :162-272, checkPermaRefOverlap :121-157
 //
 // Quirks kept on purpose: the SSE loops ignore the last size%4 in-image points (in the reference's
-// x-outer point order) for K2/K3 — emulated by the finalize kernel; LGS6::updateSSE counts 6 constraints per group of 4.
+// x-outer point order) for K2/K3 — emulated in k_lm_step; LGS6::updateSSE counts 6 constraints per group of 4;
+// `LM_lambda <= 0.2` compares a float with a double.
 //
 // Data layout: keyframe planes idepth/idepthVar/image (3 x 4 B per pixel, row-major, coalesced per wave), tracked-frame
 // texels float4 (gx, gy, I, 0) so that one bilinear tap is one 16-byte load.  Algorithmic bytes per evaluation at level l
 // (SURVEY.md §8(d)): 20 N_l + [l==1] 5 N_l + 12 min(w_l h_l, 4 N_l).
 #include "lsdhip_internal.hpp"
 
-#define RES_BLOCK 256
+#define RES_BLOCK 1024
+#define RES_PPT 2                       // reference pixels per lane
+#define RES_TILE (RES_BLOCK * RES_PPT)  // pixels per workgroup
 
 // ---- wave64 sum via DPP (row_shr 1,2,3 / 4 / 8, row_bcast 15 / 31); result valid in lane 63 ----------------------
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+__device__ __forceinline__ int dpp_max_i(int a, int b) { return a > b ? a : b; }
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_i(int v) {   // masked-off / out-of-row lanes read INT_MIN-like identity (-1)
+  return __builtin_amdgcn_update_dpp(-1, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// wave64 max of non-negative keys (identity -1); result valid in lane 63
+__device__ __forceinline__ int wave_max_to_lane63(int v) {
+  int t = dpp_max_i(v, dpp_i<0x111, 0xf, 0xf>(v));
+  t = dpp_max_i(t, dpp_i<0x112, 0xf, 0xf>(v));
+  t = dpp_max_i(t, dpp_i<0x113, 0xf, 0xf>(v));
+  t = dpp_max_i(t, dpp_i<0x114, 0xf, 0xe>(t));
+  t = dpp_max_i(t, dpp_i<0x118, 0xf, 0xc>(t));
+  t = dpp_max_i(t, dpp_i<0x142, 0xa, 0xf>(t));
+  t = dpp_max_i(t, dpp_i<0x143, 0xc, 0xf>(t));
+  return t;
 }
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   float t = v + dpp_f<0x111, 0xf, 0xf>(v);  // row_shr:1
@@ -37,7 +63,62 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return t;
 }
 
+// Workgroup-wide top-3 of non-negative unique integer keys.  Every lane contributes up to three candidates sorted
+// descending (c0 >= c1 >= c2, -1 = none).  Result in s_out[0..2] (descending, -1 = none) after the final barrier.
+__device__ __forceinline__ void block_top3(int c0, int c1, int c2, int (*s_wave)[3], int* s_out) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    int m = __builtin_amdgcn_readlane(wave_max_to_lane63(c0), 63);
+    if (lane == 0) s_wave[wave][r] = m;
+    if (c0 == m && m >= 0) { c0 = c1; c1 = c2; c2 = -1; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int nw = blockDim.x >> 6;
+    int v = (lane < nw * 3) ? s_wave[lane / 3][lane % 3] : -1;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      int m = __builtin_amdgcn_readlane(wave_max_to_lane63(v), 63);
+      if (lane == 0) s_out[r] = m;
+      if (v == m) v = -1;
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void top3_insert(int k, int& c0, int& c1, int& c2) {
+  if (k > c0) { c2 = c1; c1 = c0; c0 = k; }
+  else if (k > c1) { c2 = c1; c1 = k; }
+  else if (k > c2) { c2 = k; }
+}
+
 // ---- per-point arithmetic -----------------------------------------------------------------------------------------
+struct EvalCtx {            // one level of a job + the pose under evaluation, in registers / SGPRs
+  const float* kf_idepth;
+  const float* kf_idepthVar;
+  const float* kf_image;
+  const float4* fr_grad;
+  const float* pts_pos;
+  const float* pts_colvar;
+  int npts, w, h;
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+  float R[9], t[3];
+  float aff_a, aff_b;
+  float cameraPixelNoise2, var_weight, huber_half;
+};
+__device__ __forceinline__ void make_ctx(const TrackJob& job, const TrackState& st, int level, EvalCtx& a) {
+  const TrackLevel& L = job.lv[level];
+  a.kf_idepth = L.kf_idepth; a.kf_idepthVar = L.kf_idepthVar; a.kf_image = L.kf_image; a.fr_grad = L.fr_grad;
+  a.pts_pos = L.pts_pos; a.pts_colvar = L.pts_colvar; a.npts = L.npts; a.w = L.w; a.h = L.h;
+  a.fx = L.fx; a.fy = L.fy; a.cx = L.cx; a.cy = L.cy; a.fxi = L.fxi; a.fyi = L.fyi; a.cxi = L.cxi; a.cyi = L.cyi;
+#pragma unroll
+  for (int i = 0; i < 9; i++) a.R[i] = st.R[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) a.t[i] = st.t[i];
+  a.aff_a = st.aff_a; a.aff_b = st.aff_b;
+  a.cameraPixelNoise2 = job.cameraPixelNoise2; a.var_weight = job.var_weight; a.huber_half = job.huber_half;
+}
+
 struct PointOut {
   bool in_image;
   bool good;
@@ -49,7 +130,7 @@ struct PointOut {
 };
 
 // (px,py,pz) = reference point, I_ref / var = its colour and inverse-depth variance.
-__device__ __forceinline__ void eval_point(const ResidualArgs& a, float px, float py, float pz, float I_ref, float var, PointOut& o) {
+__device__ __forceinline__ void eval_point(const EvalCtx& a, float px, float py, float pz, float I_ref, float var, PointOut& o) {
   // Wxp = rotMat * p + transVec (Eigen coefficient product: ((r0*x + r1*y) + r2*z), then + t)
   float Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
   float Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
@@ -112,7 +193,7 @@ __device__ __forceinline__ void eval_point(const ResidualArgs& a, float px, floa
 }
 
 // fetch the reference point `i` (dense index into the keyframe level, or index into the explicit list)
-__device__ __forceinline__ bool fetch_point(const ResidualArgs& a, int i, float& px, float& py, float& pz, float& I_ref,
+__device__ __forceinline__ bool fetch_point(const EvalCtx& a, int i, float& px, float& py, float& pz, float& I_ref,
                                             float& var, int& maskIdx) {
   if (a.npts >= 0) {
     if (i >= a.npts) return false;
@@ -136,153 +217,434 @@ __device__ __forceinline__ bool fetch_point(const ResidualArgs& a, int i, float&
   return true;
 }
 
-// Residual kernel: one reference pixel per lane; 44 sums reduced wave -> workgroup -> partials[block].
-__global__ __launch_bounds__(RES_BLOCK) void k_residual(ResidualArgs a) {
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * RES_BLOCK + tid;
-  float acc[RS_NUM];
-#pragma unroll
-  for (int k = 0; k < RS_NUM; k++) acc[k] = 0.f;
+// ---- Levenberg-Marquardt step (runs on a copy of the state in LDS) -------------------------------------------------
+__device__ void set_eval_pose(TrackState& s, const lsdm::SE3fH& T) {
+  s.Tn = T;
+  lsdm::quatf_to_rot(T.q, s.R);
+  s.t[0] = T.t[0]; s.t[1] = T.t[1]; s.t[2] = T.t[2];
+}
+__device__ void write_summary(const TrackState& s, const float* tot, TrackSummary* out) {
+  out->diverged = s.diverged; out->level = s.level; out->numEvaluations = s.numEvaluations; out->numWarpUpdates = s.numWarpUpdates;
+  out->q[0] = s.T.q.w; out->q[1] = s.T.q.x; out->q[2] = s.T.q.y; out->q[3] = s.T.q.z;
+  out->t[0] = s.T.t[0]; out->t[1] = s.T.t[1]; out->t[2] = s.T.t[2];
+  out->lastResidual = s.last_residual; out->pointUsage = s.pointUsage; out->goodCount = s.goodCount; out->badCount = s.badCount;
+  out->meanRes = s.meanRes; out->aff_a = s.aff_a; out->aff_b = s.aff_b; out->aff_a_lastIt = s.aff_a_lastIt; out->aff_b_lastIt = s.aff_b_lastIt;
+  for (int i = 0; i < RS_NUM; i++) out->sums[i] = tot[i];
+  out->bytes = s.bytes;
+  __threadfence_system();
+  out->done = s.done;
+}
 
-  float px, py, pz, I_ref, var;
-  int maskIdx;
-  if (fetch_point(a, i, px, py, pz, I_ref, var, maskIdx)) {
-    acc[RS_NREF] = 1.f;
-    PointOut o;
-    eval_point(a, px, py, pz, I_ref, var, o);
-    if (!o.in_image) {
-      if (a.wasGood && maskIdx >= 0) a.wasGood[maskIdx] = 0;
-    } else {
-      if (a.wasGood && maskIdx >= 0) a.wasGood[maskIdx] = o.good ? 1 : 0;
-      acc[RS_M] = 1.f;
-      acc[RS_SXX] = o.c1 * o.c1 * o.hw;
-      acc[RS_SYY] = o.c2 * o.c2 * o.hw;
-      acc[RS_SX] = o.c1 * o.hw;
-      acc[RS_SY] = o.c2 * o.hw;
-      acc[RS_SW] = o.hw;
-      if (o.good) { acc[RS_GOOD] = 1.f; acc[RS_SUMRES2] = o.res * o.res; acc[RS_SUMSIGNED] = o.res; }
-      else acc[RS_BAD] = 1.f;
-      acc[RS_USAGE] = o.usage;
-      acc[RS_WERR] = o.werr;
-      int k = RS_A0;
+// 6x6 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics), fully unrolled: every index is a compile-time
+// constant and the pivot swaps are conditional register exchanges, so nothing spills to scratch or LDS.
+__device__ __forceinline__ void cswap(bool c, float& a, float& b) { float t = a; a = c ? b : a; b = c ? t : b; }
+__device__ void ldlt6_solve_reg(const float* Ain, const float* bin, float* x) {
+  float M[6][6];
+  int p[6];
 #pragma unroll
-      for (int r = 0; r < 6; r++) {
-        float Jw = o.J[r] * o.w;
+  for (int i = 0; i < 6; i++) {
+    p[i] = i;
 #pragma unroll
-        for (int c = r; c < 6; c++) acc[k++] = Jw * o.J[c];
-      }
-      float resw = o.res * o.w;
+    for (int j = 0; j < 6; j++) M[i][j] = Ain[i * 6 + j];
+  }
 #pragma unroll
-      for (int r = 0; r < 6; r++) acc[RS_B0 + r] = resw * o.J[r];
-      acc[RS_ERR] = resw * o.res;
+  for (int k = 0; k < 6; k++) {
+    int piv = k;
+    float big = fabsf(M[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) { float v = fabsf(M[i][i]); if (v > big) { big = v; piv = i; } }
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const bool c = (piv == i);
+#pragma unroll
+      for (int j = 0; j < 6; j++) cswap(c, M[k][j], M[i][j]);
+#pragma unroll
+      for (int r = 0; r < 6; r++) cswap(c, M[r][k], M[r][i]);
+      int tp = p[k]; p[k] = c ? p[i] : p[k]; p[i] = c ? tp : p[i];
+    }
+    float d = M[k][k];
+#pragma unroll
+    for (int j = 0; j < k; j++) d -= M[k][j] * M[k][j] * M[j][j];
+    M[k][k] = d;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      float v = M[i][k];
+#pragma unroll
+      for (int j = 0; j < k; j++) v -= M[i][j] * M[k][j] * M[j][j];
+      M[i][k] = d != 0.0f ? v / d : 0.0f;
     }
   }
-
-  __shared__ float s_part[RES_BLOCK / 64][RS_NUM];
-  const int wave = tid >> 6, lane = tid & 63;
+  float y[6];
 #pragma unroll
-  for (int k = 0; k < RS_END; k++) {
-    float s = wave_sum_to_lane63(acc[k]);
-    if (lane == 63) s_part[wave][k] = s;
+  for (int i = 0; i < 6; i++) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) v = (p[i] == j) ? bin[j] : v;
+    y[i] = v;
   }
-  __syncthreads();
-  if (tid < RS_NUM) {
-    float s = 0.f;
-    if (tid < RS_END) {
-      s = s_part[0][tid];
 #pragma unroll
-      for (int wv = 1; wv < RES_BLOCK / 64; wv++) s += s_part[wv][tid];
-    }
-    a.partials[(size_t)blockIdx.x * RS_NUM + tid] = s;
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < i; j++) y[i] -= M[i][j] * y[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = M[i][i] != 0.0f ? y[i] / M[i][i] : 0.0f;
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) y[i] -= M[j][i] * y[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) v = (p[i] == j) ? y[i] : v;
+    x[j] = v;
   }
 }
 
-// Finalize: fixed-order sum of the per-workgroup partials, then the SSE tail drop: the last (M % 4) in-image points
-// in the reference's point order (x outer, y inner over the keyframe level; or list order) are removed from the K2/K3 sums.
-__global__ __launch_bounds__(256) void k_residual_finalize(ResidualArgs a) {
-  __shared__ float s_sum[4][64];
+struct LmScratch { float M[36]; float bneg[6]; };
+
+// The control flow of SE3Tracker::trackFrame between two evaluations (SE3Tracker.cpp:324-447), run by one lane of every
+// workgroup on identical inputs (so every workgroup reaches the same decision without talking to the others).
+// `out` is non-null in workgroup 0 only.
+__device__ void lm_advance(const TrackJob& job, TrackState& s, const float* tot, LmScratch& ws, TrackSummary* out) {
+  const TrackLevel& L = job.lv[s.level];
+  // calcResidualAndBuffers epilogue (:1016-1028)
+  const int M = (int)tot[RS_M];
+  const float refNum = tot[RS_NREF];
+  const float goodCount = tot[RS_GOOD], badCount = tot[RS_BAD];
+  s.pointUsage = tot[RS_USAGE] / refNum;
+  s.goodCount = goodCount;
+  s.badCount = badCount;
+  s.meanRes = tot[RS_SUMSIGNED] / goodCount;
+  {
+    const float sxx = tot[RS_SXX], syy = tot[RS_SYY], sx = tot[RS_SX], sy = tot[RS_SY], sw = tot[RS_SW];
+    s.aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
+    s.aff_b_lastIt = (sy - s.aff_a_lastIt * sx) / sw;
+  }
+  s.numEvaluations++;
+  {
+    // algorithmic bytes of this evaluation: 20 N + [mask] 5 N + 12 min(w h, 4 N)
+    double N = refNum, wh = (double)L.w * L.h;
+    double texels = 4.0 * N < wh ? 4.0 * N : wh;
+    s.bytes += 20.0 * N + (L.writeMask ? 5.0 * N : 0.0) + 12.0 * texels;
+  }
+  if (job.evalOnly) { s.done = 1; if (out) write_summary(s, tot, out); return; }
+
+  if (M < L.minWarped) {   // :324-329 / :369-374
+    s.diverged = 1; s.done = 1;
+    if (out) write_summary(s, tot, out);
+    return;
+  }
+  // calcWeightsAndResidualSSE epilogue (:572-574) and LGS6::finish with the SSE constraint count (LGSX.h:319-325, :385)
+  const float werr = tot[RS_WERR] / ((M >> 2) << 2);
+  const float n = (float)((size_t)6 * (size_t)(M >> 2));
+
+  bool propose = false, start_iteration = false, accepted = false;
+  if (s.phase == 0) {
+    accepted = true;
+    if (job.useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
+    s.lastErr = werr;
+    s.LM_lambda = L.lambdaInitial;
+    s.iteration = 0;
+    start_iteration = true;
+  } else {
+    const float error = werr;
+    if (error < s.lastErr) {
+      accepted = true;
+      s.T = s.Tn;
+      if (job.useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
+      if (error / s.lastErr > L.convergenceEps) s.iteration = L.maxIts;
+      s.lastErr = error;
+      if (job.trackFrameSemantics) s.last_residual = error;
+      if (s.LM_lambda <= 0.2) s.LM_lambda = 0;
+      else s.LM_lambda *= job.lambdaSuccessFac;
+      s.iteration++;
+      start_iteration = true;
+    } else {
+      const float* inc = s.inc;
+      float incdot = (inc[0] * inc[0] + (inc[1] * inc[1] + inc[2] * inc[2])) + (inc[3] * inc[3] + (inc[4] * inc[4] + inc[5] * inc[5]));
+      if (!(incdot > L.stepSizeMin)) {
+        s.iteration = L.maxIts;
+        s.iteration++;
+        start_iteration = true;
+      } else {
+        if (s.LM_lambda == 0) s.LM_lambda = 0.2;
+        else {
+          double p = 1.0;
+          for (int i = 0; i < s.incTry; i++) p *= (double)job.lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
+          s.LM_lambda = (float)((double)s.LM_lambda * p);
+        }
+        propose = true;
+      }
+    }
+  }
+  if (start_iteration) {
+    if (accepted) {
+      // the accepted (or first) evaluation's normal equations are what calculateWarpUpdate would build next
+      int k = RS_A0;
+      for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++, k++) {
+          float v = (0.0f + tot[k]) / n;
+          s.A[i * 6 + j] = v;
+          s.A[j * 6 + i] = v;
+        }
+      for (int i = 0; i < 6; i++) s.b[i] = (0.0f - tot[RS_B0 + i]) / n;
+    }
+    if (s.iteration < L.maxIts) { s.numWarpUpdates++; s.incTry = 0; propose = true; }
+  }
+  if (propose) {
+    for (int i = 0; i < 36; i++) ws.M[i] = s.A[i];
+    for (int i = 0; i < 6; i++) { ws.bneg[i] = -s.b[i]; ws.M[i * 6 + i] *= 1 + s.LM_lambda; }
+    float inc[6];
+    ldlt6_solve_reg(ws.M, ws.bneg, inc);
+    s.incTry++;
+    for (int i = 0; i < 6; i++) s.inc[i] = inc[i];
+    set_eval_pose(s, lsdm::se3f_mul(lsdm::se3f_exp(inc), s.T));
+    s.phase = 1;
+    return;
+  }
+  // level finished
+  if (!job.trackFrameSemantics) s.last_residual = s.lastErr;   // trackFrameOnPermaref: lastResidual = lastErr (:265)
+  if (s.level == job.lastLevel) {
+    s.done = 1;
+    if (out) write_summary(s, tot, out);
+  } else {
+    s.level--;
+    s.phase = 0;
+    set_eval_pose(s, s.T);
+  }
+}
+
+// only the in-image test of calcResidualAndBuffers (no sampling): used by the tail-drop walk
+__device__ __forceinline__ bool point_in_image(const EvalCtx& a, float px, float py, float pz) {
+  float Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
+  float Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
+  float Wz = ((a.R[6] * px + a.R[7] * py) + a.R[8] * pz) + a.t[2];
+  float u_new = (Wx / Wz) * a.fx + a.cx;
+  float v_new = (Wy / Wz) * a.fy + a.cy;
+  return (u_new > 1 && v_new > 1 && u_new < a.w - 2 && v_new < a.h - 2);
+}
+
+// Fused tracking step, one launch per evaluation:
+//   (1) every workgroup re-derives the LM decision for the *previous* evaluation from its partial sums (fixed-order
+//       sum, SSE tail drop, lm_advance) — identical inputs, identical code, hence identical state in every workgroup
+//       without any inter-workgroup communication inside the launch;
+//   (2) the residual evaluation (K0+K1+K2+K3) of the pose that decision produced, RES_PPT reference pixels per lane,
+//       41 sums reduced wave (DPP) -> workgroup (LDS) -> partials[workgroup].
+// State and partials are double-buffered by launch parity: a launch reads [parity] and writes [1 - parity].
+__global__ __launch_bounds__(RES_BLOCK) void k_track_step(TrackJob job, TrackState* __restrict__ st2, float* __restrict__ partials2,
+                                                           int max_blocks, TrackSummary* __restrict__ out, int parity) {
+  __shared__ TrackState S;
+  __shared__ LmScratch ws;
+  __shared__ float s_sum[RES_BLOCK / 64][64];
   __shared__ float s_tot[RS_NUM];
-  __shared__ int s_flag[256];
+  __shared__ int s_wtop[RES_BLOCK / 64][3];
+  __shared__ int s_top[3];
   __shared__ int s_chosen[4];
   __shared__ int s_nchosen;
   __shared__ float s_sub[3][32];
   const int tid = threadIdx.x;
-  const int col = tid & 63, slice = tid >> 6;
-  float s = 0.f;
-  if (col < RS_NUM)
-    for (int b = slice; b < a.nblocks; b += 4) s += a.partials[(size_t)b * RS_NUM + col];
-  s_sum[slice][col] = s;
+  const TrackState* in = st2 + parity;
+  TrackState* next = st2 + (1 - parity);
+  const float* partials_in = partials2 + (size_t)parity * max_blocks * RS_NUM;
+  float* partials_out = partials2 + (size_t)(1 - parity) * max_blocks * RS_NUM;
+  {
+    const unsigned* src = (const unsigned*)in;
+    unsigned* dst = (unsigned*)&S;
+    for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
+  }
   __syncthreads();
-  if (tid < RS_NUM) s_tot[tid] = ((s_sum[0][tid] + s_sum[1][tid]) + s_sum[2][tid]) + s_sum[3][tid];
-  if (tid == 0) s_nchosen = 0;
-  __syncthreads();
+  if (S.done) {
+    if (blockIdx.x == 0) {   // keep both state buffers "done" so that later launches of the budget return at once
+      unsigned* dst = (unsigned*)next;
+      const unsigned* src = (const unsigned*)&S;
+      for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
+    }
+    return;
+  }
 
-  const int M = (int)s_tot[RS_M];
-  const int need = M & 3;
-  if (need > 0) {
-    // reverse walk in reference order, 256 candidates per round
-    const int total = (a.npts >= 0) ? a.npts : (a.w - 2) * (a.h - 2);
-    for (int base = 0; base < total; base += 256) {
-      int r = base + tid;  // r-th point from the end
-      int flag = 0, pidx = -1;
-      if (r < total) {
-        if (a.npts >= 0) pidx = a.npts - 1 - r;
-        else {
-          int q = total - 1 - r;           // forward position in x-outer / y-inner order over the interior
-          int x = 1 + q / (a.h - 2), y = 1 + q % (a.h - 2);
-          pidx = x + y * a.w;
+  if (S.pending) {
+    const int level = S.level;
+    const int nblocks = job.lv[level].nblocks;
+    const int col = tid & 63, slice = tid >> 6;
+    {
+      float s = 0.f;
+      if (col < RS_END)
+        for (int b = slice; b < nblocks; b += RES_BLOCK / 64) s += partials_in[(size_t)b * RS_NUM + col];
+      s_sum[slice][col] = s;
+    }
+    __syncthreads();
+    if (tid < RS_NUM) {
+      float s = s_sum[0][tid];
+#pragma unroll
+      for (int k = 1; k < RES_BLOCK / 64; k++) s += s_sum[k][tid];
+      s_tot[tid] = s;
+    }
+    if (tid == 0) s_nchosen = 0;
+    __syncthreads();
+
+    const int M = (int)s_tot[RS_M];
+    const int need = M & 3;
+    if (need > 0) {
+      EvalCtx a;
+      make_ctx(job, S, level, a);
+      // the last (M % 4) in-image points in reference order = the largest keys (x * h + y, or list index) over all
+      // workgroups' top-3 lists left behind by the residual pass
+      int c0 = -1, c1 = -1, c2 = -1;
+      for (int e = tid; e < nblocks * 3; e += RES_BLOCK)
+        top3_insert(__float_as_int(partials_in[(size_t)(e / 3) * RS_NUM + RS_TOP0 + (e % 3)]), c0, c1, c2);
+      block_top3(c0, c1, c2, s_wtop, s_top);
+      if (tid == 0) {
+        int nsel = 0;
+        for (int k = 0; k < need; k++) {
+          int key = s_top[k];
+          if (key < 0) break;
+          s_chosen[nsel++] = (a.npts >= 0) ? key : ((key / a.h) + (key % a.h) * a.w);
         }
+        s_nchosen = nsel;
+      }
+      __syncthreads();
+      if (tid < s_nchosen) {
         float px, py, pz, I_ref, var;
         int maskIdx;
-        if (fetch_point(a, pidx, px, py, pz, I_ref, var, maskIdx)) {
-          PointOut o;
-          eval_point(a, px, py, pz, I_ref, var, o);
-          flag = o.in_image ? 1 : 0;
+        fetch_point(a, s_chosen[tid], px, py, pz, I_ref, var, maskIdx);
+        PointOut o;
+        eval_point(a, px, py, pz, I_ref, var, o);
+        float* sub = s_sub[tid];
+        sub[0] = o.werr;
+        int k = 1;
+        for (int r = 0; r < 6; r++) {
+          float Jw = o.J[r] * o.w;
+          for (int c = r; c < 6; c++) sub[k++] = Jw * o.J[c];
         }
-      }
-      s_flag[tid] = flag ? pidx + 1 : 0;
-      __syncthreads();
-      if (tid == 0) {
-        int n = s_nchosen;
-        for (int k = 0; k < 256 && n < need; k++)
-          if (s_flag[k]) s_chosen[n++] = s_flag[k] - 1;
-        s_nchosen = n;
+        float resw = o.res * o.w;
+        for (int r = 0; r < 6; r++) sub[k++] = resw * o.J[r];
+        sub[k++] = resw * o.res;
       }
       __syncthreads();
-      if (s_nchosen >= need) break;
+      if (tid < 29) {
+        // element 0 -> RS_WERR, 1..21 -> RS_A0.., 22..27 -> RS_B0.., 28 -> RS_ERR
+        int dst = (tid == 0) ? RS_WERR : (tid <= 21 ? RS_A0 + tid - 1 : (tid <= 27 ? RS_B0 + tid - 22 : RS_ERR));
+        float v = s_tot[dst];
+        for (int k = 0; k < s_nchosen; k++) v -= s_sub[k][tid];
+        s_tot[dst] = v;
+      }
+      __syncthreads();
     }
-    if (tid < s_nchosen) {
-      float px, py, pz, I_ref, var;
-      int maskIdx;
-      fetch_point(a, s_chosen[tid], px, py, pz, I_ref, var, maskIdx);
+    if (tid == 0) {
+      lm_advance(job, S, s_tot, ws, blockIdx.x == 0 ? out : nullptr);
+      S.pending = 0;
+    }
+    __syncthreads();
+    if (S.done) {
+      if (blockIdx.x == 0) {
+        unsigned* dst = (unsigned*)next;
+        const unsigned* src = (const unsigned*)&S;
+        for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
+      }
+      return;
+    }
+  }
+
+  // ---- residual evaluation at S.level / S.R, S.t ------------------------------------------------------------------
+  const int level = S.level;
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    if (tid == 0) S.pending = 1;
+    __syncthreads();
+    unsigned* dst = (unsigned*)next;
+    const unsigned* src = (const unsigned*)&S;
+    for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
+  }
+  if ((int)blockIdx.x >= job.lv[level].nblocks) return;
+  EvalCtx a;
+  make_ctx(job, S, level, a);
+  uint8_t* wasGood = job.lv[level].writeMask ? job.wasGood : nullptr;
+  float acc[RS_NUM];
+#pragma unroll
+  for (int k = 0; k < RS_NUM; k++) acc[k] = 0.f;
+  int key0 = -1, key1 = -1, key2 = -1;   // reference-order keys of this lane's in-image points (descending)
+
+#pragma unroll
+  for (int p = 0; p < RES_PPT; p++) {
+    const int i = blockIdx.x * RES_TILE + p * RES_BLOCK + tid;
+    float px, py, pz, I_ref, var;
+    int maskIdx;
+    if (fetch_point(a, i, px, py, pz, I_ref, var, maskIdx)) {
+      acc[RS_NREF] += 1.f;
       PointOut o;
       eval_point(a, px, py, pz, I_ref, var, o);
-      float* sub = s_sub[tid];
-      sub[0] = o.werr;
-      int k = 1;
-      for (int r = 0; r < 6; r++) {
-        float Jw = o.J[r] * o.w;
-        for (int c = r; c < 6; c++) sub[k++] = Jw * o.J[c];
+      if (!o.in_image) {
+        if (wasGood && maskIdx >= 0) wasGood[maskIdx] = 0;
+      } else {
+        if (wasGood && maskIdx >= 0) wasGood[maskIdx] = o.good ? 1 : 0;
+        top3_insert(a.npts >= 0 ? i : (i % a.w) * a.h + (i / a.w), key0, key1, key2);
+        acc[RS_M] += 1.f;
+        acc[RS_SXX] += o.c1 * o.c1 * o.hw;
+        acc[RS_SYY] += o.c2 * o.c2 * o.hw;
+        acc[RS_SX] += o.c1 * o.hw;
+        acc[RS_SY] += o.c2 * o.hw;
+        acc[RS_SW] += o.hw;
+        if (o.good) { acc[RS_GOOD] += 1.f; acc[RS_SUMRES2] += o.res * o.res; acc[RS_SUMSIGNED] += o.res; }
+        else acc[RS_BAD] += 1.f;
+        acc[RS_USAGE] += o.usage;
+        acc[RS_WERR] += o.werr;
+        int k = RS_A0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          float Jw = o.J[r] * o.w;
+#pragma unroll
+          for (int c = r; c < 6; c++) acc[k++] += Jw * o.J[c];
+        }
+        float resw = o.res * o.w;
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[RS_B0 + r] += resw * o.J[r];
+        acc[RS_ERR] += resw * o.res;
       }
-      float resw = o.res * o.w;
-      for (int r = 0; r < 6; r++) sub[k++] = resw * o.J[r];
-      sub[k++] = resw * o.res;
     }
-    __syncthreads();
-    if (tid < 29) {
-      // element 0 -> RS_WERR, 1..21 -> RS_A0.., 22..27 -> RS_B0.., 28 -> RS_ERR
-      int dst = (tid == 0) ? RS_WERR : (tid <= 21 ? RS_A0 + tid - 1 : (tid <= 27 ? RS_B0 + tid - 22 : RS_ERR));
-      float v = s_tot[dst];
-      for (int k = 0; k < s_nchosen; k++) v -= s_sub[k][tid];
-      s_tot[dst] = v;
-    }
-    __syncthreads();
   }
-  if (tid < RS_NUM) a.out_record[tid] = s_tot[tid];
+
+  const int wave = tid >> 6, lane = tid & 63;
+  __syncthreads();   // s_sum is reused as the per-wave staging area
+#pragma unroll
+  for (int k = 0; k < RS_END; k++) {
+    float s = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) s_sum[wave][k] = s;
+  }
+  __syncthreads();
+  if (tid < RS_END) {
+    float s = s_sum[0][tid];
+#pragma unroll
+    for (int wv = 1; wv < RES_BLOCK / 64; wv++) s += s_sum[wv][tid];
+    partials_out[(size_t)blockIdx.x * RS_NUM + tid] = s;
+  }
+  block_top3(key0, key1, key2, s_wtop, s_top);
+  if (tid < 3) partials_out[(size_t)blockIdx.x * RS_NUM + RS_TOP0 + tid] = __int_as_float(s_top[tid]);
+}
+
+// initial state of a job (one lane): pose, level, affine parameters; both state buffers
+__global__ void k_lm_init(TrackState* st2, lsdm::SE3fH T0, int level, float aff_a, float aff_b, TrackSummary* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  TrackState s;
+  s.T = T0;
+  set_eval_pose(s, T0);
+  s.aff_a = aff_a; s.aff_b = aff_b; s.aff_a_lastIt = aff_a; s.aff_b_lastIt = aff_b;
+  s.lastErr = 0; s.LM_lambda = 0; s.last_residual = 0;
+  s.level = level; s.iteration = 0; s.incTry = 0; s.phase = 0; s.pending = 0;
+  for (int i = 0; i < 36; i++) s.A[i] = 0;
+  for (int i = 0; i < 6; i++) { s.b[i] = 0; s.inc[i] = 0; }
+  s.done = 0; s.diverged = 0; s.numEvaluations = 0; s.numWarpUpdates = 0;
+  s.pointUsage = 0; s.goodCount = 0; s.badCount = 0; s.meanRes = 0;
+  s.bytes = 0;
+  st2[0] = s;
+  st2[1] = s;
+  out->done = 0;
 }
 
 // checkPermaRefOverlap (SE3Tracker.cpp:121-157): usage only, explicit point list
-__global__ __launch_bounds__(256) void k_overlap(const float* __restrict__ pos, int n, ResidualArgs a, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_overlap(const float* __restrict__ pos, int n, EvalCtx a, float* __restrict__ out) {
   __shared__ float s_w[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -318,10 +680,14 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
     t->convergenceEps[l] = 0.999f;
     t->maxItsPerLvl[l] = maxIterations[l];
   }
-  t->max_blocks = (c->w * c->h + RES_BLOCK - 1) / RES_BLOCK;
-  HIPCHK(hipMalloc((void**)&t->d_partials, (size_t)t->max_blocks * RS_NUM * sizeof(float)));
-  HIPCHK(hipHostMalloc((void**)&t->h_record, RS_NUM * sizeof(float), hipHostMallocMapped));
-  HIPCHK(hipHostGetDevicePointer((void**)&t->d_record, t->h_record, 0));
+  t->max_blocks = (c->w * c->h + RES_TILE - 1) / RES_TILE;
+  HIPCHK(hipMalloc((void**)&t->d_partials, (size_t)2 * t->max_blocks * RS_NUM * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
+  HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
+  memset(t->h_summary, 0, sizeof(TrackSummary));
+  const char* env = getenv("LSDHIP_HOST_LM");
+  t->hostLM = env && env[0] == '1';
   *out = t;
   return LSDHIP_OK;
 }
@@ -330,13 +696,75 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
   (void)hipFree(t->d_partials);
-  (void)hipHostFree(t->h_record);
+  (void)hipFree(t->d_state);
+  (void)hipHostFree(t->h_summary);
   if (t->d_pts) (void)hipFree(t->d_pts);
   delete t;
 }
 extern "C" int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int its[LSD_LEVELS]) {
   if (!t || !its) return LSDHIP_E_ARG;
   for (int l = 0; l < LSD_LEVELS; l++) t->maxItsPerLvl[l] = its[l];
+  return LSDHIP_OK;
+}
+
+static const float MIN_GOODPERGOODBAD_PIXEL = 0.5f;
+static const float MIN_GOODPERALL_PIXEL = 0.04f;
+static const float MIN_GOODPERALL_PIXEL_ABSMIN = 0.01f;
+
+static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame* kf, lsdhip_frame* frame, const float* pts_pos,
+                       const float* pts_colvar, int npts) {
+  lsdhip_ctx* c = t->ctx;
+  TrackLevel& L = job.lv[level];
+  const LevelIntr& in = c->intr[level];
+  L.w = c->wl[level]; L.h = c->hl[level];
+  L.fx = in.fx; L.fy = in.fy; L.cx = in.cx; L.cy = in.cy; L.fxi = in.fxi; L.fyi = in.fyi; L.cxi = in.cxi; L.cyi = in.cyi;
+  L.fr_grad = frame->d_grad[level];
+  if (npts >= 0) {
+    L.pts_pos = pts_pos; L.pts_colvar = pts_colvar; L.npts = npts;
+    L.kf_idepth = L.kf_idepthVar = L.kf_image = nullptr;
+  } else {
+    L.kf_idepth = kf->d_idepth[level]; L.kf_idepthVar = kf->d_idepthVar[level]; L.kf_image = kf->d_image[level];
+    L.pts_pos = L.pts_colvar = nullptr; L.npts = -1;
+  }
+  int work = npts >= 0 ? npts : L.w * L.h;
+  L.nblocks = (work + RES_TILE - 1) / RES_TILE;
+  if (L.nblocks < 1) L.nblocks = 1;
+  L.lambdaInitial = t->lambdaInitial[level]; L.stepSizeMin = t->stepSizeMin[level]; L.convergenceEps = t->convergenceEps[level];
+  L.maxIts = t->maxItsPerLvl[level];
+  L.minWarped = MIN_GOODPERALL_PIXEL_ABSMIN * (c->w >> level) * (c->h >> level);
+  L.writeMask = 0;
+}
+static void fill_job_common(lsdhip_tracker* t, TrackJob& job) {
+  lsdhip_ctx* c = t->ctx;
+  memset(&job, 0, sizeof(job));
+  job.cameraPixelNoise2 = c->params.cameraPixelNoise2;
+  job.var_weight = t->var_weight;
+  job.huber_half = t->huber_d / 2;
+  job.lambdaSuccessFac = t->lambdaSuccessFac;
+  job.lambdaFailFac = t->lambdaFailFac;
+  job.useAffine = c->params.useAffineLightningEstimation;
+}
+
+// launch `steps` fused k_track_step kernels (alternating parity); grid = the largest level the job can still visit.
+// With profiling on, every launch is bracketed by its own HIP event pair on the context's stream.
+static int launch_steps(lsdhip_tracker* t, const TrackJob& job, int topLevel, int steps, int* parity) {
+  lsdhip_ctx* c = t->ctx;
+  int grid = 1;
+  for (int l = job.lastLevel; l <= topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
+  if (c->prof_on) {
+    while ((int)c->prof_events.size() < 2 * steps) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      c->prof_events.push_back(e);
+    }
+  }
+  for (int i = 0; i < steps; i++) {
+    if (c->prof_on) HIPCHK(hipEventRecord(c->prof_events[2 * i], c->stream));
+    hipLaunchKernelGGL(k_track_step, dim3(grid), dim3(RES_BLOCK), 0, c->stream, job, t->d_state, t->d_partials, t->max_blocks,
+                       t->d_summary, *parity);
+    if (c->prof_on) HIPCHK(hipEventRecord(c->prof_events[2 * i + 1], c->stream));
+    *parity ^= 1;
+  }
   return LSDHIP_OK;
 }
 
@@ -348,74 +776,35 @@ struct EvalOut {       // what one evaluation leaves behind, in the reference's 
   double num_constraints;
 };
 
-// launch residual + finalize for one pose and turn the raw sums into the tracker's members
-static int evaluate_pose(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const float* pts_pos, const float* pts_colvar,
-                         int npts, const lsdm::SE3fH& T, int level, bool writeMask, EvalOut* eo) {
+// one evaluation with a host round trip (evalOnly job): kernel-level parity hook and host-LM debugging path
+static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T, int level, EvalOut* eo) {
   lsdhip_ctx* c = t->ctx;
-  ResidualArgs a;
-  memset(&a, 0, sizeof(a));
-  const LevelIntr& in = c->intr[level];
-  a.w = c->wl[level]; a.h = c->hl[level];
-  a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
-  a.fr_grad = frame->d_grad[level];
-  if (npts >= 0) {
-    a.pts_pos = pts_pos; a.pts_colvar = pts_colvar; a.npts = npts;
-  } else {
-    a.kf_idepth = kf->d_idepth[level]; a.kf_idepthVar = kf->d_idepthVar[level]; a.kf_image = kf->d_image[level];
-    a.npts = -1;
-  }
-  a.wasGood = nullptr;
-  if (writeMask) {
-    int rc = lsd_frame_ensure_wasgood(frame);
-    if (rc) return rc;
-    a.wasGood = frame->d_wasGood;
-  }
-  lsdm::quatf_to_rot(T.q, a.R);
-  a.t[0] = T.t[0]; a.t[1] = T.t[1]; a.t[2] = T.t[2];
-  a.aff_a = t->affineEstimation_a; a.aff_b = t->affineEstimation_b;
-  a.cameraPixelNoise2 = c->params.cameraPixelNoise2;
-  a.var_weight = t->var_weight;
-  a.huber_half = t->huber_d / 2;
-  a.partials = t->d_partials;
-  a.out_record = t->d_record;
-  int work = npts >= 0 ? npts : a.w * a.h;
-  a.nblocks = (work + RES_BLOCK - 1) / RES_BLOCK;
-  if (a.nblocks < 1) a.nblocks = 1;
-  if (a.nblocks > t->max_blocks) { lsd_set_error("residual grid exceeds scratch"); return LSDHIP_E_CAPACITY; }
-
+  job.evalOnly = 1;
+  job.lastLevel = level;
+  hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, t->d_state, T, level, t->affineEstimation_a, t->affineEstimation_b, t->d_summary);
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
-  hipLaunchKernelGGL(k_residual, dim3(a.nblocks), dim3(RES_BLOCK), 0, c->stream, a);
+  hipLaunchKernelGGL(k_track_step, dim3(job.lv[level].nblocks), dim3(RES_BLOCK), 0, c->stream, job, t->d_state, t->d_partials,
+                     t->max_blocks, t->d_summary, 0);   // residual evaluation
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_b, c->stream));
-  hipLaunchKernelGGL(k_residual_finalize, dim3(1), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_track_step, dim3(1), dim3(RES_BLOCK), 0, c->stream, job, t->d_state, t->d_partials, t->max_blocks,
+                     t->d_summary, 1);                  // finalises the sums (evalOnly)
   HIPCHK(hipStreamSynchronize(c->stream));
-  const float* r = t->h_record;
+  const TrackSummary* S = t->h_summary;
+  const float* r = S->sums;
   if (c->prof_on) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
     c->prof_ms += ms;
     c->prof_launches++;
-    double N = r[RS_NREF];
-    double texels = 4.0 * N < (double)a.w * a.h ? 4.0 * N : (double)a.w * a.h;
-    c->prof_bytes += 20.0 * N + (writeMask ? 5.0 * N : 0.0) + 12.0 * texels;
+    c->prof_bytes += S->bytes;
   }
   t->numEvaluations++;
-
-  // calcResidualAndBuffers epilogue (SE3Tracker.cpp:1016-1028)
+  t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;
+  t->affineEstimation_a_lastIt = S->aff_a_lastIt; t->affineEstimation_b_lastIt = S->aff_b_lastIt;
   int M = (int)r[RS_M];
-  float refNum = r[RS_NREF];
-  float goodCount = r[RS_GOOD], badCount = r[RS_BAD];
-  t->pointUsage = r[RS_USAGE] / refNum;
-  t->lastGoodCount = goodCount;
-  t->lastBadCount = badCount;
-  t->lastMeanRes = r[RS_SUMSIGNED] / goodCount;
-  float sxx = r[RS_SXX], syy = r[RS_SYY], sx = r[RS_SX], sy = r[RS_SY], sw = r[RS_SW];
-  t->affineEstimation_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
-  t->affineEstimation_b_lastIt = (sy - t->affineEstimation_a_lastIt * sx) / sw;
   eo->warped_size = M;
-  eo->retval = r[RS_SUMRES2] / goodCount;
-  // calcWeightsAndResidualSSE epilogue (:572-574)
+  eo->retval = r[RS_SUMRES2] / r[RS_GOOD];
   eo->weightedError = r[RS_WERR] / ((M >> 2) << 2);
-  // LGS6::finish with the SSE constraint count (LGSX.h:319-325, :385)
   size_t num_constraints = (size_t)6 * (size_t)(M >> 2);
   float n = (float)num_constraints;
   int k = RS_A0;
@@ -431,41 +820,22 @@ static int evaluate_pose(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* fram
   return LSDHIP_OK;
 }
 
-static void fill_result(lsdhip_tracker* t, const lsdm::SE3dH& T, lsdhip_track_result* out) {
-  lsdm::se3d_to7(T, out->frameToReference);
-  out->pointUsage = t->pointUsage; out->lastGoodCount = t->lastGoodCount; out->lastBadCount = t->lastBadCount;
-  out->lastMeanRes = t->lastMeanRes; out->lastResidual = t->lastResidual;
-  out->affineEstimation_a = t->affineEstimation_a; out->affineEstimation_b = t->affineEstimation_b;
-  out->diverged = t->diverged; out->trackingWasGood = t->trackingWasGood;
-  out->numEvaluations = t->numEvaluations; out->numWarpUpdates = t->numWarpUpdates;
-}
-
-static const float MIN_GOODPERGOODBAD_PIXEL = 0.5f;
-static const float MIN_GOODPERALL_PIXEL = 0.04f;
-static const float MIN_GOODPERALL_PIXEL_ABSMIN = 0.01f;
-
-// The LM loop shared by trackFrame (levels 4..1) and trackFrameOnPermaref (level 4 only).
-// Returns LSDHIP_DIVERGED on divergence.
-static int lm_level(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const float* pts_pos, const float* pts_colvar, int npts,
-                    int lvl, bool writeMask, float lambdaInitial, float stepSizeMin, float convergenceEps, int maxIts,
-                    lsdm::SE3fH& referenceToFrame, float* lastResidualOut, bool trackFrameSemantics) {
+// host-driven LM for one level (debugging path): SE3Tracker.cpp:323-449
+static int lm_level_host(lsdhip_tracker* t, TrackJob& job, int lvl, lsdm::SE3fH& referenceToFrame, float* lastResidualOut) {
   lsdhip_ctx* c = t->ctx;
+  const TrackLevel& L = job.lv[lvl];
   EvalOut ev;
-  int rc = evaluate_pose(t, kf, frame, pts_pos, pts_colvar, npts, referenceToFrame, lvl, writeMask, &ev);
+  int rc = evaluate_pose(t, job, referenceToFrame, lvl, &ev);
   if (rc) return rc;
-  if (ev.warped_size < MIN_GOODPERALL_PIXEL_ABSMIN * (c->w >> lvl) * (c->h >> lvl)) return LSDHIP_DIVERGED;
+  if (ev.warped_size < L.minWarped) return LSDHIP_DIVERGED;
   if (c->params.useAffineLightningEstimation) {
     t->affineEstimation_a = t->affineEstimation_a_lastIt;
     t->affineEstimation_b = t->affineEstimation_b_lastIt;
   }
-  // NOTE: in the reference the first weights/LGS of a level are computed on residuals that used the *previous*
-  // affine parameters (buffers are not recomputed after the assignment above); the fused record `ev` has exactly
-  // those semantics because K2/K3 ran inside the same evaluation.
   float lastErr = ev.weightedError;
-  float LM_lambda = lambdaInitial;
-  EvalOut cur = ev;  // buffers of the last *accepted* pose feed calculateWarpUpdate
-
-  for (int iteration = 0; iteration < maxIts; iteration++) {
+  float LM_lambda = L.lambdaInitial;
+  EvalOut cur = ev;
+  for (int iteration = 0; iteration < L.maxIts; iteration++) {
     t->numWarpUpdates++;
     int incTry = 0;
     while (true) {
@@ -477,9 +847,9 @@ static int lm_level(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, co
       incTry++;
       lsdm::SE3fH new_referenceToFrame = lsdm::se3f_mul(lsdm::se3f_exp(inc), referenceToFrame);
       EvalOut nev;
-      rc = evaluate_pose(t, kf, frame, pts_pos, pts_colvar, npts, new_referenceToFrame, lvl, writeMask, &nev);
+      rc = evaluate_pose(t, job, new_referenceToFrame, lvl, &nev);
       if (rc) return rc;
-      if (nev.warped_size < MIN_GOODPERALL_PIXEL_ABSMIN * (c->w >> lvl) * (c->h >> lvl)) return LSDHIP_DIVERGED;
+      if (nev.warped_size < L.minWarped) return LSDHIP_DIVERGED;
       float error = nev.weightedError;
       if (error < lastErr) {
         referenceToFrame = new_referenceToFrame;
@@ -488,23 +858,75 @@ static int lm_level(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, co
           t->affineEstimation_a = t->affineEstimation_a_lastIt;
           t->affineEstimation_b = t->affineEstimation_b_lastIt;
         }
-        if (error / lastErr > convergenceEps) iteration = maxIts;
+        if (error / lastErr > L.convergenceEps) iteration = L.maxIts;
         lastErr = error;
-        if (trackFrameSemantics) *lastResidualOut = error;
+        if (job.trackFrameSemantics) *lastResidualOut = error;
         if (LM_lambda <= 0.2) LM_lambda = 0;
         else LM_lambda *= t->lambdaSuccessFac;
         break;
       } else {
         float incdot = (inc[0] * inc[0] + (inc[1] * inc[1] + inc[2] * inc[2])) + (inc[3] * inc[3] + (inc[4] * inc[4] + inc[5] * inc[5]));
-        if (!(incdot > stepSizeMin)) { iteration = maxIts; break; }
+        if (!(incdot > L.stepSizeMin)) { iteration = L.maxIts; break; }
         if (LM_lambda == 0) LM_lambda = 0.2;
         else LM_lambda *= std::pow(t->lambdaFailFac, incTry);
       }
     }
   }
-  if (!trackFrameSemantics) *lastResidualOut = lastErr;
+  if (!job.trackFrameSemantics) *lastResidualOut = lastErr;
   return LSDHIP_OK;
 }
+
+// device-resident LM over levels topLevel..job.lastLevel; one host synchronisation per budget of evaluations
+static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const lsdm::SE3fH& T0, lsdm::SE3fH* Tout) {
+  lsdhip_ctx* c = t->ctx;
+  job.evalOnly = 0;
+  hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, t->d_state, T0, topLevel, 1.0f, 0.0f, t->d_summary);
+  const TrackSummary* S = t->h_summary;
+  int budget = 26;
+  int guard = 0;
+  int parity = 0;
+  while (true) {
+    int rc = launch_steps(t, job, topLevel, budget, &parity);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof_on) {
+      // only the launches that did work count (pairs enqueued after the job finished return immediately)
+      int evalsNow = 0;
+      HIPCHK(hipMemcpy(&evalsNow, &t->d_state[parity].numEvaluations, sizeof(int), hipMemcpyDeviceToHost));
+      int ran = evalsNow - t->numEvaluations + 1;   // launches that did work (one more than completed evaluations)
+      for (int i = 0; i < ran && i < budget; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+        c->prof_ms += ms;
+        c->prof_launches++;
+      }
+      t->numEvaluations = evalsNow;
+    }
+    if (S->done) break;
+    budget = 8;
+    if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
+  }
+  if (c->prof_on) c->prof_bytes += S->bytes;
+  t->numEvaluations = S->numEvaluations;
+  t->numWarpUpdates = S->numWarpUpdates;
+  t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;
+  t->affineEstimation_a = S->aff_a; t->affineEstimation_b = S->aff_b;
+  t->affineEstimation_a_lastIt = S->aff_a_lastIt; t->affineEstimation_b_lastIt = S->aff_b_lastIt;
+  t->lastResidual = S->lastResidual;
+  Tout->q = {S->q[0], S->q[1], S->q[2], S->q[3]};
+  Tout->t[0] = S->t[0]; Tout->t[1] = S->t[1]; Tout->t[2] = S->t[2];
+  return S->diverged ? LSDHIP_DIVERGED : LSDHIP_OK;
+}
+
+static void fill_result(lsdhip_tracker* t, const lsdm::SE3dH& T, lsdhip_track_result* out) {
+  lsdm::se3d_to7(T, out->frameToReference);
+  out->pointUsage = t->pointUsage; out->lastGoodCount = t->lastGoodCount; out->lastBadCount = t->lastBadCount;
+  out->lastMeanRes = t->lastMeanRes; out->lastResidual = t->lastResidual;
+  out->affineEstimation_a = t->affineEstimation_a; out->affineEstimation_b = t->affineEstimation_b;
+  out->diverged = t->diverged; out->trackingWasGood = t->trackingWasGood;
+  out->numEvaluations = t->numEvaluations; out->numWarpUpdates = t->numWarpUpdates;
+}
+static lsdm::SE3dH identity_d() { lsdm::SE3dH I; I.q = {1, 0, 0, 0}; I.t[0] = I.t[1] = I.t[2] = 0; return I; }
 
 extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double init[7],
                                     lsdhip_track_result* out) {
@@ -516,21 +938,33 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   t->trackingWasGood = true;
   t->affineEstimation_a = 1; t->affineEstimation_b = 0;
   t->numEvaluations = 0; t->numWarpUpdates = 0;
+  TrackJob job;
+  fill_job_common(t, job);
+  for (int lvl = LSD_TRACK_MIN_LEVEL; lvl < LSD_TRACK_MAX_LEVEL; lvl++) fill_level(t, job, lvl, kf, frame, nullptr, nullptr, -1);
+  job.lv[LSD_TRACK_MIN_LEVEL].writeMask = 1;
+  int rc = lsd_frame_ensure_wasgood(frame);
+  if (rc) return rc;
+  job.wasGood = frame->d_wasGood;
+  job.lastLevel = LSD_TRACK_MIN_LEVEL;
+  job.trackFrameSemantics = 1;
   lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(init)));
-  float last_residual = 0;
-  for (int lvl = LSD_TRACK_MAX_LEVEL - 1; lvl >= LSD_TRACK_MIN_LEVEL; lvl--) {
-    int rc = lm_level(t, kf, frame, nullptr, nullptr, -1, lvl, lvl == LSD_TRACK_MIN_LEVEL, t->lambdaInitial[lvl], t->stepSizeMin[lvl],
-                      t->convergenceEps[lvl], t->maxItsPerLvl[lvl], referenceToFrame, &last_residual, true);
-    if (rc == LSDHIP_DIVERGED) {
-      t->diverged = true;
-      t->trackingWasGood = false;
-      lsdm::SE3dH I; I.q = {1, 0, 0, 0}; I.t[0] = I.t[1] = I.t[2] = 0;
-      fill_result(t, I, out);
-      return LSDHIP_DIVERGED;
-    }
-    if (rc) return rc;
+
+  if (t->hostLM) {
+    float last_residual = 0;
+    rc = LSDHIP_OK;
+    for (int lvl = LSD_TRACK_MAX_LEVEL - 1; lvl >= LSD_TRACK_MIN_LEVEL && rc == LSDHIP_OK; lvl--)
+      rc = lm_level_host(t, job, lvl, referenceToFrame, &last_residual);
+    t->lastResidual = last_residual;
+  } else {
+    rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
   }
-  t->lastResidual = last_residual;
+  if (rc == LSDHIP_DIVERGED) {
+    t->diverged = true;
+    t->trackingWasGood = false;
+    fill_result(t, identity_d(), out);
+    return LSDHIP_DIVERGED;
+  }
+  if (rc) return rc;
   t->trackingWasGood = !t->diverged && t->lastGoodCount / (c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) > MIN_GOODPERALL_PIXEL &&
                        t->lastGoodCount / (t->lastGoodCount + t->lastBadCount) > MIN_GOODPERGOODBAD_PIXEL;
   if (t->trackingWasGood) kf->numFramesTrackedOnThis++;
@@ -554,8 +988,18 @@ extern "C" int lsdhip_tracker_evaluate(lsdhip_tracker* t, lsdhip_frame* kf, lsdh
   T.q = {T7[0], T7[1], T7[2], T7[3]};
   T.t[0] = T7[4]; T.t[1] = T7[5]; T.t[2] = T7[6];
   t->affineEstimation_a = aff_a; t->affineEstimation_b = aff_b;
+  TrackJob job;
+  fill_job_common(t, job);
+  fill_level(t, job, level, kf, frame, nullptr, nullptr, -1);
+  if (level == LSD_TRACK_MIN_LEVEL) {
+    int rc = lsd_frame_ensure_wasgood(frame);
+    if (rc) return rc;
+    job.wasGood = frame->d_wasGood;
+    job.lv[level].writeMask = 1;
+  }
+  job.trackFrameSemantics = 1;
   EvalOut ev;
-  int rc = evaluate_pose(t, kf, frame, nullptr, nullptr, -1, T, level, level == LSD_TRACK_MIN_LEVEL, &ev);
+  int rc = evaluate_pose(t, job, T, level, &ev);
   if (rc) return rc;
   out->warped_size = ev.warped_size;
   out->goodCount = t->lastGoodCount; out->badCount = t->lastBadCount; out->pointUsage = t->pointUsage;
@@ -583,25 +1027,34 @@ extern "C" int lsdhip_tracker_track_permaref(lsdhip_tracker* t, const float* pos
   if (!t || !pos || !colvar || n <= 0 || !frame || !refToFrame || !out) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   HIPCHK(hipSetDevice(c->device));
-  if ((n + RES_BLOCK - 1) / RES_BLOCK > t->max_blocks) return LSDHIP_E_CAPACITY;
+  if ((n + RES_TILE - 1) / RES_TILE > t->max_blocks) return LSDHIP_E_CAPACITY;
   int rc = upload_points(t, pos, colvar, n);
   if (rc) return rc;
   lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_from7(refToFrame));
   t->affineEstimation_a = 1; t->affineEstimation_b = 0;
   t->diverged = false; t->trackingWasGood = true;
   t->numEvaluations = 0; t->numWarpUpdates = 0;
-  float lastErr = 0;
   const int L = LSD_QUICK_KF_CHECK_LVL;
-  rc = lm_level(t, nullptr, frame, t->d_pts, t->d_pts + (size_t)t->pts_capacity * 3, n, L, false, t->lambdaInitialTestTrack,
-                t->stepSizeMinTestTrack, t->convergenceEpsTestTrack, (int)t->maxItsTestTrack, referenceToFrame, &lastErr, false);
+  TrackJob job;
+  fill_job_common(t, job);
+  fill_level(t, job, L, nullptr, frame, t->d_pts, t->d_pts + (size_t)t->pts_capacity * 3, n);
+  job.lv[L].lambdaInitial = t->lambdaInitialTestTrack; job.lv[L].stepSizeMin = t->stepSizeMinTestTrack;
+  job.lv[L].convergenceEps = t->convergenceEpsTestTrack; job.lv[L].maxIts = (int)t->maxItsTestTrack;
+  job.lastLevel = L;
+  job.trackFrameSemantics = 0;
+  if (t->hostLM) {
+    float lastErr = 0;
+    rc = lm_level_host(t, job, L, referenceToFrame, &lastErr);
+    t->lastResidual = lastErr;
+  } else {
+    rc = track_device(t, job, L, referenceToFrame, &referenceToFrame);
+  }
   if (rc == LSDHIP_DIVERGED) {
     t->diverged = true; t->trackingWasGood = false;
-    lsdm::SE3dH I; I.q = {1, 0, 0, 0}; I.t[0] = I.t[1] = I.t[2] = 0;
-    fill_result(t, I, out);
+    fill_result(t, identity_d(), out);
     return LSDHIP_DIVERGED;
   }
   if (rc) return rc;
-  t->lastResidual = lastErr;
   t->trackingWasGood = !t->diverged && t->lastGoodCount / (c->wl[L] * c->hl[L]) > MIN_GOODPERALL_PIXEL &&
                        t->lastGoodCount / (t->lastGoodCount + t->lastBadCount) > MIN_GOODPERGOODBAD_PIXEL;
   fill_result(t, lsdm::se3d_from_f(referenceToFrame), out);
@@ -616,16 +1069,16 @@ extern "C" int lsdhip_tracker_check_overlap(lsdhip_tracker* t, const float* pos,
   if (rc) return rc;
   lsdm::SE3fH T = lsdm::se3f_from_d(lsdm::se3d_from7(refToFrame));
   const int L = LSD_QUICK_KF_CHECK_LVL;
-  ResidualArgs a;
+  EvalCtx a;
   memset(&a, 0, sizeof(a));
   const LevelIntr& in = c->intr[L];
   a.w = c->wl[L]; a.h = c->hl[L];
   a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy;
   lsdm::quatf_to_rot(T.q, a.R);
   a.t[0] = T.t[0]; a.t[1] = T.t[1]; a.t[2] = T.t[2];
-  hipLaunchKernelGGL(k_overlap, dim3(1), dim3(256), 0, c->stream, t->d_pts, n, a, t->d_record);
+  hipLaunchKernelGGL(k_overlap, dim3(1), dim3(256), 0, c->stream, t->d_pts, n, a, t->d_summary->sums);
   HIPCHK(hipStreamSynchronize(c->stream));
-  t->pointUsage = t->h_record[0] / (float)n;
+  t->pointUsage = t->h_summary->sums[0] / (float)n;
   *usage_out = t->pointUsage;
   return LSDHIP_OK;
 }

@@ -162,6 +162,11 @@ class Frame:
                 "numMappedOnThisTotal", "depthHasBeenUpdatedFlag", "reserved"]
         return dict(zip(keys, out.tolist()))
 
+    def clearDepthHasBeenUpdatedFlag(self):
+        """currentKeyFrame->depthHasBeenUpdatedFlag = false (C/SlamSystem.cpp:910, when the tracking reference is re-imported)"""
+        s = self.stats()
+        self.setCounters(int(s["numFramesTrackedOnThis"]), int(s["numMappedOnThis"]), int(s["numMappedOnThisTotal"]), False)
+
     def setCounters(self, numFramesTrackedOnThis, numMappedOnThis, numMappedOnThisTotal, depthHasBeenUpdatedFlag):
         check(self.L.lsdhip_frame_set_counters(self.h_, numFramesTrackedOnThis, numMappedOnThis, numMappedOnThisTotal,
                                                int(depthHasBeenUpdatedFlag)))
@@ -338,3 +343,72 @@ class DepthMap:
         check(self.L.lsdhip_depth_timings(self.h_, out.ctypes.data))
         keys = ["msUpdate", "msCreate", "msFinalize", "msObserve", "msRegularize", "msPropagate", "msFillHoles", "msSetDepth"]
         return dict(zip(keys, out.tolist()))
+
+
+class SlamLoop:
+    """Minimal single-sequence driver: the part of SlamSystem either side of the hot path, with doSlam=false and
+    blockUntilMapped=true semantics (C/SlamSystem.cpp:890-1040 trackFrame, :739-828 doMappingIteration, :542-614
+    updateKeyframe, :458-490 createNewCurrentKeyframe), and a deterministic keyframe policy (new keyframe every
+    `kf_every` frames) instead of the distance/usage score.  Orchestration only — every per-pixel operation is a
+    liblsdhip.so call."""
+
+    def __init__(self, ctx, first_image_or_ptr, depth0, kf_every=10, device_frames=False):
+        self.ctx = ctx
+        self.device_frames = device_frames
+        self.kf_every = kf_every
+        self.tracker = SE3Tracker(ctx)
+        self.tracker.set_maxItsPerLvl([5, 20, 50, 100, 0])  # C/SlamSystem.cpp:80-81
+        self.map = DepthMap(ctx)
+        self.reference = TrackingReference()
+        self.keyframe = self._frame(0, first_image_or_ptr)
+        self.keyframe.setDepthFromGroundTruth(depth0)     # SlamSystem::gtDepthInit (SlamSystem.cpp:831-854)
+        self.map.initializeFromGTDepth(self.keyframe)
+        self.reference.importFrame(self.keyframe)
+        self.keyframe.clearDepthHasBeenUpdatedFlag()
+        self.last_frameToKF = IDENTITY.copy()
+        self.n_since_kf = 0
+        self.frame_id = 0
+        self.t_track = 0.0
+        self.t_map = 0.0
+        self.n_track = 0
+        self.n_update = 0
+        self.evaluations = 0
+
+    def _frame(self, id_, img):
+        if self.device_frames:
+            return Frame(self.ctx, id_, device_ptr=img)
+        return Frame(self.ctx, id_, image=img)
+
+    def step(self, image_or_ptr, clock):
+        """track one frame, then one mapping iteration; returns frameToKeyframe"""
+        self.frame_id += 1
+        t0 = clock()
+        frame = self._frame(self.frame_id, image_or_ptr)
+        if self.keyframe.stats()["depthHasBeenUpdatedFlag"]:
+            self.reference.importFrame(self.keyframe)
+            self.keyframe.clearDepthHasBeenUpdatedFlag()
+        est = self.tracker.trackFrame(self.reference, frame, self.last_frameToKF)
+        t1 = clock()
+        self.t_track += t1 - t0
+        self.n_track += 1
+        self.evaluations += self.tracker.last.numEvaluations
+        if self.tracker.diverged:
+            raise RuntimeError("tracking diverged at frame %d" % self.frame_id)
+        self.n_since_kf += 1
+        if self.n_since_kf >= self.kf_every:
+            self.map.finalizeKeyFrame()
+            self.map.createKeyFrame(frame)
+            self.keyframe = frame
+            self.reference.importFrame(frame)
+            self.keyframe.clearDepthHasBeenUpdatedFlag()
+            self.last_frameToKF = IDENTITY.copy()
+            self.n_since_kf = 0
+            self.new_keyframe = True
+        else:
+            self.map.updateKeyframe([frame])
+            frame.clear_refPixelWasGood()
+            self.last_frameToKF = est
+            self.n_update += 1
+            self.new_keyframe = False
+        self.t_map += clock() - t1
+        return est

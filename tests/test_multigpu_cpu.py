@@ -1,0 +1,56 @@
+"""N>1 path on CPU: world_size-2 gloo run of the keyframe gather (the path's only exchange step)."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from lsd_slam_amd.multigpu import KeyframeGather
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+kg = KeyframeGather((2, 12, 16), torch.device("cpu"))
+for k in range(3):     # three keyframes per rank; record = f(rank, k)
+    kg.submit(lambda buf, k=k: buf.copy_(torch.full((2, 12, 16), float(100 * rank + k))), keep=True)
+kg.wait(keep=True)
+if rank == 0:
+    assert len(kg.collected) == 3
+    for k, rec in enumerate(kg.collected):
+        assert rec.shape == (world, 2, 12, 16)
+        for r in range(world):   # result of the N-rank run == concatenation of N single-rank runs, bitwise
+            assert torch.equal(rec[r], torch.full((2, 12, 16), float(100 * r + k)))
+    print("GATHER_OK")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_keyframe_gather_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GATHER_OK" in out.stdout
+
+
+def test_single_rank_is_a_noop_gather():
+    import torch
+    from lsd_slam_amd.multigpu import KeyframeGather
+    kg = KeyframeGather((2, 4, 4), torch.device("cpu"))
+    kg.submit(lambda b: b.fill_(3.0), keep=True)
+    kg.wait()
+    assert kg.world == 1 and torch.equal(kg.collected[0][0], torch.full((2, 4, 4), 3.0))
