@@ -20,9 +20,20 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(SRC, s) for s in SOURCES] + [os.path.join(SRC, "lsdhip_internal.hpp"),
+    deps = [os.path.join(SRC, s) for s in SOURCES] + [os.path.join(SRC, "lsdhip_internal.hpp"), os.path.join(SRC, "pose_math.hpp"),
                                                        os.path.join(HERE, "..", "include", "lsdhip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_trace(verbose=False):
+    """Developer build with per-phase timestamps inside k_track_step (tools/phase_trace.py); never loaded by default."""
+    out = os.path.join(HERE, "liblsdhip_trace.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-DLSD_PHASE_TRACE", "-x", "hip"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
 
 
 def build(force=False, verbose=False):
@@ -37,4 +48,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    if "--trace" in sys.argv:
+        build_trace(verbose=True)
+    else:
+        build(force="--force" in sys.argv, verbose=True)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsdhip.so")
+LIB_PATH = os.environ.get("LSDHIP_LIB") or os.path.join(_HERE, "liblsdhip.so")   # LSDHIP_LIB: developer builds only
 _lib = None
 
 HYP_DTYPE = np.dtype(

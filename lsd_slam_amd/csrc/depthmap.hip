@@ -830,8 +830,8 @@ extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
   (void)hipFree(dm->d_flags);
   (void)hipFree(dm->d_red);
   (void)hipHostFree(dm->h_red);
-  if (dm->d_refs) (void)hipFree(dm->d_refs);
-  if (dm->d_refByID) (void)hipFree(dm->d_refByID);
+  if (dm->d_stage) (void)hipFree(dm->d_stage);
+  if (dm->h_stage) (void)hipHostFree(dm->h_stage);
   delete dm;
 }
 extern "C" int lsdhip_depth_is_valid(lsdhip_depthmap* dm) { return dm && dm->activeKeyFrame != nullptr; }
@@ -939,8 +939,27 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   lsdhip_ctx* c = dm->ctx;
   lsdhip_frame* kf = dm->activeKeyFrame;
   if (n <= 0) { lsd_set_error("updateKeyframe: empty reference deque"); return LSDHIP_E_ARG; }
-  std::vector<StereoRef> hrefs(n);
-  std::vector<int> byID;
+  // host staging lives in one pinned block (refs | refByID): the copy needs no synchronisation, and the block is not
+  // touched again before the next updateKeyframe, which starts after this one has been synchronised
+  size_t byIDCount = 0;
+  {
+    int offset0 = refs[0]->id, last = offset0 - 1;
+    for (int i = 0; i < n; i++) if (refs[i]->id > last) last = refs[i]->id;
+    byIDCount = (size_t)(last - offset0 + 1);
+  }
+  const size_t refsBytes = (sizeof(StereoRef) * (size_t)n + 255) / 256 * 256;
+  const size_t need = refsBytes + sizeof(int) * byIDCount;
+  if (need > dm->stage_bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (dm->h_stage) HIPCHK(hipHostFree(dm->h_stage));
+    if (dm->d_stage) HIPCHK(hipFree(dm->d_stage));
+    dm->stage_bytes = need > 65536 ? need * 2 : 65536;
+    HIPCHK(hipHostMalloc((void**)&dm->h_stage, dm->stage_bytes, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&dm->d_stage, dm->stage_bytes));
+  }
+  StereoRef* hrefs = (StereoRef*)dm->h_stage;
+  int* byID = (int*)(dm->h_stage + refsBytes);
+  size_t nByID = 0;
   int offset = refs[0]->id;
   for (int i = 0; i < n; i++) {
     lsdhip_frame* fr = refs[i];
@@ -951,21 +970,11 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
       return LSDHIP_E_STATE;
     }
     prepare_stereo(dm, fr, hrefs[i]);
-    while ((int)byID.size() + offset <= fr->id) byID.push_back(i);
+    while ((int)nByID + offset <= fr->id) byID[nByID++] = i;
   }
-  if (n > dm->refs_capacity) {
-    if (dm->d_refs) HIPCHK(hipFree(dm->d_refs));
-    dm->refs_capacity = n > 64 ? n : 64;
-    HIPCHK(hipMalloc((void**)&dm->d_refs, sizeof(StereoRef) * dm->refs_capacity));
-  }
-  if ((int)byID.size() > dm->byid_capacity) {
-    if (dm->d_refByID) HIPCHK(hipFree(dm->d_refByID));
-    dm->byid_capacity = (int)byID.size() > 256 ? (int)byID.size() : 256;
-    HIPCHK(hipMalloc((void**)&dm->d_refByID, sizeof(int) * dm->byid_capacity));
-  }
-  HIPCHK(hipMemcpyAsync(dm->d_refs, hrefs.data(), sizeof(StereoRef) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->d_refByID, byID.data(), sizeof(int) * byID.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  HIPCHK(hipMemcpyAsync(dm->d_stage, dm->h_stage, refsBytes + sizeof(int) * nByID, hipMemcpyHostToDevice, c->stream));
+  dm->d_refs = (StereoRef*)dm->d_stage;
+  dm->d_refByID = (int*)(dm->d_stage + refsBytes);
 
   ObserveArgs a;
   a.m = dm->cur;
@@ -974,7 +983,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   a.kfMaxGrad = kf->d_maxgrad;
   a.refs = dm->d_refs;
   a.refByID = dm->d_refByID;
-  a.nByID = (int)byID.size();
+  a.nByID = (int)nByID;
   a.byIDOffset = offset;
   a.nRefs = n;
   a.reactivated = dm->activeKeyFrameIsReactivated ? 1 : 0;

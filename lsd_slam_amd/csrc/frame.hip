@@ -98,9 +98,13 @@ __global__ __launch_bounds__(256) void k_gradients(GradArgs a) {
 }
 
 // Separable 3x3 max of |grad| with the reference's linear-index validity ranges (see header comment).
-__global__ __launch_bounds__(256) void k_max_gradients(const float* __restrict__ absg, float* __restrict__ maxgrad, int w, int h) {
+// Also leaves the frame's level-1 refPixelWasGood mask in its "never written" state (0xFF), so that the tracker needs
+// no separate fill before its first use.
+__global__ __launch_bounds__(256) void k_max_gradients(const float* __restrict__ absg, float* __restrict__ maxgrad, int w, int h,
+                                                        uint32_t* __restrict__ wasGoodWords, int nMaskWords) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = w * h;
+  if (i < nMaskWords) wasGoodWords[i] = 0xFFFFFFFFu;
   if (i >= n) return;
   const int lo = w + 1, hi = w * (h - 1) - 1;
   auto vmax = [&](int j) -> float {
@@ -409,18 +413,20 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   return LSDHIP_OK;
 }
 
-int lsd_frame_build_pyramids(lsdhip_frame* f) {
+int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src) {
   lsdhip_ctx* c = f->ctx;
   dim3 grid(c->w / 16, c->h / 16);
-  hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, c->stream, f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
+  hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, c->stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
                      f->d_image[3], f->d_image[4], c->w, c->h);
   GradArgs ga;
   for (int l = 0; l < LSD_LEVELS; l++) { ga.img[l] = f->d_image[l]; ga.grad[l] = f->d_grad[l]; ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l]; }
   ga.absgrad0 = f->d_absgrad;
   int n0 = c->w * c->h;
   hipLaunchKernelGGL(k_gradients, dim3((n0 + 255) / 256, LSD_LEVELS), dim3(256), 0, c->stream, ga);
-  hipLaunchKernelGGL(k_max_gradients, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, f->d_absgrad, f->d_maxgrad, c->w, c->h);
+  hipLaunchKernelGGL(k_max_gradients, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, f->d_absgrad, f->d_maxgrad, c->w, c->h,
+                     (uint32_t*)f->d_wasGood, (c->wl[1] * c->hl[1] + 3) / 4);
   HIPCHK(hipGetLastError());
+  f->wasGoodPristine = true;
   return LSDHIP_OK;
 }
 
@@ -437,9 +443,10 @@ int lsd_frame_build_idepth_pyramid(lsdhip_frame* f) {
 
 int lsd_frame_ensure_wasgood(lsdhip_frame* f) {
   if (!f->wasGoodValid) {
-    HIPCHK(hipMemsetAsync(f->d_wasGood, 0xFF, (size_t)f->ctx->wl[1] * f->ctx->hl[1], f->ctx->stream));
+    if (!f->wasGoodPristine) HIPCHK(hipMemsetAsync(f->d_wasGood, 0xFF, (size_t)f->ctx->wl[1] * f->ctx->hl[1], f->ctx->stream));
     f->wasGoodValid = true;
   }
+  f->wasGoodPristine = false;   // the caller is about to write the mask
   return LSDHIP_OK;
 }
 
@@ -449,8 +456,8 @@ extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint
   lsdhip_frame* f = nullptr;
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(f->d_gray, gray_dev, (size_t)c->w * c->h, hipMemcpyDeviceToDevice, c->stream));
-  rc = lsd_frame_build_pyramids(f);
+  // the pyramid kernel reads the caller's device image directly (stream-ordered; nothing else needs the uint8 plane)
+  rc = lsd_frame_build_pyramids(f, gray_dev);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
   *out = f;
   return LSDHIP_OK;
@@ -462,7 +469,7 @@ extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_ho
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(f->d_gray, gray_host, (size_t)c->w * c->h, hipMemcpyHostToDevice, c->stream));
-  rc = lsd_frame_build_pyramids(f);
+  rc = lsd_frame_build_pyramids(f, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
   HIPCHK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
   *out = f;
@@ -543,6 +550,7 @@ extern "C" int lsdhip_frame_set_wasgood(lsdhip_frame* f, const uint8_t* in) {
   HIPCHK(hipMemcpyAsync(f->d_wasGood, in, (size_t)c->wl[1] * c->hl[1], hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   f->wasGoodValid = true;
+  f->wasGoodPristine = false;
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_frame_clear_wasgood(lsdhip_frame* f) {

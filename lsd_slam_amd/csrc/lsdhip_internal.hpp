@@ -56,7 +56,8 @@ struct TrackLevel {
   const float* pts_colvar;
   int npts;
   int w, h;
-  int nblocks;               // workgroups that have work at this level
+  int nblocks;               // workgroups (tiles) that have work at this level
+  int singlePass;            // nblocks * workgroup size >= points: every lane evaluates at most one point
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
   float lambdaInitial, stepSizeMin, convergenceEps;
   int maxIts;
@@ -71,7 +72,10 @@ struct TrackJob {
   float cameraPixelNoise2, var_weight, huber_half;
   float lambdaSuccessFac, lambdaFailFac;
   int useAffine;
-  int lastLevel;             // the LM loop runs levels state.level .. lastLevel
+  int lastLevel;             // the LM loop runs levels topLevel .. lastLevel
+  int topLevel;              // first (coarsest) level of the job
+  lsdm::SE3fH T0;            // referenceToFrame the job starts from
+  float aff_a0, aff_b0;      // affine-lighting parameters the job starts from
   int evalOnly;              // 1: a step only finalises the sums of one evaluation (kernel-level parity hook / host LM)
   int trackFrameSemantics;   // lastResidual bookkeeping of trackFrame (1) vs trackFrameOnPermaref (0)
 };
@@ -87,7 +91,7 @@ struct TrackState {
   int pending;               // partial sums of an evaluation are waiting for their LM step
   float A[36], b[6];         // normal equations of the last accepted evaluation (LGS6 after finish())
   float inc[6];              // increment of the trial under evaluation
-  double bytes;              // algorithmic bytes moved by the evaluations so far (bench.py roofline leg)
+  float bytes;               // algorithmic bytes moved by the evaluations so far (bench.py roofline leg)
   int done, diverged;
   int numEvaluations, numWarpUpdates;
   float pointUsage, goodCount, badCount, meanRes;
@@ -136,6 +140,7 @@ struct lsdhip_frame {
   bool hasIDepth = false;
   uint8_t* d_wasGood = nullptr;         // level-1 mask (lazily created, 0xFF)
   bool wasGoodValid = false;
+  bool wasGoodPristine = false;         // the mask still holds the 0xFF fill of frame creation
   // pose-tree node
   lsdm::Sim3dH thisToParent_raw;
   lsdhip_frame* trackingParent = nullptr;
@@ -167,14 +172,15 @@ struct lsdhip_tracker {
   int numEvaluations = 0, numWarpUpdates = 0;
   bool hostLM = false;            // debugging: run the LM control loop on the host, one evaluation per round trip
   // device scratch
-  float* d_partials = nullptr;    // [max_blocks][RS_NUM]
+  float* d_partials = nullptr;    // TrackScratch arena (sums | topkey | topval), see tracker.hip
   int max_blocks = 0;
-  TrackJob* d_job = nullptr;
-  TrackState* d_state = nullptr;
-  TrackJob* h_job = nullptr;      // pinned staging
-  TrackState* h_state = nullptr;  // pinned staging
+  TrackState* d_state = nullptr;  // [2], double-buffered by launch parity
+  int block = 256;                // workgroup size of k_track_step (LSDHIP_TRACK_BLOCK)
+  int grid_cap = 304;             // most workgroups one evaluation uses (LSDHIP_TRACK_CAP); larger levels grid-stride
+  int recent[4] = {0, 0, 0, 0};   // evaluations of the last jobs: size the launch budget of the next one
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary
+  unsigned long long* d_trace = nullptr;  // LSD_PHASE_TRACE developer build only
   float* d_pts = nullptr;         // permaref point upload
   int pts_capacity = 0;
 };
@@ -212,9 +218,11 @@ struct lsdhip_depthmap {
   void* bases[3] = {nullptr, nullptr, nullptr};  // arena base pointers (for hipFree)
   lsdhip_frame* activeKeyFrame = nullptr;
   bool activeKeyFrameIsReactivated = false;
-  StereoRef* d_refs = nullptr;
+  StereoRef* d_refs = nullptr;     // views into d_stage
   int* d_refByID = nullptr;
-  int refs_capacity = 0, byid_capacity = 0;
+  char* h_stage = nullptr;         // pinned staging block (refs | refByID) and its device twin
+  char* d_stage = nullptr;
+  size_t stage_bytes = 0;
   // K7 scratch
   int* d_slotCount = nullptr;      // per target
   int* d_slots = nullptr;          // per target x capacity source indices
@@ -227,7 +235,7 @@ struct lsdhip_depthmap {
 };
 
 // kernels / launchers implemented in the .hip files
-int lsd_frame_build_pyramids(lsdhip_frame* f);
+int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f);
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);

@@ -1,13 +1,14 @@
 // SE3Tracker on the device.  gfx950 only.
 //
-// One evaluation = two launches on the context's stream:
-//   k_residual   fused K0 (point generation from the keyframe planes) + K1 (warp / bilinear sample / mask) + K2 (weights)
-//                + K3 (normal equations); 41 sums reduced wave (DPP) -> workgroup (LDS) -> partials[workgroup]
-//   k_lm_step    one workgroup: fixed-order sum of the partials, SSE tail-drop correction, and the Levenberg-Marquardt
-//                decision of SE3Tracker::trackFrame (accept / reject, lambda schedule, 6x6 LDL^T solve, SE3 exp,
-//                level change) — the pose never leaves HBM between evaluations.
-// The host enqueues a budget of (k_residual, k_lm_step) pairs back to back and synchronises once; pairs launched after
-// the job has finished return immediately.  A host-driven LM loop (one evaluation per round trip) is kept behind
+// One evaluation = one launch of k_track_step on the context's stream:
+//   (1) every workgroup finishes the *previous* evaluation: fixed-order sum of the partial rows, SSE tail-drop
+//       correction, and the Levenberg-Marquardt decision of SE3Tracker::trackFrame (accept / reject, lambda schedule,
+//       6x6 LDL^T solve, SE3 exp, level change) — redundantly and identically in every workgroup, so the launch needs no
+//       atomics, fences or inter-workgroup waits and the pose never leaves HBM between evaluations;
+//   (2) fused K0 (point generation from the keyframe planes) + K1 (warp / bilinear sample / mask) + K2 (weights) + K3
+//       (normal equations) at the pose (1) produced; 41 sums reduced wave (DPP) -> workgroup (LDS) -> partials[tile].
+// The host enqueues a budget of k_track_step launches back to back and synchronises once; steps launched
+// after the job has finished return immediately.  A host-driven LM loop (one evaluation per round trip) is kept behind
 // lsdhip_tracker.hostLM for debugging and as the kernel-level parity hook (lsdhip_tracker_evaluate).
 //
 // Reference behaviour restated:
@@ -27,9 +28,6 @@
 // (SURVEY.md §8(d)): 20 N_l + [l==1] 5 N_l + 12 min(w_l h_l, 4 N_l).
 #include "lsdhip_internal.hpp"
 
-#define RES_BLOCK 1024
-#define RES_PPT 2                       // reference pixels per lane
-#define RES_TILE (RES_BLOCK * RES_PPT)  // pixels per workgroup
 
 // ---- wave64 sum via DPP (row_shr 1,2,3 / 4 / 8, row_bcast 15 / 31); result valid in lane 63 ----------------------
 template <int CTRL, int ROW_MASK, int BANK_MASK>
@@ -106,19 +104,6 @@ struct EvalCtx {            // one level of a job + the pose under evaluation, i
   float aff_a, aff_b;
   float cameraPixelNoise2, var_weight, huber_half;
 };
-__device__ __forceinline__ void make_ctx(const TrackJob& job, const TrackState& st, int level, EvalCtx& a) {
-  const TrackLevel& L = job.lv[level];
-  a.kf_idepth = L.kf_idepth; a.kf_idepthVar = L.kf_idepthVar; a.kf_image = L.kf_image; a.fr_grad = L.fr_grad;
-  a.pts_pos = L.pts_pos; a.pts_colvar = L.pts_colvar; a.npts = L.npts; a.w = L.w; a.h = L.h;
-  a.fx = L.fx; a.fy = L.fy; a.cx = L.cx; a.cy = L.cy; a.fxi = L.fxi; a.fyi = L.fyi; a.cxi = L.cxi; a.cyi = L.cyi;
-#pragma unroll
-  for (int i = 0; i < 9; i++) a.R[i] = st.R[i];
-#pragma unroll
-  for (int i = 0; i < 3; i++) a.t[i] = st.t[i];
-  a.aff_a = st.aff_a; a.aff_b = st.aff_b;
-  a.cameraPixelNoise2 = job.cameraPixelNoise2; a.var_weight = job.var_weight; a.huber_half = job.huber_half;
-}
-
 struct PointOut {
   bool in_image;
   bool good;
@@ -217,8 +202,8 @@ __device__ __forceinline__ bool fetch_point(const EvalCtx& a, int i, float& px, 
   return true;
 }
 
-// ---- Levenberg-Marquardt step (runs on a copy of the state in LDS) -------------------------------------------------
-__device__ void set_eval_pose(TrackState& s, const lsdm::SE3fH& T) {
+// ---- Levenberg-Marquardt step (one lane, state held in registers) ---------------------------------------------------
+__device__ __forceinline__ void set_eval_pose(TrackState& s, const lsdm::SE3fH& T) {
   s.Tn = T;
   lsdm::quatf_to_rot(T.q, s.R);
   s.t[0] = T.t[0]; s.t[1] = T.t[1]; s.t[2] = T.t[2];
@@ -235,18 +220,14 @@ __device__ void write_summary(const TrackState& s, const float* tot, TrackSummar
   out->done = s.done;
 }
 
-// 6x6 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics), fully unrolled: every index is a compile-time
-// constant and the pivot swaps are conditional register exchanges, so nothing spills to scratch or LDS.
+// 6x6 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics) on register arrays: every index is a compile-time
+// constant and the pivot swaps are conditional register exchanges, so nothing goes to scratch or LDS.  One reciprocal
+// per pivot instead of one division per entry (the LM increment is tolerance-level data).
 __device__ __forceinline__ void cswap(bool c, float& a, float& b) { float t = a; a = c ? b : a; b = c ? t : b; }
-__device__ void ldlt6_solve_reg(const float* Ain, const float* bin, float* x) {
-  float M[6][6];
+__device__ __forceinline__ void ldlt6_solve_reg(float (&M)[6][6], const float (&bin)[6], float (&x)[6]) {
   int p[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    p[i] = i;
-#pragma unroll
-    for (int j = 0; j < 6; j++) M[i][j] = Ain[i * 6 + j];
-  }
+  for (int i = 0; i < 6; i++) p[i] = i;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     int piv = k;
@@ -256,6 +237,7 @@ __device__ void ldlt6_solve_reg(const float* Ain, const float* bin, float* x) {
 #pragma unroll
     for (int i = k + 1; i < 6; i++) {
       const bool c = (piv == i);
+      // only the lower triangle is referenced below: swap rows k,i and columns k,i of the symmetric matrix
 #pragma unroll
       for (int j = 0; j < 6; j++) cswap(c, M[k][j], M[i][j]);
 #pragma unroll
@@ -266,12 +248,13 @@ __device__ void ldlt6_solve_reg(const float* Ain, const float* bin, float* x) {
 #pragma unroll
     for (int j = 0; j < k; j++) d -= M[k][j] * M[k][j] * M[j][j];
     M[k][k] = d;
+    const float rd = d != 0.0f ? 1.0f / d : 0.0f;
 #pragma unroll
     for (int i = k + 1; i < 6; i++) {
       float v = M[i][k];
 #pragma unroll
       for (int j = 0; j < k; j++) v -= M[i][j] * M[k][j] * M[j][j];
-      M[i][k] = d != 0.0f ? v / d : 0.0f;
+      M[i][k] = v * rd;
     }
   }
   float y[6];
@@ -303,13 +286,36 @@ __device__ void ldlt6_solve_reg(const float* Ain, const float* bin, float* x) {
   }
 }
 
-struct LmScratch { float M[36]; float bneg[6]; };
+// What the workgroup hands to the LM lane: corrected raw sums of the evaluation (LDS) and the normalised normal
+// equations (LGS6::finish: A / n, b / n with the SSE constraint count n = 6 * (M / 4), LGSX.h:319-325, :385), 21 + 6
+// values computed by 27 lanes in parallel.
+struct LmShared {
+  float tot[RS_NUM];
+  float norm[27];
+};
+// Job parameters the LM lane needs, staged in LDS by an otherwise idle lane while the partial sums are being added
+// (fetched field by field from the kernel-argument segment they cost one scalar-cache round trip each).
+struct LmPar {
+  float lambdaInitial, stepSizeMin, convergenceEps, minWarped, lambdaSuccessFac, lambdaFailFac;
+  int maxIts, w, h, writeMask, evalOnly, useAffine, tfSemantics, lastLevel;
+};
+__device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmPar& p) {
+  const TrackLevel& L = job.lv[level];
+  LmPar v;
+  v.lambdaInitial = L.lambdaInitial; v.stepSizeMin = L.stepSizeMin; v.convergenceEps = L.convergenceEps; v.minWarped = L.minWarped;
+  v.lambdaSuccessFac = job.lambdaSuccessFac; v.lambdaFailFac = job.lambdaFailFac;
+  v.maxIts = L.maxIts; v.w = L.w; v.h = L.h; v.writeMask = L.writeMask; v.evalOnly = job.evalOnly; v.useAffine = job.useAffine;
+  v.tfSemantics = job.trackFrameSemantics; v.lastLevel = job.lastLevel;
+  p = v;
+}
 
 // The control flow of SE3Tracker::trackFrame between two evaluations (SE3Tracker.cpp:324-447), run by one lane of every
 // workgroup on identical inputs (so every workgroup reaches the same decision without talking to the others).
 // `out` is non-null in workgroup 0 only.
-__device__ void lm_advance(const TrackJob& job, TrackState& s, const float* tot, LmScratch& ws, TrackSummary* out) {
-  const TrackLevel& L = job.lv[s.level];
+__device__ __forceinline__ void lm_advance(const LmPar& par, TrackState& s, const LmShared& sh, TrackSummary* out) {
+  const float* tot = sh.tot;
+  const LmPar L = par;
+  const int maxIts = L.maxIts;
   // calcResidualAndBuffers epilogue (:1016-1028)
   const int M = (int)tot[RS_M];
   const float refNum = tot[RS_NREF];
@@ -326,25 +332,26 @@ __device__ void lm_advance(const TrackJob& job, TrackState& s, const float* tot,
   s.numEvaluations++;
   {
     // algorithmic bytes of this evaluation: 20 N + [mask] 5 N + 12 min(w h, 4 N)
-    double N = refNum, wh = (double)L.w * L.h;
-    double texels = 4.0 * N < wh ? 4.0 * N : wh;
-    s.bytes += 20.0 * N + (L.writeMask ? 5.0 * N : 0.0) + 12.0 * texels;
+    float N = refNum, wh = (float)L.w * (float)L.h;
+    float texels = 4.0f * N < wh ? 4.0f * N : wh;
+    s.bytes += 20.0f * N + (L.writeMask ? 5.0f * N : 0.0f) + 12.0f * texels;
   }
-  if (job.evalOnly) { s.done = 1; if (out) write_summary(s, tot, out); return; }
+  if (L.evalOnly) { s.done = 1; if (out) write_summary(s, tot, out); return; }
 
   if (M < L.minWarped) {   // :324-329 / :369-374
     s.diverged = 1; s.done = 1;
     if (out) write_summary(s, tot, out);
     return;
   }
-  // calcWeightsAndResidualSSE epilogue (:572-574) and LGS6::finish with the SSE constraint count (LGSX.h:319-325, :385)
+  // calcWeightsAndResidualSSE epilogue (:572-574)
   const float werr = tot[RS_WERR] / ((M >> 2) << 2);
-  const float n = (float)((size_t)6 * (size_t)(M >> 2));
+  const bool useAffine = L.useAffine != 0;
+  const bool tfSemantics = L.tfSemantics != 0;
 
   bool propose = false, start_iteration = false, accepted = false;
   if (s.phase == 0) {
     accepted = true;
-    if (job.useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
+    if (useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
     s.lastErr = werr;
     s.LM_lambda = L.lambdaInitial;
     s.iteration = 0;
@@ -354,26 +361,26 @@ __device__ void lm_advance(const TrackJob& job, TrackState& s, const float* tot,
     if (error < s.lastErr) {
       accepted = true;
       s.T = s.Tn;
-      if (job.useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
-      if (error / s.lastErr > L.convergenceEps) s.iteration = L.maxIts;
+      if (useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
+      if (error / s.lastErr > L.convergenceEps) s.iteration = maxIts;
       s.lastErr = error;
-      if (job.trackFrameSemantics) s.last_residual = error;
+      if (tfSemantics) s.last_residual = error;
       if (s.LM_lambda <= 0.2) s.LM_lambda = 0;
-      else s.LM_lambda *= job.lambdaSuccessFac;
+      else s.LM_lambda *= L.lambdaSuccessFac;
       s.iteration++;
       start_iteration = true;
     } else {
-      const float* inc = s.inc;
-      float incdot = (inc[0] * inc[0] + (inc[1] * inc[1] + inc[2] * inc[2])) + (inc[3] * inc[3] + (inc[4] * inc[4] + inc[5] * inc[5]));
+      float incdot = (s.inc[0] * s.inc[0] + (s.inc[1] * s.inc[1] + s.inc[2] * s.inc[2])) +
+                     (s.inc[3] * s.inc[3] + (s.inc[4] * s.inc[4] + s.inc[5] * s.inc[5]));
       if (!(incdot > L.stepSizeMin)) {
-        s.iteration = L.maxIts;
+        s.iteration = maxIts;
         s.iteration++;
         start_iteration = true;
       } else {
         if (s.LM_lambda == 0) s.LM_lambda = 0.2;
         else {
           double p = 1.0;
-          for (int i = 0; i < s.incTry; i++) p *= (double)job.lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
+          for (int i = 0; i < s.incTry; i++) p *= (double)L.lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
           s.LM_lambda = (float)((double)s.LM_lambda * p);
         }
         propose = true;
@@ -383,31 +390,41 @@ __device__ void lm_advance(const TrackJob& job, TrackState& s, const float* tot,
   if (start_iteration) {
     if (accepted) {
       // the accepted (or first) evaluation's normal equations are what calculateWarpUpdate would build next
-      int k = RS_A0;
+      int k = 0;
+#pragma unroll
       for (int i = 0; i < 6; i++)
+#pragma unroll
         for (int j = i; j < 6; j++, k++) {
-          float v = (0.0f + tot[k]) / n;
+          float v = sh.norm[k];
           s.A[i * 6 + j] = v;
           s.A[j * 6 + i] = v;
         }
-      for (int i = 0; i < 6; i++) s.b[i] = (0.0f - tot[RS_B0 + i]) / n;
+#pragma unroll
+      for (int i = 0; i < 6; i++) s.b[i] = sh.norm[21 + i];
     }
-    if (s.iteration < L.maxIts) { s.numWarpUpdates++; s.incTry = 0; propose = true; }
+    if (s.iteration < maxIts) { s.numWarpUpdates++; s.incTry = 0; propose = true; }
   }
   if (propose) {
-    for (int i = 0; i < 36; i++) ws.M[i] = s.A[i];
-    for (int i = 0; i < 6; i++) { ws.bneg[i] = -s.b[i]; ws.M[i * 6 + i] *= 1 + s.LM_lambda; }
-    float inc[6];
-    ldlt6_solve_reg(ws.M, ws.bneg, inc);
+    float Mx[6][6], bneg[6], inc[6];
+    const float damp = 1 + s.LM_lambda;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) Mx[i][j] = s.A[i * 6 + j];
+      Mx[i][i] *= damp;
+      bneg[i] = -s.b[i];
+    }
+    ldlt6_solve_reg(Mx, bneg, inc);
     s.incTry++;
+#pragma unroll
     for (int i = 0; i < 6; i++) s.inc[i] = inc[i];
     set_eval_pose(s, lsdm::se3f_mul(lsdm::se3f_exp(inc), s.T));
     s.phase = 1;
     return;
   }
   // level finished
-  if (!job.trackFrameSemantics) s.last_residual = s.lastErr;   // trackFrameOnPermaref: lastResidual = lastErr (:265)
-  if (s.level == job.lastLevel) {
+  if (!tfSemantics) s.last_residual = s.lastErr;   // trackFrameOnPermaref: lastResidual = lastErr (:265)
+  if (s.level == L.lastLevel) {
     s.done = 1;
     if (out) write_summary(s, tot, out);
   } else {
@@ -417,159 +434,278 @@ __device__ void lm_advance(const TrackJob& job, TrackState& s, const float* tot,
   }
 }
 
-// only the in-image test of calcResidualAndBuffers (no sampling): used by the tail-drop walk
-__device__ __forceinline__ bool point_in_image(const EvalCtx& a, float px, float py, float pz) {
-  float Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
-  float Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
-  float Wz = ((a.R[6] * px + a.R[7] * py) + a.R[8] * pz) + a.t[2];
-  float u_new = (Wx / Wz) * a.fx + a.cx;
-  float v_new = (Wy / Wz) * a.fy + a.cy;
-  return (u_new > 1 && v_new > 1 && u_new < a.w - 2 && v_new < a.h - 2);
+__device__ __forceinline__ void make_ctx_dev(const TrackJob& jobr, const TrackState& S, int level, EvalCtx& a) {
+  const TrackJob* job = &jobr;
+  const TrackLevel& L = job->lv[level];
+  a.kf_idepth = L.kf_idepth; a.kf_idepthVar = L.kf_idepthVar; a.kf_image = L.kf_image; a.fr_grad = L.fr_grad;
+  a.pts_pos = L.pts_pos; a.pts_colvar = L.pts_colvar; a.npts = L.npts; a.w = L.w; a.h = L.h;
+  a.fx = L.fx; a.fy = L.fy; a.cx = L.cx; a.cy = L.cy; a.fxi = L.fxi; a.fyi = L.fyi; a.cxi = L.cxi; a.cyi = L.cyi;
+#pragma unroll
+  for (int i = 0; i < 9; i++) a.R[i] = S.R[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) a.t[i] = S.t[i];
+  a.aff_a = S.aff_a; a.aff_b = S.aff_b;
+  a.cameraPixelNoise2 = job->cameraPixelNoise2; a.var_weight = job->var_weight; a.huber_half = job->huber_half;
 }
 
+template <int N>
+__device__ __forceinline__ void copy_words(void* dst, const void* src, int tid, int nthreads) {
+  const unsigned* s = (const unsigned*)src;
+  unsigned* d = (unsigned*)dst;
+  for (int i = tid; i < N; i += nthreads) d[i] = s[i];
+}
+
+// logical tile of workgroup b among nb participating ones: workgroups are dealt round-robin to the 8 XCDs, so giving
+// XCD x the contiguous tile range [x nb/8, (x+1) nb/8) keeps the texels one band of the frame touches in one L2.
+__device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b; }
+
+// Scratch of a tracker in HBM, double-buffered by launch parity (a launch reads [parity], writes [1 - parity]).
+struct TrackScratch {
+  float* sums;     // [2][RS_COLS][max_rows]  column-major partial sums: one row per workgroup tile
+  int4* topkey;    // [2][max_rows]           each tile's three largest reference-order keys among in-image points (x>=y>=z)
+  float* topval;   // [2][max_rows][3][32]    K2/K3 contributions of those points (single-pass levels only)
+  int max_rows;    // multiple of 4
+#ifdef LSD_PHASE_TRACE
+  unsigned long long* trace;   // [0] = launch counter, then 12 words per launch (developer build only, tools/phase_trace.py)
+#endif
+};
+#ifdef LSD_PHASE_TRACE
+#define PHASE_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) tr_[k] = clock64(); } while (0)
+#else
+#define PHASE_MARK(k) do { } while (0)
+#endif
+#define RS_COLS 44   // RS_END rounded up
+
 // Fused tracking step, one launch per evaluation:
-//   (1) every workgroup re-derives the LM decision for the *previous* evaluation from its partial sums (fixed-order
-//       sum, SSE tail drop, lm_advance) — identical inputs, identical code, hence identical state in every workgroup
-//       without any inter-workgroup communication inside the launch;
-//   (2) the residual evaluation (K0+K1+K2+K3) of the pose that decision produced, RES_PPT reference pixels per lane,
-//       41 sums reduced wave (DPP) -> workgroup (LDS) -> partials[workgroup].
-// State and partials are double-buffered by launch parity: a launch reads [parity] and writes [1 - parity].
-__global__ __launch_bounds__(RES_BLOCK) void k_track_step(TrackJob job, TrackState* __restrict__ st2, float* __restrict__ partials2,
-                                                           int max_blocks, TrackSummary* __restrict__ out, int parity) {
+//   (1) every workgroup finishes the *previous* evaluation from its partial sums: fixed-order column sums (float4 loads
+//       of the column-major rows, all issued before the first add), SSE tail drop, LGS6::finish, then lm_advance on one
+//       lane — identical inputs, identical code, hence identical state in every workgroup without any inter-workgroup
+//       communication inside the launch (no atomics, no fences, run-to-run deterministic).  The last wave fetches (or,
+//       on multi-pass levels, re-evaluates) the at most 3 tail points while the other waves sum;
+//   (2) the residual evaluation (K0+K1+K2+K3) of the pose that decision produced, grid-stride over the level's pixels,
+//       41 sums reduced wave (DPP) -> workgroup (LDS) -> sums[.][tile].
+// The first launch of a job (first = 1) builds the initial state from the job instead of loading it.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob job, TrackState* __restrict__ st2, TrackScratch sc,
+                                                       TrackSummary* __restrict__ out, int parity, int first) {
+  constexpr int WAVES = BLOCK / 64;
+  constexpr int SUMW = WAVES - 1;                    // waves that sum partials (the last one does the tail work)
+  constexpr int NSLICE = (SUMW * 64) / RS_END;       // row slices per column
+  constexpr int QMAX = 20;                           // float4 loads per thread: rows per slice <= 80
   __shared__ TrackState S;
-  __shared__ LmScratch ws;
-  __shared__ float s_sum[RES_BLOCK / 64][64];
-  __shared__ float s_tot[RS_NUM];
-  __shared__ int s_wtop[RES_BLOCK / 64][3];
+  __shared__ LmShared sh;
+  __shared__ LmPar s_par;
+  constexpr int RSLICE_ = BLOCK / RS_END;
+  __shared__ float s_sum[(NSLICE > RSLICE_ ? NSLICE : RSLICE_)][64];
+  __shared__ float s_red[RS_END * (BLOCK + 1) + 8];
+  __shared__ int s_wtop[WAVES][3];
   __shared__ int s_top[3];
-  __shared__ int s_chosen[4];
-  __shared__ int s_nchosen;
   __shared__ float s_sub[3][32];
+  __shared__ int s_nsub;
   const int tid = threadIdx.x;
-  const TrackState* in = st2 + parity;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int max_rows = sc.max_rows;
   TrackState* next = st2 + (1 - parity);
-  const float* partials_in = partials2 + (size_t)parity * max_blocks * RS_NUM;
-  float* partials_out = partials2 + (size_t)(1 - parity) * max_blocks * RS_NUM;
-  {
-    const unsigned* src = (const unsigned*)in;
-    unsigned* dst = (unsigned*)&S;
-    for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
+  const float* sums_in = sc.sums + (size_t)parity * RS_COLS * max_rows;
+  float* sums_out = sc.sums + (size_t)(1 - parity) * RS_COLS * max_rows;
+  const int4* topkey_in = sc.topkey + (size_t)parity * max_rows;
+  int4* topkey_out = sc.topkey + (size_t)(1 - parity) * max_rows;
+  const float* topval_in = sc.topval + (size_t)parity * max_rows * 96;
+  float* topval_out = sc.topval + (size_t)(1 - parity) * max_rows * 96;
+#ifdef LSD_PHASE_TRACE
+  unsigned long long* tr_ = sc.trace;
+  if (blockIdx.x == 0 && tid == 0) {
+    unsigned long long n = sc.trace[0];
+    sc.trace[0] = n + 1;
+    tr_ = sc.trace + 1 + (n % 4096) * 12;
+    for (int k = 0; k < 12; k++) tr_[k] = 0;
+    tr_[8] = wall_clock64();
+  }
+#endif
+  PHASE_MARK(0);
+  if (first) {
+    if (tid == 0) {
+      S.T = job.T0;
+      set_eval_pose(S, job.T0);
+      S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
+      S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
+      S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
+      S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
+      S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
+      S.bytes = 0;
+    }
+    if (tid < 36) S.A[tid] = 0;
+    if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
+  } else {
+    copy_words<sizeof(TrackState) / 4>(&S, st2 + parity, tid, BLOCK);
   }
   __syncthreads();
+  PHASE_MARK(1);
   if (S.done) {
-    if (blockIdx.x == 0) {   // keep both state buffers "done" so that later launches of the budget return at once
-      unsigned* dst = (unsigned*)next;
-      const unsigned* src = (const unsigned*)&S;
-      for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
-    }
+    if (blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // keep both buffers "done"
     return;
   }
 
   if (S.pending) {
     const int level = S.level;
-    const int nblocks = job.lv[level].nblocks;
-    const int col = tid & 63, slice = tid >> 6;
-    {
-      float s = 0.f;
-      if (col < RS_END)
-        for (int b = slice; b < nblocks; b += RES_BLOCK / 64) s += partials_in[(size_t)b * RS_NUM + col];
-      s_sum[slice][col] = s;
-    }
-    __syncthreads();
-    if (tid < RS_NUM) {
-      float s = s_sum[0][tid];
+    const int nb = job.lv[level].nblocks;
+    if (wave < SUMW) {
+      // fixed-order column sums: thread t < NSLICE * RS_END takes rows [slice R, slice R + R) of column col
+      const int t = tid;
+      const int slice = t / RS_END, col = t - slice * RS_END;
+      if (slice < NSLICE) {
+        const int R = (((nb + NSLICE - 1) / NSLICE) + 3) & ~3;
+        const int row0 = slice * R;
+        const float4* p = (const float4*)(sums_in + (size_t)col * max_rows + (row0 < max_rows ? row0 : 0));
+        float4 v[QMAX];
+        const int qlast = (max_rows - row0) / 4 - 1;   // loads stay inside the column (rows < max_rows are allocated)
 #pragma unroll
-      for (int k = 1; k < RES_BLOCK / 64; k++) s += s_sum[k][tid];
-      s_tot[tid] = s;
-    }
-    if (tid == 0) s_nchosen = 0;
-    __syncthreads();
-
-    const int M = (int)s_tot[RS_M];
-    const int need = M & 3;
-    if (need > 0) {
-      EvalCtx a;
-      make_ctx(job, S, level, a);
+        for (int q = 0; q < QMAX; q++) v[q] = p[q < qlast ? q : (qlast > 0 ? qlast : 0)];   // unconditional, issued together
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < QMAX; q++) {
+          const int r = row0 + 4 * q;
+          if (4 * q < R) {
+            s += (r < nb) ? v[q].x : 0.f;
+            s += (r + 1 < nb) ? v[q].y : 0.f;
+            s += (r + 2 < nb) ? v[q].z : 0.f;
+            s += (r + 3 < nb) ? v[q].w : 0.f;
+          }
+        }
+        s_sum[slice][col] = s;
+      } else if (t == SUMW * 64 - 1) {
+        stage_lm_par(job, level, s_par);
+      }
+    } else {
       // the last (M % 4) in-image points in reference order = the largest keys (x * h + y, or list index) over all
-      // workgroups' top-3 lists left behind by the residual pass
-      int c0 = -1, c1 = -1, c2 = -1;
-      for (int e = tid; e < nblocks * 3; e += RES_BLOCK)
-        top3_insert(__float_as_int(partials_in[(size_t)(e / 3) * RS_NUM + RS_TOP0 + (e % 3)]), c0, c1, c2);
-      block_top3(c0, c1, c2, s_wtop, s_top);
-      if (tid == 0) {
-        int nsel = 0;
-        for (int k = 0; k < need; k++) {
-          int key = s_top[k];
-          if (key < 0) break;
-          s_chosen[nsel++] = (a.npts >= 0) ? key : ((key / a.h) + (key % a.h) * a.w);
+      // tiles' top-3 lists left behind by the residual pass
+      int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
+      {
+        constexpr int KROWS = 5;   // rows per lane: max_rows <= 320
+        int4 kv[KROWS];
+#pragma unroll
+        for (int q = 0; q < KROWS; q++) {
+          const int row = lane + 64 * q;
+          const int4 kq = topkey_in[row < max_rows ? row : 0];   // unconditional, issued together
+          kv[q] = row < nb ? kq : make_int4(-1, -1, -1, -1);
         }
-        s_nchosen = nsel;
-      }
-      __syncthreads();
-      if (tid < s_nchosen) {
-        float px, py, pz, I_ref, var;
-        int maskIdx;
-        fetch_point(a, s_chosen[tid], px, py, pz, I_ref, var, maskIdx);
-        PointOut o;
-        eval_point(a, px, py, pz, I_ref, var, o);
-        float* sub = s_sub[tid];
-        sub[0] = o.werr;
-        int k = 1;
-        for (int r = 0; r < 6; r++) {
-          float Jw = o.J[r] * o.w;
-          for (int c = r; c < 6; c++) sub[k++] = Jw * o.J[c];
+#pragma unroll
+        for (int q = 0; q < KROWS; q++) {
+          const int e = (lane + 64 * q) * 3;
+          const int ks[3] = {kv[q].x, kv[q].y, kv[q].z};
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++) {
+            const int k = ks[rr];
+            if (k > k0) { k2 = k1; e2 = e1; k1 = k0; e1 = e0; k0 = k; e0 = e + rr; }
+            else if (k > k1) { k2 = k1; e2 = e1; k1 = k; e1 = e + rr; }
+            else if (k > k2) { k2 = k; e2 = e + rr; }
+          }
         }
-        float resw = o.res * o.w;
-        for (int r = 0; r < 6; r++) sub[k++] = resw * o.J[r];
-        sub[k++] = resw * o.res;
       }
-      __syncthreads();
-      if (tid < 29) {
-        // element 0 -> RS_WERR, 1..21 -> RS_A0.., 22..27 -> RS_B0.., 28 -> RS_ERR
-        int dst = (tid == 0) ? RS_WERR : (tid <= 21 ? RS_A0 + tid - 1 : (tid <= 27 ? RS_B0 + tid - 22 : RS_ERR));
-        float v = s_tot[dst];
-        for (int k = 0; k < s_nchosen; k++) v -= s_sub[k][tid];
-        s_tot[dst] = v;
+      int keys[3], src[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int m = __builtin_amdgcn_readlane(wave_max_to_lane63(k0), 63);
+        const unsigned long long own = __ballot(k0 == m && m >= 0);
+        const int owner = own ? (int)__ffsll((long long)own) - 1 : 0;
+        keys[r] = m;
+        src[r] = __builtin_amdgcn_readlane(e0, owner);
+        if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
       }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      lm_advance(job, S, s_tot, ws, blockIdx.x == 0 ? out : nullptr);
-      S.pending = 0;
+      if (lane == 0) s_nsub = (keys[0] >= 0) + (keys[1] >= 0) + (keys[2] >= 0);
+      if (job.lv[level].singlePass) {
+        // the owners left their K2/K3 contributions next to the keys
+        const int j = lane & 31;
+        if (j < 29) {
+          const int r = lane >> 5;
+          if (keys[r] >= 0) s_sub[r][j] = topval_in[(size_t)src[r] * 32 + j];
+          if (r == 0 && keys[2] >= 0) s_sub[2][j] = topval_in[(size_t)src[2] * 32 + j];
+        }
+      } else {
+        // multi-pass level: re-evaluate the tail points
+        EvalCtx a;
+        make_ctx_dev(job, S, level, a);
+        const int key = lane == 0 ? keys[0] : (lane == 1 ? keys[1] : keys[2]);
+        if (lane < 3 && key >= 0) {
+          const int idx = (a.npts >= 0) ? key : ((key / a.h) + (key % a.h) * a.w);
+          float px, py, pz, I_ref, var;
+          int maskIdx;
+          fetch_point(a, idx, px, py, pz, I_ref, var, maskIdx);
+          PointOut o;
+          eval_point(a, px, py, pz, I_ref, var, o);
+          float* sub = s_sub[lane];
+          sub[0] = o.werr;
+          int k = 1;
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            float Jw = o.J[r] * o.w;
+#pragma unroll
+            for (int c = r; c < 6; c++) sub[k++] = Jw * o.J[c];
+          }
+          float resw = o.res * o.w;
+#pragma unroll
+          for (int r = 0; r < 6; r++) sub[k++] = resw * o.J[r];
+          sub[k++] = resw * o.res;
+        }
+      }
     }
     __syncthreads();
-    if (S.done) {
-      if (blockIdx.x == 0) {
-        unsigned* dst = (unsigned*)next;
-        const unsigned* src = (const unsigned*)&S;
-        for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
+    PHASE_MARK(2);
+    if (tid < 64) {
+      // column totals, tail-drop correction and LGS6::finish, one column per lane
+      float Mf = s_sum[0][RS_M];
+#pragma unroll
+      for (int k = 1; k < NSLICE; k++) Mf += s_sum[k][RS_M];
+      float s = 0.f;
+      if (tid < RS_END) {
+        s = s_sum[0][tid];
+#pragma unroll
+        for (int k = 1; k < NSLICE; k++) s += s_sum[k][tid];
       }
+      const int M = (int)Mf;
+      int need = M & 3;
+      if (need > s_nsub) need = s_nsub;
+      // RS_WERR -> 0, RS_A0.. -> 1..21, RS_B0.. -> 22..27, RS_ERR -> 28
+      const int subIdx = (tid == RS_WERR) ? 0 : ((tid >= RS_A0 && tid < RS_B0) ? 1 + tid - RS_A0 : ((tid >= RS_B0 && tid < RS_ERR) ? 22 + tid - RS_B0 : (tid == RS_ERR ? 28 : -1)));
+      if (subIdx >= 0)
+        for (int k = 0; k < need; k++) s -= s_sub[k][subIdx];
+      if (tid < RS_NUM) sh.tot[tid] = s;
+      const float n = (float)((size_t)6 * (size_t)(M >> 2));
+      if (tid >= RS_A0 && tid < RS_B0) sh.norm[tid - RS_A0] = (0.0f + s) / n;
+      if (tid >= RS_B0 && tid < RS_ERR) sh.norm[21 + tid - RS_B0] = (0.0f - s) / n;
+    }
+    __syncthreads();
+    PHASE_MARK(3);
+    if (tid == 0) {
+      TrackState s = S;
+      lm_advance(s_par, s, sh, blockIdx.x == 0 ? out : nullptr);
+      s.pending = 0;
+      S = s;
+    }
+    __syncthreads();
+    PHASE_MARK(4);
+    if (S.done) {
+      if (blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
       return;
     }
   }
 
   // ---- residual evaluation at S.level / S.R, S.t ------------------------------------------------------------------
   const int level = S.level;
-  if (blockIdx.x == 0) {
-    __syncthreads();
-    if (tid == 0) S.pending = 1;
-    __syncthreads();
-    unsigned* dst = (unsigned*)next;
-    const unsigned* src = (const unsigned*)&S;
-    for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += RES_BLOCK) dst[i] = src[i];
-  }
-  if ((int)blockIdx.x >= job.lv[level].nblocks) return;
+  if (tid == 0) S.pending = 1;
+  const int nb = job.lv[level].nblocks;
+  if ((int)blockIdx.x >= nb) return;   // workgroup 0 always has work: it publishes the state at the end
+  const int tile = xcd_tile(blockIdx.x, nb);
   EvalCtx a;
-  make_ctx(job, S, level, a);
+  make_ctx_dev(job, S, level, a);
   uint8_t* wasGood = job.lv[level].writeMask ? job.wasGood : nullptr;
-  float acc[RS_NUM];
+  const int work = a.npts >= 0 ? a.npts : a.w * a.h;
+  float acc[RS_END];
 #pragma unroll
-  for (int k = 0; k < RS_NUM; k++) acc[k] = 0.f;
+  for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
   int key0 = -1, key1 = -1, key2 = -1;   // reference-order keys of this lane's in-image points (descending)
 
-#pragma unroll
-  for (int p = 0; p < RES_PPT; p++) {
-    const int i = blockIdx.x * RES_TILE + p * RES_BLOCK + tid;
+  for (int i = tile * BLOCK + tid; i < work; i += nb * BLOCK) {
     float px, py, pz, I_ref, var;
     int maskIdx;
     if (fetch_point(a, i, px, py, pz, I_ref, var, maskIdx)) {
@@ -606,41 +742,59 @@ __global__ __launch_bounds__(RES_BLOCK) void k_track_step(TrackJob job, TrackSta
     }
   }
 
-  const int wave = tid >> 6, lane = tid & 63;
-  __syncthreads();   // s_sum is reused as the per-wave staging area
+  PHASE_MARK(5);
+#ifdef LSD_PHASE_TRACE
+  if (blockIdx.x == 0 && tid == 0) { tr_[10] = (unsigned long long)level; tr_[11] = (unsigned long long)nb; }
+#endif
+  // workgroup reduction through LDS: every lane parks its 41 accumulators in column `tid` of s_red (row stride
+  // BLOCK + 1: conflict-free both ways), then thread (slice, k) adds a contiguous run of lanes of row k in lane order
+  // and 41 threads add the slices — ~130 instructions per wave instead of 41 x 7 DPP steps
+  constexpr int RSLICE = BLOCK / RS_END;              // slices per row
+  constexpr int RRUN = (BLOCK + RSLICE - 1) / RSLICE;  // lanes per slice
 #pragma unroll
-  for (int k = 0; k < RS_END; k++) {
-    float s = wave_sum_to_lane63(acc[k]);
-    if (lane == 63) s_sum[wave][k] = s;
+  for (int k = 0; k < RS_END; k++) s_red[k * (BLOCK + 1) + tid] = acc[k];
+  __syncthreads();
+  {
+    const int slice = tid / RS_END, k = tid - slice * RS_END;
+    if (slice < RSLICE) {
+      const float* row = s_red + k * (BLOCK + 1);
+      const int j0 = slice * RRUN;
+      float v[RRUN];
+#pragma unroll
+      for (int j = 0; j < RRUN; j++) v[j] = row[j0 + j];   // unconditional: the run may spill 2 words into the next row (allocated)
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < RRUN; j++) s += (j0 + j < BLOCK) ? v[j] : 0.f;
+      s_sum[slice][k] = s;
+    }
   }
   __syncthreads();
   if (tid < RS_END) {
     float s = s_sum[0][tid];
 #pragma unroll
-    for (int wv = 1; wv < RES_BLOCK / 64; wv++) s += s_sum[wv][tid];
-    partials_out[(size_t)blockIdx.x * RS_NUM + tid] = s;
+    for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
+    sums_out[(size_t)tid * max_rows + tile] = s;
   }
   block_top3(key0, key1, key2, s_wtop, s_top);
-  if (tid < 3) partials_out[(size_t)blockIdx.x * RS_NUM + RS_TOP0 + tid] = __int_as_float(s_top[tid]);
-}
-
-// initial state of a job (one lane): pose, level, affine parameters; both state buffers
-__global__ void k_lm_init(TrackState* st2, lsdm::SE3fH T0, int level, float aff_a, float aff_b, TrackSummary* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  TrackState s;
-  s.T = T0;
-  set_eval_pose(s, T0);
-  s.aff_a = aff_a; s.aff_b = aff_b; s.aff_a_lastIt = aff_a; s.aff_b_lastIt = aff_b;
-  s.lastErr = 0; s.LM_lambda = 0; s.last_residual = 0;
-  s.level = level; s.iteration = 0; s.incTry = 0; s.phase = 0; s.pending = 0;
-  for (int i = 0; i < 36; i++) s.A[i] = 0;
-  for (int i = 0; i < 6; i++) { s.b[i] = 0; s.inc[i] = 0; }
-  s.done = 0; s.diverged = 0; s.numEvaluations = 0; s.numWarpUpdates = 0;
-  s.pointUsage = 0; s.goodCount = 0; s.badCount = 0; s.meanRes = 0;
-  s.bytes = 0;
-  st2[0] = s;
-  st2[1] = s;
-  out->done = 0;
+  if (tid == 0) topkey_out[tile] = make_int4(s_top[0], s_top[1], s_top[2], -1);
+  if (job.lv[level].singlePass && key0 >= 0) {
+    // one point per lane: its accumulators are exactly its K2/K3 contributions (0 + x == x)
+    const int r = key0 == s_top[0] ? 0 : (key0 == s_top[1] ? 1 : (key0 == s_top[2] ? 2 : -1));
+    if (r >= 0) {
+      float* dst = topval_out + (size_t)(tile * 3 + r) * 32;
+      dst[0] = acc[RS_WERR];
+#pragma unroll
+      for (int k = 0; k < 21; k++) dst[1 + k] = acc[RS_A0 + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) dst[22 + k] = acc[RS_B0 + k];
+      dst[28] = acc[RS_ERR];
+    }
+  }
+  if (blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // S.pending was set before the barriers above
+  PHASE_MARK(6);
+#ifdef LSD_PHASE_TRACE
+  if (blockIdx.x == 0 && tid == 0) tr_[9] = wall_clock64();
+#endif
 }
 
 // checkPermaRefOverlap (SE3Tracker.cpp:121-157): usage only, explicit point list
@@ -680,9 +834,26 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
     t->convergenceEps[l] = 0.999f;
     t->maxItsPerLvl[l] = maxIterations[l];
   }
-  t->max_blocks = (c->w * c->h + RES_TILE - 1) / RES_TILE;
-  HIPCHK(hipMalloc((void**)&t->d_partials, (size_t)2 * t->max_blocks * RS_NUM * sizeof(float)));
+  if (const char* e = getenv("LSDHIP_TRACK_BLOCK")) t->block = atoi(e);
+  if (const char* e = getenv("LSDHIP_TRACK_CAP")) t->grid_cap = atoi(e);
+  if (t->block != 256) { lsd_set_error("LSDHIP_TRACK_BLOCK must be 256"); delete t; return LSDHIP_E_ARG; }
+  if (t->grid_cap < 8) t->grid_cap = 8;
+  t->grid_cap &= ~7;
+  {
+    // rows per column slice must fit the 20 float4 loads of the column-sum phase: 80 rows x NSLICE slices
+    const int nslice = ((t->block / 64 - 1) * 64) / RS_END;
+    if (t->grid_cap > 80 * nslice) t->grid_cap = (80 * nslice) & ~7;
+  }
+  t->max_blocks = t->grid_cap;
+  const size_t rows = (size_t)t->max_blocks;
+  const size_t scratch_bytes = 2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4;
+  HIPCHK(hipMalloc((void**)&t->d_partials, scratch_bytes));
+  HIPCHK(hipMemsetAsync(t->d_partials, 0, scratch_bytes, c->stream));
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
+#ifdef LSD_PHASE_TRACE
+  HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 12) * 8));
+  HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 12) * 8, c->stream));
+#endif
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
   memset(t->h_summary, 0, sizeof(TrackSummary));
@@ -695,6 +866,22 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
+#ifdef LSD_PHASE_TRACE
+  if (const char* path = getenv("LSDHIP_TRACE_FILE")) {
+    std::vector<unsigned long long> h(1 + 4096 * 12);
+    if (hipMemcpy(h.data(), t->d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE* f = fopen(path, "w")) {
+        unsigned long long n = h[0] < 4096 ? h[0] : 4096;
+        for (unsigned long long i = 0; i < n; i++) {
+          for (int k = 0; k < 12; k++) fprintf(f, "%llu ", h[1 + i * 12 + k]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    }
+  }
+  (void)hipFree(t->d_trace);
+#endif
   (void)hipFree(t->d_partials);
   (void)hipFree(t->d_state);
   (void)hipHostFree(t->h_summary);
@@ -727,8 +914,11 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
     L.pts_pos = L.pts_colvar = nullptr; L.npts = -1;
   }
   int work = npts >= 0 ? npts : L.w * L.h;
-  L.nblocks = (work + RES_TILE - 1) / RES_TILE;
+  L.nblocks = (work + t->block - 1) / t->block;
+  if (L.nblocks >= 16) L.nblocks = (L.nblocks + 7) & ~7;   // multiples of 8: one contiguous band of tiles per XCD
+  if (L.nblocks > t->grid_cap) L.nblocks = t->grid_cap;     // larger levels grid-stride
   if (L.nblocks < 1) L.nblocks = 1;
+  L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
   L.lambdaInitial = t->lambdaInitial[level]; L.stepSizeMin = t->stepSizeMin[level]; L.convergenceEps = t->convergenceEps[level];
   L.maxIts = t->maxItsPerLvl[level];
   L.minWarped = MIN_GOODPERALL_PIXEL_ABSMIN * (c->w >> level) * (c->h >> level);
@@ -745,26 +935,33 @@ static void fill_job_common(lsdhip_tracker* t, TrackJob& job) {
   job.useAffine = c->params.useAffineLightningEstimation;
 }
 
-// launch `steps` fused k_track_step kernels (alternating parity); grid = the largest level the job can still visit.
-// With profiling on, every launch is bracketed by its own HIP event pair on the context's stream.
-static int launch_steps(lsdhip_tracker* t, const TrackJob& job, int topLevel, int steps, int* parity) {
+static TrackScratch scratch_of(lsdhip_tracker* t) {
+  TrackScratch sc;
+  const size_t rows = (size_t)t->max_blocks;
+  sc.sums = t->d_partials;
+  sc.topkey = (int4*)(t->d_partials + 2 * RS_COLS * rows);
+  sc.topval = t->d_partials + 2 * RS_COLS * rows + 2 * 4 * rows;
+  sc.max_rows = t->max_blocks;
+#ifdef LSD_PHASE_TRACE
+  sc.trace = t->d_trace;
+#endif
+  return sc;
+}
+static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int parity, int first) {
   lsdhip_ctx* c = t->ctx;
+  TrackScratch sc = scratch_of(t);
+  hipLaunchKernelGGL(k_track_step<256>, dim3(grid), dim3(256), 0, c->stream, job, t->d_state, sc, t->d_summary, parity, first);
+}
+// launch `steps` fused k_track_step kernels (alternating parity); grid = the largest level the job can still visit.
+static int launch_steps(lsdhip_tracker* t, const TrackJob& job, int steps, int* parity, int* first) {
   int grid = 1;
-  for (int l = job.lastLevel; l <= topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
-  if (c->prof_on) {
-    while ((int)c->prof_events.size() < 2 * steps) {
-      hipEvent_t e;
-      HIPCHK(hipEventCreate(&e));
-      c->prof_events.push_back(e);
-    }
-  }
+  for (int l = job.lastLevel; l <= job.topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
   for (int i = 0; i < steps; i++) {
-    if (c->prof_on) HIPCHK(hipEventRecord(c->prof_events[2 * i], c->stream));
-    hipLaunchKernelGGL(k_track_step, dim3(grid), dim3(RES_BLOCK), 0, c->stream, job, t->d_state, t->d_partials, t->max_blocks,
-                       t->d_summary, *parity);
-    if (c->prof_on) HIPCHK(hipEventRecord(c->prof_events[2 * i + 1], c->stream));
+    launch_step(t, job, grid, *parity, *first);
+    *first = 0;
     *parity ^= 1;
   }
+  HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }
 
@@ -781,13 +978,15 @@ static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T,
   lsdhip_ctx* c = t->ctx;
   job.evalOnly = 1;
   job.lastLevel = level;
-  hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, t->d_state, T, level, t->affineEstimation_a, t->affineEstimation_b, t->d_summary);
+  job.topLevel = level;
+  job.T0 = T;
+  job.aff_a0 = t->affineEstimation_a; job.aff_b0 = t->affineEstimation_b;
+  t->h_summary->done = 0;
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
-  hipLaunchKernelGGL(k_track_step, dim3(job.lv[level].nblocks), dim3(RES_BLOCK), 0, c->stream, job, t->d_state, t->d_partials,
-                     t->max_blocks, t->d_summary, 0);   // residual evaluation
+  launch_step(t, job, job.lv[level].nblocks, 0, 1);   // residual evaluation
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_b, c->stream));
-  hipLaunchKernelGGL(k_track_step, dim3(1), dim3(RES_BLOCK), 0, c->stream, job, t->d_state, t->d_partials, t->max_blocks,
-                     t->d_summary, 1);                  // finalises the sums (evalOnly)
+  launch_step(t, job, 1, 1, 0);                       // finalises the sums (evalOnly)
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   const TrackSummary* S = t->h_summary;
   const float* r = S->sums;
@@ -876,37 +1075,49 @@ static int lm_level_host(lsdhip_tracker* t, TrackJob& job, int lvl, lsdm::SE3fH&
   return LSDHIP_OK;
 }
 
-// device-resident LM over levels topLevel..job.lastLevel; one host synchronisation per budget of evaluations
+// device-resident LM over levels topLevel..job.lastLevel; one host synchronisation per budget of launches.  The budget
+// is the previous job's launch count (evaluations + the finalising step) plus a margin, so that few steps run empty.
+// With profiling on, the whole budget is bracketed by one HIP event pair on the context's stream and charged to the
+// launches that did work.
 static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const lsdm::SE3fH& T0, lsdm::SE3fH* Tout) {
   lsdhip_ctx* c = t->ctx;
   job.evalOnly = 0;
-  hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, t->d_state, T0, topLevel, 1.0f, 0.0f, t->d_summary);
+  job.topLevel = topLevel;
+  job.T0 = T0;
+  job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
+  t->h_summary->done = 0;
   const TrackSummary* S = t->h_summary;
+  // launches a job needs = its evaluations + the finalising step; budget = the most of the recent jobs + 1
   int budget = 26;
+  if (t->recent[0] > 0) {
+    budget = 0;
+    for (int i = 0; i < 4; i++) if (t->recent[i] > budget) budget = t->recent[i];
+    budget += 2;
+  }
   int guard = 0;
-  int parity = 0;
+  int parity = 0, first = 1;
+  int launched = 0;
   while (true) {
-    int rc = launch_steps(t, job, topLevel, budget, &parity);
+    if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    int rc = launch_steps(t, job, budget, &parity, &first);
     if (rc) return rc;
+    if (c->prof_on) HIPCHK(hipEventRecord(c->ev_b, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    launched += budget;
     if (c->prof_on) {
-      // only the launches that did work count (pairs enqueued after the job finished return immediately)
-      int evalsNow = 0;
-      HIPCHK(hipMemcpy(&evalsNow, &t->d_state[parity].numEvaluations, sizeof(int), hipMemcpyDeviceToHost));
-      int ran = evalsNow - t->numEvaluations + 1;   // launches that did work (one more than completed evaluations)
-      for (int i = 0; i < ran && i < budget; i++) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
-        c->prof_ms += ms;
-        c->prof_launches++;
-      }
-      t->numEvaluations = evalsNow;
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+      c->prof_ms += ms;
     }
     if (S->done) break;
-    budget = 8;
+    budget = 6;
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
   }
-  if (c->prof_on) c->prof_bytes += S->bytes;
+  if (c->prof_on) {
+    c->prof_bytes += S->bytes;
+    c->prof_launches += S->numEvaluations;
+  }
+  t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = S->numEvaluations;
   t->numEvaluations = S->numEvaluations;
   t->numWarpUpdates = S->numWarpUpdates;
   t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;
@@ -1027,8 +1238,7 @@ extern "C" int lsdhip_tracker_track_permaref(lsdhip_tracker* t, const float* pos
   if (!t || !pos || !colvar || n <= 0 || !frame || !refToFrame || !out) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   HIPCHK(hipSetDevice(c->device));
-  if ((n + RES_TILE - 1) / RES_TILE > t->max_blocks) return LSDHIP_E_CAPACITY;
-  int rc = upload_points(t, pos, colvar, n);
+    int rc = upload_points(t, pos, colvar, n);
   if (rc) return rc;
   lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_from7(refToFrame));
   t->affineEstimation_a = 1; t->affineEstimation_b = 0;
