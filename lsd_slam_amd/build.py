@@ -11,9 +11,35 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblsdhip.so")
 SOURCES = ["host_math.cpp", "frame.hip", "tracker.hip", "depthmap.hip"]
+# -disable-promote-alloca-to-lds: a private array the optimiser cannot split must show up as scratch (and fail the
+# guard below) instead of silently moving to LDS, where indexing it by thread costs a read of the AQL dispatch packet
+# in host memory (~20 us per launch, measured — profiles/r01_notes.md).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-mllvm", "-disable-promote-alloca-to-lds=1", "-Rpass-analysis=kernel-resource-usage",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-Wno-unused-but-set-variable"]
+
+
+def _compile_checked(cmd):
+    """Run hipcc; fail the build if any kernel needs scratch memory (every hot kernel must stay in registers)."""
+    import re
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    diag = [l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l]
+    if diag:
+        sys.stderr.write("\n".join(diag) + "\n")
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    name = None
+    bad = []
+    for l in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", l)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", l)
+        if m and int(m.group(1)) > 0:
+            bad.append((name, int(m.group(1))))
+    if bad:
+        raise RuntimeError("kernels using scratch memory: %r" % bad)
 
 
 def needs_build():
@@ -32,7 +58,7 @@ def build_trace(verbose=False):
     cmd = [hipcc] + FLAGS + ["-DLSD_PHASE_TRACE", "-x", "hip"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    _compile_checked(cmd)
     return out
 
 
@@ -43,7 +69,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc] + FLAGS + ["-x", "hip"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    _compile_checked(cmd)
     return OUT
 
 

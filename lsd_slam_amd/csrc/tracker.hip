@@ -84,10 +84,19 @@ __device__ __forceinline__ void block_top3(int c0, int c1, int c2, int (*s_wave)
   }
   __syncthreads();
 }
+// index of (r, c), c >= r, in the row-major upper triangle of the 6x6 normal matrix, as a constant expression (a running
+// counter keeps the accumulator array from being promoted to registers)
+__device__ __forceinline__ constexpr int tri_index(int r, int c) { return RS_A0 + r * 6 - (r * (r - 1)) / 2 + (c - r); }
+
+// branch-free (a branchy version gets turned into an indexed store, which drags the three keys into scratch memory)
 __device__ __forceinline__ void top3_insert(int k, int& c0, int& c1, int& c2) {
-  if (k > c0) { c2 = c1; c1 = c0; c0 = k; }
-  else if (k > c1) { c2 = c1; c1 = k; }
-  else if (k > c2) { c2 = k; }
+  const int n0 = max(c0, k);
+  int t = min(c0, k);
+  const int n1 = max(c1, t);
+  t = min(c1, t);
+  c2 = max(c2, t);
+  c1 = n1;
+  c0 = n0;
 }
 
 // ---- per-point arithmetic -----------------------------------------------------------------------------------------
@@ -202,13 +211,176 @@ __device__ __forceinline__ bool fetch_point(const EvalCtx& a, int i, float& px, 
   return true;
 }
 
-// ---- Levenberg-Marquardt step (one lane, state held in registers) ---------------------------------------------------
+// ---- Levenberg-Marquardt step, wave-parallel ------------------------------------------------------------------------
+// Runs in wave 0 of every workgroup with all 64 lanes active.  "Uniform" values are computed redundantly by every lane
+// (same inputs, same instructions); the 6x6 factorisation keeps row i of the matrix in lane i and exchanges data with
+// v_readlane; the two sincos evaluations and the four quaternion divisions of a normalisation run in different lanes.
 __device__ __forceinline__ void set_eval_pose(TrackState& s, const lsdm::SE3fH& T) {
   s.Tn = T;
   lsdm::quatf_to_rot(T.q, s.R);
   s.t[0] = T.t[0]; s.t[1] = T.t[1]; s.t[2] = T.t[2];
 }
-__device__ void write_summary(const TrackState& s, const float* tot, TrackSummary* out) {
+__device__ __forceinline__ float rl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// 6x6 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics), arithmetic and operation order exactly those
+// of lsdm::ldlt6_solve (pose_math.hpp) / the oracle's ldlt6_solve.  Lane i < 6 holds row i in m[0..5]; lanes >= 6 carry
+// a copy of row 5 and compute discarded values.  bl = right-hand side, entry j in lane j.  Result x[0..5] uniform.
+// (The right-hand side is deliberately not a local array: a select chain over array elements gets folded into a
+// dynamically indexed load, which drags the array into LDS/scratch and costs a dispatch-packet read per launch.)
+__device__ __forceinline__ void ldlt6_solve_wave(float (&m)[6], const float bl, const int lane, float (&x)[6]) {
+  int perm = lane;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float dg = m[0];
+#pragma unroll
+    for (int j = 1; j < 6; j++) dg = (lane == j) ? m[j] : dg;
+    const float ad = fabsf(dg);
+    int piv = k;
+    float best = rl(ad, k);
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const float v = rl(ad, i);
+      const bool g = v > best;
+      best = g ? v : best;
+      piv = g ? i : piv;
+    }
+    piv = __builtin_amdgcn_readfirstlane(piv);
+    if (piv != k) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const float a = rl(m[c], k), b = rl(m[c], piv);
+        m[c] = (lane == k) ? b : ((lane == piv) ? a : m[c]);
+      }
+      {
+        const int a = rli(perm, k), b = rli(perm, piv);
+        perm = (lane == k) ? b : ((lane == piv) ? a : perm);
+      }
+#pragma unroll
+      for (int i = k + 1; i < 6; i++) {
+        const bool c = (piv == i);
+        const float t = m[k];
+        m[k] = c ? m[i] : m[k];
+        m[i] = c ? t : m[i];
+      }
+    }
+    float v = m[k];
+#pragma unroll
+    for (int j = 0; j < k; j++) {
+      const float Lkj = rl(m[j], k), Dj = rl(m[j], j);
+      v -= (m[j] * Lkj) * Dj;
+    }
+    const float d = rl(v, k);
+    const float q = (d != 0.0f) ? v / d : 0.0f;
+    m[k] = (lane == k) ? d : ((lane > k) ? q : m[k]);
+  }
+  float y = rl(bl, 0);
+#pragma unroll
+  for (int j = 1; j < 6; j++) { const float bj = rl(bl, j); y = (perm == j) ? bj : y; }
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const float yj = rl(y, j);
+    const float t = y - m[j] * yj;
+    y = (lane > j) ? t : y;
+  }
+  {
+    float dg = m[0];
+#pragma unroll
+    for (int j = 1; j < 6; j++) dg = (lane == j) ? m[j] : dg;
+    y = (dg != 0.0f) ? y / dg : 0.0f;
+  }
+#pragma unroll
+  for (int i = 4; i >= 0; i--) {
+    const float prod = m[i] * y;
+    float acc = rl(y, i);
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) acc -= rl(prod, j);
+    y = (lane == i) ? acc : y;
+  }
+  float xl = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int pi = rli(perm, i);
+    const float yi = rl(y, i);
+    xl = (pi == lane) ? yi : xl;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) x[j] = rl(xl, j);
+}
+
+// Quaternion normalisation, the four divisions in four lanes (lsdm::q_normalize arithmetic)
+__device__ __forceinline__ void q_normalize_wave(lsdm::Quatf& q, const int lane) {
+  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const float c = (lane & 3) == 0 ? q.w : ((lane & 3) == 1 ? q.x : ((lane & 3) == 2 ? q.y : q.z));
+  const float r = c / n;
+  q.w = rl(r, 0); q.x = rl(r, 1); q.y = rl(r, 2); q.z = rl(r, 3);
+}
+
+// Sophus SE3Group<float>::exp (lsdm::se3f_exp arithmetic), sincos(theta/2) in even lanes and sincos(theta) in odd lanes
+__device__ __forceinline__ lsdm::SE3fH se3f_exp_wave(const float (&a)[6], const int lane) {
+  const float eps = static_cast<float>(1e-5);
+  const float ox = a[3], oy = a[4], oz = a[5];
+  const float theta_sq = ox * ox + (oy * oy + oz * oz);
+  const float theta = sqrtf(theta_sq);
+  const float half_theta = 0.5f * theta;
+  float sn, cs;
+  sincosf((lane & 1) ? theta : half_theta, &sn, &cs);
+  const float sin_half = rl(sn, 0), cos_half = rl(cs, 0), sin_theta = rl(sn, 1), cos_theta = rl(cs, 1);
+  float imag, real;
+  if (theta < eps) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag = 0.5f - static_cast<float>(1.0 / 48.0) * theta_sq + static_cast<float>(1.0 / 3840.0) * theta_po4;
+    real = 1.0f - 0.5f * theta_sq + static_cast<float>(1.0 / 384.0) * theta_po4;
+  } else {
+    imag = sin_half / theta;
+    real = cos_half;
+  }
+  lsdm::SE3fH r;
+  r.q = {real, imag * ox, imag * oy, imag * oz};
+  q_normalize_wave(r.q, lane);
+  const float Om[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+  float Om2[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float acc = Om[i * 3 + 0] * Om[0 * 3 + j];
+      acc += Om[i * 3 + 1] * Om[1 * 3 + j];
+      acc += Om[i * 3 + 2] * Om[2 * 3 + j];
+      Om2[i * 3 + j] = acc;
+    }
+  float V[9];
+  if (theta < eps) {
+    lsdm::q_to_rot<lsdm::Quatf, float>(r.q, V);
+  } else {
+    const float tsq = theta * theta;
+    const float ca = (1.0f - cos_theta) / tsq;
+    const float cb = (theta - sin_theta) / (tsq * theta);
+#pragma unroll
+    for (int i = 0; i < 9; i++) V[i] = (((i % 4) == 0 ? 1.0f : 0.0f) + ca * Om[i]) + cb * Om2[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float acc = V[i * 3 + 0] * a[0];
+    acc += V[i * 3 + 1] * a[1];
+    acc += V[i * 3 + 2] * a[2];
+    r.t[i] = acc;
+  }
+  return r;
+}
+// Sophus operator*: fastMultiply + normalize (lsdm::se3f_mul arithmetic)
+__device__ __forceinline__ lsdm::SE3fH se3f_mul_wave(const lsdm::SE3fH& a, const lsdm::SE3fH& b, const int lane) {
+  lsdm::SE3fH r = a;
+  float rt[3];
+  lsdm::q_rotate<lsdm::Quatf, float>(a.q, b.t, rt);
+#pragma unroll
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+  r.q = lsdm::q_mul(a.q, b.q);
+  q_normalize_wave(r.q, lane);
+  return r;
+}
+
+__device__ __forceinline__ void write_summary(const TrackState& s, const float* tot, TrackSummary* out) {
   out->diverged = s.diverged; out->level = s.level; out->numEvaluations = s.numEvaluations; out->numWarpUpdates = s.numWarpUpdates;
   out->q[0] = s.T.q.w; out->q[1] = s.T.q.x; out->q[2] = s.T.q.y; out->q[3] = s.T.q.z;
   out->t[0] = s.T.t[0]; out->t[1] = s.T.t[1]; out->t[2] = s.T.t[2];
@@ -220,80 +392,10 @@ __device__ void write_summary(const TrackState& s, const float* tot, TrackSummar
   out->done = s.done;
 }
 
-// 6x6 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics) on register arrays: every index is a compile-time
-// constant and the pivot swaps are conditional register exchanges, so nothing goes to scratch or LDS.  One reciprocal
-// per pivot instead of one division per entry (the LM increment is tolerance-level data).
-__device__ __forceinline__ void cswap(bool c, float& a, float& b) { float t = a; a = c ? b : a; b = c ? t : b; }
-__device__ __forceinline__ void ldlt6_solve_reg(float (&M)[6][6], const float (&bin)[6], float (&x)[6]) {
-  int p[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) p[i] = i;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    int piv = k;
-    float big = fabsf(M[k][k]);
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) { float v = fabsf(M[i][i]); if (v > big) { big = v; piv = i; } }
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      const bool c = (piv == i);
-      // only the lower triangle is referenced below: swap rows k,i and columns k,i of the symmetric matrix
-#pragma unroll
-      for (int j = 0; j < 6; j++) cswap(c, M[k][j], M[i][j]);
-#pragma unroll
-      for (int r = 0; r < 6; r++) cswap(c, M[r][k], M[r][i]);
-      int tp = p[k]; p[k] = c ? p[i] : p[k]; p[i] = c ? tp : p[i];
-    }
-    float d = M[k][k];
-#pragma unroll
-    for (int j = 0; j < k; j++) d -= M[k][j] * M[k][j] * M[j][j];
-    M[k][k] = d;
-    const float rd = d != 0.0f ? 1.0f / d : 0.0f;
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      float v = M[i][k];
-#pragma unroll
-      for (int j = 0; j < k; j++) v -= M[i][j] * M[k][j] * M[j][j];
-      M[i][k] = v * rd;
-    }
-  }
-  float y[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < 6; j++) v = (p[i] == j) ? bin[j] : v;
-    y[i] = v;
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-#pragma unroll
-    for (int j = 0; j < i; j++) y[i] -= M[i][j] * y[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) y[i] = M[i][i] != 0.0f ? y[i] / M[i][i] : 0.0f;
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-#pragma unroll
-    for (int j = i + 1; j < 6; j++) y[i] -= M[j][i] * y[j];
-  }
-#pragma unroll
-  for (int j = 0; j < 6; j++) {
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; i++) v = (p[i] == j) ? y[i] : v;
-    x[j] = v;
-  }
-}
-
-// What the workgroup hands to the LM lane: corrected raw sums of the evaluation (LDS) and the normalised normal
-// equations (LGS6::finish: A / n, b / n with the SSE constraint count n = 6 * (M / 4), LGSX.h:319-325, :385), 21 + 6
-// values computed by 27 lanes in parallel.
 struct LmShared {
-  float tot[RS_NUM];
-  float norm[27];
+  float tot[RS_NUM];   // corrected raw sums of the evaluation being finished (what the summary reports)
 };
-// Job parameters the LM lane needs, staged in LDS by an otherwise idle lane while the partial sums are being added
+// Job parameters the LM wave needs, staged in LDS by an otherwise idle lane while the partial sums are being added
 // (fetched field by field from the kernel-argument segment they cost one scalar-cache round trip each).
 struct LmPar {
   float lambdaInitial, stepSizeMin, convergenceEps, minWarped, lambdaSuccessFac, lambdaFailFac;
@@ -309,128 +411,161 @@ __device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmP
   p = v;
 }
 
-// The control flow of SE3Tracker::trackFrame between two evaluations (SE3Tracker.cpp:324-447), run by one lane of every
+// The control flow of SE3Tracker::trackFrame between two evaluations (SE3Tracker.cpp:324-447), run by wave 0 of every
 // workgroup on identical inputs (so every workgroup reaches the same decision without talking to the others).
+//   col  : this lane's column total of the evaluation's raw sums, tail-drop corrected (lane c < RS_END <-> column c)
+//   S    : the job state in LDS (read and updated in place; every lane writes the same values)
+//   tot  : LDS copy of the corrected sums (what the summary reports)
 // `out` is non-null in workgroup 0 only.
-__device__ __forceinline__ void lm_advance(const LmPar& par, TrackState& s, const LmShared& sh, TrackSummary* out) {
-  const float* tot = sh.tot;
+#ifdef LSD_PHASE_TRACE
+#define LM_MARK(k) do { if (trp && lane == 0) trp[k] = clock64(); } while (0)
+#else
+#define LM_MARK(k) do { } while (0)
+#endif
+__device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const float col, const float* tot, const int lane,
+                                        TrackSummary* out, unsigned long long* trp) {
   const LmPar L = par;
   const int maxIts = L.maxIts;
   // calcResidualAndBuffers epilogue (:1016-1028)
-  const int M = (int)tot[RS_M];
-  const float refNum = tot[RS_NREF];
-  const float goodCount = tot[RS_GOOD], badCount = tot[RS_BAD];
-  s.pointUsage = tot[RS_USAGE] / refNum;
-  s.goodCount = goodCount;
-  s.badCount = badCount;
-  s.meanRes = tot[RS_SUMSIGNED] / goodCount;
+  const int M = (int)rl(col, RS_M);
+  const float refNum = rl(col, RS_NREF);
+  const float goodCount = rl(col, RS_GOOD), badCount = rl(col, RS_BAD);
+  float aff_a_lastIt, aff_b_lastIt;
   {
-    const float sxx = tot[RS_SXX], syy = tot[RS_SYY], sx = tot[RS_SX], sy = tot[RS_SY], sw = tot[RS_SW];
-    s.aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
-    s.aff_b_lastIt = (sy - s.aff_a_lastIt * sx) / sw;
+    const float sxx = rl(col, RS_SXX), syy = rl(col, RS_SYY), sx = rl(col, RS_SX), sy = rl(col, RS_SY), sw = rl(col, RS_SW);
+    aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
+    aff_b_lastIt = (sy - aff_a_lastIt * sx) / sw;
   }
-  s.numEvaluations++;
+  S.pointUsage = rl(col, RS_USAGE) / refNum;
+  S.goodCount = goodCount;
+  S.badCount = badCount;
+  S.meanRes = rl(col, RS_SUMSIGNED) / goodCount;
+  S.aff_a_lastIt = aff_a_lastIt;
+  S.aff_b_lastIt = aff_b_lastIt;
+  S.numEvaluations = S.numEvaluations + 1;
   {
     // algorithmic bytes of this evaluation: 20 N + [mask] 5 N + 12 min(w h, 4 N)
-    float N = refNum, wh = (float)L.w * (float)L.h;
-    float texels = 4.0f * N < wh ? 4.0f * N : wh;
-    s.bytes += 20.0f * N + (L.writeMask ? 5.0f * N : 0.0f) + 12.0f * texels;
+    const float N = refNum, wh = (float)L.w * (float)L.h;
+    const float texels = 4.0f * N < wh ? 4.0f * N : wh;
+    S.bytes = S.bytes + (20.0f * N + (L.writeMask ? 5.0f * N : 0.0f) + 12.0f * texels);
   }
-  if (L.evalOnly) { s.done = 1; if (out) write_summary(s, tot, out); return; }
+  S.pending = 0;
+  LM_MARK(12);
+  if (L.evalOnly) { S.done = 1; if (out && lane == 0) write_summary(S, tot, out); return; }
 
   if (M < L.minWarped) {   // :324-329 / :369-374
-    s.diverged = 1; s.done = 1;
-    if (out) write_summary(s, tot, out);
+    S.diverged = 1; S.done = 1;
+    if (out && lane == 0) write_summary(S, tot, out);
     return;
   }
   // calcWeightsAndResidualSSE epilogue (:572-574)
-  const float werr = tot[RS_WERR] / ((M >> 2) << 2);
+  const float werr = rl(col, RS_WERR) / ((M >> 2) << 2);
   const bool useAffine = L.useAffine != 0;
   const bool tfSemantics = L.tfSemantics != 0;
 
+  float LM_lambda = S.LM_lambda, lastErr = S.lastErr;
+  int iteration = S.iteration, incTry = S.incTry;
+  lsdm::SE3fH T = S.T;
   bool propose = false, start_iteration = false, accepted = false;
-  if (s.phase == 0) {
+  if (S.phase == 0) {
     accepted = true;
-    if (useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
-    s.lastErr = werr;
-    s.LM_lambda = L.lambdaInitial;
-    s.iteration = 0;
+    lastErr = werr;
+    LM_lambda = L.lambdaInitial;
+    iteration = 0;
     start_iteration = true;
   } else {
     const float error = werr;
-    if (error < s.lastErr) {
+    if (error < lastErr) {
       accepted = true;
-      s.T = s.Tn;
-      if (useAffine) { s.aff_a = s.aff_a_lastIt; s.aff_b = s.aff_b_lastIt; }
-      if (error / s.lastErr > L.convergenceEps) s.iteration = maxIts;
-      s.lastErr = error;
-      if (tfSemantics) s.last_residual = error;
-      if (s.LM_lambda <= 0.2) s.LM_lambda = 0;
-      else s.LM_lambda *= L.lambdaSuccessFac;
-      s.iteration++;
+      T = S.Tn;
+      S.T = T;
+      if (error / lastErr > L.convergenceEps) iteration = maxIts;
+      lastErr = error;
+      if (tfSemantics) S.last_residual = error;
+      if (LM_lambda <= 0.2) LM_lambda = 0;
+      else LM_lambda *= L.lambdaSuccessFac;
+      iteration++;
       start_iteration = true;
     } else {
-      float incdot = (s.inc[0] * s.inc[0] + (s.inc[1] * s.inc[1] + s.inc[2] * s.inc[2])) +
-                     (s.inc[3] * s.inc[3] + (s.inc[4] * s.inc[4] + s.inc[5] * s.inc[5]));
+      const float i0 = S.inc[0], i1 = S.inc[1], i2 = S.inc[2], i3 = S.inc[3], i4 = S.inc[4], i5 = S.inc[5];
+      const float incdot = (i0 * i0 + (i1 * i1 + i2 * i2)) + (i3 * i3 + (i4 * i4 + i5 * i5));
       if (!(incdot > L.stepSizeMin)) {
-        s.iteration = maxIts;
-        s.iteration++;
+        iteration = maxIts;
+        iteration++;
         start_iteration = true;
       } else {
-        if (s.LM_lambda == 0) s.LM_lambda = 0.2;
+        if (LM_lambda == 0) LM_lambda = 0.2;
         else {
           double p = 1.0;
-          for (int i = 0; i < s.incTry; i++) p *= (double)L.lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
-          s.LM_lambda = (float)((double)s.LM_lambda * p);
+          for (int i = 0; i < incTry; i++) p *= (double)L.lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
+          LM_lambda = (float)((double)LM_lambda * p);
         }
         propose = true;
       }
     }
   }
-  if (start_iteration) {
-    if (accepted) {
-      // the accepted (or first) evaluation's normal equations are what calculateWarpUpdate would build next
-      int k = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++, k++) {
-          float v = sh.norm[k];
-          s.A[i * 6 + j] = v;
-          s.A[j * 6 + i] = v;
-        }
-#pragma unroll
-      for (int i = 0; i < 6; i++) s.b[i] = sh.norm[21 + i];
+  if (accepted) {
+    if (useAffine) { S.aff_a = aff_a_lastIt; S.aff_b = aff_b_lastIt; }
+    // the accepted (or first) evaluation's normal equations are what calculateWarpUpdate would build next: LGS6::finish
+    // (A / n, b / n with the SSE constraint count n = 6 (M / 4), LGSX.h:319-325, :385), one entry per lane
+    const float n = (float)((size_t)6 * (size_t)(M >> 2));
+    const int k = lane - RS_A0;
+    if (k >= 0 && k < 21) {
+      const int i = (k >= 6) + (k >= 11) + (k >= 15) + (k >= 18) + (k >= 20);
+      const int j = k - (i * 6 - (i * (i - 1)) / 2) + i;
+      const float v = (0.0f + col) / n;
+      S.A[i * 6 + j] = v;
+      S.A[j * 6 + i] = v;
     }
-    if (s.iteration < maxIts) { s.numWarpUpdates++; s.incTry = 0; propose = true; }
+    if (lane >= RS_B0 && lane < RS_B0 + 6) S.b[lane - RS_B0] = (0.0f - col) / n;
   }
+  if (start_iteration && iteration < maxIts) { S.numWarpUpdates = S.numWarpUpdates + 1; incTry = 0; propose = true; }
+  S.lastErr = lastErr;
+  S.LM_lambda = LM_lambda;
+  S.iteration = iteration;
+  LM_MARK(13);
   if (propose) {
-    float Mx[6][6], bneg[6], inc[6];
-    const float damp = 1 + s.LM_lambda;
+    const int ri = lane < 6 ? lane : 5;
+    float m[6], inc[6];
+    const float damp = 1 + LM_lambda;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-#pragma unroll
-      for (int j = 0; j < 6; j++) Mx[i][j] = s.A[i * 6 + j];
-      Mx[i][i] *= damp;
-      bneg[i] = -s.b[i];
+    for (int j = 0; j < 6; j++) {
+      const float v = S.A[ri * 6 + j];
+      m[j] = (j == ri) ? v * damp : v;
     }
-    ldlt6_solve_reg(Mx, bneg, inc);
-    s.incTry++;
+    const float bl = -S.b[ri];
+    LM_MARK(14);
+    ldlt6_solve_wave(m, bl, lane, inc);
+    LM_MARK(15);
+    S.incTry = incTry + 1;
 #pragma unroll
-    for (int i = 0; i < 6; i++) s.inc[i] = inc[i];
-    set_eval_pose(s, lsdm::se3f_mul(lsdm::se3f_exp(inc), s.T));
-    s.phase = 1;
+    for (int i = 0; i < 6; i++) S.inc[i] = inc[i];
+    const lsdm::SE3fH Tn = se3f_mul_wave(se3f_exp_wave(inc, lane), T, lane);
+    S.Tn = Tn;
+    float R[9];
+    lsdm::quatf_to_rot(Tn.q, R);
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.R[i] = R[i];
+    S.t[0] = Tn.t[0]; S.t[1] = Tn.t[1]; S.t[2] = Tn.t[2];
+    S.phase = 1;
+    LM_MARK(16);
     return;
   }
+  S.incTry = incTry;
   // level finished
-  if (!tfSemantics) s.last_residual = s.lastErr;   // trackFrameOnPermaref: lastResidual = lastErr (:265)
-  if (s.level == L.lastLevel) {
-    s.done = 1;
-    if (out) write_summary(s, tot, out);
+  if (!tfSemantics) S.last_residual = lastErr;   // trackFrameOnPermaref: lastResidual = lastErr (:265)
+  if (S.level == L.lastLevel) {
+    S.done = 1;
+    if (out && lane == 0) write_summary(S, tot, out);
   } else {
-    s.level--;
-    s.phase = 0;
-    set_eval_pose(s, s.T);
+    S.level = S.level - 1;
+    S.phase = 0;
+    S.Tn = T;
+    float R[9];
+    lsdm::quatf_to_rot(T.q, R);
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.R[i] = R[i];
+    S.t[0] = T.t[0]; S.t[1] = T.t[1]; S.t[2] = T.t[2];
   }
 }
 
@@ -466,7 +601,7 @@ struct TrackScratch {
   float* topval;   // [2][max_rows][3][32]    K2/K3 contributions of those points (single-pass levels only)
   int max_rows;    // multiple of 4
 #ifdef LSD_PHASE_TRACE
-  unsigned long long* trace;   // [0] = launch counter, then 12 words per launch (developer build only, tools/phase_trace.py)
+  unsigned long long* trace;   // [0] = launch counter, then 20 words per launch (developer build only, tools/phase_trace.py)
 #endif
 };
 #ifdef LSD_PHASE_TRACE
@@ -517,8 +652,8 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob job, TrackState* 
   if (blockIdx.x == 0 && tid == 0) {
     unsigned long long n = sc.trace[0];
     sc.trace[0] = n + 1;
-    tr_ = sc.trace + 1 + (n % 4096) * 12;
-    for (int k = 0; k < 12; k++) tr_[k] = 0;
+    tr_ = sc.trace + 1 + (n % 4096) * 20;
+    for (int k = 0; k < 20; k++) tr_[k] = 0;
     tr_[8] = wall_clock64();
   }
 #endif
@@ -595,10 +730,11 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob job, TrackState* 
           const int ks[3] = {kv[q].x, kv[q].y, kv[q].z};
 #pragma unroll
           for (int rr = 0; rr < 3; rr++) {
-            const int k = ks[rr];
-            if (k > k0) { k2 = k1; e2 = e1; k1 = k0; e1 = e0; k0 = k; e0 = e + rr; }
-            else if (k > k1) { k2 = k1; e2 = e1; k1 = k; e1 = e + rr; }
-            else if (k > k2) { k2 = k; e2 = e + rr; }
+            const int k = ks[rr], ek = e + rr;
+            const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
+            k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? ek : e2);
+            k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? ek : e1);
+            k0 = g0 ? k : k0; e0 = g0 ? ek : e0;
           }
         }
       }
@@ -651,8 +787,8 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob job, TrackState* 
     }
     __syncthreads();
     PHASE_MARK(2);
-    if (tid < 64) {
-      // column totals, tail-drop correction and LGS6::finish, one column per lane
+    if (wave == 0) {
+      // column totals and tail-drop correction, one column per lane; then the LM decision in the same wave
       float Mf = s_sum[0][RS_M];
 #pragma unroll
       for (int k = 1; k < NSLICE; k++) Mf += s_sum[k][RS_M];
@@ -667,20 +803,19 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob job, TrackState* 
       if (need > s_nsub) need = s_nsub;
       // RS_WERR -> 0, RS_A0.. -> 1..21, RS_B0.. -> 22..27, RS_ERR -> 28
       const int subIdx = (tid == RS_WERR) ? 0 : ((tid >= RS_A0 && tid < RS_B0) ? 1 + tid - RS_A0 : ((tid >= RS_B0 && tid < RS_ERR) ? 22 + tid - RS_B0 : (tid == RS_ERR ? 28 : -1)));
-      if (subIdx >= 0)
-        for (int k = 0; k < need; k++) s -= s_sub[k][subIdx];
+      const float sub0 = s_sub[0][subIdx < 0 ? 0 : subIdx], sub1 = s_sub[1][subIdx < 0 ? 0 : subIdx], sub2 = s_sub[2][subIdx < 0 ? 0 : subIdx];
+      if (subIdx >= 0) {
+        if (need > 0) s -= sub0;
+        if (need > 1) s -= sub1;
+        if (need > 2) s -= sub2;
+      }
       if (tid < RS_NUM) sh.tot[tid] = s;
-      const float n = (float)((size_t)6 * (size_t)(M >> 2));
-      if (tid >= RS_A0 && tid < RS_B0) sh.norm[tid - RS_A0] = (0.0f + s) / n;
-      if (tid >= RS_B0 && tid < RS_ERR) sh.norm[21 + tid - RS_B0] = (0.0f - s) / n;
-    }
-    __syncthreads();
-    PHASE_MARK(3);
-    if (tid == 0) {
-      TrackState s = S;
-      lm_advance(s_par, s, sh, blockIdx.x == 0 ? out : nullptr);
-      s.pending = 0;
-      S = s;
+      PHASE_MARK(3);
+#ifdef LSD_PHASE_TRACE
+      lm_wave(s_par, S, s, sh.tot, tid, blockIdx.x == 0 ? out : nullptr, blockIdx.x == 0 ? tr_ : nullptr);
+#else
+      lm_wave(s_par, S, s, sh.tot, tid, blockIdx.x == 0 ? out : nullptr, nullptr);
+#endif
     }
     __syncthreads();
     PHASE_MARK(4);
@@ -727,12 +862,11 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob job, TrackState* 
         else acc[RS_BAD] += 1.f;
         acc[RS_USAGE] += o.usage;
         acc[RS_WERR] += o.werr;
-        int k = RS_A0;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
           float Jw = o.J[r] * o.w;
 #pragma unroll
-          for (int c = r; c < 6; c++) acc[k++] += Jw * o.J[c];
+          for (int c = r; c < 6; c++) acc[tri_index(r, c)] += Jw * o.J[c];
         }
         float resw = o.res * o.w;
 #pragma unroll
@@ -851,8 +985,8 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   HIPCHK(hipMemsetAsync(t->d_partials, 0, scratch_bytes, c->stream));
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
 #ifdef LSD_PHASE_TRACE
-  HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 12) * 8));
-  HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 12) * 8, c->stream));
+  HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 20) * 8));
+  HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 20) * 8, c->stream));
 #endif
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
@@ -868,12 +1002,12 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   (void)hipStreamSynchronize(t->ctx->stream);
 #ifdef LSD_PHASE_TRACE
   if (const char* path = getenv("LSDHIP_TRACE_FILE")) {
-    std::vector<unsigned long long> h(1 + 4096 * 12);
+    std::vector<unsigned long long> h(1 + 4096 * 20);
     if (hipMemcpy(h.data(), t->d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
       if (FILE* f = fopen(path, "w")) {
         unsigned long long n = h[0] < 4096 ? h[0] : 4096;
         for (unsigned long long i = 0; i < n; i++) {
-          for (int k = 0; k < 12; k++) fprintf(f, "%llu ", h[1 + i * 12 + k]);
+          for (int k = 0; k < 20; k++) fprintf(f, "%llu ", h[1 + i * 20 + k]);
           fprintf(f, "\n");
         }
         fclose(f);

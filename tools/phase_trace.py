@@ -33,6 +33,13 @@ if path and os.path.exists(path):
     clk = (full[:, 6] - full[:, 0])
     ghz = np.median(clk / wall)
     print("launches with all phases: %d, shader clock ~%.2f GHz, kernel body %.2f us (median)" % (len(full), ghz, np.median(wall) / 1e3))
+    if a.shape[1] >= 17:
+        lm = full[(full[:, 16] > 0)]
+        if len(lm):
+            e = lm[:, [3, 12, 13, 14, 15, 16]]
+            dd = np.diff(e, axis=1)
+            print("LM (proposing launches, %d): " % len(lm) + ", ".join("%s %.2f us" % (n, np.median(dd[:, k]) / ghz / 1e3) for k, n in
+                  enumerate(["epilogue", "decision+A/b", "matrix load", "LDLT", "exp/mul/store"])))
     for lvl in sorted(set(full[:, 10].astype(int))):
         m = full[:, 10].astype(int) == lvl
         print("level %d (nb=%d, %d launches): " % (lvl, int(full[m][0, 11]), m.sum()) +
