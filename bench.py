@@ -29,6 +29,25 @@ KF_EVERY = 10
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the residual kernel from the committed PMC passes (profiles/rNN_pmc_traffic.json, made by
+    tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, KiB units,
+    FETCH_SIZE doubled on gfx950).  Counters cannot be collected from inside an un-profiled run, so the latest committed
+    summary is reported; None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for name, t in d["kernels"].items():
+            if "k_track_step" in name and t.get("hbm_bytes_per_launch") is not None:
+                return float(t["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(frames, depth0, K, n_frames, w, h):
     """The oracle's timing build (-O3, SSE tracker path, 4 mapping threads) on the same loop, bounded sample."""
     from oracle import pyoracle as po
@@ -171,9 +190,10 @@ def main():
         roofline = None
         if res_launches > 0 and res_ms > 0:
             achieved = (res_bytes / res_launches) / (res_ms / res_launches * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic()
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "k_residual (fused K0+K1+K2+K3)", "launches": int(res_launches),
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                        "kernel": "k_track_step (LM step + fused K0+K1+K2+K3 residual evaluation)", "launches": int(res_launches),
                         "avg_launch_us": res_ms / res_launches * 1e3,
                         "algorithmic_bytes_per_launch": res_bytes / res_launches}
         out = {

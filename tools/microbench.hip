@@ -102,6 +102,18 @@ int main() {
   printf("== back-to-back launch cadence (us per launch, %d launches) ==\n", reps);
   printf("empty kernel 1 WG            : %.2f\n", time_launches(s, reps, [&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (int*)d_out); }));
   printf("empty kernel 152 WG x 512    : %.2f\n", time_launches(s, reps, [&] { hipLaunchKernelGGL(k_empty, dim3(152), dim3(512), 0, s, (int*)d_out); }));
+  {
+    // the same empty kernel as a captured graph of 24 nodes
+    hipGraph_t g; hipGraphExec_t ge;
+    CHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < 24; i++) hipLaunchKernelGGL(k_empty, dim3(152), dim3(256), 0, s, (int*)d_out);
+    CHK(hipStreamEndCapture(s, &g));
+    CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    float t = time_launches(s, 50, [&] { (void)hipGraphLaunch(ge, s); });
+    printf("graph of 24 empty kernels (152 WG x 256): %.2f us per graph launch = %.2f us per kernel\n", t, t / 24);
+    float t1 = time_launches(s, 50, [&] { for (int i = 0; i < 24; i++) hipLaunchKernelGGL(k_empty, dim3(152), dim3(256), 0, s, (int*)d_out); });
+    printf("24 plain launches                        : %.2f us = %.2f us per kernel\n", t1, t1 / 24);
+  }
   printf("== straight-line code, 1 WG of 64 lanes, N dependent-ish FMAs (4 chains) ==\n");
 #define ST(N) printf("straight N=%-6d 1 WG  : %.2f us   152 WG: %.2f us\n", N, \
     time_launches(s, reps, [&] { hipLaunchKernelGGL(k_straight<N>, dim3(1), dim3(64), 0, s, d_out, 1.0001f, 0.5f); }), \
