@@ -136,54 +136,63 @@ def main():
     torch.cuda.synchronize()
     ptr = lambda i: d_frames[i % n_seq].data_ptr()
 
-    ctx = la.Context(w, h, K, device=local_rank)
-    loop = la.SlamLoop(ctx, ptr(0), depth0, kf_every=KF_EVERY, device_frames=True)
+    # the frame loop itself runs in C++ (liblsdhip_driver.so, include/lsd_slam_hip.hpp): Python only hands over
+    # batches of device pointers and, for N > 1, starts the RCCL gather after every new keyframe
+    from lsd_slam_amd.driver import DriverLoop
+    from lsd_slam_amd import capi
+    loop = DriverLoop(w, h, K, ptr(0), depth0, kf_every=KF_EVERY, images_on_device=True, device=local_rank)
+    L = capi.lib()
+    ctx_h = loop.ctx_handle()
 
     # per-keyframe gather (RCCL over xGMI): smoothed idepth + variance planes of finished keyframes -> rank 0
     from lsd_slam_amd.multigpu import KeyframeGather
     kg = KeyframeGather((2, h, w), torch.device("cuda", local_rank))
+    state = {"fi": 0}
 
-    def after_step():
-        if distributed and loop.new_keyframe:
-            kg.submit(lambda buf: loop.map.copyPlanesToDevice(buf[0].data_ptr(), buf[1].data_ptr()))
+    def run_frames(n):
+        """n frames through the C++ loop; with N > 1 the loop returns after every new keyframe for the gather"""
+        left = n
+        while left > 0:
+            ptrs = [ptr(state["fi"] + 1 + k) for k in range(left)]
+            kf_before = loop.stats().keyframes if distributed else 0
+            done, _ = loop.run(ptrs, stop_at_keyframe=distributed)
+            state["fi"] += done
+            left -= done
+            if distributed and loop.stats().keyframes > kf_before:
+                kg.submit(lambda buf: loop.copy_keyframe_planes(buf[0].data_ptr(), buf[1].data_ptr()))
 
-    clock = time.perf_counter
-    fi = 0
-    for _ in range(args.warmup):
-        fi += 1
-        loop.step(ptr(fi), clock)
-        after_step()
+    run_frames(args.warmup)
     kg.wait()
 
     # timed region: exactly K steps between barrier + synchronize
-    loop.t_track = loop.t_map = 0.0
-    loop.n_track = loop.n_update = 0
-    loop.evaluations = 0
+    loop.reset_stats()
     if not args.no_roofline_events:
-        ctx.prof_reset()
-        ctx.prof_enable(True)
-    ctx.synchronize()
+        capi.check(L.lsdhip_prof_reset(ctx_h))
+        capi.check(L.lsdhip_prof_enable(ctx_h, 1))
+    capi.check(L.lsdhip_ctx_synchronize(ctx_h))
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
+    clock = time.perf_counter
     t0 = clock()
-    for _ in range(args.steps):
-        fi += 1
-        loop.step(ptr(fi), clock)
-        after_step()
+    run_frames(args.steps)
     kg.wait()
-    ctx.synchronize()
+    capi.check(L.lsdhip_ctx_synchronize(ctx_h))
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     elapsed = clock() - t0
-    ctx.prof_enable(False)
+    capi.check(L.lsdhip_prof_enable(ctx_h, 0))
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    res_ms, res_launches, res_bytes = ctx.prof_read()
+    st = loop.stats()
+    import ctypes as C
+    ms_, n_, b_ = C.c_double(), C.c_longlong(), C.c_double()
+    capi.check(L.lsdhip_prof_read(ctx_h, C.byref(ms_), C.byref(n_), C.byref(b_)))
+    res_ms, res_launches, res_bytes = ms_.value, n_.value, b_.value
     out = None
     if rank == 0:
         value = world * args.steps / elapsed
@@ -204,9 +213,10 @@ def main():
                                    "(BASELINE.json configs[1]); synthetic scene S1, GT-depth init, new keyframe every %d frames"
                                    % KF_EVERY,
                        "width": w, "height": h, "parallelism": "1 sequence per GPU, RCCL gather of keyframe depth planes"},
-            "track_fps": loop.n_track / loop.t_track if loop.t_track > 0 else None,
-            "depth_mpix_per_s": (w * h * loop.n_update) / loop.t_map / 1e6 if loop.t_map > 0 else None,
-            "lm_evaluations_per_frame": loop.evaluations / max(1, loop.n_track),
+            "track_fps": st.frames / st.seconds_track if st.seconds_track > 0 else None,
+            "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,
+            "keyframe_ms": st.seconds_keyframe / st.keyframes * 1e3 if st.keyframes > 0 else None,
+            "lm_evaluations_per_frame": st.evaluations / max(1, st.frames),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,426 @@
+// lsd_slam_hip.hpp — header-only C++ host side above the C ABI (include/lsdhip.h).
+//
+// The reference's boundary for this path is a C++ class API; these classes put the reference's
+// signatures back on top of liblsdhip.so so that SlamSystem-style callers read the same:
+//
+//   reference (lsd_slam_core/src/…)                         here (namespace lsd_slam_hip)
+//   Frame(int id,int w,int h,const Eigen::Matrix3f& K,       Frame(int id,int w,int h,const Mat3f& K,double ts,
+//         double timestamp,const unsigned char* image)            const unsigned char* image)
+//                              DataStructures/Frame.h:43
+//   TrackingReference::importFrame(Frame*)                  TrackingReference::importFrame(Frame*)
+//                              Tracking/TrackingReference.h:49
+//   SE3Tracker(int w,int h,Eigen::Matrix3f K)               SE3Tracker(int w,int h,const Mat3f& K)
+//   SE3 trackFrame(TrackingReference*,Frame*,const SE3&)    SE3 trackFrame(TrackingReference*,Frame*,const SE3&)
+//   SE3 trackFrameOnPermaref(Frame*,Frame*,SE3)             SE3 trackFrameOnPermaref(Frame*,Frame*,SE3)
+//   float checkPermaRefOverlap(Frame*,SE3)                  float checkPermaRefOverlap(Frame*,SE3)
+//                              Tracking/SE3Tracker.h:41-93
+//   DepthMap(int w,int h,const Eigen::Matrix3f& K)          DepthMap(int w,int h,const Mat3f& K)
+//   updateKeyframe(std::deque<std::shared_ptr<Frame>>)      updateKeyframe(std::deque<std::shared_ptr<Frame>>)
+//   createKeyFrame(Frame*) / finalizeKeyFrame() / …         same names
+//                              DepthEstimation/DepthMap.h:47-98
+//
+// Only the value types differ: Eigen / Sophus are not part of this repository, so Mat3f and SE3 / Sim3 are plain
+// structs with the same content (row-major 3x3; unit quaternion + translation [+ scale], what Sophus::SE3d / Sim3d
+// store).  INTEGRATION.md shows the two-line conversions a lsd_slam_core build adds.
+//
+// Error behaviour: the reference asserts on misuse and reports divergence through flags.  Here divergence is reported
+// the same way (diverged = true, identity returned); usage / runtime errors of the C ABI (negative status) throw
+// lsd_slam_hip::Error carrying lsdhip_last_error().  Nothing is computed on the host: without liblsdhip.so and a GPU
+// every call fails loudly.
+#ifndef LSD_SLAM_HIP_HPP
+#define LSD_SLAM_HIP_HPP
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "lsdhip.h"
+
+namespace lsd_slam_hip {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+inline int check(int rc, const char* where) {
+  if (rc < 0) throw Error(rc, std::string(where) + ": " + lsdhip_last_error());
+  return rc;
+}
+
+struct Mat3f {
+  float m[9];  // row-major
+  float fx() const { return m[0]; }
+  float fy() const { return m[4]; }
+  float cx() const { return m[2]; }
+  float cy() const { return m[5]; }
+  static Mat3f intrinsics(float fx, float fy, float cx, float cy) { return Mat3f{{fx, 0, cx, 0, fy, cy, 0, 0, 1}}; }
+};
+
+// Sophus::SE3d content: unit quaternion (w,x,y,z) + translation
+struct SE3 {
+  double q[4] = {1, 0, 0, 0};
+  double t[3] = {0, 0, 0};
+  void to7(double p[7]) const { for (int i = 0; i < 4; i++) p[i] = q[i]; for (int i = 0; i < 3; i++) p[4 + i] = t[i]; }
+  static SE3 from7(const double p[7]) { SE3 r; for (int i = 0; i < 4; i++) r.q[i] = p[i]; for (int i = 0; i < 3; i++) r.t[i] = p[4 + i]; return r; }
+};
+// Sophus::Sim3d content
+struct Sim3 {
+  double q[4] = {1, 0, 0, 0};
+  double t[3] = {0, 0, 0};
+  double s = 1;
+};
+
+// One device context per (device, w, h, K): what the (w, h, K) constructor arguments of Frame / SE3Tracker / DepthMap
+// share in the reference.  Objects created with the same arguments use the same context and therefore the same stream.
+class Context {
+ public:
+  static std::shared_ptr<Context> get(int w, int h, const Mat3f& K, int device = defaultDevice()) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, float, float, float, float>, std::weak_ptr<Context>> registry;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_tuple(device, w, h, K.fx(), K.fy(), K.cx(), K.cy());
+    if (auto sp = registry[key].lock()) return sp;
+    std::shared_ptr<Context> sp(new Context(device, w, h, K));
+    registry[key] = sp;
+    return sp;
+  }
+  static int& defaultDevice() { static int d = 0; return d; }
+  ~Context() { lsdhip_ctx_destroy(h_); }
+  lsdhip_ctx* handle() const { return h_; }
+  int width() const { return w_; }
+  int height() const { return h_px_; }
+  const Mat3f& K() const { return K_; }
+  lsdhip_params params;  // the hot-path globals of util/settings.cpp:77-88 this context was created with
+  void synchronize() { check(lsdhip_ctx_synchronize(h_), "lsdhip_ctx_synchronize"); }
+
+ private:
+  Context(int device, int w, int h, const Mat3f& K) : w_(w), h_px_(h), K_(K) {
+    lsdhip_default_params(&params);
+    const float k4[4] = {K.fx(), K.fy(), K.cx(), K.cy()};
+    check(lsdhip_ctx_create(device, w, h, k4, &params, &h_), "lsdhip_ctx_create");
+  }
+  lsdhip_ctx* h_ = nullptr;
+  int w_, h_px_;
+  Mat3f K_;
+};
+
+class TrackingReference;
+
+// DataStructures/Frame.h — a frame whose pyramids live on the device
+class Frame {
+ public:
+  Frame(int id, int width, int height, const Mat3f& K, double timestamp, const unsigned char* image)
+      : ctx_(Context::get(width, height, K)), id_(id), timestamp_(timestamp) {
+    check(lsdhip_frame_create(ctx_->handle(), id, image, &h_), "lsdhip_frame_create");
+  }
+  // image already resident on the context's GPU (uint8, w*h): no PCIe transfer
+  struct DeviceImage { const unsigned char* ptr; };
+  Frame(int id, int width, int height, const Mat3f& K, double timestamp, DeviceImage image)
+      : ctx_(Context::get(width, height, K)), id_(id), timestamp_(timestamp) {
+    check(lsdhip_frame_create_from_device(ctx_->handle(), id, image.ptr, &h_), "lsdhip_frame_create_from_device");
+  }
+  Frame(const Frame&) = delete;
+  Frame& operator=(const Frame&) = delete;
+  ~Frame() { lsdhip_frame_destroy(h_); }
+
+  int id() const { return id_; }
+  int width(int level = 0) const { return ctx_->width() >> level; }
+  int height(int level = 0) const { return ctx_->height() >> level; }
+  double timestamp() const { return timestamp_; }
+  lsdhip_frame* handle() const { return h_; }
+  const std::shared_ptr<Context>& context() const { return ctx_; }
+
+  // Frame::image / gradients / maxGradients / idepth / idepthVar (Frame.h:357-418), copied to the host
+  std::vector<float> image(int level = 0) const { return plane(0, level, 1); }
+  std::vector<float> gradients(int level = 0) const { return plane(1, level, 4); }
+  std::vector<float> maxGradients(int level = 0) const { return plane(2, level, 1); }
+  std::vector<float> idepth(int level = 0) const { return plane(3, level, 1); }
+  std::vector<float> idepthVar(int level = 0) const { return plane(4, level, 1); }
+
+  void setDepthFromGroundTruth(const float* depth, float cov_scale = 1.0f) {
+    check(lsdhip_frame_set_depth_gt(h_, depth, cov_scale), "lsdhip_frame_set_depth_gt");
+  }
+  // refPixelWasGood() (Frame.h:421-437): empty vector when the mask does not exist
+  std::vector<uint8_t> refPixelWasGoodNoCreate() const {
+    std::vector<uint8_t> m((size_t)width(1) * height(1));
+    if (check(lsdhip_frame_get_wasgood(h_, m.data()), "lsdhip_frame_get_wasgood") != 1) m.clear();
+    return m;
+  }
+  void clear_refPixelWasGood() { check(lsdhip_frame_clear_wasgood(h_), "lsdhip_frame_clear_wasgood"); }
+
+  // FramePoseStruct::thisToParent_raw / trackingParent (written by trackFrame; settable for callers that track elsewhere)
+  Sim3 thisToParent_raw() const {
+    double p[8];
+    check(lsdhip_frame_get_pose(h_, p), "lsdhip_frame_get_pose");
+    Sim3 s;
+    for (int i = 0; i < 4; i++) s.q[i] = p[i];
+    for (int i = 0; i < 3; i++) s.t[i] = p[4 + i];
+    s.s = p[7];
+    return s;
+  }
+  void setPose(const Sim3& thisToParent, Frame* trackingParent, float initialTrackedResidual) {
+    const double p[8] = {thisToParent.q[0], thisToParent.q[1], thisToParent.q[2], thisToParent.q[3],
+                         thisToParent.t[0], thisToParent.t[1], thisToParent.t[2], thisToParent.s};
+    check(lsdhip_frame_set_pose(h_, p, trackingParent ? trackingParent->h_ : nullptr, initialTrackedResidual), "lsdhip_frame_set_pose");
+  }
+
+  struct Stats {
+    float initialTrackedResidual, meanIdepth;
+    int numPoints, numFramesTrackedOnThis, numMappedOnThis, numMappedOnThisTotal;
+    bool depthHasBeenUpdatedFlag;
+  };
+  Stats stats() const {
+    float o[8];
+    check(lsdhip_frame_stats(h_, o), "lsdhip_frame_stats");
+    return Stats{o[0], o[1], (int)o[2], (int)o[3], (int)o[4], (int)o[5], o[6] != 0.0f};
+  }
+  float initialTrackedResidual() const { return stats().initialTrackedResidual; }
+  float meanIdepth() const { return stats().meanIdepth; }
+  int numPoints() const { return stats().numPoints; }
+  bool depthHasBeenUpdatedFlag() const { return stats().depthHasBeenUpdatedFlag; }
+  void clearDepthHasBeenUpdatedFlag() {  // currentKeyFrame->depthHasBeenUpdatedFlag = false (SlamSystem.cpp:910)
+    Stats s = stats();
+    check(lsdhip_frame_set_counters(h_, s.numFramesTrackedOnThis, s.numMappedOnThis, s.numMappedOnThisTotal, 0), "lsdhip_frame_set_counters");
+  }
+
+  // Frame::setPermaRef (Frame.cpp:149-174): keeps the level-QUICK_KF_CHECK_LVL point cloud of `reference` on the host
+  inline void setPermaRef(TrackingReference* reference);
+  std::vector<float> permaRef_posData;       // 3 floats per point
+  std::vector<float> permaRef_colorAndVarData;  // 2 floats per point
+  int permaRefNumPts = 0;
+
+ private:
+  std::vector<float> plane(int what, int level, int channels) const {
+    std::vector<float> v((size_t)width(level) * height(level) * channels);
+    check(lsdhip_frame_download(h_, what, level, v.data()), "lsdhip_frame_download");
+    return v;
+  }
+  std::shared_ptr<Context> ctx_;
+  lsdhip_frame* h_ = nullptr;
+  int id_;
+  double timestamp_;
+};
+
+// Tracking/TrackingReference.h — on the device the point cloud is generated inside the residual kernel, so this object
+// only remembers which keyframe it refers to; makePointCloud() exports the compacted arrays in the reference's order.
+class TrackingReference {
+ public:
+  Frame* keyframe = nullptr;
+  int frameID = -1;
+  void importFrame(Frame* source) { keyframe = source; frameID = source ? source->id() : -1; }
+  void invalidate() { keyframe = nullptr; frameID = -1; }
+  // returns the number of points; any output may be null (TrackingReference.cpp:96-147)
+  int makePointCloud(int level, std::vector<float>* posData, std::vector<float>* colorAndVarData,
+                     std::vector<float>* gradData = nullptr, std::vector<int>* pointPosInXYGrid = nullptr) const {
+    if (!keyframe) throw Error(LSDHIP_E_STATE, "TrackingReference::makePointCloud: no keyframe");
+    const size_t cap = (size_t)keyframe->width(level) * keyframe->height(level);
+    std::vector<float> pos(cap * 3), cv(cap * 2), gr(cap * 2);
+    std::vector<int> idx(cap);
+    const int n = check(lsdhip_ref_pointcloud(keyframe->handle(), level, pos.data(), cv.data(), gr.data(), idx.data()), "lsdhip_ref_pointcloud");
+    if (posData) posData->assign(pos.begin(), pos.begin() + (size_t)n * 3);
+    if (colorAndVarData) colorAndVarData->assign(cv.begin(), cv.begin() + (size_t)n * 2);
+    if (gradData) gradData->assign(gr.begin(), gr.begin() + (size_t)n * 2);
+    if (pointPosInXYGrid) pointPosInXYGrid->assign(idx.begin(), idx.begin() + n);
+    return n;
+  }
+};
+
+inline void Frame::setPermaRef(TrackingReference* reference) {
+  permaRefNumPts = reference->makePointCloud(4 /* QUICK_KF_CHECK_LVL */, &permaRef_posData, &permaRef_colorAndVarData);
+}
+
+// util/settings.h:355-402 (the fields the C ABI exposes)
+struct DenseDepthTrackerSettings {
+  int maxItsPerLvl[LSDHIP_PYRAMID_LEVELS] = {5, 20, 50, 100, 100};
+};
+
+// Tracking/SE3Tracker.h:41-93
+class SE3Tracker {
+ public:
+  int width, height;
+  Mat3f K;
+  DenseDepthTrackerSettings settings;
+
+  SE3Tracker(int w, int h, const Mat3f& K_) : width(w), height(h), K(K_), ctx_(Context::get(w, h, K_)) {
+    check(lsdhip_tracker_create(ctx_->handle(), &h_), "lsdhip_tracker_create");
+  }
+  SE3Tracker(const SE3Tracker&) = delete;
+  SE3Tracker& operator=(const SE3Tracker&) = delete;
+  ~SE3Tracker() { lsdhip_tracker_destroy(h_); }
+
+  SE3 trackFrame(TrackingReference* reference, Frame* frame, const SE3& frameToReference_initialEstimate) {
+    check(lsdhip_tracker_set_max_its(h_, settings.maxItsPerLvl), "lsdhip_tracker_set_max_its");
+    double init[7];
+    frameToReference_initialEstimate.to7(init);
+    lsdhip_track_result r;
+    check(lsdhip_tracker_track(h_, reference->keyframe->handle(), frame->handle(), init, &r), "lsdhip_tracker_track");
+    publish(r);
+    return SE3::from7(r.frameToReference);
+  }
+  SE3 trackFrameOnPermaref(Frame* reference, Frame* frame, SE3 referenceToFrame) {
+    double init[7];
+    referenceToFrame.to7(init);
+    lsdhip_track_result r;
+    check(lsdhip_tracker_track_permaref(h_, reference->permaRef_posData.data(), reference->permaRef_colorAndVarData.data(),
+                                        reference->permaRefNumPts, frame->handle(), init, &r), "lsdhip_tracker_track_permaref");
+    publish(r);
+    return SE3::from7(r.frameToReference);
+  }
+  float checkPermaRefOverlap(Frame* reference, SE3 referenceToFrame) {
+    double init[7];
+    referenceToFrame.to7(init);
+    float usage = 0;
+    check(lsdhip_tracker_check_overlap(h_, reference->permaRef_posData.data(), reference->permaRefNumPts, init, &usage), "lsdhip_tracker_check_overlap");
+    pointUsage = usage;
+    return usage;
+  }
+
+  float pointUsage = 0, lastGoodCount = 0, lastMeanRes = 0, lastBadCount = 0, lastResidual = 0;
+  float affineEstimation_a = 1, affineEstimation_b = 0;
+  bool diverged = false, trackingWasGood = false;
+  int numEvaluations = 0, numWarpUpdates = 0;  // instrumentation (residual-kernel launches, LM outer iterations)
+
+ private:
+  void publish(const lsdhip_track_result& r) {
+    pointUsage = r.pointUsage; lastGoodCount = r.lastGoodCount; lastMeanRes = r.lastMeanRes; lastBadCount = r.lastBadCount;
+    lastResidual = r.lastResidual; affineEstimation_a = r.affineEstimation_a; affineEstimation_b = r.affineEstimation_b;
+    diverged = r.diverged != 0; trackingWasGood = r.trackingWasGood != 0;
+    numEvaluations = r.numEvaluations; numWarpUpdates = r.numWarpUpdates;
+  }
+  std::shared_ptr<Context> ctx_;
+  lsdhip_tracker* h_ = nullptr;
+};
+
+// DepthEstimation/DepthMap.h:47-98
+class DepthMap {
+ public:
+  DepthMap(int w, int h, const Mat3f& K) : ctx_(Context::get(w, h, K)) { check(lsdhip_depth_create(ctx_->handle(), &h_), "lsdhip_depth_create"); }
+  DepthMap(const DepthMap&) = delete;
+  DepthMap& operator=(const DepthMap&) = delete;
+  ~DepthMap() { lsdhip_depth_destroy(h_); }
+
+  void reset() { check(lsdhip_depth_reset(h_), "lsdhip_depth_reset"); }
+  void updateKeyframe(std::deque<std::shared_ptr<Frame>> referenceFrames) {
+    std::vector<lsdhip_frame*> refs;
+    refs.reserve(referenceFrames.size());
+    for (auto& f : referenceFrames) refs.push_back(f->handle());
+    check(lsdhip_depth_update(h_, refs.data(), (int)refs.size()), "lsdhip_depth_update");
+    timings();
+  }
+  void createKeyFrame(Frame* new_keyframe) {
+    check(lsdhip_depth_create_keyframe(h_, new_keyframe->handle(), &lastRescaleFactor), "lsdhip_depth_create_keyframe");
+    timings();
+  }
+  void finalizeKeyFrame() { check(lsdhip_depth_finalize(h_), "lsdhip_depth_finalize"); timings(); }
+  void invalidate() { check(lsdhip_depth_invalidate(h_), "lsdhip_depth_invalidate"); }
+  bool isValid() { return lsdhip_depth_is_valid(h_) != 0; }
+  void initializeFromGTDepth(Frame* new_frame) { check(lsdhip_depth_init_gt(h_, new_frame->handle()), "lsdhip_depth_init_gt"); }
+  void initializeRandomly(Frame* new_frame) { check(lsdhip_depth_init_random(h_, new_frame->handle()), "lsdhip_depth_init_random"); }
+  void setFromExistingKF(Frame* kf) { check(lsdhip_depth_set_from_existing(h_, kf->handle()), "lsdhip_depth_set_from_existing"); }
+
+  // currentDepthMap in the reference's 32-byte AoS layout (DepthMapPixelHypothesis.h:43-60)
+  std::vector<lsdhip_hypothesis> currentDepthMap() const {
+    std::vector<lsdhip_hypothesis> v((size_t)ctx_->width() * ctx_->height());
+    check(lsdhip_depth_download(h_, v.data()), "lsdhip_depth_download");
+    return v;
+  }
+  // smoothed idepth / variance planes of the active keyframe, device to device (payload of the multi-GPU gather)
+  void copyPlanesToDevice(float* idepth_dev, float* idepthVar_dev) { check(lsdhip_depth_copy_planes_dev(h_, idepth_dev, idepthVar_dev), "lsdhip_depth_copy_planes_dev"); }
+
+  float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0, msSetDepth = 0;
+  float lastRescaleFactor = 1;  // rescaleFactor of the last createKeyFrame (DepthMap.cpp:1294)
+  lsdhip_depthmap* handle() const { return h_; }
+
+ private:
+  void timings() {
+    float t[8];
+    if (lsdhip_depth_timings(h_, t) == 0) { msUpdate = t[0]; msCreate = t[1]; msFinalize = t[2]; msObserve = t[3]; msRegularize = t[4]; msPropagate = t[5]; msFillHoles = t[6]; msSetDepth = t[7]; }
+  }
+  std::shared_ptr<Context> ctx_;
+  lsdhip_depthmap* h_ = nullptr;
+};
+
+// The part of SlamSystem either side of the hot path, with doSlam = false and blockUntilMapped = true
+// (SlamSystem.cpp:890-1040 trackFrame, :739-828 doMappingIteration, :542-614 updateKeyframe, :458-490
+// createNewCurrentKeyframe) and a deterministic keyframe policy (a new keyframe every `kfEvery` frames) in place of the
+// distance / usage score.  Orchestration only: every per-pixel operation is a liblsdhip.so call.
+class SlamLoop {
+ public:
+  SlamLoop(int w, int h, const Mat3f& K, const unsigned char* firstImage, bool imagesOnDevice, const float* gtDepth0, int kfEvery)
+      : w_(w), h_(h), K_(K), onDevice_(imagesOnDevice), kfEvery_(kfEvery), tracker(w, h, K), map(w, h, K) {
+    const int its[LSDHIP_PYRAMID_LEVELS] = {5, 20, 50, 100, 0};  // SlamSystem.cpp:80-81 (no level-4 iterations are run by the tracker)
+    std::memcpy(tracker.settings.maxItsPerLvl, its, sizeof(its));
+    keyframe = makeFrame(0, firstImage);
+    keyframe->setDepthFromGroundTruth(gtDepth0);  // SlamSystem::gtDepthInit (SlamSystem.cpp:831-854)
+    map.initializeFromGTDepth(keyframe.get());
+    reference.importFrame(keyframe.get());
+    keyframe->clearDepthHasBeenUpdatedFlag();
+  }
+  // track one frame, then one mapping iteration; returns frameToKeyframe.  Throws when tracking diverges.
+  SE3 step(const unsigned char* image) { return step(image, [](double) {}); }
+  // same, reporting the wall-clock instant (seconds, steady clock) at which tracking ended and mapping began
+  template <typename F>
+  SE3 step(const unsigned char* image, F&& onTrackEnd) {
+    frameId_++;
+    std::shared_ptr<Frame> frame = makeFrame(frameId_, image);
+    if (keyframe->depthHasBeenUpdatedFlag()) {
+      reference.importFrame(keyframe.get());
+      keyframe->clearDepthHasBeenUpdatedFlag();
+    }
+    SE3 est = tracker.trackFrame(&reference, frame.get(), lastFrameToKF_);
+    evaluations += tracker.numEvaluations;
+    numTracked++;
+    lastTrackEnd = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    onTrackEnd(lastTrackEnd);
+    if (tracker.diverged) throw Error(LSDHIP_DIVERGED, "SlamLoop: tracking diverged at frame " + std::to_string(frameId_));
+    if (++sinceKF_ >= kfEvery_) {
+      map.finalizeKeyFrame();
+      map.createKeyFrame(frame.get());
+      keyframe = frame;
+      reference.importFrame(keyframe.get());
+      keyframe->clearDepthHasBeenUpdatedFlag();
+      lastFrameToKF_ = SE3();
+      sinceKF_ = 0;
+      newKeyframe = true;
+    } else {
+      std::deque<std::shared_ptr<Frame>> q;
+      q.push_back(frame);
+      map.updateKeyframe(q);
+      frame->clear_refPixelWasGood();
+      lastFrameToKF_ = est;
+      numUpdates++;
+      newKeyframe = false;
+    }
+    return est;
+  }
+  SE3Tracker tracker;
+  DepthMap map;
+  TrackingReference reference;
+  std::shared_ptr<Frame> keyframe;
+  bool newKeyframe = false;
+  long evaluations = 0, numTracked = 0, numUpdates = 0;
+  double lastTrackEnd = 0;
+
+ private:
+  std::shared_ptr<Frame> makeFrame(int id, const unsigned char* img) {
+    if (onDevice_) return std::make_shared<Frame>(id, w_, h_, K_, 0.0, Frame::DeviceImage{img});
+    return std::make_shared<Frame>(id, w_, h_, K_, 0.0, img);
+  }
+  int w_, h_;
+  Mat3f K_;
+  bool onDevice_;
+  int kfEvery_, sinceKF_ = 0, frameId_ = 0;
+  SE3 lastFrameToKF_;
+};
+
+}  // namespace lsd_slam_hip
+#endif  // LSD_SLAM_HIP_HPP

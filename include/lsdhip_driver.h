@@ -1,0 +1,37 @@
+/* lsdhip_driver.h — C entry points of liblsdhip_driver.so: the C++ sequence driver (lsd_slam_hip::SlamLoop in
+ * include/lsd_slam_hip.hpp, i.e. the doSlam=false / blockUntilMapped=true slice of SlamSystem, C/SlamSystem.cpp:890-1040,
+ * :739-828, :542-614, :458-490) behind plain C so that bench.py and tests can run whole frame batches without going
+ * through the Python interpreter per frame.  Not part of the drop-in boundary (that is include/lsdhip.h). */
+#ifndef LSDHIP_DRIVER_H
+#define LSDHIP_DRIVER_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct lsdloop lsdloop;
+typedef struct lsdloop_stats {
+  double seconds_track;      /* wall time inside frame creation + SE3Tracker::trackFrame */
+  double seconds_map;        /* wall time inside DepthMap::updateKeyframe (frames that did not become keyframes) */
+  double seconds_keyframe;   /* wall time inside finalizeKeyFrame + createKeyFrame (frames that became keyframes) */
+  long long frames;          /* frames tracked */
+  long long updates;         /* updateKeyframe calls */
+  long long keyframes;       /* keyframes created */
+  long long evaluations;     /* residual evaluations (k_track_step launches that did work) */
+} lsdloop_stats;
+/* K4 = fx, fy, cx, cy.  first_image / images: uint8 w*h, host memory or (images_on_device != 0) memory of `device`. */
+int lsdloop_create(int device, int w, int h, const float K4[4], const uint8_t* first_image, int images_on_device,
+                   const float* gt_depth0_host, int kf_every, lsdloop** out);
+void lsdloop_destroy(lsdloop* l);
+/* Runs up to n frames; stops early right after a frame that became a keyframe when stop_at_keyframe != 0.
+ * Returns the number of frames consumed (>= 0) or a negative lsdhip status.  frameToKeyframe_out: n x 7 doubles or NULL. */
+int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int stop_at_keyframe, double* frameToKeyframe_out);
+int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out);
+int lsdloop_reset_stats(lsdloop* l);
+/* smoothed idepth / variance planes of the current keyframe, device to device (the multi-GPU gather payload) */
+int lsdloop_copy_keyframe_planes(lsdloop* l, float* idepth_dev, float* idepthVar_dev);
+void* lsdloop_ctx(lsdloop* l);   /* the lsdhip_ctx* the loop runs on (prof hooks, stream) */
+const char* lsdloop_last_error(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -62,14 +62,34 @@ def build_trace(verbose=False):
     return out
 
 
+DRIVER_OUT = os.path.join(HERE, "liblsdhip_driver.so")
+DRIVER_SRC = os.path.join(HERE, "driver", "slam_loop.cpp")
+
+
+def build_driver(force=False, verbose=False):
+    """liblsdhip_driver.so: the C++ host loop (include/lsd_slam_hip.hpp) — plain g++, links liblsdhip.so."""
+    deps = [DRIVER_SRC, os.path.join(HERE, "..", "include", "lsd_slam_hip.hpp"), os.path.join(HERE, "..", "include", "lsdhip.h"),
+            os.path.join(HERE, "..", "include", "lsdhip_driver.h"), OUT]
+    if not force and os.path.exists(DRIVER_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(DRIVER_OUT) for d in deps):
+        return DRIVER_OUT
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-reorder", DRIVER_SRC, "-o", DRIVER_OUT,
+           "-L" + HERE, "-llsdhip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DRIVER_OUT
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
+        build_driver(False, verbose)
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + ["-x", "hip"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     _compile_checked(cmd)
+    build_driver(True, verbose)
     return OUT
 
 

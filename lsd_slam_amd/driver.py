@@ -1,0 +1,100 @@
+"""ctypes binding of liblsdhip_driver.so (include/lsdhip_driver.h): the C++ sequence loop, so that a batch of frames runs
+without the Python interpreter between frames.  No fallback: a missing library raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DRIVER_PATH = os.path.join(_HERE, "liblsdhip_driver.so")
+_lib = None
+
+
+class LoopStats(C.Structure):
+    _fields_ = [("seconds_track", C.c_double), ("seconds_map", C.c_double), ("seconds_keyframe", C.c_double), ("frames", C.c_longlong),
+                ("updates", C.c_longlong), ("keyframes", C.c_longlong), ("evaluations", C.c_longlong)]
+
+
+EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop_get_stats", "lsdloop_reset_stats",
+                    "lsdloop_copy_keyframe_planes", "lsdloop_ctx", "lsdloop_last_error"]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        capi.lib()  # liblsdhip.so first (same file the driver links against)
+        if not os.path.exists(DRIVER_PATH):
+            raise RuntimeError("liblsdhip_driver.so is missing (%s): run __graft_entry__.build()" % DRIVER_PATH)
+        L = C.CDLL(DRIVER_PATH)
+        vp, i = C.c_void_p, C.c_int
+        L.lsdloop_create.restype = i
+        L.lsdloop_create.argtypes = [i, i, i, vp, vp, i, vp, i, C.POINTER(vp)]
+        L.lsdloop_destroy.restype = None
+        L.lsdloop_destroy.argtypes = [vp]
+        L.lsdloop_run.restype = i
+        L.lsdloop_run.argtypes = [vp, vp, i, i, vp]
+        L.lsdloop_get_stats.restype = i
+        L.lsdloop_get_stats.argtypes = [vp, C.POINTER(LoopStats)]
+        L.lsdloop_reset_stats.restype = i
+        L.lsdloop_reset_stats.argtypes = [vp]
+        L.lsdloop_copy_keyframe_planes.restype = i
+        L.lsdloop_copy_keyframe_planes.argtypes = [vp, vp, vp]
+        L.lsdloop_ctx.restype = vp
+        L.lsdloop_ctx.argtypes = [vp]
+        L.lsdloop_last_error.restype = C.c_char_p
+        L.lsdloop_last_error.argtypes = []
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise capi.LsdHipError("liblsdhip_driver call failed (%d): %s" % (rc, (lib().lsdloop_last_error() or b"").decode()))
+    return rc
+
+
+class DriverLoop:
+    """lsd_slam_hip::SlamLoop (include/lsd_slam_hip.hpp).  Images are raw pointers: device pointers when
+    images_on_device, else host pointers (numpy .ctypes.data)."""
+
+    def __init__(self, w, h, K, first_image_ptr, depth0, kf_every=10, images_on_device=True, device=0):
+        self.L = lib()
+        K4 = np.ascontiguousarray(K, dtype=np.float32)
+        d0 = np.ascontiguousarray(depth0, dtype=np.float32)
+        h_ = C.c_void_p()
+        _check(self.L.lsdloop_create(device, w, h, K4.ctypes.data, C.c_void_p(first_image_ptr), int(images_on_device),
+                                     d0.ctypes.data, kf_every, C.byref(h_)))
+        self.h_ = h_
+        self.w, self.h = w, h
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.lsdloop_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, image_ptrs, stop_at_keyframe=False, want_poses=False):
+        """Runs the frames; returns (frames consumed, poses or None)."""
+        n = len(image_ptrs)
+        arr = (C.c_void_p * n)(*image_ptrs)
+        poses = np.zeros((n, 7), np.float64) if want_poses else None
+        done = _check(self.L.lsdloop_run(self.h_, arr, n, int(stop_at_keyframe), poses.ctypes.data if want_poses else None))
+        return done, (poses[:done] if want_poses else None)
+
+    def stats(self):
+        s = LoopStats()
+        _check(self.L.lsdloop_get_stats(self.h_, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        _check(self.L.lsdloop_reset_stats(self.h_))
+
+    def copy_keyframe_planes(self, idepth_ptr, var_ptr):
+        _check(self.L.lsdloop_copy_keyframe_planes(self.h_, C.c_void_p(idepth_ptr), C.c_void_p(var_ptr)))
+
+    def ctx_handle(self):
+        return self.L.lsdloop_ctx(self.h_)

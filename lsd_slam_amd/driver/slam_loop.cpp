@@ -1,0 +1,82 @@
+// liblsdhip_driver.so — the C++ host side of the sequence loop (include/lsd_slam_hip.hpp) behind a C interface.
+// Plain host C++ (g++): everything that touches pixels is a liblsdhip.so call.
+#include <chrono>
+#include <string>
+
+#include "../../include/lsd_slam_hip.hpp"
+#include "../../include/lsdhip_driver.h"
+
+using namespace lsd_slam_hip;
+
+static thread_local std::string g_err;
+
+struct lsdloop {
+  std::unique_ptr<SlamLoop> loop;
+  std::shared_ptr<Context> ctx;
+  lsdloop_stats st{};
+};
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+extern "C" const char* lsdloop_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lsdloop_create(int device, int w, int h, const float K4[4], const uint8_t* first_image, int images_on_device,
+                              const float* gt_depth0_host, int kf_every, lsdloop** out) {
+  if (!K4 || !first_image || !gt_depth0_host || !out || kf_every < 1) return LSDHIP_E_ARG;
+  try {
+    Context::defaultDevice() = device;
+    Mat3f K = Mat3f::intrinsics(K4[0], K4[1], K4[2], K4[3]);
+    std::unique_ptr<lsdloop> l(new lsdloop());
+    l->ctx = Context::get(w, h, K, device);
+    l->loop.reset(new SlamLoop(w, h, K, first_image, images_on_device != 0, gt_depth0_host, kf_every));
+    *out = l.release();
+    return LSDHIP_OK;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.status;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return LSDHIP_E_STATE;
+  }
+}
+extern "C" void lsdloop_destroy(lsdloop* l) { delete l; }
+
+extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int stop_at_keyframe, double* out7) {
+  if (!l || !images || n < 0) return LSDHIP_E_ARG;
+  try {
+    int done = 0;
+    for (int i = 0; i < n; i++) {
+      // SlamLoop::step, split so that tracking and mapping are timed separately (the two metrics of SURVEY.md §8(d))
+      const double t0 = now_s();
+      SlamLoop& L = *l->loop;
+      const long upd0 = L.numUpdates;
+      const long ev0 = L.evaluations;
+      SE3 est = L.step(images[i], [&](double tTrackEnd) { l->st.seconds_track += tTrackEnd - t0; });
+      const double t2 = now_s();
+      if (L.newKeyframe) l->st.seconds_keyframe += t2 - L.lastTrackEnd;
+      else l->st.seconds_map += t2 - L.lastTrackEnd;
+      l->st.frames++;
+      l->st.updates += L.numUpdates - upd0;
+      l->st.evaluations += L.evaluations - ev0;
+      if (L.newKeyframe) l->st.keyframes++;
+      if (out7) est.to7(out7 + 7 * (size_t)i);
+      done++;
+      if (stop_at_keyframe && L.newKeyframe) break;
+    }
+    return done;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.status > 0 ? -100 - e.status : e.status;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return LSDHIP_E_STATE;
+  }
+}
+extern "C" int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out) { if (!l || !out) return LSDHIP_E_ARG; *out = l->st; return LSDHIP_OK; }
+extern "C" int lsdloop_reset_stats(lsdloop* l) { if (!l) return LSDHIP_E_ARG; l->st = lsdloop_stats{}; return LSDHIP_OK; }
+extern "C" int lsdloop_copy_keyframe_planes(lsdloop* l, float* idepth_dev, float* var_dev) {
+  if (!l) return LSDHIP_E_ARG;
+  try { l->loop->map.copyPlanesToDevice(idepth_dev, var_dev); return LSDHIP_OK; }
+  catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+extern "C" void* lsdloop_ctx(lsdloop* l) { return l ? (void*)l->ctx->handle() : nullptr; }

@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Generates tests/golden/s1_160x128.npz: oracle outputs on a seeded synthetic sequence (scene S1, 160x128, 4 frames).
+
+The reference ships no golden vectors for this path and cannot be built here, so the fixtures are the
+CPU oracle's outputs, frozen: the CPU suite checks that the oracle still reproduces them (oracle drift), the GPU suite
+checks the HIP path against them (bit-exact where the contract says so).  Run from the repository root:
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from lsd_slam_amd import synth  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+W, H, N = 160, 128, 4
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s1_160x128.npz")
+ITS = [5, 20, 50, 100, 0]
+
+
+def digest(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def compute(frames, depth0, K):
+    """Everything the fixture freezes, from the oracle."""
+    g = {}
+    kf = po.Frame(0, frames[0], K)
+    kf.set_depth_gt(depth0)
+    for lvl in range(5):
+        g["image_L%d" % lvl] = digest(kf.plane("image", lvl))
+        g["gradients_L%d" % lvl] = digest(kf.plane("gradients", lvl))
+        g["idepth_L%d" % lvl] = digest(kf.plane("idepth", lvl))
+        g["idepthVar_L%d" % lvl] = digest(kf.plane("idepthVar", lvl))
+    g["maxGradients_L0"] = digest(kf.plane("maxGradients", 0))
+    ref = po.TrackingReference()
+    ref.import_frame(kf)
+    g["pointcloud_counts"] = np.array([len(ref.pointcloud(l)[0]) for l in range(5)], np.int32)
+    # residual evaluation at a fixed pose, every level
+    tr = po.SE3Tracker(W, H, K, mode=po.SSE_EXACT_RCP)
+    T = po.se3_exp(np.array([0.02, -0.01, 0.01, 0.005, -0.01, 0.015])).astype(np.float32)
+    rec = []
+    for lvl in (4, 3, 2, 1):
+        f = po.Frame(3, frames[3], K)
+        r = tr.evaluate(ref, f, T, lvl, 1.0, 0.0)
+        rec.append([r.warped_size, r.goodCount, r.badCount, r.num_constraints, r.pointUsage, r.weightedError] + list(r.A) + list(r.b))
+        if lvl == 1:
+            g["wasgood_fixed_pose"] = np.packbits(f.wasgood() == 1)
+            g["wasgood_unset"] = np.packbits(f.wasgood() == 255)
+    g["fixed_pose"] = T
+    g["residual_records"] = np.array(rec, np.float64)
+    # trackFrame (SSE path of the reference) frame 2 on keyframe 0
+    tr2 = po.SE3Tracker(W, H, K, mode=po.SSE)
+    tr2.set_max_its(ITS)
+    f2 = po.Frame(2, frames[2], K)
+    r = tr2.track(ref, f2, np.array([1.0, 0, 0, 0, 0, 0, 0]))
+    g["track_pose"] = np.array(r.frameToRef, np.float64)
+    g["track_scalars"] = np.array([r.pointUsage, r.lastGoodCount, r.lastBadCount, r.lastResidual, r.diverged, r.trackingWasGood], np.float64)
+    g["track_wasgood"] = f2.wasgood().astype(np.uint8)          # 0 bad, 1 good, 255 never written (counts as good)
+    g["track_initialTrackedResidual"] = np.array([f2.stats()["initialTrackedResidual"]], np.float32)
+    # depth map: GT init, one updateKeyframe with that frame (pose / mask as the oracle left them)
+    dm = po.DepthMap(W, H, K)
+    dm.init_gt(kf)
+    dm.update([f2])
+    hyp = dm.get()
+    v = hyp["isValid"] > 0
+    g["update_valid"] = np.packbits(v)
+    g["update_blacklisted"] = digest(hyp["blacklisted"])
+    g["update_validity_counter"] = digest(hyp["validity_counter"][v])
+    for k in ("idepth", "idepth_var", "idepth_smoothed", "idepth_var_smoothed"):
+        g["update_" + k] = digest(hyp[k][v])
+    g["update_num_valid"] = np.array([int(v.sum())], np.int64)
+    g["update_kf_idepth_L1"] = digest(kf.plane("idepth", 1))
+    return g
+
+
+def main():
+    po.build()
+    frames, depth0, K, gt = synth.make_sequence(W, H, N)
+    g = compute(frames, depth0, K)
+    np.savez_compressed(OUT, frames=frames, depth0=depth0.astype(np.float32), K=np.asarray(K, np.float32), **g)
+    print("wrote %s (%d bytes, %d entries)" % (OUT, os.path.getsize(OUT), len(g)))
+
+
+if __name__ == "__main__":
+    main()

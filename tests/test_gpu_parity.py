@@ -448,3 +448,28 @@ def test_usage_errors_are_loud(hip):
     dm = hip.DepthMap(ctx)
     with pytest.raises(hip.LsdHipError):
         dm.updateKeyframe([f])                # no active keyframe
+
+
+@pytest.mark.gpu
+def test_cpp_driver_loop_matches_python_loop(hip):
+    """The C++ host loop (liblsdhip_driver.so, include/lsd_slam_hip.hpp) and the Python mirror issue the same C-ABI
+    calls: identical poses, frame for frame, across two keyframe changes."""
+    import time
+    import lsd_slam_amd as la
+    from lsd_slam_amd.driver import DriverLoop
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 26)
+    ctx = la.Context(w, h, K)
+    loop = la.SlamLoop(ctx, frames[0], depth0, kf_every=10)
+    py = [loop.step(frames[i], time.perf_counter) for i in range(1, 26)]
+    imgs = [np.ascontiguousarray(f) for f in frames]
+    drv = DriverLoop(w, h, K, imgs[0].ctypes.data, depth0, kf_every=10, images_on_device=False)
+    done, poses = drv.run([imgs[i].ctypes.data for i in range(1, 26)], want_poses=True)
+    assert done == 25
+    st = drv.stats()
+    assert st.frames == 25 and st.keyframes == 2 and st.updates == 23 and st.evaluations > 0
+    assert np.array_equal(np.array(py), poses)
+    # stop_at_keyframe returns right after the frame that became a keyframe
+    drv2 = DriverLoop(w, h, K, imgs[0].ctypes.data, depth0, kf_every=10, images_on_device=False)
+    done2, _ = drv2.run([imgs[i].ctypes.data for i in range(1, 26)], stop_at_keyframe=True)
+    assert done2 == 10
