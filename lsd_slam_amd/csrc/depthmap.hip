@@ -565,6 +565,202 @@ __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
   a.validOut[idx] = nowValid;
 }
 
+// K5 + K6 (+ K8) fused over one LDS tile: regularizeDepthMapFillHoles -> regularizeDepthMap<removeOcclusions> ->
+// Frame::setDepth, in one launch.  A workgroup owns 32x8 pixels; K6 on them needs the post-K5 map on a 2-pixel halo, and
+// K5 on that 36x12 region needs the pre-K5 snapshot on a 4-pixel halo, so the tile is 40x16 (36x12 without K5).  The
+// halo's K5 results are recomputed locally (identical arithmetic => identical values in every workgroup that needs
+// them) and only the owner writes them to HBM.  Every neighbour access is an LDS read issued in a fully unrolled batch;
+// the per-pixel arithmetic and its order are those of k_fill_holes / k_regularize above (and of the reference).
+//   id0 / var0 / partials: outputs of K8 (SET only): level-0 idepth planes of the keyframe and per-workgroup (sum, count).
+template <bool FILL, bool OCC, bool SET>
+__global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict__ id0, float* __restrict__ var0,
+                                                    double* __restrict__ partials) {
+  constexpr int HALO = FILL ? 4 : 2;
+  constexpr int TW = 32 + 2 * HALO, TH = 8 + 2 * HALO, TN = TW * TH;
+  __shared__ uint8_t s_valid[TN];     // snapshot validity
+  __shared__ uint8_t s_validP[TN];    // validity after K5
+  __shared__ uint8_t s_created[TN];
+  __shared__ int s_validity[TN];
+  __shared__ float s_id[TN];
+  __shared__ float s_var[TN];
+  __shared__ double s_sum[256];
+  __shared__ int s_cnt[256];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 32 - HALO, y0 = blockIdx.y * 8 - HALO;
+  const int w = a.w, h = a.h;
+
+  // ---- tile load (unconditional, clamped addresses; out-of-image entries are invalid) ----
+#pragma unroll
+  for (int it = 0; it < (TN + 255) / 256; it++) {
+    const int e = tid + it * 256;
+    if (e < TN) {
+      const int gx = x0 + e % TW, gy = y0 + e / TW;
+      const bool inb = gx >= 0 && gx < w && gy >= 0 && gy < h;
+      const int g = inb ? gx + gy * w : 0;
+      const uint8_t v = a.validIn[g];
+      const int vc = a.m.validity[g];
+      const float id = a.m.idepth[g];
+      const float var = a.m.var[g];
+      const uint8_t vv = inb ? v : (uint8_t)0;
+      s_valid[e] = vv;
+      s_validP[e] = vv;
+      s_created[e] = 0;
+      s_validity[e] = vc;
+      s_id[e] = id;
+      s_var[e] = var;
+    }
+  }
+  __syncthreads();
+
+  if (FILL) {
+    // ---- K5 on the inner (TW-4) x (TH-4) region ----
+    constexpr int FW = TW - 4, FH = TH - 4, FN = FW * FH;
+#pragma unroll
+    for (int it = 0; it < (FN + 255) / 256; it++) {
+      const int f = tid + it * 256;
+      if (f < FN) {
+        const int lx = 2 + f % FW, ly = 2 + f / FW;
+        const int e = lx + ly * TW;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= 3 && x < w - 2 && y >= 3 && y < h - 2 && !s_valid[e]) {
+          const int idx = x + y * w;
+          if (!(a.kfMaxGrad[idx] < a.minUseGrad)) {
+            int val = 0;
+#pragma unroll
+            for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+              for (int dx = -2; dx <= 2; dx++) {
+                const int j = e + dx + dy * TW;
+                val += s_valid[j] ? s_validity[j] : 0;
+              }
+            if (val > VAL_SUM_MIN_FOR_UNBLACKLIST || (val > VAL_SUM_MIN_FOR_CREATE && a.m.blacklisted[idx] >= MIN_BLACKLIST)) {
+              float sumIdepthObs = 0, sumIVarObs = 0;
+#pragma unroll
+              for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+                for (int dx = -2; dx <= 2; dx++) {
+                  const int j = e + dx + dy * TW;
+                  if (s_valid[j]) {
+                    const float sv = s_var[j];
+                    sumIdepthObs += s_id[j] / sv;
+                    sumIVarObs += 1.0f / sv;
+                  }
+                }
+              float idepthObs = sumIdepthObs / sumIVarObs;
+              idepthObs = unzero(idepthObs);
+              s_created[e] = 1;
+              s_validP[e] = 1;
+              // nobody reads these entries during K5 (their snapshot validity is 0)
+              s_validity[e] = 0;
+              s_id[e] = idepthObs;
+              s_var[e] = VAR_RANDOM_INIT_INITIAL;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- K6 on the owned 32x8 pixels ----
+  const int lx = HALO + (tid & 31), ly = HALO + (tid >> 5);
+  const int e = lx + ly * TW;
+  const int x = x0 + lx, y = y0 + ly;
+  const bool inImage = x < w && y < h;
+  const int idx = inImage ? x + y * w : 0;
+  const bool created = FILL && s_created[e] != 0;
+  const uint8_t wasValid = s_validP[e];
+  uint8_t nowValid = wasValid;
+  bool smoothed = false, blacklistDec = false;
+  float out_ids = 0.f, out_vars = 0.f;
+  if (inImage && x >= 2 && x < w - 2 && y >= 2 && y < h - 2 && wasValid) {
+    const float c_id = s_id[e];
+    const float c_var = s_var[e];
+    float sum = 0, val_sum = 0, sumIvar = 0;
+    int numOccluding = 0, numNotOccluding = 0;
+#pragma unroll
+    for (int dx = -2; dx <= 2; dx++)
+#pragma unroll
+      for (int dy = -2; dy <= 2; dy++) {
+        const int j = e + dx + dy * TW;
+        const bool nv = s_validP[j] != 0;
+        const float s_idj = s_id[j];
+        const float s_varj = s_var[j];
+        const int vcj = s_validity[j];
+        if (!nv) continue;
+        const float diff = s_idj - c_id;
+        if (DIFF_FAC_SMOOTHING * diff * diff > s_varj + c_var) {
+          if (OCC) { if (s_idj > c_id) numOccluding++; }
+          continue;
+        }
+        val_sum += vcj;
+        if (OCC) numNotOccluding++;
+        const float distFac = (float)(dx * dx + dy * dy) * a.regDistVar;
+        const float ivar = 1.0f / (s_varj + distFac);
+        sum += s_idj * ivar;
+        sumIvar += ivar;
+      }
+    if (val_sum < a.validityTH) {
+      nowValid = 0;
+      blacklistDec = true;
+    } else if (OCC && numOccluding > numNotOccluding) {
+      nowValid = 0;
+    } else {
+      sum = sum / sumIvar;
+      out_ids = unzero(sum);
+      out_vars = 1.0f / sumIvar;
+      smoothed = true;
+    }
+  }
+  if (inImage) {
+    a.validOut[idx] = nowValid;
+    if (created) {
+      a.m.nextID[idx] = 0;
+      a.m.validity[idx] = 0;
+      a.m.idepth[idx] = s_id[e];
+      a.m.var[idx] = s_var[e];
+      a.m.blacklisted[idx] = blacklistDec ? -1 : 0;
+      if (!smoothed) { a.m.idepth_s[idx] = -1; a.m.var_s[idx] = -1; }
+    } else if (blacklistDec) {
+      a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1;
+    }
+    if (smoothed) { a.m.idepth_s[idx] = out_ids; a.m.var_s[idx] = out_vars; }
+  }
+
+  if (SET) {
+    // ---- K8: Frame::setDepth on the owned pixel + (sum, count) partials ----
+    double s = 0;
+    int c = 0;
+    if (inImage) {
+      float ids, vars;
+      if (smoothed) { ids = out_ids; vars = out_vars; }
+      else if (created) { ids = -1.f; vars = -1.f; }
+      else { ids = a.m.idepth_s[idx]; vars = a.m.var_s[idx]; }
+      if (nowValid && (double)ids >= -0.05) {
+        id0[idx] = ids;
+        var0[idx] = vars;
+        s = ids;
+        c = 1;
+      } else {
+        id0[idx] = -1.f;
+        var0[idx] = -1.f;
+      }
+    }
+    s_sum[tid] = s;
+    s_cnt[tid] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) { s_sum[tid] += s_sum[tid + off]; s_cnt[tid] += s_cnt[tid + off]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int b = blockIdx.x + blockIdx.y * gridDim.x;
+      partials[2 * b] = s_sum[0];
+      partials[2 * b + 1] = (double)s_cnt[0];
+    }
+  }
+}
+
 // K8: Frame::setDepth (Frame.cpp:199-243) + per-workgroup (sum, count) partials for meanIdepth / numPoints
 __global__ __launch_bounds__(256) void k_set_depth(HypPlanes m, float* __restrict__ id0, float* __restrict__ var0, int n, double* __restrict__ partials) {
   __shared__ double s_sum[256];
@@ -814,7 +1010,8 @@ extern "C" int lsdhip_depth_create(lsdhip_ctx* c, lsdhip_depthmap** out) {
   HIPCHK(hipMalloc((void**)&dm->d_cand, n * 16));
   HIPCHK(hipMalloc((void**)&dm->d_flags, 64));
   int nb = (int)((n + 255) / 256);
-  HIPCHK(hipMalloc((void**)&dm->d_red, (size_t)(2 * nb + 16) * sizeof(double)));
+  const int ntiles = ((c->w + 31) / 32) * ((c->h + 7) / 8);   // partials of the fused regulariser: one pair per 32x8 tile
+  HIPCHK(hipMalloc((void**)&dm->d_red, (size_t)(2 * (nb > ntiles ? nb : ntiles) + 16) * sizeof(double)));
   HIPCHK(hipHostMalloc((void**)&dm->h_red, 16 * sizeof(double), hipHostMallocMapped));
   *out = dm;
   return LSDHIP_OK;
@@ -844,6 +1041,7 @@ extern "C" int lsdhip_depth_reset(lsdhip_depthmap* dm) {
   return LSDHIP_OK;
 }
 
+static int set_depth_finish(lsdhip_depthmap* dm, int nPartials);
 // Frame::setDepth on the active keyframe: level-0 planes, idepth pyramid, meanIdepth / numPoints
 static int set_depth(lsdhip_depthmap* dm) {
   lsdhip_ctx* c = dm->ctx;
@@ -851,7 +1049,13 @@ static int set_depth(lsdhip_depthmap* dm) {
   int n = c->w * c->h;
   int nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_set_depth, dim3(nb), dim3(256), 0, c->stream, dm->cur, kf->d_idepth[0], kf->d_idepthVar[0], n, dm->d_red + 16);
-  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nb, dm->h_red);
+  return set_depth_finish(dm, nb);
+}
+// second half of Frame::setDepth: mean inverse depth / point count from the (sum, count) partials, idepth pyramid
+static int set_depth_finish(lsdhip_depthmap* dm, int nPartials) {
+  lsdhip_ctx* c = dm->ctx;
+  lsdhip_frame* kf = dm->activeKeyFrame;
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nPartials, dm->h_red);
   int rc = lsd_frame_build_idepth_pyramid(kf);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -890,10 +1094,25 @@ static int regularize(lsdhip_depthmap* dm, bool removeOcclusions, int validityTH
   lsdhip_ctx* c = dm->ctx;
   RegArgs a = reg_args(dm, validityTH);
   dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
-  if (removeOcclusions) hipLaunchKernelGGL(k_regularize<true>, grid, dim3(256), 0, c->stream, a);
-  else hipLaunchKernelGGL(k_regularize<false>, grid, dim3(256), 0, c->stream, a);
+  if (removeOcclusions) hipLaunchKernelGGL((k_reg_fused<false, true, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
+  else hipLaunchKernelGGL((k_reg_fused<false, false, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
   HIPCHK(hipGetLastError());
   swap_valid(dm);
+  return LSDHIP_OK;
+}
+// regularizeDepthMapFillHoles + regularizeDepthMap(false, validityTH) [+ Frame::setDepth] in one launch
+static int fill_regularize(lsdhip_depthmap* dm, int validityTH, bool setDepth) {
+  lsdhip_ctx* c = dm->ctx;
+  lsdhip_frame* kf = dm->activeKeyFrame;
+  RegArgs a = reg_args(dm, validityTH);
+  dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
+  if (setDepth)
+    hipLaunchKernelGGL((k_reg_fused<true, false, true>), grid, dim3(256), 0, c->stream, a, kf->d_idepth[0], kf->d_idepthVar[0], dm->d_red + 16);
+  else
+    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
+  HIPCHK(hipGetLastError());
+  swap_valid(dm);
+  if (setDepth) return set_depth_finish(dm, (int)(grid.x * grid.y));
   return LSDHIP_OK;
 }
 
@@ -1125,17 +1344,11 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   double t0 = now_ms();
   int rc = observe(dm, refs, n);
   if (rc) return rc;
-  rc = fill_holes(dm);
-  if (rc) return rc;
-  rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
-  if (rc) return rc;
   lsdhip_frame* kf = dm->activeKeyFrame;
-  if (!kf->depthHasBeenUpdatedFlag) {
-    rc = set_depth(dm);
-    if (rc) return rc;
-  } else {
-    HIPCHK(hipStreamSynchronize(c->stream));
-  }
+  const bool setDepth = !kf->depthHasBeenUpdatedFlag;
+  rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, setDepth);
+  if (rc) return rc;
+  if (!setDepth) HIPCHK(hipStreamSynchronize(c->stream));
   dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);
   kf->numMappedOnThis++;
   kf->numMappedOnThisTotal++;
@@ -1161,9 +1374,7 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   dm->activeKeyFrameIsReactivated = false;
   rc = regularize(dm, true, VAL_SUM_MIN_FOR_KEEP);
   if (rc) return rc;
-  rc = fill_holes(dm);
-  if (rc) return rc;
-  rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
+  rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, false);
   if (rc) return rc;
 
   // make mean inverse depth be one (DepthMap.cpp:1285-1304)
@@ -1192,11 +1403,7 @@ extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
   lsdhip_ctx* c = dm->ctx;
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
-  int rc = fill_holes(dm);
-  if (rc) return rc;
-  rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
-  if (rc) return rc;
-  rc = set_depth(dm);
+  int rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, true);
   if (rc) return rc;
   lsdhip_frame* kf = dm->activeKeyFrame;
   size_t n = (size_t)c->w * c->h;
