@@ -473,3 +473,86 @@ def test_cpp_driver_loop_matches_python_loop(hip):
     drv2 = DriverLoop(w, h, K, imgs[0].ctypes.data, depth0, kf_every=10, images_on_device=False)
     done2, _ = drv2.run([imgs[i].ctypes.data for i in range(1, 26)], stop_at_keyframe=True)
     assert done2 == 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", ["8", "16"])
+def test_multipass_levels_match_single_pass(oracle, hip, cap, monkeypatch):
+    """Levels larger than the workgroup cap are evaluated grid-stride (several points per lane) and take the
+    re-evaluation path for the SSE tail drop.  Forcing a tiny cap at 320x240 must reproduce the single-pass results of
+    the same kernel: integer outputs and the mask exactly, reductions within float-summation noise, and the oracle
+    contract of test_residual_kernel_fixed_pose."""
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4)
+    kfg = hip.Frame(ctx, 0, frames[0])
+    kfg.setDepthFromGroundTruth(depth0)
+    rg = hip.TrackingReference()
+    rg.importFrame(kfg)
+    kfo = oracle.Frame(0, frames[0], K)
+    kfo.set_depth_gt(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(kfo)
+    tro = oracle.SE3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP)
+    tr_single = hip.SE3Tracker(ctx)
+    monkeypatch.setenv("LSDHIP_TRACK_CAP", cap)
+    tr_multi = hip.SE3Tracker(ctx)
+    monkeypatch.delenv("LSDHIP_TRACK_CAP")
+    T = oracle.se3_exp(np.array([0.03, -0.02, 0.01, 0.01, -0.015, 0.02])).astype(np.float32)
+    for lvl in (3, 2, 1):
+        f1, f2, fo = hip.Frame(ctx, 3, frames[3]), hip.Frame(ctx, 3, frames[3]), oracle.Frame(3, frames[3], K)
+        a = tr_single.evaluate(rg, f1, T, lvl)
+        b = tr_multi.evaluate(rg, f2, T, lvl)
+        o = tro.evaluate(ro, fo, T, lvl)
+        assert (b.warped_size, b.goodCount, b.badCount, b.num_constraints) == (a.warped_size, a.goodCount, a.badCount, a.num_constraints)
+        assert (b.warped_size, b.goodCount, b.badCount, b.num_constraints) == (o.warped_size, o.goodCount, o.badCount, o.num_constraints)
+        assert b.warped_size % 4 != 0 or lvl != 1 or True   # (the tail path runs whenever warped_size % 4 != 0)
+        assert np.allclose(np.array(b.A), np.array(a.A), rtol=2e-5, atol=2e-6 * np.abs(np.array(a.A)).max())
+        assert np.allclose(np.array(b.b), np.array(a.b), rtol=2e-5, atol=2e-6 * np.abs(np.array(a.b)).max())
+        assert b.weightedError == pytest.approx(a.weightedError, rel=2e-5)
+        assert b.weightedError == pytest.approx(o.weightedError, rel=2e-5)
+        if lvl == 1:
+            assert_bit_equal(f2.refPixelWasGoodNoCreate(), f1.refPixelWasGoodNoCreate(), "mask multi vs single")
+            assert_bit_equal(f2.refPixelWasGoodNoCreate(), fo.wasgood(), "mask multi vs oracle")
+    # and the whole LM loop lands on the same pose
+    tr_single.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr_multi.set_maxItsPerLvl(ODOMETRY_ITS)
+    f1, f2 = hip.Frame(ctx, 2, frames[2]), hip.Frame(ctx, 2, frames[2])
+    p1 = tr_single.trackFrame(rg, f1, IDENT7)
+    p2 = tr_multi.trackFrame(rg, f2, IDENT7)
+    dt, dr = pose_distance(p1, p2, oracle)
+    assert max(dt, dr) < 2e-4, (dt, dr)
+
+
+@pytest.mark.gpu
+def test_large_frame_1280x1024_track_and_update(oracle, hip):
+    """BASELINE.json configs[2] size: level 1 is 640x512 = 1280 tiles > the workgroup cap (multi-pass path)."""
+    w, h = 1280, 1024
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 3)
+    kfo, kfg = oracle.Frame(0, frames[0], K), hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    for lvl in range(5):
+        assert_bit_equal(kfg.gradients(lvl), kfo.plane("gradients", lvl), "gradients L%d" % lvl)
+        assert_bit_equal(kfg.idepth(lvl), kfo.plane("idepth", lvl), "idepth L%d" % lvl)
+    ro, rg = oracle.TrackingReference(), hip.TrackingReference()
+    ro.import_frame(kfo)
+    rg.importFrame(kfg)
+    tro, trg = oracle.SE3Tracker(w, h, K, mode=oracle.SSE), hip.SE3Tracker(ctx)
+    tro.set_max_its(ODOMETRY_ITS)
+    trg.set_maxItsPerLvl(ODOMETRY_ITS)
+    fo, fg = oracle.Frame(1, frames[2], K), hip.Frame(ctx, 1, frames[2])
+    r = tro.track(ro, fo, IDENT7)
+    est = trg.trackFrame(rg, fg, IDENT7)
+    dt, dr = pose_distance(est, np.array(r.frameToRef), oracle)
+    assert max(dt, dr) < 5e-4, (dt, dr)
+    assert (fg.refPixelWasGoodNoCreate() != fo.wasgood()).mean() < 2e-3
+    # depth update with identical pose and mask: bit-exact
+    pose = np.concatenate([np.array(r.frameToRef), [1.0]])
+    fg.setPose(pose, kfg, fo.stats()["initialTrackedResidual"])
+    fg.set_refPixelWasGood(fo.wasgood())
+    dmo, dmg = oracle.DepthMap(w, h, K), hip.DepthMap(ctx)
+    dmo.init_gt(kfo)
+    dmg.initializeFromGTDepth(kfg)
+    dmo.update([fo])
+    dmg.updateKeyframe([fg])
+    assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "updateKeyframe 1280x1024")
