@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=250)
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--seq-frames", type=int, default=50,
+                    help="synthetic frames to render (one camera revolution = 50); fewer are played back and forth")
     args = ap.parse_args()
 
     import torch
@@ -130,11 +132,15 @@ def main():
     from lsd_slam_amd import synth
 
     w, h = args.width, args.height
-    n_seq = 50
+    n_seq = args.seq_frames
     frames, depth0, K, gt = synth.make_sequence(w, h, n_seq, seq_index=rank)
     d_frames = torch.from_numpy(frames).cuda(local_rank)           # inputs resident in HBM
     torch.cuda.synchronize()
-    ptr = lambda i: d_frames[i % n_seq].data_ptr()
+    if n_seq >= 50:
+        order = list(range(n_seq))                                  # a closed camera loop
+    else:
+        order = list(range(n_seq)) + list(range(n_seq - 2, 0, -1))  # back and forth: no jump at the wrap-around
+    ptr = lambda i: d_frames[order[i % len(order)]].data_ptr()
 
     # the frame loop itself runs in C++ (liblsdhip_driver.so, include/lsd_slam_hip.hpp): Python only hands over
     # batches of device pointers and, for N > 1, starts the RCCL gather after every new keyframe
@@ -206,12 +212,12 @@ def main():
                         "avg_launch_us": res_ms / res_launches * 1e3,
                         "algorithmic_bytes_per_launch": res_bytes / res_launches}
         out = {
-            "metric": "tracked frames/sec (full track+map loop) at 640x480", "value": value, "unit": "frames/s",
+            "metric": "tracked frames/sec (full track+map loop) at %dx%d" % (w, h), "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "640x480 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
-                                   "(BASELINE.json configs[1]); synthetic scene S1, GT-depth init, new keyframe every %d frames"
-                                   % KF_EVERY,
+            "config": {"workload": "%dx%d 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
+                                   "(BASELINE.json configs[%d]); synthetic scene S1, GT-depth init, new keyframe every %d frames"
+                                   % (w, h, 1 if (w, h) == (640, 480) else 2, KF_EVERY),
                        "width": w, "height": h, "parallelism": "1 sequence per GPU, RCCL gather of keyframe depth planes"},
             "track_fps": st.frames / st.seconds_track if st.seconds_track > 0 else None,
             "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,

@@ -101,6 +101,8 @@ class Context {
   const Mat3f& K() const { return K_; }
   lsdhip_params params;  // the hot-path globals of util/settings.cpp:77-88 this context was created with
   void synchronize() { check(lsdhip_ctx_synchronize(h_), "lsdhip_ctx_synchronize"); }
+  // mapping calls return after enqueueing; host-side results are picked up lazily (lsdhip.h: lsdhip_ctx_set_async)
+  void setAsync(bool on) { check(lsdhip_ctx_set_async(h_, on ? 1 : 0), "lsdhip_ctx_set_async"); }
 
  private:
   Context(int device, int w, int h, const Mat3f& K) : w_(w), h_px_(h), K_(K) {
@@ -186,11 +188,9 @@ class Frame {
   float initialTrackedResidual() const { return stats().initialTrackedResidual; }
   float meanIdepth() const { return stats().meanIdepth; }
   int numPoints() const { return stats().numPoints; }
-  bool depthHasBeenUpdatedFlag() const { return stats().depthHasBeenUpdatedFlag; }
-  void clearDepthHasBeenUpdatedFlag() {  // currentKeyFrame->depthHasBeenUpdatedFlag = false (SlamSystem.cpp:910)
-    Stats s = stats();
-    check(lsdhip_frame_set_counters(h_, s.numFramesTrackedOnThis, s.numMappedOnThis, s.numMappedOnThisTotal, 0), "lsdhip_frame_set_counters");
-  }
+  bool depthHasBeenUpdatedFlag() const { return check(lsdhip_frame_depth_updated(h_), "lsdhip_frame_depth_updated") != 0; }
+  // currentKeyFrame->depthHasBeenUpdatedFlag = false (SlamSystem.cpp:910)
+  void clearDepthHasBeenUpdatedFlag() { check(lsdhip_frame_clear_depth_updated(h_), "lsdhip_frame_clear_depth_updated"); }
 
   // Frame::setPermaRef (Frame.cpp:149-174): keeps the level-QUICK_KF_CHECK_LVL point cloud of `reference` on the host
   inline void setPermaRef(TrackingReference* reference);
@@ -317,9 +317,11 @@ class DepthMap {
     timings();
   }
   void createKeyFrame(Frame* new_keyframe) {
-    check(lsdhip_depth_create_keyframe(h_, new_keyframe->handle(), &lastRescaleFactor), "lsdhip_depth_create_keyframe");
+    check(lsdhip_depth_create_keyframe(h_, new_keyframe->handle(), nullptr), "lsdhip_depth_create_keyframe");
     timings();
   }
+  // GPU time (ms, summed) and call counts of updateKeyframe [0] / createKeyFrame [1] / finalizeKeyFrame [2]; synchronises
+  void gpuTimes(double ms[3], long long calls[3]) { check(lsdhip_depth_gpu_times(h_, ms, calls), "lsdhip_depth_gpu_times"); }
   void finalizeKeyFrame() { check(lsdhip_depth_finalize(h_), "lsdhip_depth_finalize"); timings(); }
   void invalidate() { check(lsdhip_depth_invalidate(h_), "lsdhip_depth_invalidate"); }
   bool isValid() { return lsdhip_depth_is_valid(h_) != 0; }
@@ -337,7 +339,6 @@ class DepthMap {
   void copyPlanesToDevice(float* idepth_dev, float* idepthVar_dev) { check(lsdhip_depth_copy_planes_dev(h_, idepth_dev, idepthVar_dev), "lsdhip_depth_copy_planes_dev"); }
 
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0, msSetDepth = 0;
-  float lastRescaleFactor = 1;  // rescaleFactor of the last createKeyFrame (DepthMap.cpp:1294)
   lsdhip_depthmap* handle() const { return h_; }
 
  private:

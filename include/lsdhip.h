@@ -66,6 +66,11 @@ typedef struct lsdhip_hypothesis {
 int lsdhip_ctx_create(int device, int w, int h, const float K[4], const lsdhip_params* params, lsdhip_ctx** out);
 void lsdhip_ctx_destroy(lsdhip_ctx* ctx);
 void* lsdhip_ctx_stream(lsdhip_ctx* ctx);        /* hipStream_t of the context */
+/* on != 0: the DepthMap calls (update / createKeyFrame / finalizeKeyFrame) return once their kernels are enqueued; the
+ * values the host only needs later (Frame::meanIdepth / numPoints, the Sim3 scale of a new keyframe, a propagation
+ * overflow) are picked up by the first call that asks for them (lsdhip_frame_stats / _get_pose) or by
+ * lsdhip_ctx_synchronize.  Default 0: every call is synchronous, like the reference's. */
+int lsdhip_ctx_set_async(lsdhip_ctx* ctx, int on);
 int lsdhip_ctx_synchronize(lsdhip_ctx* ctx);
 const char* lsdhip_last_error(void);
 /* per-level intrinsics fx,fy,cx,cy,fxi,fyi,cxi,cyi (C/DataStructures/Frame.cpp:445-459) */
@@ -100,6 +105,10 @@ int lsdhip_frame_get_pose(lsdhip_frame* f, double thisToParent_sim3[8]);
 int lsdhip_frame_stats(lsdhip_frame* f, float out[8]);
 int lsdhip_frame_set_counters(lsdhip_frame* f, int numFramesTrackedOnThis, int numMappedOnThis,
                               int numMappedOnThisTotal, int depthHasBeenUpdatedFlag);
+/* Frame::depthHasBeenUpdatedFlag alone (read / reset by SlamSystem::trackFrame, C/SlamSystem.cpp:907-911): host-side flag,
+ * never synchronises */
+int lsdhip_frame_depth_updated(lsdhip_frame* f);
+int lsdhip_frame_clear_depth_updated(lsdhip_frame* f);
 /* TrackingReference::makePointCloud(level) (C/Tracking/TrackingReference.cpp:96-147) for the keyframe `kf`,
  * in the reference's x-outer/y-inner order.  Any output pointer may be NULL.  Returns the number of points. */
 int lsdhip_ref_pointcloud(lsdhip_frame* kf, int level, float* pos3_host, float* colorAndVar2_host,
@@ -174,6 +183,9 @@ int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* 
 /* timing fields DepthMap keeps public (DepthMap.h:86-93): msUpdate, msCreate, msFinalize, msObserve, msRegularize,
  * msPropagate, msFillHoles, msSetDepth (exponential moving averages, ms) */
 int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);
+/* GPU time (HIP events on the context's stream, ms, summed since creation) and call counts of updateKeyframe [0],
+ * createKeyFrame [1], finalizeKeyFrame [2]; synchronises the stream */
+int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]);
 
 /* ---- measurement hooks ---------------------------------------------------------------------------- */
 /* Accumulated HIP-event time (ms) and launch count of the residual kernel on the context's stream since the last

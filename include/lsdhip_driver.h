@@ -10,9 +10,9 @@ extern "C" {
 #endif
 typedef struct lsdloop lsdloop;
 typedef struct lsdloop_stats {
-  double seconds_track;      /* wall time inside frame creation + SE3Tracker::trackFrame */
-  double seconds_map;        /* wall time inside DepthMap::updateKeyframe (frames that did not become keyframes) */
-  double seconds_keyframe;   /* wall time inside finalizeKeyFrame + createKeyFrame (frames that became keyframes) */
+  double seconds_track;      /* wall time of the batches minus the two below: frame creation + SE3Tracker::trackFrame */
+  double seconds_map;        /* GPU time (HIP events) of DepthMap::updateKeyframe (frames that did not become keyframes) */
+  double seconds_keyframe;   /* GPU time of finalizeKeyFrame + createKeyFrame (frames that became keyframes) */
   long long frames;          /* frames tracked */
   long long updates;         /* updateKeyframe calls */
   long long keyframes;       /* keyframes created */

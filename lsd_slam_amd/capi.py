@@ -48,6 +48,7 @@ def _signatures():
         "lsdhip_ctx_destroy": (None, [vp]),
         "lsdhip_ctx_stream": (vp, [vp]),
         "lsdhip_ctx_synchronize": (i, [vp]),
+        "lsdhip_ctx_set_async": (i, [vp, i]),
         "lsdhip_last_error": (C.c_char_p, []),
         "lsdhip_ctx_intrinsics": (i, [vp, i, vp]),
         "lsdhip_frame_create": (i, [vp, i, vp, pvp]),
@@ -64,6 +65,8 @@ def _signatures():
         "lsdhip_frame_get_pose": (i, [vp, vp]),
         "lsdhip_frame_stats": (i, [vp, vp]),
         "lsdhip_frame_set_counters": (i, [vp, i, i, i, i]),
+        "lsdhip_frame_depth_updated": (i, [vp]),
+        "lsdhip_frame_clear_depth_updated": (i, [vp]),
         "lsdhip_ref_pointcloud": (i, [vp, i, vp, vp, vp, vp]),
         "lsdhip_tracker_create": (i, [vp, pvp]),
         "lsdhip_tracker_destroy": (None, [vp]),
@@ -88,6 +91,7 @@ def _signatures():
         "lsdhip_depth_stage": (i, [vp, i, pvp, i]),
         "lsdhip_depth_copy_planes_dev": (i, [vp, vp, vp]),
         "lsdhip_depth_timings": (i, [vp, vp]),
+        "lsdhip_depth_gpu_times": (i, [vp, vp, vp]),
         "lsdhip_prof_enable": (i, [vp, i]),
         "lsdhip_prof_read": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
         "lsdhip_prof_reset": (i, [vp]),

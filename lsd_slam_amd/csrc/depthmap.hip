@@ -90,6 +90,7 @@ struct ObserveArgs {
   float minUseGrad, cameraPixelNoise2;
   int allowNegativeIdepths, useSubpixelStereo;
   int kfNumFramesTrackedOnThis, kfNumMappedOnThis;
+  StereoRef one;   // nRefs == 1 (the blockUntilMapped case): the reference travels in the kernel arguments, no staging copy
 };
 
 // DepthMap::doLineStereo (DepthMap.cpp:1442-1972).  Status codes as in the reference: >= 0 matching error,
@@ -363,6 +364,7 @@ LSD_HD bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x,
 }
 
 // observeDepthRow body for one pixel (DepthMap.cpp:117-143), hypothesis updated in place.
+template <bool ONE>
 LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int y) {
   if (x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3) return;
   const int idx = x + y * a.w;
@@ -373,7 +375,7 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
 
   if (!hasHypothesis) {
     // observeDepthCreate (DepthMap.cpp:237-292)
-    const StereoRef& rf = a.refs[a.reactivated ? a.nRefs - 1 : 0];
+    const StereoRef& rf = ONE ? a.one : a.refs[a.reactivated ? a.nRefs - 1 : 0];
     if (rf.parentIsKF && rf.wasGood != nullptr && !rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)]) return;
     float epx, epy;
     if (!make_and_check_epl(a, rf, x, y, &epx, &epy)) return;
@@ -400,10 +402,10 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
   if (!a.reactivated) {
     int rel = (int)nextID - a.byIDOffset;
     if (rel >= a.nByID) return;
-    refIdx = rel < 0 ? 0 : a.refByID[rel];
+    refIdx = (ONE || rel < 0) ? 0 : a.refByID[rel];
   } else
     refIdx = a.nRefs - 1;
-  const StereoRef& rf = a.refs[refIdx];
+  const StereoRef& rf = ONE ? a.one : a.refs[refIdx];
   if (rf.parentIsKF && rf.wasGood != nullptr && !rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)]) return;
   float epx, epy;
   if (!make_and_check_epl(a, rf, x, y, &epx, &epy)) return;
@@ -462,10 +464,11 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
 }
 
 // K4: observeDepthRow over the whole map, one pixel per lane.
+template <bool ONE>
 __global__ __launch_bounds__(256) void k_observe(ObserveArgs a) {
   const int x = blockIdx.x * 32 + (threadIdx.x & 31);
   const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
-  observe_pixel(a, x, y);
+  observe_pixel<ONE>(a, x, y);
 }
 
 struct RegArgs {
@@ -806,7 +809,9 @@ __global__ __launch_bounds__(256) void k_sum_valid_idepth(HypPlanes m, int n, do
   }
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s_sum[0]; partials[2 * blockIdx.x + 1] = (double)s_cnt[0]; }
 }
-__global__ __launch_bounds__(256) void k_reduce_pairs(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+// out = pinned DeferredSlot (sum, count, flag); dev_out = the same pair in HBM for a kernel that follows (k_rescale)
+__global__ __launch_bounds__(256) void k_reduce_pairs(const double* __restrict__ partials, int nblocks, double* __restrict__ out,
+                                                       double* __restrict__ dev_out, const int* __restrict__ flag) {
   __shared__ double s_a[256], s_b[256];
   double a = 0, b = 0;
   for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
@@ -817,10 +822,17 @@ __global__ __launch_bounds__(256) void k_reduce_pairs(const double* __restrict__
     if (threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[0] = s_a[0]; out[1] = s_b[0]; }
+  if (threadIdx.x == 0) {
+    out[0] = s_a[0]; out[1] = s_b[0]; out[2] = flag ? (double)flag[0] : 0.0;
+    if (dev_out) { dev_out[0] = s_a[0]; dev_out[1] = s_b[0]; }
+  }
 }
 // rescale (DepthMap.cpp:1296-1304)
-__global__ __launch_bounds__(256) void k_rescale(HypPlanes m, int n, float rescaleFactor, float rescaleFactor2) {
+__global__ __launch_bounds__(256) void k_rescale(HypPlanes m, int n, const double* __restrict__ sumCount) {
+  // rescaleFactor = numIdepth / sumIdepth with both cast to float first (DepthMap.cpp:1286-1294)
+  const float sumIdepth = (float)sumCount[0], numIdepth = (float)sumCount[1];
+  const float rescaleFactor = numIdepth / sumIdepth;
+  const float rescaleFactor2 = rescaleFactor * rescaleFactor;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || !m.valid[i]) return;
   m.idepth[i] *= rescaleFactor;
@@ -1027,6 +1039,7 @@ extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
   (void)hipFree(dm->d_flags);
   (void)hipFree(dm->d_red);
   (void)hipHostFree(dm->h_red);
+  for (int i = 0; i < 8; i++) if (dm->ev[i][0]) { (void)hipEventDestroy(dm->ev[i][0]); (void)hipEventDestroy(dm->ev[i][1]); }
   if (dm->d_stage) (void)hipFree(dm->d_stage);
   if (dm->h_stage) (void)hipHostFree(dm->h_stage);
   delete dm;
@@ -1055,15 +1068,17 @@ static int set_depth(lsdhip_depthmap* dm) {
 static int set_depth_finish(lsdhip_depthmap* dm, int nPartials) {
   lsdhip_ctx* c = dm->ctx;
   lsdhip_frame* kf = dm->activeKeyFrame;
-  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nPartials, dm->h_red);
+  const int slot = lsd_ctx_take_slot(c);
+  if (slot < 0) return slot;
+  if (kf->pendStats >= 0) c->slot_stats_owner[kf->pendStats] = nullptr;   // superseded by this setDepth
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nPartials, (double*)&c->h_slots[slot],
+                     (double*)nullptr, (const int*)nullptr);
+  kf->pendStats = slot;
+  c->slot_stats_owner[slot] = kf;
   int rc = lsd_frame_build_idepth_pyramid(kf);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(c->stream));
-  float sumIdepth = (float)dm->h_red[0];
-  int numIdepth = (int)dm->h_red[1];
-  kf->meanIdepth = sumIdepth / numIdepth;
-  kf->numPoints = numIdepth;
   kf->depthHasBeenUpdatedFlag = true;
+  if (!c->async) return lsd_frame_resolve(kf);
   return LSDHIP_OK;
 }
 
@@ -1158,44 +1173,54 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   lsdhip_ctx* c = dm->ctx;
   lsdhip_frame* kf = dm->activeKeyFrame;
   if (n <= 0) { lsd_set_error("updateKeyframe: empty reference deque"); return LSDHIP_E_ARG; }
-  // host staging lives in one pinned block (refs | refByID): the copy needs no synchronisation, and the block is not
-  // touched again before the next updateKeyframe, which starts after this one has been synchronised
-  size_t byIDCount = 0;
-  {
-    int offset0 = refs[0]->id, last = offset0 - 1;
-    for (int i = 0; i < n; i++) if (refs[i]->id > last) last = refs[i]->id;
-    byIDCount = (size_t)(last - offset0 + 1);
-  }
-  const size_t refsBytes = (sizeof(StereoRef) * (size_t)n + 255) / 256 * 256;
-  const size_t need = refsBytes + sizeof(int) * byIDCount;
-  if (need > dm->stage_bytes) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (dm->h_stage) HIPCHK(hipHostFree(dm->h_stage));
-    if (dm->d_stage) HIPCHK(hipFree(dm->d_stage));
-    dm->stage_bytes = need > 65536 ? need * 2 : 65536;
-    HIPCHK(hipHostMalloc((void**)&dm->h_stage, dm->stage_bytes, hipHostMallocDefault));
-    HIPCHK(hipMalloc((void**)&dm->d_stage, dm->stage_bytes));
-  }
-  StereoRef* hrefs = (StereoRef*)dm->h_stage;
-  int* byID = (int*)(dm->h_stage + refsBytes);
-  size_t nByID = 0;
-  int offset = refs[0]->id;
   for (int i = 0; i < n; i++) {
-    lsdhip_frame* fr = refs[i];
-    if (fr->trackingParentID != kf->id) {
+    if (refs[i]->trackingParentID != kf->id) {
       // DepthMap.cpp:1099 needs getScaledCamToWorld() from the pose graph, which stays on the host side of the boundary
       lsd_set_error("updateKeyframe: frame %d was tracked on keyframe %d, active keyframe is %d (pose-graph path is out of scope)",
-                    fr->id, fr->trackingParentID, kf->id);
+                    refs[i]->id, refs[i]->trackingParentID, kf->id);
       return LSDHIP_E_STATE;
     }
-    prepare_stereo(dm, fr, hrefs[i]);
-    while ((int)nByID + offset <= fr->id) byID[nByID++] = i;
   }
-  HIPCHK(hipMemcpyAsync(dm->d_stage, dm->h_stage, refsBytes + sizeof(int) * nByID, hipMemcpyHostToDevice, c->stream));
-  dm->d_refs = (StereoRef*)dm->d_stage;
-  dm->d_refByID = (int*)(dm->d_stage + refsBytes);
-
+  size_t nByID = 0;
+  const int offset = refs[0]->id;
   ObserveArgs a;
+  if (n == 1) {
+    // one reference frame (blockUntilMapped): it travels in the kernel arguments
+    prepare_stereo(dm, refs[0], a.one);
+    nByID = 1;
+    dm->d_refs = nullptr;
+    dm->d_refByID = nullptr;
+  } else {
+    // host staging lives in one pinned block (refs | refByID); it is reused by the next call, which must not start
+    // before this copy has been consumed
+    size_t byIDCount = 0;
+    {
+      int last = offset - 1;
+      for (int i = 0; i < n; i++) if (refs[i]->id > last) last = refs[i]->id;
+      byIDCount = (size_t)(last - offset + 1);
+    }
+    const size_t refsBytes = (sizeof(StereoRef) * (size_t)n + 255) / 256 * 256;
+    const size_t need = refsBytes + sizeof(int) * byIDCount;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (need > dm->stage_bytes) {
+      if (dm->h_stage) HIPCHK(hipHostFree(dm->h_stage));
+      if (dm->d_stage) HIPCHK(hipFree(dm->d_stage));
+      dm->stage_bytes = need > 65536 ? need * 2 : 65536;
+      HIPCHK(hipHostMalloc((void**)&dm->h_stage, dm->stage_bytes, hipHostMallocDefault));
+      HIPCHK(hipMalloc((void**)&dm->d_stage, dm->stage_bytes));
+    }
+    StereoRef* hrefs = (StereoRef*)dm->h_stage;
+    int* byID = (int*)(dm->h_stage + refsBytes);
+    for (int i = 0; i < n; i++) {
+      prepare_stereo(dm, refs[i], hrefs[i]);
+      while ((int)nByID + offset <= refs[i]->id) byID[nByID++] = i;
+    }
+    HIPCHK(hipMemcpyAsync(dm->d_stage, dm->h_stage, refsBytes + sizeof(int) * nByID, hipMemcpyHostToDevice, c->stream));
+    dm->d_refs = (StereoRef*)dm->d_stage;
+    dm->d_refByID = (int*)(dm->d_stage + refsBytes);
+    memset(&a.one, 0, sizeof(a.one));
+  }
+
   a.m = dm->cur;
   a.kfImage = kf->d_image[0];
   a.kfGrad = kf->d_grad[0];
@@ -1215,12 +1240,13 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   a.useSubpixelStereo = c->params.useSubpixelStereo;
   a.kfNumFramesTrackedOnThis = kf->numFramesTrackedOnThis;
   a.kfNumMappedOnThis = kf->numMappedOnThis;
-  hipLaunchKernelGGL(k_observe, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
+  if (n == 1) hipLaunchKernelGGL(k_observe<true>, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_observe<false>, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }
 
-static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk) {
+static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNow) {
   lsdhip_ctx* c = dm->ctx;
   lsdhip_frame* old = dm->activeKeyFrame;
   size_t n = (size_t)c->w * c->h;
@@ -1253,13 +1279,15 @@ static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk) {
   HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, c->stream));
   hipLaunchKernelGGL(k_prop_candidates, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_prop_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
-  int flag = 0;
-  HIPCHK(hipMemcpyAsync(&flag, dm->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (flag) {
-    lsd_set_error("propagateDepth: more than %d source hypotheses mapped to one target pixel", PROP_SLOT_CAP);
-    return LSDHIP_E_CAPACITY;
-  }
+  if (checkOverflowNow) {
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, dm->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (flag) {
+      lsd_set_error("propagateDepth: more than %d source hypotheses mapped to one target pixel", PROP_SLOT_CAP);
+      return LSDHIP_E_CAPACITY;
+    }
+  }   // otherwise the flag travels with the rescale sums of createKeyFrame (one synchronisation for the whole call)
   std::swap(dm->cur, dm->oth);
   return LSDHIP_OK;
 }
@@ -1272,6 +1300,37 @@ struct StageTimer {
   ~StageTimer() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
 };
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// GPU-side duration of a mapping call: an event pair on the stream, read back lazily (kind 0 update, 1 create, 2 finalize)
+static void timing_collect(lsdhip_depthmap* dm, bool all) {
+  for (int i = 0; i < 8; i++) {
+    if (!dm->ev_pending[i]) continue;
+    if (!all && hipEventQuery(dm->ev[i][1]) != hipSuccess) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, dm->ev[i][0], dm->ev[i][1]) == hipSuccess) {
+      dm->gpu_ms[dm->ev_kind[i]] += ms;
+      dm->gpu_calls[dm->ev_kind[i]]++;
+    }
+    dm->ev_pending[i] = false;
+  }
+}
+static int timing_begin(lsdhip_depthmap* dm, int kind) {
+  const int i = dm->ev_next;
+  dm->ev_next = (dm->ev_next + 1) % 8;
+  if (dm->ev_pending[i]) {
+    HIPCHK(hipEventSynchronize(dm->ev[i][1]));
+    timing_collect(dm, false);
+  }
+  if (!dm->ev[i][0]) { HIPCHK(hipEventCreate(&dm->ev[i][0])); HIPCHK(hipEventCreate(&dm->ev[i][1])); }
+  dm->ev_kind[i] = kind;
+  HIPCHK(hipEventRecord(dm->ev[i][0], dm->ctx->stream));
+  return i;
+}
+static int timing_end(lsdhip_depthmap* dm, int i) {
+  HIPCHK(hipEventRecord(dm->ev[i][1], dm->ctx->stream));
+  dm->ev_pending[i] = true;
+  return LSDHIP_OK;
+}
 
 extern "C" int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   if (!dm || !kf) return LSDHIP_E_ARG;
@@ -1342,14 +1401,18 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   lsdhip_ctx* c = dm->ctx;
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
+  const int ev = timing_begin(dm, 0);
+  if (ev < 0) return ev;
   int rc = observe(dm, refs, n);
   if (rc) return rc;
   lsdhip_frame* kf = dm->activeKeyFrame;
   const bool setDepth = !kf->depthHasBeenUpdatedFlag;
   rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, setDepth);
   if (rc) return rc;
-  if (!setDepth) HIPCHK(hipStreamSynchronize(c->stream));
-  dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);
+  rc = timing_end(dm, ev);
+  if (rc) return rc;
+  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
+  dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);   // host wall time of the call (enqueue time only in async mode)
   kf->numMappedOnThis++;
   kf->numMappedOnThisTotal++;
   return LSDHIP_OK;
@@ -1367,7 +1430,9 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   for (int i = 0; i < 3; i++) newToOld.t[i] = nk->thisToParent_raw.t[i];
   lsdm::SE3dH oldToNew = lsdm::se3d_inverse(newToOld);
 
-  int rc = propagate(dm, nk);
+  const int ev = timing_begin(dm, 1);
+  if (ev < 0) return ev;
+  int rc = propagate(dm, nk, false);
   if (rc) return rc;
   dm->msPropagate = ema(dm->msPropagate, now_ms() - t0);
   dm->activeKeyFrame = nk;
@@ -1377,24 +1442,33 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, false);
   if (rc) return rc;
 
-  // make mean inverse depth be one (DepthMap.cpp:1285-1304)
+  // make mean inverse depth be one (DepthMap.cpp:1285-1304): the factor is formed on the device (k_rescale), the host
+  // copy of (sum, count) and the propagation overflow flag are a deferred result of the new keyframe
   int n = c->w * c->h;
   int nb = (n + 255) / 256;
+  const int slot = lsd_ctx_take_slot(c);
+  if (slot < 0) return slot;
   hipLaunchKernelGGL(k_sum_valid_idepth, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, dm->d_red + 16);
-  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nb, dm->h_red);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  float sumIdepth = (float)dm->h_red[0], numIdepth = (float)dm->h_red[1];
-  float rescaleFactor = numIdepth / sumIdepth;
-  float rescaleFactor2 = rescaleFactor * rescaleFactor;
-  hipLaunchKernelGGL(k_rescale, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, rescaleFactor, rescaleFactor2);
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nb, (double*)&c->h_slots[slot], dm->d_red,
+                     (const int*)dm->d_flags);
+  hipLaunchKernelGGL(k_rescale, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, dm->d_red);
   lsdm::SE3dH back = lsdm::se3d_inverse(oldToNew);
   nk->thisToParent_raw.q = back.q;
   for (int i = 0; i < 3; i++) nk->thisToParent_raw.t[i] = back.t[i];
-  nk->thisToParent_raw.s = rescaleFactor;
-  if (rescale_out) *rescale_out = rescaleFactor;
+  if (nk->pendRescale >= 0) c->slot_rescale_owner[nk->pendRescale] = nullptr;
+  nk->pendRescale = slot;
+  c->slot_rescale_owner[slot] = nk;
   rc = set_depth(dm);
+  if (rc) return rc;
+  rc = timing_end(dm, ev);
+  if (rc) return rc;
+  if (!c->async || rescale_out) {
+    rc = lsd_frame_resolve(nk);
+    if (rc) return rc;
+    if (rescale_out) *rescale_out = (float)nk->thisToParent_raw.s;
+  }
   dm->msCreate = ema(dm->msCreate, now_ms() - t0);
-  return rc;
+  return LSDHIP_OK;
 }
 
 extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
@@ -1403,23 +1477,29 @@ extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
   lsdhip_ctx* c = dm->ctx;
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
+  const int ev = timing_begin(dm, 2);
+  if (ev < 0) return ev;
   int rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, true);
   if (rc) return rc;
   lsdhip_frame* kf = dm->activeKeyFrame;
   size_t n = (size_t)c->w * c->h;
-  if (!kf->d_idepth_reAct) {
-    char* base = nullptr;
-    HIPCHK(hipMalloc((void**)&base, n * 9 + 512));
-    HIPCHK(hipMemsetAsync(base, 0, n * 9 + 512, c->stream));
-    kf->d_idepth_reAct = (float*)base;
-    kf->d_idepthVar_reAct = (float*)(base + (n * 4 + 255) / 256 * 256);
-    kf->d_validity_reAct = (uint8_t*)(base + 2 * ((n * 4 + 255) / 256 * 256));
-  }
   hipLaunchKernelGGL(k_take_react, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dm->cur, kf->d_idepth_reAct,
                      kf->d_idepthVar_reAct, kf->d_validity_reAct, (int)n);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  rc = timing_end(dm, ev);
+  if (rc) return rc;
+  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
   kf->reActValid = true;
   dm->msFinalize = ema(dm->msFinalize, now_ms() - t0);
+  return LSDHIP_OK;
+}
+
+// GPU time (ms, summed) and call counts of updateKeyframe / createKeyFrame / finalizeKeyFrame since creation
+extern "C" int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]) {
+  if (!dm || !ms_out || !calls_out) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(dm->ctx->device));
+  HIPCHK(hipStreamSynchronize(dm->ctx->stream));
+  timing_collect(dm, true);
+  for (int i = 0; i < 3; i++) { ms_out[i] = dm->gpu_ms[i]; calls_out[i] = dm->gpu_calls[i]; }
   return LSDHIP_OK;
 }
 
@@ -1488,7 +1568,7 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
     case 3: rc = regularize(dm, true, VAL_SUM_MIN_FOR_KEEP); break;
     case 4:
       if (!refs || n < 1) return LSDHIP_E_ARG;
-      rc = propagate(dm, refs[0]);
+      rc = propagate(dm, refs[0], true);
       if (rc == LSDHIP_OK) { dm->activeKeyFrame = refs[0]; dm->activeKeyFrameIsReactivated = false; }
       break;
     default: return LSDHIP_E_ARG;

@@ -330,6 +330,8 @@ extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], con
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&c->ev_a));
   HIPCHK(hipEventCreate(&c->ev_b));
+  HIPCHK(hipHostMalloc((void**)&c->h_slots, LSD_NUM_SLOTS * sizeof(DeferredSlot), hipHostMallocMapped));
+  memset(c->h_slots, 0, LSD_NUM_SLOTS * sizeof(DeferredSlot));
   *out = c;
   return LSDHIP_OK;
 }
@@ -339,6 +341,7 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (void* p : c->free_arenas) (void)hipFree(p);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+  if (c->h_slots) (void)hipHostFree(c->h_slots);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   (void)hipStreamDestroy(c->stream);
@@ -346,9 +349,53 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
 }
 extern "C" void* lsdhip_ctx_stream(lsdhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
+  if (c) {
+    for (int i = 0; i < LSD_NUM_SLOTS; i++) {   // pick up every deferred result
+      if (c->slot_stats_owner[i]) { int rc = lsd_frame_resolve(c->slot_stats_owner[i]); if (rc) return rc; }
+      if (c->slot_rescale_owner[i]) { int rc = lsd_frame_resolve(c->slot_rescale_owner[i]); if (rc) return rc; }
+    }
+  }
   if (!c) return LSDHIP_E_ARG;
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_set_async(lsdhip_ctx* c, int on) {
+  if (!c) return LSDHIP_E_ARG;
+  c->async = on != 0;
+  return LSDHIP_OK;
+}
+int lsd_ctx_take_slot(lsdhip_ctx* c) {
+  const int i = c->slot_next;
+  c->slot_next = (c->slot_next + 1) % LSD_NUM_SLOTS;
+  if (c->slot_stats_owner[i]) { int rc = lsd_frame_resolve(c->slot_stats_owner[i]); if (rc) return rc; }
+  if (c->slot_rescale_owner[i]) { int rc = lsd_frame_resolve(c->slot_rescale_owner[i]); if (rc) return rc; }
+  return i;
+}
+int lsd_frame_resolve(lsdhip_frame* f) {
+  if (f->pendStats < 0 && f->pendRescale < 0) return LSDHIP_OK;
+  lsdhip_ctx* c = f->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int rc = LSDHIP_OK;
+  if (f->pendRescale >= 0) {
+    const DeferredSlot& s = c->h_slots[f->pendRescale];
+    // rescaleFactor = numIdepth / sumIdepth in float (DepthMap.cpp:1294), the expression k_rescale evaluated
+    const float sumIdepth = (float)s.sum, numIdepth = (float)s.count;
+    f->thisToParent_raw.s = numIdepth / sumIdepth;
+    if (s.flag != 0) { lsd_set_error("propagateDepth: too many source hypotheses mapped to one target pixel"); rc = LSDHIP_E_CAPACITY; }
+    c->slot_rescale_owner[f->pendRescale] = nullptr;
+    f->pendRescale = -1;
+  }
+  if (f->pendStats >= 0) {
+    const DeferredSlot& s = c->h_slots[f->pendStats];
+    const float sumIdepth = (float)s.sum;
+    const int numIdepth = (int)s.count;
+    f->meanIdepth = sumIdepth / numIdepth;
+    f->numPoints = numIdepth;
+    c->slot_stats_owner[f->pendStats] = nullptr;
+    f->pendStats = -1;
+  }
+  return rc;
 }
 extern "C" int lsdhip_ctx_intrinsics(lsdhip_ctx* c, int level, float out[8]) {
   if (!c || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
@@ -391,6 +438,9 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
   for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
   take((size_t)c->wl[1] * c->hl[1]);
+  take(n0 * 4);   // re-activation data (Frame::takeReActivationData): idepth, idepthVar, validity
+  take(n0 * 4);
+  take(n0);
   char* base = nullptr;
   c->arena_bytes = align_up(off, 256);
   if (!c->free_arenas.empty()) {
@@ -409,6 +459,9 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   for (int l = 0; l < LSD_LEVELS; l++) f->d_idepth[l] = (float*)(base + offs[k++]);
   for (int l = 0; l < LSD_LEVELS; l++) f->d_idepthVar[l] = (float*)(base + offs[k++]);
   f->d_wasGood = (uint8_t*)(base + offs[k++]);
+  f->d_idepth_reAct = (float*)(base + offs[k++]);
+  f->d_idepthVar_reAct = (float*)(base + offs[k++]);
+  f->d_validity_reAct = (uint8_t*)(base + offs[k++]);
   *out = f;
   return LSDHIP_OK;
 }
@@ -485,11 +538,8 @@ extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(f->d_gray);
   }
-  if (f->d_idepth_reAct) {
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(f->d_idepth_reAct);
-  }
+  if (f->pendStats >= 0) c->slot_stats_owner[f->pendStats] = nullptr;
+  if (f->pendRescale >= 0) c->slot_rescale_owner[f->pendRescale] = nullptr;
   delete f;
 }
 extern "C" int lsdhip_frame_id(lsdhip_frame* f) { return f ? f->id : -1; }
@@ -570,13 +620,21 @@ extern "C" int lsdhip_frame_set_pose(lsdhip_frame* f, const double s[8], lsdhip_
 }
 extern "C" int lsdhip_frame_get_pose(lsdhip_frame* f, double s[8]) {
   if (!f || !s) return LSDHIP_E_ARG;
+  { int rc = lsd_frame_resolve(f); if (rc) return rc; }   // the Sim3 scale of a new keyframe is a deferred result
   s[0] = f->thisToParent_raw.q.w; s[1] = f->thisToParent_raw.q.x; s[2] = f->thisToParent_raw.q.y; s[3] = f->thisToParent_raw.q.z;
   s[4] = f->thisToParent_raw.t[0]; s[5] = f->thisToParent_raw.t[1]; s[6] = f->thisToParent_raw.t[2];
   s[7] = f->thisToParent_raw.s;
   return LSDHIP_OK;
 }
+extern "C" int lsdhip_frame_depth_updated(lsdhip_frame* f) { return f ? (f->depthHasBeenUpdatedFlag ? 1 : 0) : LSDHIP_E_ARG; }
+extern "C" int lsdhip_frame_clear_depth_updated(lsdhip_frame* f) {
+  if (!f) return LSDHIP_E_ARG;
+  f->depthHasBeenUpdatedFlag = false;
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_frame_stats(lsdhip_frame* f, float out[8]) {
   if (!f || !out) return LSDHIP_E_ARG;
+  { int rc = lsd_frame_resolve(f); if (rc) return rc; }   // meanIdepth / numPoints are deferred results
   out[0] = f->initialTrackedResidual; out[1] = f->meanIdepth; out[2] = (float)f->numPoints;
   out[3] = (float)f->numFramesTrackedOnThis; out[4] = (float)f->numMappedOnThis; out[5] = (float)f->numMappedOnThisTotal;
   out[6] = f->depthHasBeenUpdatedFlag ? 1.f : 0.f; out[7] = 0.f;

@@ -107,8 +107,20 @@ struct TrackSummary {
   double bytes;              // algorithmic bytes of all evaluations of the job
 };
 
+// A result the host needs eventually but not now (mean inverse depth / point count of a setDepth, the rescale factor
+// of a createKeyFrame): written by the device into a pinned slot, read by the host at the first later point that
+// synchronises anyway (or when somebody asks for the value).
+struct DeferredSlot { double sum, count, flag, pad; };
+#define LSD_NUM_SLOTS 32
+struct lsdhip_frame;
+
 struct lsdhip_ctx {
   int device = 0;
+  bool async = false;                    // lsdhip_ctx_set_async: mapping calls return after enqueueing
+  DeferredSlot* h_slots = nullptr;       // pinned, device-mapped ring
+  lsdhip_frame* slot_stats_owner[LSD_NUM_SLOTS] = {};
+  lsdhip_frame* slot_rescale_owner[LSD_NUM_SLOTS] = {};
+  int slot_next = 0;
   int w = 0, h = 0;
   int wl[LSD_LEVELS], hl[LSD_LEVELS];
   LevelIntr intr[LSD_LEVELS];
@@ -149,6 +161,8 @@ struct lsdhip_frame {
   int numFramesTrackedOnThis = 0, numMappedOnThis = 0, numMappedOnThisTotal = 0;
   float meanIdepth = 1;
   int numPoints = 0;
+  int pendStats = -1;                   // slot index of a setDepth whose (sum, count) the host has not read yet
+  int pendRescale = -1;                 // slot index of a createKeyFrame whose rescale factor the host has not read yet
   bool depthHasBeenUpdatedFlag = false;
   // re-activation data (Frame::takeReActivationData)
   float* d_idepth_reAct = nullptr;
@@ -230,6 +244,13 @@ struct lsdhip_depthmap {
   int* d_flags = nullptr;          // overflow flag etc.
   double* d_red = nullptr;         // reduction scratch (sum, count)
   double* h_red = nullptr;         // pinned
+  // GPU-side timing of the mapping calls (events on the context's stream; read back lazily)
+  hipEvent_t ev[8][2] = {};
+  int ev_kind[8] = {};
+  bool ev_pending[8] = {};
+  int ev_next = 0;
+  double gpu_ms[3] = {0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame
+  long long gpu_calls[3] = {0, 0, 0};
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
         msSetDepth = 0;
 };
@@ -239,3 +260,5 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f);
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);
+int lsd_frame_resolve(lsdhip_frame* f);        // reads the frame's deferred results (synchronises the stream if any)
+int lsd_ctx_take_slot(lsdhip_ctx* c);          // next slot of the ring (resolving whoever still waits on it)

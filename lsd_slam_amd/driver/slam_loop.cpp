@@ -14,6 +14,8 @@ struct lsdloop {
   std::unique_ptr<SlamLoop> loop;
   std::shared_ptr<Context> ctx;
   lsdloop_stats st{};
+  double wall = 0;                       // wall time inside lsdloop_run since the last reset
+  double gpu0[3] = {0, 0, 0};            // DepthMap GPU times at the last reset
 };
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -29,6 +31,7 @@ extern "C" int lsdloop_create(int device, int w, int h, const float K4[4], const
     std::unique_ptr<lsdloop> l(new lsdloop());
     l->ctx = Context::get(w, h, K, device);
     l->loop.reset(new SlamLoop(w, h, K, first_image, images_on_device != 0, gt_depth0_host, kf_every));
+    l->ctx->setAsync(true);   // mapping kernels are enqueued behind the tracker's; the host never waits for them
     *out = l.release();
     return LSDHIP_OK;
   } catch (const Error& e) {
@@ -45,16 +48,12 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
   if (!l || !images || n < 0) return LSDHIP_E_ARG;
   try {
     int done = 0;
+    const double t0 = now_s();
     for (int i = 0; i < n; i++) {
-      // SlamLoop::step, split so that tracking and mapping are timed separately (the two metrics of SURVEY.md §8(d))
-      const double t0 = now_s();
       SlamLoop& L = *l->loop;
       const long upd0 = L.numUpdates;
       const long ev0 = L.evaluations;
-      SE3 est = L.step(images[i], [&](double tTrackEnd) { l->st.seconds_track += tTrackEnd - t0; });
-      const double t2 = now_s();
-      if (L.newKeyframe) l->st.seconds_keyframe += t2 - L.lastTrackEnd;
-      else l->st.seconds_map += t2 - L.lastTrackEnd;
+      SE3 est = L.step(images[i]);
       l->st.frames++;
       l->st.updates += L.numUpdates - upd0;
       l->st.evaluations += L.evaluations - ev0;
@@ -63,6 +62,8 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       done++;
       if (stop_at_keyframe && L.newKeyframe) break;
     }
+    l->ctx->synchronize();   // one synchronisation per batch: the enqueued mapping work belongs to this batch's time
+    l->wall += now_s() - t0;
     return done;
   } catch (const Error& e) {
     g_err = e.what();
@@ -72,8 +73,31 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
     return LSDHIP_E_STATE;
   }
 }
-extern "C" int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out) { if (!l || !out) return LSDHIP_E_ARG; *out = l->st; return LSDHIP_OK; }
-extern "C" int lsdloop_reset_stats(lsdloop* l) { if (!l) return LSDHIP_E_ARG; l->st = lsdloop_stats{}; return LSDHIP_OK; }
+// Mapping runs asynchronously behind tracking on one stream, so the split is made from GPU event times: map / keyframe
+// = HIP-event time of the DepthMap calls; track = wall time of the batches minus those.
+extern "C" int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out) {
+  if (!l || !out) return LSDHIP_E_ARG;
+  try {
+    double ms[3];
+    long long calls[3];
+    l->loop->map.gpuTimes(ms, calls);
+    l->st.seconds_map = (ms[0] - l->gpu0[0]) * 1e-3;
+    l->st.seconds_keyframe = ((ms[1] - l->gpu0[1]) + (ms[2] - l->gpu0[2])) * 1e-3;
+    l->st.seconds_track = l->wall - l->st.seconds_map - l->st.seconds_keyframe;
+    *out = l->st;
+    return LSDHIP_OK;
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+extern "C" int lsdloop_reset_stats(lsdloop* l) {
+  if (!l) return LSDHIP_E_ARG;
+  try {
+    long long calls[3];
+    l->loop->map.gpuTimes(l->gpu0, calls);
+    l->st = lsdloop_stats{};
+    l->wall = 0;
+    return LSDHIP_OK;
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+}
 extern "C" int lsdloop_copy_keyframe_planes(lsdloop* l, float* idepth_dev, float* var_dev) {
   if (!l) return LSDHIP_E_ARG;
   try { l->loop->map.copyPlanesToDevice(idepth_dev, var_dev); return LSDHIP_OK; }
