@@ -409,6 +409,7 @@ extern "C" int lsdhip_prof_reset(lsdhip_ctx* c) {
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_prof_read(lsdhip_ctx* c, double* ms, long long* launches, double* bytes) {
+  if (c) { int rc = lsd_prof_collect(c); if (rc) return rc; }
   if (!c) return LSDHIP_E_ARG;
   if (ms) *ms = c->prof_ms;
   if (launches) *launches = c->prof_launches;

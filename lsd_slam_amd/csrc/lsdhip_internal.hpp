@@ -130,6 +130,7 @@ struct lsdhip_ctx {
   // profiling of the residual kernel (bench.py roofline leg)
   bool prof_on = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  bool prof_pending = false;             // ev_a / ev_b of the last launch batch not yet read
   double prof_ms = 0, prof_bytes = 0;
   long long prof_launches = 0;
   std::vector<hipEvent_t> prof_events;   // per-launch event pairs for the device-resident LM loop
@@ -184,6 +185,7 @@ struct lsdhip_tracker {
   float affineEstimation_a = 1, affineEstimation_b = 0, affineEstimation_a_lastIt = 1, affineEstimation_b_lastIt = 0;
   bool diverged = false, trackingWasGood = false;
   int numEvaluations = 0, numWarpUpdates = 0;
+  bool spinWait = true;           // poll the pinned summary instead of hipStreamSynchronize (LSDHIP_SPIN=0 disables)
   bool hostLM = false;            // debugging: run the LM control loop on the host, one evaluation per round trip
   // device scratch
   float* d_partials = nullptr;    // TrackScratch arena (sums | topkey | topval), see tracker.hip
@@ -260,5 +262,6 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f);
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);
+int lsd_prof_collect(lsdhip_ctx* c);
 int lsd_frame_resolve(lsdhip_frame* f);        // reads the frame's deferred results (synchronises the stream if any)
 int lsd_ctx_take_slot(lsdhip_ctx* c);          // next slot of the ring (resolving whoever still waits on it)

@@ -26,6 +26,8 @@
 // Data layout: keyframe planes idepth/idepthVar/image (3 x 4 B per pixel, row-major, coalesced per wave), tracked-frame
 // texels float4 (gx, gy, I, 0) so that one bilinear tap is one 16-byte load.  Algorithmic bytes per evaluation at level l
 // (SURVEY.md §8(d)): 20 N_l + [l==1] 5 N_l + 12 min(w_l h_l, 4 N_l).
+#include <atomic>
+#include <chrono>
 #include "lsdhip_internal.hpp"
 
 
@@ -993,6 +995,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   memset(t->h_summary, 0, sizeof(TrackSummary));
   const char* env = getenv("LSDHIP_HOST_LM");
   t->hostLM = env && env[0] == '1';
+  if (const char* e = getenv("LSDHIP_SPIN")) t->spinWait = e[0] != '0';
   *out = t;
   return LSDHIP_OK;
 }
@@ -1099,6 +1102,7 @@ static int launch_steps(lsdhip_tracker* t, const TrackJob& job, int steps, int* 
   return LSDHIP_OK;
 }
 
+static int prof_collect(lsdhip_ctx* c);
 struct EvalOut {       // what one evaluation leaves behind, in the reference's terms
   int warped_size;
   float retval;        // calcResidualAndBuffers return value
@@ -1116,6 +1120,7 @@ static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T,
   job.T0 = T;
   job.aff_a0 = t->affineEstimation_a; job.aff_b0 = t->affineEstimation_b;
   t->h_summary->done = 0;
+  if (int rcp = prof_collect(c)) return rcp;
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
   launch_step(t, job, job.lv[level].nblocks, 0, 1);   // residual evaluation
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_b, c->stream));
@@ -1209,6 +1214,18 @@ static int lm_level_host(lsdhip_tracker* t, TrackJob& job, int lvl, lsdm::SE3fH&
   return LSDHIP_OK;
 }
 
+// elapsed time of the last profiled launch batch (events are read one call late so that nothing waits for them)
+static int prof_collect(lsdhip_ctx* c) {
+  if (!c->prof_pending) return LSDHIP_OK;
+  HIPCHK(hipEventSynchronize(c->ev_b));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+  c->prof_ms += ms;
+  c->prof_pending = false;
+  return LSDHIP_OK;
+}
+int lsd_prof_collect(lsdhip_ctx* c) { return prof_collect(c); }
+
 // device-resident LM over levels topLevel..job.lastLevel; one host synchronisation per budget of launches.  The budget
 // is the previous job's launch count (evaluations + the finalising step) plus a margin, so that few steps run empty.
 // With profiling on, the whole budget is bracketed by one HIP event pair on the context's stream and charged to the
@@ -1230,20 +1247,36 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   }
   int guard = 0;
   int parity = 0, first = 1;
-  int launched = 0;
+  if (int rc = prof_collect(c)) return rc;
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     int rc = launch_steps(t, job, budget, &parity, &first);
     if (rc) return rc;
-    if (c->prof_on) HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    launched += budget;
-    if (c->prof_on) {
-      float ms = 0;
-      HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
-      c->prof_ms += ms;
+    if (c->prof_on) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
+    // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
+    // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
+    // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.
+    if (t->spinWait) {
+      volatile const int* done = &S->done;
+      const auto tStart = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (!*done) {
+        if ((++spins & 1023u) == 0) {
+          hipError_t q = hipStreamQuery(c->stream);
+          if (q == hipSuccess) break;                       // budget consumed (done or not)
+          if (q != hipErrorNotReady) { lsd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return LSDHIP_E_HIP; }
+          if (std::chrono::steady_clock::now() - tStart > std::chrono::seconds(5)) { HIPCHK(hipStreamSynchronize(c->stream)); break; }
+        }
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+      HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (S->done) break;
+    HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
+    if (S->done) break;
+    if (int rc2 = prof_collect(c)) return rc2;
     budget = 6;
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
   }
