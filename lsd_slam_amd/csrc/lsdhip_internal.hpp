@@ -251,6 +251,8 @@ struct lsdhip_depthmap {
   int ev_kind[8] = {};
   bool ev_pending[8] = {};
   int ev_next = 0;
+  unsigned long long* d_obs_trace = nullptr;   // LSD_PHASE_TRACE developer build only
+  size_t obs_trace_words = 0;
   double gpu_ms[3] = {0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame
   long long gpu_calls[3] = {0, 0, 0};
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
