@@ -90,6 +90,8 @@ int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float* out_host)
 int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_host, float cov_scale);
 /* raw level-0 idepth / idepthVar planes (what Frame::setDepth leaves behind, Frame.cpp:199-243) */
 int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* idepth_host, const float* idepthVar_host);
+/* test / synthetic-benchmark hook: overwrite the level-0 maxGradients plane (Frame::maxGradients(0)) */
+int lsdhip_frame_set_maxgrad(lsdhip_frame* f, const float* maxgrad_host);
 /* Frame::refPixelWasGood() (Frame.h:421-437): level-1 mask, bytes 0xFF until the tracker writes 0/1.
  * returns 1 and fills out_host if the mask exists, 0 if it was never created / was cleared. */
 int lsdhip_frame_get_wasgood(lsdhip_frame* f, uint8_t* out_host);
@@ -175,11 +177,16 @@ int lsdhip_depth_finalize(lsdhip_depthmap* dm);
 int lsdhip_depth_download(lsdhip_depthmap* dm, lsdhip_hypothesis* out_host);
 int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const lsdhip_hypothesis* in_host, int reactivated);
 /* single stages for kernel-level parity: 0 observeDepth (refs/n as in update), 1 regularizeDepthMapFillHoles,
- * 2 regularizeDepthMap(false,24), 3 regularizeDepthMap(true,24), 4 propagateDepth(refs[0] = new keyframe) */
+ * 2 regularizeDepthMap(false,24), 3 regularizeDepthMap(true,24), 4 propagateDepth(refs[0] = new keyframe),
+ * 5 regularizeDepthMapFillHoles + regularizeDepthMap(false,24) fused in one launch (what updateKeyframe runs) */
 int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame** refs, int n);
 /* smoothed idepth / variance planes of the active keyframe (what setDepth produced), device to device —
  * the payload the multi-GPU gather collects per keyframe. */
 int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* idepthVar_dev);
+/* rows [row0, row0+nrows) of the eight hypothesis planes <-> one packed device buffer (29 bytes per pixel, plane after
+ * plane in the order of lsdhip_hypothesis): halo exchange of the row-band decomposition.
+ * to_map != 0 copies the buffer into the map. */
+int lsdhip_depth_copy_rows_dev(lsdhip_depthmap* dm, int row0, int nrows, void* packed_dev, int to_map);
 /* timing fields DepthMap keeps public (DepthMap.h:86-93): msUpdate, msCreate, msFinalize, msObserve, msRegularize,
  * msPropagate, msFillHoles, msSetDepth (exponential moving averages, ms) */
 int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);

@@ -58,6 +58,7 @@ def _signatures():
         "lsdhip_frame_download": (i, [vp, i, i, vp]),
         "lsdhip_frame_set_depth_gt": (i, [vp, vp, f]),
         "lsdhip_frame_set_depth_planes": (i, [vp, vp, vp]),
+        "lsdhip_frame_set_maxgrad": (i, [vp, vp]),
         "lsdhip_frame_get_wasgood": (i, [vp, vp]),
         "lsdhip_frame_set_wasgood": (i, [vp, vp]),
         "lsdhip_frame_clear_wasgood": (i, [vp]),
@@ -90,6 +91,7 @@ def _signatures():
         "lsdhip_depth_upload": (i, [vp, vp, vp, i]),
         "lsdhip_depth_stage": (i, [vp, i, pvp, i]),
         "lsdhip_depth_copy_planes_dev": (i, [vp, vp, vp]),
+        "lsdhip_depth_copy_rows_dev": (i, [vp, i, i, vp, i]),
         "lsdhip_depth_timings": (i, [vp, vp]),
         "lsdhip_depth_gpu_times": (i, [vp, vp, vp]),
         "lsdhip_prof_enable": (i, [vp, i]),

@@ -1719,6 +1719,7 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
       rc = propagate(dm, refs[0], true);
       if (rc == LSDHIP_OK) { dm->activeKeyFrame = refs[0]; dm->activeKeyFrameIsReactivated = false; }
       break;
+    case 5: rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, false); break;
     default: return LSDHIP_E_ARG;
   }
   if (rc) return rc;
@@ -1733,6 +1734,30 @@ extern "C" int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_d
   size_t n = (size_t)c->w * c->h;
   HIPCHK(hipMemcpyAsync(idepth_dev, dm->activeKeyFrame->d_idepth[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(var_dev, dm->activeKeyFrame->d_idepthVar[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+
+// Rows [row0, row0 + nrows) of the eight hypothesis planes <-> one packed device buffer (plane after plane: isValid u8,
+// blacklisted i32, nextStereoFrameMinID f32, validity_counter i32, idepth, idepth_var, idepth_smoothed,
+// idepth_var_smoothed = 29 bytes per pixel): the halo payload of the row-band decomposition.
+extern "C" int lsdhip_depth_copy_rows_dev(lsdhip_depthmap* dm, int row0, int nrows, void* packed_dev, int to_map) {
+  if (!dm || !packed_dev || row0 < 0 || nrows <= 0) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = dm->ctx;
+  if (row0 + nrows > c->h) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t px = (size_t)nrows * c->w, off = (size_t)row0 * c->w;
+  char* p = (char*)packed_dev;
+  struct { void* plane; size_t elt; } planes[8] = {
+      {dm->cur.valid, 1}, {dm->cur.blacklisted, 4}, {dm->cur.nextID, 4}, {dm->cur.validity, 4},
+      {dm->cur.idepth, 4}, {dm->cur.var, 4}, {dm->cur.idepth_s, 4}, {dm->cur.var_s, 4}};
+  for (int k = 0; k < 8; k++) {
+    char* mp = (char*)planes[k].plane + off * planes[k].elt;
+    const size_t bytes = px * planes[k].elt;
+    if (to_map) HIPCHK(hipMemcpyAsync(mp, p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(hipMemcpyAsync(p, mp, bytes, hipMemcpyDeviceToDevice, c->stream));
+    p += bytes;
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
 }

@@ -587,6 +587,16 @@ extern "C" int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* id, c
   HIPCHK(hipStreamSynchronize(c->stream));
   return rc;
 }
+// Test / synthetic-benchmark hook: overwrite the level-0 maxGradients plane (scene S3 of SURVEY.md §8(d) generates
+// hypothesis maps and gradient masks directly, without images)
+extern "C" int lsdhip_frame_set_maxgrad(lsdhip_frame* f, const float* maxgrad_host) {
+  if (!f || !maxgrad_host) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = f->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(f->d_maxgrad, maxgrad_host, (size_t)c->w * c->h * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_frame_get_wasgood(lsdhip_frame* f, uint8_t* out) {
   if (!f || !out) return LSDHIP_E_ARG;
   if (!f->wasGoodValid) return 0;

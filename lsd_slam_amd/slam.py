@@ -132,6 +132,10 @@ class Frame:
         b = np.ascontiguousarray(idepthVar, dtype=np.float32)
         check(self.L.lsdhip_frame_set_depth_planes(self.h_, a.ctypes.data, b.ctypes.data), False)
 
+    def setMaxGradients(self, plane):
+        p = np.ascontiguousarray(plane, dtype=np.float32)
+        check(self.L.lsdhip_frame_set_maxgrad(self.h_, p.ctypes.data), False)
+
     def refPixelWasGoodNoCreate(self):
         out = np.zeros((self.height(1), self.width(1)), np.uint8)
         rc = check(self.L.lsdhip_frame_get_wasgood(self.h_, out.ctypes.data))
@@ -265,7 +269,7 @@ class SE3Tracker:
 
 
 class DepthMap:
-    STAGES = {"observe": 0, "fillholes": 1, "regularize": 2, "regularize_occ": 3, "propagate": 4}
+    STAGES = {"observe": 0, "fillholes": 1, "regularize": 2, "regularize_occ": 3, "propagate": 4, "fill_regularize": 5}
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -334,6 +338,10 @@ class DepthMap:
         frames = list(frames)
         self._keep.extend(frames)
         check(self.L.lsdhip_depth_stage(self.h_, self.STAGES[name], self._arr(frames) if frames else None, len(frames)), False)
+
+    def copyRows(self, row0, nrows, packed_dev_ptr, to_map):
+        """rows of the 8 hypothesis planes <-> packed device buffer (29 B/px), see lsdhip_depth_copy_rows_dev"""
+        check(self.L.lsdhip_depth_copy_rows_dev(self.h_, row0, nrows, C.c_void_p(packed_dev_ptr), int(to_map)), False)
 
     def copyPlanesToDevice(self, idepth_ptr, var_ptr):
         check(self.L.lsdhip_depth_copy_planes_dev(self.h_, C.c_void_p(idepth_ptr), C.c_void_p(var_ptr)), False)

@@ -76,6 +76,7 @@ class Frame {
   const float* image(int l = 0);
   const float* gradients(int l = 0);     // Vector4f plane (gx, gy, I, 0), 4 floats per pixel
   const float* maxGradients(int l = 0);
+  void overrideMaxGradients(const float* plane);   // test hook, level 0
   const float* idepth(int l = 0);
   const float* idepthVar(int l = 0);
   bool hasIDepthBeenSet() const { return hasIDepth_; }

@@ -78,6 +78,8 @@ void orc_frame_set_wasgood(void* f, const unsigned char* in) {
   memcpy(fr->refPixelWasGood(), in, (size_t)fr->width(1) * fr->height(1));
 }
 void orc_frame_clear_wasgood(void* f) { F(f)->clear_refPixelWasGood(); }
+// test hook (scene S3 generates gradient masks directly): overwrite the level-0 maxGradients plane
+void orc_frame_set_maxgrad(void* f, const float* in) { F(f)->overrideMaxGradients(in); }
 void orc_frame_set_pose(void* f, const double sim3[8], void* parent, float initialTrackedResidual) {
   Frame* fr = F(f);
   fr->thisToParent_raw.q.w = sim3[0]; fr->thisToParent_raw.q.x = sim3[1]; fr->thisToParent_raw.q.y = sim3[2];

@@ -61,6 +61,10 @@ Frame::Frame(int id, int width, int height, const float Kin[4], const unsigned c
 
 const float* Frame::image(int l) { if (!imageValid_[l]) buildImage(l); return image_[l].data(); }
 const float* Frame::gradients(int l) { if (!gradValid_[l]) buildGradients(l); return grad_[l].data(); }
+void Frame::overrideMaxGradients(const float* plane) {
+  maxGradients(0);   // allocate / build, then replace
+  std::copy(plane, plane + (size_t)width(0) * height(0), maxGrad_[0].begin());
+}
 const float* Frame::maxGradients(int l) { if (!maxGradValid_[l]) buildMaxGradients(l); return maxGrad_[l].data(); }
 const float* Frame::idepth(int l) { if (!idepthValid_[l]) buildIDepthAndIDepthVar(l); return idepth_[l].data(); }
 const float* Frame::idepthVar(int l) { if (!idepthValid_[l]) buildIDepthAndIDepthVar(l); return idepthVar_[l].data(); }

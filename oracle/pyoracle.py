@@ -68,6 +68,7 @@ def lib(fast=False):
         "orc_frame_get_wasgood": (i, [vp, u8p]),
         "orc_frame_set_wasgood": (None, [vp, u8p]),
         "orc_frame_clear_wasgood": (None, [vp]),
+        "orc_frame_set_maxgrad": (None, [vp, fp]),
         "orc_frame_set_pose": (None, [vp, dp, vp, f]),
         "orc_frame_get_pose": (None, [vp, dp]),
         "orc_frame_stats": (None, [vp, fp]),
@@ -178,6 +179,9 @@ class Frame:
 
     def clear_wasgood(self):
         self.L.orc_frame_clear_wasgood(self.h_)
+
+    def set_maxgrad(self, plane):
+        self.L.orc_frame_set_maxgrad(self.h_, np.ascontiguousarray(plane, dtype=np.float32))
 
     def set_pose(self, sim3, parent, initialTrackedResidual=0.0):
         self.L.orc_frame_set_pose(self.h_, np.ascontiguousarray(sim3, dtype=np.float64), parent.h_ if parent else None,

@@ -1,0 +1,103 @@
+"""Row-band decomposition of the regulariser (lsd_slam_amd/bands.py) checked on CPU: the plan
+arithmetic, and — with the oracle as the per-window engine — that banded passes with halo exchange reproduce the
+full-frame result exactly, in one process and across two gloo ranks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import ROOT
+from lsd_slam_amd.bands import HALO_BOTTOM, HALO_TOP, BandPlan, BandRegularizer, LocalComm, synth_s3
+
+
+@pytest.mark.parametrize("H,world", [(2160 + 16 - 2160 % 16, 8), (480, 4), (192, 3), (64, 2), (48, 1)])
+def test_plan_covers_rows_and_windows_are_sufficient(H, world):
+    p = BandPlan(H, world)
+    rows = []
+    for (y0, y1), (a, b) in zip(p.owned, p.window):
+        rows += list(range(y0, y1))
+        assert (b - a) == p.window_rows and p.window_rows % 16 == 0 and 0 <= a and b <= H
+        assert a == 0 or a <= y0 - HALO_TOP
+        assert b == H or b >= y1 + HALO_BOTTOM
+    assert rows == list(range(H))
+    for r in range(world):
+        a, b = p.window[r]
+        got = sorted(list(range(*p.owned[r])) + [y for (_, lo, n) in p.recv_list(r) for y in range(lo, lo + n)])
+        assert got == list(range(a, b))                       # every window row is owned or received exactly once
+        for (d, lo, n) in p.send_list(r):
+            assert (r, lo, n) in p.recv_list(d) and p.owned[r][0] <= lo and lo + n <= p.owned[r][1]
+    assert sum(len(p.send_list(r)) for r in range(world)) == sum(len(p.recv_list(r)) for r in range(world))
+
+
+def _full_frame(oracle, hyp, maxgrad, passes):
+    from band_engines import OracleBandEngine
+    h, w = hyp.shape
+    e = OracleBandEngine(w, h)
+    e.load(hyp, maxgrad)
+    for _ in range(passes):
+        e.run_pass()
+    return e.get()
+
+
+def _assert_rows_equal(got, ref, what):
+    for k in ("isValid", "blacklisted", "validity_counter"):
+        assert np.array_equal(got[k], ref[k]), (what, k)
+    v = ref["isValid"] > 0
+    for k in ("idepth", "idepth_var", "idepth_smoothed", "idepth_var_smoothed"):
+        assert np.array_equal(got[k][v].view(np.uint32), ref[k][v].view(np.uint32)), (what, k)
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_banded_passes_equal_full_frame_oracle(oracle, world):
+    from band_engines import OracleBandEngine
+    w, H, passes = 160, 192, 3
+    hyp, maxgrad = synth_s3(w, H)
+    ref = _full_frame(oracle, hyp, maxgrad, passes)
+    assert (ref["isValid"] != hyp["isValid"]).sum() > 100      # the passes do create and delete hypotheses
+    plan = BandPlan(H, world)
+    engines = [OracleBandEngine(w, plan.window_rows) for _ in range(world)]
+    br = BandRegularizer(plan, engines, LocalComm(), list(range(world)))
+    br.load(hyp, maxgrad)
+    br.run(passes)
+    for r, rows in br.owned_rows().items():
+        y0, y1 = plan.owned[r]
+        _assert_rows_equal(rows, ref[y0:y1], "band %d of %d" % (r, world))
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from lsd_slam_amd.bands import BandPlan, BandRegularizer, DistComm, synth_s3
+from band_engines import OracleBandEngine
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+w, H, passes = 160, 96, 3
+hyp, maxgrad = synth_s3(w, H)
+plan = BandPlan(H, 2)
+br = BandRegularizer(plan, [OracleBandEngine(w, plan.window_rows)], DistComm(), [dist.get_rank()])
+br.load(hyp, maxgrad)
+br.run(passes)
+rows = br.owned_rows()[dist.get_rank()]
+np.save(os.path.join({out!r}, "band%d.npy" % dist.get_rank()), rows)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_banded_passes_two_gloo_ranks(oracle, tmp_path):
+    port = 29500 + os.getpid() % 2000
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, port=port, out=str(tmp_path)))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    w, H, passes = 160, 96, 3
+    hyp, maxgrad = synth_s3(w, H)
+    ref = _full_frame(oracle, hyp, maxgrad, passes)
+    plan = BandPlan(H, 2)
+    for r in range(2):
+        y0, y1 = plan.owned[r]
+        _assert_rows_equal(np.load(tmp_path / ("band%d.npy" % r)), ref[y0:y1], "rank %d" % r)
