@@ -106,7 +106,6 @@ struct ObserveArgs {
 // DepthMap::doLineStereo (DepthMap.cpp:1442-1972).  Status codes as in the reference: >= 0 matching error,
 // -1 out of bounds, -2 ambiguous / negative, -3 error too large, -4 arithmetic.  The epipolar walk is capped at 1000
 // steps (the reference loop is unbounded; no finite input reaches the cap).
-template <bool PIPE>
 LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, const float u, const float v, const float epxn,
                                 const float epyn, const float min_idepth, const float prior_idepth, float max_idepth,
                                 float& result_idepth, float& result_var, float& result_eplLength) {
@@ -219,73 +218,6 @@ LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, 
   float eeLast = -1;
   float e1A = NAN, e1B = NAN, e2A = NAN, e2B = NAN, e3A = NAN, e3B = NAN, e4A = NAN, e4B = NAN, e5A = NAN, e5B = NAN;
   int loopCBest = -1, loopCSecond = -1;
-  if (PIPE) {
-  // The reference's loop `while (cpx / cpy have not passed pClose || first)` samples one new point (cp + 2 inc) per step.
-  // Here the sample positions of the next four steps are formed first (same additions, same order) and their loads are
-  // issued together, so a lane waits for memory once per four steps instead of once per step; positions past the end
-  // of the walk are at most 6 px beyond pClose, inside the SAMPLE_POINT_TO_BORDER margin, and their values are unused.
-  bool walking = true;
-  while (walking) {
-    float bx[4], by[4], p2[4];
-    bx[0] = cpx; by[0] = cpy;
-#pragma unroll
-    for (int j = 1; j < 4; j++) { bx[j] = bx[j - 1] + incx; by[j] = by[j - 1] + incy; }
-#pragma unroll
-    for (int j = 0; j < 4; j++) p2[j] = interp1(refImg, bx[j] + 2 * incx, by[j] + 2 * incy, width);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (!walking) break;
-      cpx = bx[j]; cpy = by[j];
-      if (!((((incx < 0) == (cpx > pClose0) && (incy < 0) == (cpy > pClose1)) || loopCounter == 0) && loopCounter < 1000)) {
-        walking = false;
-        break;
-      }
-      val_cp_p2 = p2[j];
-      float ee = 0;
-      if (loopCounter % 2 == 0) {
-        e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
-        e2A = val_cp_p1 - realVal_p1; ee += e2A * e2A;
-        e3A = val_cp - realVal;       ee += e3A * e3A;
-        e4A = val_cp_m1 - realVal_m1; ee += e4A * e4A;
-        e5A = val_cp_m2 - realVal_m2; ee += e5A * e5A;
-      } else {
-        e1B = val_cp_p2 - realVal_p2; ee += e1B * e1B;
-        e2B = val_cp_p1 - realVal_p1; ee += e2B * e2B;
-        e3B = val_cp - realVal;       ee += e3B * e3B;
-        e4B = val_cp_m1 - realVal_m1; ee += e4B * e4B;
-        e5B = val_cp_m2 - realVal_m2; ee += e5B * e5B;
-      }
-      if (ee < best_match_err) {
-        second_best_match_err = best_match_err;
-        loopCSecond = loopCBest;
-        best_match_err = ee;
-        loopCBest = loopCounter;
-        best_match_errPre = eeLast;
-        best_match_DiffErrPre = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
-        best_match_errPost = -1;
-        best_match_DiffErrPost = -1;
-        best_match_x = cpx;
-        best_match_y = cpy;
-        bestWasLastLoop = true;
-      } else {
-        if (bestWasLastLoop) {
-          best_match_errPost = ee;
-          best_match_DiffErrPost = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
-          bestWasLastLoop = false;
-        }
-        if (ee < second_best_match_err) {
-          second_best_match_err = ee;
-          loopCSecond = loopCounter;
-        }
-      }
-      eeLast = ee;
-      val_cp_m2 = val_cp_m1; val_cp_m1 = val_cp; val_cp = val_cp_p1; val_cp_p1 = val_cp_p2;
-      loopCounter++;
-    }
-    if (walking) { cpx = bx[3] + incx; cpy = by[3] + incy; }
-  }
-
-  } else {
   while ((((incx < 0) == (cpx > pClose0) && (incy < 0) == (cpy > pClose1)) || loopCounter == 0) && loopCounter < 1000) {
     val_cp_p2 = interp1(refImg, cpx + 2 * incx, cpy + 2 * incy, width);
     float ee = 0;
@@ -332,7 +264,6 @@ LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, 
     loopCounter++;
   }
 
-  }
   OBS_MARK(5);
   OBS_VAL(8, loopCounter);
   if (best_match_err > 4.0f * (float)MAX_ERROR_STEREO) return -3;
@@ -449,7 +380,7 @@ LSD_HD bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x,
 }
 
 // observeDepthRow body for one pixel (DepthMap.cpp:117-143), hypothesis updated in place.
-template <bool ONE, bool PIPE>
+template <bool ONE>
 LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int y) {
   if (x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3) return;
   const int idx = x + y * a.w;
@@ -466,7 +397,7 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
     if (!make_and_check_epl(a, rf, x, y, &epx, &epy)) return;
     float new_u = x, new_v = y;
     float result_idepth = 0, result_var = 0, result_eplLength = 0;
-    float error = do_line_stereo<PIPE>(a, rf, new_u, new_v, epx, epy, 0.0f, 1.0f, 1.0f / MIN_DEPTH, result_idepth, result_var, result_eplLength);
+    float error = do_line_stereo(a, rf, new_u, new_v, epx, epy, 0.0f, 1.0f, 1.0f / MIN_DEPTH, result_idepth, result_var, result_eplLength);
     if (error == -3 || error == -2) a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1;
     if (error < 0 || result_var > MAX_VAR) return;
     result_idepth = unzero(result_idepth);
@@ -504,7 +435,7 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
   if (max_idepth > 1 / MIN_DEPTH) max_idepth = 1 / MIN_DEPTH;
 
   float result_idepth = 0, result_var = 0, result_eplLength = 0;
-  float error = do_line_stereo<PIPE>(a, rf, x, y, epx, epy, min_idepth, idepth_smoothed, max_idepth, result_idepth, result_var, result_eplLength);
+  float error = do_line_stereo(a, rf, x, y, epx, epy, min_idepth, idepth_smoothed, max_idepth, result_idepth, result_var, result_eplLength);
   float diff = result_idepth - idepth_smoothed;
 
   if (error == -1) return;
@@ -549,44 +480,15 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
 }
 
 // K4: observeDepthRow over the whole map, one pixel per lane.
-// The cheap part of observeDepthRow for one pixel (DepthMap.cpp:117-135): true if the pixel goes on to the epipolar
-// search.  Side effect as in the reference: a hypothesis on a pixel whose gradient dropped below minUseGrad is removed.
-LSD_HD bool observe_wants_stereo(const ObserveArgs& a, const int x, const int y) {
-  if (x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3) return false;
-  const int idx = x + y * a.w;
-  const bool hasHypothesis = a.m.valid[idx] != 0;
-  const float maxGrad = a.kfMaxGrad[idx];
-  if (hasHypothesis && maxGrad < a.minUseGrad) { a.m.valid[idx] = 0; return false; }
-  if (maxGrad < a.minUseGrad || a.m.blacklisted[idx] < MIN_BLACKLIST) return false;
-  return true;
-}
-
-// K4: observeDepthRow over the whole map.  Only ~20 % of the pixels reach the epipolar search, so each 32x8 workgroup
-// first compacts its candidates (wave ballots + an LDS list) and then runs the search with dense lanes: a tile's
-// candidates usually fit one wave, and the other three retire at once instead of idling through the 30-step walk.
-template <bool ONE, bool COMPACT, bool PIPE>
+// K4: observeDepthRow over the whole map, one pixel per lane.  (Compacting the ~20 % of pixels that reach the epipolar
+// search into dense waves, and batching the loads of four walk steps, were both measured and gave nothing: the kernel
+// is bound by chains of dependent first-touch loads, not by issue slots — profiles/r01_notes.md.)
+template <bool ONE>
 __global__ __launch_bounds__(256) void k_observe(ObserveArgs a) {
-  __shared__ int s_list[256];
-  __shared__ int s_wcount[4];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int x = blockIdx.x * 32 + (tid & 31);
-  const int y = blockIdx.y * 8 + (tid >> 5);
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
   OBS_MARK(0);
-  if (!COMPACT) { observe_pixel<ONE, PIPE>(a, x, y); return; }
-  const bool cand = observe_wants_stereo(a, x, y);
-  const unsigned long long m = __ballot(cand);
-  if (lane == 0) s_wcount[wave] = __popcll(m);
-  __syncthreads();
-  int base = 0, total = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) { const int ck = s_wcount[k]; if (k < wave) base += ck; total += ck; }
-  if (cand) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = tid;
-  __syncthreads();
-  OBS_MARK(1);
-  if (tid < total) {
-    const int p = s_list[tid];
-    observe_pixel<ONE, PIPE>(a, blockIdx.x * 32 + (p & 31), blockIdx.y * 8 + (p >> 5));
-  }
+  observe_pixel<ONE>(a, x, y);
   OBS_MARK(7);
 }
 
@@ -1382,13 +1284,9 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   }
 #endif
   {
-    static const int variant = getenv("LSDHIP_OBS_VARIANT") ? atoi(getenv("LSDHIP_OBS_VARIANT")) : 0;   // experiment switch
     const dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
-    if (n != 1) hipLaunchKernelGGL((k_observe<false, false, false>), grid, dim3(256), 0, c->stream, a);
-    else if (variant == 1) hipLaunchKernelGGL((k_observe<true, true, false>), grid, dim3(256), 0, c->stream, a);
-    else if (variant == 2) hipLaunchKernelGGL((k_observe<true, false, true>), grid, dim3(256), 0, c->stream, a);
-    else if (variant == 3) hipLaunchKernelGGL((k_observe<true, true, true>), grid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_observe<true, false, false>), grid, dim3(256), 0, c->stream, a);
+    if (n == 1) hipLaunchKernelGGL(k_observe<true>, grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_observe<false>, grid, dim3(256), 0, c->stream, a);
   }
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
