@@ -145,6 +145,12 @@ int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int maxItsPerLvl[LSDHIP_
  * initialTrackedResidual, keyframe numFramesTrackedOnThis++.  Returns LSDHIP_DIVERGED when diverged. */
 int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame,
                          const double frameToReference_initialEstimate[7], lsdhip_track_result* out);
+/* trackFrame for n independent (keyframe, frame) pairs in the same kernel launches (one job per blockIdx.y): results are
+ * identical to n lsdhip_tracker_track calls; n evaluations share every launch.  This is how several sequences share
+ * one GPU (BASELINE configs[3] with fewer GPUs than sequences) and how batches of keyframe candidates are checked
+ * (SURVEY.md §8(f) N2).  inits: n x 7 doubles, results: n records.  Returns LSDHIP_DIVERGED if any job diverged. */
+int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
+                               const double* frameToReference_initialEstimates, lsdhip_track_result* results);
 /* K1+K2+K3 once, at a fixed referenceToFrame (float (qw,qx,qy,qz,tx,ty,tz)) — kernel-level parity hook. */
 int lsdhip_tracker_evaluate(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame,
                             const float referenceToFrame[7], int level, float affine_a, float affine_b,

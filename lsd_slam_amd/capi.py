@@ -73,6 +73,7 @@ def _signatures():
         "lsdhip_tracker_destroy": (None, [vp]),
         "lsdhip_tracker_set_max_its": (i, [vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),
+        "lsdhip_tracker_track_batch": (i, [vp, i, pvp, pvp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(ResidualRecord)]),
         "lsdhip_tracker_track_permaref": (i, [vp, vp, vp, i, vp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_check_overlap": (i, [vp, vp, i, vp, C.POINTER(C.c_float)]),

@@ -193,10 +193,18 @@ struct lsdhip_tracker {
   TrackState* d_state = nullptr;  // [2], double-buffered by launch parity
   int block = 256;                // workgroup size of k_track_step (LSDHIP_TRACK_BLOCK)
   int grid_cap = 304;             // most workgroups one evaluation uses (LSDHIP_TRACK_CAP); larger levels grid-stride
+  int cap_override = 0;           // batch tracking: per-job workgroup cap while the jobs of a batch are being described
   int recent[4] = {0, 0, 0, 0};   // evaluations of the last jobs: size the launch budget of the next one
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary
   unsigned long long* d_trace = nullptr;  // LSD_PHASE_TRACE developer build only
+  // batch tracking (lsdhip_tracker_track_batch): per-job descriptions, states, scratch and summaries
+  int batch_capacity = 0;
+  TrackJob* d_bjobs = nullptr;
+  TrackJob* h_bjobs = nullptr;        // pinned staging
+  TrackState* d_bstate = nullptr;     // [capacity][2]
+  float* d_bscratch = nullptr;        // TrackScratch arena x capacity (sums | topkey | topval, each [job][...])
+  TrackSummary* h_bsummary = nullptr; // pinned, device-mapped
   float* d_pts = nullptr;         // permaref point upload
   int pts_capacity = 0;
 };

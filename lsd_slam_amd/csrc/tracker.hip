@@ -622,9 +622,20 @@ struct TrackScratch {
 //   (2) the residual evaluation (K0+K1+K2+K3) of the pose that decision produced, grid-stride over the level's pixels,
 //       41 sums reduced wave (DPP) -> workgroup (LDS) -> sums[.][tile].
 // The first launch of a job (first = 1) builds the initial state from the job instead of loading it.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob job, TrackState* __restrict__ st2, TrackScratch sc,
-                                                       TrackSummary* __restrict__ out, int parity, int first) {
+// BATCH: blockIdx.y selects one of several independent jobs (tracking a batch of frames / permanent references in the
+// same launches): the job descriptions then live in HBM (`jobs`), and state / scratch / summary are arrays over jobs.
+template <int BLOCK, bool BATCH>
+__global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
+                                                       TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
+  const TrackJob& job = BATCH ? jobs[blockIdx.y] : jobv;
+  if (BATCH) {
+    const size_t j = blockIdx.y, rows = (size_t)sc.max_rows;
+    st2 += 2 * j;
+    out += j;
+    sc.sums += j * 2 * RS_COLS * rows;
+    sc.topkey += j * 2 * rows;
+    sc.topval += j * 2 * rows * 96;
+  }
   constexpr int WAVES = BLOCK / 64;
   constexpr int SUMW = WAVES - 1;                    // waves that sum partials (the last one does the tail work)
   constexpr int NSLICE = (SUMW * 64) / RS_END;       // row slices per column
@@ -1019,6 +1030,7 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   }
   (void)hipFree(t->d_trace);
 #endif
+  if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   (void)hipFree(t->d_partials);
   (void)hipFree(t->d_state);
   (void)hipHostFree(t->h_summary);
@@ -1053,7 +1065,8 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   int work = npts >= 0 ? npts : L.w * L.h;
   L.nblocks = (work + t->block - 1) / t->block;
   if (L.nblocks >= 16) L.nblocks = (L.nblocks + 7) & ~7;   // multiples of 8: one contiguous band of tiles per XCD
-  if (L.nblocks > t->grid_cap) L.nblocks = t->grid_cap;     // larger levels grid-stride
+  const int cap = t->cap_override > 0 ? t->cap_override : t->grid_cap;
+  if (L.nblocks > cap) L.nblocks = cap;                     // larger levels grid-stride
   if (L.nblocks < 1) L.nblocks = 1;
   L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
   L.lambdaInitial = t->lambdaInitial[level]; L.stepSizeMin = t->stepSizeMin[level]; L.convergenceEps = t->convergenceEps[level];
@@ -1087,7 +1100,8 @@ static TrackScratch scratch_of(lsdhip_tracker* t) {
 static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int parity, int first) {
   lsdhip_ctx* c = t->ctx;
   TrackScratch sc = scratch_of(t);
-  hipLaunchKernelGGL(k_track_step<256>, dim3(grid), dim3(256), 0, c->stream, job, t->d_state, sc, t->d_summary, parity, first);
+  hipLaunchKernelGGL((k_track_step<256, false>), dim3(grid), dim3(256), 0, c->stream, job, (const TrackJob*)nullptr, t->d_state, sc,
+                     t->d_summary, parity, first);
 }
 // launch `steps` fused k_track_step kernels (alternating parity); grid = the largest level the job can still visit.
 static int launch_steps(lsdhip_tracker* t, const TrackJob& job, int steps, int* parity, int* first) {
@@ -1306,17 +1320,8 @@ static void fill_result(lsdhip_tracker* t, const lsdm::SE3dH& T, lsdhip_track_re
 }
 static lsdm::SE3dH identity_d() { lsdm::SE3dH I; I.q = {1, 0, 0, 0}; I.t[0] = I.t[1] = I.t[2] = 0; return I; }
 
-extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double init[7],
-                                    lsdhip_track_result* out) {
-  if (!t || !kf || !frame || !init || !out) return LSDHIP_E_ARG;
-  if (!kf->hasIDepth) { lsd_set_error("lsdhip_tracker_track: keyframe %d has no depth", kf->id); return LSDHIP_E_STATE; }
-  lsdhip_ctx* c = t->ctx;
-  HIPCHK(hipSetDevice(c->device));
-  t->diverged = false;
-  t->trackingWasGood = true;
-  t->affineEstimation_a = 1; t->affineEstimation_b = 0;
-  t->numEvaluations = 0; t->numWarpUpdates = 0;
-  TrackJob job;
+// trackFrame job description (SE3Tracker.cpp:280-322): levels SE3TRACKING_MAX_LEVEL-1 .. SE3TRACKING_MIN_LEVEL
+static int fill_trackframe_job(lsdhip_tracker* t, TrackJob& job, lsdhip_frame* kf, lsdhip_frame* frame) {
   fill_job_common(t, job);
   for (int lvl = LSD_TRACK_MIN_LEVEL; lvl < LSD_TRACK_MAX_LEVEL; lvl++) fill_level(t, job, lvl, kf, frame, nullptr, nullptr, -1);
   job.lv[LSD_TRACK_MIN_LEVEL].writeMask = 1;
@@ -1325,25 +1330,28 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   job.wasGood = frame->d_wasGood;
   job.lastLevel = LSD_TRACK_MIN_LEVEL;
   job.trackFrameSemantics = 1;
-  lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(init)));
-
-  if (t->hostLM) {
-    float last_residual = 0;
-    rc = LSDHIP_OK;
-    for (int lvl = LSD_TRACK_MAX_LEVEL - 1; lvl >= LSD_TRACK_MIN_LEVEL && rc == LSDHIP_OK; lvl--)
-      rc = lm_level_host(t, job, lvl, referenceToFrame, &last_residual);
-    t->lastResidual = last_residual;
-  } else {
-    rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
-  }
-  if (rc == LSDHIP_DIVERGED) {
+  return LSDHIP_OK;
+}
+// epilogue of trackFrame (SE3Tracker.cpp:451-485) from the job's summary: flags, frame / keyframe side effects, result
+static int finish_trackframe(lsdhip_tracker* t, const TrackSummary* S, lsdhip_frame* kf, lsdhip_frame* frame, lsdhip_track_result* out) {
+  lsdhip_ctx* c = t->ctx;
+  t->numEvaluations = S->numEvaluations;
+  t->numWarpUpdates = S->numWarpUpdates;
+  t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;
+  t->affineEstimation_a = S->aff_a; t->affineEstimation_b = S->aff_b;
+  t->affineEstimation_a_lastIt = S->aff_a_lastIt; t->affineEstimation_b_lastIt = S->aff_b_lastIt;
+  t->lastResidual = S->lastResidual;
+  if (S->diverged) {
     t->diverged = true;
     t->trackingWasGood = false;
     fill_result(t, identity_d(), out);
     return LSDHIP_DIVERGED;
   }
-  if (rc) return rc;
-  t->trackingWasGood = !t->diverged && t->lastGoodCount / (c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) > MIN_GOODPERALL_PIXEL &&
+  t->diverged = false;
+  lsdm::SE3fH referenceToFrame;
+  referenceToFrame.q = {S->q[0], S->q[1], S->q[2], S->q[3]};
+  referenceToFrame.t[0] = S->t[0]; referenceToFrame.t[1] = S->t[1]; referenceToFrame.t[2] = S->t[2];
+  t->trackingWasGood = t->lastGoodCount / (c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) > MIN_GOODPERALL_PIXEL &&
                        t->lastGoodCount / (t->lastGoodCount + t->lastBadCount) > MIN_GOODPERGOODBAD_PIXEL;
   if (t->trackingWasGood) kf->numFramesTrackedOnThis++;
   frame->initialTrackedResidual = t->lastResidual / t->pointUsage;
@@ -1355,6 +1363,139 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   frame->trackingParentID = kf->id;
   fill_result(t, f2r, out);
   return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double init[7],
+                                    lsdhip_track_result* out) {
+  if (!t || !kf || !frame || !init || !out) return LSDHIP_E_ARG;
+  if (!kf->hasIDepth) { lsd_set_error("lsdhip_tracker_track: keyframe %d has no depth", kf->id); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = t->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  t->diverged = false;
+  t->trackingWasGood = true;
+  t->affineEstimation_a = 1; t->affineEstimation_b = 0;
+  t->numEvaluations = 0; t->numWarpUpdates = 0;
+  TrackJob job;
+  int rc = fill_trackframe_job(t, job, kf, frame);
+  if (rc) return rc;
+  lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(init)));
+
+  if (t->hostLM) {
+    float last_residual = 0;
+    rc = LSDHIP_OK;
+    for (int lvl = LSD_TRACK_MAX_LEVEL - 1; lvl >= LSD_TRACK_MIN_LEVEL && rc == LSDHIP_OK; lvl--)
+      rc = lm_level_host(t, job, lvl, referenceToFrame, &last_residual);
+    t->lastResidual = last_residual;
+    if (rc == LSDHIP_DIVERGED) {
+      t->diverged = true;
+      t->trackingWasGood = false;
+      fill_result(t, identity_d(), out);
+      return LSDHIP_DIVERGED;
+    }
+    if (rc) return rc;
+    // host-LM debugging path: build the summary the common epilogue expects
+    TrackSummary S = *t->h_summary;
+    S.diverged = 0;
+    S.q[0] = referenceToFrame.q.w; S.q[1] = referenceToFrame.q.x; S.q[2] = referenceToFrame.q.y; S.q[3] = referenceToFrame.q.z;
+    S.t[0] = referenceToFrame.t[0]; S.t[1] = referenceToFrame.t[1]; S.t[2] = referenceToFrame.t[2];
+    S.lastResidual = last_residual; S.numEvaluations = t->numEvaluations; S.numWarpUpdates = t->numWarpUpdates;
+    S.pointUsage = t->pointUsage; S.goodCount = t->lastGoodCount; S.badCount = t->lastBadCount; S.meanRes = t->lastMeanRes;
+    S.aff_a = t->affineEstimation_a; S.aff_b = t->affineEstimation_b;
+    S.aff_a_lastIt = t->affineEstimation_a_lastIt; S.aff_b_lastIt = t->affineEstimation_b_lastIt;
+    return finish_trackframe(t, &S, kf, frame, out);
+  }
+  rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
+  if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) return rc;
+  return finish_trackframe(t, t->h_summary, kf, frame, out);
+}
+
+// SE3Tracker::trackFrame for n independent (keyframe, frame) pairs in the same launches: job j = blockIdx.y.  Each job
+// runs exactly the arithmetic of lsdhip_tracker_track (same kernel, same summation order), so results are identical to
+// n single calls; the point is throughput — n evaluations share one launch and its latency chain.  inits: n x 7,
+// results: n.  Returns LSDHIP_OK, or LSDHIP_DIVERGED if any job diverged (see results[j].diverged).
+extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
+                                          const double* inits, lsdhip_track_result* results) {
+  if (!t || n <= 0 || !keyframes || !frames || !inits || !results) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = t->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  for (int j = 0; j < n; j++) {
+    if (!keyframes[j] || !frames[j]) return LSDHIP_E_ARG;
+    if (!keyframes[j]->hasIDepth) { lsd_set_error("lsdhip_tracker_track_batch: keyframe %d has no depth", keyframes[j]->id); return LSDHIP_E_STATE; }
+  }
+  if (n > t->batch_capacity) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
+    t->batch_capacity = n < 8 ? 8 : n;
+    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
+    const size_t per_job = 2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4;
+    HIPCHK(hipMalloc((void**)&t->d_bjobs, B * sizeof(TrackJob)));
+    HIPCHK(hipMalloc((void**)&t->d_bstate, B * 2 * sizeof(TrackState)));
+    HIPCHK(hipMalloc((void**)&t->d_bscratch, B * per_job));
+    HIPCHK(hipMemsetAsync(t->d_bscratch, 0, B * per_job, c->stream));
+    HIPCHK(hipHostMalloc((void**)&t->h_bjobs, B * sizeof(TrackJob), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&t->h_bsummary, B * sizeof(TrackSummary), hipHostMallocMapped));
+  }
+  int grid = 1;
+  // With many jobs in flight the other jobs hide a job's latency, so each job gets fewer, fatter workgroups: the
+  // per-workgroup LM replay (the price of the launch needing no inter-workgroup communication) shrinks accordingly.
+  t->cap_override = (t->grid_cap / n) & ~7;
+  if (t->cap_override < 16) t->cap_override = 16;
+  if (n == 1) t->cap_override = 0;
+  for (int j = 0; j < n; j++) {
+    TrackJob& job = t->h_bjobs[j];
+    int rc = fill_trackframe_job(t, job, keyframes[j], frames[j]);
+    if (rc) { t->cap_override = 0; return rc; }
+    job.evalOnly = 0;
+    job.topLevel = LSD_TRACK_MAX_LEVEL - 1;
+    job.T0 = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(inits + 7 * (size_t)j)));
+    job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
+    for (int l = job.lastLevel; l <= job.topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
+    t->h_bsummary[j].done = 0;
+  }
+  t->cap_override = 0;
+  HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
+  TrackScratch sc;
+  {
+    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
+    sc.sums = t->d_bscratch;
+    sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
+    sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
+    sc.max_rows = t->max_blocks;
+#ifdef LSD_PHASE_TRACE
+    sc.trace = nullptr;
+#endif
+  }
+  TrackSummary* d_sum = nullptr;
+  HIPCHK(hipHostGetDevicePointer((void**)&d_sum, t->h_bsummary, 0));
+  if (int rcp = prof_collect(c)) return rcp;
+  int budget = 26, parity = 0, first = 1, guard = 0;
+  while (true) {
+    if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    for (int i = 0; i < budget; i++) {
+      hipLaunchKernelGGL((k_track_step<256, true>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
+                         t->d_bstate, sc, d_sum, parity, first);
+      first = 0;
+      parity ^= 1;
+    }
+    HIPCHK(hipGetLastError());
+    if (c->prof_on) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bool all = true;
+    for (int j = 0; j < n; j++) all = all && t->h_bsummary[j].done;
+    if (all) break;
+    if (int rc2 = prof_collect(c)) return rc2;
+    budget = 6;
+    if (++guard > 200) { lsd_set_error("tracking batch did not terminate"); return LSDHIP_E_STATE; }
+  }
+  int rcAll = LSDHIP_OK;
+  for (int j = 0; j < n; j++) {
+    const TrackSummary* S = &t->h_bsummary[j];
+    if (c->prof_on) { c->prof_bytes += S->bytes; c->prof_launches += S->numEvaluations; }
+    int rc = finish_trackframe(t, S, keyframes[j], frames[j], &results[j]);
+    if (rc == LSDHIP_DIVERGED) rcAll = LSDHIP_DIVERGED;
+    else if (rc) return rc;
+  }
+  return rcAll;
 }
 
 extern "C" int lsdhip_tracker_evaluate(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const float T7[7], int level,

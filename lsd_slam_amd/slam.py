@@ -244,6 +244,20 @@ class SE3Tracker:
             frame._parent = reference.keyframe
         return np.array(r.frameToReference)
 
+    def trackFrameBatch(self, references, frames, inits):
+        """trackFrame for independent (reference, frame) pairs in the same kernel launches; returns (poses n x 7,
+        list of result records)."""
+        n = len(frames)
+        kfs = (C.c_void_p * n)(*[r.keyframe.h_ for r in references])
+        frs = (C.c_void_p * n)(*[f.h_ for f in frames])
+        init = np.ascontiguousarray(inits, dtype=np.float64).reshape(n, 7)
+        res = (capi.TrackResult * n)()
+        check(self.L.lsdhip_tracker_track_batch(self.h_, n, kfs, frs, init.ctypes.data, res))
+        for f, r, ref in zip(frames, res, references):
+            if not r.diverged:
+                f._parent = ref.keyframe
+        return np.array([list(r.frameToReference) for r in res]), list(res)
+
     def evaluate(self, reference, frame, referenceToFrame, level, a=1.0, b=0.0):
         T = np.ascontiguousarray(referenceToFrame, dtype=np.float32)
         r = capi.ResidualRecord()

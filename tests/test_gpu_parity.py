@@ -556,3 +556,38 @@ def test_large_frame_1280x1024_track_and_update(oracle, hip):
     dmo.update([fo])
     dmg.updateKeyframe([fg])
     assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "updateKeyframe 1280x1024")
+
+
+@pytest.mark.gpu
+def test_track_batch_equals_single_calls(oracle, hip):
+    """lsdhip_tracker_track_batch: n jobs in the same launches give the poses, flags, masks and side effects of n single
+    trackFrame calls (same kernel; a batch may tile a level into fewer workgroups, which only changes summation order)."""
+    w, h = 320, 240
+    seqs = [sequence(w, h, 4, seq_index=s) for s in range(3)]
+    ctx = hip.Context(w, h, seqs[0][2])
+    singles, batch_in = [], []
+    for s, (frames, depth0, K, gt) in enumerate(seqs):
+        for copy in range(2):
+            kf = hip.Frame(ctx, 100 * s, frames[0])
+            kf.setDepthFromGroundTruth(depth0)
+            ref = hip.TrackingReference()
+            ref.importFrame(kf)
+            fr = hip.Frame(ctx, 100 * s + 1, frames[1 + s])
+            (singles if copy == 0 else batch_in).append((ref, fr, kf))
+    tr = hip.SE3Tracker(ctx)
+    tr.set_maxItsPerLvl(ODOMETRY_ITS)
+    single_res = []
+    for ref, fr, kf in singles:
+        pose = tr.trackFrame(ref, fr, IDENT7)
+        single_res.append((pose, tr.last.numEvaluations, tr.lastResidual, tr.pointUsage, tr.trackingWasGood, fr.refPixelWasGoodNoCreate(),
+                           fr.stats()["initialTrackedResidual"], kf.stats()["numFramesTrackedOnThis"]))
+    poses, recs = tr.trackFrameBatch([b[0] for b in batch_in], [b[1] for b in batch_in], np.tile(IDENT7, (3, 1)))
+    for j, (ref, fr, kf) in enumerate(batch_in):
+        sp, sev, sres, suse, sgood, smask, sitr, sntr = single_res[j]
+        dtj, drj = pose_distance(poses[j], sp, oracle)
+        assert max(dtj, drj) < 2e-4, (j, dtj, drj)   # a batch uses fewer, fatter workgroups per job: other summation order
+        assert abs(recs[j].numEvaluations - sev) <= 2
+        assert recs[j].lastResidual == pytest.approx(sres, rel=5e-2) and recs[j].pointUsage == pytest.approx(suse, rel=1e-3)
+        assert bool(recs[j].trackingWasGood) == sgood
+        assert (fr.refPixelWasGoodNoCreate() != smask).mean() < 2e-3
+        assert fr.stats()["initialTrackedResidual"] == pytest.approx(sitr, rel=5e-2) and kf.stats()["numFramesTrackedOnThis"] == sntr
