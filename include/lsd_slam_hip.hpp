@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -356,16 +357,30 @@ class DepthMap {
 // distance / usage score.  Orchestration only: every per-pixel operation is a liblsdhip.so call.
 class SlamLoop {
  public:
+  // gtDepth0 != null: SlamSystem::gtDepthInit (SlamSystem.cpp:831-854); null: SlamSystem::randomInit (:857-881).
+  // kfEvery > 0: a new keyframe every kfEvery frames (deterministic; what bench.py and the parity tests use);
+  // kfEvery == 0: the reference's distance / usage score (SlamSystem.cpp:997-1015 with doSlam = false, see keyframeScore).
   SlamLoop(int w, int h, const Mat3f& K, const unsigned char* firstImage, bool imagesOnDevice, const float* gtDepth0, int kfEvery)
       : w_(w), h_(h), K_(K), onDevice_(imagesOnDevice), kfEvery_(kfEvery), tracker(w, h, K), map(w, h, K) {
     const int its[LSDHIP_PYRAMID_LEVELS] = {5, 20, 50, 100, 0};  // SlamSystem.cpp:80-81 (no level-4 iterations are run by the tracker)
     std::memcpy(tracker.settings.maxItsPerLvl, its, sizeof(its));
     keyframe = makeFrame(0, firstImage);
-    keyframe->setDepthFromGroundTruth(gtDepth0);  // SlamSystem::gtDepthInit (SlamSystem.cpp:831-854)
-    map.initializeFromGTDepth(keyframe.get());
+    if (gtDepth0) {
+      keyframe->setDepthFromGroundTruth(gtDepth0);
+      map.initializeFromGTDepth(keyframe.get());
+    } else {
+      map.initializeRandomly(keyframe.get());
+    }
     reference.importFrame(keyframe.get());
     keyframe->clearDepthHasBeenUpdatedFlag();
   }
+  // TrackableKeyFrameSearch::getRefFrameScore (GlobalMapping/TrackableKeyFrameSearch.h:75-79) with the default weights
+  // KFDistWeight = 4, KFUsageWeight = 3 (util/settings.cpp:77-78)
+  static float keyframeScore(float distanceSquared, float usage) {
+    return distanceSquared * 4.0f * 4.0f + (1 - usage) * (1 - usage) * 3.0f * 3.0f;
+  }
+  // called with the keyframe that has just been finalised (before the next one replaces it): output hook (PLY, messages)
+  std::function<void(Frame&, DepthMap&)> onKeyframeFinished;
   // track one frame, then one mapping iteration; returns frameToKeyframe.  Throws when tracking diverges.
   SE3 step(const unsigned char* image) { return step(image, [](double) {}); }
   // same, reporting the wall-clock instant (seconds, steady clock) at which tracking ended and mapping began
@@ -383,8 +398,18 @@ class SlamLoop {
     lastTrackEnd = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     onTrackEnd(lastTrackEnd);
     if (tracker.diverged) throw Error(LSDHIP_DIVERGED, "SlamLoop: tracking diverged at frame " + std::to_string(frameId_));
-    if (++sinceKF_ >= kfEvery_) {
+    ++sinceKF_;
+    bool createNewKeyFrame = kfEvery_ > 0 && sinceKF_ >= kfEvery_;
+    if (kfEvery_ == 0 && keyframe->stats().numMappedOnThisTotal > 5 /* MIN_NUM_MAPPED */) {
+      // SlamSystem.cpp:997-1015: dist = translation * meanIdepth; keyframesAll is empty without the pose graph, so
+      // minVal = 0.2 * 0.7 (SURVEY.md §8(d) driver notes)
+      const float mi = keyframe->meanIdepth();
+      const float d0 = (float)est.t[0] * mi, d1 = (float)est.t[1] * mi, d2 = (float)est.t[2] * mi;
+      createNewKeyFrame = keyframeScore(d0 * d0 + d1 * d1 + d2 * d2, tracker.pointUsage) > 0.2f * 0.7f;
+    }
+    if (createNewKeyFrame) {
       map.finalizeKeyFrame();
+      if (onKeyframeFinished) onKeyframeFinished(*keyframe, map);
       map.createKeyFrame(frame.get());
       keyframe = frame;
       reference.importFrame(keyframe.get());

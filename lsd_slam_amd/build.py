@@ -68,7 +68,8 @@ DRIVER_SRC = os.path.join(HERE, "driver", "slam_loop.cpp")
 
 def build_driver(force=False, verbose=False):
     """liblsdhip_driver.so: the C++ host loop (include/lsd_slam_hip.hpp) — plain g++, links liblsdhip.so."""
-    deps = [DRIVER_SRC, os.path.join(HERE, "..", "include", "lsd_slam_hip.hpp"), os.path.join(HERE, "..", "include", "lsdhip.h"),
+    deps = [DRIVER_SRC, os.path.join(HERE, "driver", "dataset_slam.cpp"), os.path.join(HERE, "..", "include", "lsd_slam_hip_io.hpp"),
+            os.path.join(HERE, "..", "include", "lsd_slam_hip.hpp"), os.path.join(HERE, "..", "include", "lsdhip.h"),
             os.path.join(HERE, "..", "include", "lsdhip_driver.h"), OUT]
     if not force and os.path.exists(DRIVER_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(DRIVER_OUT) for d in deps):
         return DRIVER_OUT
@@ -77,6 +78,13 @@ def build_driver(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # dataset_slam: the ROS-free image-folder driver (lsd_slam_amd/driver/dataset_slam.cpp)
+    cmd2 = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-reorder", "-I" + os.path.join(HERE, "..", "include"),
+            os.path.join(HERE, "driver", "dataset_slam.cpp"), "-o", os.path.join(HERE, "dataset_slam"), "-L" + HERE, "-llsdhip",
+            "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd2))
+    subprocess.check_call(cmd2)
     return DRIVER_OUT
 
 

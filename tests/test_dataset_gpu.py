@@ -1,0 +1,47 @@
+"""dataset_slam (the ROS-free image-folder driver) end to end on a synthetic PGM sequence:
+random initialisation, score-based keyframe selection, trajectory / keyframeMsg / PLY outputs."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import ROOT, sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dataset_slam_on_pgm_sequence(tmp_path):
+    w, h, n = 640, 480, 40
+    frames, depth0, K, gt = sequence(w, h, n)
+    lst = []
+    for i in range(n):
+        p = tmp_path / ("f%04d.pgm" % i)
+        with open(p, "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (w, h))
+            f.write(frames[i].tobytes())
+        lst.append(str(p))
+    (tmp_path / "files.txt").write_text("\n".join(lst) + "\n")
+    # absolute-pixel calibration (values >= 1 are taken as pixels)
+    (tmp_path / "calib.cfg").write_text("%f %f %f %f 0\n%d %d\nnone\n%d %d\n" % (K[0], K[1], K[2], K[3], w, h, w, h))
+    exe = os.path.join(ROOT, "lsd_slam_amd", "dataset_slam")
+    out = subprocess.check_output([exe, str(tmp_path / "calib.cfg"), str(tmp_path / "files.txt"), str(tmp_path)], timeout=300).decode()
+    s = dict(zip(out.split()[0::2], map(int, out.split()[1::2])))
+    assert s["frames"] == n - 1
+    assert s["tracked_good"] >= int(0.9 * (n - 1))          # random depth initialisation converges on this motion
+    assert s["keyframes"] >= 1 and s["points"] > 1000
+    traj = np.loadtxt(tmp_path / "trajectory.txt")
+    assert traj.shape == (n - 1, 20)
+    assert np.allclose(np.linalg.norm(traj[:, 2:6], axis=1), 1.0, atol=1e-6)
+    # the camera moves on a circle parallel to the image plane: translation dominates, rotation stays small
+    assert np.all(np.abs(traj[:, 2]) > 0.99)
+    raw = (tmp_path / "pc.ply").read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    assert (b"element vertex %d\n" % s["points"]) in head and len(body) == 16 * s["points"]
+    msgs = sorted(p for p in os.listdir(tmp_path) if p.startswith("keyframe_"))
+    assert len(msgs) == s["keyframes"]
+    b = (tmp_path / msgs[0]).read_bytes()
+    hh, ww = struct.unpack_from("<2I", b, 4 + 8 + 1 + 28 + 16)
+    npc, = struct.unpack_from("<I", b, 4 + 8 + 1 + 28 + 16 + 8)
+    assert (ww, hh) == (w, h) and npc == w * h * 12 and len(b) == 4 + 8 + 1 + 28 + 16 + 8 + 4 + npc
