@@ -159,6 +159,11 @@ int lsdhip_tracker_evaluate(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_fr
  * level-4 point cloud (Frame::setPermaRef data, Frame.cpp:149-174). */
 int lsdhip_tracker_track_permaref(lsdhip_tracker* t, const float* pos3_host, const float* colorAndVar2_host, int n,
                                   lsdhip_frame* frame, const double referenceToFrame[7], lsdhip_track_result* out);
+/* trackFrameOnPermaref for n permanent references in the same launches (reference clouds concatenated, counts[j] points
+ * each; each tracked against frames[j]) — many keyframe candidates against one new frame */
+int lsdhip_tracker_track_permaref_batch(lsdhip_tracker* t, int n, const float* pos3_host, const float* colorAndVar2_host,
+                                        const int* counts, lsdhip_frame** frames, const double* referenceToFrame,
+                                        lsdhip_track_result* results);
 int lsdhip_tracker_check_overlap(lsdhip_tracker* t, const float* pos3_host, int n, const double referenceToFrame[7],
                                  float* usage_out);
 

@@ -76,6 +76,7 @@ def _signatures():
         "lsdhip_tracker_track_batch": (i, [vp, i, pvp, pvp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(ResidualRecord)]),
         "lsdhip_tracker_track_permaref": (i, [vp, vp, vp, i, vp, vp, C.POINTER(TrackResult)]),
+        "lsdhip_tracker_track_permaref_batch": (i, [vp, i, vp, vp, vp, pvp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_check_overlap": (i, [vp, vp, i, vp, C.POINTER(C.c_float)]),
         "lsdhip_depth_create": (i, [vp, pvp]),
         "lsdhip_depth_destroy": (None, [vp]),

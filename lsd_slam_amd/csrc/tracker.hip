@@ -1409,50 +1409,40 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   return finish_trackframe(t, t->h_summary, kf, frame, out);
 }
 
-// SE3Tracker::trackFrame for n independent (keyframe, frame) pairs in the same launches: job j = blockIdx.y.  Each job
-// runs exactly the arithmetic of lsdhip_tracker_track (same kernel, same summation order), so results are identical to
-// n single calls; the point is throughput — n evaluations share one launch and its latency chain.  inits: n x 7,
-// results: n.  Returns LSDHIP_OK, or LSDHIP_DIVERGED if any job diverged (see results[j].diverged).
-extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
-                                          const double* inits, lsdhip_track_result* results) {
-  if (!t || n <= 0 || !keyframes || !frames || !inits || !results) return LSDHIP_E_ARG;
+// ---- batches: n independent jobs in the same launches (job = blockIdx.y) -------------------------------------------
+static int batch_reserve(lsdhip_tracker* t, int n) {
   lsdhip_ctx* c = t->ctx;
-  HIPCHK(hipSetDevice(c->device));
-  for (int j = 0; j < n; j++) {
-    if (!keyframes[j] || !frames[j]) return LSDHIP_E_ARG;
-    if (!keyframes[j]->hasIDepth) { lsd_set_error("lsdhip_tracker_track_batch: keyframe %d has no depth", keyframes[j]->id); return LSDHIP_E_STATE; }
-  }
-  if (n > t->batch_capacity) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
-    t->batch_capacity = n < 8 ? 8 : n;
-    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
-    const size_t per_job = 2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4;
-    HIPCHK(hipMalloc((void**)&t->d_bjobs, B * sizeof(TrackJob)));
-    HIPCHK(hipMalloc((void**)&t->d_bstate, B * 2 * sizeof(TrackState)));
-    HIPCHK(hipMalloc((void**)&t->d_bscratch, B * per_job));
-    HIPCHK(hipMemsetAsync(t->d_bscratch, 0, B * per_job, c->stream));
-    HIPCHK(hipHostMalloc((void**)&t->h_bjobs, B * sizeof(TrackJob), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&t->h_bsummary, B * sizeof(TrackSummary), hipHostMallocMapped));
-  }
-  int grid = 1;
-  // With many jobs in flight the other jobs hide a job's latency, so each job gets fewer, fatter workgroups: the
-  // per-workgroup LM replay (the price of the launch needing no inter-workgroup communication) shrinks accordingly.
+  if (n <= t->batch_capacity) return LSDHIP_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
+  t->batch_capacity = n < 8 ? 8 : n;
+  const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
+  const size_t per_job = 2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4;
+  HIPCHK(hipMalloc((void**)&t->d_bjobs, B * sizeof(TrackJob)));
+  HIPCHK(hipMalloc((void**)&t->d_bstate, B * 2 * sizeof(TrackState)));
+  HIPCHK(hipMalloc((void**)&t->d_bscratch, B * per_job));
+  HIPCHK(hipMemsetAsync(t->d_bscratch, 0, B * per_job, c->stream));
+  HIPCHK(hipHostMalloc((void**)&t->h_bjobs, B * sizeof(TrackJob), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&t->h_bsummary, B * sizeof(TrackSummary), hipHostMallocMapped));
+  return LSDHIP_OK;
+}
+// With many jobs in flight the other jobs hide a job's latency, so each job gets fewer, fatter workgroups: the
+// per-workgroup LM replay (the price of the launch needing no inter-workgroup communication) shrinks accordingly.
+static void batch_begin(lsdhip_tracker* t, int n) {
   t->cap_override = (t->grid_cap / n) & ~7;
   if (t->cap_override < 16) t->cap_override = 16;
   if (n == 1) t->cap_override = 0;
+}
+// runs the n jobs described in t->h_bjobs[0..n) to completion; summaries in t->h_bsummary
+static int batch_run(lsdhip_tracker* t, int n) {
+  lsdhip_ctx* c = t->ctx;
+  t->cap_override = 0;
+  int grid = 1;
   for (int j = 0; j < n; j++) {
-    TrackJob& job = t->h_bjobs[j];
-    int rc = fill_trackframe_job(t, job, keyframes[j], frames[j]);
-    if (rc) { t->cap_override = 0; return rc; }
-    job.evalOnly = 0;
-    job.topLevel = LSD_TRACK_MAX_LEVEL - 1;
-    job.T0 = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(inits + 7 * (size_t)j)));
-    job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
+    const TrackJob& job = t->h_bjobs[j];
     for (int l = job.lastLevel; l <= job.topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
     t->h_bsummary[j].done = 0;
   }
-  t->cap_override = 0;
   HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
   TrackScratch sc;
   {
@@ -1487,11 +1477,41 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
     budget = 6;
     if (++guard > 200) { lsd_set_error("tracking batch did not terminate"); return LSDHIP_E_STATE; }
   }
+  if (c->prof_on)
+    for (int j = 0; j < n; j++) { c->prof_bytes += t->h_bsummary[j].bytes; c->prof_launches += t->h_bsummary[j].numEvaluations; }
+  return LSDHIP_OK;
+}
+
+// SE3Tracker::trackFrame for n independent (keyframe, frame) pairs in the same launches.  Each job runs the arithmetic
+// of lsdhip_tracker_track (same kernel; a batch tiles a level into fewer workgroups, which only changes summation
+// order); the point is throughput — n evaluations share one launch and its latency chain.  inits: n x 7, results: n.
+// Returns LSDHIP_OK, or LSDHIP_DIVERGED if any job diverged (see results[j].diverged).
+extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
+                                          const double* inits, lsdhip_track_result* results) {
+  if (!t || n <= 0 || !keyframes || !frames || !inits || !results) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = t->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  for (int j = 0; j < n; j++) {
+    if (!keyframes[j] || !frames[j]) return LSDHIP_E_ARG;
+    if (!keyframes[j]->hasIDepth) { lsd_set_error("lsdhip_tracker_track_batch: keyframe %d has no depth", keyframes[j]->id); return LSDHIP_E_STATE; }
+  }
+  int rc = batch_reserve(t, n);
+  if (rc) return rc;
+  batch_begin(t, n);
+  for (int j = 0; j < n; j++) {
+    TrackJob& job = t->h_bjobs[j];
+    rc = fill_trackframe_job(t, job, keyframes[j], frames[j]);
+    if (rc) { t->cap_override = 0; return rc; }
+    job.evalOnly = 0;
+    job.topLevel = LSD_TRACK_MAX_LEVEL - 1;
+    job.T0 = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(inits + 7 * (size_t)j)));
+    job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
+  }
+  rc = batch_run(t, n);
+  if (rc) return rc;
   int rcAll = LSDHIP_OK;
   for (int j = 0; j < n; j++) {
-    const TrackSummary* S = &t->h_bsummary[j];
-    if (c->prof_on) { c->prof_bytes += S->bytes; c->prof_launches += S->numEvaluations; }
-    int rc = finish_trackframe(t, S, keyframes[j], frames[j], &results[j]);
+    rc = finish_trackframe(t, &t->h_bsummary[j], keyframes[j], frames[j], &results[j]);
     if (rc == LSDHIP_DIVERGED) rcAll = LSDHIP_DIVERGED;
     else if (rc) return rc;
   }
@@ -1577,6 +1597,64 @@ extern "C" int lsdhip_tracker_track_permaref(lsdhip_tracker* t, const float* pos
                        t->lastGoodCount / (t->lastGoodCount + t->lastBadCount) > MIN_GOODPERGOODBAD_PIXEL;
   fill_result(t, lsdm::se3d_from_f(referenceToFrame), out);
   return LSDHIP_OK;
+}
+
+// SE3Tracker::trackFrameOnPermaref (SE3Tracker.cpp:162-272) for n permanent references against frames[j] in the same
+// launches — the shape of TrackableKeyFrameSearch::findRePositionCandidate and of the relocaliser, which test many
+// keyframes against one new frame.  pos / colvar: the references' level-4 point clouds
+// concatenated (counts[j] points each); refToFrame: n x 7; results: n.
+extern "C" int lsdhip_tracker_track_permaref_batch(lsdhip_tracker* t, int n, const float* pos, const float* colvar, const int* counts,
+                                                   lsdhip_frame** frames, const double* refToFrame, lsdhip_track_result* results) {
+  if (!t || n <= 0 || !pos || !colvar || !counts || !frames || !refToFrame || !results) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = t->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  int total = 0;
+  for (int j = 0; j < n; j++) { if (counts[j] <= 0 || !frames[j]) return LSDHIP_E_ARG; total += counts[j]; }
+  int rc = upload_points(t, pos, colvar, total);
+  if (rc) return rc;
+  rc = batch_reserve(t, n);
+  if (rc) return rc;
+  batch_begin(t, n);
+  const int L = LSD_QUICK_KF_CHECK_LVL;
+  int off = 0;
+  for (int j = 0; j < n; j++) {
+    TrackJob& job = t->h_bjobs[j];
+    fill_job_common(t, job);
+    fill_level(t, job, L, nullptr, frames[j], t->d_pts + (size_t)off * 3, t->d_pts + (size_t)t->pts_capacity * 3 + (size_t)off * 2, counts[j]);
+    job.lv[L].lambdaInitial = t->lambdaInitialTestTrack; job.lv[L].stepSizeMin = t->stepSizeMinTestTrack;
+    job.lv[L].convergenceEps = t->convergenceEpsTestTrack; job.lv[L].maxIts = (int)t->maxItsTestTrack;
+    job.lastLevel = L;
+    job.topLevel = L;
+    job.trackFrameSemantics = 0;
+    job.evalOnly = 0;
+    job.T0 = lsdm::se3f_from_d(lsdm::se3d_from7(refToFrame + 7 * (size_t)j));
+    job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
+    off += counts[j];
+  }
+  rc = batch_run(t, n);
+  if (rc) return rc;
+  int rcAll = LSDHIP_OK;
+  for (int j = 0; j < n; j++) {
+    const TrackSummary* S = &t->h_bsummary[j];
+    t->numEvaluations = S->numEvaluations; t->numWarpUpdates = S->numWarpUpdates;
+    t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;
+    t->affineEstimation_a = S->aff_a; t->affineEstimation_b = S->aff_b;
+    t->lastResidual = S->lastResidual;
+    if (S->diverged) {
+      t->diverged = true; t->trackingWasGood = false;
+      fill_result(t, identity_d(), &results[j]);
+      rcAll = LSDHIP_DIVERGED;
+      continue;
+    }
+    t->diverged = false;
+    t->trackingWasGood = t->lastGoodCount / (c->wl[L] * c->hl[L]) > MIN_GOODPERALL_PIXEL &&
+                         t->lastGoodCount / (t->lastGoodCount + t->lastBadCount) > MIN_GOODPERGOODBAD_PIXEL;
+    lsdm::SE3fH T;
+    T.q = {S->q[0], S->q[1], S->q[2], S->q[3]};
+    T.t[0] = S->t[0]; T.t[1] = S->t[1]; T.t[2] = S->t[2];
+    fill_result(t, lsdm::se3d_from_f(T), &results[j]);
+  }
+  return rcAll;
 }
 
 extern "C" int lsdhip_tracker_check_overlap(lsdhip_tracker* t, const float* pos, int n, const double refToFrame[7], float* usage_out) {

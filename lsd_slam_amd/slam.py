@@ -273,6 +273,18 @@ class SE3Tracker:
         self._publish(r)
         return np.array(r.frameToReference)
 
+    def trackFrameOnPermarefBatch(self, clouds, frames, referenceToFrames):
+        """clouds: list of (pos n_j x 3, colVar n_j x 2); each tracked against frames[j]; returns (poses, records)"""
+        n = len(clouds)
+        pos = np.ascontiguousarray(np.concatenate([c[0] for c in clouds]), np.float32)
+        cv = np.ascontiguousarray(np.concatenate([c[1] for c in clouds]), np.float32)
+        counts = np.array([len(c[0]) for c in clouds], np.int32)
+        frs = (C.c_void_p * n)(*[f.h_ for f in frames])
+        T = np.ascontiguousarray(referenceToFrames, np.float64).reshape(n, 7)
+        res = (capi.TrackResult * n)()
+        check(self.L.lsdhip_tracker_track_permaref_batch(self.h_, n, pos.ctypes.data, cv.ctypes.data, counts.ctypes.data, frs, T.ctypes.data, res))
+        return np.array([list(r.frameToReference) for r in res]), list(res)
+
     def checkPermaRefOverlap(self, permaRef_pos, referenceToFrame):
         pos = np.ascontiguousarray(permaRef_pos, np.float32)
         T = np.ascontiguousarray(referenceToFrame, np.float64)

@@ -591,3 +591,41 @@ def test_track_batch_equals_single_calls(oracle, hip):
         assert bool(recs[j].trackingWasGood) == sgood
         assert (fr.refPixelWasGoodNoCreate() != smask).mean() < 2e-3
         assert fr.stats()["initialTrackedResidual"] == pytest.approx(sitr, rel=5e-2) and kf.stats()["numFramesTrackedOnThis"] == sntr
+
+
+@pytest.mark.gpu
+def test_permaref_batch_matches_single_and_oracle(oracle, hip):
+    """several keyframes' permanent references (level-4 clouds) tracked against one new frame in the same
+    launches give what single trackFrameOnPermaref calls and the oracle give."""
+    w, h = 640, 480
+    K = sequence(w, h, 4, seq_index=0)[2]
+    ctx = hip.Context(w, h, K)
+    clouds, singles, oracles = [], [], []
+    target_frames = sequence(w, h, 4, seq_index=0)[0]
+    fg = hip.Frame(ctx, 50, target_frames[2])
+    T0s = []
+    for s in range(3):
+        frames, depth0, K_, gt = sequence(w, h, 4, seq_index=0)
+        kfo = oracle.Frame(s, frames[s], K)      # keyframes = frames 0, 1, 2 of the sequence, all with GT depth of frame 0's view
+        kfo.set_depth_gt(depth0)
+        ro = oracle.TrackingReference()
+        ro.import_frame(kfo)
+        pos, cv, _, _ = ro.pointcloud(4)
+        clouds.append((pos, cv))
+        T0 = oracle.se3_exp(np.array([0.005 * (s + 1), 0.0, 0.0, 0, 0, 0.001 * s]))
+        T0s.append(T0)
+        tro = oracle.SE3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP)
+        r = tro.track_permaref(pos, cv, oracle.Frame(50, target_frames[2], K), T0)
+        oracles.append(r)
+        trs = hip.SE3Tracker(ctx)
+        singles.append((trs.trackFrameOnPermaref(pos, cv, fg, T0), trs.trackingWasGood, trs.lastResidual))
+    trb = hip.SE3Tracker(ctx)
+    poses, recs = trb.trackFrameOnPermarefBatch(clouds, [fg] * 3, np.array(T0s))
+    for j in range(3):
+        # level 4 is a single tile either way: identical arithmetic to the single call
+        assert np.array_equal(poses[j], singles[j][0]), j
+        assert bool(recs[j].trackingWasGood) == singles[j][1] and recs[j].lastResidual == singles[j][2]
+        if not oracles[j].diverged:
+            dt, dr = pose_distance(poses[j], np.array(oracles[j].frameToRef), oracle)
+            assert max(dt, dr) < 2e-3, (j, dt, dr)
+        assert bool(recs[j].diverged) == bool(oracles[j].diverged)
