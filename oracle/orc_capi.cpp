@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstring>
 #include "lsd_oracle.hpp"
+#include "orc_sim3.hpp"
 
 using namespace orc;
 
@@ -265,6 +266,43 @@ void orc_depth_stage(void* d, int stage, void** frames, int n) {
     dm->activeKeyFrame = nk;
     dm->refreshActiveKeyFrameImage();
   }
+}
+
+// ---- Sim3Tracker ----------------------------------------------------------------------------------
+// Sim3 as double[8] = (qw, qx, qy, qz, tx, ty, tz, scale)
+struct orc_sim3_result {
+  double frameToRef[8];
+  float lastResidual, lastDepthResidual, lastPhotometricResidual, pointUsage, affine_a, affine_b;
+  int diverged, numEvaluations;
+  float hessian[49];
+};
+static Sim3d sim3_in(const double p[8]) {
+  Sim3d T;
+  T.q.w = p[0]; T.q.x = p[1]; T.q.y = p[2]; T.q.z = p[3];
+  T.t = mk3<double>(p[4], p[5], p[6]);
+  T.s = p[7];
+  return T;
+}
+void* orc_sim3tracker_create(int w, int h, const float K[4], const orc_params* p) { return new Sim3Tracker(w, h, K, to_params(p)); }
+void orc_sim3tracker_destroy(void* t) { delete (Sim3Tracker*)t; }
+void orc_sim3tracker_set_mode(void* t, int mode) { ((Sim3Tracker*)t)->mode = (TrackerMode)mode; }
+void orc_sim3tracker_set_max_its(void* t, const int its[5]) { for (int i = 0; i < 5; i++) ((Sim3Tracker*)t)->settings.maxItsPerLvl[i] = its[i]; }
+void orc_sim3tracker_track(void* t, void* ref, void* frame, const double init_frameToRef[8], int startLevel, int finalLevel, orc_sim3_result* out) {
+  Sim3Tracker* tr = (Sim3Tracker*)t;
+  Sim3d T = tr->trackFrameSim3((TrackingReference*)ref, F(frame), sim3_in(init_frameToRef), startLevel, finalLevel);
+  out->frameToRef[0] = T.q.w; out->frameToRef[1] = T.q.x; out->frameToRef[2] = T.q.y; out->frameToRef[3] = T.q.z;
+  out->frameToRef[4] = T.t[0]; out->frameToRef[5] = T.t[1]; out->frameToRef[6] = T.t[2]; out->frameToRef[7] = T.s;
+  out->lastResidual = tr->lastResidual; out->lastDepthResidual = tr->lastDepthResidual; out->lastPhotometricResidual = tr->lastPhotometricResidual;
+  out->pointUsage = tr->pointUsage; out->affine_a = tr->affineEstimation_a; out->affine_b = tr->affineEstimation_b;
+  out->diverged = tr->diverged; out->numEvaluations = tr->numEvaluations;
+  memcpy(out->hessian, tr->lastSim3Hessian, sizeof(out->hessian));
+}
+void orc_sim3tracker_evaluate(void* t, void* ref, void* frame, const double refToFrame[8], int level, float a, float b, Sim3EvalRecord* out) {
+  ((Sim3Tracker*)t)->evaluate((TrackingReference*)ref, F(frame), sim3_in(refToFrame), level, a, b, out);
+}
+void orc_sim3_exp(const double a[7], double out[8]) {
+  Sim3d T = sim3_exp(a);
+  out[0] = T.q.w; out[1] = T.q.x; out[2] = T.q.y; out[3] = T.q.z; out[4] = T.t[0]; out[5] = T.t[1]; out[6] = T.t[2]; out[7] = T.s;
 }
 
 double orc_now_seconds() {

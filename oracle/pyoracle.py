@@ -36,6 +36,19 @@ class ResidualRecord(C.Structure):
                 ("lsError", C.c_float), ("num_constraints", C.c_double)]
 
 
+class Sim3Result(C.Structure):
+    _fields_ = [("frameToRef", C.c_double * 8), ("lastResidual", C.c_float), ("lastDepthResidual", C.c_float),
+                ("lastPhotometricResidual", C.c_float), ("pointUsage", C.c_float), ("affine_a", C.c_float), ("affine_b", C.c_float),
+                ("diverged", C.c_int), ("numEvaluations", C.c_int), ("hessian", C.c_float * 49)]
+
+
+class Sim3EvalRecord(C.Structure):
+    _fields_ = [("warped_size", C.c_int), ("pointUsage", C.c_float), ("affine_a_lastIt", C.c_float), ("affine_b_lastIt", C.c_float),
+                ("sumResD", C.c_float), ("sumResP", C.c_float), ("numTermsD", C.c_int), ("numTermsP", C.c_int),
+                ("meanD", C.c_float), ("meanP", C.c_float), ("mean", C.c_float), ("A", C.c_float * 49), ("b", C.c_float * 7),
+                ("num_constraints", C.c_double)]
+
+
 def build(force=False):
     """Compile both oracle builds (parity + timing) with the committed Makefile."""
     need = force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liblsd_oracle.so", "liblsd_oracle_fast.so"))
@@ -108,6 +121,13 @@ def lib(fast=False):
         "orc_frame_take_reactivation": (None, [vp, vp]),
         "orc_frame_set_depth_from_map": (None, [vp, vp]),
         "orc_depth_stage": (None, [vp, i, C.POINTER(vp), i]),
+        "orc_sim3tracker_create": (vp, [i, i, fp, C.POINTER(Params)]),
+        "orc_sim3tracker_destroy": (None, [vp]),
+        "orc_sim3tracker_set_mode": (None, [vp, i]),
+        "orc_sim3tracker_set_max_its": (None, [vp, ip]),
+        "orc_sim3tracker_track": (None, [vp, vp, vp, dp, i, i, C.POINTER(Sim3Result)]),
+        "orc_sim3tracker_evaluate": (None, [vp, vp, vp, dp, i, f, f, C.POINTER(Sim3EvalRecord)]),
+        "orc_sim3_exp": (None, [dp, dp]),
         "orc_now_seconds": (d, []),
     }
     for name_, (res, args) in sig.items():
@@ -280,6 +300,57 @@ class SE3Tracker:
         pos = np.ascontiguousarray(pos, np.float32)
         return self.L.orc_tracker_check_overlap(self.h_, pos, len(pos), ref_frame.h_,
                                                 np.ascontiguousarray(refToFrame, np.float64))
+
+
+class Sim3Tracker:
+    """C/Tracking/Sim3Tracker.{h,cpp} restated (oracle/orc_sim3.cpp).  Sim3 = double[8] (qw,qx,qy,qz,tx,ty,tz,scale)."""
+
+    def __init__(self, w, h, K, params=None, mode=SSE, L=None):
+        self.L = L or lib()
+        self.params = params or default_params(self.L)
+        self.h_ = self.L.orc_sim3tracker_create(w, h, np.ascontiguousarray(K, dtype=np.float32), C.byref(self.params))
+        self.L.orc_sim3tracker_set_mode(self.h_, mode)
+
+    def __del__(self):
+        if getattr(self, "h_", None):
+            self.L.orc_sim3tracker_destroy(self.h_)
+            self.h_ = None
+
+    def set_max_its(self, its):
+        self.L.orc_sim3tracker_set_max_its(self.h_, np.ascontiguousarray(its, dtype=np.int32))
+
+    def track(self, ref, frame, init_frameToRef8, startLevel, finalLevel):
+        r = Sim3Result()
+        self.L.orc_sim3tracker_track(self.h_, ref.h_, frame.h_, np.ascontiguousarray(init_frameToRef8, dtype=np.float64), startLevel,
+                                     finalLevel, C.byref(r))
+        return r
+
+    def evaluate(self, ref, frame, refToFrame8, level, a=1.0, b=0.0):
+        r = Sim3EvalRecord()
+        self.L.orc_sim3tracker_evaluate(self.h_, ref.h_, frame.h_, np.ascontiguousarray(refToFrame8, dtype=np.float64), level, a, b,
+                                        C.byref(r))
+        return r
+
+
+def sim3_exp(a7):
+    out = np.zeros(8)
+    lib().orc_sim3_exp(np.ascontiguousarray(a7, dtype=np.float64), out)
+    return out
+
+
+def sim3_inv(T):
+    """inverse of (qw,qx,qy,qz,tx,ty,tz,s): p' = s R p + t"""
+    q = np.array([T[0], -T[1], -T[2], -T[3]])
+    s = 1.0 / T[7]
+    R = quat_to_rot(q)
+    return np.concatenate([q, -(R @ np.asarray(T[4:7])) * s, [s]])
+
+
+def quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
 class DepthMap:

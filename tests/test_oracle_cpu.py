@@ -176,3 +176,66 @@ def test_regulariser_idempotent_on_constant_map(oracle):
     dm.stage("regularize")
     b = dm.get()
     assert_bit_equal(a["idepth_smoothed"], b["idepth_smoothed"], "idempotent")
+
+
+# ---- Sim3 tracker -------------------------------------------------------------------------------
+def _sim3_pair(oracle, w, h, k, scale):
+    """Keyframe A = frame 0 with its GT depth; keyframe B = frame k with its own GT depth, all depths of B divided by
+    `scale` (B's map lives in a world `scale` times smaller).  Returns (refA, frameB, expected B->A Sim3)."""
+    from lsd_slam_amd import synth
+    sc = synth.Scene(0)
+    K = synth.intrinsics(w, h)
+    imgA, depthA = sc.render(0, w, h)
+    imgB, depthB = sc.render(k, w, h)
+    fa = oracle.Frame(0, imgA, K)
+    fa.set_depth_gt(depthA)
+    fb = oracle.Frame(k, imgB, K)
+    fb.set_depth_gt((depthB / scale).astype(np.float32))
+    ra = oracle.TrackingReference()
+    ra.import_frame(fa)
+    R, t = sc.frame_to_ref(k, 0)              # p_A = R p_B + t (metric)
+    # points of B's (shrunk) map: p_Bs = p_B / scale  =>  p_A = scale R p_Bs + t
+    exp = np.concatenate([synth.rot_to_quat(R), t, [scale]])
+    return ra, fb, fa, exp
+
+
+def test_sim3_exp_reduces_to_se3_and_scales(oracle):
+    a = np.array([0.1, -0.2, 0.05, 0.02, -0.01, 0.03, 0.0])
+    T = oracle.sim3_exp(a)
+    assert T[7] == pytest.approx(1.0) and np.allclose(T[:7], oracle.se3_exp(a[:6]), atol=1e-12)
+    T2 = oracle.sim3_exp(np.array([0, 0, 0, 0, 0, 0, np.log(2.0)]))
+    assert T2[7] == pytest.approx(2.0) and np.allclose(T2[:7], [1, 0, 0, 0, 0, 0, 0])
+
+
+@pytest.mark.parametrize("mode", ["SCALAR", "SSE", "SSE_EXACT_RCP"])
+def test_sim3_tracker_recovers_pose_and_scale(oracle, mode):
+    w, h = 320, 240
+    ra, fb, fa, exp = _sim3_pair(oracle, w, h, 3, 1.25)
+    from lsd_slam_amd import synth
+    tr = oracle.Sim3Tracker(w, h, synth.intrinsics(w, h), mode=getattr(oracle, mode))
+    init = exp.copy()
+    init[7] = 1.0                                   # start from the right pose but the wrong scale
+    r = tr.track(ra, fb, init, 3, 1)
+    got = np.array(r.frameToRef)
+    assert not r.diverged and r.numEvaluations > 5
+    assert got[7] == pytest.approx(1.25, rel=2e-2)                  # scale recovered from the depth residuals
+    assert np.linalg.norm(got[4:7] - exp[4:7]) < 5e-3
+    assert min(np.linalg.norm(got[:4] - exp[:4]), np.linalg.norm(got[:4] + exp[:4])) < 2e-3
+    H = np.array(r.hessian).reshape(7, 7)
+    assert np.allclose(H, H.T) and np.all(np.diag(H) > 0)
+
+
+def test_sim3_sse_drops_tail_and_counts_constraints(oracle):
+    from lsd_slam_amd import synth
+    w, h = 320, 240
+    ra, fb, fa, exp = _sim3_pair(oracle, w, h, 2, 1.0)
+    K = synth.intrinsics(w, h)
+    T = oracle.sim3_inv(exp)
+    rs = oracle.Sim3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP).evaluate(ra, fb, T, 2)
+    rc = oracle.Sim3Tracker(w, h, K, mode=oracle.SCALAR).evaluate(ra, fb, T, 2)
+    assert rs.warped_size == rc.warped_size
+    assert rs.numTermsP == (rs.warped_size // 4) * 4 and rc.numTermsP == rc.warped_size
+    assert rs.num_constraints == 10 * (rs.warped_size // 4)          # LGS6 counts 6, LGS4 counts 4 per group of four
+    assert rc.num_constraints == 2 * rc.warped_size
+    # raw (undivided) systems agree up to the <= 3 dropped points of ~1000 and the reassociated sums
+    assert np.allclose(np.array(rs.A), np.array(rc.A), rtol=2e-2, atol=5e-3 * np.abs(np.array(rc.A)).max())
