@@ -301,6 +301,51 @@ class SE3Tracker {
   lsdhip_tracker* h_ = nullptr;
 };
 
+// Tracking/Sim3Tracker.h:71-187
+class Sim3Tracker {
+ public:
+  int width, height;
+  Mat3f K;
+  DenseDepthTrackerSettings settings;
+
+  Sim3Tracker(int w, int h, const Mat3f& K_) : width(w), height(h), K(K_), ctx_(Context::get(w, h, K_)) {
+    check(lsdhip_sim3tracker_create(ctx_->handle(), &h_), "lsdhip_sim3tracker_create");
+  }
+  Sim3Tracker(const Sim3Tracker&) = delete;
+  Sim3Tracker& operator=(const Sim3Tracker&) = delete;
+  ~Sim3Tracker() { lsdhip_sim3tracker_destroy(h_); }
+
+  Sim3 trackFrameSim3(TrackingReference* reference, Frame* frame, const Sim3& frameToReference_initialEstimate, int startLevel,
+                      int finalLevel) {
+    check(lsdhip_sim3tracker_set_max_its(h_, settings.maxItsPerLvl), "lsdhip_sim3tracker_set_max_its");
+    double init[8] = {frameToReference_initialEstimate.q[0], frameToReference_initialEstimate.q[1], frameToReference_initialEstimate.q[2],
+                      frameToReference_initialEstimate.q[3], frameToReference_initialEstimate.t[0], frameToReference_initialEstimate.t[1],
+                      frameToReference_initialEstimate.t[2], frameToReference_initialEstimate.s};
+    lsdhip_sim3_result r;
+    check(lsdhip_sim3tracker_track(h_, reference->keyframe->handle(), frame->handle(), init, startLevel, finalLevel, &r),
+          "lsdhip_sim3tracker_track");
+    pointUsage = r.pointUsage; lastResidual = r.lastResidual; lastDepthResidual = r.lastDepthResidual;
+    lastPhotometricResidual = r.lastPhotometricResidual; affineEstimation_a = r.affineEstimation_a; affineEstimation_b = r.affineEstimation_b;
+    diverged = r.diverged != 0; numEvaluations = r.numEvaluations;
+    for (int i = 0; i < 49; i++) lastSim3Hessian[i] = r.lastSim3Hessian[i];
+    Sim3 out;
+    for (int i = 0; i < 4; i++) out.q[i] = r.frameToReference[i];
+    for (int i = 0; i < 3; i++) out.t[i] = r.frameToReference[4 + i];
+    out.s = r.frameToReference[7];
+    return out;
+  }
+
+  float pointUsage = 0, lastResidual = 0, lastDepthResidual = 0, lastPhotometricResidual = 0;
+  float affineEstimation_a = 1, affineEstimation_b = 0;
+  float lastSim3Hessian[49] = {};   // row-major 7x7
+  bool diverged = false;
+  int numEvaluations = 0;
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  lsdhip_sim3tracker* h_ = nullptr;
+};
+
 // DepthEstimation/DepthMap.h:47-98
 class DepthMap {
  public:

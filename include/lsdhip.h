@@ -167,6 +167,42 @@ int lsdhip_tracker_track_permaref_batch(lsdhip_tracker* t, int n, const float* p
 int lsdhip_tracker_check_overlap(lsdhip_tracker* t, const float* pos3_host, int n, const double referenceToFrame[7],
                                  float* usage_out);
 
+/* ---- Sim3Tracker ----------------------------------------------------------------- */
+/* Sim3 as double[8] = (qw,qx,qy,qz,tx,ty,tz,scale): p' = scale * R(q) p + t.
+ * Replaces Sim3Tracker (C/Tracking/Sim3Tracker.h:71-187): the keyframe-to-keyframe constraint tracker of
+ * SlamSystem::tryTrackSim3 (C/SlamSystem.cpp:1153-1228). */
+typedef struct lsdhip_sim3tracker lsdhip_sim3tracker;
+typedef struct lsdhip_sim3_result {
+  double frameToReference[8];          /* return value of trackFrameSim3; identity when diverged */
+  float lastResidual, lastDepthResidual, lastPhotometricResidual; /* Sim3Tracker.h:89-91 */
+  float pointUsage;                    /* Sim3Tracker.h:85 */
+  float affineEstimation_a, affineEstimation_b;
+  int diverged;
+  int numEvaluations;
+  float lastSim3Hessian[49];           /* Sim3Tracker.h:93, row-major */
+} lsdhip_sim3_result;
+/* one evaluation (calcSim3Buffers + calcSim3WeightsAndResidual + calcSim3LGS, Sim3Tracker.cpp:414-983) */
+typedef struct lsdhip_sim3_eval_record {
+  int warped_size;
+  float pointUsage, affine_a_lastIt, affine_b_lastIt;
+  float sumResD, sumResP;
+  int numTermsD, numTermsP;
+  float meanD, meanP, mean;
+  float A[49], b[7];                   /* LGS7 after initializeFrom(ls6, ls4), before the division by num_constraints */
+  double num_constraints;
+} lsdhip_sim3_eval_record;
+int lsdhip_sim3tracker_create(lsdhip_ctx* ctx, lsdhip_sim3tracker** out);     /* Sim3Tracker::Sim3Tracker, Sim3Tracker.cpp:43-103 */
+void lsdhip_sim3tracker_destroy(lsdhip_sim3tracker* t);
+int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int maxItsPerLvl[5]);
+/* Sim3Tracker::trackFrameSim3(reference, frame, frameToReference_initialEstimate, startLevel, finalLevel)
+ * (Sim3Tracker.cpp:149-378).  `keyframe` is reference->keyframe; both frames need inverse-depth planes (Frame::setDepth).
+ * Returns LSDHIP_DIVERGED when the reference sets diverged or returns Sim3() early. */
+int lsdhip_sim3tracker_track(lsdhip_sim3tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame, const double init_frameToReference[8],
+                             int startLevel, int finalLevel, lsdhip_sim3_result* out);
+/* test hook: one evaluation at referenceToFrame on `level` with affine (a, b) */
+int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame, const double referenceToFrame[8],
+                                int level, float aff_a, float aff_b, lsdhip_sim3_eval_record* out);
+
 /* ---- DepthMap ------------------------------------------------------------------------------------- */
 /* DepthMap::DepthMap (DepthMap.cpp:41-83) */
 int lsdhip_depth_create(lsdhip_ctx* ctx, lsdhip_depthmap** out);

@@ -5,4 +5,4 @@ This package holds only what that path needs: csrc/ (HIP kernels + the C ABI), c
 (host-side mirror of the reference's class interface), synth.py (deterministic synthetic sequences), build.py.
 """
 from .capi import HYP_DTYPE, LsdHipError  # noqa: F401
-from .slam import IDENTITY, Context, DepthMap, Frame, SE3Tracker, SlamLoop, TrackingReference  # noqa: F401
+from .slam import IDENTITY, Context, DepthMap, Frame, SE3Tracker, Sim3Tracker, SlamLoop, TrackingReference  # noqa: F401

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblsdhip.so")
-SOURCES = ["host_math.cpp", "frame.hip", "tracker.hip", "depthmap.hip"]
+SOURCES = ["host_math.cpp", "frame.hip", "tracker.hip", "depthmap.hip", "sim3.hip"]
 # -disable-promote-alloca-to-lds: a private array the optimiser cannot split must show up as scratch (and fail the
 # guard below) instead of silently moving to LDS, where indexing it by thread costs a read of the AQL dispatch packet
 # in host memory (~20 us per launch, measured — profiles/r01_notes.md).

@@ -38,6 +38,20 @@ class ResidualRecord(C.Structure):
                 ("lsError", C.c_float), ("num_constraints", C.c_double)]
 
 
+class Sim3Result(C.Structure):
+    _fields_ = [("frameToReference", C.c_double * 8), ("lastResidual", C.c_float), ("lastDepthResidual", C.c_float),
+                ("lastPhotometricResidual", C.c_float), ("pointUsage", C.c_float), ("affineEstimation_a", C.c_float),
+                ("affineEstimation_b", C.c_float), ("diverged", C.c_int), ("numEvaluations", C.c_int),
+                ("lastSim3Hessian", C.c_float * 49)]
+
+
+class Sim3EvalRecord(C.Structure):
+    _fields_ = [("warped_size", C.c_int), ("pointUsage", C.c_float), ("affine_a_lastIt", C.c_float), ("affine_b_lastIt", C.c_float),
+                ("sumResD", C.c_float), ("sumResP", C.c_float), ("numTermsD", C.c_int), ("numTermsP", C.c_int),
+                ("meanD", C.c_float), ("meanP", C.c_float), ("mean", C.c_float), ("A", C.c_float * 49), ("b", C.c_float * 7),
+                ("num_constraints", C.c_double)]
+
+
 # every symbol declared in include/lsdhip.h: name -> (restype, argtypes)
 def _signatures():
     vp, i, f = C.c_void_p, C.c_int, C.c_float
@@ -78,6 +92,11 @@ def _signatures():
         "lsdhip_tracker_track_permaref": (i, [vp, vp, vp, i, vp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_track_permaref_batch": (i, [vp, i, vp, vp, vp, pvp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_check_overlap": (i, [vp, vp, i, vp, C.POINTER(C.c_float)]),
+        "lsdhip_sim3tracker_create": (i, [vp, pvp]),
+        "lsdhip_sim3tracker_destroy": (None, [vp]),
+        "lsdhip_sim3tracker_set_max_its": (i, [vp, vp]),
+        "lsdhip_sim3tracker_track": (i, [vp, vp, vp, vp, i, i, C.POINTER(Sim3Result)]),
+        "lsdhip_sim3tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(Sim3EvalRecord)]),
         "lsdhip_depth_create": (i, [vp, pvp]),
         "lsdhip_depth_destroy": (None, [vp]),
         "lsdhip_depth_is_valid": (i, [vp]),

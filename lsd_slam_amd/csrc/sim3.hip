@@ -1,0 +1,620 @@
+// Sim3Tracker on the device.  gfx950 only.
+//
+// Reference behaviour restated (C/ = lsd_slam_core/src/):
+//   Sim3Tracker::calcSim3Buffers                 C/Tracking/Sim3Tracker.cpp:414-607
+//   Sim3Tracker::calcSim3WeightsAndResidualSSE   :611-736   (_mm_rcp_ps -> IEEE 1/x)
+//   Sim3Tracker::calcSim3LGSSSE                  :858-983 + LGS4 / LGS6 / LGS7  C/Tracking/LGSX.h:45-176, :184-402, :411-443
+//   Sim3Tracker::trackFrameSim3                  :149-378
+//
+// One evaluation = k_sim3_eval (buffers + weights + both least-squares systems fused, one reference pixel per lane,
+// 54 sums reduced lane -> LDS -> one row per tile) + k_sim3_finalize (fixed-order row sums, SSE tail drop) -> pinned host
+// record.  The Levenberg-Marquardt loop itself runs on the host in the reference's precision (7x7 float LDL^T, Sim3 exp /
+// composition in double): this tracker serves the constraint search, where a ~30 us round trip per evaluation does not
+// matter; the pose-critical SE3 tracker (tracker.hip) keeps its loop on the device.
+//
+// Quirks kept: the SSE loops ignore the last size % 4 in-image points (x-outer / y-inner order) for the residual sums and
+// both systems; LGS6::updateSSE counts 6 and LGS4::updateSSE 4 constraints per group of four points.
+#include "lsdhip_internal.hpp"
+
+#define S3_BLOCK 256
+enum {
+  S3_M = 0, S3_USAGE, S3_SXX, S3_SYY, S3_SX, S3_SY, S3_SW, S3_NREF,
+  S3_SUMRESP, S3_SUMRESD, S3_NUMD,          // first tail-corrected column
+  S3_A6,                                    // 21 + 6 + 1
+  S3_A4 = S3_A6 + 28,                       // 10 + 4 + 1
+  S3_END = S3_A4 + 15
+};
+#define S3_TAIL0 S3_SUMRESP
+#define S3_NTAIL (S3_END - S3_TAIL0)        // 46 contributions per point
+static_assert(S3_END == 54 && S3_NTAIL == 46, "layout");
+
+struct Sim3Job {
+  const float* kf_idepth; const float* kf_idepthVar; const float* kf_image; const float4* kf_grad;
+  const float4* fr_grad; const float* fr_idepth; const float* fr_idepthVar;
+  int w, h, nblocks;
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+  float R[9], t[3];                         // rxso3().matrix() (scale * rotation) and translation, cast to float
+  float xRoll0, xRoll1, yRoll0, yRoll1;     // in-plane rotation of the reference gradients (ESM, Sim3Tracker.cpp:455-464)
+  float aff_a, aff_b, cameraPixelNoise2, var_weight, huber_d;
+  float* rows;                              // [nblocks][64] partial sums
+  int4* topkey;                             // [nblocks] three largest order keys of in-image points
+  float* topval;                            // [nblocks][3][48] their tail contributions
+  float* record;                            // pinned host: S3_END totals (tail-corrected)
+};
+
+__global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Job a) {
+  __shared__ float s_red[S3_END * (S3_BLOCK + 1) + 8];
+  __shared__ float s_sum[4][64];
+  __shared__ int s_max;
+  __shared__ int s_top[3];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * S3_BLOCK + tid;
+  float acc[S3_END];
+#pragma unroll
+  for (int k = 0; k < S3_END; k++) acc[k] = 0.f;
+  int key = -1;
+  const int x = i % a.w, y = i / a.w;
+  if (i < a.w * a.h && x >= 1 && x < a.w - 1 && y >= 1 && y < a.h - 1) {
+    const float var = a.kf_idepthVar[i];
+    const float id = a.kf_idepth[i];
+    if (!(var <= 0 || id == 0)) {
+      // TrackingReference::makePointCloud (TrackingReference.cpp:128-138)
+      const float inv = 1.0f / id;
+      const float px = inv * (a.fxi * x + a.cxi), py = inv * (a.fyi * y + a.cyi), pz = inv * 1.0f;
+      const float I_ref = a.kf_image[i];
+      const float4 gref = a.kf_grad[i];
+      acc[S3_NREF] = 1.f;
+      const float Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
+      const float Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
+      const float Wz = ((a.R[6] * px + a.R[7] * py) + a.R[8] * pz) + a.t[2];
+      const float u_new = (Wx / Wz) * a.fx + a.cx;
+      const float v_new = (Wy / Wz) * a.fy + a.cy;
+      if (u_new > 1 && v_new > 1 && u_new < a.w - 2 && v_new < a.h - 2) {
+        key = x * a.h + y;
+        // getInterpolatedElement43
+        const int ix = (int)u_new, iy = (int)v_new;
+        const float dx = u_new - ix, dy = v_new - iy, dxdy = dx * dy;
+        const float4* bp = a.fr_grad + ix + iy * a.w;
+        const float4 t00 = bp[0], t10 = bp[1], t01 = bp[a.w], t11 = bp[1 + a.w];
+        const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+        const float rx = w11 * t11.x + w01 * t01.x + w10 * t10.x + w00 * t00.x;
+        const float ry = w11 * t11.y + w01 * t01.y + w10 * t10.y + w00 * t00.y;
+        const float rz = w11 * t11.z + w01 * t01.z + w10 * t10.z + w00 * t00.z;
+        // ESM gradients (USE_ESM_TRACKING == 1)
+        const float rotatedGradX = a.xRoll0 * gref.x + a.xRoll1 * gref.y;
+        const float rotatedGradY = a.yRoll0 * gref.x + a.yRoll1 * gref.y;
+        const float gx = a.fx * 0.5f * (rx + rotatedGradX);
+        const float gy = a.fy * 0.5f * (ry + rotatedGradY);
+        const float c1 = a.aff_a * I_ref + a.aff_b;
+        const float c2 = rz;
+        const float rp = c1 - c2;
+        const float hwgt = fabsf(rp) < 2.0f ? 1 : 2.0f / fabsf(rp);
+        acc[S3_M] = 1.f;
+        acc[S3_SXX] = c1 * c1 * hwgt; acc[S3_SYY] = c2 * c2 * hwgt; acc[S3_SX] = c1 * hwgt; acc[S3_SY] = c2 * hwgt; acc[S3_SW] = hwgt;
+        const int idx_rounded = (int)(u_new + 0.5f) + a.w * (int)(v_new + 0.5f);
+        const float var_frameDepth = a.fr_idepthVar[idx_rounded];
+        const float ref_idepth = 1.0f / Wz;
+        const float d = 1.0f / pz;
+        float rd = -1, sv = -1;
+        if (var_frameDepth > 0) { rd = ref_idepth - a.fr_idepth[idx_rounded]; sv = var_frameDepth; }
+        const float depthChange = pz / Wz;
+        acc[S3_USAGE] = depthChange < 1 ? depthChange : 1;
+
+        // calcSim3WeightsAndResidualSSE, operation order of the SSE path
+        const float pz2d = 1.0f / ((Wz * Wz) * d);
+        const float g0 = (Wz * a.t[0] - Wx * a.t[2]) * pz2d;
+        const float g1 = (Wz * a.t[1] - Wy * a.t[2]) * pz2d;
+        const float g2 = (Wz - a.t[2]) * pz2d;
+        const float drpdd = g0 * gx + g1 * gy;
+        const float s_ = a.var_weight * var;
+        const float w_p = 1.0f / (a.cameraPixelNoise2 + drpdd * (drpdd * s_));
+        const float w_d = 1.0f / (sv + g2 * (g2 * s_));
+        float wrp = rp * sqrtf(w_p);
+        wrp = fmaxf(wrp, 0.0f - wrp);
+        float wrd = rd * sqrtf(w_d);
+        wrd = fmaxf(wrd, 0.0f - wrd);
+        const bool depthValid = 0.0f < sv;
+        const float wabs = (depthValid ? wrd : 0.0f) + wrp;
+        const float wh = (wabs < a.huber_d) ? 1.0f : a.huber_d * (1.0f / wabs);
+        acc[S3_NUMD] = depthValid ? 1.f : 0.f;
+        acc[S3_SUMRESD] = depthValid ? wh * (wrd * wrd) : 0.f;
+        acc[S3_SUMRESP] = wh * (wrp * wrp);
+        const float wp = wh * w_p;
+        const float wd = depthValid ? wh * w_d : 0.f;
+
+        // calcSim3LGSSSE
+        const float z = 1.0f / Wz;
+        float J6[6], J4[4];
+        J4[3] = z;
+        J6[0] = z * gx;
+        J6[1] = z * gy;
+        J6[5] = ((Wx * gy) * z) - ((Wy * gx) * z);
+        const float z2 = z * z;
+        J4[0] = z2;
+        J4[1] = z2 * Wy;
+        J4[2] = 0.0f - (z2 * Wx);
+        const float val1 = (Wx * gx) * z2, val2 = (Wy * gy) * z2;
+        J6[2] = 0.0f - (val1 + val2);
+        J6[3] = 0.0f - ((val2 * Wy) + (gy + val1 * Wy));
+        J6[4] = (gx + val1 * Wx) + val2 * Wx;
+        int k = S3_A6;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const float Jw = J6[r] * wp;
+#pragma unroll
+          for (int c = r; c < 6; c++) acc[S3_A6 + (r * 6 - (r * (r - 1)) / 2 + (c - r))] = Jw * J6[c];
+        }
+        (void)k;
+        const float resw6 = rp * wp;
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[S3_A6 + 21 + r] = resw6 * J6[r];
+        acc[S3_A6 + 27] = resw6 * rp;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float Jw = J4[r] * wd;
+#pragma unroll
+          for (int c = r; c < 4; c++) acc[S3_A4 + (r * 4 - (r * (r - 1)) / 2 + (c - r))] = Jw * J4[c];
+        }
+        const float resw4 = rd * wd;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[S3_A4 + 10 + r] = resw4 * J4[r];
+        acc[S3_A4 + 14] = resw4 * rd;
+      }
+    }
+  }
+  // workgroup reduction through LDS (same scheme as k_track_step)
+  constexpr int RSLICE = 4, RRUN = 64;
+#pragma unroll
+  for (int k = 0; k < S3_END; k++) s_red[k * (S3_BLOCK + 1) + tid] = acc[k];
+  if (tid == 0) s_max = -1;
+  __syncthreads();
+  {
+    const int slice = tid >> 6, k = tid & 63;
+    if (k < S3_END) {
+      const float* row = s_red + k * (S3_BLOCK + 1) + slice * RRUN;
+      float v[RRUN];
+#pragma unroll
+      for (int j = 0; j < RRUN; j++) v[j] = row[j];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < RRUN; j++) s += v[j];
+      s_sum[slice][k] = s;
+    }
+  }
+  // top-3 order keys of the tile (one candidate per lane): three rounds of an LDS max
+  int rank = -1;
+  for (int r = 0; r < 3; r++) {
+    if (rank < 0 && key >= 0) atomicMax(&s_max, key);
+    __syncthreads();
+    const int m = s_max;
+    if (rank < 0 && key >= 0 && key == m) rank = r;
+    if (tid == 0) s_top[r] = m;
+    __syncthreads();
+    if (tid == 0) s_max = -1;
+    __syncthreads();
+  }
+  if (tid < 64) {
+    float s = 0.f;
+    if (tid < S3_END) s = ((s_sum[0][tid] + s_sum[1][tid]) + s_sum[2][tid]) + s_sum[3][tid];
+    a.rows[(size_t)blockIdx.x * 64 + tid] = s;
+  }
+  if (tid == 0) a.topkey[blockIdx.x] = make_int4(s_top[0], s_top[1], s_top[2], -1);
+  if (rank >= 0) {
+    float* dst = a.topval + ((size_t)blockIdx.x * 3 + rank) * 48;
+#pragma unroll
+    for (int k = 0; k < S3_NTAIL; k++) dst[k] = acc[S3_TAIL0 + k];
+  }
+}
+
+// fixed-order sum of the tile rows, global top-3 keys, SSE tail drop; result to the pinned record
+__global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Job a) {
+  __shared__ float s_part[4][64];
+  __shared__ float s_tot[64];
+  __shared__ int s_keys[3], s_src[3];
+  const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
+  {
+    // slice s sums rows [s R, s R + R) of column `col`, in row order
+    const int R = (a.nblocks + 3) / 4;
+    float s = 0.f;
+    for (int r = slice * R; r < (slice + 1) * R && r < a.nblocks; r++) s += a.rows[(size_t)r * 64 + col];
+    s_part[slice][col] = s;
+  }
+  if (tid == 0) {
+    // global top-3 of the tiles' top-3 lists (a few hundred candidates, once per evaluation)
+    int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
+    for (int r = 0; r < a.nblocks; r++) {
+      const int4 kv = a.topkey[r];
+      const int ks[3] = {kv.x, kv.y, kv.z};
+      for (int q = 0; q < 3; q++) {
+        const int k = ks[q], e = r * 3 + q;
+        if (k > k0) { k2 = k1; e2 = e1; k1 = k0; e1 = e0; k0 = k; e0 = e; }
+        else if (k > k1) { k2 = k1; e2 = e1; k1 = k; e1 = e; }
+        else if (k > k2) { k2 = k; e2 = e; }
+      }
+    }
+    s_keys[0] = k0; s_keys[1] = k1; s_keys[2] = k2;
+    s_src[0] = e0; s_src[1] = e1; s_src[2] = e2;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float s = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
+    s_tot[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float s = s_tot[tid];
+    const int M = (int)s_tot[S3_M];
+    int need = M & 3;
+    if (tid >= S3_TAIL0 && tid < S3_END)
+      for (int k = 0; k < need; k++)
+        if (s_keys[k] >= 0) s -= a.topval[(size_t)s_src[k] * 48 + (tid - S3_TAIL0)];
+    a.record[tid] = tid < S3_END ? s : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: Sim3 algebra (double, Sophus semantics), 7x7 LDL^T, the LM loop
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct Sim3H { lsdm::Quatd q; double t[3]; double s; };
+
+Sim3H sim3_identity() { Sim3H r; r.q = {1, 0, 0, 0}; r.t[0] = r.t[1] = r.t[2] = 0; r.s = 1; return r; }
+void qd_normalize(lsdm::Quatd& q) {
+  double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.w /= n; q.x /= n; q.y /= n; q.z /= n;
+}
+Sim3H sim3_inverse(const Sim3H& S) {   // sim3.hpp:169-173
+  Sim3H r;
+  r.q = lsdm::q_conj(S.q);
+  r.s = 1.0 / S.s;
+  double rt[3];
+  lsdm::q_rotate<lsdm::Quatd, double>(r.q, S.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = -(rt[i] * r.s);
+  return r;
+}
+Sim3H sim3_mul(const Sim3H& a, const Sim3H& b) {   // sim3.hpp:160-163
+  Sim3H r;
+  double rt[3];
+  lsdm::q_rotate<lsdm::Quatd, double>(a.q, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + a.s * rt[i];
+  r.q = lsdm::q_mul(a.q, b.q);
+  qd_normalize(r.q);
+  r.s = a.s * b.s;
+  return r;
+}
+Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-425, calcW sim3.hpp:608-650
+  const double eps = 1e-10;
+  const double ox = a[3], oy = a[4], oz = a[5], sigma = a[6];
+  const double scale = std::exp(sigma);
+  const double theta_sq = ox * ox + (oy * oy + oz * oz);
+  const double theta = std::sqrt(theta_sq);
+  const double half_theta = 0.5 * theta;
+  double imag, real;
+  if (theta < eps) {
+    const double theta_po4 = theta_sq * theta_sq;
+    imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+    real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
+  } else {
+    imag = std::sin(half_theta) / theta;
+    real = std::cos(half_theta);
+  }
+  Sim3H r;
+  r.q = {real, imag * ox, imag * oy, imag * oz};
+  qd_normalize(r.q);
+  r.s = scale;
+  const double Om[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+  double Om2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = Om[i * 3 + 0] * Om[0 * 3 + j];
+      acc += Om[i * 3 + 1] * Om[1 * 3 + j];
+      acc += Om[i * 3 + 2] * Om[2 * 3 + j];
+      Om2[i * 3 + j] = acc;
+    }
+  double A, B, C;
+  if (std::abs(sigma) < eps) {
+    C = 1.0;
+    if (std::abs(theta) < eps) { A = 0.5; B = 1.0 / 6.0; }
+    else { A = (1.0 - std::cos(theta)) / theta_sq; B = (theta - std::sin(theta)) / (theta_sq * theta); }
+  } else {
+    C = (scale - 1.0) / sigma;
+    if (std::abs(theta) < eps) {
+      const double sigma_sq = sigma * sigma;
+      A = ((sigma - 1.0) * scale + 1.0) / sigma_sq;
+      B = ((0.5 * sigma * sigma - sigma + 1.0) * scale) / (sigma_sq * sigma);
+    } else {
+      const double sa = scale * std::sin(theta), sb = scale * std::cos(theta), c = theta_sq + sigma * sigma;
+      A = (sa * sigma + (1.0 - sb) * theta) / (theta * c);
+      B = (C - ((sb - 1.0) * sigma + sa * theta) / c) * 1.0 / theta_sq;
+    }
+  }
+  for (int i = 0; i < 3; i++) {
+    double acc = 0;
+    for (int j = 0; j < 3; j++) {
+      const double W = A * Om[i * 3 + j] + B * Om2[i * 3 + j] + C * (i == j ? 1.0 : 0.0);
+      acc = j == 0 ? W * a[j] : acc + W * a[j];
+    }
+    r.t[i] = acc;
+  }
+  return r;
+}
+// 7x7 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics), as lsdm::ldlt6_solve
+void ldlt7_solve(const float Ain[49], const float bin[7], float x[7]) {
+  const int n = 7;
+  float M[7][7];
+  int p[7];
+  for (int i = 0; i < n; i++) { p[i] = i; for (int j = 0; j < n; j++) M[i][j] = Ain[i * n + j]; }
+  for (int k = 0; k < n; k++) {
+    int piv = k;
+    float big = fabsf(M[k][k]);
+    for (int i = k + 1; i < n; i++) if (fabsf(M[i][i]) > big) { big = fabsf(M[i][i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < n; j++) { float t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+      for (int i = 0; i < n; i++) { float t = M[i][k]; M[i][k] = M[i][piv]; M[i][piv] = t; }
+      int tp = p[k]; p[k] = p[piv]; p[piv] = tp;
+    }
+    float d = M[k][k];
+    for (int j = 0; j < k; j++) d -= M[k][j] * M[k][j] * M[j][j];
+    M[k][k] = d;
+    for (int i = k + 1; i < n; i++) {
+      float v = M[i][k];
+      for (int j = 0; j < k; j++) v -= M[i][j] * M[k][j] * M[j][j];
+      M[i][k] = d != 0.0f ? v / d : 0.0f;
+    }
+  }
+  float y[7];
+  for (int i = 0; i < n; i++) y[i] = bin[p[i]];
+  for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) y[i] -= M[i][j] * y[j];
+  for (int i = 0; i < n; i++) y[i] = M[i][i] != 0.0f ? y[i] / M[i][i] : 0.0f;
+  for (int i = n - 1; i >= 0; i--) for (int j = i + 1; j < n; j++) y[i] -= M[j][i] * y[j];
+  for (int i = 0; i < n; i++) x[p[i]] = y[i];
+}
+
+struct Sim3Res { float sumResD, sumResP; int numTermsD, numTermsP; float meanD, meanP, mean; };
+struct Eval {
+  int M;
+  float pointUsage, aff_a_lastIt, aff_b_lastIt;
+  Sim3Res res;
+  float A[49], b[7];
+  size_t num_constraints;
+};
+}  // namespace
+
+struct lsdhip_sim3tracker {
+  lsdhip_ctx* ctx = nullptr;
+  int maxItsPerLvl[LSD_LEVELS] = {5, 20, 50, 100, 100};
+  float lambdaSuccessFac = 0.5f, lambdaFailFac = 2.0f, lambdaInitial = 0, stepSizeMin = 1e-8f, convergenceEps = 0.999f;
+  float huber_d = 3, var_weight = 1.0f;
+  float affineEstimation_a = 1, affineEstimation_b = 0;
+  float* d_rows = nullptr;
+  int4* d_topkey = nullptr;
+  float* d_topval = nullptr;
+  float* h_record = nullptr;   // pinned, device-mapped
+  int max_blocks = 0;
+};
+
+extern "C" int lsdhip_sim3tracker_create(lsdhip_ctx* c, lsdhip_sim3tracker** out) {
+  if (!c || !out) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  lsdhip_sim3tracker* t = new lsdhip_sim3tracker();
+  t->ctx = c;
+  t->max_blocks = (c->w * c->h + S3_BLOCK - 1) / S3_BLOCK;
+  HIPCHK(hipMalloc((void**)&t->d_rows, (size_t)t->max_blocks * 64 * 4));
+  HIPCHK(hipMalloc((void**)&t->d_topkey, (size_t)t->max_blocks * 16));
+  HIPCHK(hipMalloc((void**)&t->d_topval, (size_t)t->max_blocks * 3 * 48 * 4));
+  HIPCHK(hipMemsetAsync(t->d_topval, 0, (size_t)t->max_blocks * 3 * 48 * 4, c->stream));
+  HIPCHK(hipHostMalloc((void**)&t->h_record, 64 * 4, hipHostMallocMapped));
+  *out = t;
+  return LSDHIP_OK;
+}
+extern "C" void lsdhip_sim3tracker_destroy(lsdhip_sim3tracker* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->ctx->stream);
+  (void)hipFree(t->d_rows); (void)hipFree(t->d_topkey); (void)hipFree(t->d_topval); (void)hipHostFree(t->h_record);
+  delete t;
+}
+extern "C" int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int its[LSD_LEVELS]) {
+  if (!t || !its) return LSDHIP_E_ARG;
+  for (int l = 0; l < LSD_LEVELS; l++) t->maxItsPerLvl[l] = its[l];
+  return LSDHIP_OK;
+}
+
+// calcSim3Buffers + calcSim3WeightsAndResidualSSE + calcSim3LGSSSE at one transformation
+static int sim3_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const Sim3H& referenceToFrame, int level, Eval* ev) {
+  lsdhip_ctx* c = t->ctx;
+  Sim3Job a;
+  a.kf_idepth = kf->d_idepth[level]; a.kf_idepthVar = kf->d_idepthVar[level]; a.kf_image = kf->d_image[level]; a.kf_grad = kf->d_grad[level];
+  a.fr_grad = frame->d_grad[level]; a.fr_idepth = frame->d_idepth[level]; a.fr_idepthVar = frame->d_idepthVar[level];
+  a.w = c->wl[level]; a.h = c->hl[level];
+  a.nblocks = (a.w * a.h + S3_BLOCK - 1) / S3_BLOCK;
+  const LevelIntr& in = c->intr[level];
+  a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
+  double Rd[9];
+  lsdm::quatd_to_rot(referenceToFrame.q, Rd);
+  float Ru[9];
+  for (int i = 0; i < 9; i++) { a.R[i] = (float)(referenceToFrame.s * Rd[i]); Ru[i] = (float)Rd[i]; }
+  for (int i = 0; i < 3; i++) a.t[i] = (float)referenceToFrame.t[i];
+  {
+    // Quaternionf::setFromTwoVectors(R * (0,0,-1), (0,0,-1)).toRotationMatrix() * R   (Sim3Tracker.cpp:455-464)
+    const float rf[3] = {Ru[0] * 0.f + Ru[1] * 0.f + Ru[2] * -1.f, Ru[3] * 0.f + Ru[4] * 0.f + Ru[5] * -1.f, Ru[6] * 0.f + Ru[7] * 0.f + Ru[8] * -1.f};
+    const float n0 = sqrtf(rf[0] * rf[0] + (rf[1] * rf[1] + rf[2] * rf[2]));
+    const float v0[3] = {rf[0] / n0, rf[1] / n0, rf[2] / n0};
+    const float v1[3] = {0, 0, -1};
+    const float cdot = v1[0] * v0[0] + (v1[1] * v0[1] + v1[2] * v0[2]);
+    lsdm::Quatf q;
+    if (cdot < -1.0f + 1e-5f) {
+      q = {0, 1, 0, 0};
+    } else {
+      const float ax = v0[1] * v1[2] - v0[2] * v1[1], ay = v0[2] * v1[0] - v0[0] * v1[2], az = v0[0] * v1[1] - v0[1] * v1[0];
+      const float s = sqrtf((1.0f + cdot) * 2.0f);
+      const float invs = 1.0f / s;
+      q = {s * 0.5f, ax * invs, ay * invs, az * invs};
+    }
+    float Q[9];
+    lsdm::quatf_to_rot(q, Q);
+    float roll[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        float acc = Q[i * 3 + 0] * Ru[0 * 3 + j];
+        acc += Q[i * 3 + 1] * Ru[1 * 3 + j];
+        acc += Q[i * 3 + 2] * Ru[2 * 3 + j];
+        roll[i * 3 + j] = acc;
+      }
+    a.xRoll0 = roll[0]; a.xRoll1 = roll[1]; a.yRoll0 = roll[3]; a.yRoll1 = roll[4];
+  }
+  a.aff_a = t->affineEstimation_a; a.aff_b = t->affineEstimation_b;
+  a.cameraPixelNoise2 = c->params.cameraPixelNoise2; a.var_weight = t->var_weight; a.huber_d = t->huber_d;
+  a.rows = t->d_rows; a.topkey = t->d_topkey; a.topval = t->d_topval;
+  HIPCHK(hipHostGetDevicePointer((void**)&a.record, t->h_record, 0));
+  hipLaunchKernelGGL(k_sim3_eval, dim3(a.nblocks), dim3(S3_BLOCK), 0, c->stream, a);
+  hipLaunchKernelGGL(k_sim3_finalize, dim3(1), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const float* r = t->h_record;
+  ev->M = (int)r[S3_M];
+  ev->pointUsage = r[S3_USAGE] / r[S3_NREF];
+  {
+    const float sxx = r[S3_SXX], syy = r[S3_SYY], sx = r[S3_SX], sy = r[S3_SY], sw = r[S3_SW];
+    ev->aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
+    ev->aff_b_lastIt = (sy - ev->aff_a_lastIt * sx) / sw;
+  }
+  Sim3Res& s = ev->res;
+  s.sumResP = r[S3_SUMRESP];
+  s.numTermsP = (ev->M >> 2) << 2;
+  s.sumResD = r[S3_SUMRESD];
+  s.numTermsD = (int)r[S3_NUMD];
+  s.mean = (s.sumResD + s.sumResP) / (s.numTermsD + s.numTermsP);
+  s.meanD = s.sumResD / s.numTermsD;
+  s.meanP = s.sumResP / s.numTermsP;
+  // LGS6 / LGS4 finishNoDivide + LGS7::initializeFrom (LGSX.h:424-442)
+  memset(ev->A, 0, sizeof(ev->A));
+  memset(ev->b, 0, sizeof(ev->b));
+  int k = S3_A6;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++, k++) { const float v = 0.0f + r[k]; ev->A[i * 7 + j] = v; ev->A[j * 7 + i] = v; }
+  for (int i = 0; i < 6; i++) ev->b[i] = 0.0f - r[S3_A6 + 21 + i];
+  float A4[16], b4[4];
+  k = S3_A4;
+  for (int i = 0; i < 4; i++)
+    for (int j = i; j < 4; j++, k++) { const float v = 0.0f + r[k]; A4[i * 4 + j] = v; A4[j * 4 + i] = v; }
+  for (int i = 0; i < 4; i++) b4[i] = 0.0f - r[S3_A4 + 10 + i];
+  const int remap[4] = {2, 3, 4, 6};
+  for (int i = 0; i < 4; i++) {
+    ev->b[remap[i]] += b4[i];
+    for (int j = 0; j < 4; j++) ev->A[remap[i] * 7 + remap[j]] += A4[i * 4 + j];
+  }
+  ev->num_constraints = (size_t)6 * (size_t)(ev->M >> 2) + (size_t)4 * (size_t)(ev->M >> 2);
+  return LSDHIP_OK;
+}
+
+static Sim3H sim3_in(const double p[8]) { Sim3H T; T.q = {p[0], p[1], p[2], p[3]}; T.t[0] = p[4]; T.t[1] = p[5]; T.t[2] = p[6]; T.s = p[7]; return T; }
+static void sim3_out(const Sim3H& T, double p[8]) { p[0] = T.q.w; p[1] = T.q.x; p[2] = T.q.y; p[3] = T.q.z; p[4] = T.t[0]; p[5] = T.t[1]; p[6] = T.t[2]; p[7] = T.s; }
+
+extern "C" int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double refToFrame[8], int level,
+                                           float aff_a, float aff_b, lsdhip_sim3_eval_record* out) {
+  if (!t || !kf || !frame || !refToFrame || !out || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
+  if (!kf->hasIDepth || !frame->hasIDepth) { lsd_set_error("Sim3 tracking needs inverse depth on both frames"); return LSDHIP_E_STATE; }
+  HIPCHK(hipSetDevice(t->ctx->device));
+  t->affineEstimation_a = aff_a; t->affineEstimation_b = aff_b;
+  Eval ev;
+  int rc = sim3_evaluate(t, kf, frame, sim3_in(refToFrame), level, &ev);
+  if (rc) return rc;
+  out->warped_size = ev.M; out->pointUsage = ev.pointUsage; out->affine_a_lastIt = ev.aff_a_lastIt; out->affine_b_lastIt = ev.aff_b_lastIt;
+  out->sumResD = ev.res.sumResD; out->sumResP = ev.res.sumResP; out->numTermsD = ev.res.numTermsD; out->numTermsP = ev.res.numTermsP;
+  out->meanD = ev.res.meanD; out->meanP = ev.res.meanP; out->mean = ev.res.mean;
+  memcpy(out->A, ev.A, sizeof(ev.A)); memcpy(out->b, ev.b, sizeof(ev.b));
+  out->num_constraints = (double)ev.num_constraints;
+  return LSDHIP_OK;
+}
+
+// Sim3Tracker::trackFrameSim3 (Sim3Tracker.cpp:149-378)
+extern "C" int lsdhip_sim3tracker_track(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double init[8], int startLevel,
+                                        int finalLevel, lsdhip_sim3_result* out) {
+  if (!t || !kf || !frame || !init || !out || startLevel < finalLevel || finalLevel < 0 || startLevel >= LSD_LEVELS) return LSDHIP_E_ARG;
+  if (!kf->hasIDepth || !frame->hasIDepth) { lsd_set_error("Sim3 tracking needs inverse depth on both frames"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = t->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  memset(out, 0, sizeof(*out));
+  out->frameToReference[0] = 1; out->frameToReference[7] = 1;   // Sim3() on failure
+  t->affineEstimation_a = 1; t->affineEstimation_b = 0;
+  const bool useAffine = c->params.useAffineLightningEstimation != 0;
+  Sim3H referenceToFrame = sim3_inverse(sim3_in(init));
+  Eval cur;
+  memset(&cur, 0, sizeof(cur));
+  Sim3Res finalResidual;
+  memset(&finalResidual, 0, sizeof(finalResidual));
+  bool warp_update_up_to_date = false;
+  int numEvaluations = 0;
+  auto diverge = [&]() { out->diverged = 1; out->numEvaluations = numEvaluations; return LSDHIP_DIVERGED; };
+  for (int lvl = startLevel; lvl >= finalLevel; lvl--) {
+    if (t->maxItsPerLvl[lvl] == 0) continue;
+    int rc = sim3_evaluate(t, kf, frame, referenceToFrame, lvl, &cur);
+    if (rc) return rc;
+    numEvaluations++;
+    if (cur.M < 0.5 * 0.01 * (c->w >> lvl) * (c->h >> lvl) || cur.M < 10) return diverge();
+    Sim3Res lastErr = cur.res;
+    if (useAffine) { t->affineEstimation_a = cur.aff_a_lastIt; t->affineEstimation_b = cur.aff_b_lastIt; }
+    float LM_lambda = t->lambdaInitial;
+    warp_update_up_to_date = false;
+    for (int iteration = 0; iteration < t->maxItsPerLvl[lvl]; iteration++) {
+      // the system of the last accepted evaluation is what calcSim3LGS would build here
+      warp_update_up_to_date = true;
+      int incTry = 0;
+      while (true) {
+        float b[7], A[49], inc[7];
+        const float nc = (float)cur.num_constraints;
+        for (int i = 0; i < 7; i++) b[i] = -cur.b[i] / nc;
+        for (int i = 0; i < 49; i++) A[i] = cur.A[i] / nc;
+        for (int i = 0; i < 7; i++) A[i * 7 + i] *= 1 + LM_lambda;
+        ldlt7_solve(A, b, inc);
+        incTry++;
+        float absInc = 0;
+        for (int i = 0; i < 7; i++) absInc += inc[i] * inc[i];
+        if (!(absInc >= 0 && absInc < 1)) { out->numEvaluations = numEvaluations; return LSDHIP_DIVERGED; }   // returns Sim3(), Hessian zero
+        double incd[7];
+        for (int i = 0; i < 7; i++) incd[i] = (double)inc[i];
+        const Sim3H new_referenceToFrame = sim3_mul(sim3_exp(incd), referenceToFrame);
+        Eval nev;
+        rc = sim3_evaluate(t, kf, frame, new_referenceToFrame, lvl, &nev);
+        if (rc) return rc;
+        numEvaluations++;
+        if (nev.M < 0.5 * 0.01 * (c->w >> lvl) * (c->h >> lvl) || nev.M < 10) return diverge();
+        if (nev.res.mean < lastErr.mean) {
+          referenceToFrame = new_referenceToFrame;
+          cur = nev;
+          warp_update_up_to_date = false;
+          if (useAffine) { t->affineEstimation_a = nev.aff_a_lastIt; t->affineEstimation_b = nev.aff_b_lastIt; }
+          if (nev.res.mean / lastErr.mean > t->convergenceEps) iteration = t->maxItsPerLvl[lvl];
+          finalResidual = lastErr = nev.res;
+          if (LM_lambda <= 0.2) LM_lambda = 0;
+          else LM_lambda *= t->lambdaSuccessFac;
+          break;
+        } else {
+          if (!(absInc > t->stepSizeMin)) { iteration = t->maxItsPerLvl[lvl]; break; }
+          if (LM_lambda == 0) LM_lambda = 0.2;
+          else LM_lambda *= std::pow(t->lambdaFailFac, incTry);
+        }
+      }
+    }
+  }
+  // `cur` always holds the system at the accepted transformation (every evaluation builds it), which is what the
+  // reference recomputes when warp_update_up_to_date is false (Sim3Tracker.cpp:354-360) — except that the final level may
+  // differ from the level of the last evaluation when the finer levels have zero iterations
+  if (!warp_update_up_to_date) {
+    int rc = sim3_evaluate(t, kf, frame, referenceToFrame, finalLevel, &cur);
+    if (rc) return rc;
+    numEvaluations++;
+    finalResidual = cur.res;
+  }
+  memcpy(out->lastSim3Hessian, cur.A, sizeof(cur.A));
+  out->numEvaluations = numEvaluations;
+  out->pointUsage = cur.pointUsage;
+  out->affineEstimation_a = t->affineEstimation_a; out->affineEstimation_b = t->affineEstimation_b;
+  if (referenceToFrame.s <= 0) return diverge();
+  out->lastResidual = finalResidual.mean;
+  out->lastDepthResidual = finalResidual.meanD;
+  out->lastPhotometricResidual = finalResidual.meanP;
+  sim3_out(sim3_inverse(referenceToFrame), out->frameToReference);
+  return LSDHIP_OK;
+}

@@ -294,6 +294,43 @@ class SE3Tracker:
         return u.value
 
 
+class Sim3Tracker:
+    """Sim3Tracker (C/Tracking/Sim3Tracker.h:71-187).  Sim3 = (qw,qx,qy,qz,tx,ty,tz,scale)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = ctx.L
+        h_ = C.c_void_p()
+        check(self.L.lsdhip_sim3tracker_create(ctx.h_, C.byref(h_)))
+        self.h_ = h_
+        self.diverged = False
+        self.last = None
+
+    def __del__(self):
+        if getattr(self, "h_", None):
+            self.L.lsdhip_sim3tracker_destroy(self.h_)
+            self.h_ = None
+
+    def setMaxItsPerLvl(self, its):
+        a = np.ascontiguousarray(its, np.int32)
+        check(self.L.lsdhip_sim3tracker_set_max_its(self.h_, a.ctypes.data))
+
+    def trackFrameSim3(self, keyframe, frame, frameToReference_initialEstimate, startLevel, finalLevel):
+        """-> (frameToReference[8], result record); self.diverged mirrors the reference's flag"""
+        T = np.ascontiguousarray(frameToReference_initialEstimate, np.float64)
+        r = capi.Sim3Result()
+        check(self.L.lsdhip_sim3tracker_track(self.h_, keyframe.h_, frame.h_, T.ctypes.data, startLevel, finalLevel, C.byref(r)))
+        self.diverged = bool(r.diverged)
+        self.last = r
+        return np.array(list(r.frameToReference)), r
+
+    def evaluate(self, keyframe, frame, referenceToFrame, level, a=1.0, b=0.0):
+        T = np.ascontiguousarray(referenceToFrame, np.float64)
+        r = capi.Sim3EvalRecord()
+        check(self.L.lsdhip_sim3tracker_evaluate(self.h_, keyframe.h_, frame.h_, T.ctypes.data, level, a, b, C.byref(r)))
+        return r
+
+
 class DepthMap:
     STAGES = {"observe": 0, "fillholes": 1, "regularize": 2, "regularize_occ": 3, "propagate": 4, "fill_regularize": 5}
 
