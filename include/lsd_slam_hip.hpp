@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <map>
 #include <memory>
@@ -263,8 +264,10 @@ class SE3Tracker {
     double init[7];
     frameToReference_initialEstimate.to7(init);
     lsdhip_track_result r;
+    hookError_ = nullptr;
     check(lsdhip_tracker_track(h_, reference->keyframe->handle(), frame->handle(), init, &r), "lsdhip_tracker_track");
     publish(r);
+    if (hookError_) std::rethrow_exception(hookError_);
     return SE3::from7(r.frameToReference);
   }
   SE3 trackFrameOnPermaref(Frame* reference, Frame* frame, SE3 referenceToFrame) {
@@ -275,6 +278,13 @@ class SE3Tracker {
                                         reference->permaRefNumPts, frame->handle(), init, &r), "lsdhip_tracker_track_permaref");
     publish(r);
     return SE3::from7(r.frameToReference);
+  }
+  // Runs on the calling thread inside trackFrame once the job is queued on the device and before the host waits for it
+  // (lsdhip_tracker_set_enqueue_hook): queue independent work here, e.g. the next frame's upload and pyramids.
+  // Exceptions thrown by the hook surface from trackFrame after the tracking result has been collected.
+  void setEnqueueHook(std::function<void()> fn) {
+    hook_ = std::move(fn);
+    check(lsdhip_tracker_set_enqueue_hook(h_, hook_ ? &SE3Tracker::hookTrampoline : nullptr, this), "lsdhip_tracker_set_enqueue_hook");
   }
   float checkPermaRefOverlap(Frame* reference, SE3 referenceToFrame) {
     double init[7];
@@ -297,6 +307,12 @@ class SE3Tracker {
     diverged = r.diverged != 0; trackingWasGood = r.trackingWasGood != 0;
     numEvaluations = r.numEvaluations; numWarpUpdates = r.numWarpUpdates;
   }
+  static void hookTrampoline(void* self) {
+    SE3Tracker* t = static_cast<SE3Tracker*>(self);
+    try { if (t->hook_) t->hook_(); } catch (...) { t->hookError_ = std::current_exception(); }
+  }
+  std::function<void()> hook_;
+  std::exception_ptr hookError_;
   std::shared_ptr<Context> ctx_;
   lsdhip_tracker* h_ = nullptr;
 };
@@ -418,7 +434,14 @@ class SlamLoop {
     }
     reference.importFrame(keyframe.get());
     keyframe->clearDepthHasBeenUpdatedFlag();
+    tracker.setEnqueueHook([this]() {
+      if (!pendingNext_) return;
+      prefetched_ = makeFrame(frameId_ + 1, pendingNext_);
+      prefetchedSrc_ = pendingNext_;
+    });
   }
+  SlamLoop(const SlamLoop&) = delete;
+  SlamLoop& operator=(const SlamLoop&) = delete;
   // TrackableKeyFrameSearch::getRefFrameScore (GlobalMapping/TrackableKeyFrameSearch.h:75-79) with the default weights
   // KFDistWeight = 4, KFUsageWeight = 3 (util/settings.cpp:77-78)
   static float keyframeScore(float distanceSquared, float usage) {
@@ -428,16 +451,24 @@ class SlamLoop {
   std::function<void(Frame&, DepthMap&)> onKeyframeFinished;
   // track one frame, then one mapping iteration; returns frameToKeyframe.  Throws when tracking diverges.
   SE3 step(const unsigned char* image) { return step(image, [](double) {}); }
-  // same, reporting the wall-clock instant (seconds, steady clock) at which tracking ended and mapping began
+  // same, reporting the wall-clock instant (seconds, steady clock) at which tracking ended and mapping began.
+  // nextImage (optional): the image of the following step() call, if it is already available — its upload and pyramids
+  // are queued while the host waits for this frame's tracking result, so they fill the device's idle time of that round
+  // trip.  The bytes behind nextImage must stay unchanged until that following call (same pointer) has returned.
   template <typename F>
-  SE3 step(const unsigned char* image, F&& onTrackEnd) {
+  SE3 step(const unsigned char* image, F&& onTrackEnd, const unsigned char* nextImage = nullptr) {
     frameId_++;
-    std::shared_ptr<Frame> frame = makeFrame(frameId_, image);
+    std::shared_ptr<Frame> frame;
+    if (prefetched_ && prefetchedSrc_ == image) frame = std::move(prefetched_);
+    else frame = makeFrame(frameId_, image);
+    prefetched_.reset();
+    pendingNext_ = nextImage;
     if (keyframe->depthHasBeenUpdatedFlag()) {
       reference.importFrame(keyframe.get());
       keyframe->clearDepthHasBeenUpdatedFlag();
     }
     SE3 est = tracker.trackFrame(&reference, frame.get(), lastFrameToKF_);
+    pendingNext_ = nullptr;
     evaluations += tracker.numEvaluations;
     numTracked++;
     lastTrackEnd = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -491,6 +522,9 @@ class SlamLoop {
   bool onDevice_;
   int kfEvery_, sinceKF_ = 0, frameId_ = 0;
   SE3 lastFrameToKF_;
+  std::shared_ptr<Frame> prefetched_;
+  const unsigned char* prefetchedSrc_ = nullptr;
+  const unsigned char* pendingNext_ = nullptr;
 };
 
 }  // namespace lsd_slam_hip

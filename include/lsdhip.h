@@ -139,6 +139,12 @@ typedef struct lsdhip_residual_record {
 int lsdhip_tracker_create(lsdhip_ctx* ctx, lsdhip_tracker** out);
 void lsdhip_tracker_destroy(lsdhip_tracker* t);
 int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int maxItsPerLvl[LSDHIP_PYRAMID_LEVELS]);
+/* Host-side pipelining: `fn(user)` is called on the calling thread by lsdhip_tracker_track once the job's launches are
+ * queued and before the host waits for the result — the place to queue independent work on the same context (the next
+ * image's upload and pyramids, what the reference's image-loader thread does ahead of the tracking thread,
+ * C/LiveSLAMWrapper.cpp:82-118).  fn = NULL removes the hook.  The hook must not call into this tracker. */
+typedef void (*lsdhip_enqueue_hook)(void* user);
+int lsdhip_tracker_set_enqueue_hook(lsdhip_tracker* t, lsdhip_enqueue_hook fn, void* user);
 /* SE3Tracker::trackFrame(TrackingReference*, Frame*, const SE3& frameToReference_initialEstimate)
  * (SE3Tracker.cpp:280-486).  `keyframe` plays the role of reference->keyframe (its idepth planes must be set).
  * Side effects as in the reference: frame mask refPixelWasGood, frame pose / trackingParent /

@@ -86,6 +86,7 @@ def _signatures():
         "lsdhip_tracker_create": (i, [vp, pvp]),
         "lsdhip_tracker_destroy": (None, [vp]),
         "lsdhip_tracker_set_max_its": (i, [vp, vp]),
+        "lsdhip_tracker_set_enqueue_hook": (i, [vp, vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_track_batch": (i, [vp, i, pvp, pvp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(ResidualRecord)]),

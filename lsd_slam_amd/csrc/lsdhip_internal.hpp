@@ -185,6 +185,8 @@ struct lsdhip_tracker {
   float affineEstimation_a = 1, affineEstimation_b = 0, affineEstimation_a_lastIt = 1, affineEstimation_b_lastIt = 0;
   bool diverged = false, trackingWasGood = false;
   int numEvaluations = 0, numWarpUpdates = 0;
+  void (*enqueueHook)(void*) = nullptr;   // lsdhip_tracker_set_enqueue_hook
+  void* enqueueHookUser = nullptr;
   bool spinWait = true;           // poll the pinned summary instead of hipStreamSynchronize (LSDHIP_SPIN=0 disables)
   bool hostLM = false;            // debugging: run the LM control loop on the host, one evaluation per round trip
   // device scratch

@@ -1037,6 +1037,12 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   if (t->d_pts) (void)hipFree(t->d_pts);
   delete t;
 }
+extern "C" int lsdhip_tracker_set_enqueue_hook(lsdhip_tracker* t, lsdhip_enqueue_hook fn, void* user) {
+  if (!t) return LSDHIP_E_ARG;
+  t->enqueueHook = fn;
+  t->enqueueHookUser = user;
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int its[LSD_LEVELS]) {
   if (!t || !its) return LSDHIP_E_ARG;
   for (int l = 0; l < LSD_LEVELS; l++) t->maxItsPerLvl[l] = its[l];
@@ -1267,6 +1273,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     int rc = launch_steps(t, job, budget, &parity, &first);
     if (rc) return rc;
     if (c->prof_on) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
+    if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) t->enqueueHook(t->enqueueHookUser);
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
     // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.

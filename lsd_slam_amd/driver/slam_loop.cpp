@@ -1,6 +1,7 @@
 // liblsdhip_driver.so — the C++ host side of the sequence loop (include/lsd_slam_hip.hpp) behind a C interface.
 // Plain host C++ (g++): everything that touches pixels is a liblsdhip.so call.
 #include <chrono>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/lsd_slam_hip.hpp"
@@ -48,12 +49,13 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
   if (!l || !images || n < 0) return LSDHIP_E_ARG;
   try {
     int done = 0;
+    static const bool prefetch = !std::getenv("LSDHIP_NO_PREFETCH");   // developer switch for A/B timing
     const double t0 = now_s();
     for (int i = 0; i < n; i++) {
       SlamLoop& L = *l->loop;
       const long upd0 = L.numUpdates;
       const long ev0 = L.evaluations;
-      SE3 est = L.step(images[i]);
+      SE3 est = L.step(images[i], [](double) {}, (prefetch && i + 1 < n) ? images[i + 1] : nullptr);
       l->st.frames++;
       l->st.updates += L.numUpdates - upd0;
       l->st.evaluations += L.evaluations - ev0;
