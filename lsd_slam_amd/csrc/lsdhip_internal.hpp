@@ -58,6 +58,7 @@ struct TrackLevel {
   int w, h;
   int nblocks;               // workgroups (tiles) that have work at this level
   int singlePass;            // nblocks * workgroup size >= points: every lane evaluates at most one point
+  int tilePx;                // > 0: batch throughput mode, one strip of tilePx pixels per workgroup (compacted in LDS)
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
   float lambdaInitial, stepSizeMin, convergenceEps;
   int maxIts;
@@ -195,6 +196,7 @@ struct lsdhip_tracker {
   TrackState* d_state = nullptr;  // [2], double-buffered by launch parity
   int block = 256;                // workgroup size of k_track_step (LSDHIP_TRACK_BLOCK)
   int grid_cap = 304;             // most workgroups one evaluation uses (LSDHIP_TRACK_CAP); larger levels grid-stride
+  int batch_jobs = 0;             // > 1 while the jobs of a batch are being described
   int cap_override = 0;           // batch tracking: per-job workgroup cap while the jobs of a batch are being described
   int recent[4] = {0, 0, 0, 0};   // evaluations of the last jobs: size the launch budget of the next one
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped

@@ -571,6 +571,30 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
   }
 }
 
+// one in-image point's contribution to the running sums (K1 statistics, K2 weighted error, K3 normal equations)
+__device__ __forceinline__ void accumulate_point(const PointOut& o, float (&acc)[RS_END]) {
+  acc[RS_M] += 1.f;
+  acc[RS_SXX] += o.c1 * o.c1 * o.hw;
+  acc[RS_SYY] += o.c2 * o.c2 * o.hw;
+  acc[RS_SX] += o.c1 * o.hw;
+  acc[RS_SY] += o.c2 * o.hw;
+  acc[RS_SW] += o.hw;
+  if (o.good) { acc[RS_GOOD] += 1.f; acc[RS_SUMRES2] += o.res * o.res; acc[RS_SUMSIGNED] += o.res; }
+  else acc[RS_BAD] += 1.f;
+  acc[RS_USAGE] += o.usage;
+  acc[RS_WERR] += o.werr;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    float Jw = o.J[r] * o.w;
+#pragma unroll
+    for (int c = r; c < 6; c++) acc[tri_index(r, c)] += Jw * o.J[c];
+  }
+  float resw = o.res * o.w;
+#pragma unroll
+  for (int r = 0; r < 6; r++) acc[RS_B0 + r] += resw * o.J[r];
+  acc[RS_ERR] += resw * o.res;
+}
+
 __device__ __forceinline__ void make_ctx_dev(const TrackJob& jobr, const TrackState& S, int level, EvalCtx& a) {
   const TrackJob* job = &jobr;
   const TrackLevel& L = job->lv[level];
@@ -853,6 +877,85 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
   for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
   int key0 = -1, key1 = -1, key2 = -1;   // reference-order keys of this lane's in-image points (descending)
 
+  if (BATCH && job.lv[level].tilePx > 0) {
+    // Throughput mode (batches): the workgroup owns a strip of tilePx consecutive pixels of the keyframe level.  It first
+    // compacts the strip's valid reference pixels (semi-dense: ~30 %) into an LDS list — fixed order: chunk, then pixel
+    // slot, then lane, so the result is run-to-run deterministic — and then evaluates the list with all lanes busy.
+    unsigned* s_list = (unsigned*)s_red;   // (x | y << 16); s_red is not live before the reduction
+    const int tilePx = job.lv[level].tilePx;
+    const int base = tile * tilePx;
+    const int nchunk = tilePx >> 10;
+    const float inv_w = 1.0f / (float)a.w;
+    unsigned vmask = 0;      // 4 validity bits per chunk
+    int wcount = 0;          // valid pixels of this wave (uniform)
+    for (int c = 0; c < nchunk; c++) {
+      const int i0 = base + (c << 10) + (tid << 2);
+      if (i0 < work) {
+        // work is a multiple of 4 whenever the level width is (checked on the host): the 4 pixels exist together
+        const float4 v4 = *(const float4*)(a.kf_idepthVar + i0);
+        const float4 d4 = *(const float4*)(a.kf_idepth + i0);
+        int y = (int)((float)i0 * inv_w);
+        int x = i0 - y * a.w;
+        if (x < 0) { y--; x += a.w; }
+        if (x >= a.w) { y++; x -= a.w; }
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool ok = !(x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) && !(vv[k] <= 0 || dd[k] == 0);
+          vmask |= (ok ? 1u : 0u) << (c * 4 + k);
+          if (++x >= a.w) { x = 0; y++; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) wcount += __popcll(__ballot((vmask >> (c * 4 + k)) & 1u));
+    }
+    if (lane == 0) s_wtop[wave][0] = wcount;
+    __syncthreads();
+    int pos = 0, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; wv++) {
+      const int cw = s_wtop[wv][0];
+      if (wv < wave) pos += cw;
+      total += cw;
+    }
+    for (int c = 0; c < nchunk; c++) {
+      const int i0 = base + (c << 10) + (tid << 2);
+      int y = (int)((float)i0 * inv_w);
+      int x = i0 - y * a.w;
+      if (x < 0) { y--; x += a.w; }
+      if (x >= a.w) { y++; x -= a.w; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool ok = (vmask >> (c * 4 + k)) & 1u;
+        const unsigned long long bal = __ballot(ok);
+        if (ok) s_list[pos + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned)x | ((unsigned)y << 16);
+        pos += __popcll(bal);
+        if (++x >= a.w) { x = 0; y++; }
+      }
+    }
+    __syncthreads();
+    for (int p = tid; p < total; p += BLOCK) {
+      const unsigned xy = s_list[p];
+      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+      const int i = y * a.w + x;
+      const float var = a.kf_idepthVar[i];
+      const float id = a.kf_idepth[i];
+      const float inv = 1.0f / id;
+      const float px = inv * (a.fxi * x + a.cxi), py = inv * (a.fyi * y + a.cyi), pz = inv * 1.0f;
+      const float I_ref = a.kf_image[i];
+      acc[RS_NREF] += 1.f;
+      PointOut o;
+      eval_point(a, px, py, pz, I_ref, var, o);
+      if (!o.in_image) {
+        if (wasGood) wasGood[i] = 0;
+      } else {
+        if (wasGood) wasGood[i] = o.good ? 1 : 0;
+        top3_insert(x * a.h + y, key0, key1, key2);
+        accumulate_point(o, acc);
+      }
+    }
+    __syncthreads();   // the list aliases s_red
+  } else
   for (int i = tile * BLOCK + tid; i < work; i += nb * BLOCK) {
     float px, py, pz, I_ref, var;
     int maskIdx;
@@ -865,26 +968,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
       } else {
         if (wasGood && maskIdx >= 0) wasGood[maskIdx] = o.good ? 1 : 0;
         top3_insert(a.npts >= 0 ? i : (i % a.w) * a.h + (i / a.w), key0, key1, key2);
-        acc[RS_M] += 1.f;
-        acc[RS_SXX] += o.c1 * o.c1 * o.hw;
-        acc[RS_SYY] += o.c2 * o.c2 * o.hw;
-        acc[RS_SX] += o.c1 * o.hw;
-        acc[RS_SY] += o.c2 * o.hw;
-        acc[RS_SW] += o.hw;
-        if (o.good) { acc[RS_GOOD] += 1.f; acc[RS_SUMRES2] += o.res * o.res; acc[RS_SUMSIGNED] += o.res; }
-        else acc[RS_BAD] += 1.f;
-        acc[RS_USAGE] += o.usage;
-        acc[RS_WERR] += o.werr;
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-          float Jw = o.J[r] * o.w;
-#pragma unroll
-          for (int c = r; c < 6; c++) acc[tri_index(r, c)] += Jw * o.J[c];
-        }
-        float resw = o.res * o.w;
-#pragma unroll
-        for (int r = 0; r < 6; r++) acc[RS_B0 + r] += resw * o.J[r];
-        acc[RS_ERR] += resw * o.res;
+        accumulate_point(o, acc);
       }
     }
   }
@@ -1075,6 +1159,17 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   if (L.nblocks > cap) L.nblocks = cap;                     // larger levels grid-stride
   if (L.nblocks < 1) L.nblocks = 1;
   L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
+  L.tilePx = 0;
+  if (t->batch_jobs >= 8 && npts < 0 && (L.w & 3) == 0) {
+    // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
+    long long px = ((long long)work * t->batch_jobs / 512 + 1023) & ~1023LL;
+    if (px < 1024) px = 1024;
+    if (px > 8192) px = 8192;
+    while ((work + px - 1) / px > t->max_blocks) px += 1024;   // cannot happen below 2.6 Mpixel levels
+    L.tilePx = (int)px;
+    L.nblocks = (int)((work + px - 1) / px);
+    L.singlePass = 0;
+  }
   L.lambdaInitial = t->lambdaInitial[level]; L.stepSizeMin = t->stepSizeMin[level]; L.convergenceEps = t->convergenceEps[level];
   L.maxIts = t->maxItsPerLvl[level];
   L.minWarped = MIN_GOODPERALL_PIXEL_ABSMIN * (c->w >> level) * (c->h >> level);
@@ -1436,6 +1531,7 @@ static int batch_reserve(lsdhip_tracker* t, int n) {
 // With many jobs in flight the other jobs hide a job's latency, so each job gets fewer, fatter workgroups: the
 // per-workgroup LM replay (the price of the launch needing no inter-workgroup communication) shrinks accordingly.
 static void batch_begin(lsdhip_tracker* t, int n) {
+  t->batch_jobs = n;
   t->cap_override = (t->grid_cap / n) & ~7;
   if (t->cap_override < 16) t->cap_override = 16;
   if (n == 1) t->cap_override = 0;
@@ -1444,6 +1540,7 @@ static void batch_begin(lsdhip_tracker* t, int n) {
 static int batch_run(lsdhip_tracker* t, int n) {
   lsdhip_ctx* c = t->ctx;
   t->cap_override = 0;
+  t->batch_jobs = 0;
   int grid = 1;
   for (int j = 0; j < n; j++) {
     const TrackJob& job = t->h_bjobs[j];
@@ -1508,7 +1605,7 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
   for (int j = 0; j < n; j++) {
     TrackJob& job = t->h_bjobs[j];
     rc = fill_trackframe_job(t, job, keyframes[j], frames[j]);
-    if (rc) { t->cap_override = 0; return rc; }
+    if (rc) { t->cap_override = 0; t->batch_jobs = 0; return rc; }
     job.evalOnly = 0;
     job.topLevel = LSD_TRACK_MAX_LEVEL - 1;
     job.T0 = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(inits + 7 * (size_t)j)));

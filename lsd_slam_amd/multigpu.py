@@ -23,6 +23,10 @@ class KeyframeGather:
         if self.pending is not None:
             self.pending.wait()
             self.pending = None
+            if self.send.is_cuda:
+                # work.wait() only orders torch's current stream behind the collective; the send buffer is refilled from
+                # liblsdhip's own stream, so the host has to see the gather finished before that
+                torch.cuda.current_stream(self.send.device).synchronize()
             if keep and self.rank == self.root:
                 self.collected.append(torch.stack([r.clone() for r in self.recv]))
 

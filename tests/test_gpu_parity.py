@@ -594,6 +594,47 @@ def test_track_batch_equals_single_calls(oracle, hip):
 
 
 @pytest.mark.gpu
+def test_track_batch_throughput_mode_matches_single_calls(oracle, hip):
+    """>= 8 jobs switch the batch to its throughput mode (strips of the keyframe level compacted to their valid pixels in
+    LDS, tail points re-evaluated): same points, same per-point arithmetic, another summation order."""
+    w, h = 320, 240
+    seqs = [sequence(w, h, 4, seq_index=s) for s in range(3)]
+    ctx = hip.Context(w, h, seqs[0][2])
+    tr = hip.SE3Tracker(ctx)
+    tr.set_maxItsPerLvl(ODOMETRY_ITS)
+    refs, frs, want = [], [], []
+    for s, (frames, depth0, K, gt) in enumerate(seqs):
+        for k in (1, 2, 3):
+            pair = []
+            for copy in range(2):
+                kf = hip.Frame(ctx, 100 * s + 10 * k, frames[0])
+                depth = depth0.copy()
+                if k == 3:
+                    depth[::2, 1::3] = 0          # ragged validity
+                kf.setDepthFromGroundTruth(depth)
+                ref = hip.TrackingReference()
+                ref.importFrame(kf)
+                pair.append((ref, hip.Frame(ctx, 100 * s + 10 * k + 1, frames[k]), kf))
+            (ref, fr, kf) = pair[0]
+            pose = tr.trackFrame(ref, fr, IDENT7)
+            want.append((pose, tr.last.numEvaluations, tr.lastResidual, tr.pointUsage, tr.trackingWasGood, fr.refPixelWasGoodNoCreate()))
+            refs.append(pair[1][0]); frs.append(pair[1][1])
+    assert len(refs) == 9
+    poses, recs = tr.trackFrameBatch(refs, frs, np.tile(IDENT7, (9, 1)))
+    for j in range(9):
+        sp, sev, sres, suse, sgood, smask = want[j]
+        dtj, drj = pose_distance(poses[j], sp, oracle)
+        assert max(dtj, drj) < 2e-4, (j, dtj, drj)
+        assert abs(recs[j].numEvaluations - sev) <= 2
+        assert recs[j].lastResidual == pytest.approx(sres, rel=5e-2) and recs[j].pointUsage == pytest.approx(suse, rel=1e-3)
+        assert bool(recs[j].trackingWasGood) == sgood
+        assert (frs[j].refPixelWasGoodNoCreate() != smask).mean() < 2e-3
+    # run-to-run deterministic
+    frs2 = [hip.Frame(ctx, 900 + j, seqs[j // 3][0][1 + j % 3]) for j in range(9)]
+    poses2, _ = tr.trackFrameBatch(refs, frs2, np.tile(IDENT7, (9, 1)))
+    assert np.array_equal(poses, poses2)
+
+
 def test_permaref_batch_matches_single_and_oracle(oracle, hip):
     """several keyframes' permanent references (level-4 clouds) tracked against one new frame in the same
     launches give what single trackFrameOnPermaref calls and the oracle give."""
