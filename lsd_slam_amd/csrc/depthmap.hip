@@ -1105,11 +1105,10 @@ static int set_depth_finish(lsdhip_depthmap* dm, int nPartials) {
   const int slot = lsd_ctx_take_slot(c);
   if (slot < 0) return slot;
   if (kf->pendStats >= 0) c->slot_stats_owner[kf->pendStats] = nullptr;   // superseded by this setDepth
-  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nPartials, (double*)&c->h_slots[slot],
-                     (double*)nullptr, (const int*)nullptr);
   kf->pendStats = slot;
   c->slot_stats_owner[slot] = kf;
-  int rc = lsd_frame_build_idepth_pyramid(kf);
+  // the (sum, count) reduction rides on the pyramid launch (one extra workgroup): both depend only on the level-0 planes
+  int rc = lsd_frame_build_idepth_pyramid(kf, dm->d_red + 16, nPartials, (double*)&c->h_slots[slot]);
   if (rc) return rc;
   kf->depthHasBeenUpdatedFlag = true;
   if (!c->async) return lsd_frame_resolve(kf);

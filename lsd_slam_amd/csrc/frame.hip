@@ -20,9 +20,12 @@
 
 // One 16x16 level-0 tile per workgroup -> 8x8, 4x4, 2x2, 1x1 tiles of levels 1..4, all in one launch.
 // HBM traffic: 1 B/px read (uint8) + 4 B * (1 + 1/4 + 1/16 + 1/64 + 1/256) written.
+// The same workgroup also writes the level-0 gradient texels (gx, gy, I, 0) and |grad| of its 16x16 pixels, straight from
+// the uint8 source (the float image is its exact conversion), with the reference's linear-index neighbour rule.
 __global__ __launch_bounds__(256) void k_image_pyramid(const uint8_t* __restrict__ gray, float* __restrict__ i0,
                                                         float* __restrict__ i1, float* __restrict__ i2,
-                                                        float* __restrict__ i3, float* __restrict__ i4, int w, int h) {
+                                                        float* __restrict__ i3, float* __restrict__ i4, int w, int h,
+                                                        float4* __restrict__ grad0, float* __restrict__ absgrad0) {
   __shared__ float s0[16][17];
   __shared__ float s1[8][9];
   __shared__ float s2[4][5];
@@ -32,9 +35,20 @@ __global__ __launch_bounds__(256) void k_image_pyramid(const uint8_t* __restrict
   const int bx = blockIdx.x, by = blockIdx.y;
   {
     int x = bx * 16 + tx, y = by * 16 + ty;
-    float v = (float)gray[y * w + x];
-    i0[y * w + x] = v;
+    const int i = y * w + x;
+    float v = (float)gray[i];
+    i0[i] = v;
     s0[ty][tx] = v;
+    // Frame::buildGradients (Frame.cpp:643-680): rows 1..h-2 by linear index, so x = 0 / w-1 wrap into the neighbouring rows
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool inner = (i >= w) && (i < w * (h - 1));
+    if (inner) {
+      g.x = 0.5f * ((float)gray[i + 1] - (float)gray[i - 1]);
+      g.y = 0.5f * ((float)gray[i + w] - (float)gray[i - w]);
+      g.z = v;
+    }
+    grad0[i] = g;
+    absgrad0[i] = inner ? sqrtf(g.x * g.x + g.y * g.y) : 0.f;
   }
   __syncthreads();
   if (tid < 64) {
@@ -78,33 +92,47 @@ struct GradArgs {
   int w[LSD_LEVELS], h[LSD_LEVELS];
 };
 
-// All five gradient planes in one launch (blockIdx.y = level).  4 B/px read (+ neighbours from L2), 16 B/px
-// written; level 0 additionally writes |grad| (4 B/px) for the maxGradients pass.
-__global__ __launch_bounds__(256) void k_gradients(GradArgs a) {
-  const int l = blockIdx.y;
-  const int w = a.w[l], h = a.h[l];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= w * h) return;
-  const float* __restrict__ img = a.img[l];
-  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool inner = (i >= w) && (i < w * (h - 1));
-  if (inner) {
-    g.x = 0.5f * (img[i + 1] - img[i - 1]);
-    g.y = 0.5f * (img[i + w] - img[i - w]);
-    g.z = img[i];
+// Second launch of a new frame: the gradient planes of levels 1..4 (blocks [0, gradBlocks)) and the level-0 maxGradients
+// (the remaining blocks) — independent of each other, both depend on the first launch only.
+// Gradients: 4 B/px read (+ neighbours from L2), 16 B/px written.
+// maxGradients: separable 3x3 max of |grad| with the reference's linear-index validity ranges (see header comment); also
+// leaves the frame's level-1 refPixelWasGood mask in its "never written" state (0xFF), so that the tracker needs no separate
+// fill before its first use.
+struct GradMaxArgs {
+  const float* img[LSD_LEVELS];
+  float4* grad[LSD_LEVELS];
+  int w[LSD_LEVELS], h[LSD_LEVELS];
+  int blk0[LSD_LEVELS + 1];     // first block of level l's gradient range (levels 1..4); blk0[LSD_LEVELS] = gradBlocks
+  const float* absg;
+  float* maxgrad;
+  uint32_t* wasGoodWords;
+  int nMaskWords;
+};
+__global__ __launch_bounds__(256) void k_gradients_max(GradMaxArgs a) {
+  const int b = blockIdx.x;
+  if (b < a.blk0[LSD_LEVELS]) {
+    int l = 1;
+#pragma unroll
+    for (int k = 2; k < LSD_LEVELS; k++) if (b >= a.blk0[k]) l = k;
+    const int w = a.w[l], h = a.h[l];
+    const int i = (b - a.blk0[l]) * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const float* __restrict__ img = a.img[l];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool inner = (i >= w) && (i < w * (h - 1));
+    if (inner) {
+      g.x = 0.5f * (img[i + 1] - img[i - 1]);
+      g.y = 0.5f * (img[i + w] - img[i - w]);
+      g.z = img[i];
+    }
+    a.grad[l][i] = g;
+    return;
   }
-  a.grad[l][i] = g;
-  if (l == 0) a.absgrad0[i] = inner ? sqrtf(g.x * g.x + g.y * g.y) : 0.f;
-}
-
-// Separable 3x3 max of |grad| with the reference's linear-index validity ranges (see header comment).
-// Also leaves the frame's level-1 refPixelWasGood mask in its "never written" state (0xFF), so that the tracker needs
-// no separate fill before its first use.
-__global__ __launch_bounds__(256) void k_max_gradients(const float* __restrict__ absg, float* __restrict__ maxgrad, int w, int h,
-                                                        uint32_t* __restrict__ wasGoodWords, int nMaskWords) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* __restrict__ absg = a.absg;
+  const int w = a.w[0], h = a.h[0];
+  const int i = (b - a.blk0[LSD_LEVELS]) * 256 + threadIdx.x;
   const int n = w * h;
-  if (i < nMaskWords) wasGoodWords[i] = 0xFFFFFFFFu;
+  if (i < a.nMaskWords) a.wasGoodWords[i] = 0xFFFFFFFFu;
   if (i >= n) return;
   const int lo = w + 1, hi = w * (h - 1) - 1;
   auto vmax = [&](int j) -> float {
@@ -125,7 +153,7 @@ __global__ __launch_bounds__(256) void k_max_gradients(const float* __restrict__
   } else if (i == w || i == hi) {
     out = absg[i];
   }
-  maxgrad[i] = out;
+  a.maxgrad[i] = out;
 }
 
 // inverse-variance pooling of one 2x2 block, children in the order idx, idx+1, idx+sw, idx+sw+1
@@ -155,6 +183,11 @@ struct DepthPyrArgs {
   float* id[LSD_LEVELS];
   float* var[LSD_LEVELS];
   int w0;
+  // optional passenger: one extra workgroup (blockIdx.y == gridDim.y - 1, blockIdx.x == 0 of an extra grid row) folds the
+  // (sum, count) partials of the setDepth that produced level 0 into a pinned record (Frame::setDepth's meanIdepth / numPoints)
+  const double* redPartials;
+  int redN;
+  double* redOut;
 };
 
 // Levels 1..4 of (idepth, idepthVar) from level 0, one 16x16 level-0 tile per workgroup.
@@ -167,6 +200,21 @@ __global__ __launch_bounds__(256) void k_idepth_pyramid(DepthPyrArgs a) {
   const int tx = tid & 15, ty = tid >> 4;
   const int bx = blockIdx.x, by = blockIdx.y;
   const int w0 = a.w0;
+  if (a.redPartials && by == (int)gridDim.y - 1) {
+    if (bx != 0) return;
+    __shared__ double s_a[256], s_b[256];
+    double sa = 0, sb = 0;
+    for (int i = tid; i < a.redN; i += 256) { sa += a.redPartials[2 * i]; sb += a.redPartials[2 * i + 1]; }
+    s_a[tid] = sa;
+    s_b[tid] = sb;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) { s_a[tid] += s_a[tid + off]; s_b[tid] += s_b[tid + off]; }
+      __syncthreads();
+    }
+    if (tid == 0) { a.redOut[0] = s_a[0]; a.redOut[1] = s_b[0]; a.redOut[2] = 0.0; }
+    return;
+  }
   {
     int x = bx * 16 + tx, y = by * 16 + ty;
     sid[ty][tx] = a.id[0][y * w0 + x];
@@ -471,25 +519,31 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src) {
   lsdhip_ctx* c = f->ctx;
   dim3 grid(c->w / 16, c->h / 16);
   hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, c->stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
-                     f->d_image[3], f->d_image[4], c->w, c->h);
-  GradArgs ga;
-  for (int l = 0; l < LSD_LEVELS; l++) { ga.img[l] = f->d_image[l]; ga.grad[l] = f->d_grad[l]; ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l]; }
-  ga.absgrad0 = f->d_absgrad;
+                     f->d_image[3], f->d_image[4], c->w, c->h, f->d_grad[0], f->d_absgrad);
+  GradMaxArgs ga;
+  int nb = 0;
+  for (int l = 0; l < LSD_LEVELS; l++) {
+    ga.img[l] = f->d_image[l]; ga.grad[l] = f->d_grad[l]; ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l];
+    ga.blk0[l] = nb;
+    if (l >= 1) nb += (c->wl[l] * c->hl[l] + 255) / 256;
+  }
+  ga.blk0[LSD_LEVELS] = nb;
+  ga.absg = f->d_absgrad; ga.maxgrad = f->d_maxgrad;
+  ga.wasGoodWords = (uint32_t*)f->d_wasGood; ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
   int n0 = c->w * c->h;
-  hipLaunchKernelGGL(k_gradients, dim3((n0 + 255) / 256, LSD_LEVELS), dim3(256), 0, c->stream, ga);
-  hipLaunchKernelGGL(k_max_gradients, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, f->d_absgrad, f->d_maxgrad, c->w, c->h,
-                     (uint32_t*)f->d_wasGood, (c->wl[1] * c->hl[1] + 3) / 4);
+  hipLaunchKernelGGL(k_gradients_max, dim3(nb + (n0 + 255) / 256), dim3(256), 0, c->stream, ga);
   HIPCHK(hipGetLastError());
   f->wasGoodPristine = true;
   return LSDHIP_OK;
 }
 
-int lsd_frame_build_idepth_pyramid(lsdhip_frame* f) {
+int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, int redN, double* redOut) {
   lsdhip_ctx* c = f->ctx;
   DepthPyrArgs a;
   for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = f->d_idepth[l]; a.var[l] = f->d_idepthVar[l]; }
   a.w0 = c->w;
-  hipLaunchKernelGGL(k_idepth_pyramid, dim3(c->w / 16, c->h / 16), dim3(256), 0, c->stream, a);
+  a.redPartials = redPartials; a.redN = redN; a.redOut = redOut;
+  hipLaunchKernelGGL(k_idepth_pyramid, dim3(c->w / 16, c->h / 16 + (redPartials ? 1 : 0)), dim3(256), 0, c->stream, a);
   HIPCHK(hipGetLastError());
   f->hasIDepth = true;
   return LSDHIP_OK;

@@ -273,7 +273,7 @@ struct lsdhip_depthmap {
 
 // kernels / launchers implemented in the .hip files
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src);
-int lsd_frame_build_idepth_pyramid(lsdhip_frame* f);
+int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);
 int lsd_prof_collect(lsdhip_ctx* c);
