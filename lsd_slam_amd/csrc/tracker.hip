@@ -125,25 +125,36 @@ struct PointOut {
   float J[6];
 };
 
-// (px,py,pz) = reference point, I_ref / var = its colour and inverse-depth variance.
-__device__ __forceinline__ void eval_point(const EvalCtx& a, float px, float py, float pz, float I_ref, float var, PointOut& o) {
+// The evaluation of one point in three steps, so that a caller may interleave the steps of different points (the batch
+// throughput mode keeps the texel fetches of the next point in flight while it finishes the current one).  eval_point
+// below is the plain composition; operation order is that of the reference (see the comments inside).
+struct PointWarp { float Wx, Wy, Wz, u_new, v_new; bool in_image; };
+struct PointTexels { float4 t00, t10, t01, t11; };
+__device__ __forceinline__ void eval_warp(const EvalCtx& a, float px, float py, float pz, PointWarp& q) {
   // Wxp = rotMat * p + transVec (Eigen coefficient product: ((r0*x + r1*y) + r2*z), then + t)
-  float Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
-  float Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
-  float Wz = ((a.R[6] * px + a.R[7] * py) + a.R[8] * pz) + a.t[2];
-  float u_new = (Wx / Wz) * a.fx + a.cx;
-  float v_new = (Wy / Wz) * a.fy + a.cy;
-  o.in_image = (u_new > 1 && v_new > 1 && u_new < a.w - 2 && v_new < a.h - 2);
-  if (!o.in_image) return;
-
-  // getInterpolatedElement43 (C/util/globalFuncs.h:63-77)
+  q.Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
+  q.Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
+  q.Wz = ((a.R[6] * px + a.R[7] * py) + a.R[8] * pz) + a.t[2];
+  q.u_new = (q.Wx / q.Wz) * a.fx + a.cx;
+  q.v_new = (q.Wy / q.Wz) * a.fy + a.cy;
+  q.in_image = (q.u_new > 1 && q.v_new > 1 && q.u_new < a.w - 2 && q.v_new < a.h - 2);
+}
+// the four texels of getInterpolatedElement43 (C/util/globalFuncs.h:63-77); `fetch` = false reads texel 0 instead
+__device__ __forceinline__ void eval_fetch(const EvalCtx& a, const PointWarp& q, bool fetch, PointTexels& t) {
+  const int ix = fetch ? (int)q.u_new : 0;
+  const int iy = fetch ? (int)q.v_new : 0;
+  const float4* bp = a.fr_grad + ix + iy * a.w;
+  t.t00 = bp[0]; t.t10 = bp[1]; t.t01 = bp[a.w]; t.t11 = bp[1 + a.w];
+}
+__device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q, const PointTexels& t, float pz, float I_ref, float var,
+                                            PointOut& o) {
+  const float Wx = q.Wx, Wy = q.Wy, Wz = q.Wz, u_new = q.u_new, v_new = q.v_new;
+  const float4 t00 = t.t00, t10 = t.t10, t01 = t.t01, t11 = t.t11;
   int ix = (int)u_new;
   int iy = (int)v_new;
   float dx = u_new - ix;
   float dy = v_new - iy;
   float dxdy = dx * dy;
-  const float4* bp = a.fr_grad + ix + iy * a.w;
-  float4 t00 = bp[0], t10 = bp[1], t01 = bp[a.w], t11 = bp[1 + a.w];
   float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
   float rx = w11 * t11.x + w01 * t01.x + w10 * t10.x + w00 * t00.x;
   float ry = w11 * t11.y + w01 * t01.y + w10 * t10.y + w00 * t00.y;
@@ -186,6 +197,16 @@ __device__ __forceinline__ void eval_point(const EvalCtx& a, float px, float py,
   o.J[2] = 0.0f - (v1 + v2);
   o.J[3] = 0.0f - ((v2 * Wy) + (gy + v1 * Wy));
   o.J[4] = (gx + v1 * Wx) + v2 * Wx;
+}
+// (px,py,pz) = reference point, I_ref / var = its colour and inverse-depth variance.
+__device__ __forceinline__ void eval_point(const EvalCtx& a, float px, float py, float pz, float I_ref, float var, PointOut& o) {
+  PointWarp q;
+  eval_warp(a, px, py, pz, q);
+  o.in_image = q.in_image;
+  if (!o.in_image) return;
+  PointTexels t;
+  eval_fetch(a, q, true, t);
+  eval_finish(a, q, t, pz, I_ref, var, o);
 }
 
 // fetch the reference point `i` (dense index into the keyframe level, or index into the explicit list)
@@ -648,7 +669,11 @@ struct TrackScratch {
 // The first launch of a job (first = 1) builds the initial state from the job instead of loading it.
 // BATCH: blockIdx.y selects one of several independent jobs (tracking a batch of frames / permanent references in the
 // same launches): the job descriptions then live in HBM (`jobs`), and state / scratch / summary are arrays over jobs.
-template <int BLOCK, bool BATCH>
+// MODE (batches in throughput mode split a step into two launches, so that the LM replay is paid once per job instead of
+// once per workgroup): TS_FUSED = finish + evaluate as described above; TS_LM = finish the pending evaluation and publish the
+// state (grid.x = 1); TS_EVAL = evaluate the published state (reads st2[parity], writes scratch[parity]; no state change).
+enum { TS_FUSED = 0, TS_LM = 1, TS_EVAL = 2 };
+template <int BLOCK, bool BATCH, int MODE = TS_FUSED>
 __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
                                                        TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
   const TrackJob& job = BATCH ? jobs[blockIdx.y] : jobv;
@@ -678,12 +703,13 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
   const int wave = tid >> 6, lane = tid & 63;
   const int max_rows = sc.max_rows;
   TrackState* next = st2 + (1 - parity);
+  const int outp = MODE == TS_EVAL ? parity : 1 - parity;
   const float* sums_in = sc.sums + (size_t)parity * RS_COLS * max_rows;
-  float* sums_out = sc.sums + (size_t)(1 - parity) * RS_COLS * max_rows;
+  float* sums_out = sc.sums + (size_t)outp * RS_COLS * max_rows;
   const int4* topkey_in = sc.topkey + (size_t)parity * max_rows;
-  int4* topkey_out = sc.topkey + (size_t)(1 - parity) * max_rows;
+  int4* topkey_out = sc.topkey + (size_t)outp * max_rows;
   const float* topval_in = sc.topval + (size_t)parity * max_rows * 96;
-  float* topval_out = sc.topval + (size_t)(1 - parity) * max_rows * 96;
+  float* topval_out = sc.topval + (size_t)outp * max_rows * 96;
 #ifdef LSD_PHASE_TRACE
   unsigned long long* tr_ = sc.trace;
   if (blockIdx.x == 0 && tid == 0) {
@@ -714,11 +740,11 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
   __syncthreads();
   PHASE_MARK(1);
   if (S.done) {
-    if (blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // keep both buffers "done"
+    if (MODE != TS_EVAL && blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // keep both buffers "done"
     return;
   }
 
-  if (S.pending) {
+  if (MODE != TS_EVAL && S.pending) {
     const int level = S.level;
     const int nb = job.lv[level].nblocks;
     if (wave < SUMW) {
@@ -862,9 +888,16 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
     }
   }
 
+  if (MODE == TS_LM) {
+    if (tid == 0) S.pending = 1;
+    __syncthreads();
+    copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
+    return;
+  }
+
   // ---- residual evaluation at S.level / S.R, S.t ------------------------------------------------------------------
   const int level = S.level;
-  if (tid == 0) S.pending = 1;
+  if (MODE == TS_FUSED && tid == 0) S.pending = 1;
   const int nb = job.lv[level].nblocks;
   if ((int)blockIdx.x >= nb) return;   // workgroup 0 always has work: it publishes the state at the end
   const int tile = xcd_tile(blockIdx.x, nb);
@@ -934,24 +967,56 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
       }
     }
     __syncthreads();
-    for (int p = tid; p < total; p += BLOCK) {
-      const unsigned xy = s_list[p];
-      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-      const int i = y * a.w + x;
-      const float var = a.kf_idepthVar[i];
-      const float id = a.kf_idepth[i];
-      const float inv = 1.0f / id;
-      const float px = inv * (a.fxi * x + a.cxi), py = inv * (a.fyi * y + a.cyi), pz = inv * 1.0f;
-      const float I_ref = a.kf_image[i];
-      acc[RS_NREF] += 1.f;
-      PointOut o;
-      eval_point(a, px, py, pz, I_ref, var, o);
-      if (!o.in_image) {
-        if (wasGood) wasGood[i] = 0;
-      } else {
-        if (wasGood) wasGood[i] = o.good ? 1 : 0;
-        top3_insert(x * a.h + y, key0, key1, key2);
-        accumulate_point(o, acc);
+    if (total > 0) {
+      // three-stage software pipeline over the list entries tid, tid + BLOCK, ...: (A) list entry + keyframe planes,
+      // (B) reference point, warp, texel fetch, (C) residual / weights / normal equations.  Stage A of entry r + 2 and
+      // stage B of entry r + 1 are issued before stage C of entry r, so two dependent memory round trips overlap the
+      // arithmetic.  Lanes past the end of the list run the loads on entry 0 and discard them.
+      struct StA { unsigned xy; float var, id, img; bool live; };
+      struct StB { int x, y; float pz, I_ref, var; PointWarp q; PointTexels t; bool live; };
+      auto stageA = [&](int p, StA& A) {
+        A.live = p < total;
+        A.xy = s_list[A.live ? p : 0];
+        const int i = (int)(A.xy >> 16) * a.w + (int)(A.xy & 0xffffu);
+        A.var = a.kf_idepthVar[i];
+        A.id = a.kf_idepth[i];
+        A.img = a.kf_image[i];
+      };
+      auto stageB = [&](const StA& A, StB& B) {
+        B.live = A.live;
+        B.x = (int)(A.xy & 0xffffu); B.y = (int)(A.xy >> 16);
+        const float inv = 1.0f / A.id;
+        const float px = inv * (a.fxi * B.x + a.cxi), py = inv * (a.fyi * B.y + a.cyi);
+        B.pz = inv * 1.0f;
+        B.I_ref = A.img; B.var = A.var;
+        eval_warp(a, px, py, B.pz, B.q);
+        eval_fetch(a, B.q, B.live && B.q.in_image, B.t);
+      };
+      const int rounds = (total + BLOCK - 1) / BLOCK;
+      StA A1, A2;
+      StB B0, B1;
+      stageA(tid, A1);
+      stageA(tid + BLOCK, A2);
+      stageB(A1, B0);
+      A1 = A2;
+      for (int r = 0; r < rounds; r++) {
+        stageA(tid + (r + 2) * BLOCK, A2);
+        stageB(A1, B1);
+        if (B0.live) {
+          const int i = B0.y * a.w + B0.x;
+          acc[RS_NREF] += 1.f;
+          if (!B0.q.in_image) {
+            if (wasGood) wasGood[i] = 0;
+          } else {
+            PointOut o;
+            eval_finish(a, B0.q, B0.t, B0.pz, B0.I_ref, B0.var, o);
+            if (wasGood) wasGood[i] = o.good ? 1 : 0;
+            top3_insert(B0.x * a.h + B0.y, key0, key1, key2);
+            accumulate_point(o, acc);
+          }
+        }
+        B0 = B1;
+        A1 = A2;
       }
     }
     __syncthreads();   // the list aliases s_red
@@ -1021,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
       dst[28] = acc[RS_ERR];
     }
   }
-  if (blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // S.pending was set before the barriers above
+  if (MODE == TS_FUSED && blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // S.pending was set before the barriers above
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
   if (blockIdx.x == 0 && tid == 0) tr_[9] = wall_clock64();
@@ -1542,9 +1607,13 @@ static int batch_run(lsdhip_tracker* t, int n) {
   t->cap_override = 0;
   t->batch_jobs = 0;
   int grid = 1;
+  bool split = false;
   for (int j = 0; j < n; j++) {
     const TrackJob& job = t->h_bjobs[j];
-    for (int l = job.lastLevel; l <= job.topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
+    for (int l = job.lastLevel; l <= job.topLevel; l++) {
+      if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
+      if (job.lv[l].tilePx > 0) split = true;
+    }
     t->h_bsummary[j].done = 0;
   }
   HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
@@ -1566,8 +1635,16 @@ static int batch_run(lsdhip_tracker* t, int n) {
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     for (int i = 0; i < budget; i++) {
-      hipLaunchKernelGGL((k_track_step<256, true>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
-                         t->d_bstate, sc, d_sum, parity, first);
+      if (split) {
+        // throughput mode: one LM workgroup per job, then a pure evaluation launch over all jobs' strips
+        hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
+                           t->d_bstate, sc, d_sum, parity, first);
+        hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
+                           t->d_bstate, sc, d_sum, 1 - parity, 0);
+      } else {
+        hipLaunchKernelGGL((k_track_step<256, true>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
+                           t->d_bstate, sc, d_sum, parity, first);
+      }
       first = 0;
       parity ^= 1;
     }
