@@ -10,6 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblsdhip.so")
+# kernels allowed to spill a few loop-invariant registers (long, memory-bound batch kernels where occupancy matters more;
+# the latency-critical single-job kernels must stay at zero)
+SCRATCH_OK = ()
 SOURCES = ["host_math.cpp", "frame.hip", "tracker.hip", "depthmap.hip", "sim3.hip"]
 # -disable-promote-alloca-to-lds: a private array the optimiser cannot split must show up as scratch (and fail the
 # guard below) instead of silently moving to LDS, where indexing it by thread costs a read of the AQL dispatch packet
@@ -36,7 +39,7 @@ def _compile_checked(cmd):
         if m:
             name = m.group(1)
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", l)
-        if m and int(m.group(1)) > 0:
+        if m and int(m.group(1)) > 0 and not any(k in (name or "") for k in SCRATCH_OK):
             bad.append((name, int(m.group(1))))
     if bad:
         raise RuntimeError("kernels using scratch memory: %r" % bad)

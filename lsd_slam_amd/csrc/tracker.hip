@@ -129,7 +129,8 @@ struct PointOut {
 // throughput mode keeps the texel fetches of the next point in flight while it finishes the current one).  eval_point
 // below is the plain composition; operation order is that of the reference (see the comments inside).
 struct PointWarp { float Wx, Wy, Wz, u_new, v_new; bool in_image; };
-struct PointTexels { float4 t00, t10, t01, t11; };
+struct Texel3 { float x, y, z; };   // (gx, gy, I) of a 16-byte texel; the fourth word is never read
+struct PointTexels { Texel3 t00, t10, t01, t11; };
 __device__ __forceinline__ void eval_warp(const EvalCtx& a, float px, float py, float pz, PointWarp& q) {
   // Wxp = rotMat * p + transVec (Eigen coefficient product: ((r0*x + r1*y) + r2*z), then + t)
   q.Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
@@ -144,12 +145,13 @@ __device__ __forceinline__ void eval_fetch(const EvalCtx& a, const PointWarp& q,
   const int ix = fetch ? (int)q.u_new : 0;
   const int iy = fetch ? (int)q.v_new : 0;
   const float4* bp = a.fr_grad + ix + iy * a.w;
-  t.t00 = bp[0]; t.t10 = bp[1]; t.t01 = bp[a.w]; t.t11 = bp[1 + a.w];
+  auto ld = [](const float4* p) { const float* f = (const float*)p; Texel3 r = {f[0], f[1], f[2]}; return r; };
+  t.t00 = ld(bp); t.t10 = ld(bp + 1); t.t01 = ld(bp + a.w); t.t11 = ld(bp + 1 + a.w);
 }
 __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q, const PointTexels& t, float pz, float I_ref, float var,
                                             PointOut& o) {
   const float Wx = q.Wx, Wy = q.Wy, Wz = q.Wz, u_new = q.u_new, v_new = q.v_new;
-  const float4 t00 = t.t00, t10 = t.t10, t01 = t.t01, t11 = t.t11;
+  const Texel3 t00 = t.t00, t10 = t.t10, t01 = t.t01, t11 = t.t11;
   int ix = (int)u_new;
   int iy = (int)v_new;
   float dx = u_new - ix;
@@ -673,9 +675,9 @@ struct TrackScratch {
 // once per workgroup): TS_FUSED = finish + evaluate as described above; TS_LM = finish the pending evaluation and publish the
 // state (grid.x = 1); TS_EVAL = evaluate the published state (reads st2[parity], writes scratch[parity]; no state change).
 enum { TS_FUSED = 0, TS_LM = 1, TS_EVAL = 2 };
-template <int BLOCK, bool BATCH, int MODE = TS_FUSED>
-__global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
-                                                       TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
+template <int BLOCK, bool BATCH, int MODE>
+__device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
+                                                TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
   const TrackJob& job = BATCH ? jobs[blockIdx.y] : jobv;
   if (BATCH) {
     const size_t j = blockIdx.y, rows = (size_t)sc.max_rows;
@@ -692,9 +694,11 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
   __shared__ TrackState S;
   __shared__ LmShared sh;
   __shared__ LmPar s_par;
-  constexpr int RSLICE_ = BLOCK / RS_END;
+  constexpr int NPASS = 1;   // the workgroup reduction handles the columns in NPASS batches (2 halves the LDS; measured slower)
+  constexpr int CPP = (RS_END + NPASS - 1) / NPASS;      // columns per batch
+  constexpr int RSLICE_ = BLOCK / CPP;
   __shared__ float s_sum[(NSLICE > RSLICE_ ? NSLICE : RSLICE_)][64];
-  __shared__ float s_red[RS_END * (BLOCK + 1) + 8];
+  __shared__ float s_red[CPP * (BLOCK + 1) + 8];
   __shared__ int s_wtop[WAVES][3];
   __shared__ int s_top[3];
   __shared__ float s_sub[3][32];
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
       // stage B of entry r + 1 are issued before stage C of entry r, so two dependent memory round trips overlap the
       // arithmetic.  Lanes past the end of the list run the loads on entry 0 and discard them.
       struct StA { unsigned xy; float var, id, img; bool live; };
-      struct StB { int x, y; float pz, I_ref, var; PointWarp q; PointTexels t; bool live; };
+      struct StB { unsigned xy; float pz, I_ref, var; PointWarp q; PointTexels t; bool live; };
       auto stageA = [&](int p, StA& A) {
         A.live = p < total;
         A.xy = s_list[A.live ? p : 0];
@@ -984,9 +988,10 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
       };
       auto stageB = [&](const StA& A, StB& B) {
         B.live = A.live;
-        B.x = (int)(A.xy & 0xffffu); B.y = (int)(A.xy >> 16);
+        B.xy = A.xy;
+        const int bx_ = (int)(A.xy & 0xffffu), by_ = (int)(A.xy >> 16);
         const float inv = 1.0f / A.id;
-        const float px = inv * (a.fxi * B.x + a.cxi), py = inv * (a.fyi * B.y + a.cyi);
+        const float px = inv * (a.fxi * bx_ + a.cxi), py = inv * (a.fyi * by_ + a.cyi);
         B.pz = inv * 1.0f;
         B.I_ref = A.img; B.var = A.var;
         eval_warp(a, px, py, B.pz, B.q);
@@ -996,14 +1001,14 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
       StA A1, A2;
       StB B0, B1;
       stageA(tid, A1);
-      stageA(tid + BLOCK, A2);
       stageB(A1, B0);
-      A1 = A2;
+      stageA(tid + BLOCK, A1);
       for (int r = 0; r < rounds; r++) {
-        stageA(tid + (r + 2) * BLOCK, A2);
         stageB(A1, B1);
+        stageA(tid + (r + 2) * BLOCK, A2);
         if (B0.live) {
-          const int i = B0.y * a.w + B0.x;
+          const int x_ = (int)(B0.xy & 0xffffu), y_ = (int)(B0.xy >> 16);
+          const int i = y_ * a.w + x_;
           acc[RS_NREF] += 1.f;
           if (!B0.q.in_image) {
             if (wasGood) wasGood[i] = 0;
@@ -1011,7 +1016,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
             PointOut o;
             eval_finish(a, B0.q, B0.t, B0.pz, B0.I_ref, B0.var, o);
             if (wasGood) wasGood[i] = o.good ? 1 : 0;
-            top3_insert(B0.x * a.h + B0.y, key0, key1, key2);
+            top3_insert(x_ * a.h + y_, key0, key1, key2);
             accumulate_point(o, acc);
           }
         }
@@ -1045,31 +1050,36 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
   // workgroup reduction through LDS: every lane parks its 41 accumulators in column `tid` of s_red (row stride
   // BLOCK + 1: conflict-free both ways), then thread (slice, k) adds a contiguous run of lanes of row k in lane order
   // and 41 threads add the slices — ~130 instructions per wave instead of 41 x 7 DPP steps
-  constexpr int RSLICE = BLOCK / RS_END;              // slices per row
+  constexpr int RSLICE = BLOCK / CPP;                  // slices per row
   constexpr int RRUN = (BLOCK + RSLICE - 1) / RSLICE;  // lanes per slice
 #pragma unroll
-  for (int k = 0; k < RS_END; k++) s_red[k * (BLOCK + 1) + tid] = acc[k];
-  __syncthreads();
-  {
-    const int slice = tid / RS_END, k = tid - slice * RS_END;
-    if (slice < RSLICE) {
-      const float* row = s_red + k * (BLOCK + 1);
-      const int j0 = slice * RRUN;
-      float v[RRUN];
+  for (int hp = 0; hp < NPASS; hp++) {
+    if (hp > 0) __syncthreads();
 #pragma unroll
-      for (int j = 0; j < RRUN; j++) v[j] = row[j0 + j];   // unconditional: the run may spill 2 words into the next row (allocated)
-      float s = 0.f;
+    for (int k = 0; k < CPP; k++)
+      if (hp * CPP + k < RS_END) s_red[k * (BLOCK + 1) + tid] = acc[hp * CPP + k];
+    __syncthreads();
+    {
+      const int slice = tid / CPP, k = tid - slice * CPP;
+      if (slice < RSLICE) {
+        const float* row = s_red + k * (BLOCK + 1);
+        const int j0 = slice * RRUN;
+        float v[RRUN];
 #pragma unroll
-      for (int j = 0; j < RRUN; j++) s += (j0 + j < BLOCK) ? v[j] : 0.f;
-      s_sum[slice][k] = s;
+        for (int j = 0; j < RRUN; j++) v[j] = row[j0 + j];   // unconditional: the run may spill 2 words into the next row (allocated)
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < RRUN; j++) s += (j0 + j < BLOCK) ? v[j] : 0.f;
+        s_sum[slice][k] = s;
+      }
     }
-  }
-  __syncthreads();
-  if (tid < RS_END) {
-    float s = s_sum[0][tid];
+    __syncthreads();
+    if (tid < CPP && hp * CPP + tid < RS_END) {
+      float s = s_sum[0][tid];
 #pragma unroll
-    for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
-    sums_out[(size_t)tid * max_rows + tile] = s;
+      for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
+      sums_out[(size_t)(hp * CPP + tid) * max_rows + tile] = s;
+    }
   }
   block_top3(key0, key1, key2, s_wtop, s_top);
   if (tid == 0) topkey_out[tile] = make_int4(s_top[0], s_top[1], s_top[2], -1);
@@ -1093,6 +1103,11 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 #endif
 }
 
+template <int BLOCK, bool BATCH, int MODE = TS_FUSED>
+__global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
+                                                       TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
+  track_step_impl<BLOCK, BATCH, MODE>(jobv, jobs, st2, sc, out, parity, first);
+}
 // checkPermaRefOverlap (SE3Tracker.cpp:121-157): usage only, explicit point list
 __global__ __launch_bounds__(256) void k_overlap(const float* __restrict__ pos, int n, EvalCtx a, float* __restrict__ out) {
   __shared__ float s_w[4];
@@ -1229,7 +1244,7 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
     // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
     long long px = ((long long)work * t->batch_jobs / 512 + 1023) & ~1023LL;
     if (px < 1024) px = 1024;
-    if (px > 8192) px = 8192;
+    if (px > 8192) px = 8192;                                  // the strip's list lives in the reduction's LDS (10545 words)
     while ((work + px - 1) / px > t->max_blocks) px += 1024;   // cannot happen below 2.6 Mpixel levels
     L.tilePx = (int)px;
     L.nblocks = (int)((work + px - 1) / px);
