@@ -715,6 +715,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   const float* topval_in = sc.topval + (size_t)parity * max_rows * 96;
   float* topval_out = sc.topval + (size_t)outp * max_rows * 96;
 #ifdef LSD_PHASE_TRACE
+  __shared__ unsigned long long* s_trp;
   unsigned long long* tr_ = sc.trace;
   if (blockIdx.x == 0 && tid == 0) {
     unsigned long long n = sc.trace[0];
@@ -722,6 +723,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     tr_ = sc.trace + 1 + (n % 4096) * 20;
     for (int k = 0; k < 20; k++) tr_[k] = 0;
     tr_[8] = wall_clock64();
+    s_trp = tr_;
   }
 #endif
   PHASE_MARK(0);
@@ -775,6 +777,9 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
           }
         }
         s_sum[slice][col] = s;
+#ifdef LSD_PHASE_TRACE
+        if (blockIdx.x == 0 && tid == 0) tr_[17] = clock64();
+#endif
       } else if (t == SUMW * 64 - 1) {
         stage_lm_par(job, level, s_par);
       }
@@ -852,6 +857,9 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         }
       }
     }
+#ifdef LSD_PHASE_TRACE
+    if (blockIdx.x == 0 && tid == SUMW * 64) s_trp[18] = clock64();
+#endif
     __syncthreads();
     PHASE_MARK(2);
     if (wave == 0) {

@@ -40,6 +40,15 @@ if path and os.path.exists(path):
             dd = np.diff(e, axis=1)
             print("LM (proposing launches, %d): " % len(lm) + ", ".join("%s %.2f us" % (n, np.median(dd[:, k]) / ghz / 1e3) for k, n in
                   enumerate(["epilogue", "decision+A/b", "matrix load", "LDLT", "exp/mul/store"])))
+    if a.shape[1] >= 19:
+        both = full[(full[:, 17] > 0) & (full[:, 18] > 0)]
+        if len(both):
+            print("inside sums+tail (from the state barrier): sums branch %.2f us, tail branch %.2f us (median, %d launches)" % (
+                np.median(both[:, 17] - both[:, 1]) / ghz / 1e3, np.median(both[:, 18] - both[:, 1]) / ghz / 1e3, len(both)))
+            for lvl in sorted(set(both[:, 10].astype(int))):
+                m = both[:, 10].astype(int) == lvl
+                print("   level %d: sums %.2f us, tail %.2f us" % (lvl, np.median(both[m][:, 17] - both[m][:, 1]) / ghz / 1e3,
+                                                                  np.median(both[m][:, 18] - both[m][:, 1]) / ghz / 1e3))
     for lvl in sorted(set(full[:, 10].astype(int))):
         m = full[:, 10].astype(int) == lvl
         print("level %d (nb=%d, %d launches): " % (lvl, int(full[m][0, 11]), m.sum()) +
