@@ -610,7 +610,14 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
   __shared__ double s_sum[256];
   __shared__ int s_cnt[256];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * 32 - HALO, y0 = blockIdx.y * 8 - HALO;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and every tile re-reads a 4-pixel halo of its
+  // neighbours: give XCD x the contiguous tile range [x nt/8, (x+1) nt/8) (whole bands of tile rows), so that a halo line is
+  // fetched into one L2 instead of into the L2s of up to four XCDs.
+  const int nt = gridDim.x * gridDim.y;
+  const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+  const int tIdx = (nt & 7) == 0 ? (lin & 7) * (nt >> 3) + (lin >> 3) : lin;
+  const int tbx = tIdx % gridDim.x, tby = tIdx / gridDim.x;
+  const int x0 = tbx * 32 - HALO, y0 = tby * 8 - HALO;
   const int w = a.w, h = a.h;
 
   // ---- tile load (unconditional, clamped addresses; out-of-image entries are invalid) ----
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
       __syncthreads();
     }
     if (tid == 0) {
-      const int b = blockIdx.x + blockIdx.y * gridDim.x;
+      const int b = tIdx;
       partials[2 * b] = s_sum[0];
       partials[2 * b + 1] = (double)s_cnt[0];
     }
