@@ -208,7 +208,7 @@ def main():
             traffic, traffic_src = pmc_traffic()
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "k_track_step (LM step + fused K0+K1+K2+K3 residual evaluation)", "launches": int(res_launches),
+                        "kernel": "k_track_step (LM step + fused K0+K1+K2+K3 residual evaluation)", "launches": int(res_launches), "launches_note": "HIP events bracket every 8th trackFrame call of the timed region",
                         "avg_launch_us": res_ms / res_launches * 1e3,
                         "algorithmic_bytes_per_launch": res_bytes / res_launches}
         out = {

@@ -130,6 +130,7 @@ struct lsdhip_ctx {
   hipStream_t stream = nullptr;
   // profiling of the residual kernel (bench.py roofline leg)
   bool prof_on = false;
+  unsigned prof_tick = 0;                // trackFrame jobs seen while profiling (every 8th is timed)
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   bool prof_pending = false;             // ev_a / ev_b of the last launch batch not yet read
   double prof_ms = 0, prof_bytes = 0;
