@@ -8,8 +8,8 @@ KF_EVERY-th frame finalizeKeyFrame + createKeyFrame (propagate, 2x regularise, f
 Inputs (the rendered uint8 frames) are resident in HBM before the timed region starts.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank runs an independent sequence
-(weak scaling; BASELINE.json configs[3]) and the finished keyframes' inverse-depth planes are collected on rank 0 with
-an RCCL gather over xGMI — the only exchange step of the path.
+(weak scaling; BASELINE.json configs[3]).  Finished keyframes' inverse-depth planes leave the C++ loop through a device
+ring and are collected on rank 0 with one RCCL gather over xGMI per batch of frames — the only exchange step of the path.
 
 Prints ONE JSON line on rank 0.
 """
@@ -120,7 +120,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # LSD_FORCE_DIST=1: run the RCCL path (process group, keyframe gather, barriers) even with one rank — a one-GPU check of the N > 1 code
+    distributed = world > 1 or os.environ.get("LSD_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     torch.cuda.set_device(local_rank)
@@ -150,25 +151,32 @@ def main():
     L = capi.lib()
     ctx_h = loop.ctx_handle()
 
-    # per-keyframe gather (RCCL over xGMI): smoothed idepth + variance planes of finished keyframes -> rank 0
-    from lsd_slam_amd.multigpu import KeyframeGather
-    kg = KeyframeGather((2, h, w), torch.device("cuda", local_rank))
-    state = {"fi": 0}
+    # Finished keyframes leave the loop through a device ring (smoothed idepth + variance planes, copied on the loop's
+    # stream); after every batch of frames the ring's new entries are collected on rank 0 with ONE gather (RCCL over xGMI) —
+    # the only exchange step of the path.  With one rank the export still runs, so per-GPU work is the same for every N.
+    from lsd_slam_amd.multigpu import gather_keyframe_ring
+    RING = 32
+    ring = torch.empty((RING, 2, h, w), dtype=torch.float32, device=torch.device("cuda", local_rank))
+    loop.set_keyframe_ring(ring.data_ptr(), RING)
+    recv = [torch.empty_like(ring) for _ in range(world)] if (distributed and rank == 0) else None
+    state = {"fi": 0, "exported": 0, "gathered_bytes": 0}
 
     def run_frames(n):
-        """n frames through the C++ loop; with N > 1 the loop returns after every new keyframe for the gather"""
+        """n frames through the C++ loop in batches that produce at most RING keyframes; one gather per batch"""
         left = n
         while left > 0:
-            ptrs = [ptr(state["fi"] + 1 + k) for k in range(left)]
-            kf_before = loop.stats().keyframes if distributed else 0
-            done, _ = loop.run(ptrs, stop_at_keyframe=distributed)
+            m = min(left, RING * KF_EVERY)
+            ptrs = [ptr(state["fi"] + 1 + k) for k in range(m)]
+            loop.set_keyframe_ring(ring.data_ptr(), RING)       # the batch's keyframes land in ring[0:new]
+            done, _ = loop.run(ptrs)                            # returns with the stream drained: the ring is complete
             state["fi"] += done
             left -= done
-            if distributed and loop.stats().keyframes > kf_before:
-                kg.submit(lambda buf: loop.copy_keyframe_planes(buf[0].data_ptr(), buf[1].data_ptr()))
+            new = loop.keyframes_exported()
+            state["exported"] += new
+            if distributed:
+                state["gathered_bytes"] += gather_keyframe_ring(ring, new, recv)
 
     run_frames(args.warmup)
-    kg.wait()
 
     # timed region: exactly K steps between barrier + synchronize
     loop.reset_stats()
@@ -182,7 +190,6 @@ def main():
     clock = time.perf_counter
     t0 = clock()
     run_frames(args.steps)
-    kg.wait()
     capi.check(L.lsdhip_ctx_synchronize(ctx_h))
     torch.cuda.synchronize()
     if distributed:
@@ -218,7 +225,7 @@ def main():
             "config": {"workload": "%dx%d 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
                                    "(BASELINE.json configs[%d]); synthetic scene S1, GT-depth init, new keyframe every %d frames"
                                    % (w, h, 1 if (w, h) == (640, 480) else 2, KF_EVERY),
-                       "width": w, "height": h, "parallelism": "1 sequence per GPU, RCCL gather of keyframe depth planes"},
+                       "width": w, "height": h, "parallelism": "1 sequence per GPU; finished keyframes' depth planes exported to a device ring and gathered to rank 0 (RCCL) once per batch"},
             "track_fps": st.frames / st.seconds_track if st.seconds_track > 0 else None,
             "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,
             "keyframe_ms": st.seconds_keyframe / st.keyframes * 1e3 if st.keyframes > 0 else None,

@@ -29,6 +29,12 @@ int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out);
 int lsdloop_reset_stats(lsdloop* l);
 /* smoothed idepth / variance planes of the current keyframe, device to device (the multi-GPU gather payload) */
 int lsdloop_copy_keyframe_planes(lsdloop* l, float* idepth_dev, float* idepthVar_dev);
+/* Export of finished keyframes without leaving the loop: from now on every keyframe that is finalised has its (idepth,
+ * idepthVar) level-0 planes copied (device to device, on the loop's stream) into slot (count % slots) of ring_dev, a device
+ * buffer of slots x 2 x w x h floats; count restarts at 0.  ring_dev = NULL switches the export off.
+ * lsdloop_keyframes_exported returns count.  The copies are complete when lsdloop_run returns. */
+int lsdloop_set_keyframe_ring(lsdloop* l, float* ring_dev, int slots);
+long long lsdloop_keyframes_exported(lsdloop* l);
 void* lsdloop_ctx(lsdloop* l);   /* the lsdhip_ctx* the loop runs on (prof hooks, stream) */
 const char* lsdloop_last_error(void);
 #ifdef __cplusplus

@@ -1638,7 +1638,7 @@ extern "C" int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_d
   size_t n = (size_t)c->w * c->h;
   HIPCHK(hipMemcpyAsync(idepth_dev, dm->activeKeyFrame->d_idepth[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(var_dev, dm->activeKeyFrame->d_idepthVar[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));   // asynchronous contexts: ordered on the stream, see lsdhip_ctx_synchronize
   return LSDHIP_OK;
 }
 

@@ -18,7 +18,8 @@ class LoopStats(C.Structure):
 
 
 EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop_get_stats", "lsdloop_reset_stats",
-                    "lsdloop_copy_keyframe_planes", "lsdloop_ctx", "lsdloop_last_error"]
+                    "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
+                    "lsdloop_last_error"]
 
 
 def lib():
@@ -41,6 +42,10 @@ def lib():
         L.lsdloop_reset_stats.argtypes = [vp]
         L.lsdloop_copy_keyframe_planes.restype = i
         L.lsdloop_copy_keyframe_planes.argtypes = [vp, vp, vp]
+        L.lsdloop_set_keyframe_ring.restype = i
+        L.lsdloop_set_keyframe_ring.argtypes = [vp, vp, i]
+        L.lsdloop_keyframes_exported.restype = C.c_longlong
+        L.lsdloop_keyframes_exported.argtypes = [vp]
         L.lsdloop_ctx.restype = vp
         L.lsdloop_ctx.argtypes = [vp]
         L.lsdloop_last_error.restype = C.c_char_p
@@ -95,6 +100,13 @@ class DriverLoop:
 
     def copy_keyframe_planes(self, idepth_ptr, var_ptr):
         _check(self.L.lsdloop_copy_keyframe_planes(self.h_, C.c_void_p(idepth_ptr), C.c_void_p(var_ptr)))
+
+    def set_keyframe_ring(self, ring_ptr, slots):
+        """finished keyframes' (idepth, idepthVar) planes go to slot (count % slots) of the device buffer; None switches it off"""
+        _check(self.L.lsdloop_set_keyframe_ring(self.h_, C.c_void_p(ring_ptr) if ring_ptr else None, slots))
+
+    def keyframes_exported(self):
+        return int(self.L.lsdloop_keyframes_exported(self.h_))
 
     def ctx_handle(self):
         return self.L.lsdloop_ctx(self.h_)

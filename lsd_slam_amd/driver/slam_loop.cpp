@@ -17,6 +17,9 @@ struct lsdloop {
   lsdloop_stats st{};
   double wall = 0;                       // wall time inside lsdloop_run since the last reset
   double gpu0[3] = {0, 0, 0};            // DepthMap GPU times at the last reset
+  float* ring = nullptr;                 // lsdloop_set_keyframe_ring
+  int ring_slots = 0;
+  long long ring_count = 0;
 };
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -105,4 +108,19 @@ extern "C" int lsdloop_copy_keyframe_planes(lsdloop* l, float* idepth_dev, float
   try { l->loop->map.copyPlanesToDevice(idepth_dev, var_dev); return LSDHIP_OK; }
   catch (const Error& e) { g_err = e.what(); return e.status; }
 }
+extern "C" int lsdloop_set_keyframe_ring(lsdloop* l, float* ring_dev, int slots) {
+  if (!l || (ring_dev && slots < 1)) return LSDHIP_E_ARG;
+  l->ring = ring_dev;
+  l->ring_slots = slots;
+  l->ring_count = 0;
+  if (!ring_dev) { l->loop->onKeyframeFinished = nullptr; return LSDHIP_OK; }
+  const size_t plane = (size_t)l->ctx->width() * l->ctx->height();
+  l->loop->onKeyframeFinished = [l, plane](Frame&, DepthMap& map) {
+    float* slot = l->ring + (size_t)(l->ring_count % l->ring_slots) * 2 * plane;
+    map.copyPlanesToDevice(slot, slot + plane);
+    l->ring_count++;
+  };
+  return LSDHIP_OK;
+}
+extern "C" long long lsdloop_keyframes_exported(lsdloop* l) { return l ? l->ring_count : -1; }
 extern "C" void* lsdloop_ctx(lsdloop* l) { return l ? (void*)l->ctx->handle() : nullptr; }

@@ -40,3 +40,16 @@ class KeyframeGather:
                 self.collected.append(self.send.clone()[None])
             return
         self.pending = dist.gather(self.send, self.recv, dst=self.root, async_op=True)
+
+
+def gather_keyframe_ring(ring, new, recv, root=0):
+    """One collective per batch of frames: the first `new` slots of every rank's keyframe ring (slots x 2 x h x w, filled by
+    lsdloop_set_keyframe_ring while the batch ran) are gathered into recv[r][:new] on `root`; recv is None elsewhere.
+    All ranks must pass the same `new` (they run the same keyframe cadence).  Returns the bytes this rank contributed."""
+    if new <= 0:
+        return 0
+    rank = dist.get_rank()
+    dist.gather(ring[:new], [r[:new] for r in recv] if rank == root else None, dst=root)
+    if ring.is_cuda:
+        torch.cuda.current_stream(ring.device).synchronize()   # the ring is refilled from liblsdhip's stream by the next batch
+    return new * ring[0].numel() * ring.element_size()

@@ -24,6 +24,22 @@ if rank == 0:
         for r in range(world):   # result of the N-rank run == concatenation of N single-rank runs, bitwise
             assert torch.equal(rec[r], torch.full((2, 12, 16), float(100 * r + k)))
     print("GATHER_OK")
+# the bench's exchange step: one gather per batch of the first `new` ring slots
+from lsd_slam_amd.multigpu import gather_keyframe_ring
+ring = torch.zeros((5, 2, 6, 8))
+for batch, new in enumerate((3, 0, 5)):
+    for k in range(new):
+        ring[k].fill_(1000.0 * batch + 100 * rank + k)
+    recv = [torch.zeros_like(ring) for _ in range(world)] if rank == 0 else None
+    nbytes = gather_keyframe_ring(ring, new, recv)
+    assert nbytes == new * 2 * 6 * 8 * 4
+    if rank == 0:
+        for r in range(world):
+            for k in range(new):
+                assert torch.equal(recv[r][k], torch.full((2, 6, 8), 1000.0 * batch + 100 * r + k))
+            assert torch.count_nonzero(recv[r][new:]) == 0
+if rank == 0:
+    print("RING_OK")
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -44,7 +60,7 @@ def test_keyframe_gather_world2_gloo(tmp_path):
            "--master-port", str(free_port()), str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "GATHER_OK" in out.stdout
+    assert "GATHER_OK" in out.stdout and "RING_OK" in out.stdout
 
 
 def test_single_rank_is_a_noop_gather():
