@@ -15,6 +15,8 @@
 // Quirks kept: the SSE loops ignore the last size % 4 in-image points (x-outer / y-inner order) for the residual sums and
 // both systems; LGS6::updateSSE counts 6 and LGS4::updateSSE 4 constraints per group of four points.
 #include "lsdhip_internal.hpp"
+#include <atomic>
+#include <chrono>
 
 #define S3_BLOCK 256
 enum {
@@ -39,7 +41,8 @@ struct Sim3Job {
   float* rows;                              // [nblocks][64] partial sums
   int4* topkey;                             // [nblocks] three largest order keys of in-image points
   float* topval;                            // [nblocks][3][48] their tail contributions
-  float* record;                            // pinned host: S3_END totals (tail-corrected)
+  float* record;                            // pinned host: S3_END totals (tail-corrected); word 63 = seq, raised last
+  int seq;
 };
 
 __global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Job a) {
@@ -211,29 +214,49 @@ __global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Job a) {
   __shared__ float s_part[4][64];
   __shared__ float s_tot[64];
   __shared__ int s_keys[3], s_src[3];
+  __shared__ int s_max;
   const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
   {
-    // slice s sums rows [s R, s R + R) of column `col`, in row order
+    // slice s sums rows [s R, s R + R) of column `col`: four interleaved accumulators (rows = 0..3 mod 4) so that the loads
+    // overlap, combined in a fixed order
     const int R = (a.nblocks + 3) / 4;
-    float s = 0.f;
-    for (int r = slice * R; r < (slice + 1) * R && r < a.nblocks; r++) s += a.rows[(size_t)r * 64 + col];
-    s_part[slice][col] = s;
-  }
-  if (tid == 0) {
-    // global top-3 of the tiles' top-3 lists (a few hundred candidates, once per evaluation)
-    int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
-    for (int r = 0; r < a.nblocks; r++) {
-      const int4 kv = a.topkey[r];
-      const int ks[3] = {kv.x, kv.y, kv.z};
-      for (int q = 0; q < 3; q++) {
-        const int k = ks[q], e = r * 3 + q;
-        if (k > k0) { k2 = k1; e2 = e1; k1 = k0; e1 = e0; k0 = k; e0 = e; }
-        else if (k > k1) { k2 = k1; e2 = e1; k1 = k; e1 = e; }
-        else if (k > k2) { k2 = k; e2 = e; }
-      }
+    const int r0 = slice * R, r1 = min((slice + 1) * R, a.nblocks);
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      const float v0 = a.rows[(size_t)r * 64 + col], v1 = a.rows[(size_t)(r + 1) * 64 + col];
+      const float v2 = a.rows[(size_t)(r + 2) * 64 + col], v3 = a.rows[(size_t)(r + 3) * 64 + col];
+      acc4[0] += v0; acc4[1] += v1; acc4[2] += v2; acc4[3] += v3;
     }
-    s_keys[0] = k0; s_keys[1] = k1; s_keys[2] = k2;
-    s_src[0] = e0; s_src[1] = e1; s_src[2] = e2;
+    float tailsum = 0.f;
+    for (; r < r1; r++) tailsum += a.rows[(size_t)r * 64 + col];
+    s_part[slice][col] = ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + tailsum;
+  }
+  // global top-3 of the tiles' top-3 lists: per-thread top-3 over tiles tid, tid + 256, ..., then three rounds of an LDS max
+  int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
+  for (int r = tid; r < a.nblocks; r += 256) {
+    const int4 kv = a.topkey[r];
+    const int ks[3] = {kv.x, kv.y, kv.z};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int k = ks[q], e = r * 3 + q;
+      const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
+      k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? e : e2);
+      k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? e : e1);
+      k0 = g0 ? k : k0; e0 = g0 ? e : e0;
+    }
+  }
+  if (tid == 0) s_max = -1;
+  __syncthreads();
+  for (int rr = 0; rr < 3; rr++) {
+    if (k0 >= 0) atomicMax(&s_max, k0);
+    __syncthreads();
+    const int m = s_max;
+    if (tid == 0) s_keys[rr] = m;
+    if (m >= 0 && k0 == m) { s_src[rr] = e0; k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }   // keys are unique: one owner
+    __syncthreads();
+    if (tid == 0) s_max = -1;
+    __syncthreads();
   }
   __syncthreads();
   if (tid < 64) {
@@ -248,7 +271,14 @@ __global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Job a) {
     if (tid >= S3_TAIL0 && tid < S3_END)
       for (int k = 0; k < need; k++)
         if (s_keys[k] >= 0) s -= a.topval[(size_t)s_src[k] * 48 + (tid - S3_TAIL0)];
-    a.record[tid] = tid < S3_END ? s : 0.f;
+    if (tid < 63) a.record[tid] = tid < S3_END ? s : 0.f;
+  }
+  // the host polls word 63 instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the evaluation)
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    ((volatile int*)a.record)[63] = a.seq;
+    __threadfence_system();
   }
 }
 
@@ -390,6 +420,7 @@ struct lsdhip_sim3tracker {
   int4* d_topkey = nullptr;
   float* d_topval = nullptr;
   float* h_record = nullptr;   // pinned, device-mapped
+  int seq = 0;                 // evaluation counter, echoed by k_sim3_finalize in word 63 of the record
   int max_blocks = 0;
 };
 
@@ -404,6 +435,7 @@ extern "C" int lsdhip_sim3tracker_create(lsdhip_ctx* c, lsdhip_sim3tracker** out
   HIPCHK(hipMalloc((void**)&t->d_topval, (size_t)t->max_blocks * 3 * 48 * 4));
   HIPCHK(hipMemsetAsync(t->d_topval, 0, (size_t)t->max_blocks * 3 * 48 * 4, c->stream));
   HIPCHK(hipHostMalloc((void**)&t->h_record, 64 * 4, hipHostMallocMapped));
+  memset(t->h_record, 0, 64 * 4);
   *out = t;
   return LSDHIP_OK;
 }
@@ -467,10 +499,25 @@ static int sim3_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* 
   a.cameraPixelNoise2 = c->params.cameraPixelNoise2; a.var_weight = t->var_weight; a.huber_d = t->huber_d;
   a.rows = t->d_rows; a.topkey = t->d_topkey; a.topval = t->d_topval;
   HIPCHK(hipHostGetDevicePointer((void**)&a.record, t->h_record, 0));
+  a.seq = ++t->seq;
   hipLaunchKernelGGL(k_sim3_eval, dim3(a.nblocks), dim3(S3_BLOCK), 0, c->stream, a);
   hipLaunchKernelGGL(k_sim3_finalize, dim3(1), dim3(256), 0, c->stream, a);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
+  {
+    volatile const int* flag = (volatile const int*)t->h_record + 63;
+    const auto tStart = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != a.seq) {
+      if ((++spins & 4095u) == 0) {
+        hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) { lsd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return LSDHIP_E_HIP; }
+        if (std::chrono::steady_clock::now() - tStart > std::chrono::seconds(5)) { HIPCHK(hipStreamSynchronize(c->stream)); break; }
+      }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*flag != a.seq) { lsd_set_error("Sim3 evaluation did not complete"); return LSDHIP_E_STATE; }
+  }
   const float* r = t->h_record;
   ev->M = (int)r[S3_M];
   ev->pointUsage = r[S3_USAGE] / r[S3_NREF];

@@ -392,6 +392,27 @@ def test_update_keyframe_end_to_end(oracle, hip):
         assert_bit_equal(kfg.idepthVar(lvl), kfo.plane("idepthVar", lvl), "kf idepthVar L%d" % lvl)
 
 
+def test_initialize_randomly_draws_the_same_rand_sequence(oracle, hip):
+    """DepthMap::initializeRandomly (DepthMap.cpp:883-916) consumes the C library's rand() once per pixel above minUseGrad,
+    in row-major order: with the same seed both sides must produce the same map, and the keyframe planes setDepth derives."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 1)
+    kfo, kfg = oracle.Frame(0, frames[0], K), hip.Frame(ctx, 0, frames[0])
+    dmo, dmg = oracle.DepthMap(w, h, K), hip.DepthMap(ctx)
+    libc.srand(12345)
+    dmo.init_random(kfo)
+    libc.srand(12345)
+    dmg.initializeRandomly(kfg)
+    ho = dmo.get()
+    assert int(ho["isValid"].sum()) > 1000
+    assert_hyp_equal(dmg.currentDepthMap(), ho, "initializeRandomly")
+    for lvl in range(5):
+        assert_bit_equal(kfg.idepth(lvl), kfo.plane("idepth", lvl), "kf idepth L%d" % lvl)
+        assert_bit_equal(kfg.idepthVar(lvl), kfo.plane("idepthVar", lvl), "kf idepthVar L%d" % lvl)
+
+
 @pytest.mark.parametrize("use_mask", [True, False])
 def test_propagate_and_create_keyframe(oracle, hip, use_mask):
     w, h = 640, 480
