@@ -483,10 +483,12 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
 // K4: observeDepthRow over the whole map, one pixel per lane.  (Compacting the ~20 % of pixels that reach the epipolar
 // search into dense waves, and batching the loads of four walk steps, were both measured and gave nothing: the kernel
 // is bound by chains of dependent first-touch loads, not by issue slots — profiles/r01_notes.md.)
-template <bool ONE>
-__global__ __launch_bounds__(256) void k_observe(ObserveArgs a) {
+// ROWS = rows of the 32-pixel-wide tile a workgroup owns (workgroup size 32 * ROWS).  The kernel has no barriers and no LDS,
+// so the workgroup is only a scheduling unit: small workgroups free their wave slots as soon as their own lanes are done.
+template <bool ONE, int ROWS>
+__global__ __launch_bounds__(32 * ROWS) void k_observe(ObserveArgs a) {
   const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int y = blockIdx.y * ROWS + (threadIdx.x >> 5);
   OBS_MARK(0);
   observe_pixel<ONE>(a, x, y);
   OBS_MARK(7);
@@ -1290,9 +1292,22 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   }
 #endif
   {
-    const dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
-    if (n == 1) hipLaunchKernelGGL(k_observe<true>, grid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_observe<false>, grid, dim3(256), 0, c->stream, a);
+#ifdef LSD_PHASE_TRACE
+    constexpr int rows = 8;   // the trace buffer is laid out for 32x8 tiles
+#else
+    static const int rows = [] { const char* e = getenv("LSDHIP_OBS_ROWS"); int r = e ? atoi(e) : 2; return (r == 8 || r == 4) ? r : 2; }();   // 64-thread workgroups measured best (+2.5 % Mpixel/s over 256)
+#endif
+    const dim3 grid((c->w + 31) / 32, (c->h + rows - 1) / rows);
+    if (rows == 8) {
+      if (n == 1) hipLaunchKernelGGL((k_observe<true, 8>), grid, dim3(256), 0, c->stream, a);
+      else hipLaunchKernelGGL((k_observe<false, 8>), grid, dim3(256), 0, c->stream, a);
+    } else if (rows == 4) {
+      if (n == 1) hipLaunchKernelGGL((k_observe<true, 4>), grid, dim3(128), 0, c->stream, a);
+      else hipLaunchKernelGGL((k_observe<false, 4>), grid, dim3(128), 0, c->stream, a);
+    } else {
+      if (n == 1) hipLaunchKernelGGL((k_observe<true, 2>), grid, dim3(64), 0, c->stream, a);
+      else hipLaunchKernelGGL((k_observe<false, 2>), grid, dim3(64), 0, c->stream, a);
+    }
   }
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
