@@ -93,8 +93,8 @@ def cpu_baseline(frames, depth0, K, n_frames, w, h):
     total = time.perf_counter() - t_all
     return {
         "value": n_frames / total, "unit": "frames/s", "cores": 4, "kind": "port",
-        "sample": "%d frames of the same 640x480 track+map loop (oracle -O3 build: SSE tracker on 1 thread, depth map on 4 "
-                  "threads x 10-row chunks as the reference)" % n_frames,
+        "sample": "%d frames of the same %dx%d track+map loop (oracle -O3 build: SSE tracker on 1 thread, depth map on 4 "
+                  "threads x 10-row chunks as the reference)" % (n_frames, w, h),
         "track_fps": n_frames / t_track, "depth_mpix_per_s": (w * h * n_upd) / t_map / 1e6 if t_map > 0 else None,
         "seconds": total,
     }
@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=250)
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--scene", type=str, default="S1", choices=["S1", "S2"],
+                    help="synthetic scene (SURVEY.md §8(d)): S1 smooth texture (configs[1]); S2 Voronoi edge texture (configs[2], ~23 %% semi-dense)")
     ap.add_argument("--seq-frames", type=int, default=50,
                     help="synthetic frames to render (one camera revolution = 50); fewer are played back and forth")
     args = ap.parse_args()
@@ -134,7 +136,7 @@ def main():
 
     w, h = args.width, args.height
     n_seq = args.seq_frames
-    frames, depth0, K, gt = synth.make_sequence(w, h, n_seq, seq_index=rank)
+    frames, depth0, K, gt = synth.make_sequence(w, h, n_seq, seq_index=rank, kind=args.scene)
     d_frames = torch.from_numpy(frames).cuda(local_rank)           # inputs resident in HBM
     torch.cuda.synchronize()
     if n_seq >= 50:
@@ -212,7 +214,8 @@ def main():
         roofline = None
         if res_launches > 0 and res_ms > 0:
             achieved = (res_bytes / res_launches) / (res_ms / res_launches * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic()
+            # the committed PMC pass was taken on the default workload; other sizes / scenes report no counter traffic
+            traffic, traffic_src = pmc_traffic() if ((w, h) == (640, 480) and args.scene == "S1") else (None, None)
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "k_track_step (LM step + fused K0+K1+K2+K3 residual evaluation)", "launches": int(res_launches), "launches_note": "HIP events bracket every 8th trackFrame call of the timed region",
@@ -223,8 +226,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
-                                   "(BASELINE.json configs[%d]); synthetic scene S1, GT-depth init, new keyframe every %d frames"
-                                   % (w, h, 1 if (w, h) == (640, 480) else 2, KF_EVERY),
+                                   "(BASELINE.json configs[%d]); synthetic scene %s, GT-depth init, new keyframe every %d frames"
+                                   % (w, h, 1 if (w, h) == (640, 480) else 2, args.scene, KF_EVERY),
                        "width": w, "height": h, "parallelism": "1 sequence per GPU; finished keyframes' depth planes exported to a device ring and gathered to rank 0 (RCCL) once per batch"},
             "track_fps": st.frames / st.seconds_track if st.seconds_track > 0 else None,
             "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,
