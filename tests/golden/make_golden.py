@@ -75,6 +75,24 @@ def compute(frames, depth0, K):
         g["update_" + k] = digest(hyp[k][v])
     g["update_num_valid"] = np.array([int(v.sum())], np.int64)
     g["update_kf_idepth_L1"] = digest(kf.plane("idepth", 1))
+    # Sim3 tracker: keyframe 0 against frame 3 carrying a (scaled) copy of the depth, fixed Sim3 pose
+    kfa = po.Frame(0, frames[0], K)
+    kfa.set_depth_gt(depth0)
+    refa = po.TrackingReference()
+    refa.import_frame(kfa)
+    fb = po.Frame(3, frames[3], K)
+    fb.set_depth_gt((depth0 / 1.1).astype(np.float32))
+    T8 = np.concatenate([po.se3_exp(np.array([0.01, -0.005, 0.004, 0.003, -0.004, 0.006])), [1.05]])
+    s3 = po.Sim3Tracker(W, H, K, mode=po.SSE_EXACT_RCP)
+    srec = []
+    for lvl in (3, 2, 1):
+        r = s3.evaluate(refa, fb, T8, lvl, 1.0, 0.0)
+        srec.append([r.warped_size, r.numTermsD, r.numTermsP, r.num_constraints, r.pointUsage, r.sumResD, r.sumResP] + list(r.A) + list(r.b))
+    g["sim3_fixed_pose"] = T8
+    g["sim3_records"] = np.array(srec, np.float64)
+    rs = s3.track(refa, fb, np.array([1.0, 0, 0, 0, 0, 0, 0, 1.0]), 3, 1)
+    g["sim3_track_pose"] = np.array(rs.frameToRef, np.float64)
+    g["sim3_track_scalars"] = np.array([rs.lastResidual, rs.lastDepthResidual, rs.lastPhotometricResidual, rs.pointUsage, rs.diverged], np.float64)
     return g
 
 

@@ -93,3 +93,24 @@ def test_trackframe_and_update_match_golden(env):
     for k in ("idepth", "idepth_var", "idepth_smoothed", "idepth_var_smoothed"):
         assert np.array_equal(digest(hyp[k][v]), g["update_" + k]), k
     assert np.array_equal(digest(kf.idepth(1)), g["update_kf_idepth_L1"])
+
+
+def test_sim3_matches_golden_records(env):
+    la, g, ctx, kf = env
+    fb = la.Frame(ctx, 3, g["frames"][3])
+    fb.setDepthFromGroundTruth((g["depth0"] / 1.1).astype(np.float32))
+    s3 = la.Sim3Tracker(ctx)
+    for row, lvl in zip(g["sim3_records"], (3, 2, 1)):
+        r = s3.evaluate(kf, fb, g["sim3_fixed_pose"], lvl, 1.0, 0.0)
+        assert (r.warped_size, r.numTermsD, r.numTermsP, r.num_constraints) == tuple(row[:4]), lvl   # exact
+        assert r.pointUsage == pytest.approx(row[4], rel=2e-5)
+        assert r.sumResD == pytest.approx(row[5], rel=5e-5) and r.sumResP == pytest.approx(row[6], rel=5e-5)
+        A, b = np.array(row[7:56]), np.array(row[56:63])
+        assert np.abs(np.array(r.A) - A).max() <= 5e-5 * np.abs(A).max()
+        assert np.abs(np.array(r.b) - b).max() <= 5e-5 * np.abs(b).max()
+    est, rs = s3.trackFrameSim3(kf, fb, np.array([1.0, 0, 0, 0, 0, 0, 0, 1.0]), 3, 1)
+    gp, sc = g["sim3_track_pose"], g["sim3_track_scalars"]
+    assert int(rs.diverged) == int(sc[4])
+    dq = min(np.linalg.norm(est[:4] - gp[:4]), np.linalg.norm(est[:4] + gp[:4]))
+    assert dq < 1e-3 and np.linalg.norm(est[4:7] - gp[4:7]) < 2e-3 and est[7] == pytest.approx(gp[7], rel=2e-3)
+    assert rs.lastResidual == pytest.approx(sc[0], rel=3e-2) and rs.pointUsage == pytest.approx(sc[3], rel=1e-3)
