@@ -112,6 +112,10 @@ LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, 
   const int width = a.w, height = a.h;
   const float* __restrict__ kfImg = a.kfImage;
   const float* __restrict__ refImg = rf.image;
+  // the keyframe gradient taps of the geometric-error term (used after the search) depend on (u, v) only: issue their loads
+  // now so that they do not add a memory round trip after the walk
+  const float4* const gbp = a.kfGrad + (int)u + (int)v * width;
+  const float4 gt00 = gbp[0], gt10 = gbp[1], gt01 = gbp[width], gt11 = gbp[1 + width];
   float KinvP0 = a.fxi * u + a.cxi, KinvP1 = a.fyi * v + a.cyi, KinvP2 = 1.0f;
   float pInf0 = (rf.K_otherToThis_R[0] * KinvP0 + rf.K_otherToThis_R[1] * KinvP1) + rf.K_otherToThis_R[2] * KinvP2;
   float pInf1 = (rf.K_otherToThis_R[3] * KinvP0 + rf.K_otherToThis_R[4] * KinvP1) + rf.K_otherToThis_R[5] * KinvP2;
@@ -343,8 +347,7 @@ LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, 
     float dx = u - ix;
     float dy = v - iy;
     float dxdy = dx * dy;
-    const float4* bp = a.kfGrad + ix + iy * width;
-    float4 t00 = bp[0], t10 = bp[1], t01 = bp[width], t11 = bp[1 + width];
+    const float4 t00 = gt00, t10 = gt10, t01 = gt01, t11 = gt11;
     gI0 = dxdy * t11.x + (dy - dxdy) * t01.x + (dx - dxdy) * t10.x + (1 - dx - dy + dxdy) * t00.x;
     gI1 = dxdy * t11.y + (dy - dxdy) * t01.y + (dx - dxdy) * t10.y + (1 - dx - dy + dxdy) * t00.y;
   }
@@ -358,15 +361,17 @@ LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, 
 }
 
 // DepthMap::makeAndCheckEPL (DepthMap.cpp:184-234)
-LSD_HD bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x, int y, float* pepx, float* pepy) {
-  int idx = x + y * a.w;
+// (the four keyframe-image taps of the gradient travel as arguments: the caller loads them together with the other
+// per-pixel inputs, one memory round trip instead of one per check)
+LSD_HD bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x, int y, float kR, float kL, float kD, float kU, float* pepx,
+                               float* pepy) {
   float epx = -a.fx * rf.thisToOther_t[0] + rf.thisToOther_t[2] * (x - a.cx);
   float epy = -a.fy * rf.thisToOther_t[1] + rf.thisToOther_t[2] * (y - a.cy);
   if (__builtin_isnan(epx + epy)) return false;
   float eplLengthSquared = epx * epx + epy * epy;
   if (eplLengthSquared < MIN_EPL_LENGTH_SQUARED) return false;
-  float gx = a.kfImage[idx + 1] - a.kfImage[idx - 1];
-  float gy = a.kfImage[idx + a.w] - a.kfImage[idx - a.w];
+  float gx = kR - kL;
+  float gy = kD - kU;
   float eplGradSquared = gx * epx + gy * epy;
   eplGradSquared = eplGradSquared * eplGradSquared / eplLengthSquared;
   if (eplGradSquared < MIN_EPL_GRAD_SQUARED) return false;
@@ -384,21 +389,45 @@ template <bool ONE>
 LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int y) {
   if (x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3) return;
   const int idx = x + y * a.w;
+  // The per-pixel inputs are loaded in two batches, each issued before any of its values is tested, so that the checks
+  // below cost two memory round trips instead of one each (every plane was last written by a kernel on another XCD):
+  // batch 1 = what the cheap rejections need (13 B per pixel, every pixel), batch 2 = everything else of this pixel.
   const bool hasHypothesis = a.m.valid[idx] != 0;
   const float maxGrad = a.kfMaxGrad[idx];
+  const int blacklisted0 = a.m.blacklisted[idx];
+  const float nextID = a.m.nextID[idx];
   if (hasHypothesis && maxGrad < a.minUseGrad) { a.m.valid[idx] = 0; return; }
-  if (maxGrad < a.minUseGrad || a.m.blacklisted[idx] < MIN_BLACKLIST) return;
+  if (maxGrad < a.minUseGrad || blacklisted0 < MIN_BLACKLIST) return;
+
+  int refIdx = 0;
+  if (!hasHypothesis) {
+    refIdx = a.reactivated ? a.nRefs - 1 : 0;
+  } else if (!a.reactivated) {
+    int rel = (int)nextID - a.byIDOffset;
+    if (rel >= a.nByID) return;
+    refIdx = (ONE || rel < 0) ? 0 : a.refByID[rel];
+  } else {
+    refIdx = a.nRefs - 1;
+  }
+  const StereoRef& rf = ONE ? a.one : a.refs[refIdx];
+  const bool useMask = rf.parentIsKF && rf.wasGood != nullptr;
+  const uint8_t wasGoodHere = useMask ? rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)] : (uint8_t)1;
+  const float kR = a.kfImage[idx + 1], kL = a.kfImage[idx - 1], kD = a.kfImage[idx + a.w], kU = a.kfImage[idx - a.w];
+  const float idepth_smoothed = a.m.idepth_s[idx];
+  const float var_smoothed = a.m.var_s[idx];
+  const float var0 = a.m.var[idx];
+  const float idepth0 = a.m.idepth[idx];
+  const int validity0 = a.m.validity[idx];
 
   if (!hasHypothesis) {
     // observeDepthCreate (DepthMap.cpp:237-292)
-    const StereoRef& rf = ONE ? a.one : a.refs[a.reactivated ? a.nRefs - 1 : 0];
-    if (rf.parentIsKF && rf.wasGood != nullptr && !rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)]) return;
+    if (!wasGoodHere) return;
     float epx, epy;
-    if (!make_and_check_epl(a, rf, x, y, &epx, &epy)) return;
+    if (!make_and_check_epl(a, rf, x, y, kR, kL, kD, kU, &epx, &epy)) return;
     float new_u = x, new_v = y;
     float result_idepth = 0, result_var = 0, result_eplLength = 0;
     float error = do_line_stereo(a, rf, new_u, new_v, epx, epy, 0.0f, 1.0f, 1.0f / MIN_DEPTH, result_idepth, result_var, result_eplLength);
-    if (error == -3 || error == -2) a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1;
+    if (error == -3 || error == -2) a.m.blacklisted[idx] = blacklisted0 - 1;
     if (error < 0 || result_var > MAX_VAR) return;
     result_idepth = unzero(result_idepth);
     a.m.valid[idx] = 1;
@@ -413,21 +442,10 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
   }
 
   // observeDepthUpdate (DepthMap.cpp:294-473)
-  int refIdx;
-  const float nextID = a.m.nextID[idx];
-  if (!a.reactivated) {
-    int rel = (int)nextID - a.byIDOffset;
-    if (rel >= a.nByID) return;
-    refIdx = (ONE || rel < 0) ? 0 : a.refByID[rel];
-  } else
-    refIdx = a.nRefs - 1;
-  const StereoRef& rf = ONE ? a.one : a.refs[refIdx];
-  if (rf.parentIsKF && rf.wasGood != nullptr && !rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)]) return;
+  if (!wasGoodHere) return;
   float epx, epy;
-  if (!make_and_check_epl(a, rf, x, y, &epx, &epy)) return;
+  if (!make_and_check_epl(a, rf, x, y, kR, kL, kD, kU, &epx, &epy)) return;
 
-  const float idepth_smoothed = a.m.idepth_s[idx];
-  const float var_smoothed = a.m.var_s[idx];
   float sv = sqrtf(var_smoothed);
   float min_idepth = idepth_smoothed - sv * STEREO_EPL_VAR_FAC;
   float max_idepth = idepth_smoothed + sv * STEREO_EPL_VAR_FAC;
@@ -440,31 +458,31 @@ LSD_HD_NOINLINE void observe_pixel(const ObserveArgs& a, const int x, const int 
 
   if (error == -1) return;
   if (error == -2) {
-    int vc = a.m.validity[idx] - VALIDITY_COUNTER_DEC;
+    int vc = validity0 - VALIDITY_COUNTER_DEC;
     if (vc < 0) vc = 0;
     a.m.validity[idx] = vc;
     a.m.nextID[idx] = 0;
-    float nv = a.m.var[idx] * FAIL_VAR_INC_FAC;
+    float nv = var0 * FAIL_VAR_INC_FAC;
     a.m.var[idx] = nv;
-    if (nv > MAX_VAR) { a.m.valid[idx] = 0; a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1; }
+    if (nv > MAX_VAR) { a.m.valid[idx] = 0; a.m.blacklisted[idx] = blacklisted0 - 1; }
     return;
   }
   if (error == -3 || error == -4) return;
   if (DIFF_FAC_OBSERVE * diff * diff > result_var + var_smoothed) {
-    float nv = a.m.var[idx] * FAIL_VAR_INC_FAC;
+    float nv = var0 * FAIL_VAR_INC_FAC;
     a.m.var[idx] = nv;
     if (nv > MAX_VAR) a.m.valid[idx] = 0;
     return;
   }
   {
-    const float old_var = a.m.var[idx];
+    const float old_var = var0;
     float id_var = old_var * SUCC_VAR_INC_FAC;
     float w = result_var / (result_var + id_var);
-    float new_idepth = (1 - w) * result_idepth + w * a.m.idepth[idx];
+    float new_idepth = (1 - w) * result_idepth + w * idepth0;
     a.m.idepth[idx] = unzero(new_idepth);
     id_var = id_var * w;
     if (id_var < old_var) a.m.var[idx] = id_var;
-    int vc = a.m.validity[idx] + VALIDITY_COUNTER_INC;
+    int vc = validity0 + VALIDITY_COUNTER_INC;
     float absGrad = maxGrad;
     if (vc > VALIDITY_COUNTER_MAX + absGrad * (VALIDITY_COUNTER_MAX_VARIABLE) / 255.0f)
       vc = VALIDITY_COUNTER_MAX + absGrad * (VALIDITY_COUNTER_MAX_VARIABLE) / 255.0f;
