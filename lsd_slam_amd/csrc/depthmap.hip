@@ -222,8 +222,20 @@ LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, 
   float eeLast = -1;
   float e1A = NAN, e1B = NAN, e2A = NAN, e2B = NAN, e3A = NAN, e3B = NAN, e4A = NAN, e4B = NAN, e5A = NAN, e5B = NAN;
   int loopCBest = -1, loopCSecond = -1;
+  // The sample positions of the walk do not depend on the sampled values, so the loads of the next two steps are kept in
+  // flight while a step is evaluated (same positions, formed by the same additions as the loop's own cpx += incx; they stay
+  // inside the image: at most 4 samples beyond pClose, which is SAMPLE_POINT_TO_BORDER = 7 pixels away from the border).
+  float w1x = cpx + incx, w1y = cpy + incy;
+  float w2x = w1x + incx, w2y = w1y + incy;
+  float p2_0 = interp1(refImg, cpx + 2 * incx, cpy + 2 * incy, width);
+  float p2_1 = interp1(refImg, w1x + 2 * incx, w1y + 2 * incy, width);
   while ((((incx < 0) == (cpx > pClose0) && (incy < 0) == (cpy > pClose1)) || loopCounter == 0) && loopCounter < 1000) {
-    val_cp_p2 = interp1(refImg, cpx + 2 * incx, cpy + 2 * incy, width);
+    const float p2_2 = interp1(refImg, w2x + 2 * incx, w2y + 2 * incy, width);
+    val_cp_p2 = p2_0;
+    p2_0 = p2_1;
+    p2_1 = p2_2;
+    w2x += incx;
+    w2y += incy;
     float ee = 0;
     if (loopCounter % 2 == 0) {
       e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
