@@ -27,7 +27,7 @@ def make_pair(oracle, hip, w, h, n, seq_index=0):
 # ---------------------------------------------------------------------------------------------------------------
 # K-pyr
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("w,h", [(160, 128), (640, 480)])
+@pytest.mark.parametrize("w,h", [(160, 128), (176, 144), (640, 480)])   # 176 = 5.5 tiles of 32: partial tiles, odd level-4 width
 def test_pyramids_bit_exact(oracle, hip, w, h):
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 2)
     fo = oracle.Frame(0, frames[1], K)
@@ -120,7 +120,7 @@ def _oracle_terms64(oracle, tr):
     return A, Aabs, b, babs, err, n
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+@pytest.mark.parametrize("w,h", [(176, 144), (320, 240), (640, 480)])
 def test_residual_kernel_fixed_pose(oracle, hip, w, h):
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4)
     kfo = oracle.Frame(0, frames[0], K)
@@ -176,8 +176,8 @@ def test_residual_kernel_fixed_pose(oracle, hip, w, h):
             assert np.allclose(np.array(r_g.A), np.array(r_o.A), rtol=2e-4, atol=1e-4 * np.abs(np.array(r_o.A)).max()), tag
 
 
-def test_trackframe_parity(oracle, hip):
-    w, h = 640, 480
+@pytest.mark.parametrize("w,h", [(176, 144), (640, 480)])
+def test_trackframe_parity(oracle, hip, w, h):
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
     kfo = oracle.Frame(0, frames[0], K)
     kfg = hip.Frame(ctx, 0, frames[0])
@@ -330,7 +330,7 @@ def _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, ids, with_masks=True,
     return fos, fgs
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+@pytest.mark.parametrize("w,h", [(176, 144), (320, 240), (640, 480)])
 def test_depth_stages_bit_exact(oracle, hip, w, h):
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8)
     kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h)
@@ -371,8 +371,8 @@ def test_observe_reactivated_and_no_masks(oracle, hip):
     assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "observeDepth reactivated")
 
 
-def test_update_keyframe_end_to_end(oracle, hip):
-    w, h = 640, 480
+@pytest.mark.parametrize("w,h", [(176, 144), (640, 480)])
+def test_update_keyframe_end_to_end(oracle, hip, w, h):
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
     kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, seed=11)
     for i in range(1, 6):
