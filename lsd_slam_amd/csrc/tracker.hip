@@ -29,6 +29,7 @@
 #include <atomic>
 #include <chrono>
 #include "lsdhip_internal.hpp"
+#include <type_traits>
 
 
 // ---- wave64 sum via DPP (row_shr 1,2,3 / 4 / 8, row_bcast 15 / 31); result valid in lane 63 ----------------------
@@ -761,21 +762,29 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         const int R = (((nb + NSLICE - 1) / NSLICE) + 3) & ~3;
         const int row0 = slice * R;
         const float4* p = (const float4*)(sums_in + (size_t)col * max_rows + (row0 < max_rows ? row0 : 0));
-        float4 v[QMAX];
         const int qlast = (max_rows - row0) / 4 - 1;   // loads stay inside the column (rows < max_rows are allocated)
-#pragma unroll
-        for (int q = 0; q < QMAX; q++) v[q] = p[q < qlast ? q : (qlast > 0 ? qlast : 0)];   // unconditional, issued together
         float s = 0.f;
+        // the loads are unconditional and issued together; coarse levels (few tiles) take the short form so that they do
+        // not pay for 20 vector loads per thread when 5 cover their rows
+        auto colsum = [&](auto qn) {
+          constexpr int Q = decltype(qn)::value;
+          float4 v[Q];
 #pragma unroll
-        for (int q = 0; q < QMAX; q++) {
-          const int r = row0 + 4 * q;
-          if (4 * q < R) {
-            s += (r < nb) ? v[q].x : 0.f;
-            s += (r + 1 < nb) ? v[q].y : 0.f;
-            s += (r + 2 < nb) ? v[q].z : 0.f;
-            s += (r + 3 < nb) ? v[q].w : 0.f;
+          for (int q = 0; q < Q; q++) v[q] = p[q < qlast ? q : (qlast > 0 ? qlast : 0)];
+#pragma unroll
+          for (int q = 0; q < Q; q++) {
+            const int r = row0 + 4 * q;
+            if (4 * q < R) {
+              s += (r < nb) ? v[q].x : 0.f;
+              s += (r + 1 < nb) ? v[q].y : 0.f;
+              s += (r + 2 < nb) ? v[q].z : 0.f;
+              s += (r + 3 < nb) ? v[q].w : 0.f;
+            }
           }
-        }
+        };
+        if (R <= 8) colsum(std::integral_constant<int, 2>());
+        else if (R <= 20) colsum(std::integral_constant<int, 5>());
+        else colsum(std::integral_constant<int, QMAX>());
         s_sum[slice][col] = s;
 #ifdef LSD_PHASE_TRACE
         if (blockIdx.x == 0 && tid == 0) tr_[17] = clock64();
