@@ -680,6 +680,17 @@ template <int BLOCK, bool BATCH, int MODE>
 __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
                                                 TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
   const TrackJob& job = BATCH ? jobs[blockIdx.y] : jobv;
+  // The job description travels in the kernel arguments, which the host has just written: the first touch of each of its
+  // cache lines misses down to HBM (~1 us), and the fields of lv[level] are addressed only once the level is known, i.e. in
+  // the middle of the dependent chain.  Touch every line now, together with the loads of the prologue.
+  unsigned warm = 0;
+  if (!BATCH) {
+    typedef const unsigned __attribute__((address_space(4))) cuint;
+    cuint* ka = (cuint*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(TrackJob) / 4); i += 32) warm ^= ka[i];
+    asm volatile("" ::"s"(warm));   // the loads complete here, in the shadow of the prologue's own argument loads
+  }
   if (BATCH) {
     const size_t j = blockIdx.y, rows = (size_t)sc.max_rows;
     st2 += 2 * j;
