@@ -140,14 +140,12 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Job a) {
         J6[2] = 0.0f - (val1 + val2);
         J6[3] = 0.0f - ((val2 * Wy) + (gy + val1 * Wy));
         J6[4] = (gx + val1 * Wx) + val2 * Wx;
-        int k = S3_A6;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
           const float Jw = J6[r] * wp;
 #pragma unroll
           for (int c = r; c < 6; c++) acc[S3_A6 + (r * 6 - (r * (r - 1)) / 2 + (c - r))] = Jw * J6[c];
         }
-        (void)k;
         const float resw6 = rp * wp;
 #pragma unroll
         for (int r = 0; r < 6; r++) acc[S3_A6 + 21 + r] = resw6 * J6[r];
