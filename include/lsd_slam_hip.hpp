@@ -422,7 +422,7 @@ class SlamLoop {
   // kfEvery > 0: a new keyframe every kfEvery frames (deterministic; what bench.py and the parity tests use);
   // kfEvery == 0: the reference's distance / usage score (SlamSystem.cpp:997-1015 with doSlam = false, see keyframeScore).
   SlamLoop(int w, int h, const Mat3f& K, const unsigned char* firstImage, bool imagesOnDevice, const float* gtDepth0, int kfEvery)
-      : w_(w), h_(h), K_(K), onDevice_(imagesOnDevice), kfEvery_(kfEvery), tracker(w, h, K), map(w, h, K) {
+      : tracker(w, h, K), map(w, h, K), w_(w), h_(h), K_(K), onDevice_(imagesOnDevice), kfEvery_(kfEvery) {
     const int its[LSDHIP_PYRAMID_LEVELS] = {5, 20, 50, 100, 0};  // SlamSystem.cpp:80-81 (no level-4 iterations are run by the tracker)
     std::memcpy(tracker.settings.maxItsPerLvl, its, sizeof(its));
     keyframe = makeFrame(0, firstImage);

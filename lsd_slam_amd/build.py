@@ -76,13 +76,13 @@ def build_driver(force=False, verbose=False):
             os.path.join(HERE, "..", "include", "lsdhip_driver.h"), OUT]
     if not force and os.path.exists(DRIVER_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(DRIVER_OUT) for d in deps):
         return DRIVER_OUT
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-reorder", DRIVER_SRC, "-o", DRIVER_OUT,
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", DRIVER_SRC, "-o", DRIVER_OUT,
            "-L" + HERE, "-llsdhip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     # dataset_slam: the ROS-free image-folder driver (lsd_slam_amd/driver/dataset_slam.cpp)
-    cmd2 = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-reorder", "-I" + os.path.join(HERE, "..", "include"),
+    cmd2 = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(HERE, "..", "include"),
             os.path.join(HERE, "driver", "dataset_slam.cpp"), "-o", os.path.join(HERE, "dataset_slam"), "-L" + HERE, "-llsdhip",
             "-Wl,-rpath,$ORIGIN"]
     if verbose:
