@@ -351,6 +351,34 @@ class Sim3Tracker {
     return out;
   }
 
+  // n independent jobs in lock step (their evaluations share launches); results[j] as a single call would leave them
+  std::vector<Sim3> trackFrameSim3Batch(const std::vector<TrackingReference*>& references, const std::vector<Frame*>& frames,
+                                        const std::vector<Sim3>& inits, int startLevel, int finalLevel,
+                                        std::vector<lsdhip_sim3_result>* results = nullptr) {
+    check(lsdhip_sim3tracker_set_max_its(h_, settings.maxItsPerLvl), "lsdhip_sim3tracker_set_max_its");
+    const size_t n = frames.size();
+    std::vector<lsdhip_frame*> kfs(n), frs(n);
+    std::vector<double> init(8 * n);
+    for (size_t j = 0; j < n; j++) {
+      kfs[j] = references[j]->keyframe->handle();
+      frs[j] = frames[j]->handle();
+      for (int i = 0; i < 4; i++) init[8 * j + i] = inits[j].q[i];
+      for (int i = 0; i < 3; i++) init[8 * j + 4 + i] = inits[j].t[i];
+      init[8 * j + 7] = inits[j].s;
+    }
+    std::vector<lsdhip_sim3_result> res(n);
+    check(lsdhip_sim3tracker_track_batch(h_, (int)n, kfs.data(), frs.data(), init.data(), startLevel, finalLevel, res.data()),
+          "lsdhip_sim3tracker_track_batch");
+    std::vector<Sim3> out(n);
+    for (size_t j = 0; j < n; j++) {
+      for (int i = 0; i < 4; i++) out[j].q[i] = res[j].frameToReference[i];
+      for (int i = 0; i < 3; i++) out[j].t[i] = res[j].frameToReference[4 + i];
+      out[j].s = res[j].frameToReference[7];
+    }
+    if (results) *results = res;
+    return out;
+  }
+
   float pointUsage = 0, lastResidual = 0, lastDepthResidual = 0, lastPhotometricResidual = 0;
   float affineEstimation_a = 1, affineEstimation_b = 0;
   float lastSim3Hessian[49] = {};   // row-major 7x7

@@ -205,6 +205,11 @@ int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int maxItsPerLvl
  * Returns LSDHIP_DIVERGED when the reference sets diverged or returns Sim3() early. */
 int lsdhip_sim3tracker_track(lsdhip_sim3tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame, const double init_frameToReference[8],
                              int startLevel, int finalLevel, lsdhip_sim3_result* out);
+/* n independent trackFrameSim3 jobs advanced in lock step, their evaluations sharing launches (the constraint search tests
+ * every candidate in both directions, C/SlamSystem.cpp:1140-1187).  inits: n x 8 doubles, results: n records; each job
+ * computes what a single call computes.  Returns LSDHIP_DIVERGED if any job returned early (see results[j].diverged). */
+int lsdhip_sim3tracker_track_batch(lsdhip_sim3tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
+                                   const double* init_frameToReference, int startLevel, int finalLevel, lsdhip_sim3_result* results);
 /* test hook: one evaluation at referenceToFrame on `level` with affine (a, b) */
 int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame, const double referenceToFrame[8],
                                 int level, float aff_a, float aff_b, lsdhip_sim3_eval_record* out);

@@ -15,8 +15,10 @@
 // Quirks kept: the SSE loops ignore the last size % 4 in-image points (x-outer / y-inner order) for the residual sums and
 // both systems; LGS6::updateSSE counts 6 and LGS4::updateSSE 4 constraints per group of four points.
 #include "lsdhip_internal.hpp"
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <vector>
 
 #define S3_BLOCK 256
 enum {
@@ -45,7 +47,14 @@ struct Sim3Job {
   int seq;
 };
 
-__global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Job a) {
+// Up to S3_MAXB independent evaluations per launch (blockIdx.y = slot); the job descriptions travel in the kernel arguments.
+#define S3_MAXB 12
+struct Sim3Batch { Sim3Job j[S3_MAXB]; };
+static_assert(sizeof(Sim3Batch) <= 4096, "kernel-argument limit");
+
+__global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Batch batch) {
+  const Sim3Job& a = batch.j[blockIdx.y];
+  if ((int)blockIdx.x >= a.nblocks) return;
   __shared__ float s_red[S3_END * (S3_BLOCK + 1) + 8];
   __shared__ float s_sum[4][64];
   __shared__ int s_max;
@@ -208,7 +217,9 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Job a) {
 }
 
 // fixed-order sum of the tile rows, global top-3 keys, SSE tail drop; result to the pinned record
-__global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Job a) {
+__global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Batch batch) {
+  const Sim3Job& a = batch.j[blockIdx.y];
+  if (a.nblocks <= 0) return;
   __shared__ float s_part[4][64];
   __shared__ float s_tot[64];
   __shared__ int s_keys[3], s_src[3];
@@ -413,12 +424,12 @@ struct lsdhip_sim3tracker {
   int maxItsPerLvl[LSD_LEVELS] = {5, 20, 50, 100, 100};
   float lambdaSuccessFac = 0.5f, lambdaFailFac = 2.0f, lambdaInitial = 0, stepSizeMin = 1e-8f, convergenceEps = 0.999f;
   float huber_d = 3, var_weight = 1.0f;
-  float affineEstimation_a = 1, affineEstimation_b = 0;
-  float* d_rows = nullptr;
-  int4* d_topkey = nullptr;
-  float* d_topval = nullptr;
-  float* h_record = nullptr;   // pinned, device-mapped
-  int seq = 0;                 // evaluation counter, echoed by k_sim3_finalize in word 63 of the record
+  float* d_rows = nullptr;     // [S3_MAXB][max_blocks][64]
+  int4* d_topkey = nullptr;    // [S3_MAXB][max_blocks]
+  float* d_topval = nullptr;   // [S3_MAXB][max_blocks][3][48]
+  float* h_record = nullptr;   // [S3_MAXB][64] pinned, device-mapped
+  float* d_record = nullptr;   // device alias of h_record
+  int seq = 0;                 // launch counter, echoed by k_sim3_finalize in word 63 of every active slot's record
   int max_blocks = 0;
 };
 
@@ -428,12 +439,14 @@ extern "C" int lsdhip_sim3tracker_create(lsdhip_ctx* c, lsdhip_sim3tracker** out
   lsdhip_sim3tracker* t = new lsdhip_sim3tracker();
   t->ctx = c;
   t->max_blocks = (c->w * c->h + S3_BLOCK - 1) / S3_BLOCK;
-  HIPCHK(hipMalloc((void**)&t->d_rows, (size_t)t->max_blocks * 64 * 4));
-  HIPCHK(hipMalloc((void**)&t->d_topkey, (size_t)t->max_blocks * 16));
-  HIPCHK(hipMalloc((void**)&t->d_topval, (size_t)t->max_blocks * 3 * 48 * 4));
-  HIPCHK(hipMemsetAsync(t->d_topval, 0, (size_t)t->max_blocks * 3 * 48 * 4, c->stream));
-  HIPCHK(hipHostMalloc((void**)&t->h_record, 64 * 4, hipHostMallocMapped));
-  memset(t->h_record, 0, 64 * 4);
+  const size_t mb = (size_t)t->max_blocks * S3_MAXB;
+  HIPCHK(hipMalloc((void**)&t->d_rows, mb * 64 * 4));
+  HIPCHK(hipMalloc((void**)&t->d_topkey, mb * 16));
+  HIPCHK(hipMalloc((void**)&t->d_topval, mb * 3 * 48 * 4));
+  HIPCHK(hipMemsetAsync(t->d_topval, 0, mb * 3 * 48 * 4, c->stream));
+  HIPCHK(hipHostMalloc((void**)&t->h_record, S3_MAXB * 64 * 4, hipHostMallocMapped));
+  memset(t->h_record, 0, S3_MAXB * 64 * 4);
+  HIPCHK(hipHostGetDevicePointer((void**)&t->d_record, t->h_record, 0));
   *out = t;
   return LSDHIP_OK;
 }
@@ -450,8 +463,10 @@ extern "C" int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int i
   return LSDHIP_OK;
 }
 
-// calcSim3Buffers + calcSim3WeightsAndResidualSSE + calcSim3LGSSSE at one transformation
-static int sim3_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const Sim3H& referenceToFrame, int level, Eval* ev) {
+// one evaluation = calcSim3Buffers + calcSim3WeightsAndResidualSSE + calcSim3LGSSSE at one transformation.
+// Description of the evaluation for batch slot `slot`:
+static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsdhip_frame* frame, const Sim3H& referenceToFrame, int level,
+                          float aff_a, float aff_b, Sim3Job* out) {
   lsdhip_ctx* c = t->ctx;
   Sim3Job a;
   a.kf_idepth = kf->d_idepth[level]; a.kf_idepthVar = kf->d_idepthVar[level]; a.kf_image = kf->d_image[level]; a.kf_grad = kf->d_grad[level];
@@ -493,19 +508,36 @@ static int sim3_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* 
       }
     a.xRoll0 = roll[0]; a.xRoll1 = roll[1]; a.yRoll0 = roll[3]; a.yRoll1 = roll[4];
   }
-  a.aff_a = t->affineEstimation_a; a.aff_b = t->affineEstimation_b;
+  a.aff_a = aff_a; a.aff_b = aff_b;
   a.cameraPixelNoise2 = c->params.cameraPixelNoise2; a.var_weight = t->var_weight; a.huber_d = t->huber_d;
-  a.rows = t->d_rows; a.topkey = t->d_topkey; a.topval = t->d_topval;
-  HIPCHK(hipHostGetDevicePointer((void**)&a.record, t->h_record, 0));
-  a.seq = ++t->seq;
-  hipLaunchKernelGGL(k_sim3_eval, dim3(a.nblocks), dim3(S3_BLOCK), 0, c->stream, a);
-  hipLaunchKernelGGL(k_sim3_finalize, dim3(1), dim3(256), 0, c->stream, a);
+  a.rows = t->d_rows + (size_t)slot * t->max_blocks * 64;
+  a.topkey = t->d_topkey + (size_t)slot * t->max_blocks;
+  a.topval = t->d_topval + (size_t)slot * t->max_blocks * 3 * 48;
+  a.record = t->d_record + (size_t)slot * 64;
+  a.seq = 0;
+  *out = a;
+  return LSDHIP_OK;
+}
+// launches the slots with nblocks > 0 and waits until each of them has raised the launch's sequence number
+static int sim3_run_batch(lsdhip_sim3tracker* t, Sim3Batch& batch, int nslots) {
+  lsdhip_ctx* c = t->ctx;
+  const int seq = ++t->seq;
+  int grid = 0;
+  for (int k = 0; k < S3_MAXB; k++) {
+    if (k >= nslots) batch.j[k].nblocks = 0;
+    batch.j[k].seq = seq;
+    if (batch.j[k].nblocks > grid) grid = batch.j[k].nblocks;
+  }
+  if (grid == 0) return LSDHIP_OK;
+  hipLaunchKernelGGL(k_sim3_eval, dim3(grid, nslots), dim3(S3_BLOCK), 0, c->stream, batch);
+  hipLaunchKernelGGL(k_sim3_finalize, dim3(1, nslots), dim3(256), 0, c->stream, batch);
   HIPCHK(hipGetLastError());
-  {
-    volatile const int* flag = (volatile const int*)t->h_record + 63;
-    const auto tStart = std::chrono::steady_clock::now();
+  const auto tStart = std::chrono::steady_clock::now();
+  for (int k = 0; k < nslots; k++) {
+    if (batch.j[k].nblocks <= 0) continue;
+    volatile const int* flag = (volatile const int*)(t->h_record + (size_t)k * 64) + 63;
     unsigned spins = 0;
-    while (*flag != a.seq) {
+    while (*flag != seq) {
       if ((++spins & 4095u) == 0) {
         hipError_t q = hipStreamQuery(c->stream);
         if (q != hipSuccess && q != hipErrorNotReady) { lsd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return LSDHIP_E_HIP; }
@@ -514,9 +546,13 @@ static int sim3_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* 
       __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (*flag != a.seq) { lsd_set_error("Sim3 evaluation did not complete"); return LSDHIP_E_STATE; }
+    if (*flag != seq) { lsd_set_error("Sim3 evaluation did not complete"); return LSDHIP_E_STATE; }
   }
-  const float* r = t->h_record;
+  return LSDHIP_OK;
+}
+// the evaluation's outcome in the reference's terms, from slot `slot`'s record
+static void sim3_read_eval(lsdhip_sim3tracker* t, int slot, Eval* ev) {
+  const float* r = t->h_record + (size_t)slot * 64;
   ev->M = (int)r[S3_M];
   ev->pointUsage = r[S3_USAGE] / r[S3_NREF];
   {
@@ -550,7 +586,6 @@ static int sim3_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* 
     for (int j = 0; j < 4; j++) ev->A[remap[i] * 7 + remap[j]] += A4[i * 4 + j];
   }
   ev->num_constraints = (size_t)6 * (size_t)(ev->M >> 2) + (size_t)4 * (size_t)(ev->M >> 2);
-  return LSDHIP_OK;
 }
 
 static Sim3H sim3_in(const double p[8]) { Sim3H T; T.q = {p[0], p[1], p[2], p[3]}; T.t[0] = p[4]; T.t[1] = p[5]; T.t[2] = p[6]; T.s = p[7]; return T; }
@@ -561,10 +596,14 @@ extern "C" int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* 
   if (!t || !kf || !frame || !refToFrame || !out || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
   if (!kf->hasIDepth || !frame->hasIDepth) { lsd_set_error("Sim3 tracking needs inverse depth on both frames"); return LSDHIP_E_STATE; }
   HIPCHK(hipSetDevice(t->ctx->device));
-  t->affineEstimation_a = aff_a; t->affineEstimation_b = aff_b;
-  Eval ev;
-  int rc = sim3_evaluate(t, kf, frame, sim3_in(refToFrame), level, &ev);
+  Sim3Batch batch;
+  memset(&batch, 0, sizeof(batch));
+  int rc = sim3_build_job(t, 0, kf, frame, sim3_in(refToFrame), level, aff_a, aff_b, &batch.j[0]);
   if (rc) return rc;
+  rc = sim3_run_batch(t, batch, 1);
+  if (rc) return rc;
+  Eval ev;
+  sim3_read_eval(t, 0, &ev);
   out->warped_size = ev.M; out->pointUsage = ev.pointUsage; out->affine_a_lastIt = ev.aff_a_lastIt; out->affine_b_lastIt = ev.aff_b_lastIt;
   out->sumResD = ev.res.sumResD; out->sumResP = ev.res.sumResP; out->numTermsD = ev.res.numTermsD; out->numTermsP = ev.res.numTermsP;
   out->meanD = ev.res.meanD; out->meanP = ev.res.meanP; out->mean = ev.res.mean;
@@ -573,93 +612,216 @@ extern "C" int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* 
   return LSDHIP_OK;
 }
 
-// Sim3Tracker::trackFrameSim3 (Sim3Tracker.cpp:149-378)
-extern "C" int lsdhip_sim3tracker_track(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double init[8], int startLevel,
-                                        int finalLevel, lsdhip_sim3_result* out) {
-  if (!t || !kf || !frame || !init || !out || startLevel < finalLevel || finalLevel < 0 || startLevel >= LSD_LEVELS) return LSDHIP_E_ARG;
-  if (!kf->hasIDepth || !frame->hasIDepth) { lsd_set_error("Sim3 tracking needs inverse depth on both frames"); return LSDHIP_E_STATE; }
-  lsdhip_ctx* c = t->ctx;
-  HIPCHK(hipSetDevice(c->device));
-  memset(out, 0, sizeof(*out));
-  out->frameToReference[0] = 1; out->frameToReference[7] = 1;   // Sim3() on failure
-  t->affineEstimation_a = 1; t->affineEstimation_b = 0;
-  const bool useAffine = c->params.useAffineLightningEstimation != 0;
-  Sim3H referenceToFrame = sim3_inverse(sim3_in(init));
-  Eval cur;
-  memset(&cur, 0, sizeof(cur));
-  Sim3Res finalResidual;
-  memset(&finalResidual, 0, sizeof(finalResidual));
+// Sim3Tracker::trackFrameSim3 (Sim3Tracker.cpp:149-378) as a resumable state machine: the control flow of the reference
+// between two evaluations is `advance`, which either asks for the next evaluation (pose + level) or finishes the job.
+// Several jobs advance in lock step and share the launches of their evaluations (lsdhip_sim3tracker_track_batch).
+namespace {
+struct Sim3Track {
+  lsdhip_frame* kf = nullptr;
+  lsdhip_frame* frame = nullptr;
+  lsdhip_sim3_result* out = nullptr;
+  enum Phase { LEVEL_FIRST, TRY, FINAL, DONE } phase = DONE;
+  int rc = LSDHIP_OK;
+  Sim3H referenceToFrame, candidate;
+  float aff_a = 1, aff_b = 0;
+  int lvl = 0, finalLevel = 0, iteration = 0, incTry = 0, numEvaluations = 0;
+  float LM_lambda = 0, absInc = 0;
   bool warp_update_up_to_date = false;
-  int numEvaluations = 0;
-  auto diverge = [&]() { out->diverged = 1; out->numEvaluations = numEvaluations; return LSDHIP_DIVERGED; };
-  for (int lvl = startLevel; lvl >= finalLevel; lvl--) {
-    if (t->maxItsPerLvl[lvl] == 0) continue;
-    int rc = sim3_evaluate(t, kf, frame, referenceToFrame, lvl, &cur);
-    if (rc) return rc;
-    numEvaluations++;
-    if (cur.M < 0.5 * 0.01 * (c->w >> lvl) * (c->h >> lvl) || cur.M < 10) return diverge();
-    Sim3Res lastErr = cur.res;
-    if (useAffine) { t->affineEstimation_a = cur.aff_a_lastIt; t->affineEstimation_b = cur.aff_b_lastIt; }
-    float LM_lambda = t->lambdaInitial;
-    warp_update_up_to_date = false;
-    for (int iteration = 0; iteration < t->maxItsPerLvl[lvl]; iteration++) {
-      // the system of the last accepted evaluation is what calcSim3LGS would build here
-      warp_update_up_to_date = true;
-      int incTry = 0;
-      while (true) {
-        float b[7], A[49], inc[7];
-        const float nc = (float)cur.num_constraints;
-        for (int i = 0; i < 7; i++) b[i] = -cur.b[i] / nc;
-        for (int i = 0; i < 49; i++) A[i] = cur.A[i] / nc;
-        for (int i = 0; i < 7; i++) A[i * 7 + i] *= 1 + LM_lambda;
-        ldlt7_solve(A, b, inc);
-        incTry++;
-        float absInc = 0;
-        for (int i = 0; i < 7; i++) absInc += inc[i] * inc[i];
-        if (!(absInc >= 0 && absInc < 1)) { out->numEvaluations = numEvaluations; return LSDHIP_DIVERGED; }   // returns Sim3(), Hessian zero
-        double incd[7];
-        for (int i = 0; i < 7; i++) incd[i] = (double)inc[i];
-        const Sim3H new_referenceToFrame = sim3_mul(sim3_exp(incd), referenceToFrame);
-        Eval nev;
-        rc = sim3_evaluate(t, kf, frame, new_referenceToFrame, lvl, &nev);
+  Eval cur;
+  Sim3Res lastErr, finalResidual;
+  // the evaluation this job waits for
+  Sim3H reqPose;
+  int reqLevel = 0;
+};
+
+void sim3_finish(lsdhip_sim3tracker* t, Sim3Track& J) {
+  lsdhip_sim3_result* out = J.out;
+  memcpy(out->lastSim3Hessian, J.cur.A, sizeof(J.cur.A));
+  out->numEvaluations = J.numEvaluations;
+  out->pointUsage = J.cur.pointUsage;
+  out->affineEstimation_a = J.aff_a; out->affineEstimation_b = J.aff_b;
+  J.phase = Sim3Track::DONE;
+  if (J.referenceToFrame.s <= 0) { out->diverged = 1; J.rc = LSDHIP_DIVERGED; return; }
+  out->lastResidual = J.finalResidual.mean;
+  out->lastDepthResidual = J.finalResidual.meanD;
+  out->lastPhotometricResidual = J.finalResidual.meanP;
+  sim3_out(sim3_inverse(J.referenceToFrame), out->frameToReference);
+  J.rc = LSDHIP_OK;
+}
+void sim3_diverge(Sim3Track& J, bool setFlag) {
+  // Sim3() is already in the result; `diverged` is only raised where the reference raises it (too few points, scale <= 0)
+  if (setFlag) J.out->diverged = 1;
+  J.out->numEvaluations = J.numEvaluations;
+  J.phase = Sim3Track::DONE;
+  J.rc = LSDHIP_DIVERGED;
+}
+// enter the next level that has iterations (or the final re-evaluation / the end)
+void sim3_next_level(lsdhip_sim3tracker* t, Sim3Track& J) {
+  while (J.lvl >= J.finalLevel && t->maxItsPerLvl[J.lvl] == 0) J.lvl--;
+  if (J.lvl >= J.finalLevel) {
+    J.phase = Sim3Track::LEVEL_FIRST;
+    J.reqPose = J.referenceToFrame; J.reqLevel = J.lvl;
+    return;
+  }
+  // the system at the accepted transformation is recomputed on the final level when the last evaluation was accepted
+  // (the affine parameters have moved since) or belonged to another level (Sim3Tracker.cpp:354-360)
+  if (!J.warp_update_up_to_date) {
+    J.phase = Sim3Track::FINAL;
+    J.reqPose = J.referenceToFrame; J.reqLevel = J.finalLevel;
+    return;
+  }
+  sim3_finish(t, J);
+}
+// solve the damped system of the last accepted evaluation and ask for the evaluation of the candidate
+void sim3_propose(lsdhip_sim3tracker* t, Sim3Track& J) {
+  float b[7], A[49], inc[7];
+  const float nc = (float)J.cur.num_constraints;
+  for (int i = 0; i < 7; i++) b[i] = -J.cur.b[i] / nc;
+  for (int i = 0; i < 49; i++) A[i] = J.cur.A[i] / nc;
+  for (int i = 0; i < 7; i++) A[i * 7 + i] *= 1 + J.LM_lambda;
+  ldlt7_solve(A, b, inc);
+  J.incTry++;
+  float absInc = 0;
+  for (int i = 0; i < 7; i++) absInc += inc[i] * inc[i];
+  J.absInc = absInc;
+  if (!(absInc >= 0 && absInc < 1)) { sim3_diverge(J, false); return; }   // returns Sim3(), Hessian zero
+  double incd[7];
+  for (int i = 0; i < 7; i++) incd[i] = (double)inc[i];
+  J.candidate = sim3_mul(sim3_exp(incd), J.referenceToFrame);
+  J.phase = Sim3Track::TRY;
+  J.reqPose = J.candidate; J.reqLevel = J.lvl;
+}
+// start of an iteration of the level's loop (`for iteration < maxIts`), or leave the level
+void sim3_iteration(lsdhip_sim3tracker* t, Sim3Track& J) {
+  if (J.iteration >= t->maxItsPerLvl[J.lvl]) { J.lvl--; sim3_next_level(t, J); return; }
+  J.warp_update_up_to_date = true;   // the system of the last accepted evaluation is what calcSim3LGS would build here
+  J.incTry = 0;
+  sim3_propose(t, J);
+}
+// the requested evaluation has arrived
+void sim3_advance(lsdhip_sim3tracker* t, Sim3Track& J, const Eval& ev) {
+  lsdhip_ctx* c = t->ctx;
+  const bool useAffine = c->params.useAffineLightningEstimation != 0;
+  J.numEvaluations++;
+  if (J.phase == Sim3Track::FINAL) {
+    J.cur = ev;
+    J.finalResidual = ev.res;
+    sim3_finish(t, J);
+    return;
+  }
+  if (ev.M < 0.5 * 0.01 * (c->w >> J.lvl) * (c->h >> J.lvl) || ev.M < 10) { sim3_diverge(J, true); return; }
+  if (J.phase == Sim3Track::LEVEL_FIRST) {
+    J.cur = ev;
+    J.lastErr = ev.res;
+    if (useAffine) { J.aff_a = ev.aff_a_lastIt; J.aff_b = ev.aff_b_lastIt; }
+    J.LM_lambda = t->lambdaInitial;
+    J.warp_update_up_to_date = false;
+    J.iteration = 0;
+    sim3_iteration(t, J);
+    return;
+  }
+  // TRY
+  if (ev.res.mean < J.lastErr.mean) {
+    J.referenceToFrame = J.candidate;
+    J.cur = ev;
+    J.warp_update_up_to_date = false;
+    if (useAffine) { J.aff_a = ev.aff_a_lastIt; J.aff_b = ev.aff_b_lastIt; }
+    if (ev.res.mean / J.lastErr.mean > t->convergenceEps) J.iteration = t->maxItsPerLvl[J.lvl];
+    J.finalResidual = J.lastErr = ev.res;
+    if (J.LM_lambda <= 0.2) J.LM_lambda = 0;
+    else J.LM_lambda *= t->lambdaSuccessFac;
+    J.iteration++;
+    sim3_iteration(t, J);
+  } else {
+    if (!(J.absInc > t->stepSizeMin)) {
+      J.iteration = t->maxItsPerLvl[J.lvl];
+      J.iteration++;
+      sim3_iteration(t, J);
+      return;
+    }
+    if (J.LM_lambda == 0) J.LM_lambda = 0.2;
+    else J.LM_lambda *= std::pow(t->lambdaFailFac, J.incTry);
+    sim3_propose(t, J);
+  }
+}
+}  // namespace
+
+// n independent trackFrameSim3 jobs in lock step: every round evaluates the pending transformation of each unfinished job
+// in one pair of launches (at most S3_MAXB jobs per launch)
+static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs) {
+  const int n = (int)jobs.size();
+  for (int base = 0; base < n; base += S3_MAXB) {
+    const int m = std::min(S3_MAXB, n - base);
+    while (true) {
+      Sim3Batch batch;
+      memset(&batch, 0, sizeof(batch));
+      int active = 0;
+      for (int k = 0; k < m; k++) {
+        Sim3Track& J = jobs[base + k];
+        if (J.phase == Sim3Track::DONE) continue;
+        int rc = sim3_build_job(t, k, J.kf, J.frame, J.reqPose, J.reqLevel, J.aff_a, J.aff_b, &batch.j[k]);
         if (rc) return rc;
-        numEvaluations++;
-        if (nev.M < 0.5 * 0.01 * (c->w >> lvl) * (c->h >> lvl) || nev.M < 10) return diverge();
-        if (nev.res.mean < lastErr.mean) {
-          referenceToFrame = new_referenceToFrame;
-          cur = nev;
-          warp_update_up_to_date = false;
-          if (useAffine) { t->affineEstimation_a = nev.aff_a_lastIt; t->affineEstimation_b = nev.aff_b_lastIt; }
-          if (nev.res.mean / lastErr.mean > t->convergenceEps) iteration = t->maxItsPerLvl[lvl];
-          finalResidual = lastErr = nev.res;
-          if (LM_lambda <= 0.2) LM_lambda = 0;
-          else LM_lambda *= t->lambdaSuccessFac;
-          break;
-        } else {
-          if (!(absInc > t->stepSizeMin)) { iteration = t->maxItsPerLvl[lvl]; break; }
-          if (LM_lambda == 0) LM_lambda = 0.2;
-          else LM_lambda *= std::pow(t->lambdaFailFac, incTry);
-        }
+        active++;
+      }
+      if (!active) break;
+      int rc = sim3_run_batch(t, batch, m);
+      if (rc) return rc;
+      for (int k = 0; k < m; k++) {
+        Sim3Track& J = jobs[base + k];
+        if (J.phase == Sim3Track::DONE) continue;
+        Eval ev;
+        sim3_read_eval(t, k, &ev);
+        sim3_advance(t, J, ev);
       }
     }
   }
-  // `cur` always holds the system at the accepted transformation (every evaluation builds it), which is what the
-  // reference recomputes when warp_update_up_to_date is false (Sim3Tracker.cpp:354-360) — except that the final level may
-  // differ from the level of the last evaluation when the finer levels have zero iterations
-  if (!warp_update_up_to_date) {
-    int rc = sim3_evaluate(t, kf, frame, referenceToFrame, finalLevel, &cur);
-    if (rc) return rc;
-    numEvaluations++;
-    finalResidual = cur.res;
-  }
-  memcpy(out->lastSim3Hessian, cur.A, sizeof(cur.A));
-  out->numEvaluations = numEvaluations;
-  out->pointUsage = cur.pointUsage;
-  out->affineEstimation_a = t->affineEstimation_a; out->affineEstimation_b = t->affineEstimation_b;
-  if (referenceToFrame.s <= 0) return diverge();
-  out->lastResidual = finalResidual.mean;
-  out->lastDepthResidual = finalResidual.meanD;
-  out->lastPhotometricResidual = finalResidual.meanP;
-  sim3_out(sim3_inverse(referenceToFrame), out->frameToReference);
   return LSDHIP_OK;
+}
+static int sim3_init_job(lsdhip_sim3tracker* t, Sim3Track& J, lsdhip_frame* kf, lsdhip_frame* frame, const double init[8], int startLevel,
+                         int finalLevel, lsdhip_sim3_result* out) {
+  if (!kf || !frame || !init || !out) return LSDHIP_E_ARG;
+  if (!kf->hasIDepth || !frame->hasIDepth) { lsd_set_error("Sim3 tracking needs inverse depth on both frames"); return LSDHIP_E_STATE; }
+  memset(out, 0, sizeof(*out));
+  out->frameToReference[0] = 1; out->frameToReference[7] = 1;   // Sim3() on failure
+  J.kf = kf; J.frame = frame; J.out = out;
+  J.aff_a = 1; J.aff_b = 0;
+  J.referenceToFrame = sim3_inverse(sim3_in(init));
+  memset(&J.cur, 0, sizeof(J.cur));
+  memset(&J.finalResidual, 0, sizeof(J.finalResidual));
+  memset(&J.lastErr, 0, sizeof(J.lastErr));
+  J.warp_update_up_to_date = false;
+  J.numEvaluations = 0;
+  J.lvl = startLevel; J.finalLevel = finalLevel;
+  J.rc = LSDHIP_OK;
+  sim3_next_level(t, J);
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_sim3tracker_track(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double init[8], int startLevel,
+                                        int finalLevel, lsdhip_sim3_result* out) {
+  if (!t || !kf || !frame || !init || !out || startLevel < finalLevel || finalLevel < 0 || startLevel >= LSD_LEVELS) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(t->ctx->device));
+  std::vector<Sim3Track> jobs(1);
+  int rc = sim3_init_job(t, jobs[0], kf, frame, init, startLevel, finalLevel, out);
+  if (rc) return rc;
+  rc = sim3_track_jobs(t, jobs);
+  if (rc) return rc;
+  return jobs[0].rc;
+}
+
+extern "C" int lsdhip_sim3tracker_track_batch(lsdhip_sim3tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames, const double* inits,
+                                              int startLevel, int finalLevel, lsdhip_sim3_result* results) {
+  if (!t || n <= 0 || !keyframes || !frames || !inits || !results || startLevel < finalLevel || finalLevel < 0 || startLevel >= LSD_LEVELS)
+    return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(t->ctx->device));
+  std::vector<Sim3Track> jobs((size_t)n);
+  for (int j = 0; j < n; j++) {
+    int rc = sim3_init_job(t, jobs[j], keyframes[j], frames[j], inits + 8 * (size_t)j, startLevel, finalLevel, &results[j]);
+    if (rc) return rc;
+  }
+  int rc = sim3_track_jobs(t, jobs);
+  if (rc) return rc;
+  int rcAll = LSDHIP_OK;
+  for (int j = 0; j < n; j++) if (jobs[j].rc == LSDHIP_DIVERGED) rcAll = LSDHIP_DIVERGED;
+  return rcAll;
 }

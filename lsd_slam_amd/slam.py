@@ -324,6 +324,16 @@ class Sim3Tracker:
         self.last = r
         return np.array(list(r.frameToReference)), r
 
+    def trackFrameSim3Batch(self, keyframes, frames, inits, startLevel, finalLevel):
+        """n independent (keyframe, frame, init) jobs in lock step -> (n x 8 poses, list of result records)"""
+        n = len(frames)
+        kfs = (C.c_void_p * n)(*[k.h_ for k in keyframes])
+        frs = (C.c_void_p * n)(*[f.h_ for f in frames])
+        T = np.ascontiguousarray(inits, np.float64).reshape(n, 8)
+        res = (capi.Sim3Result * n)()
+        check(self.L.lsdhip_sim3tracker_track_batch(self.h_, n, kfs, frs, T.ctypes.data, startLevel, finalLevel, res))
+        return np.array([list(r.frameToReference) for r in res]), list(res)
+
     def evaluate(self, keyframe, frame, referenceToFrame, level, a=1.0, b=0.0):
         T = np.ascontiguousarray(referenceToFrame, np.float64)
         r = capi.Sim3EvalRecord()

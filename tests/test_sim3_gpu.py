@@ -134,3 +134,36 @@ def test_sim3_diverges_on_too_few_points_and_needs_depth(oracle, hip):
     bare = hip.Frame(P["ctx"], 9, synth.Scene(0).render(1, w, h)[0])
     with pytest.raises(hip.LsdHipError):
         tg.trackFrameSim3(P["ga"], bare, far, 3, 1)
+
+
+def test_sim3_batch_equals_single_calls(hip):
+    """lsdhip_sim3tracker_track_batch: jobs in lock step share launches; each job computes exactly what a single call computes
+    (same kernels, one slot per job), including a job that returns early while the others go on."""
+    from lsd_slam_amd import synth
+    w, h = 320, 240
+    scn = synth.Scene(0)
+    ctx = hip.Context(w, h, synth.intrinsics(w, h))
+    tr = hip.Sim3Tracker(ctx)
+    kfs, frs, inits = [], [], []
+    for (k, scale) in ((2, 1.0), (3, 1.25), (4, 0.8)):
+        imgA, depthA = scn.render(0, w, h)
+        imgB, depthB = scn.render(k, w, h)
+        a, b = hip.Frame(ctx, 0, imgA), hip.Frame(ctx, k, imgB)
+        a.setDepthFromGroundTruth(depthA)
+        b.setDepthFromGroundTruth((depthB / scale).astype(np.float32))
+        R, t = scn.frame_to_ref(k, 0)
+        kfs.append(a); frs.append(b)
+        inits.append(np.concatenate([synth.rot_to_quat(R), t, [1.0]]))
+    kfs.append(kfs[0]); frs.append(frs[0])
+    inits.append(np.array([1.0, 0, 0, 0, 50.0, 0, 0, 1.0]))            # a job that diverges on its first evaluation
+    want = []
+    for j in range(4):
+        pose, r = tr.trackFrameSim3(kfs[j], frs[j], inits[j], 3, 1)
+        want.append((pose, r.numEvaluations, r.lastResidual, r.diverged, np.array(r.lastSim3Hessian)))
+    poses, recs = tr.trackFrameSim3Batch(kfs, frs, np.array(inits), 3, 1)
+    for j in range(4):
+        assert np.array_equal(poses[j], want[j][0]), j
+        assert recs[j].numEvaluations == want[j][1] and recs[j].lastResidual == want[j][2] and recs[j].diverged == want[j][3]
+        assert np.array_equal(np.array(recs[j].lastSim3Hessian), want[j][4])
+    assert recs[3].diverged == 1 and recs[0].diverged == 0 and recs[1].numEvaluations > 5
+    assert poses[1][7] == pytest.approx(1.25, rel=2e-2)

@@ -30,5 +30,13 @@ for (w, h) in ((640, 480), (1280, 1024)):
         T, r = tr.trackFrameSim3(a, b, init, 3, 1)
         ev += r.numEvaluations
     dt = time.perf_counter() - t0
-    print(json.dumps({"size": "%dx%d" % (w, h), "ms_per_trackFrameSim3": dt / n * 1e3, "evaluations_per_call": ev / n,
+    # the same job eight times in one lock-step batch (lsdhip_sim3tracker_track_batch)
+    B = 8
+    for _ in range(2):
+        tr.trackFrameSim3Batch([a] * B, [b] * B, np.tile(init, (B, 1)), 3, 1)
+    tb = time.perf_counter()
+    for _ in range(n):
+        tr.trackFrameSim3Batch([a] * B, [b] * B, np.tile(init, (B, 1)), 3, 1)
+    dtb = time.perf_counter() - tb
+    print(json.dumps({"size": "%dx%d" % (w, h), "ms_per_job_in_batch_of_8": dtb / n / B * 1e3, "ms_per_trackFrameSim3": dt / n * 1e3, "evaluations_per_call": ev / n,
                       "us_per_evaluation": dt / ev * 1e6, "scale": float(T[7]), "diverged": bool(tr.diverged)}))
