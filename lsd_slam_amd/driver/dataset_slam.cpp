@@ -4,11 +4,15 @@
 // through include/lsd_slam_hip.hpp.  Outputs: a trajectory text file, one keyframeMsg (ROS 1 wire format) per finished
 // keyframe, and the viewer's PLY point cloud.
 //
-//   dataset_slam <calib.cfg> <image_list.txt> <out_dir> [--kf-every N] [--device D]
+//   dataset_slam <calib.cfg> <image_list.txt> <out_dir> [--kf-every N] [--device D] [--constraints 1]
+//
+// --constraints 1 additionally aligns every new keyframe with the keyframe it replaces by Sim3Tracker::trackFrameSim3 (the
+// tracking-parent edge the reference's constraint search always tests, C/SlamSystem.cpp:1253-1262) and writes constraints.txt.
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 
 #include "../../include/lsd_slam_hip_io.hpp"
 
@@ -33,13 +37,14 @@ static Sim3 sim3_mul(const Sim3& a, const Sim3& b) {
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::cerr << "usage: dataset_slam <calib.cfg> <image_list.txt> <out_dir> [--kf-every N] [--device D]\n";
+    std::cerr << "usage: dataset_slam <calib.cfg> <image_list.txt> <out_dir> [--kf-every N] [--device D] [--constraints 1]\n";
     return 2;
   }
-  int kfEvery = 0, device = 0;
+  int kfEvery = 0, device = 0, constraints = 0;
   for (int i = 4; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--kf-every")) kfEvery = atoi(argv[i + 1]);
     if (!strcmp(argv[i], "--device")) device = atoi(argv[i + 1]);
+    if (!strcmp(argv[i], "--constraints")) constraints = atoi(argv[i + 1]);
   }
   try {
     const Calibration cal = parseCalibration(argv[1]);
@@ -71,10 +76,34 @@ int main(int argc, char** argv) {
       flushPointCloud(m, cloud);
       nKeyframes++;
     };
-    int good = 0;
+    int good = 0, nConstraints = 0;
+    std::unique_ptr<Sim3Tracker> sim3;
+    std::ofstream cons;
+    if (constraints) {
+      sim3.reset(new Sim3Tracker(w, h, cal.K));
+      cons.open(outDir + "/constraints.txt");
+      cons << "# parentKeyframe newKeyframe init(qw qx qy qz tx ty tz s) estimate(qw qx qy qz tx ty tz s) residual depthResidual photoResidual usage diverged\n";
+    }
     for (size_t i = 1; i < files.size(); i++) {
       if (!readPGM(files[i], w, h, img)) { std::cerr << "skipping " << files[i] << " (wrong size or unreadable)\n"; continue; }
+      std::shared_ptr<Frame> parentKF = loop.keyframe;
       SE3 f2k = loop.step(img.data());
+      if (constraints && loop.newKeyframe) {
+        // new keyframe -> replaced keyframe, starting from the tracked pose with the depth rescale as scale
+        TrackingReference parentRef;
+        parentRef.importFrame(parentKF.get());
+        const Sim3 init = loop.keyframe->thisToParent_raw();
+        const Sim3 est = sim3->trackFrameSim3(&parentRef, loop.keyframe.get(), init, 3, 1);
+        cons << parentKF->id() << " " << loop.keyframe->id();
+        for (int k = 0; k < 4; k++) cons << " " << init.q[k];
+        for (int k = 0; k < 3; k++) cons << " " << init.t[k];
+        cons << " " << init.s;
+        for (int k = 0; k < 4; k++) cons << " " << est.q[k];
+        for (int k = 0; k < 3; k++) cons << " " << est.t[k];
+        cons << " " << est.s << " " << sim3->lastResidual << " " << sim3->lastDepthResidual << " " << sim3->lastPhotometricResidual << " "
+             << sim3->pointUsage << " " << (sim3->diverged ? 1 : 0) << "\n";
+        nConstraints++;
+      }
       Sim3 rel;
       for (int k = 0; k < 4; k++) rel.q[k] = f2k.q[k];
       for (int k = 0; k < 3; k++) rel.t[k] = f2k.t[k];
@@ -96,7 +125,8 @@ int main(int argc, char** argv) {
     loop.map.finalizeKeyFrame();
     loop.onKeyframeFinished(*loop.keyframe, loop.map);
     writePLY(outDir + "/pc.ply", cloud);
-    std::cout << "frames " << files.size() - 1 << " tracked_good " << good << " keyframes " << nKeyframes << " points " << cloud.size() / 4 << "\n";
+    std::cout << "frames " << files.size() - 1 << " tracked_good " << good << " keyframes " << nKeyframes << " points " << cloud.size() / 4
+              << " constraints " << nConstraints << "\n";
     return 0;
   } catch (const Error& e) {
     std::cerr << "dataset_slam: " << e.what() << "\n";

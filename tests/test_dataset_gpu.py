@@ -26,7 +26,8 @@ def test_dataset_slam_on_pgm_sequence(tmp_path):
     # absolute-pixel calibration (values >= 1 are taken as pixels)
     (tmp_path / "calib.cfg").write_text("%f %f %f %f 0\n%d %d\nnone\n%d %d\n" % (K[0], K[1], K[2], K[3], w, h, w, h))
     exe = os.path.join(ROOT, "lsd_slam_amd", "dataset_slam")
-    out = subprocess.check_output([exe, str(tmp_path / "calib.cfg"), str(tmp_path / "files.txt"), str(tmp_path)], timeout=300).decode()
+    out = subprocess.check_output([exe, str(tmp_path / "calib.cfg"), str(tmp_path / "files.txt"), str(tmp_path), "--constraints", "1"],
+                                  timeout=300).decode()
     s = dict(zip(out.split()[0::2], map(int, out.split()[1::2])))
     assert s["frames"] == n - 1
     assert s["tracked_good"] >= int(0.9 * (n - 1))          # random depth initialisation converges on this motion
@@ -45,3 +46,25 @@ def test_dataset_slam_on_pgm_sequence(tmp_path):
     hh, ww = struct.unpack_from("<2I", b, 4 + 8 + 1 + 28 + 16)
     npc, = struct.unpack_from("<I", b, 4 + 8 + 1 + 28 + 16 + 8)
     assert (ww, hh) == (w, h) and npc == w * h * 12 and len(b) == 4 + 8 + 1 + 28 + 16 + 8 + 4 + npc
+    # --constraints 1: every keyframe change produced a Sim3 edge to the replaced keyframe, close to the tracked pose it started from
+    rows = [l.split() for l in (tmp_path / "constraints.txt").read_text().splitlines() if l and not l.startswith("#")]
+    cons = np.array(rows, np.float64).reshape(len(rows), 23) if rows else np.zeros((0, 23))
+    assert s["constraints"] == len(cons) == s["keyframes"] - 1
+    if len(cons):
+        init, est = cons[:, 2:10], cons[:, 10:18]
+        assert np.all(cons[:, 22] == 0)                                   # none diverged
+        assert np.allclose(est[:, 7], init[:, 7], rtol=5e-2)              # scale of the edge ~ the depth rescale of createKeyFrame
+        assert np.all(np.linalg.norm(est[:, 4:7] - init[:, 4:7], axis=1) < 2e-2)
+    # fixed keyframe cadence on a second run: two keyframe changes in 25 frames, hence two edges, both sensible
+    out2 = tmp_path / "run2"
+    out2.mkdir()
+    (tmp_path / "files25.txt").write_text("\n".join(lst[:25]) + "\n")
+    o2 = subprocess.check_output([exe, str(tmp_path / "calib.cfg"), str(tmp_path / "files25.txt"), str(out2), "--kf-every", "10",
+                                  "--constraints", "1"], timeout=300).decode()
+    s2 = dict(zip(o2.split()[0::2], map(int, o2.split()[1::2])))
+    rows2 = [l.split() for l in (out2 / "constraints.txt").read_text().splitlines() if l and not l.startswith("#")]
+    c2 = np.array(rows2, np.float64).reshape(len(rows2), 23)
+    assert s2["constraints"] == len(c2) == 2 and s2["keyframes"] == 3
+    assert np.all(c2[:, 22] == 0) and np.all(c2[:, 18] > 0)
+    assert np.allclose(c2[:, 17], c2[:, 9], rtol=5e-2)                    # estimated scale ~ the rescale it started from
+    assert np.all(np.linalg.norm(c2[:, 14:17] - c2[:, 6:9], axis=1) < 2e-2)
