@@ -146,7 +146,7 @@ def main():
     ptr = lambda i: d_frames[order[i % len(order)]].data_ptr()
 
     # the frame loop itself runs in C++ (liblsdhip_driver.so, include/lsd_slam_hip.hpp): Python only hands over
-    # batches of device pointers and, for N > 1, starts the RCCL gather after every new keyframe
+    # batches of device pointers and, for N > 1, gathers the batch's finished keyframes afterwards
     from lsd_slam_amd.driver import DriverLoop
     from lsd_slam_amd import capi
     loop = DriverLoop(w, h, K, ptr(0), depth0, kf_every=KF_EVERY, images_on_device=True, device=local_rank)
