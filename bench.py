@@ -100,6 +100,44 @@ def cpu_baseline(frames, depth0, K, n_frames, w, h):
     }
 
 
+def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
+    """The same residual evaluation with enough independent work per launch: `jobs` trackFrame jobs (frames 1..5 of the
+    sequence against the keyframe with ground-truth depth) share every launch (lsdhip_tracker_track_batch, throughput mode:
+    LM launch + evaluation launch per step).  Reports the algorithmic bandwidth of the step kernels over ALL launches of the
+    jobs, HIP events around each batch; the level-1 evaluation launches alone run ~2.3x higher (profiles/r01_sizes.md).
+    An extra, not the bench metric: the single-sequence loop above is what `value` and `roofline` describe."""
+    ctx = la.Context(w, h, K, device=device)
+    refs, keep = [], []
+    for j in range(jobs):
+        kf = la.Frame(ctx, 100000 + j, device_ptr=d_frames[0].data_ptr())
+        kf.setDepthFromGroundTruth(depth0)
+        r = la.TrackingReference()
+        r.importFrame(kf)
+        refs.append(r)
+        keep.append(kf)
+    tr = la.SE3Tracker(ctx)
+    tr.set_maxItsPerLvl([5, 20, 50, 100, 0])
+    inits = np.tile(la.IDENTITY, (jobs, 1))
+
+    def one_round(k):
+        frs = [la.Frame(ctx, 200000 + jobs * k + j, device_ptr=d_frames[1 + (j + k) % 5].data_ptr()) for j in range(jobs)]
+        return tr.trackFrameBatch(refs, frs, inits)
+
+    one_round(0)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    ctx.synchronize()
+    for k in range(rounds):
+        one_round(k + 1)
+    ctx.synchronize()
+    ctx.prof_enable(False)
+    ms, n_eval, nbytes = ctx.prof_read()
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "jobs_per_launch": jobs, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "evaluations": int(n_eval), "stream_ms": ms,
+            "kernel": "k_track_step<TS_LM> + k_track_step<TS_EVAL>, all launches of %d rounds of %d jobs" % (rounds, jobs)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=250)
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra 64-jobs-per-launch measurement")
     ap.add_argument("--scene", type=str, default="S1", choices=["S1", "S2"],
                     help="synthetic scene (SURVEY.md §8(d)): S1 smooth texture (configs[1]); S2 Voronoi edge texture (configs[2], ~23 %% semi-dense)")
     ap.add_argument("--seq-frames", type=int, default=50,
@@ -235,6 +274,11 @@ def main():
             "lm_evaluations_per_frame": st.evaluations / max(1, st.frames),
             "roofline": roofline,
         }
+        if world == 1 and (w, h) == (640, 480) and not args.no_throughput_mode:
+            try:
+                out["roofline_throughput_mode"] = throughput_mode(la, w, h, K, d_frames, depth0, local_rank)
+            except Exception as e:   # an extra: never let it take the bench line down
+                out["roofline_throughput_mode"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, depth0, K, args.cpu_frames, w, h)
         else:

@@ -8,7 +8,7 @@ LSDHIP_LIB=lsd_slam_amd/liblsdhip_trace.so LSDHIP_TRACE_FILE=$OUT/trace.txt time
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 python -c "import json; d=json.load(open('$OUT/bench.json')); print('fps', d['value'], 'track', d['track_fps'], 'depth', d['depth_mpix_per_s'], 'evals', d['lm_evaluations_per_frame'], 'launch_us', d['roofline'] and d['roofline']['avg_launch_us'])"
 if [ -n "$PROF" ]; then
-  cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline-events > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/prof.err
+  cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline-events --no-throughput-mode > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/prof.err
   cd $GRAFT_REPO_ROOT
   python - <<PY
 import csv, glob
