@@ -207,6 +207,57 @@ def test_sim3_exp_reduces_to_se3_and_scales(oracle):
     assert T2[7] == pytest.approx(2.0) and np.allclose(T2[:7], [1, 0, 0, 0, 0, 0, 0])
 
 
+def test_sim3_exp_on_the_sophus_test_tangents(oracle):
+    """The tangent vectors of thirdparty/Sophus/sophus/test_sim3.cpp:72-85 through the oracle's Sim3::exp, against an
+    independent float64 evaluation of the closed form (rotation = SO3 exp, scale = e^sigma, translation = W(omega, sigma) upsilon,
+    sim3.hpp:417-428, :608-650) and the group properties tests.hpp checks for them: exp(a) exp(-a) = 1, (A B) p = A (B p)."""
+    def hat(o):
+        return np.array([[0, -o[2], o[1]], [o[2], 0, -o[0]], [-o[1], o[0], 0]])
+
+    def closed_form(a):
+        ups, om, sig = a[:3], a[3:6], a[6]
+        th = np.linalg.norm(om)
+        Om = hat(om)
+        R = np.eye(3) if th < 1e-12 else np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
+        s = np.exp(sig)
+        # W = integral_0^1 exp(t sigma) exp(t Omega) dt, evaluated numerically (Gauss-Legendre, 40 nodes): no formula shared
+        x, wq = np.polynomial.legendre.leggauss(40)
+        W = np.zeros((3, 3))
+        for xi, wi in zip(0.5 * (x + 1), 0.5 * wq):
+            tt = th * xi
+            Rt = np.eye(3) if th < 1e-12 else np.eye(3) + np.sin(tt) / th * Om + (1 - np.cos(tt)) / th ** 2 * Om @ Om
+            W += wi * np.exp(sig * xi) * Rt
+        return R, W @ ups, s
+
+    def act(T, p):
+        return T[7] * (oracle.quat_to_rot(T[:4]) @ p) + T[4:7]
+
+    def mul(A, B):
+        Ra, Rb = oracle.quat_to_rot(A[:4]), oracle.quat_to_rot(B[:4])
+        return Ra @ Rb, A[7] * (Ra @ B[4:7]) + A[4:7], A[7] * B[7]
+
+    tangents = [[0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0], [0, 1, 0, 1, 0, 0, 0.1], [0, 0, 1, 0, 1, 0, 0.1],
+                [-1, 1, 0, 0, 0, 1, -0.1], [20, -1, 0, -1, 1, 0, -0.1], [30, 5, -1, 20, -1, 0, 1.5]]
+    p = np.array([1.0, 2.0, 4.0])                      # test_sim3.cpp:89
+    Ts = []
+    for a in tangents:
+        a = np.array(a, np.float64)
+        T = oracle.sim3_exp(a)
+        R, t, s = closed_form(a)
+        # rotations by more than pi wrap: compare the matrices, not the quaternions
+        assert np.allclose(oracle.quat_to_rot(T[:4]), R, atol=1e-9), a
+        assert T[7] == pytest.approx(s, rel=1e-12)
+        assert np.allclose(T[4:7], t, rtol=1e-8, atol=1e-8), a
+        Rm, tm, sm = mul(T, oracle.sim3_exp(-a))
+        assert np.allclose(Rm, np.eye(3), atol=1e-9) and np.allclose(tm, 0, atol=1e-7) and sm == pytest.approx(1.0, rel=1e-12)
+        assert np.allclose(act(oracle.sim3_inv(T), act(T, p)), p, atol=1e-8)
+        Ts.append(T)
+    for A in Ts[1:4]:
+        for B in Ts[3:]:
+            Rm, tm, sm = mul(A, B)
+            assert np.allclose(sm * (Rm @ p) + tm, act(A, act(B, p)), atol=1e-7)
+
+
 @pytest.mark.parametrize("mode", ["SCALAR", "SSE", "SSE_EXACT_RCP"])
 def test_sim3_tracker_recovers_pose_and_scale(oracle, mode):
     w, h = 320, 240
