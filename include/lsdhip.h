@@ -210,6 +210,10 @@ int lsdhip_sim3tracker_track(lsdhip_sim3tracker* t, lsdhip_frame* keyframe, lsdh
  * computes what a single call computes.  Returns LSDHIP_DIVERGED if any job returned early (see results[j].diverged). */
 int lsdhip_sim3tracker_track_batch(lsdhip_sim3tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
                                    const double* init_frameToReference, int startLevel, int finalLevel, lsdhip_sim3_result* results);
+/* test hooks for the host-side arithmetic of the Sim3 LM step (pure CPU, usable without a GPU): out = exp(increment) *
+ * referenceToFrame with Sophus semantics (sim3.hpp:417-428, :160-163); x = A.ldlt().solve(b) for the 7x7 system */
+int lsdhip_host_sim3_step(const double increment[7], const double referenceToFrame[8], double out[8]);
+int lsdhip_host_ldlt7(const float A[49], const float b[7], float x[7]);
 /* test hook: one evaluation at referenceToFrame on `level` with affine (a, b) */
 int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame, const double referenceToFrame[8],
                                 int level, float aff_a, float aff_b, lsdhip_sim3_eval_record* out);

@@ -591,6 +591,18 @@ static void sim3_read_eval(lsdhip_sim3tracker* t, int slot, Eval* ev) {
 static Sim3H sim3_in(const double p[8]) { Sim3H T; T.q = {p[0], p[1], p[2], p[3]}; T.t[0] = p[4]; T.t[1] = p[5]; T.t[2] = p[6]; T.s = p[7]; return T; }
 static void sim3_out(const Sim3H& T, double p[8]) { p[0] = T.q.w; p[1] = T.q.x; p[2] = T.q.y; p[3] = T.q.z; p[4] = T.t[0]; p[5] = T.t[1]; p[6] = T.t[2]; p[7] = T.s; }
 
+// host-side algebra of the LM step, exported for CPU tests of the product's own arithmetic (no device involved)
+extern "C" int lsdhip_host_sim3_step(const double increment[7], const double referenceToFrame[8], double out[8]) {
+  if (!increment || !referenceToFrame || !out) return LSDHIP_E_ARG;
+  sim3_out(sim3_mul(sim3_exp(increment), sim3_in(referenceToFrame)), out);
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_host_ldlt7(const float A[49], const float b[7], float x[7]) {
+  if (!A || !b || !x) return LSDHIP_E_ARG;
+  ldlt7_solve(A, b, x);
+  return LSDHIP_OK;
+}
+
 extern "C" int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const double refToFrame[8], int level,
                                            float aff_a, float aff_b, lsdhip_sim3_eval_record* out) {
   if (!t || !kf || !frame || !refToFrame || !out || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
