@@ -212,6 +212,10 @@ int lsdhip_sim3tracker_track_batch(lsdhip_sim3tracker* t, int n, lsdhip_frame** 
                                    const double* init_frameToReference, int startLevel, int finalLevel, lsdhip_sim3_result* results);
 /* test hooks for the host-side arithmetic of the Sim3 LM step (pure CPU, usable without a GPU): out = exp(increment) *
  * referenceToFrame with Sophus semantics (sim3.hpp:417-428, :160-163); x = A.ldlt().solve(b) for the 7x7 system */
+/* the same for the SE3 tracker's LM step (float, Sophus SE3f semantics, C/Tracking/SE3Tracker.cpp:356-363): the functions the
+ * device kernel uses, compiled for the host */
+int lsdhip_host_se3f_step(const float increment[6], const float referenceToFrame[7], float out[7]);
+int lsdhip_host_ldlt6(const float A[36], const float b[6], float x[6]);
 int lsdhip_host_sim3_step(const double increment[7], const double referenceToFrame[8], double out[8]);
 int lsdhip_host_ldlt7(const float A[49], const float b[7], float x[7]);
 /* test hook: one evaluation at referenceToFrame on `level` with affine (a, b) */

@@ -98,6 +98,8 @@ def _signatures():
         "lsdhip_sim3tracker_set_max_its": (i, [vp, vp]),
         "lsdhip_sim3tracker_track": (i, [vp, vp, vp, vp, i, i, C.POINTER(Sim3Result)]),
         "lsdhip_sim3tracker_track_batch": (i, [vp, i, pvp, pvp, vp, i, i, C.POINTER(Sim3Result)]),
+        "lsdhip_host_se3f_step": (i, [vp, vp, vp]),
+        "lsdhip_host_ldlt6": (i, [vp, vp, vp]),
         "lsdhip_host_sim3_step": (i, [vp, vp, vp]),
         "lsdhip_host_ldlt7": (i, [vp, vp, vp]),
         "lsdhip_sim3tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(Sim3EvalRecord)]),

@@ -66,3 +66,27 @@ def test_ldlt7_solves_damped_normal_equations(L):
     x = np.zeros(7, np.float32)
     assert L.lsdhip_host_ldlt7(A.ctypes.data, b.ctypes.data, x.ctypes.data) == 0
     assert np.all(np.isfinite(x)) and x[2] == 0 and x[0] == pytest.approx(1.0) and x[6] == pytest.approx(1.0)
+
+
+def test_se3f_exp_and_ldlt6_match_the_oracle_bit_for_bit(L, oracle):
+    """pose_math.hpp (what the device LM runs) compiled for the host, against the oracle's Sophus SE3f restatement: same
+    operation order, contraction off on both sides"""
+    OL = oracle.lib()
+    rng = np.random.default_rng(6)
+    ident = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)
+    for k in range(40):
+        a = (rng.normal(0, 0.05 if k % 2 else 1.0, 6)).astype(np.float32)
+        if k == 0:
+            a[3:] = 0                                    # small-angle branch
+        got, want = np.zeros(7, np.float32), np.zeros(7, np.float32)
+        assert L.lsdhip_host_se3f_step(a.ctypes.data, ident.ctypes.data, got.ctypes.data) == 0
+        OL.orc_se3_exp_f(a, want)
+        assert np.allclose(got, want, rtol=0, atol=2e-7), (k, got, want)   # sinf/cosf of two C libraries may differ in the last bit
+    for k in range(30):
+        J = rng.normal(size=(50, 6)) * rng.uniform(0.01, 50.0, 6)
+        A = np.ascontiguousarray((J.T @ J).astype(np.float32))
+        b = rng.normal(size=6).astype(np.float32)
+        x, xo = np.zeros(6, np.float32), np.zeros(6, np.float32)
+        assert L.lsdhip_host_ldlt6(A.ctypes.data, b.ctypes.data, x.ctypes.data) == 0
+        OL.orc_ldlt6_solve(A.ravel(), b, xo)
+        assert np.array_equal(x, xo), k                                     # pure +,-,*,/ in a fixed order: identical bits
