@@ -38,3 +38,31 @@ def test_banded_hip_equals_full_frame_hip_and_oracle(oracle, world):
     for r, rows in br.owned_rows().items():
         y0, y1 = plan.owned[r]
         _rows_equal(rows, ref[y0:y1], "band %d of %d" % (r, world))
+
+
+def test_full_size_3840x2160_hip_vs_oracle_and_8_bands(oracle):
+    """BASELINE.json configs[4] at its real size: two fill-holes + regularise passes over the 3840x2160 scene-S3 map, full
+    frame HIP vs full-frame oracle, then 8 row bands (LocalComm on one GPU) vs the full frame — all bit-exact."""
+    from band_engines import OracleBandEngine
+    w, H, passes = 3840, 2160, 2
+    hyp, maxgrad = synth_s3(w, H)
+    full = HipBandEngine(w, H)
+    full.load(hyp, maxgrad)
+    orc = OracleBandEngine(w, H)
+    orc.load(hyp, maxgrad)
+    for _ in range(passes):
+        full.run_pass()
+        orc.run_pass()
+    ref = full.get()
+    _rows_equal(ref, orc.get(), "3840x2160 full-frame HIP vs oracle")
+    assert int((ref["isValid"] > 0).sum()) > 1_000_000
+    del orc
+    world = 8
+    plan = BandPlan(H, world)
+    engines = [HipBandEngine(w, plan.window_rows) for _ in range(world)]
+    br = BandRegularizer(plan, engines, LocalComm(), list(range(world)))
+    br.load(hyp, maxgrad)
+    br.run(passes)
+    for r, rows in br.owned_rows().items():
+        y0, y1 = plan.owned[r]
+        _rows_equal(rows, ref[y0:y1], "3840x2160 band %d of %d" % (r, world))

@@ -18,10 +18,28 @@ def hip():
     return la
 
 
-def make_pair(oracle, hip, w, h, n, seq_index=0):
-    frames, depth0, K, gt = sequence(w, h, n, seq_index)
-    ctx = hip.Context(w, h, K)
+def make_pair(oracle, hip, w, h, n, seq_index=0, params=None, kind="S1"):
+    frames, depth0, K, gt = sequence(w, h, n, seq_index, kind)
+    ctx = hip.Context(w, h, K, params=params)
     return frames, depth0, K, gt, ctx
+
+
+def oracle_params(oracle, params=None):
+    """the oracle's parameter block with the same overrides the HIP context got"""
+    op = oracle.default_params()
+    for k, v in (params or {}).items():
+        setattr(op, k, v)
+    return op
+
+
+# The reference's run-time switches on this path (C/util/settings.cpp:84-88).  The ROS front end pushes
+# useAffineLightningEstimation = False (cfg/LSDParams.cfg:27 via IOWrapper/ROS/rosReconfigure.h:84): that is the
+# configuration live_slam actually runs, so every function-level test covers both values.
+AFFINE = [pytest.param({}, id="affine1"), pytest.param({"useAffineLightningEstimation": 0}, id="affine0")]
+STEREO = [pytest.param({}, id="neg1-subpix1"),
+          pytest.param({"allowNegativeIdepths": 0}, id="neg0"),
+          pytest.param({"useSubpixelStereo": 0}, id="subpix0"),
+          pytest.param({"allowNegativeIdepths": 0, "useSubpixelStereo": 0, "useAffineLightningEstimation": 0}, id="ros-all0")]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -120,9 +138,11 @@ def _oracle_terms64(oracle, tr):
     return A, Aabs, b, babs, err, n
 
 
+@pytest.mark.parametrize("params", AFFINE)
 @pytest.mark.parametrize("w,h", [(176, 144), (320, 240), (640, 480)])
-def test_residual_kernel_fixed_pose(oracle, hip, w, h):
-    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4)
+def test_residual_kernel_fixed_pose(oracle, hip, w, h, params):
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4, params=params)
+    op = oracle_params(oracle, params)
     kfo = oracle.Frame(0, frames[0], K)
     kfg = hip.Frame(ctx, 0, frames[0])
     kfo.set_depth_gt(depth0)
@@ -131,7 +151,7 @@ def test_residual_kernel_fixed_pose(oracle, hip, w, h):
     ro.import_frame(kfo)
     rg = hip.TrackingReference()
     rg.importFrame(kfg)
-    tro = oracle.SE3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP)
+    tro = oracle.SE3Tracker(w, h, K, params=op, mode=oracle.SSE_EXACT_RCP)
     trg = hip.SE3Tracker(ctx)
     poses = [IDENT7.astype(np.float32),
              oracle.se3_inv(gt[3]).astype(np.float32),
@@ -176,9 +196,11 @@ def test_residual_kernel_fixed_pose(oracle, hip, w, h):
             assert np.allclose(np.array(r_g.A), np.array(r_o.A), rtol=2e-4, atol=1e-4 * np.abs(np.array(r_o.A)).max()), tag
 
 
+@pytest.mark.parametrize("params", AFFINE)
 @pytest.mark.parametrize("w,h", [(176, 144), (640, 480)])
-def test_trackframe_parity(oracle, hip, w, h):
-    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
+def test_trackframe_parity(oracle, hip, w, h, params):
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6, params=params)
+    op = oracle_params(oracle, params)
     kfo = oracle.Frame(0, frames[0], K)
     kfg = hip.Frame(ctx, 0, frames[0])
     kfo.set_depth_gt(depth0)
@@ -189,8 +211,8 @@ def test_trackframe_parity(oracle, hip, w, h):
     rg.importFrame(kfg)
     trg = hip.SE3Tracker(ctx)
     trg.set_maxItsPerLvl(ODOMETRY_ITS)
-    tr_sse = oracle.SE3Tracker(w, h, K, mode=oracle.SSE)
-    tr_sc = oracle.SE3Tracker(w, h, K, mode=oracle.SCALAR)
+    tr_sse = oracle.SE3Tracker(w, h, K, params=op, mode=oracle.SSE)
+    tr_sc = oracle.SE3Tracker(w, h, K, params=op, mode=oracle.SCALAR)
     tr_sse.set_max_its(ODOMETRY_ITS)
     tr_sc.set_max_its(ODOMETRY_ITS)
     init = IDENT7.copy()
@@ -209,6 +231,12 @@ def test_trackframe_parity(oracle, hip, w, h):
         assert trg.diverged == bool(r_sse.diverged) and trg.trackingWasGood == bool(r_sse.trackingWasGood)
         assert trg.lastResidual == pytest.approx(r_sse.lastResidual, rel=5e-2)
         assert trg.pointUsage == pytest.approx(r_sse.pointUsage, rel=1e-3)
+        if params.get("useAffineLightningEstimation", 1) == 0:
+            # the estimate is never applied (C/Tracking/SE3Tracker.cpp:331-335,393-397): (a, b) stay (1, 0)
+            assert trg.affineEstimation_a == 1.0 and trg.affineEstimation_b == 0.0
+            assert r_sse.affine_a == 1.0 and r_sse.affine_b == 0.0
+        else:
+            assert trg.affineEstimation_a == pytest.approx(r_sse.affine_a, rel=2e-3)
         # frame side effects
         so, sg = fo.stats(), fg.stats()
         assert sg["initialTrackedResidual"] == pytest.approx(so["initialTrackedResidual"], rel=5e-2)
@@ -266,12 +294,12 @@ def test_permaref_paths(oracle, hip):
 # ---------------------------------------------------------------------------------------------------------------
 # depth map stages
 # ---------------------------------------------------------------------------------------------------------------
-def _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, sigma=0.1, seed=1):
+def _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, sigma=0.1, seed=1, op=None):
     kfo = oracle.Frame(0, frames[0], K)
     kfg = hip.Frame(ctx, 0, frames[0])
     kfo.set_depth_gt(depth0)
     kfg.setDepthFromGroundTruth(depth0)
-    dmo = oracle.DepthMap(w, h, K)
+    dmo = oracle.DepthMap(w, h, K, params=op)
     dmg = hip.DepthMap(ctx)
     dmo.init_gt(kfo)
     dmg.initializeFromGTDepth(kfg)
@@ -330,10 +358,11 @@ def _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, ids, with_masks=True,
     return fos, fgs
 
 
+@pytest.mark.parametrize("params", STEREO)
 @pytest.mark.parametrize("w,h", [(176, 144), (320, 240), (640, 480)])
-def test_depth_stages_bit_exact(oracle, hip, w, h):
-    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8)
-    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h)
+def test_depth_stages_bit_exact(oracle, hip, w, h, params):
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8, params=params)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, op=oracle_params(oracle, params))
     kfo.set_counters(7, 3, 3, 0)
     kfg.setCounters(7, 3, 3, 0)
     fos, fgs = _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [3, 4, 6, 7])
@@ -371,10 +400,43 @@ def test_observe_reactivated_and_no_masks(oracle, hip):
     assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "observeDepth reactivated")
 
 
+@pytest.mark.parametrize("allow", [1, 0])
+def test_observe_far_scene_negative_idepths(oracle, hip, allow):
+    """allowNegativeIdepths (C/DepthEstimation/DepthMap.cpp:1904-1909; the ROS cfg offers it, cfg/LSDParams.cfg:25): a
+    prior 50x too far puts the search at the infinity end of the epipolar line, where the matched position gives
+    idepth_new < 0 for a few hundred pixels.  With the switch off those return -2 (validity -= 5, var *= 1.1, possibly
+    invalidate + blacklist); with it on they are fused.  Both settings bit-exact, and the two settings must differ (the
+    branch is really taken)."""
+    w, h = 320, 240
+    params = {"allowNegativeIdepths": allow}
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8, params=params)
+
+    def far_map(op, with_hip):
+        kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, op=op)
+        hyp = dmo.get()
+        for k in ("idepth", "idepth_smoothed"):
+            hyp[k] *= np.float32(0.02)
+        for k in ("idepth_var", "idepth_var_smoothed"):
+            hyp[k] *= np.float32(0.02 * 0.02)
+        dmo.set(kfo, hyp)
+        dmg.setCurrentDepthMap(kfg, hyp)
+        fos, fgs = _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [3, 4, 6, 7])
+        dmo.stage("observe", fos)
+        if with_hip:
+            dmg.stage("observe", fgs)
+            assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "observeDepth far scene allowNegativeIdepths=%d" % allow)
+        return dmo.get()
+
+    mine = far_map(oracle_params(oracle, params), True)
+    other = far_map(oracle_params(oracle, {"allowNegativeIdepths": 1 - allow}), False)
+    assert int((mine["validity_counter"] != other["validity_counter"]).sum()) > 50, "the negative-idepth branch was not exercised"
+
+
+@pytest.mark.parametrize("params", STEREO)
 @pytest.mark.parametrize("w,h", [(176, 144), (640, 480)])
-def test_update_keyframe_end_to_end(oracle, hip, w, h):
-    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
-    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, seed=11)
+def test_update_keyframe_end_to_end(oracle, hip, w, h, params):
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6, params=params)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, seed=11, op=oracle_params(oracle, params))
     for i in range(1, 6):
         fos, fgs = _ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [i], seed=i)
         dmo.update(fos)
@@ -545,10 +607,12 @@ def test_multipass_levels_match_single_pass(oracle, hip, cap, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_large_frame_1280x1024_track_and_update(oracle, hip):
-    """BASELINE.json configs[2] size: level 1 is 640x512 = 1280 tiles > the workgroup cap (multi-pass path)."""
+@pytest.mark.parametrize("kind", ["S1", "S2"])
+def test_large_frame_1280x1024_track_and_update(oracle, hip, kind):
+    """BASELINE.json configs[2]: 1280x1024, scene S2 (Voronoi edge texture, ~300 k semi-dense pixels) — and S1 at the same
+    size.  Level 1 is 640x512 = 1280 tiles > the workgroup cap (multi-pass path)."""
     w, h = 1280, 1024
-    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 3)
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 3, kind=kind)
     kfo, kfg = oracle.Frame(0, frames[0], K), hip.Frame(ctx, 0, frames[0])
     kfo.set_depth_gt(depth0)
     kfg.setDepthFromGroundTruth(depth0)
@@ -577,6 +641,9 @@ def test_large_frame_1280x1024_track_and_update(oracle, hip):
     dmo.update([fo])
     dmg.updateKeyframe([fg])
     assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), "updateKeyframe 1280x1024")
+    if kind == "S2":
+        n = int((dmo.get()["isValid"] > 0).sum())
+        assert 200_000 < n < 420_000, n     # configs[2]: ~300 k semi-dense pixels
 
 
 @pytest.mark.gpu

@@ -1,0 +1,74 @@
+"""Sequence-level parity (SURVEY.md Appendix C level 5): 50 frames of scene S1 at 640x480 through trackFrame ->
+updateKeyframe -> (every 10th frame) finalizeKeyFrame + createKeyFrame, the HIP library and the oracle each feeding
+their own outputs forward (tests/seq_loops.py; the loop is C/SlamSystem.cpp:890-1040 + :542-614 with doSlam=false,
+blockUntilMapped=true).  Errors compound over the sequence (pose -> mask -> depth map -> next reference), so the bar is
+expressed in units of the reference's own arithmetic spread: the oracle's scalar path vs its SSE path on the same
+sequence."""
+import numpy as np
+import pytest
+
+import seq_loops as sl
+from common import sequence
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 50
+CONFIGS = [pytest.param({}, id="defaults"),
+           pytest.param({"useAffineLightningEstimation": 0, "allowNegativeIdepths": 0, "useSubpixelStereo": 0}, id="ros-all0")]
+
+
+@pytest.mark.parametrize("params", CONFIGS)
+def test_sequence_50_frames_hip_vs_oracle(oracle, params):
+    import lsd_slam_amd as la
+    w, h = 640, 480
+    frames, depth0, K, gt = sequence(w, h, N_FRAMES)
+    op = oracle.default_params()
+    for k, v in params.items():
+        setattr(op, k, v)
+    o_sse = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SSE, params=op)
+    o_sc = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SCALAR, params=op)
+    ctx = la.Context(w, h, K, params=params)
+    g = sl.run_hip(la, ctx, frames, depth0, N_FRAMES)
+
+    assert len(g.frameToKF) == len(o_sse.frameToKF) == N_FRAMES
+    # identical verdicts, frame for frame
+    assert g.diverged == o_sse.diverged and not any(g.diverged)
+    assert g.good == o_sse.good
+    assert g.kf_frames == o_sse.kf_frames == [10, 20, 30, 40, 50]
+
+    # trajectory: camera centres in the world frame (keyframe chain with the createKeyFrame rescale factors)
+    spread = sl.rmse(o_sse.trajectory(), o_sc.trajectory())
+    err = sl.rmse(g.trajectory(), o_sse.trajectory())
+    gtc = np.array([gt[i % N_FRAMES][4:7] for i in range(1, N_FRAMES + 1)])
+    err_gt_g, err_gt_o = sl.rmse(g.trajectory(), gtc), sl.rmse(o_sse.trajectory(), gtc)
+    print("trajectory RMSE: HIP vs oracle-SSE %.3e, oracle scalar vs SSE %.3e, vs GT: HIP %.3e oracle %.3e"
+          % (err, spread, err_gt_g, err_gt_o))
+    assert err <= max(10.0 * spread, 1e-4), (err, spread)
+    assert err_gt_g <= 1.5 * err_gt_o + 1e-4, (err_gt_g, err_gt_o)
+    # per-frame relative poses
+    for i, (a, b) in enumerate(zip(g.frameToKF, o_sse.frameToKF)):
+        assert np.linalg.norm(a[4:7] - b[4:7]) < 5e-4 and min(np.linalg.norm(a[:4] - b[:4]), np.linalg.norm(a[:4] + b[:4])) < 5e-4, i
+    for a, b in zip(g.usage, o_sse.usage):
+        assert a == pytest.approx(b, rel=5e-3)
+
+    # keyframe changes: rescale factors and semi-dense counts (within 1 %)
+    for a, b in zip(g.rescale, o_sse.rescale):
+        assert a == pytest.approx(b, rel=1e-3)
+    for a, b in zip(g.semidense + [g.final_semidense], o_sse.semidense + [o_sse.final_semidense]):
+        assert abs(a - b) <= 0.01 * b, (a, b)
+    # the final map itself: validity masks nearly identical, inverse depths close where both are valid
+    ham = float((g.final_valid != o_sse.final_valid).mean())
+    ham_ref = float((o_sc.final_valid != o_sse.final_valid).mean())
+    print("final map: %d valid (oracle %d), mask Hamming %.2e (oracle scalar vs SSE %.2e)"
+          % (g.final_semidense, o_sse.final_semidense, ham, ham_ref))
+    assert ham <= max(10 * ham_ref, 2e-3)
+    both = g.final_valid & o_sse.final_valid
+    d = np.abs(g.final_map["idepth"][both] - o_sse.final_map["idepth"][both])
+    both_ref = o_sc.final_valid & o_sse.final_valid
+    d_ref = np.abs(o_sc.final_map["idepth"][both_ref] - o_sse.final_map["idepth"][both_ref])
+    print("final idepth |diff|: median %.2e p99 %.2e (oracle scalar vs SSE: %.2e, %.2e)"
+          % (np.median(d), np.percentile(d, 99), np.median(d_ref), np.percentile(d_ref, 99)))
+    # without sub-pixel stereo the matched position is quantised, so a flipped match moves a pixel by a whole step:
+    # the tail is bounded relative to the reference's own scalar-vs-SSE tail
+    assert np.median(d) <= max(3 * np.median(d_ref), 1e-4)
+    assert np.percentile(d, 99) <= max(3 * np.percentile(d_ref, 99), 5e-3)
