@@ -29,6 +29,10 @@ LSDM_HD void q_normalize(Quatf& q) {
   float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
   q.w /= n; q.x /= n; q.y /= n; q.z /= n;
 }
+LSDM_HD void q_normalize(Quatd& q) {
+  double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.w /= n; q.x /= n; q.y /= n; q.z /= n;
+}
 // v' = v + w*(2 q_v x v) + q_v x (2 q_v x v)   (Eigen QuaternionBase::_transformVector)
 template <typename Q, typename T> LSDM_HD void q_rotate(const Q& q, const T v[3], T out[3]) {
   T ux = q.y * v[2] - q.z * v[1], uy = q.z * v[0] - q.x * v[2], uz = q.x * v[1] - q.y * v[0];
@@ -60,15 +64,19 @@ LSDM_HD SE3dH se3d_inverse(const SE3dH& T) {
   q_rotate<Quatd, double>(r.q, nt, r.t);
   return r;
 }
+// Sophus SE3Group::cast<>() re-normalises the quaternion in the new scalar type (sophus/se3.hpp:144-149 ->
+// so3.hpp:125-129 -> SO3Group(const Quaternion&) so3.hpp:630-633)
 LSDM_HD SE3fH se3f_from_d(const SE3dH& T) {
   SE3fH r;
   r.q = {(float)T.q.w, (float)T.q.x, (float)T.q.y, (float)T.q.z};
+  q_normalize(r.q);
   for (int i = 0; i < 3; i++) r.t[i] = (float)T.t[i];
   return r;
 }
 LSDM_HD SE3dH se3d_from_f(const SE3fH& T) {
   SE3dH r;
   r.q = {(double)T.q.w, (double)T.q.x, (double)T.q.y, (double)T.q.z};
+  q_normalize(r.q);
   for (int i = 0; i < 3; i++) r.t[i] = (double)T.t[i];
   return r;
 }

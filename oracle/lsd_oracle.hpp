@@ -1,10 +1,22 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the shipped product path.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
 //
-// PARITY UNPINNED: tum-vision/lsd_slam ships no tests, golden vectors or fixtures for SE3Tracker /
-// DepthMap, and lsd_slam_core cannot be compiled here (ROS rosbuild, Eigen, boost, OpenCV, g2o are
-// absent, no network).  This is a dependency-free CPU restatement of the hot path, function by
-// function, each citing the reference file:line it follows.  `C/` = /root/reference/lsd_slam_core/src/.
+// A dependency-free CPU restatement of the hot path, function by function, each citing the reference
+// file:line it follows.  `C/` = /root/reference/lsd_slam_core/src/.
+//
+// PINNING: tum-vision/lsd_slam ships no tests, golden vectors or fixtures for SE3Tracker / DepthMap, and
+// lsd_slam_core as a whole cannot be built here (ROS rosbuild, Eigen, boost, OpenCV, g2o absent).  The
+// hot-path translation units themselves CAN be compiled, unchanged and where they lie, against stand-in
+// headers for those dependencies: oracle/_ref (recipe: oracle/Makefile target `ref`, stand-ins under
+// oracle/ref/shim).  tests/test_ref_pin_cpu.py runs this restatement against that build — pyramids, point
+// clouds, K1/K2/K3 buffers and normal equations (SSE and scalar paths), whole trackFrame calls, every
+// depth-map stage, doLineStereo pixel by pixel with its status codes, updateKeyframe / createKeyFrame /
+// finalizeKeyFrame and a 30-frame sequence fed forward — all BIT-EXACT.  What is NOT the reference's own
+// code in that build, and therefore still rests on restatement: the Eigen fixed-size arithmetic
+// (3x3 products / inverse, 6x6 LDL^T) and the Sophus SE3 / Sim3 group operations, which oracle/_ref
+// shares with this oracle (orc_math.hpp); Sophus exp / log are checked against the element list of the
+// reference's own sophus/test_se3.cpp (tests/test_oracle_cpu.py).  Sim3Tracker (orc_sim3.cpp) is not
+// part of oracle/_ref: PARITY UNPINNED for that file.
 //
 // Conventions: unwritten pool memory is defined as 0 (the reference recycles FrameMemory buffers,
 // C/DataStructures/FrameMemory.cpp:80-86); float op order is the *written* order of the reference and
@@ -256,10 +268,12 @@ class DepthMap {
   void observeDepthRow(int yMin, int yMax);
   bool observeDepthCreate(int x, int y, int idx);
   bool observeDepthUpdate(int x, int y, int idx, const float* keyFrameMaxGradBuf);
+ public:   // per-pixel parity hook (orc_depth_line_stereo)
   bool makeAndCheckEPL(int x, int y, const Frame* ref, float* pepx, float* pepy);
   float doLineStereo(float u, float v, float epxn, float epyn, float min_idepth, float prior_idepth, float max_idepth,
                      const Frame* referenceFrame, const float* referenceFrameImage, float& result_idepth,
                      float& result_var, float& result_eplLength);
+ private:
   void regularizeDepthMapFillHolesRow(int yMin, int yMax);
   void buildRegIntegralBuffer();
   void buildRegIntegralBufferRow1(int yMin, int yMax);

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see lsd_oracle.hpp).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lsd_oracle.hpp for what is pinned against oracle/_ref and what is not).
 // Flat C entry points over the oracle classes so that tests/ and bench.py's cpu_baseline leg can drive it
 // through ctypes.  Poses are double[7] = (qw,qx,qy,qz,tx,ty,tz); Sim3 adds the scale as an 8th element.
 #include <chrono>
@@ -310,3 +310,17 @@ double orc_now_seconds() {
 }
 
 }  // extern "C"
+
+// Per-pixel stereo hook (same contract as oracle/ref/ref_capi.cpp orc_depth_line_stereo)
+extern "C" void orc_depth_line_stereo(void* d, void* ref, int x, int y, float min_idepth, float prior_idepth, float max_idepth, float out[7]) {
+  orc::DepthMap* dm = (orc::DepthMap*)d;
+  dm->refreshActiveKeyFrameImage();
+  orc::Frame* rf = F(ref);
+  float epx = 0, epy = 0;
+  bool good = dm->makeAndCheckEPL(x, y, rf, &epx, &epy);
+  out[0] = good; out[1] = epx; out[2] = epy; out[3] = out[4] = out[5] = out[6] = 0;
+  if (!good) return;
+  float ri = 0, rv = 0, rl = 0;
+  out[3] = dm->doLineStereo((float)x, (float)y, epx, epy, min_idepth, prior_idepth, max_idepth, rf, rf->image(0), ri, rv, rl);
+  out[4] = ri; out[5] = rv; out[6] = rl;
+}

@@ -236,7 +236,10 @@ void DepthMap::propagateDepth(Frame* new_keyframe) {
 
   // SE3 oldToNew_SE3 = se3FromSim3(new_keyframe->pose->thisToParent_raw).inverse();  (double, :503)
   SE3d newToOld;
+  // se3FromSim3 = SE3(sim3.quaternion(), translation): the scaled quaternion, normalised by the SO3 constructor (so3.hpp:630-633)
   newToOld.q = new_keyframe->thisToParent_raw.q;
+  { const double s_ = new_keyframe->thisToParent_raw.s; newToOld.q.w *= s_; newToOld.q.x *= s_; newToOld.q.y *= s_; newToOld.q.z *= s_; }
+  qnormalize(newToOld.q);
   newToOld.t = new_keyframe->thisToParent_raw.t;
   SE3d oldToNew_SE3 = newToOld.inverse();
   V3f trafoInv_t = mk3<float>((float)oldToNew_SE3.t[0], (float)oldToNew_SE3.t[1], (float)oldToNew_SE3.t[2]);
@@ -494,7 +497,10 @@ void DepthMap::updateKeyframe(std::deque<std::shared_ptr<Frame>> referenceFrames
 // DepthMap.cpp:1222-1327
 void DepthMap::createKeyFrame(Frame* new_keyframe) {
   SE3d newToOld;
+  // se3FromSim3 = SE3(sim3.quaternion(), translation): the scaled quaternion, normalised by the SO3 constructor (so3.hpp:630-633)
   newToOld.q = new_keyframe->thisToParent_raw.q;
+  { const double s_ = new_keyframe->thisToParent_raw.s; newToOld.q.w *= s_; newToOld.q.x *= s_; newToOld.q.y *= s_; newToOld.q.z *= s_; }
+  qnormalize(newToOld.q);
   newToOld.t = new_keyframe->thisToParent_raw.t;
   SE3d oldToNew_SE3 = newToOld.inverse();
 
@@ -525,6 +531,7 @@ void DepthMap::createKeyFrame(Frame* new_keyframe) {
   lastRescaleFactor = rescaleFactor;
   SE3d back = oldToNew_SE3.inverse();
   activeKeyFrame->thisToParent_raw.q = back.q;
+  qnormalize(activeKeyFrame->thisToParent_raw.q);   // sim3FromSE3 -> Sim3::setScale normalises (rxso3.hpp:332-335)
   activeKeyFrame->thisToParent_raw.t = back.t;
   activeKeyFrame->thisToParent_raw.s = rescaleFactor;
   activeKeyFrame->setDepth(currentDepthMap);

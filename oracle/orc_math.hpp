@@ -1,9 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the shipped product path.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
 //
-// PARITY UNPINNED: the reference (tum-vision/lsd_slam) ships no golden vectors / unit tests for this
-// path and cannot be compiled in this environment (needs ROS, Eigen, boost, OpenCV, g2o).  This file
-// restates the small amount of Eigen 3.2 / Sophus v0.9a arithmetic the hot path relies on.
+// PARITY UNPINNED FOR THIS FILE beyond the Sophus test vectors: Eigen is absent from this machine and the
+// vendored Sophus needs it, so this file restates the small amount of Eigen 3.2 / Sophus v0.9a arithmetic
+// the hot path relies on (checked against the element list of sophus/test_se3.cpp in tests/test_oracle_cpu.py).
+// oracle/_ref (the reference's own sources, see lsd_oracle.hpp) is compiled against THIS arithmetic too.
 //
 // Minimal float/double linear algebra with the *operation order* of the libraries the reference uses:
 //  - fixed-size Matrix3f*Vector3f / Matrix3f*Matrix3f: Eigen 3.2 coefficient-based lazy product,
@@ -153,9 +154,12 @@ template <typename T> struct SE3 {
     qnormalize(r.q);
     return r;
   }
+  // se3.hpp:144-149 -> so3.hpp:125-129: the cast builds SO3Group<U>(quaternion.cast<U>()), and that constructor
+  // re-normalises in the NEW scalar type (so3.hpp:630-633).  (Found by running the oracle against oracle/_ref.)
   template <typename U> SE3<U> cast() const {
     SE3<U> r;
     r.q.w = (U)q.w; r.q.x = (U)q.x; r.q.y = (U)q.y; r.q.z = (U)q.z;
+    qnormalize(r.q);
     r.t = mk3<U>((U)t[0], (U)t[1], (U)t[2]);
     return r;
   }

@@ -412,6 +412,7 @@ SE3d SE3Tracker::trackFrame(TrackingReference* reference, Frame* frame, const SE
   frame->initialTrackedResidual = lastResidual / pointUsage;
   SE3d f2r = referenceToFrame.inverse().cast<double>();
   frame->thisToParent_raw.q = f2r.q;
+  qnormalize(frame->thisToParent_raw.q);   // sim3FromSE3 -> Sim3::setScale normalises the quaternion (rxso3.hpp:332-335)
   frame->thisToParent_raw.t = f2r.t;
   frame->thisToParent_raw.s = 1;
   frame->trackingParent = reference->keyframe;

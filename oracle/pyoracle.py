@@ -1,5 +1,5 @@
-"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/liblsd_oracle*.so (PARITY UNPINNED, see
-oracle/lsd_oracle.hpp).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/liblsd_oracle*.so and of oracle/_ref (the reference's
+own sources behind the same entry points; see oracle/lsd_oracle.hpp for what is pinned and what is not).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
 import ctypes as C
 import os
 import subprocess
@@ -56,12 +56,36 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
-def lib(fast=False):
-    name = "liblsd_oracle_fast.so" if fast else "liblsd_oracle.so"
+REF_DIR = os.path.join(_HERE, "_ref")
+
+
+def have_ref():
+    """oracle/_ref/liblsd_ref_{sse,scalar}.so: the reference's own hot-path sources compiled against the stand-in
+    dependency headers (oracle/ref/).  Built by `make -C oracle ref` where /root/reference exists; git-ignored, travels
+    with the gpurun snapshot."""
+    return all(os.path.exists(os.path.join(REF_DIR, "liblsd_ref_%s.so" % k)) for k in ("sse", "scalar"))
+
+
+def build_ref():
+    """Compile oracle/_ref from the reference sources where they lie (only possible where /root/reference exists)."""
+    if os.path.isdir("/root/reference/lsd_slam_core/src"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return have_ref()
+
+
+def lib(fast=False, ref=None):
+    """fast: the -O3 timing build of the oracle.  ref = "sse" | "scalar": the REFERENCE itself (oracle/_ref) behind the
+    same entry points — every class below works on either library."""
+    if ref is not None:
+        name = os.path.join("_ref", "liblsd_ref_%s.so" % ref)
+    else:
+        name = "liblsd_oracle_fast.so" if fast else "liblsd_oracle.so"
     if name in _LIBS:
         return _LIBS[name]
     path = os.path.join(_HERE, name)
     if not os.path.exists(path):
+        if ref is not None:
+            raise FileNotFoundError(path + " (make -C oracle ref, needs /root/reference)")
         build()
     L = C.CDLL(path)
     vp, i, f, d = C.c_void_p, C.c_int, C.c_float, C.c_double
@@ -121,6 +145,7 @@ def lib(fast=False):
         "orc_frame_take_reactivation": (None, [vp, vp]),
         "orc_frame_set_depth_from_map": (None, [vp, vp]),
         "orc_depth_stage": (None, [vp, i, C.POINTER(vp), i]),
+        "orc_depth_line_stereo": (None, [vp, vp, i, i, f, f, f, fp]),
         "orc_sim3tracker_create": (vp, [i, i, fp, C.POINTER(Params)]),
         "orc_sim3tracker_destroy": (None, [vp]),
         "orc_sim3tracker_set_mode": (None, [vp, i]),
@@ -131,6 +156,8 @@ def lib(fast=False):
         "orc_now_seconds": (d, []),
     }
     for name_, (res, args) in sig.items():
+        if ref is not None and not hasattr(L, name_):
+            continue          # the reference library exports the Frame / TrackingReference / SE3Tracker / DepthMap entry points only
         fn = getattr(L, name_)
         fn.restype = res
         fn.argtypes = args
@@ -403,6 +430,12 @@ class DepthMap:
     def set_from_existing(self, frame):
         self._keep.append(frame)
         self.L.orc_depth_set_from_existing(self.h_, frame.h_)
+
+    def line_stereo(self, ref_frame, x, y, min_idepth, prior_idepth, max_idepth):
+        """makeAndCheckEPL + doLineStereo for one pixel (no map update): (isGood, epx, epy, error, idepth, var, eplLength)"""
+        out = np.zeros(7, np.float32)
+        self.L.orc_depth_line_stereo(self.h_, ref_frame.h_, int(x), int(y), min_idepth, prior_idepth, max_idepth, out)
+        return out
 
     def stage(self, name, frames=()):
         k = {"observe": 0, "fillholes": 1, "regularize": 2, "regularize_occ": 3, "propagate": 4}[name]

@@ -1,9 +1,14 @@
 #!/usr/bin/env python
-"""Generates tests/golden/s1_160x128.npz: oracle outputs on a seeded synthetic sequence (scene S1, 160x128, 4 frames).
+"""Generates tests/golden/s1_160x128.npz on a seeded synthetic sequence (scene S1, 160x128, 4 frames).
 
-The reference ships no golden vectors for this path and cannot be built here, so the fixtures are the
-CPU oracle's outputs, frozen: the CPU suite checks that the oracle still reproduces them (oracle drift), the GPU suite
-checks the HIP path against them (bit-exact where the contract says so).  Run from the repository root:
+The reference ships no golden vectors for this path, so they are made here FROM THE REFERENCE ITSELF: pyramids, point-cloud
+counts, the trackFrame result and the updateKeyframe result come from oracle/_ref/liblsd_ref_sse.so — the reference's own
+SE3Tracker.cpp / DepthMap.cpp / Frame.cpp compiled against stand-in dependency headers (oracle/ref/, `make -C oracle ref`;
+needs /root/reference, so the fixture is generated in the build container and committed).  Two groups have no reference
+counterpart and come from the oracle: the fixed-pose residual records in the exact-reciprocal arithmetic a GPU can match
+(the reference's SSE path uses _mm_rcp_ps) and the Sim3 records (Sim3Tracker is not part of oracle/_ref).
+The CPU suite checks that the ORACLE reproduces every entry (so oracle == reference on this input, and no drift); the GPU
+suite checks the HIP path against them with no oracle involved at run time.  Run from the repository root:
     python tests/golden/make_golden.py
 """
 import hashlib
@@ -26,10 +31,11 @@ def digest(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
 
-def compute(frames, depth0, K):
-    """Everything the fixture freezes, from the oracle."""
+def compute(frames, depth0, K, L=None):
+    """Everything the fixture freezes.  L = po.lib(ref="sse"): the reference build (used by main()); L = None: the oracle
+    (used by tests/test_golden_cpu.py to check that it reproduces the reference-made fixture)."""
     g = {}
-    kf = po.Frame(0, frames[0], K)
+    kf = po.Frame(0, frames[0], K, L=L)
     kf.set_depth_gt(depth0)
     for lvl in range(5):
         g["image_L%d" % lvl] = digest(kf.plane("image", lvl))
@@ -37,16 +43,20 @@ def compute(frames, depth0, K):
         g["idepth_L%d" % lvl] = digest(kf.plane("idepth", lvl))
         g["idepthVar_L%d" % lvl] = digest(kf.plane("idepthVar", lvl))
     g["maxGradients_L0"] = digest(kf.plane("maxGradients", 0))
-    ref = po.TrackingReference()
+    ref = po.TrackingReference(L=L)
     ref.import_frame(kf)
     g["pointcloud_counts"] = np.array([len(ref.pointcloud(l)[0]) for l in range(5)], np.int32)
-    # residual evaluation at a fixed pose, every level
+    # residual evaluation at a fixed pose, every level — oracle only: SSE operation order with exact reciprocals
+    kf_o = po.Frame(0, frames[0], K)
+    kf_o.set_depth_gt(depth0)
+    ref_o = po.TrackingReference()
+    ref_o.import_frame(kf_o)
     tr = po.SE3Tracker(W, H, K, mode=po.SSE_EXACT_RCP)
     T = po.se3_exp(np.array([0.02, -0.01, 0.01, 0.005, -0.01, 0.015])).astype(np.float32)
     rec = []
     for lvl in (4, 3, 2, 1):
         f = po.Frame(3, frames[3], K)
-        r = tr.evaluate(ref, f, T, lvl, 1.0, 0.0)
+        r = tr.evaluate(ref_o, f, T, lvl, 1.0, 0.0)
         rec.append([r.warped_size, r.goodCount, r.badCount, r.num_constraints, r.pointUsage, r.weightedError] + list(r.A) + list(r.b))
         if lvl == 1:
             g["wasgood_fixed_pose"] = np.packbits(f.wasgood() == 1)
@@ -54,16 +64,16 @@ def compute(frames, depth0, K):
     g["fixed_pose"] = T
     g["residual_records"] = np.array(rec, np.float64)
     # trackFrame (SSE path of the reference) frame 2 on keyframe 0
-    tr2 = po.SE3Tracker(W, H, K, mode=po.SSE)
+    tr2 = po.SE3Tracker(W, H, K, mode=po.SSE, L=L)
     tr2.set_max_its(ITS)
-    f2 = po.Frame(2, frames[2], K)
+    f2 = po.Frame(2, frames[2], K, L=L)
     r = tr2.track(ref, f2, np.array([1.0, 0, 0, 0, 0, 0, 0]))
     g["track_pose"] = np.array(r.frameToRef, np.float64)
     g["track_scalars"] = np.array([r.pointUsage, r.lastGoodCount, r.lastBadCount, r.lastResidual, r.diverged, r.trackingWasGood], np.float64)
     g["track_wasgood"] = f2.wasgood().astype(np.uint8)          # 0 bad, 1 good, 255 never written (counts as good)
     g["track_initialTrackedResidual"] = np.array([f2.stats()["initialTrackedResidual"]], np.float32)
     # depth map: GT init, one updateKeyframe with that frame (pose / mask as the oracle left them)
-    dm = po.DepthMap(W, H, K)
+    dm = po.DepthMap(W, H, K, L=L)
     dm.init_gt(kf)
     dm.update([f2])
     hyp = dm.get()
@@ -98,8 +108,11 @@ def compute(frames, depth0, K):
 
 def main():
     po.build()
+    if not po.build_ref():
+        raise SystemExit("oracle/_ref is needed to make the fixture (make -C oracle ref; needs /root/reference)")
     frames, depth0, K, gt = synth.make_sequence(W, H, N)
-    g = compute(frames, depth0, K)
+    g = compute(frames, depth0, K, L=po.lib(ref="sse"))
+    g["generated_by"] = np.array("oracle/_ref/liblsd_ref_sse.so (reference sources, -DENABLE_SSE -DNDEBUG) + oracle for residual_records / sim3_*")
     np.savez_compressed(OUT, frames=frames, depth0=depth0.astype(np.float32), K=np.asarray(K, np.float32), **g)
     print("wrote %s (%d bytes, %d entries)" % (OUT, os.path.getsize(OUT), len(g)))
 

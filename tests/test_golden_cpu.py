@@ -1,5 +1,6 @@
-"""The committed golden fixture (tests/golden/s1_160x128.npz, made by tests/golden/make_golden.py) pins the oracle:
-any change of the oracle's arithmetic or of the synthetic generator shows up here, on CPU."""
+"""The committed golden fixture (tests/golden/s1_160x128.npz, made by tests/golden/make_golden.py FROM THE REFERENCE's own
+sources, oracle/_ref) pins the oracle: it must reproduce every entry bit for bit; any change of the oracle's arithmetic or of
+the synthetic generator shows up here, on CPU, also where /root/reference is absent."""
 import importlib.util
 import os
 
@@ -29,6 +30,7 @@ def test_synthetic_generator_reproduces_fixture_inputs():
 def test_oracle_reproduces_golden_outputs(oracle):
     m = _maker()
     g = np.load(GOLDEN)
+    assert "oracle/_ref" in str(g["generated_by"])
     now = m.compute(g["frames"], g["depth0"], g["K"])
     for k, v in now.items():
         assert np.array_equal(np.asarray(v), g[k]), "oracle output %s drifted from the committed fixture" % k

@@ -1,0 +1,418 @@
+"""PINNING THE ORACLE AGAINST THE REFERENCE ITSELF.
+
+oracle/_ref/liblsd_ref_{sse,scalar}.so are the reference's own hot-path translation units (SE3Tracker.cpp, DepthMap.cpp,
+Frame.cpp, TrackingReference.cpp, DepthMapPixelHypothesis.cpp, FrameMemory.cpp, FramePoseStruct.cpp, settings.cpp)
+compiled unchanged from /root/reference against stand-in headers for the absent external dependencies (oracle/ref/shim:
+Eigen, Sophus-on-Eigen, boost, OpenCV, g2o), behind the same orc_* entry points as the oracle (oracle/ref/ref_capi.cpp).
+These tests run the oracle's restatement and the reference side by side on the same seeded inputs.  Everything per-pixel
+is the reference's code, so the bar is BIT-EXACT for every stage, and — because the 6x6 solve and SE3 exponential are
+shared stand-in algebra — also for whole trackFrame calls and for a 30-frame sequence fed forward.
+
+Skipped where oracle/_ref cannot be built (/root/reference absent and no prebuilt library in the snapshot)."""
+import numpy as np
+import pytest
+
+import seq_loops as sl
+from common import ODOMETRY_ITS, assert_bit_equal, sequence
+
+IDENT7 = np.array([1.0, 0, 0, 0, 0, 0, 0])
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.have_ref() and not oracle.build_ref():
+        pytest.skip("oracle/_ref not available (needs /root/reference to build)")
+    oracle.build_ref()          # rebuild if the stand-in headers changed
+    return {"sse": oracle.lib(ref="sse"), "scalar": oracle.lib(ref="scalar")}
+
+
+MODES = [("sse", 1), ("scalar", 0)]   # (reference build, oracle TrackerMode)
+
+
+def params_of(oracle, L, overrides):
+    p = oracle.default_params(L)
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def stats_equal(a, b, tracked=True):
+    """Frame::initialize (C/DataStructures/Frame.cpp:397-484) never sets initialTrackedResidual: until trackFrame writes it the
+    reference holds whatever the allocation held — only compared for frames that were tracked."""
+    a, b = dict(a), dict(b)
+    if not tracked:
+        a.pop("initialTrackedResidual"), b.pop("initialTrackedResidual")
+    return a == b
+
+
+def assert_hyp_bits(a, b, what):
+    for k in ("isValid", "blacklisted"):
+        assert_bit_equal(a[k], b[k], what + ": " + k)
+    v = b["isValid"] > 0
+    for k in ("validity_counter", "nextStereoFrameMinID", "idepth", "idepth_var", "idepth_smoothed", "idepth_var_smoothed"):
+        assert_bit_equal(a[k][v], b[k][v], what + ": " + k)
+
+
+@pytest.mark.parametrize("w,h", [(160, 128), (176, 144), (640, 480)])
+@pytest.mark.parametrize("build", ["sse", "scalar"])
+def test_pyramids_and_intrinsics(oracle, ref, w, h, build):
+    frames, depth0, K, gt = sequence(w, h, 2)
+    L = ref[build]
+    fo, fr = oracle.Frame(0, frames[1], K), oracle.Frame(0, frames[1], K, L=L)
+    oracle.lib().orc_frame_set_sse_pyramid(fo.h_, 1 if build == "sse" else 0)
+    for lvl in range(5):
+        assert np.array_equal(fo.intrinsics(lvl), fr.intrinsics(lvl)), lvl
+        assert_bit_equal(fo.plane("image", lvl), fr.plane("image", lvl), "image L%d" % lvl)
+        assert_bit_equal(fo.plane("gradients", lvl), fr.plane("gradients", lvl), "gradients L%d" % lvl)
+        assert_bit_equal(fo.plane("maxGradients", lvl), fr.plane("maxGradients", lvl), "maxGradients L%d" % lvl)
+    assert fo.stats()["numMappablePixels"] == fr.stats()["numMappablePixels"]
+    fo.set_depth_gt(depth0)
+    fr.set_depth_gt(depth0)
+    for lvl in range(5):
+        assert_bit_equal(fo.plane("idepth", lvl), fr.plane("idepth", lvl), "idepth L%d" % lvl)
+        assert_bit_equal(fo.plane("idepthVar", lvl), fr.plane("idepthVar", lvl), "idepthVar L%d" % lvl)
+    # ragged validity through the inverse-variance pooling
+    rng = np.random.default_rng(7)
+    idp = rng.uniform(-0.2, 2.0, (h, w)).astype(np.float32)
+    var = rng.uniform(1e-6, 0.25, (h, w)).astype(np.float32)
+    hole = rng.uniform(size=(h, w)) < 0.6
+    idp[hole] = -1
+    var[hole] = -1
+    fo.set_depth_planes(idp, var)
+    fr.set_depth_planes(idp, var)
+    for lvl in range(5):
+        assert_bit_equal(fo.plane("idepth", lvl), fr.plane("idepth", lvl), "ragged idepth L%d" % lvl)
+        assert_bit_equal(fo.plane("idepthVar", lvl), fr.plane("idepthVar", lvl), "ragged idepthVar L%d" % lvl)
+
+
+def _kf_pair(oracle, L, frames, depth0, K):
+    kfo, kfr = oracle.Frame(0, frames[0], K), oracle.Frame(0, frames[0], K, L=L)
+    kfo.set_depth_gt(depth0)
+    kfr.set_depth_gt(depth0)
+    ro, rr = oracle.TrackingReference(), oracle.TrackingReference(L=L)
+    ro.import_frame(kfo)
+    rr.import_frame(kfr)
+    return kfo, kfr, ro, rr
+
+
+def test_pointcloud(oracle, ref):
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 1)
+    kfo, kfr, ro, rr = _kf_pair(oracle, ref["sse"], frames, depth0, K)
+    for lvl in (4, 3, 2, 1, 0):
+        a, b = ro.pointcloud(lvl), rr.pointcloud(lvl)
+        assert len(a[0]) == len(b[0]) > 0
+        for x, y, name in zip(a, b, ("posData", "colorAndVarData", "gradData", "pointPosInXYGrid")):
+            assert_bit_equal(x, y, "%s L%d" % (name, lvl))
+
+
+@pytest.mark.parametrize("affine", [1, 0])
+@pytest.mark.parametrize("build,mode", MODES)
+@pytest.mark.parametrize("w,h", [(176, 144), (640, 480)])
+def test_residual_weights_and_normal_equations(oracle, ref, w, h, build, mode, affine):
+    """calcResidualAndBuffers + calcWeightsAndResidual + calculateWarpUpdate (K1+K2+K3) at fixed poses: every buffer, the
+    mask, the statistics and the 6x6 system bit for bit — SSE build vs the oracle's SSE mode (real _mm_rcp_ps on both
+    sides), scalar build vs its scalar mode."""
+    frames, depth0, K, gt = sequence(w, h, 4)
+    L = ref[build]
+    ov = {"useAffineLightningEstimation": affine}
+    kfo, kfr, ro, rr = _kf_pair(oracle, L, frames, depth0, K)
+    tro = oracle.SE3Tracker(w, h, K, params=params_of(oracle, None, ov), mode=mode)
+    trr = oracle.SE3Tracker(w, h, K, params=params_of(oracle, L, ov), L=L)
+    poses = [IDENT7.astype(np.float32), oracle.se3_inv(gt[3]).astype(np.float32),
+             oracle.se3_exp(np.array([0.05, -0.03, 0.02, 0.01, -0.02, 0.03])).astype(np.float32),
+             oracle.se3_exp(np.array([0.9, 0.1, 0.0, 0.0, 0.35, 0.0])).astype(np.float32)]
+    for pi, T in enumerate(poses):
+        for lvl in (4, 3, 2, 1):
+            fo, fr = oracle.Frame(3, frames[3], K), oracle.Frame(3, frames[3], K, L=L)
+            a, b = (1.0, 0.0) if pi % 2 == 0 else (1.03, -2.5)
+            r_o, r_r = tro.evaluate(ro, fo, T, lvl, a, b), trr.evaluate(rr, fr, T, lvl, a, b)
+            tag = "pose %d level %d" % (pi, lvl)
+            assert r_o.warped_size == r_r.warped_size, tag
+            for k in ("goodCount", "badCount", "pointUsage", "meanRes", "retval", "affine_a_lastIt", "affine_b_lastIt",
+                      "weightedError", "lsError", "num_constraints"):
+                assert np.float64(getattr(r_o, k)).tobytes() == np.float64(getattr(r_r, k)).tobytes(), (tag, k, getattr(r_o, k), getattr(r_r, k))
+            for name in ("x", "y", "z", "dx", "dy", "residual", "d", "idepthVar", "weight_p"):
+                assert_bit_equal(tro.buffer(name), trr.buffer(name), "%s buf_%s" % (tag, name))
+            assert_bit_equal(np.array(r_o.A, np.float32), np.array(r_r.A, np.float32), tag + " A")
+            assert_bit_equal(np.array(r_o.b, np.float32), np.array(r_r.b, np.float32), tag + " b")
+            if lvl == 1:
+                assert_bit_equal(fo.wasgood(), fr.wasgood(), tag + " refPixelWasGood")
+            else:
+                assert fo.wasgood() is None and fr.wasgood() is None
+
+
+@pytest.mark.parametrize("affine", [1, 0])
+@pytest.mark.parametrize("build,mode", MODES)
+def test_trackframe(oracle, ref, build, mode, affine):
+    w, h = 640, 480
+    frames, depth0, K, gt = sequence(w, h, 6)
+    L = ref[build]
+    ov = {"useAffineLightningEstimation": affine}
+    kfo, kfr, ro, rr = _kf_pair(oracle, L, frames, depth0, K)
+    tro = oracle.SE3Tracker(w, h, K, params=params_of(oracle, None, ov), mode=mode)
+    trr = oracle.SE3Tracker(w, h, K, params=params_of(oracle, L, ov), L=L)
+    tro.set_max_its(ODOMETRY_ITS)
+    trr.set_max_its(ODOMETRY_ITS)
+    io, ir = IDENT7.copy(), IDENT7.copy()
+    for i in range(1, 6):
+        fo, fr = oracle.Frame(i, frames[i], K), oracle.Frame(i, frames[i], K, L=L)
+        a, b = tro.track(ro, fo, io), trr.track(rr, fr, ir)
+        assert np.array_equal(np.array(a.frameToRef), np.array(b.frameToRef)), (i, np.array(a.frameToRef) - np.array(b.frameToRef))
+        for k in ("pointUsage", "lastGoodCount", "lastBadCount", "lastMeanRes", "lastResidual", "affine_a", "affine_b", "diverged", "trackingWasGood"):
+            assert getattr(a, k) == getattr(b, k), (i, k)
+        assert_bit_equal(fo.wasgood(), fr.wasgood(), "refPixelWasGood frame %d" % i)
+        assert fo.stats() == fr.stats()
+        assert np.array_equal(fo.pose(), fr.pose())
+        io, ir = np.array(a.frameToRef), np.array(b.frameToRef)
+    assert kfo.stats()["numFramesTrackedOnThis"] == kfr.stats()["numFramesTrackedOnThis"] == 5
+    # divergence: identity + flags (C/Tracking/SE3Tracker.cpp:324-329)
+    bad = oracle.se3_exp(np.array([5.0, 0, 0, 0, 0, 0]))
+    a, b = tro.track(ro, oracle.Frame(9, frames[1], K), bad), trr.track(rr, oracle.Frame(9, frames[1], K, L=L), bad)
+    assert a.diverged and b.diverged and not a.trackingWasGood and not b.trackingWasGood
+    assert np.array_equal(np.array(a.frameToRef), IDENT7) and np.array_equal(np.array(b.frameToRef), IDENT7)
+
+
+def test_permaref_and_overlap(oracle, ref):
+    w, h = 640, 480
+    frames, depth0, K, gt = sequence(w, h, 4)
+    L = ref["sse"]
+    kfo, kfr, ro, rr = _kf_pair(oracle, L, frames, depth0, K)
+    pos, cv, _, _ = ro.pointcloud(4)
+    tro, trr = oracle.SE3Tracker(w, h, K, mode=oracle.SSE), oracle.SE3Tracker(w, h, K, L=L)
+    T0 = oracle.se3_exp(np.array([0.01, 0.0, 0.0, 0, 0, 0.002]))
+    a = tro.track_permaref(pos, cv, oracle.Frame(3, frames[3], K), T0)
+    b = trr.track_permaref(pos, cv, oracle.Frame(3, frames[3], K, L=L), T0)
+    assert np.array_equal(np.array(a.frameToRef), np.array(b.frameToRef))
+    assert (a.trackingWasGood, a.diverged, a.lastResidual, a.pointUsage) == (b.trackingWasGood, b.diverged, b.lastResidual, b.pointUsage)
+    assert tro.check_overlap(pos, kfo, T0) == trr.check_overlap(pos, kfr, T0)
+
+
+STEREO = [pytest.param({}, id="neg1-subpix1"), pytest.param({"allowNegativeIdepths": 0}, id="neg0"),
+          pytest.param({"useSubpixelStereo": 0}, id="subpix0"),
+          pytest.param({"allowNegativeIdepths": 0, "useSubpixelStereo": 0}, id="ros-all0")]
+
+
+def _noisy_maps(oracle, L, op, opr, frames, depth0, K, w, h, sigma=0.1, seed=1, idscale=1.0):
+    kfo, kfr = oracle.Frame(0, frames[0], K), oracle.Frame(0, frames[0], K, L=L)
+    kfo.set_depth_gt(depth0)
+    kfr.set_depth_gt(depth0)
+    dmo, dmr = oracle.DepthMap(w, h, K, params=op), oracle.DepthMap(w, h, K, params=opr, L=L)
+    dmo.init_gt(kfo)
+    dmr.init_gt(kfr)
+    assert_hyp_bits(dmo.get(), dmr.get(), "initializeFromGTDepth")
+    hyp = dmo.get()
+    rng = np.random.default_rng(seed)
+    v = hyp["isValid"] > 0
+    noise = rng.normal(0, sigma, hyp.shape).astype(np.float32)
+    for k in ("idepth", "idepth_smoothed"):
+        hyp[k][v] = (hyp[k][v] + noise[v]) * np.float32(idscale)
+    for k in ("idepth_var", "idepth_var_smoothed"):
+        hyp[k][v] = (sigma * idscale) ** 2
+    hyp["isValid"][rng.uniform(size=hyp.shape) < 0.15] = 0
+    hyp["blacklisted"][rng.uniform(size=hyp.shape) < 0.03] = -2
+    hyp["blacklisted"][rng.uniform(size=hyp.shape) < 0.03] = -1
+    hyp["validity_counter"] = rng.integers(0, 60, hyp.shape).astype(np.int32)
+    hyp["nextStereoFrameMinID"][rng.uniform(size=hyp.shape) < 0.2] = 4.0
+    dmo.set(kfo, hyp)
+    dmr.set(kfr, hyp)
+    return kfo, kfr, dmo, dmr
+
+
+def _ref_frames(oracle, L, frames, K, gt, kfo, kfr, ids, with_masks=True, seed=5):
+    rng = np.random.default_rng(seed)
+    fos, frs = [], []
+    for i in ids:
+        fo, fr = oracle.Frame(i, frames[i], K), oracle.Frame(i, frames[i], K, L=L)
+        twist = np.array([0.0, 0.0, 0.003, 0.0008, -0.0006, 0.0004]) * (1 + 0.1 * i)
+        sim3 = np.concatenate([oracle.se3_mul(gt[i], oracle.se3_exp(twist)), [1.0]])
+        fo.set_pose(sim3, kfo, 0.3 + 0.1 * i)
+        fr.set_pose(sim3, kfr, 0.3 + 0.1 * i)
+        if with_masks:
+            m = (rng.uniform(size=(fo.h >> 1, fo.w >> 1)) < 0.9).astype(np.uint8)
+            fo.set_wasgood(m)
+            fr.set_wasgood(m)
+        fos.append(fo)
+        frs.append(fr)
+    return fos, frs
+
+
+@pytest.mark.parametrize("threads", [4, 1])
+@pytest.mark.parametrize("ov", STEREO)
+@pytest.mark.parametrize("w,h", [(176, 144), (640, 480)])
+def test_depth_stages(oracle, ref, w, h, ov, threads):
+    """observeDepth (makeAndCheckEPL + doLineStereo + create / update), fill holes, both regularise variants, a second
+    observe pass — DepthMap.cpp's own code against the restatement, 4 worker threads and single-threaded."""
+    if (w, h) == (640, 480) and threads == 1 and ov:
+        pytest.skip("single-threaded run covered at the small size")
+    frames, depth0, K, gt = sequence(w, h, 8)
+    L = ref["sse"]
+    op, opr = params_of(oracle, None, ov), params_of(oracle, L, ov)
+    kfo, kfr, dmo, dmr = _noisy_maps(oracle, L, op, opr, frames, depth0, K, w, h)
+    for dm in (dmo, dmr):
+        dm.L.orc_depth_set_threads(dm.h_, threads)
+    kfo.set_counters(7, 3, 3, 0)
+    kfr.set_counters(7, 3, 3, 0)
+    fos, frs = _ref_frames(oracle, L, frames, K, gt, kfo, kfr, [3, 4, 6, 7])
+    dmo.stage("observe", fos)
+    dmr.stage("observe", frs)
+    for a, b in zip(fos, frs):
+        assert_bit_equal(a.stereo_precomp(), b.stereo_precomp(), "prepareForStereoWith")
+    assert_hyp_bits(dmo.get(), dmr.get(), "observeDepth")
+    for st in ("fillholes", "regularize", "regularize_occ"):
+        dmo.stage(st)
+        dmr.stage(st)
+        assert_hyp_bits(dmo.get(), dmr.get(), st)
+    dmo.stage("observe", fos[1:])
+    dmr.stage("observe", frs[1:])
+    assert_hyp_bits(dmo.get(), dmr.get(), "observeDepth (2nd)")
+
+
+def test_line_stereo_status_codes_per_pixel(oracle, ref):
+    """makeAndCheckEPL + doLineStereo pixel by pixel (every 2nd pixel, create- and update-style search intervals): the
+    EPL direction, the status code (-1 ... -4) or matching error, and the three results, bit for bit —
+    including the codes the callers never store."""
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 8)
+    L = ref["sse"]
+    kfo, kfr, dmo, dmr = _noisy_maps(oracle, L, None, None, frames, depth0, K, w, h)
+    # frame "6" shows ANOTHER scene (sequence index 1) under frame 6's pose: photometric failures (-3) and ambiguity (-2)
+    other = sequence(w, h, 8, 1)[0]
+    frames = frames.copy()
+    frames[6] = other[6]
+    fos, frs = _ref_frames(oracle, L, frames, K, gt, kfo, kfr, [3, 6])
+    hyp = dmo.get().copy()
+    dmo.stage("observe", fos)     # runs prepareForStereoWith on the reference frames
+    dmr.stage("observe", frs)
+    dmo.set(kfo, hyp)
+    dmr.set(kfr, hyp)
+    codes = {}
+    for y in range(3, h - 3, 2):
+        for x in range(3 + (y % 4) // 2, w - 3, 2):
+            t = hyp[y, x]
+            if t["isValid"]:
+                sv = np.float32(np.sqrt(np.float64(t["idepth_var_smoothed"])))
+                lo = max(np.float32(t["idepth_smoothed"] - sv * np.float32(2)), np.float32(0))
+                hi = min(np.float32(t["idepth_smoothed"] + sv * np.float32(2)), np.float32(20))
+                args = (lo, t["idepth_smoothed"], hi)
+            else:
+                args = (0.0, 1.0, 20.0)
+            k = (x + y) % 2
+            a, b = dmo.line_stereo(fos[k], x, y, *args), dmr.line_stereo(frs[k], x, y, *args)
+            assert a.tobytes() == b.tobytes(), (x, y, a, b)
+            c = int(a[3]) if a[0] and a[3] < 0 else (1 if a[0] else 0)
+            codes[c] = codes.get(c, 0) + 1
+    assert codes.get(1, 0) > 1000 and codes.get(0, 0) > 1000 and codes.get(-1, 0) > 10 and codes.get(-2, 0) > 10 and codes.get(-3, 0) > 10, codes
+    print(codes)
+
+
+@pytest.mark.parametrize("allow", [1, 0])
+def test_observe_far_scene_negative_idepths(oracle, ref, allow):
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 8)
+    L = ref["sse"]
+    ov = {"allowNegativeIdepths": allow}
+    kfo, kfr, dmo, dmr = _noisy_maps(oracle, L, params_of(oracle, None, ov), params_of(oracle, L, ov), frames, depth0, K, w, h, idscale=0.02)
+    fos, frs = _ref_frames(oracle, L, frames, K, gt, kfo, kfr, [3, 4, 6, 7])
+    dmo.stage("observe", fos)
+    dmr.stage("observe", frs)
+    assert_hyp_bits(dmo.get(), dmr.get(), "observeDepth far scene")
+
+
+def test_observe_reactivated_no_masks(oracle, ref):
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 8)
+    L = ref["sse"]
+    kfo, kfr, dmo, dmr = _noisy_maps(oracle, L, None, None, frames, depth0, K, w, h, seed=3)
+    hyp = dmo.get()
+    dmo.set(kfo, hyp, reactivated=True)
+    dmr.set(kfr, hyp, reactivated=True)
+    fos, frs = _ref_frames(oracle, L, frames, K, gt, kfo, kfr, [2, 5], with_masks=False)
+    dmo.stage("observe", fos)
+    dmr.stage("observe", frs)
+    assert_hyp_bits(dmo.get(), dmr.get(), "observeDepth reactivated")
+
+
+@pytest.mark.parametrize("ov", STEREO[:1] + STEREO[3:])
+def test_update_keyframe_calls(oracle, ref, ov):
+    w, h = 640, 480
+    frames, depth0, K, gt = sequence(w, h, 6)
+    L = ref["sse"]
+    kfo, kfr, dmo, dmr = _noisy_maps(oracle, L, params_of(oracle, None, ov), params_of(oracle, L, ov), frames, depth0, K, w, h, seed=11)
+    for i in range(1, 6):
+        fos, frs = _ref_frames(oracle, L, frames, K, gt, kfo, kfr, [i], seed=i)
+        dmo.update(fos)
+        dmr.update(frs)
+        assert_hyp_bits(dmo.get(), dmr.get(), "updateKeyframe %d" % i)
+    assert stats_equal(kfo.stats(), kfr.stats(), tracked=False)
+    for lvl in range(5):
+        assert_bit_equal(kfo.plane("idepth", lvl), kfr.plane("idepth", lvl), "kf idepth L%d" % lvl)
+        assert_bit_equal(kfo.plane("idepthVar", lvl), kfr.plane("idepthVar", lvl), "kf idepthVar L%d" % lvl)
+
+
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_propagate_create_finalize_reactivate(oracle, ref, use_mask):
+    w, h = 640, 480
+    frames, depth0, K, gt = sequence(w, h, 10)
+    L = ref["sse"]
+    kfo, kfr, dmo, dmr = _noisy_maps(oracle, L, None, None, frames, depth0, K, w, h, sigma=0.05, seed=21)
+    dmo.stage("regularize")
+    dmr.stage("regularize")
+    fos, frs = _ref_frames(oracle, L, frames, K, gt, kfo, kfr, [9], with_masks=use_mask)
+    hyp0 = dmo.get()
+    dmo.stage("propagate", fos)
+    dmr.stage("propagate", frs)
+    assert_hyp_bits(dmo.get(), dmr.get(), "propagateDepth")
+    # the full createKeyFrame from the same starting state (fresh maps: the stage hook switched keyframes)
+    kfo, kfr, dmo, dmr = _noisy_maps(oracle, L, None, None, frames, depth0, K, w, h, sigma=0.05, seed=21)
+    dmo.set(kfo, hyp0)
+    dmr.set(kfr, hyp0)
+    fos, frs = _ref_frames(oracle, L, frames, K, gt, kfo, kfr, [9], with_masks=use_mask)
+    s_o, s_r = dmo.create_keyframe(fos[0]), dmr.create_keyframe(frs[0])
+    assert s_o == s_r
+    assert_hyp_bits(dmo.get(), dmr.get(), "createKeyFrame")
+    assert np.array_equal(fos[0].pose(), frs[0].pose())
+    assert fos[0].stats() == frs[0].stats()
+    dmo.finalize()
+    dmr.finalize()
+    assert_hyp_bits(dmo.get(), dmr.get(), "finalizeKeyFrame")
+    for lvl in range(5):
+        assert_bit_equal(fos[0].plane("idepth", lvl), frs[0].plane("idepth", lvl), "finalize idepth L%d" % lvl)
+    dmo.set_from_existing(fos[0])
+    dmr.set_from_existing(frs[0])
+    assert_hyp_bits(dmo.get(), dmr.get(), "setFromExistingKF")
+
+
+def test_initialize_randomly(oracle, ref):
+    import ctypes
+    libc = ctypes.CDLL(None)
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 1)
+    L = ref["sse"]
+    kfo, kfr = oracle.Frame(0, frames[0], K), oracle.Frame(0, frames[0], K, L=L)
+    dmo, dmr = oracle.DepthMap(w, h, K), oracle.DepthMap(w, h, K, L=L)
+    libc.srand(12345)
+    dmo.init_random(kfo)
+    libc.srand(12345)
+    dmr.init_random(kfr)
+    assert_hyp_bits(dmo.get(), dmr.get(), "initializeRandomly")
+    for lvl in range(5):
+        assert_bit_equal(kfo.plane("idepth", lvl), kfr.plane("idepth", lvl), "kf idepth L%d" % lvl)
+
+
+@pytest.mark.parametrize("build,mode", MODES)
+@pytest.mark.parametrize("ov", [pytest.param({}, id="defaults"),
+                                pytest.param({"useAffineLightningEstimation": 0, "allowNegativeIdepths": 0, "useSubpixelStereo": 0}, id="ros-all0")])
+def test_sequence_fed_forward(oracle, ref, build, mode, ov):
+    """30 frames of the track + map loop (keyframe change every 10), each library feeding its own outputs forward: the
+    trajectories, verdicts, rescale factors and the final depth map must be IDENTICAL."""
+    w, h, n = 320, 240, 30
+    frames, depth0, K, gt = sequence(w, h, n)
+    L = ref[build]
+    a = sl.run_oracle(oracle, frames, depth0, K, n, mode=mode, params=params_of(oracle, None, ov))
+    b = sl.run_oracle(oracle, frames, depth0, K, n, mode=mode, params=params_of(oracle, L, ov), L=L)
+    assert len(a.frameToKF) == len(b.frameToKF) == n
+    assert np.array_equal(np.array(a.frameToKF), np.array(b.frameToKF))
+    assert a.good == b.good and a.diverged == b.diverged and a.usage == b.usage and a.residual == b.residual
+    assert a.rescale == b.rescale and a.semidense == b.semidense
+    assert_hyp_bits(a.final_map, b.final_map, "final map after %d frames" % n)
