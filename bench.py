@@ -48,32 +48,40 @@ def pmc_traffic():
     return None, None
 
 
-def cpu_baseline(frames, depth0, K, n_frames, w, h):
-    """The oracle's timing build (-O3, SSE tracker path, 4 mapping threads) on the same loop, bounded sample."""
-    from oracle import pyoracle as po
-    po.build()
-    L = po.lib(fast=True)
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def _cpu_loop(po, L, frames, depth0, K, n_frames, w, h, mode):
+    """the same track + map loop (new keyframe every KF_EVERY frames) on a CPU library behind the oracle's entry points"""
     kf = po.Frame(0, frames[0], K, L=L)
     kf.set_depth_gt(depth0)
     dm = po.DepthMap(w, h, K, L=L, threads=4)
     dm.init_gt(kf)
     ref = po.TrackingReference(L=L)
     ref.import_frame(kf)
-    tr = po.SE3Tracker(w, h, K, mode=po.SSE, L=L)
+    tr = po.SE3Tracker(w, h, K, mode=mode, L=L)
     tr.set_max_its([5, 20, 50, 100, 0])
     last = np.array([1.0, 0, 0, 0, 0, 0, 0])
     t_track = t_map = 0.0
     n_upd = 0
     since = 0
-    keep = [kf]
+    good = 0
     t_all = time.perf_counter()
     for i in range(1, n_frames + 1):
         t0 = time.perf_counter()
         f = po.Frame(i, frames[i % len(frames)], K, L=L)
         ref.import_frame(kf)
-        s = kf.stats()
-        kf.set_counters(int(s["numFramesTrackedOnThis"]), int(s["numMappedOnThis"]), int(s["numMappedOnThisTotal"]), 0)
         r = tr.track(ref, f, last)
+        good += int(r.trackingWasGood)
         t1 = time.perf_counter()
         t_track += t1 - t0
         since += 1
@@ -81,7 +89,6 @@ def cpu_baseline(frames, depth0, K, n_frames, w, h):
             dm.finalize()
             dm.create_keyframe(f)
             kf = f
-            keep = [kf]
             last = np.array([1.0, 0, 0, 0, 0, 0, 0])
             since = 0
         else:
@@ -91,13 +98,68 @@ def cpu_baseline(frames, depth0, K, n_frames, w, h):
             n_upd += 1
         t_map += time.perf_counter() - t1
     total = time.perf_counter() - t_all
-    return {
-        "value": n_frames / total, "unit": "frames/s", "cores": 4, "kind": "port",
-        "sample": "%d frames of the same %dx%d track+map loop (oracle -O3 build: SSE tracker on 1 thread, depth map on 4 "
-                  "threads x 10-row chunks as the reference)" % (n_frames, w, h),
-        "track_fps": n_frames / t_track, "depth_mpix_per_s": (w * h * n_upd) / t_map / 1e6 if t_map > 0 else None,
-        "seconds": total,
-    }
+    return {"value": n_frames / total, "unit": "frames/s", "track_fps": n_frames / t_track,
+            "depth_mpix_per_s": (w * h * n_upd) / t_map / 1e6 if t_map > 0 else None, "seconds": total, "tracked_good": good}
+
+
+def cpu_baseline(frames, depth0, K, n_frames, w, h):
+    """CPU baseline on this box's host cores, bounded sample of the same workload.  Preferred: the REFERENCE's own hot-path
+    sources (oracle/_ref/liblsd_ref_sse.so: SE3Tracker.cpp / DepthMap.cpp / Frame.cpp compiled with -DENABLE_SSE against the
+    stand-in dependency headers of oracle/ref; tracking on 1 thread, mapping on the reference's own 4-worker
+    IndexThreadReduce pool) -> kind "reference".  Also reported: the oracle's restatement in its timing build for THIS host
+    (-O3 -march=native, the reference's flags) -> cpu_baseline_port."""
+    from oracle import pyoracle as po
+    po.build()
+    info = host_cpu()
+    native = po.build_native()
+    Lp = po.lib(native=True) if native else po.lib(fast=True)
+    port = _cpu_loop(po, Lp, frames, depth0, K, n_frames, w, h, po.SSE)
+    port.update({"cores": 4, "kind": "port", "build": "-O3 -march=native" if native else "-O3 -march=x86-64-v3 (prebuilt)",
+                 "sample": "%d frames of the same %dx%d track+map loop (oracle: SSE tracker on 1 thread, depth map on a persistent "
+                           "pool of 4 workers x 10-row chunks as the reference)" % (n_frames, w, h)})
+    port.update(info)
+    out = port
+    extra = None
+    if po.have_ref():
+        Lr = po.lib(ref="sse")
+        refb = _cpu_loop(po, Lr, frames, depth0, K, n_frames, w, h, po.SSE)
+        refb.update({"cores": 4, "kind": "reference",
+                     "build": "reference sources, -O2 -march=x86-64-v2 -DENABLE_SSE -DNDEBUG, stand-in Eigen/Sophus/boost/OpenCV headers (prebuilt where /root/reference exists)",
+                     "sample": "%d frames of the same %dx%d track+map loop through the reference's own SE3Tracker / DepthMap / Frame code "
+                               "(tracking 1 thread, mapping: IndexThreadReduce pool of 4 workers)" % (n_frames, w, h)})
+        refb.update(info)
+        out, extra = refb, port
+    return out, extra
+
+
+def quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def trajectory_rmse(poses, scales, gt_of_frame, first_scored):
+    """Camera centres in the frame of image 0 from the loop's outputs — frame->keyframe poses chained through every keyframe change
+    with the Sim3 scale createKeyFrame assigned (C/DepthEstimation/DepthMap.cpp:1305) — against the synthetic ground truth.
+    Returns (rmse over frames >= first_scored, number of keyframe changes)."""
+    s, R, t = 1.0, np.eye(3), np.zeros(3)
+    since = k = 0
+    err = []
+    for i, est in enumerate(poses):
+        c = s * (R @ est[4:7]) + t
+        if i >= first_scored:
+            err.append(float(np.sum((c - gt_of_frame(i)[4:7]) ** 2)))
+        since += 1
+        if since >= KF_EVERY:
+            if k >= len(scales):
+                break
+            t = s * (R @ est[4:7]) + t
+            R = R @ quat_to_rot(est[:4])
+            s = s * float(scales[k])
+            k += 1
+            since = 0
+    return (float(np.sqrt(np.mean(err))) if err else None), k
 
 
 def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
@@ -151,9 +213,27 @@ def main():
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra 64-jobs-per-launch measurement")
     ap.add_argument("--scene", type=str, default="S1", choices=["S1", "S2"],
                     help="synthetic scene (SURVEY.md §8(d)): S1 smooth texture (configs[1]); S2 Voronoi edge texture (configs[2], ~23 %% semi-dense)")
+    ap.add_argument("--live-queue", type=int, default=1,
+                    help="frames handed to updateKeyframe per mapping iteration (1 = blockUntilMapped as BASELINE configs[1]; K > 1 "
+                         "restates live operation, C/SlamSystem.cpp:559-571)")
+    ap.add_argument("--persistent", type=int, default=0, help="lsdhip_tracker_set_persistent(max strips); 0 = launch per evaluation")
+    ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra host-image (PCIe-inclusive) measurement")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group plumbing only (no GPU work, gloo when there is no GPU): prints the JSON skeleton")
     ap.add_argument("--seq-frames", type=int, default=50,
                     help="synthetic frames to render (one camera revolution = 50); fewer are played back and forth")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run on this node)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -163,6 +243,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # LSD_FORCE_DIST=1: run the RCCL path (process group, keyframe gather, barriers) even with one rank — a one-GPU check of the N > 1 code
     distributed = world > 1 or os.environ.get("LSD_FORCE_DIST") == "1"
+    if args.dry_run:
+        # plumbing check of the N-rank path: rendezvous, barrier, max-over-ranks reduction, one JSON line from rank 0
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert int(t.item()) == world
+        if rank == 0:
+            print(json.dumps({"metric": "tracked frames/sec (full track+map loop) at %dx%d" % (args.width, args.height), "value": None,
+                              "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "scaling": "weak"}))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     torch.cuda.set_device(local_rank)
@@ -189,6 +286,11 @@ def main():
     from lsd_slam_amd.driver import DriverLoop
     from lsd_slam_amd import capi
     loop = DriverLoop(w, h, K, ptr(0), depth0, kf_every=KF_EVERY, images_on_device=True, device=local_rank)
+    if args.persistent > 0:
+        loop.set_persistent(args.persistent)
+    if args.live_queue > 1:
+        loop.set_live_queue(args.live_queue)
+    loop.keep_keyframes(True)          # validation: the rescale factor of every keyframe, read back after the timed region
     L = capi.lib()
     ctx_h = loop.ctx_handle()
 
@@ -200,7 +302,7 @@ def main():
     ring = torch.empty((RING, 2, h, w), dtype=torch.float32, device=torch.device("cuda", local_rank))
     loop.set_keyframe_ring(ring.data_ptr(), RING)
     recv = [torch.empty_like(ring) for _ in range(world)] if (distributed and rank == 0) else None
-    state = {"fi": 0, "exported": 0, "gathered_bytes": 0}
+    state = {"fi": 0, "exported": 0, "gathered_bytes": 0, "poses": []}
 
     def run_frames(n):
         """n frames through the C++ loop in batches that produce at most RING keyframes; one gather per batch"""
@@ -209,7 +311,8 @@ def main():
             m = min(left, RING * KF_EVERY)
             ptrs = [ptr(state["fi"] + 1 + k) for k in range(m)]
             loop.set_keyframe_ring(ring.data_ptr(), RING)       # the batch's keyframes land in ring[0:new]
-            done, _ = loop.run(ptrs)                            # returns with the stream drained: the ring is complete
+            done, poses = loop.run(ptrs, want_poses=True)       # returns with the stream drained: the ring is complete
+            state["poses"].append(poses)
             state["fi"] += done
             left -= done
             new = loop.keyframes_exported()
@@ -243,6 +346,11 @@ def main():
         elapsed = float(t.item())
 
     st = loop.stats()
+    obs_ms, obs_calls = loop.observe_time()
+    # ---- self-validation of the run that was just timed (nothing below is inside the timed region) ----------------------------------------
+    poses_all = np.concatenate(state["poses"]) if state["poses"] else np.zeros((0, 7))
+    kf_scales, kf_points = loop.keyframe_log()
+    rmse, n_kf = trajectory_rmse(poses_all, kf_scales, lambda i: gt[order[(i + 1) % len(order)]], args.warmup)
     import ctypes as C
     ms_, n_, b_ = C.c_double(), C.c_longlong(), C.c_double()
     capi.check(L.lsdhip_prof_read(ctx_h, C.byref(ms_), C.byref(n_), C.byref(b_)))
@@ -272,15 +380,55 @@ def main():
             "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,
             "keyframe_ms": st.seconds_keyframe / st.keyframes * 1e3 if st.keyframes > 0 else None,
             "lm_evaluations_per_frame": st.evaluations / max(1, st.frames),
+            "lm_evaluations_per_frame_by_level": {"L%d" % l: st.level_evaluations[l] / max(1, st.frames) for l in (4, 3, 2, 1)},
+            # self-validation: a loop that diverged or drifted shows here, not only in frames/s
+            "validation": {"frames": int(st.frames), "tracked_good": int(st.tracked_good), "keyframes": int(st.keyframes),
+                           "rmse_vs_gt": rmse, "rmse_unit": "scene units (camera circle radius 0.08; depth ~2)",
+                           "semidense_px": float(np.mean(kf_points)) if len(kf_points) else None,
+                           "semidense_px_last": int(kf_points[-1]) if len(kf_points) else None,
+                           "ok": bool(st.tracked_good == st.frames and rmse is not None and rmse < 5e-3 and len(kf_points) > 0 and np.min(kf_points) > 0.05 * w * h)},
+            "live_queue": args.live_queue, "persistent_strips": args.persistent,
             "roofline": roofline,
         }
+        if obs_calls > 0 and obs_ms > 0:
+            # K4 algorithmic bytes: hypothesis 29 read + <= 29 written, maxGradients 4, keyframe image 4, keyframe gradients 8,
+            # reference image 4 per map pixel = 78 B/px upper bound (x live_queue reference images is not counted)
+            obs_us = obs_ms / obs_calls * 1e3
+            ach = 78.0 * w * h / (obs_us * 1e-6) / 1e9
+            out["roofline_depth"] = {"bound": "hbm", "kernel": "k_observe (makeAndCheckEPL + doLineStereo + observeDepthCreate/Update, one launch per updateKeyframe)",
+                                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_us": obs_us,
+                                     "launches": int(obs_calls), "algorithmic_bytes_per_launch": 78.0 * w * h,
+                                     "note": "upper-bound bytes (every pixel assumed to carry a hypothesis); HIP events around every 8th launch"}
         if world == 1 and (w, h) == (640, 480) and not args.no_throughput_mode:
             try:
                 out["roofline_throughput_mode"] = throughput_mode(la, w, h, K, d_frames, depth0, local_rank)
             except Exception as e:   # an extra: never let it take the bench line down
                 out["roofline_throughput_mode"] = {"error": str(e)}
+        if world == 1 and not args.no_pcie_leg:
+            # SURVEY.md §8(d) counts the 8-bit upload inside tracked frames/s: the same loop fed from (pinned) host memory, every frame
+            # crossing PCIe inside lsdhip_frame_create.  Reported beside `value`, never as `value`.
+            try:
+                h_frames = torch.from_numpy(frames).pin_memory()
+                hptr = lambda i: h_frames[order[i % len(order)]].data_ptr()
+                loop2 = DriverLoop(w, h, K, hptr(0), depth0, kf_every=KF_EVERY, images_on_device=False, device=local_rank)
+                if args.persistent > 0:
+                    loop2.set_persistent(args.persistent)
+                n2 = min(args.steps, 200)
+                loop2.run([hptr(1 + k) for k in range(args.warmup)])
+                capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+                t1 = clock()
+                loop2.run([hptr(1 + args.warmup + k) for k in range(n2)])
+                capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+                dt2 = clock() - t1
+                out["value_pcie_inclusive"] = {"value": n2 / dt2, "unit": "frames/s", "steps": n2,
+                                               "note": "frames start in pinned host memory; upload (%d KB per frame) inside the timed loop" % (w * h // 1024)}
+                loop2.close()
+            except Exception as e:
+                out["value_pcie_inclusive"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, depth0, K, args.cpu_frames, w, h)
+            out["cpu_baseline"], port = cpu_baseline(frames, depth0, K, args.cpu_frames, w, h)
+            if port is not None:
+                out["cpu_baseline_port"] = port
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -299,6 +299,9 @@ class SE3Tracker {
   float affineEstimation_a = 1, affineEstimation_b = 0;
   bool diverged = false, trackingWasGood = false;
   int numEvaluations = 0, numWarpUpdates = 0;  // instrumentation (residual-kernel launches, LM outer iterations)
+  int levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};   // evaluations of the last trackFrame per pyramid level
+  // execution strategy on the device (lsdhip_tracker_set_persistent): 0 = one launch per evaluation
+  void setPersistent(int maxStrips) { check(lsdhip_tracker_set_persistent(h_, maxStrips), "lsdhip_tracker_set_persistent"); }
 
  private:
   void publish(const lsdhip_track_result& r) {
@@ -306,6 +309,8 @@ class SE3Tracker {
     lastResidual = r.lastResidual; affineEstimation_a = r.affineEstimation_a; affineEstimation_b = r.affineEstimation_b;
     diverged = r.diverged != 0; trackingWasGood = r.trackingWasGood != 0;
     numEvaluations = r.numEvaluations; numWarpUpdates = r.numWarpUpdates;
+    int st[8];
+    if (lsdhip_tracker_exec_stats(h_, st) == 0) for (int l = 0; l < LSDHIP_PYRAMID_LEVELS; l++) levelEvaluations[l] = st[3 + l];
   }
   static void hookTrampoline(void* self) {
     SE3Tracker* t = static_cast<SE3Tracker*>(self);
@@ -498,6 +503,8 @@ class SlamLoop {
     SE3 est = tracker.trackFrame(&reference, frame.get(), lastFrameToKF_);
     pendingNext_ = nullptr;
     evaluations += tracker.numEvaluations;
+    for (int l = 0; l < LSDHIP_PYRAMID_LEVELS; l++) levelEvaluations[l] += tracker.levelEvaluations[l];
+    if (tracker.trackingWasGood) numTrackedGood++;
     numTracked++;
     lastTrackEnd = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     onTrackEnd(lastTrackEnd);
@@ -516,14 +523,20 @@ class SlamLoop {
       if (onKeyframeFinished) onKeyframeFinished(*keyframe, map);
       map.createKeyFrame(frame.get());
       keyframe = frame;
+      if (keepKeyframes) keyframeLog.push_back(frame);
+      liveQueue_.clear();
       reference.importFrame(keyframe.get());
       keyframe->clearDepthHasBeenUpdatedFlag();
       lastFrameToKF_ = SE3();
       sinceKF_ = 0;
       newKeyframe = true;
     } else {
-      std::deque<std::shared_ptr<Frame>> q;
-      q.push_back(frame);
+      // blockUntilMapped = true: the unmapped queue holds exactly this frame (SlamSystem.cpp:559-571, :1030-1039).
+      // liveQueueLength > 1 restates live operation, where the mapper finds several tracked frames waiting and passes the
+      // whole deque (oldest first, at most liveQueueLength of them) to updateKeyframe.
+      liveQueue_.push_back(frame);
+      while ((int)liveQueue_.size() > (liveQueueLength > 1 ? liveQueueLength : 1)) liveQueue_.pop_front();
+      std::deque<std::shared_ptr<Frame>> q(liveQueue_.begin(), liveQueue_.end());
       map.updateKeyframe(q);
       frame->clear_refPixelWasGood();
       lastFrameToKF_ = est;
@@ -537,8 +550,12 @@ class SlamLoop {
   TrackingReference reference;
   std::shared_ptr<Frame> keyframe;
   bool newKeyframe = false;
-  long evaluations = 0, numTracked = 0, numUpdates = 0;
+  long evaluations = 0, numTracked = 0, numUpdates = 0, numTrackedGood = 0;
+  long levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};
   double lastTrackEnd = 0;
+  int liveQueueLength = 1;                           // frames handed to updateKeyframe per mapping iteration
+  bool keepKeyframes = false;                        // keep every keyframe alive in keyframeLog (validation: rescale factors)
+  std::vector<std::shared_ptr<Frame>> keyframeLog;
 
  private:
   std::shared_ptr<Frame> makeFrame(int id, const unsigned char* img) {
@@ -553,6 +570,7 @@ class SlamLoop {
   std::shared_ptr<Frame> prefetched_;
   const unsigned char* prefetchedSrc_ = nullptr;
   const unsigned char* pendingNext_ = nullptr;
+  std::deque<std::shared_ptr<Frame>> liveQueue_;
 };
 
 }  // namespace lsd_slam_hip

@@ -139,6 +139,21 @@ typedef struct lsdhip_residual_record {
 int lsdhip_tracker_create(lsdhip_ctx* ctx, lsdhip_tracker** out);
 void lsdhip_tracker_destroy(lsdhip_tracker* t);
 int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int maxItsPerLvl[LSDHIP_PYRAMID_LEVELS]);
+/* Execution strategy of trackFrame on the device (no reference counterpart; results are the same up to summation order).
+ * Default: one kernel launch per residual evaluation (k_track_step).  maxStrips > 0: pyramid levels that fit maxStrips strips
+ * of 640 pixels (one workgroup each, at most 128) run inside ONE persistent launch whose workgroups exchange their partial
+ * sums through memory (k_track_persist); finer levels continue launch-per-evaluation.  maxStrips = 0 switches it off.
+ * Measured on MI355X at 640x480: the exchange costs 1.5 us at 8 strips, 4.8 us at 30, 10 us at 120 (profiles/r02_notes.md),
+ * so only the two coarsest levels profit; environment LSDHIP_PERSIST=1 / LSDHIP_PT_MAXG=n set the same at creation. */
+int lsdhip_tracker_set_persistent(lsdhip_tracker* t, int maxStrips);
+/* Diagnostics (no reference counterpart): how trackFrame jobs were executed on the device so far.
+ * out[0] = jobs run by the persistent kernel (one launch for the whole coarse-to-fine loop), out[1] = jobs it gave up on and
+ * that were rerun launch-per-evaluation, out[2] = 1 if the persistent kernel has been switched off, out[3] = evaluations of
+ * the last job per pyramid level 0..4 follow in out[3..7]. */
+int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
+/* Diagnostics: shader cycles workgroup 0 of the persistent kernel spent in each phase of the last job (0 level entry, 1 warp +
+ * texel issue, 2 workgroup top-3, 3 residual arithmetic, 4 reduction + publish, 5 all-gather, 6 totals + tail, 7 LM step). */
+int lsdhip_tracker_phase_cycles(const lsdhip_tracker* t, unsigned long long out[10]);
 /* Host-side pipelining: `fn(user)` is called on the calling thread by lsdhip_tracker_track once the job's launches are
  * queued and before the host waits for the result — the place to queue independent work on the same context (the next
  * image's upload and pyramids, what the reference's image-loader thread does ahead of the tracking thread,
@@ -260,6 +275,9 @@ int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);
 /* GPU time (HIP events on the context's stream, ms, summed since creation) and call counts of updateKeyframe [0],
  * createKeyFrame [1], finalizeKeyFrame [2]; synchronises the stream */
 int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]);
+/* GPU time (ms, summed) and count of the observe kernel alone (DepthMap::observeDepth, C/DepthEstimation/DepthMap.cpp:147-150),
+ * sampled on every 8th updateKeyframe while lsdhip_prof_enable is on; synchronises the stream. */
+int lsdhip_depth_observe_time(lsdhip_depthmap* dm, double* ms_out, long long* calls_out);
 
 /* ---- measurement hooks ---------------------------------------------------------------------------- */
 /* Accumulated HIP-event time (ms) and launch count of the residual kernel on the context's stream since the last

@@ -17,6 +17,8 @@ typedef struct lsdloop_stats {
   long long updates;         /* updateKeyframe calls */
   long long keyframes;       /* keyframes created */
   long long evaluations;     /* residual evaluations (k_track_step launches that did work) */
+  long long tracked_good;    /* frames whose trackFrame ended with trackingWasGood (C/Tracking/SE3Tracker.cpp:472-477) */
+  long long level_evaluations[5];   /* residual evaluations per pyramid level 0..4 */
 } lsdloop_stats;
 /* K4 = fx, fy, cx, cy.  first_image / images: uint8 w*h, host memory or (images_on_device != 0) memory of `device`. */
 int lsdloop_create(int device, int w, int h, const float K4[4], const uint8_t* first_image, int images_on_device,
@@ -35,6 +37,19 @@ int lsdloop_copy_keyframe_planes(lsdloop* l, float* idepth_dev, float* idepthVar
  * lsdloop_keyframes_exported returns count.  The copies are complete when lsdloop_run returns. */
 int lsdloop_set_keyframe_ring(lsdloop* l, float* ring_dev, int slots);
 long long lsdloop_keyframes_exported(lsdloop* l);
+/* Validation helpers (bench.py's self-check): keep every keyframe created from now on (on != 0) so that, after the run, the
+ * Sim3 scale createKeyFrame gave each of them (C/DepthEstimation/DepthMap.cpp:1286-1305) and its semi-dense point count can
+ * be read back: scales_out / points_out receive up to max entries in creation order; returns the number of keyframes kept.
+ * The read-back resolves deferred results, i.e. synchronises — call it outside timed regions. */
+int lsdloop_keep_keyframes(lsdloop* l, int on);
+int lsdloop_keyframe_log(lsdloop* l, double* scales_out, long long* points_out, int max);
+/* frames handed to DepthMap::updateKeyframe per mapping iteration (1 = blockUntilMapped, the default; K > 1 restates live
+ * operation where the mapper finds up to K tracked frames queued, C/SlamSystem.cpp:559-571) */
+int lsdloop_set_live_queue(lsdloop* l, int frames);
+/* trackFrame execution strategy on the device (lsdhip_tracker_set_persistent) */
+int lsdloop_set_persistent(lsdloop* l, int max_strips);
+/* lsdhip_depth_observe_time of the loop's depth map */
+int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out);
 void* lsdloop_ctx(lsdloop* l);   /* the lsdhip_ctx* the loop runs on (prof hooks, stream) */
 const char* lsdloop_last_error(void);
 #ifdef __cplusplus

@@ -86,6 +86,9 @@ def _signatures():
         "lsdhip_tracker_create": (i, [vp, pvp]),
         "lsdhip_tracker_destroy": (None, [vp]),
         "lsdhip_tracker_set_max_its": (i, [vp, vp]),
+        "lsdhip_tracker_set_persistent": (i, [vp, i]),
+        "lsdhip_tracker_exec_stats": (i, [vp, vp]),
+        "lsdhip_tracker_phase_cycles": (i, [vp, vp]),
         "lsdhip_tracker_set_enqueue_hook": (i, [vp, vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_track_batch": (i, [vp, i, pvp, pvp, vp, C.POINTER(TrackResult)]),
@@ -121,6 +124,7 @@ def _signatures():
         "lsdhip_depth_copy_rows_dev": (i, [vp, i, i, vp, i]),
         "lsdhip_depth_timings": (i, [vp, vp]),
         "lsdhip_depth_gpu_times": (i, [vp, vp, vp]),
+        "lsdhip_depth_observe_time": (i, [vp, vp, vp]),
         "lsdhip_prof_enable": (i, [vp, i]),
         "lsdhip_prof_read": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
         "lsdhip_prof_reset": (i, [vp]),

@@ -96,6 +96,7 @@ struct TrackState {
   int done, diverged;
   int numEvaluations, numWarpUpdates;
   float pointUsage, goodCount, badCount, meanRes;
+  int levelEvals[LSD_LEVELS];  // evaluations per pyramid level (diagnostics / bench line)
 };
 
 // What the host reads back (pinned, device-mapped): written by k_lm_step when the job finishes (or every step in
@@ -106,6 +107,9 @@ struct TrackSummary {
   float lastResidual, pointUsage, goodCount, badCount, meanRes, aff_a, aff_b, aff_a_lastIt, aff_b_lastIt;
   float sums[RS_NUM];        // raw sums of the last evaluation (tail-drop corrected)
   double bytes;              // algorithmic bytes of all evaluations of the job
+  int levelEvals[LSD_LEVELS];
+  int pad2_[3];
+  unsigned long long phase[10];   // k_track_persist: shader cycles workgroup 0 spent per phase, summed over the job's evaluations
 };
 
 // A result the host needs eventually but not now (mean inverse depth / point count of a setDepth, the rescale factor
@@ -195,6 +199,14 @@ struct lsdhip_tracker {
   float* d_partials = nullptr;    // TrackScratch arena (sums | topkey | topval), see tracker.hip
   int max_blocks = 0;
   TrackState* d_state = nullptr;  // [2], double-buffered by launch parity
+  unsigned long long* d_ptrows = nullptr;   // k_track_persist: published rows [2][PT_MAXG][PT_ROW] + state record [128] (granules)
+  unsigned ptSalt = 0;            // per-launch tag salt (20 bits)
+  int ptMaxG = 8;                 // levels needing more strips than this continue in the k_track_step chain (LSDHIP_PT_MAXG)
+  bool persist = false;           // run trackFrame's coarse levels in the persistent kernel (lsdhip_tracker_set_persistent / LSDHIP_PERSIST=1)
+  bool persistOff = false;        // switched off after repeated give-ups
+  int persistFallbacks = 0;       // jobs the persistent kernel gave up on (rerun with k_track_step)
+  int persistJobs = 0;            // jobs launched on the persistent kernel
+  int levelEvaluations[LSD_LEVELS] = {};   // evaluations of the last job per pyramid level
   int block = 256;                // workgroup size of k_track_step (LSDHIP_TRACK_BLOCK)
   int grid_cap = 304;             // most workgroups one evaluation uses (LSDHIP_TRACK_CAP); larger levels grid-stride
   int batch_jobs = 0;             // > 1 while the jobs of a batch are being described
@@ -266,8 +278,9 @@ struct lsdhip_depthmap {
   int ev_next = 0;
   unsigned long long* d_obs_trace = nullptr;   // LSD_PHASE_TRACE developer build only
   size_t obs_trace_words = 0;
-  double gpu_ms[3] = {0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame
-  long long gpu_calls[3] = {0, 0, 0};
+  double gpu_ms[4] = {0, 0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame, k_observe alone (sampled while profiling)
+  long long gpu_calls[4] = {0, 0, 0, 0};
+  unsigned obs_tick = 0;
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
         msSetDepth = 0;
 };

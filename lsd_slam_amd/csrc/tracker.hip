@@ -334,6 +334,53 @@ __device__ __forceinline__ void ldlt6_solve_wave(float (&m)[6], const float bl, 
   for (int j = 0; j < 6; j++) x[j] = rl(xl, j);
 }
 
+// 6x6 solve for the LM step, Gauss-Jordan on the augmented 6x7 system with ONE ELEMENT PER LANE (lane = 8 i + j, i < 6 rows,
+// j < 7 columns) and the pivot row / pivot column read back through LDS: six steps of (write own element, read pivot, pivot-row
+// and pivot-column entries, divide, multiply-subtract) instead of the ~460 dependent lane-exchange instructions of the
+// row-per-lane LDL^T above (3800 -> ~1300 cycles of the single wave the whole launch waits for).  No pivoting: the matrix
+// is J^T W J with its diagonal scaled by (1 + lambda), symmetric positive definite.  Same solution as A.ldlt().solve(b) up
+// to rounding (tolerance-level, like every reduction feeding it); the pivoted LDL^T stays in pose_math.hpp for the host
+// paths and as the CPU-checked reference of this routine (tests/test_host_math_cpu.py).
+__device__ __forceinline__ void gj6_solve_wave(const float* A /*LDS, 6x6*/, const float* bvec /*LDS*/, const float damp, float* s_m /*LDS [6][8]*/,
+                                               const int lane, float (&x)[6]) {
+  const int i = lane >> 3, j = lane & 7;
+  const bool act = i < 6 && j < 7;
+  const int ii = act ? i : 0, jj = act ? (j < 6 ? j : 0) : 0;
+  float m = (j == 6) ? -bvec[ii] : A[ii * 6 + jj];
+  if (i == j) m *= damp;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (act) s_m[i * 8 + j] = m;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float d = s_m[k * 8 + k], rk = s_m[k * 8 + (act ? j : 0)], ck = s_m[ii * 8 + k];
+    const float f = ck / d;
+    const float upd = m - f * rk;
+    m = (i == k) ? m : upd;
+    __builtin_amdgcn_wave_barrier();
+  }
+  // now diagonal: x_i = rhs_i / m_ii
+  if (act) s_m[i * 8 + j] = m;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int r = 0; r < 6; r++) x[r] = s_m[r * 8 + 6] / s_m[r * 8 + r];
+}
+
+// sin / cos for the small angles of an LM increment: Taylor polynomials (|x| < 0.5: truncation error < 2e-10 relative),
+// the library routine beyond
+__device__ __forceinline__ void sincos_small(const float xx, float* sn, float* cs) {
+  if (fabsf(xx) < 0.5f) {
+    const float x2 = xx * xx;
+    *sn = xx * (1.0f + x2 * (-1.0f / 6.0f + x2 * (1.0f / 120.0f + x2 * (-1.0f / 5040.0f + x2 * (1.0f / 362880.0f + x2 * (-1.0f / 39916800.0f))))));
+    *cs = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24.0f + x2 * (-1.0f / 720.0f + x2 * (1.0f / 40320.0f + x2 * (-1.0f / 3628800.0f + x2 * (1.0f / 479001600.0f))))));
+  } else {
+    sincosf(xx, sn, cs);
+  }
+}
+
 // Quaternion normalisation, the four divisions in four lanes (lsdm::q_normalize arithmetic)
 __device__ __forceinline__ void q_normalize_wave(lsdm::Quatf& q, const int lane) {
   const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
@@ -350,7 +397,7 @@ __device__ __forceinline__ lsdm::SE3fH se3f_exp_wave(const float (&a)[6], const 
   const float theta = sqrtf(theta_sq);
   const float half_theta = 0.5f * theta;
   float sn, cs;
-  sincosf((lane & 1) ? theta : half_theta, &sn, &cs);
+  sincos_small((lane & 1) ? theta : half_theta, &sn, &cs);
   const float sin_half = rl(sn, 0), cos_half = rl(cs, 0), sin_theta = rl(sn, 1), cos_theta = rl(cs, 1);
   float imag, real;
   if (theta < eps) {
@@ -414,11 +461,13 @@ __device__ __forceinline__ void write_summary(const TrackState& s, const float* 
   out->meanRes = s.meanRes; out->aff_a = s.aff_a; out->aff_b = s.aff_b; out->aff_a_lastIt = s.aff_a_lastIt; out->aff_b_lastIt = s.aff_b_lastIt;
   for (int i = 0; i < RS_NUM; i++) out->sums[i] = tot[i];
   out->bytes = s.bytes;
+  for (int l = 0; l < LSD_LEVELS; l++) out->levelEvals[l] = s.levelEvals[l];
   __threadfence_system();
   out->done = s.done;
 }
 
 struct LmShared {
+  float gj[48];        // scratch of the 6x6 solve
   float tot[RS_NUM];   // corrected raw sums of the evaluation being finished (what the summary reports)
 };
 // Job parameters the LM wave needs, staged in LDS by an otherwise idle lane while the partial sums are being added
@@ -448,8 +497,9 @@ __device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmP
 #else
 #define LM_MARK(k) do { } while (0)
 #endif
-__device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const float col, const float* tot, const int lane,
+__device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const float col, float* tot, const int lane,
                                         TrackSummary* out, unsigned long long* trp) {
+  float* const s_gj = tot - 48;   // LmShared::gj precedes tot
   const LmPar L = par;
   const int maxIts = L.maxIts;
   // calcResidualAndBuffers epilogue (:1016-1028)
@@ -469,6 +519,7 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
   S.aff_a_lastIt = aff_a_lastIt;
   S.aff_b_lastIt = aff_b_lastIt;
   S.numEvaluations = S.numEvaluations + 1;
+  if (lane == 0) S.levelEvals[S.level] = S.levelEvals[S.level] + 1;
   {
     // algorithmic bytes of this evaluation: 20 N + [mask] 5 N + 12 min(w h, 4 N)
     const float N = refNum, wh = (float)L.w * (float)L.h;
@@ -551,17 +602,10 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
   S.iteration = iteration;
   LM_MARK(13);
   if (propose) {
-    const int ri = lane < 6 ? lane : 5;
-    float m[6], inc[6];
+    float inc[6];
     const float damp = 1 + LM_lambda;
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      const float v = S.A[ri * 6 + j];
-      m[j] = (j == ri) ? v * damp : v;
-    }
-    const float bl = -S.b[ri];
     LM_MARK(14);
-    ldlt6_solve_wave(m, bl, lane, inc);
+    gj6_solve_wave(S.A, S.b, damp, s_gj, lane, inc);
     LM_MARK(15);
     S.incTry = incTry + 1;
 #pragma unroll
@@ -749,6 +793,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
       S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
       S.bytes = 0;
+      for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
     }
     if (tid < 36) S.A[tid] = 0;
     if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
@@ -1136,6 +1181,442 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
                                                        TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
   track_step_impl<BLOCK, BATCH, MODE>(jobv, jobs, st2, sc, out, parity, first);
 }
+
+// =====================================================================================================================
+// Persistent tracking kernel: ONE launch runs SE3Tracker::trackFrame's whole coarse-to-fine loop.
+//
+// The launch-per-evaluation chain above pays, per evaluation, a kernel boundary (~2.3 us), a re-read of every tile's
+// partial row by every workgroup (~3 us at level 1) and a cold start of the workgroup (state, job description).  Here
+// the workgroups stay resident and exchange their partial rows INSIDE the launch:
+//   * level l is cut into strips of <= PT_STRIP consecutive pixels, strip g owned by workgroup g < G_l (G_l = plan.pg[l],
+//     growing as the levels get finer).  On entering a level a workgroup compacts the valid reference pixels of its strip
+//     into an LDS point list ONCE (position, colour, variance: the pose-independent part of K0) — evaluations only read LDS
+//     and the tracked frame's texels;
+//   * one evaluation = warp + texel fetch of the list (two entries per lane in flight), workgroup top-3 order keys while
+//     the texels travel, residual / weights / normal equations, workgroup reduction, then ONE all-gather: every participant
+//     publishes a row of 8-byte {tag, value} granules (write-through relaxed agent-scope stores: the data is its own flag,
+//     no fences — cdna_hip_programming.md Guideline 16, form R2) and sweeps the rows of all participants;
+//   * every participant then runs the same Levenberg-Marquardt step on the same totals (lm_wave, as in k_track_step), so
+//     no second hop is needed to distribute the pose;
+//   * workgroups a level does not need yet sleep on a state record that workgroup 0 publishes at each level change.
+// The SSE tail drop needs the globally last (M mod 4) in-image points: a row carries its workgroup's 3 largest order keys and
+// the K2/K3 contributions of those points; the readers merge the keys and subtract the contributions of the winners.
+// Every spin is bounded: on a time-out the kernel reports done = 2 and the host reruns the job with k_track_step.
+// Levels too large for PT_MAXG strips (plan.pg[l] == 0) are handed to the k_track_step chain through st_out.
+// =====================================================================================================================
+#define PT_BLOCK 256
+#define PT_STRIP 640           // pixels per strip = capacity of the LDS point list
+#define PT_MAXG 128            // most workgroups (strips) per level
+#define PT_ROW 136             // granules per published row: 41 sums | 3 keys | pad | 3 x 29 contributions
+#define PT_KEY0 RS_END
+#define PT_SUB0 48
+typedef unsigned long long pt_u64;
+typedef __attribute__((address_space(1))) pt_u64 pt_gu64;
+struct PersistPlan { int pg[LSD_LEVELS]; };
+__device__ __forceinline__ void pt_store(pt_u64* p, unsigned tag, unsigned val) {
+  __hip_atomic_store((pt_gu64*)p, ((pt_u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ pt_u64 pt_load(const pt_u64* p) {
+  return __hip_atomic_load((pt_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define PT_SPIN_LIMIT (1u << 21)     // polls of one wave before it gives up (~1 s)
+
+// the K2/K3 contributions of one point, in the order of s_sub (werr | 21 A | 6 b | err)
+__device__ __forceinline__ void point_contrib(const PointOut& o, float* dst) {
+  dst[0] = o.werr;
+  int k = 1;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const float Jw = o.J[r] * o.w;
+#pragma unroll
+    for (int c = r; c < 6; c++) dst[k++] = Jw * o.J[c];
+  }
+  const float resw = o.res * o.w;
+#pragma unroll
+  for (int r = 0; r < 6; r++) dst[k++] = resw * o.J[r];
+  dst[k] = resw * o.res;
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void k_track_persist(TrackJob job, PersistPlan plan, TrackState* __restrict__ st_out,
+                                                            pt_u64* __restrict__ rows, pt_u64* __restrict__ stg, unsigned salt,
+                                                            TrackSummary* __restrict__ out) {
+  constexpr int BLOCK = PT_BLOCK;
+  constexpr int WAVES = BLOCK / 64;
+  constexpr int SW = sizeof(TrackState) / 4;
+  static_assert(SW <= 126, "state record too large for the state granules");
+  __shared__ TrackState S;
+  __shared__ LmShared sh;
+  __shared__ LmPar s_par;
+  __shared__ float s_sum[(PT_BLOCK / RS_END) > 4 ? (PT_BLOCK / RS_END) : 4][64];
+  __shared__ float s_red[RS_END * (BLOCK + 1) + 8];     // workgroup reduction; afterwards the gathered rows [44][PT_MAXG + 1]
+  __shared__ int s_keys[PT_MAXG * 3];
+  __shared__ int s_wtop[WAVES][3];
+  __shared__ int s_top[3];
+  __shared__ float s_contrib[3][32];
+  __shared__ float s_sub[3][32];
+  __shared__ int s_nsub;
+  __shared__ int s_cnt[WAVES];
+  __shared__ int s_flag;
+  __shared__ float l_px[PT_STRIP], l_py[PT_STRIP], l_pz[PT_STRIP], l_I[PT_STRIP], l_var[PT_STRIP];
+  __shared__ unsigned l_xy[PT_STRIP];
+  static_assert(44 * (PT_MAXG + 1) <= RS_END * (BLOCK + 1) + 8, "gather area must fit the reduction scratch");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x;
+  const unsigned tagbase = salt << 12;
+  if (tid == 0) s_flag = 1;
+
+  // ---- which level does this workgroup join at? ----------------------------------------------------------------------
+  int joinLevel = -1;
+  for (int l = job.topLevel; l >= job.lastLevel; l--) {
+    if (plan.pg[l] == 0) break;            // from here on the k_track_step chain takes over
+    if (b < plan.pg[l]) { joinLevel = l; break; }
+  }
+  if (joinLevel < 0) return;
+  if (joinLevel == job.topLevel) {
+    if (tid == 0) {
+      S.T = job.T0;
+      set_eval_pose(S, job.T0);
+      S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
+      S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
+      S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
+      S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
+      S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
+      S.bytes = 0;
+      for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
+    }
+    if (tid < 36) S.A[tid] = 0;
+    if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
+  } else {
+    // sleep until workgroup 0 publishes the state at the start of `joinLevel` (or the end of the job)
+    const unsigned want = tagbase | (0xF00u + (unsigned)joinLevel), fin = tagbase | 0xFFFu;
+    if (wave == 0) {
+      int st = 0;   // 1 = state there, 2 = job over, 3 = time-out
+      for (unsigned spins = 0; st == 0; spins++) {
+        const unsigned t0 = (unsigned)(pt_load(stg) >> 32), t1 = (unsigned)(pt_load(stg + 127) >> 32);
+        if (t1 == fin) st = 2;
+        else if (t0 == want) st = 1;
+        else if (spins > PT_SPIN_LIMIT) st = 3;
+        else __builtin_amdgcn_s_sleep(32);
+      }
+      if (lane == 0) s_flag = st;
+    }
+    __syncthreads();
+    if (s_flag != 1) return;
+    if (wave == 0) {
+      // every word of the record carries the tag: re-read until complete
+      unsigned* Sw = (unsigned*)&S;
+      bool bad = false;
+      for (unsigned spins = 0;; spins++) {
+        bool ok = true;
+        for (int i = lane; i < SW; i += 64) {
+          const pt_u64 x = pt_load(stg + i);
+          ok &= (unsigned)(x >> 32) == want;
+          Sw[i] = (unsigned)x;
+        }
+        if (__all(ok)) break;
+        if (spins > PT_SPIN_LIMIT) { bad = true; break; }
+      }
+      if (lane == 0) s_flag = bad ? 3 : 1;
+    }
+    __syncthreads();
+    if (s_flag != 1) return;
+  }
+  __syncthreads();
+
+  int curLevel = -1, n_list = 0, G = 0;
+  EvalCtx a;
+  uint8_t* wasGood = nullptr;
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#define PT_MARK(k) do { const unsigned long long tn_ = clock64(); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
+  while (true) {
+    // leaving (job finished, or the next level belongs to the k_track_step chain, which reads st_out[0] with pending = 0):
+    // both state buffers get the final state, so that steps queued behind a finished job exit at once
+    if (S.done || plan.pg[S.level] == 0) {
+      if (b == 0) { copy_words<SW>(st_out, &S, tid, BLOCK); copy_words<SW>(st_out + 1, &S, tid, BLOCK); }
+      if (b == 0 && tid == 0) {
+        out->pad_[0] = 4; out->pad_[1] = S.level; out->pad_[2] = S.done * 1000 + S.numEvaluations;
+        for (int k = 0; k < 10; k++) out->phase[k] = ph[k];
+      }
+      break;
+    }
+    const int level = S.level;
+    if (level != curLevel) {
+      G = plan.pg[level];
+      curLevel = level;
+      make_ctx_dev(job, S, level, a);
+      wasGood = job.lv[level].writeMask ? job.wasGood : nullptr;
+      if (tid == BLOCK - 1) stage_lm_par(job, level, s_par);
+      // ---- the strip's valid reference pixels -> LDS point list (TrackingReference::makePointCloud, pose-independent) --
+      const int work = a.w * a.h;
+      const int strip = (work + G - 1) / G;
+      const int base = b * strip;
+      const int end = min(base + strip, work);
+      constexpr int KMAX = (PT_STRIP + BLOCK - 1) / BLOCK;
+      unsigned vmask = 0;
+      float vv[KMAX], dd[KMAX], ii[KMAX];
+      int wcount = 0;
+#pragma unroll
+      for (int k = 0; k < KMAX; k++) {
+        const int i = base + k * BLOCK + tid;
+        const bool in = i < end;
+        vv[k] = in ? a.kf_idepthVar[i] : 0.f;
+        dd[k] = in ? a.kf_idepth[i] : 0.f;
+        ii[k] = in ? a.kf_image[i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; k++) {
+        const int i = base + k * BLOCK + tid;
+        const int x = i % a.w, y = i / a.w;
+        const bool ok = i < end && !(x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) && !(vv[k] <= 0 || dd[k] == 0);
+        vmask |= (ok ? 1u : 0u) << k;
+        wcount += __popcll(__ballot(ok));
+      }
+      if (lane == 0) s_cnt[wave] = wcount;
+      __syncthreads();
+      int pos = 0, total = 0;
+#pragma unroll
+      for (int wv = 0; wv < WAVES; wv++) { const int cw = s_cnt[wv]; if (wv < wave) pos += cw; total += cw; }
+#pragma unroll
+      for (int k = 0; k < KMAX; k++) {
+        const bool ok = (vmask >> k) & 1u;
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+          const int i = base + k * BLOCK + tid;
+          const int x = i % a.w, y = i / a.w;
+          const int p = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          const float inv = 1.0f / dd[k];
+          l_px[p] = inv * (a.fxi * x + a.cxi);
+          l_py[p] = inv * (a.fyi * y + a.cyi);
+          l_pz[p] = inv * 1.0f;
+          l_I[p] = ii[k];
+          l_var[p] = vv[k];
+          l_xy[p] = (unsigned)x | ((unsigned)y << 16);
+        }
+        pos += __popcll(bal);
+      }
+      n_list = total;
+      __syncthreads();
+      PT_MARK(0);     // level entry (point list)
+    }
+    // ---- pose of this evaluation ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.R[i] = S.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) a.t[i] = S.t[i];
+    a.aff_a = S.aff_a; a.aff_b = S.aff_b;
+    const unsigned epoch = tagbase | ((unsigned)(S.numEvaluations + 1) & 0xFFFu);
+
+    float acc[RS_END];
+#pragma unroll
+    for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
+    int key0 = -1, key1 = -1, key2 = -1;
+    // entries tid and tid + BLOCK: warp + texel fetch now, finish after the key exchange
+    PointWarp q0, q1;
+    PointTexels t0, t1;
+    const bool live0 = tid < n_list, live1 = tid + BLOCK < n_list;
+    {
+      const int e0 = live0 ? tid : 0, e1 = live1 ? tid + BLOCK : 0;
+      eval_warp(a, l_px[e0], l_py[e0], l_pz[e0], q0);
+      eval_warp(a, l_px[e1], l_py[e1], l_pz[e1], q1);
+      eval_fetch(a, q0, live0 && q0.in_image, t0);
+      eval_fetch(a, q1, live1 && q1.in_image, t1);
+      if (live0 && q0.in_image) { const unsigned xy = l_xy[e0]; top3_insert((int)(xy & 0xffffu) * a.h + (int)(xy >> 16), key0, key1, key2); }
+      if (live1 && q1.in_image) { const unsigned xy = l_xy[e1]; top3_insert((int)(xy & 0xffffu) * a.h + (int)(xy >> 16), key0, key1, key2); }
+    }
+    for (int e = tid + 2 * BLOCK; e < n_list; e += BLOCK) {      // strips denser than 2 points per lane: keys only
+      PointWarp q;
+      eval_warp(a, l_px[e], l_py[e], l_pz[e], q);
+      if (q.in_image) { const unsigned xy = l_xy[e]; top3_insert((int)(xy & 0xffffu) * a.h + (int)(xy >> 16), key0, key1, key2); }
+    }
+    PT_MARK(1);       // pose, warp, texel issue
+    block_top3(key0, key1, key2, s_wtop, s_top);                 // two barriers, in the shadow of the texel loads
+    PT_MARK(2);       // workgroup top-3
+    const int top0 = s_top[0], top1 = s_top[1], top2 = s_top[2];
+    auto finish_entry = [&](int e, const PointWarp& q, const PointTexels& t) {
+      const unsigned xy = l_xy[e];
+      const int x_ = (int)(xy & 0xffffu), y_ = (int)(xy >> 16);
+      acc[RS_NREF] += 1.f;
+      if (!q.in_image) {
+        if (wasGood) wasGood[y_ * a.w + x_] = 0;
+        return;
+      }
+      PointOut o;
+      eval_finish(a, q, t, l_pz[e], l_I[e], l_var[e], o);
+      if (wasGood) wasGood[y_ * a.w + x_] = o.good ? 1 : 0;
+      accumulate_point(o, acc);
+      const int key = x_ * a.h + y_;
+      const int r = key == top0 ? 0 : (key == top1 ? 1 : (key == top2 ? 2 : -1));
+      if (r >= 0) point_contrib(o, s_contrib[r]);
+    };
+    if (live0) finish_entry(tid, q0, t0);
+    if (live1) finish_entry(tid + BLOCK, q1, t1);
+    for (int e = tid + 2 * BLOCK; e < n_list; e += BLOCK) {
+      PointWarp q;
+      PointTexels t;
+      eval_warp(a, l_px[e], l_py[e], l_pz[e], q);
+      eval_fetch(a, q, q.in_image, t);
+      finish_entry(e, q, t);
+    }
+
+    PT_MARK(3);       // texel wait + residual / weights / normal equations
+    // ---- workgroup reduction (as k_track_step) --------------------------------------------------------------------
+    constexpr int CPP = RS_END;
+    constexpr int RSLICE = BLOCK / CPP;
+    constexpr int RRUN = (BLOCK + RSLICE - 1) / RSLICE;
+#pragma unroll
+    for (int k = 0; k < CPP; k++) s_red[k * (BLOCK + 1) + tid] = acc[k];
+    __syncthreads();
+    {
+      const int slice = tid / CPP, k = tid - slice * CPP;
+      if (slice < RSLICE) {
+        const float* row = s_red + k * (BLOCK + 1);
+        const int j0 = slice * RRUN;
+        float v[RRUN];
+#pragma unroll
+        for (int j = 0; j < RRUN; j++) v[j] = row[j0 + j];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < RRUN; j++) s += (j0 + j < BLOCK) ? v[j] : 0.f;
+        s_sum[slice][k] = s;
+      }
+    }
+    __syncthreads();
+    // ---- publish this workgroup's row -------------------------------------------------------------------------------
+    // rows are double-buffered by evaluation parity: a workgroup can run at most one evaluation ahead of the slowest
+    // reader of its row (its next-but-one publication needs that reader's next row), so two buffers never collide
+    pt_u64* const rowsE = rows + (size_t)(S.numEvaluations & 1) * PT_MAXG * PT_ROW;
+    pt_u64* myrow = rowsE + (size_t)b * PT_ROW;
+    if (tid < RS_END) {
+      float s = s_sum[0][tid];
+#pragma unroll
+      for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
+      pt_store(myrow + tid, epoch, __float_as_uint(s));
+    } else if (tid >= 64 && tid < 67) {
+      pt_store(myrow + PT_KEY0 + (tid - 64), epoch, (unsigned)s_top[tid - 64]);
+    } else if (tid >= 128 && tid < 128 + 87) {
+      const int r = (tid - 128) / 29, j = (tid - 128) - r * 29;
+      pt_store(myrow + PT_SUB0 + r * 29 + j, epoch, __float_as_uint(s_top[r] >= 0 ? s_contrib[r][j] : 0.f));
+    }
+    PT_MARK(4);       // workgroup reduction + publish
+    // ---- gather the rows of all G participants: sums and keys ------------------------------------------------------------
+    float* s_g = s_red;                    // [col][PT_MAXG + 1]; the reduction scratch is dead (barrier above)
+    {
+      constexpr int NC = RS_END + 3;       // 41 sums, 3 keys
+      const int totalg = G * NC;
+      bool bad = false;
+      for (unsigned spins = 0;; spins++) {
+        bool ok = true;
+        for (int idx = tid; idx < totalg; idx += BLOCK) {
+          const int r = idx / NC, c = idx - r * NC;
+          const pt_u64 x = pt_load(rowsE + (size_t)r * PT_ROW + c);
+          ok &= (unsigned)(x >> 32) == epoch;
+          if (c < RS_END) s_g[c * (PT_MAXG + 1) + r] = __uint_as_float((unsigned)x);
+          else s_keys[r * 3 + (c - RS_END)] = (int)(unsigned)x;
+        }
+        if (__all(ok)) break;
+        if (spins > PT_SPIN_LIMIT) { bad = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (bad) s_flag = 3;
+    }
+    __syncthreads();
+    if (s_flag == 3) {                     // give up: the host reruns the job with the launch-per-evaluation chain
+      if (b == 0 && tid == 0) { out->diverged = 0; __threadfence_system(); out->done = 2; }
+      return;
+    }
+    { const unsigned long long tn_ = clock64(); if (level == 1) ph[8] += tn_ - tprev; if (level == 3) ph[9] += tn_ - tprev; }
+    PT_MARK(5);       // all-gather (waiting for the slowest participant included)
+    // ---- column totals (waves 0..2) and the global tail points (wave 3) ----------------------------------------------------
+    if (wave < 3) {
+      constexpr int NSL = 4;
+      const int slice = tid / RS_END, col = tid - slice * RS_END;
+      if (slice < NSL) {
+        const int R = (G + NSL - 1) / NSL;
+        const float* colp = s_g + col * (PT_MAXG + 1);
+        float s = 0.f;
+        for (int r = slice * R; r < min(slice * R + R, G); r++) s += colp[r];
+        s_sum[slice][col] = s;
+      }
+    } else {
+      int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
+#pragma unroll
+      for (int qq = 0; qq < (PT_MAXG + 63) / 64; qq++) {
+        const int row = lane + 64 * qq;
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+          const int k = row < G ? s_keys[row * 3 + rr] : -1, ek = row * 3 + rr;
+          const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
+          k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? ek : e2);
+          k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? ek : e1);
+          k0 = g0 ? k : k0; e0 = g0 ? ek : e0;
+        }
+      }
+      int keys[3], src[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int m = __builtin_amdgcn_readlane(wave_max_to_lane63(k0), 63);
+        const unsigned long long own = __ballot(k0 == m && m >= 0);
+        const int owner = own ? (int)__ffsll((long long)own) - 1 : 0;
+        keys[r] = m;
+        src[r] = __builtin_amdgcn_readlane(e0, owner);
+        if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
+      }
+      if (lane == 0) s_nsub = (keys[0] >= 0) + (keys[1] >= 0) + (keys[2] >= 0);
+      // the winners' contributions: 29 granules each, published with the rows (same epoch)
+      const int j = lane & 31;
+      if (j < 29) {
+        const int r = lane >> 5;
+        for (int rr = r; rr < 3; rr += 2) {
+          if (keys[rr] < 0) continue;
+          const pt_u64* p = rowsE + (size_t)(src[rr] / 3) * PT_ROW + PT_SUB0 + (src[rr] % 3) * 29 + j;
+          pt_u64 x = pt_load(p);
+          for (unsigned spins = 0; (unsigned)(x >> 32) != epoch && spins < PT_SPIN_LIMIT; spins++) x = pt_load(p);
+          s_sub[rr][j] = __uint_as_float((unsigned)x);
+        }
+      }
+    }
+    __syncthreads();
+    PT_MARK(6);       // column totals, key merge, tail contributions
+    if (wave == 0) {
+      float Mf = s_sum[0][RS_M];
+#pragma unroll
+      for (int k = 1; k < 4; k++) Mf += s_sum[k][RS_M];
+      float s = 0.f;
+      if (tid < RS_END) {
+        s = s_sum[0][tid];
+#pragma unroll
+        for (int k = 1; k < 4; k++) s += s_sum[k][tid];
+      }
+      const int M = (int)Mf;
+      int need = M & 3;
+      if (need > s_nsub) need = s_nsub;
+      const int subIdx = (tid == RS_WERR) ? 0 : ((tid >= RS_A0 && tid < RS_B0) ? 1 + tid - RS_A0 : ((tid >= RS_B0 && tid < RS_ERR) ? 22 + tid - RS_B0 : (tid == RS_ERR ? 28 : -1)));
+      const float sub0 = s_sub[0][subIdx < 0 ? 0 : subIdx], sub1 = s_sub[1][subIdx < 0 ? 0 : subIdx], sub2 = s_sub[2][subIdx < 0 ? 0 : subIdx];
+      if (subIdx >= 0) {
+        if (need > 0) s -= sub0;
+        if (need > 1) s -= sub1;
+        if (need > 2) s -= sub2;
+      }
+      if (tid < RS_NUM) sh.tot[tid] = s;
+      lm_wave(s_par, S, s, sh.tot, tid, b == 0 ? out : nullptr, nullptr);
+    }
+    __syncthreads();
+    PT_MARK(7);       // Levenberg-Marquardt step
+    // ---- level change / end of job: wake the workgroups that join next (or tell them it is over) -----------------------------
+    if (b == 0 && (S.done || S.level != level)) {
+      bool later = false;        // does any workgroup still sleep?
+      for (int l = level - 1; l >= job.lastLevel && plan.pg[l] > 0; l--) later = later || plan.pg[l] > G;
+      if (S.done) {
+        if (later && tid == 0) pt_store(stg + 127, tagbase | 0xFFFu, 0u);
+      } else if (plan.pg[S.level] > G) {
+        const unsigned tg = tagbase | (0xF00u + (unsigned)S.level);
+        const unsigned* Sw = (const unsigned*)&S;
+        for (int i = tid; i < SW; i += BLOCK) pt_store(stg + i, tg, Sw[i]);
+      }
+    }
+  }
+}
+
 // checkPermaRefOverlap (SE3Tracker.cpp:121-157): usage only, explicit point list
 __global__ __launch_bounds__(256) void k_overlap(const float* __restrict__ pos, int n, EvalCtx a, float* __restrict__ out) {
   __shared__ float s_w[4];
@@ -1193,6 +1674,14 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 20) * 8));
   HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 20) * 8, c->stream));
 #endif
+  {
+    // persistent kernel: published rows (two parities) and the state record for late joiners, all {tag, value} granules
+    const size_t pt_bytes = ((size_t)2 * PT_MAXG * PT_ROW + 128) * sizeof(pt_u64);
+    HIPCHK(hipMalloc((void**)&t->d_ptrows, pt_bytes));
+    HIPCHK(hipMemsetAsync(t->d_ptrows, 0, pt_bytes, c->stream));
+    if (const char* e = getenv("LSDHIP_PERSIST")) t->persist = e[0] != '0';
+    if (const char* e = getenv("LSDHIP_PT_MAXG")) { t->ptMaxG = atoi(e); if (t->ptMaxG > PT_MAXG) t->ptMaxG = PT_MAXG; if (t->ptMaxG < 1) t->ptMaxG = 1; }
+  }
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
   memset(t->h_summary, 0, sizeof(TrackSummary));
@@ -1224,6 +1713,7 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
 #endif
   if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   (void)hipFree(t->d_partials);
+  (void)hipFree(t->d_ptrows);
   (void)hipFree(t->d_state);
   (void)hipHostFree(t->h_summary);
   if (t->d_pts) (void)hipFree(t->d_pts);
@@ -1233,6 +1723,25 @@ extern "C" int lsdhip_tracker_set_enqueue_hook(lsdhip_tracker* t, lsdhip_enqueue
   if (!t) return LSDHIP_E_ARG;
   t->enqueueHook = fn;
   t->enqueueHookUser = user;
+  return LSDHIP_OK;
+}
+// developer hook (tools/pt_check.py): shader cycles per phase of the last persistent job
+extern "C" int lsdhip_tracker_phase_cycles(const lsdhip_tracker* t, unsigned long long out[10]) {
+  if (!t || !out) return LSDHIP_E_ARG;
+  for (int k = 0; k < 10; k++) out[k] = t->h_summary->phase[k];
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_tracker_set_persistent(lsdhip_tracker* t, int maxStrips) {
+  if (!t || maxStrips < 0) return LSDHIP_E_ARG;
+  t->persist = maxStrips > 0;
+  t->persistOff = false;
+  if (maxStrips > 0) t->ptMaxG = maxStrips > PT_MAXG ? PT_MAXG : maxStrips;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]) {
+  if (!t || !out) return LSDHIP_E_ARG;
+  out[0] = t->persistJobs; out[1] = t->persistFallbacks; out[2] = t->persistOff ? 1 : 0;
+  for (int l = 0; l < LSD_LEVELS; l++) out[3 + l] = t->levelEvaluations[l];
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int its[LSD_LEVELS]) {
@@ -1473,9 +1982,44 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   if (int rc = prof_collect(c)) return rc;
   // timing events on every 8th job only: two event packets and a host-side event query per job cost ~5 % of a frame
   const bool sample = c->prof_on && ((c->prof_tick++ & 7) == 0);
+  // Persistent kernel (k_track_persist): the levels whose strips fit PT_MAXG workgroups run inside ONE launch; finer levels
+  // (if any) continue in the launch-per-evaluation chain from the state it leaves in d_state[0].
+  PersistPlan plan;
+  int ptGrid = 0;
+  bool ptHandoff = false;
+  for (int l = 0; l < LSD_LEVELS; l++) plan.pg[l] = 0;
+  if (t->persist && !t->persistOff) {
+    for (int l = topLevel; l >= job.lastLevel; l--) {
+      const long long work = (long long)job.lv[l].w * job.lv[l].h;
+      const int G = (int)((work + PT_STRIP - 1) / PT_STRIP);
+      if (job.lv[l].npts >= 0 || G > t->ptMaxG || (job.lv[l].w > 65535 || job.lv[l].h > 65535)) { ptHandoff = true; break; }
+      plan.pg[l] = G < 1 ? 1 : G;
+      if (l < topLevel && plan.pg[l] < plan.pg[l + 1]) plan.pg[l] = plan.pg[l + 1];   // participants never leave
+      if (plan.pg[l] > ptGrid) ptGrid = plan.pg[l];
+    }
+    if (plan.pg[topLevel] == 0) ptGrid = 0;
+  }
+  bool usedPersist = false;
   while (true) {
     if (sample) HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    int rc = launch_steps(t, job, budget, &parity, &first);
+    int rc = LSDHIP_OK;
+    if (ptGrid > 0 && guard == 0) {
+      t->ptSalt = (t->ptSalt + 1) & 0xFFFFFu;
+      if (t->ptSalt == 0) {   // tags wrap: clear the granules so that no stale tag can match
+        HIPCHK(hipMemsetAsync(t->d_ptrows, 0, ((size_t)2 * PT_MAXG * PT_ROW + 128) * sizeof(pt_u64), c->stream));
+        t->ptSalt = 1;
+      }
+      hipLaunchKernelGGL(k_track_persist, dim3(ptGrid), dim3(PT_BLOCK), 0, c->stream, job, plan, t->d_state, t->d_ptrows,
+                         t->d_ptrows + (size_t)2 * PT_MAXG * PT_ROW, t->ptSalt, t->d_summary);
+      HIPCHK(hipGetLastError());
+      usedPersist = true;
+      t->persistJobs++;
+      first = 0;
+      parity = 0;
+      if (ptHandoff) rc = launch_steps(t, job, budget, &parity, &first);
+    } else {
+      rc = launch_steps(t, job, budget, &parity, &first);
+    }
     if (rc) return rc;
     if (sample) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
     if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) t->enqueueHook(t->enqueueHookUser);
@@ -1499,9 +2043,26 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     } else {
       HIPCHK(hipStreamSynchronize(c->stream));
     }
+    if (S->done == 2) {
+      // the persistent kernel gave up on a spin (it never should): rerun the job with the launch-per-evaluation chain
+      HIPCHK(hipStreamSynchronize(c->stream));
+      t->persistFallbacks++;
+      if (t->persistFallbacks >= 3) t->persistOff = true;
+      ptGrid = 0;
+      t->h_summary->done = 0;
+      parity = 0; first = 1; guard = 1;
+      usedPersist = false;
+      continue;
+    }
     if (S->done) break;
     HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
+    if (S->done == 2) continue;
     if (S->done) break;
+    if (usedPersist && !ptHandoff) {
+      lsd_set_error("persistent tracking kernel ended without a result (exit %d, level %d, state %d, grid %d, plan %d %d %d %d %d)", S->pad_[0], S->pad_[1],
+                    S->pad_[2], ptGrid, plan.pg[0], plan.pg[1], plan.pg[2], plan.pg[3], plan.pg[4]);
+      return LSDHIP_E_STATE;
+    }
     if (int rc2 = prof_collect(c)) return rc2;
     budget = 6;
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
@@ -1511,6 +2072,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     c->prof_launches += S->numEvaluations;
   }
   t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = S->numEvaluations;
+  for (int l = 0; l < LSD_LEVELS; l++) t->levelEvaluations[l] = S->levelEvals[l];
   t->numEvaluations = S->numEvaluations;
   t->numWarpUpdates = S->numWarpUpdates;
   t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;

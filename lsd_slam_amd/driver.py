@@ -14,12 +14,13 @@ _lib = None
 
 class LoopStats(C.Structure):
     _fields_ = [("seconds_track", C.c_double), ("seconds_map", C.c_double), ("seconds_keyframe", C.c_double), ("frames", C.c_longlong),
-                ("updates", C.c_longlong), ("keyframes", C.c_longlong), ("evaluations", C.c_longlong)]
+                ("updates", C.c_longlong), ("keyframes", C.c_longlong), ("evaluations", C.c_longlong), ("tracked_good", C.c_longlong),
+                ("level_evaluations", C.c_longlong * 5)]
 
 
 EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop_get_stats", "lsdloop_reset_stats",
                     "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
-                    "lsdloop_last_error"]
+                    "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_persistent", "lsdloop_observe_time"]
 
 
 def lib():
@@ -46,6 +47,16 @@ def lib():
         L.lsdloop_set_keyframe_ring.argtypes = [vp, vp, i]
         L.lsdloop_keyframes_exported.restype = C.c_longlong
         L.lsdloop_keyframes_exported.argtypes = [vp]
+        L.lsdloop_keep_keyframes.restype = i
+        L.lsdloop_keep_keyframes.argtypes = [vp, i]
+        L.lsdloop_keyframe_log.restype = i
+        L.lsdloop_keyframe_log.argtypes = [vp, vp, vp, i]
+        L.lsdloop_set_live_queue.restype = i
+        L.lsdloop_set_live_queue.argtypes = [vp, i]
+        L.lsdloop_set_persistent.restype = i
+        L.lsdloop_set_persistent.argtypes = [vp, i]
+        L.lsdloop_observe_time.restype = i
+        L.lsdloop_observe_time.argtypes = [vp, vp, vp]
         L.lsdloop_ctx.restype = vp
         L.lsdloop_ctx.argtypes = [vp]
         L.lsdloop_last_error.restype = C.c_char_p
@@ -104,6 +115,29 @@ class DriverLoop:
     def set_keyframe_ring(self, ring_ptr, slots):
         """finished keyframes' (idepth, idepthVar) planes go to slot (count % slots) of the device buffer; None switches it off"""
         _check(self.L.lsdloop_set_keyframe_ring(self.h_, C.c_void_p(ring_ptr) if ring_ptr else None, slots))
+
+    def keep_keyframes(self, on=True):
+        _check(self.L.lsdloop_keep_keyframes(self.h_, int(on)))
+
+    def keyframe_log(self, max_entries=4096):
+        """(scales, numPoints) of the keyframes kept since keep_keyframes(True); synchronises"""
+        sc = np.zeros(max_entries, np.float64)
+        pts = np.zeros(max_entries, np.int64)
+        n = _check(self.L.lsdloop_keyframe_log(self.h_, sc.ctypes.data, pts.ctypes.data, max_entries))
+        n = min(n, max_entries)
+        return sc[:n], pts[:n]
+
+    def set_live_queue(self, frames):
+        _check(self.L.lsdloop_set_live_queue(self.h_, int(frames)))
+
+    def set_persistent(self, max_strips):
+        _check(self.L.lsdloop_set_persistent(self.h_, int(max_strips)))
+
+    def observe_time(self):
+        """(ms, calls) of the observe kernel alone, sampled while profiling is on; synchronises"""
+        ms, n = C.c_double(), C.c_longlong()
+        _check(self.L.lsdloop_observe_time(self.h_, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def keyframes_exported(self):
         return int(self.L.lsdloop_keyframes_exported(self.h_))

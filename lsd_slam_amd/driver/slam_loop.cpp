@@ -58,10 +58,15 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       SlamLoop& L = *l->loop;
       const long upd0 = L.numUpdates;
       const long ev0 = L.evaluations;
+      const long good0 = L.numTrackedGood;
+      long lev0[5];
+      for (int k = 0; k < 5; k++) lev0[k] = L.levelEvaluations[k];
       SE3 est = L.step(images[i], [](double) {}, (prefetch && i + 1 < n) ? images[i + 1] : nullptr);
       l->st.frames++;
       l->st.updates += L.numUpdates - upd0;
       l->st.evaluations += L.evaluations - ev0;
+      l->st.tracked_good += L.numTrackedGood - good0;
+      for (int k = 0; k < 5; k++) l->st.level_evaluations[k] += L.levelEvaluations[k] - lev0[k];
       if (L.newKeyframe) l->st.keyframes++;
       if (out7) est.to7(out7 + 7 * (size_t)i);
       done++;
@@ -121,6 +126,37 @@ extern "C" int lsdloop_set_keyframe_ring(lsdloop* l, float* ring_dev, int slots)
     l->ring_count++;
   };
   return LSDHIP_OK;
+}
+extern "C" int lsdloop_keep_keyframes(lsdloop* l, int on) {
+  if (!l) return LSDHIP_E_ARG;
+  l->loop->keepKeyframes = on != 0;
+  if (!on) l->loop->keyframeLog.clear();
+  return LSDHIP_OK;
+}
+extern "C" int lsdloop_keyframe_log(lsdloop* l, double* scales_out, long long* points_out, int max) {
+  if (!l) return LSDHIP_E_ARG;
+  try {
+    const auto& log = l->loop->keyframeLog;
+    for (int i = 0; i < (int)log.size() && i < max; i++) {
+      if (scales_out) scales_out[i] = log[i]->thisToParent_raw().s;
+      if (points_out) points_out[i] = log[i]->stats().numPoints;
+    }
+    return (int)log.size();
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+extern "C" int lsdloop_set_live_queue(lsdloop* l, int frames) {
+  if (!l || frames < 1) return LSDHIP_E_ARG;
+  l->loop->liveQueueLength = frames;
+  return LSDHIP_OK;
+}
+extern "C" int lsdloop_set_persistent(lsdloop* l, int max_strips) {
+  if (!l) return LSDHIP_E_ARG;
+  try { l->loop->tracker.setPersistent(max_strips); return LSDHIP_OK; }
+  catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+extern "C" int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out) {
+  if (!l) return LSDHIP_E_ARG;
+  return lsdhip_depth_observe_time(l->loop->map.handle(), ms_out, calls_out);
 }
 extern "C" long long lsdloop_keyframes_exported(lsdloop* l) { return l ? l->ring_count : -1; }
 extern "C" void* lsdloop_ctx(lsdloop* l) { return l ? (void*)l->ctx->handle() : nullptr; }

@@ -222,6 +222,16 @@ class SE3Tracker:
         its = np.ascontiguousarray(its, dtype=np.int32)
         check(self.L.lsdhip_tracker_set_max_its(self.h_, its.ctypes.data))
 
+    def set_persistent(self, max_strips):
+        """coarse pyramid levels in one persistent launch (0 = off, the default); see include/lsdhip.h"""
+        check(self.L.lsdhip_tracker_set_persistent(self.h_, int(max_strips)))
+
+    def exec_stats(self):
+        """diagnostics: (persistent-kernel jobs, give-ups rerun launch-per-evaluation, switched off, evaluations per level 0..4)"""
+        out = np.zeros(8, np.int32)
+        check(self.L.lsdhip_tracker_exec_stats(self.h_, out.ctypes.data))
+        return int(out[0]), int(out[1]), bool(out[2]), out[3:8].tolist()
+
     def _publish(self, r):
         self.last = r
         self.pointUsage = r.pointUsage

@@ -211,6 +211,7 @@ class SE3Tracker {
   float affineEstimation_a = 1, affineEstimation_b = 0;
   bool diverged = false, trackingWasGood = false;
   int numEvaluations = 0, numWarpUpdates = 0;  // instrumentation (not in the reference)
+  long long levelEvaluations[ORC_PYRAMID_LEVELS] = {}, levelPoints[ORC_PYRAMID_LEVELS] = {}, levelWarped[ORC_PYRAMID_LEVELS] = {};   // per pyramid level, cumulative
 
   // SoA scratch (SE3Tracker.cpp:67-78)
   float *buf_warped_residual, *buf_warped_dx, *buf_warped_dy, *buf_warped_x, *buf_warped_y, *buf_warped_z, *buf_d,
@@ -263,6 +264,8 @@ class DepthMap {
   float lastRescaleFactor = 1;   // rescaleFactor of the last createKeyFrame (DepthMap.cpp:1294)
   Params params;
   int numThreads = ORC_MAPPING_THREADS;
+  struct Pool;                       // persistent worker pool (IndexThreadReduce)
+  std::shared_ptr<Pool> pool;
 
  private:
   void observeDepthRow(int yMin, int yMax);

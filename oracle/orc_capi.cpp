@@ -147,6 +147,11 @@ struct orc_track_result {
 };
 void* orc_tracker_create(int w, int h, const float K[4], const orc_params* p) { return new SE3Tracker(w, h, K, to_params(p)); }
 void orc_tracker_destroy(void* t) { delete (SE3Tracker*)t; }
+// instrumentation: cumulative evaluations / reference points / in-image points per pyramid level
+void orc_tracker_level_stats(void* t, long long out[15]) {
+  SE3Tracker* tr = (SE3Tracker*)t;
+  for (int l = 0; l < 5; l++) { out[l] = tr->levelEvaluations[l]; out[5 + l] = tr->levelPoints[l]; out[10 + l] = tr->levelWarped[l]; }
+}
 void orc_tracker_set_mode(void* t, int mode) { ((SE3Tracker*)t)->mode = (TrackerMode)mode; }
 void orc_tracker_set_max_its(void* t, const int its[5]) {
   for (int i = 0; i < 5; i++) ((SE3Tracker*)t)->settings.maxItsPerLvl[i] = its[i];

@@ -5,6 +5,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include "lsd_oracle.hpp"
 
@@ -72,22 +75,56 @@ void DepthMap::reset() {
   for (int i = 0; i < width * height; i++) { otherDepthMap[i].isValid = false; currentDepthMap[i].isValid = false; }
 }
 
-// IndexThreadReduce.h:68-123 / :147-187: MAPPING_THREADS workers pull [todo, todo+stepSize) chunks.
+// IndexThreadReduce.h:68-123 / :147-187: a PERSISTENT pool of MAPPING_THREADS workers, woken per reduce() call, each pulling
+// [todo, todo + stepSize) chunks under the pool mutex until the range is exhausted; reduce() returns when all are idle again.
+// (Restated with std::thread / condition_variable; the calling thread only waits, as in the reference.)
+struct DepthMap::Pool {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable todo_signal, done_signal;
+  std::function<void(int, int)> call;
+  int nextIndex = 0, maxIndex = 0, stepSize = 1, busy = 0;
+  unsigned generation = 0;
+  bool running = true;
+  explicit Pool(int n) {
+    for (int i = 0; i < n; i++) workers.emplace_back([this] { loop(); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> l(m); running = false; }
+    todo_signal.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lock(m);
+    while (running) {
+      if (nextIndex < maxIndex) {
+        const int todo = nextIndex;
+        nextIndex += stepSize;
+        busy++;
+        lock.unlock();
+        call(todo, std::min(todo + stepSize, maxIndex));
+        lock.lock();
+        busy--;
+        if (nextIndex >= maxIndex && busy == 0) done_signal.notify_all();
+      } else {
+        todo_signal.wait(lock);
+      }
+    }
+  }
+  void run(std::function<void(int, int)> f, int first, int end, int step) {
+    std::unique_lock<std::mutex> lock(m);
+    call = std::move(f);
+    nextIndex = first; maxIndex = end; stepSize = step;
+    todo_signal.notify_all();
+    done_signal.wait(lock, [this] { return nextIndex >= maxIndex && busy == 0; });
+    nextIndex = maxIndex = 0;
+  }
+};
 template <typename F> void DepthMap::reduce(F f, int first, int end, int stepSize) {
   if (!params.multiThreading || numThreads <= 1) { f(first, end); return; }
   if (stepSize == 0) stepSize = ((end - first) + numThreads - 1) / numThreads;
-  std::atomic<int> next(first);
-  auto worker = [&]() {
-    while (true) {
-      int todo = next.fetch_add(stepSize);
-      if (todo >= end) break;
-      f(todo, std::min(todo + stepSize, end));
-    }
-  };
-  std::vector<std::thread> ths;
-  for (int i = 0; i < numThreads - 1; i++) ths.emplace_back(worker);
-  worker();
-  for (auto& t : ths) t.join();
+  if (!pool || (int)pool->workers.size() != numThreads) pool.reset(new Pool(numThreads));
+  pool->run(f, first, end, stepSize);
 }
 
 // DepthMap.cpp:111-146

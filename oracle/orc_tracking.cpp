@@ -177,6 +177,7 @@ float SE3Tracker::calcResidualAndBuffers(const float* refPoint, const float* ref
   affineEstimation_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
   affineEstimation_b_lastIt = (sy - affineEstimation_a_lastIt * sx) / sw;
   numEvaluations++;
+  if (level >= 0 && level < ORC_PYRAMID_LEVELS) { levelEvaluations[level]++; levelPoints[level] += refNum; levelWarped[level] += idx; }
   return sumResUnweighted / goodCount;
 }
 

@@ -73,11 +73,22 @@ def build_ref():
     return have_ref()
 
 
-def lib(fast=False, ref=None):
+def build_native():
+    """-O3 -march=native timing build for the host this runs on (falls back to the portable -march=x86-64-v3 build)"""
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+        return os.path.exists(os.path.join(_HERE, "liblsd_oracle_native.so"))
+    except Exception:
+        return False
+
+
+def lib(fast=False, ref=None, native=False):
     """fast: the -O3 timing build of the oracle.  ref = "sse" | "scalar": the REFERENCE itself (oracle/_ref) behind the
     same entry points — every class below works on either library."""
     if ref is not None:
         name = os.path.join("_ref", "liblsd_ref_%s.so" % ref)
+    elif native:
+        name = "liblsd_oracle_native.so"
     else:
         name = "liblsd_oracle_fast.so" if fast else "liblsd_oracle.so"
     if name in _LIBS:

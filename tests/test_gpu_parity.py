@@ -758,3 +758,40 @@ def test_permaref_batch_matches_single_and_oracle(oracle, hip):
             dt, dr = pose_distance(poses[j], np.array(oracles[j].frameToRef), oracle)
             assert max(dt, dr) < 2e-3, (j, dt, dr)
         assert bool(recs[j].diverged) == bool(oracles[j].diverged)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strips", [8, 32, 128])
+def test_persistent_kernel_matches_launch_per_evaluation(oracle, hip, strips):
+    """lsdhip_tracker_set_persistent: the coarse levels of trackFrame in one persistent launch (workgroups exchange their partial
+    sums through {tag, value} granules) give what the launch-per-evaluation chain gives — same points, same per-point
+    arithmetic, same LM step, another summation order — and the run never falls back."""
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
+    kf = hip.Frame(ctx, 0, frames[0])
+    kf.setDepthFromGroundTruth(depth0)
+    ref = hip.TrackingReference()
+    ref.importFrame(kf)
+    tr_a, tr_b = hip.SE3Tracker(ctx), hip.SE3Tracker(ctx)
+    tr_a.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr_b.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr_b.set_persistent(strips)
+    init = IDENT7.copy()
+    for i in range(1, 6):
+        fa, fb = hip.Frame(ctx, i, frames[i]), hip.Frame(ctx, i, frames[i])
+        pa = tr_a.trackFrame(ref, fa, init)
+        pb = tr_b.trackFrame(ref, fb, init)
+        dt, dr = pose_distance(pa, pb, oracle)
+        assert max(dt, dr) < 2e-5, (i, dt, dr)
+        assert (tr_a.diverged, tr_a.trackingWasGood) == (tr_b.diverged, tr_b.trackingWasGood)
+        assert abs(tr_a.last.numEvaluations - tr_b.last.numEvaluations) <= 2
+        assert tr_b.lastResidual == pytest.approx(tr_a.lastResidual, rel=1e-3) and tr_b.pointUsage == pytest.approx(tr_a.pointUsage, rel=1e-5)
+        assert (fa.refPixelWasGoodNoCreate() != fb.refPixelWasGoodNoCreate()).mean() < 1e-3
+        init = pa
+    jobs, fallbacks, off, levels = tr_b.exec_stats()
+    assert jobs == 5 and fallbacks == 0 and not off
+    assert sum(levels) == tr_b.last.numEvaluations and levels[4] == 1
+    # divergence inside the persistent kernel: identity + flags
+    bad = oracle.se3_exp(np.array([5.0, 0, 0, 0, 0, 0]))
+    est = tr_b.trackFrame(ref, hip.Frame(ctx, 9, frames[1]), bad)
+    assert tr_b.diverged and not tr_b.trackingWasGood and np.array_equal(est, IDENT7)

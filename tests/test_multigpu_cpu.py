@@ -70,3 +70,21 @@ def test_single_rank_is_a_noop_gather():
     kg.submit(lambda b: b.fill_(3.0), keep=True)
     kg.wait()
     assert kg.world == 1 and torch.equal(kg.collected[0][0], torch.full((2, 4, 4), 3.0))
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one rank per GPU); the
+    --dry-run leg runs the same rendezvous / barrier / max-over-ranks plumbing on gloo and prints n_gpus == 2."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
