@@ -212,6 +212,7 @@ struct lsdhip_tracker {
   int batch_jobs = 0;             // > 1 while the jobs of a batch are being described
   int cap_override = 0;           // batch tracking: per-job workgroup cap while the jobs of a batch are being described
   int recent[4] = {0, 0, 0, 0};   // evaluations of the last jobs: size the launch budget of the next one
+  int recentChain[4] = {0, 0, 0, 0};   // same, counting only the levels the k_track_step chain ran behind the persistent kernel
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary
   unsigned long long* d_trace = nullptr;  // LSD_PHASE_TRACE developer build only

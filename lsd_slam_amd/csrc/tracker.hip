@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_track_persist(TrackJob job, Persis
   __shared__ int s_flag;
   __shared__ float l_px[PT_STRIP], l_py[PT_STRIP], l_pz[PT_STRIP], l_I[PT_STRIP], l_var[PT_STRIP];
   __shared__ unsigned l_xy[PT_STRIP];
-  static_assert(44 * (PT_MAXG + 1) <= RS_END * (BLOCK + 1) + 8, "gather area must fit the reduction scratch");
+  static_assert(44 * (PT_MAXG + 1) + 16 * 87 <= RS_END * (BLOCK + 1) + 8, "gather area must fit the reduction scratch");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x;
   const unsigned tagbase = salt << 12;
@@ -1501,17 +1501,27 @@ __global__ __launch_bounds__(PT_BLOCK) void k_track_persist(TrackJob job, Persis
     // ---- gather the rows of all G participants: sums and keys ------------------------------------------------------------
     float* s_g = s_red;                    // [col][PT_MAXG + 1]; the reduction scratch is dead (barrier above)
     {
-      constexpr int NC = RS_END + 3;       // 41 sums, 3 keys
-      const int totalg = G * NC;
+      // per row: 41 sums and 3 keys; with few participants also the 87 tail contributions, so that the winners' values are
+      // already here when the keys have been merged (no second, dependent round trip)
+      constexpr int NC = RS_END + 3;
+      // (measured: at 8 participants the 87 extra granules per row cost more in the sweep — 3.7k -> 7.1k cycles — than the
+      // dependent fetch they save, 0.7k; kept for a single participant only)
+      constexpr int PT_EAGER_G = 16;
+      const bool eager = G <= 1;
+      const int per_row = eager ? NC + 87 : NC;
+      const int totalg = G * per_row;
+      float* s_csub = s_red + 44 * (PT_MAXG + 1);     // [PT_EAGER_G][87]
       bool bad = false;
       for (unsigned spins = 0;; spins++) {
         bool ok = true;
         for (int idx = tid; idx < totalg; idx += BLOCK) {
-          const int r = idx / NC, c = idx - r * NC;
+          const int r = idx / per_row, e = idx - r * per_row;
+          const int c = e < NC ? e : PT_SUB0 + (e - NC);
           const pt_u64 x = pt_load(rowsE + (size_t)r * PT_ROW + c);
           ok &= (unsigned)(x >> 32) == epoch;
-          if (c < RS_END) s_g[c * (PT_MAXG + 1) + r] = __uint_as_float((unsigned)x);
-          else s_keys[r * 3 + (c - RS_END)] = (int)(unsigned)x;
+          if (e < RS_END) s_g[e * (PT_MAXG + 1) + r] = __uint_as_float((unsigned)x);
+          else if (e < NC) s_keys[r * 3 + (e - RS_END)] = (int)(unsigned)x;
+          else s_csub[r * 87 + (e - NC)] = __uint_as_float((unsigned)x);
         }
         if (__all(ok)) break;
         if (spins > PT_SPIN_LIMIT) { bad = true; break; }
@@ -1564,7 +1574,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_track_persist(TrackJob job, Persis
       if (lane == 0) s_nsub = (keys[0] >= 0) + (keys[1] >= 0) + (keys[2] >= 0);
       // the winners' contributions: 29 granules each, published with the rows (same epoch)
       const int j = lane & 31;
-      if (j < 29) {
+      if (j < 29 && G <= 1) {
+        const float* s_csub = s_red + 44 * (PT_MAXG + 1);
+        const int r = lane >> 5;
+        for (int rr = r; rr < 3; rr += 2)
+          if (keys[rr] >= 0) s_sub[rr][j] = s_csub[(src[rr] / 3) * 87 + (src[rr] % 3) * 29 + j];
+      } else if (j < 29) {
         const int r = lane >> 5;
         for (int rr = r; rr < 3; rr += 2) {
           if (keys[rr] < 0) continue;
@@ -2016,7 +2031,16 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       t->persistJobs++;
       first = 0;
       parity = 0;
-      if (ptHandoff) rc = launch_steps(t, job, budget, &parity, &first);
+      if (ptHandoff) {
+        // budget of the chain = what the finer levels alone needed recently (+ the finishing step and a margin)
+        int cb = 26;
+        if (t->recentChain[0] > 0) {
+          cb = 0;
+          for (int i = 0; i < 4; i++) if (t->recentChain[i] > cb) cb = t->recentChain[i];
+          cb += 2;
+        }
+        rc = launch_steps(t, job, cb, &parity, &first);
+      }
     } else {
       rc = launch_steps(t, job, budget, &parity, &first);
     }
@@ -2073,6 +2097,11 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   }
   t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = S->numEvaluations;
   for (int l = 0; l < LSD_LEVELS; l++) t->levelEvaluations[l] = S->levelEvals[l];
+  if (usedPersist) {
+    int ce = 0;
+    for (int l = job.lastLevel; l <= topLevel; l++) if (plan.pg[l] == 0) ce += S->levelEvals[l];
+    t->recentChain[3] = t->recentChain[2]; t->recentChain[2] = t->recentChain[1]; t->recentChain[1] = t->recentChain[0]; t->recentChain[0] = ce;
+  }
   t->numEvaluations = S->numEvaluations;
   t->numWarpUpdates = S->numWarpUpdates;
   t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;
