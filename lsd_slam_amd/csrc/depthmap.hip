@@ -1131,6 +1131,7 @@ static int set_depth_finish(lsdhip_depthmap* dm, int nPartials);
 // Frame::setDepth on the active keyframe: level-0 planes, idepth pyramid, meanIdepth / numPoints
 static int set_depth(lsdhip_depthmap* dm) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   lsdhip_frame* kf = dm->activeKeyFrame;
   int n = c->w * c->h;
   int nb = (n + 255) / 256;
@@ -1140,6 +1141,7 @@ static int set_depth(lsdhip_depthmap* dm) {
 // second half of Frame::setDepth: mean inverse depth / point count from the (sum, count) partials, idepth pyramid
 static int set_depth_finish(lsdhip_depthmap* dm, int nPartials) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   lsdhip_frame* kf = dm->activeKeyFrame;
   const int slot = lsd_ctx_take_slot(c);
   if (slot < 0) return slot;
@@ -1156,6 +1158,7 @@ static int set_depth_finish(lsdhip_depthmap* dm, int nPartials) {
 
 static RegArgs reg_args(lsdhip_depthmap* dm, int validityTH) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   RegArgs a;
   a.m = dm->cur;
   a.validIn = dm->cur.valid;
@@ -1171,6 +1174,7 @@ static void swap_valid(lsdhip_depthmap* dm) { std::swap(dm->cur.valid, dm->d_val
 
 static int fill_holes(lsdhip_depthmap* dm) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   RegArgs a = reg_args(dm, 0);
   hipLaunchKernelGGL(k_fill_holes, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
   HIPCHK(hipGetLastError());
@@ -1179,6 +1183,7 @@ static int fill_holes(lsdhip_depthmap* dm) {
 }
 static int regularize(lsdhip_depthmap* dm, bool removeOcclusions, int validityTH) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   RegArgs a = reg_args(dm, validityTH);
   dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
   if (removeOcclusions) hipLaunchKernelGGL((k_reg_fused<false, true, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
@@ -1190,6 +1195,7 @@ static int regularize(lsdhip_depthmap* dm, bool removeOcclusions, int validityTH
 // regularizeDepthMapFillHoles + regularizeDepthMap(false, validityTH) [+ Frame::setDepth] in one launch
 static int fill_regularize(lsdhip_depthmap* dm, int validityTH, bool setDepth) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   lsdhip_frame* kf = dm->activeKeyFrame;
   RegArgs a = reg_args(dm, validityTH);
   dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
@@ -1206,6 +1212,7 @@ static int fill_regularize(lsdhip_depthmap* dm, int validityTH, bool setDepth) {
 // Frame::prepareForStereoWith (Frame.cpp:295-317): Sim3 algebra in double, results cast to float
 static void prepare_stereo(lsdhip_depthmap* dm, lsdhip_frame* fr, StereoRef& s) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   const lsdm::Sim3dH& thisToOther = fr->thisToParent_raw;
   lsdm::Sim3dH otherToThis = lsdm::sim3_inverse(thisToOther);
   double Rd[9];
@@ -1243,6 +1250,7 @@ static void prepare_stereo(lsdhip_depthmap* dm, lsdhip_frame* fr, StereoRef& s) 
 
 static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   lsdhip_frame* kf = dm->activeKeyFrame;
   if (n <= 0) { lsd_set_error("updateKeyframe: empty reference deque"); return LSDHIP_E_ARG; }
   for (int i = 0; i < n; i++) {
@@ -1345,6 +1353,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
 
 static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNow) {
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   lsdhip_frame* old = dm->activeKeyFrame;
   size_t n = (size_t)c->w * c->h;
   PropArgs a;
@@ -1433,6 +1442,7 @@ extern "C" int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   if (!dm || !kf) return LSDHIP_E_ARG;
   if (!kf->hasIDepth) { lsd_set_error("initializeFromGTDepth: frame has no depth"); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = false;
@@ -1444,6 +1454,7 @@ extern "C" int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf) {
 extern "C" int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   if (!dm || !kf) return LSDHIP_E_ARG;
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = false;
@@ -1476,6 +1487,7 @@ extern "C" int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame*
   if (!dm || !kf) return LSDHIP_E_ARG;
   if (!kf->reActValid) { lsd_set_error("setFromExistingKF: frame %d has no re-activation data", kf->id); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   dm->activeKeyFrame = kf;
   kf->numMappedOnThis = 0;
@@ -1496,6 +1508,7 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   if (!dm || !refs || n <= 0) return LSDHIP_E_ARG;
   if (!dm->activeKeyFrame) { lsd_set_error("updateKeyframe: depth map has no active keyframe"); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
   const int ev = timing_begin(dm, 0);
@@ -1525,6 +1538,7 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   if (!dm->activeKeyFrame) { lsd_set_error("createKeyFrame: depth map has no active keyframe"); return LSDHIP_E_STATE; }
   if (!nk->trackingParent) { lsd_set_error("createKeyFrame: new keyframe has no tracking parent"); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
   lsdm::SE3dH newToOld;
@@ -1577,6 +1591,7 @@ extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
   if (!dm) return LSDHIP_E_ARG;
   if (!dm->activeKeyFrame) { lsd_set_error("finalizeKeyFrame: depth map has no active keyframe"); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
   const int ev = timing_begin(dm, 2);
@@ -1617,6 +1632,7 @@ extern "C" int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], lon
 extern "C" int lsdhip_depth_download(lsdhip_depthmap* dm, lsdhip_hypothesis* out) {
   if (!dm || !out) return LSDHIP_E_ARG;
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   size_t n = (size_t)c->w * c->h;
   std::vector<uint8_t> v(n);
@@ -1642,6 +1658,7 @@ extern "C" int lsdhip_depth_download(lsdhip_depthmap* dm, lsdhip_hypothesis* out
 extern "C" int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const lsdhip_hypothesis* in, int reactivated) {
   if (!dm || !kf || !in) return LSDHIP_E_ARG;
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   size_t n = (size_t)c->w * c->h;
   std::vector<uint8_t> v(n);
@@ -1670,6 +1687,7 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
   if (!dm) return LSDHIP_E_ARG;
   if (!dm->activeKeyFrame) { lsd_set_error("depth stage: no active keyframe"); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   int rc = LSDHIP_E_ARG;
   switch (stage) {
@@ -1694,6 +1712,7 @@ extern "C" int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_d
   if (!dm || !idepth_dev || !var_dev) return LSDHIP_E_ARG;
   if (!dm->activeKeyFrame || !dm->activeKeyFrame->hasIDepth) return LSDHIP_E_STATE;
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   size_t n = (size_t)c->w * c->h;
   HIPCHK(hipMemcpyAsync(idepth_dev, dm->activeKeyFrame->d_idepth[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(var_dev, dm->activeKeyFrame->d_idepthVar[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -1707,6 +1726,7 @@ extern "C" int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_d
 extern "C" int lsdhip_depth_copy_rows_dev(lsdhip_depthmap* dm, int row0, int nrows, void* packed_dev, int to_map) {
   if (!dm || !packed_dev || row0 < 0 || nrows <= 0) return LSDHIP_E_ARG;
   lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
   if (row0 + nrows > c->h) return LSDHIP_E_ARG;
   HIPCHK(hipSetDevice(c->device));
   const size_t px = (size_t)nrows * c->w, off = (size_t)row0 * c->w;

@@ -353,6 +353,7 @@ extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], con
   }
   HIPCHK(hipSetDevice(device));
   lsdhip_ctx* c = new lsdhip_ctx();
+  LSD_CTX_LOCK(c);
   c->device = device;
   c->w = w;
   c->h = h;
@@ -397,6 +398,8 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
 }
 extern "C" void* lsdhip_ctx_stream(lsdhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
+  if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
   if (c) {
     for (int i = 0; i < LSD_NUM_SLOTS; i++) {   // pick up every deferred result
       if (c->slot_stats_owner[i]) { int rc = lsd_frame_resolve(c->slot_stats_owner[i]); if (rc) return rc; }
@@ -409,10 +412,12 @@ extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
 }
 extern "C" int lsdhip_ctx_set_async(lsdhip_ctx* c, int on) {
   if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
   c->async = on != 0;
   return LSDHIP_OK;
 }
 int lsd_ctx_take_slot(lsdhip_ctx* c) {
+  LSD_CTX_LOCK(c);
   const int i = c->slot_next;
   c->slot_next = (c->slot_next + 1) % LSD_NUM_SLOTS;
   if (c->slot_stats_owner[i]) { int rc = lsd_frame_resolve(c->slot_stats_owner[i]); if (rc) return rc; }
@@ -422,6 +427,7 @@ int lsd_ctx_take_slot(lsdhip_ctx* c) {
 int lsd_frame_resolve(lsdhip_frame* f) {
   if (f->pendStats < 0 && f->pendRescale < 0) return LSDHIP_OK;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   int rc = LSDHIP_OK;
@@ -453,6 +459,7 @@ extern "C" int lsdhip_ctx_intrinsics(lsdhip_ctx* c, int level, float out[8]) {
 extern "C" int lsdhip_prof_enable(lsdhip_ctx* c, int on) { if (!c) return LSDHIP_E_ARG; c->prof_on = on != 0; return LSDHIP_OK; }
 extern "C" int lsdhip_prof_reset(lsdhip_ctx* c) {
   if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
   c->prof_ms = 0; c->prof_bytes = 0; c->prof_launches = 0;
   return LSDHIP_OK;
 }
@@ -468,6 +475,7 @@ extern "C" int lsdhip_prof_read(lsdhip_ctx* c, double* ms, long long* launches, 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
+  LSD_CTX_LOCK(c);
   lsdhip_frame* f = new lsdhip_frame();
   f->ctx = c;
   f->id = id;
@@ -517,6 +525,7 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
 
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src) {
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   dim3 grid(c->w / 16, c->h / 16);
   hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, c->stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
                      f->d_image[3], f->d_image[4], c->w, c->h, f->d_grad[0], f->d_absgrad);
@@ -539,6 +548,7 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src) {
 
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, int redN, double* redOut) {
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   DepthPyrArgs a;
   for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = f->d_idepth[l]; a.var[l] = f->d_idepthVar[l]; }
   a.w0 = c->w;
@@ -560,6 +570,7 @@ int lsd_frame_ensure_wasgood(lsdhip_frame* f) {
 
 extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint8_t* gray_dev, lsdhip_frame** out) {
   if (!c || !gray_dev || !out) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   lsdhip_frame* f = nullptr;
   int rc = frame_alloc(c, id, &f);
@@ -572,6 +583,7 @@ extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint
 }
 extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_host, lsdhip_frame** out) {
   if (!c || !gray_host || !out) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   lsdhip_frame* f = nullptr;
   int rc = frame_alloc(c, id, &f);
@@ -586,6 +598,7 @@ extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_ho
 extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   if (!f) return;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   if (c->free_arenas.size() < 16) {
     c->free_arenas.push_back(f->d_gray);  // arena base; reuse is ordered on the context's stream
   } else {
@@ -602,6 +615,7 @@ extern "C" int lsdhip_frame_id(lsdhip_frame* f) { return f ? f->id : -1; }
 extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float* out) {
   if (!f || !out || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   size_t n = (size_t)c->wl[level] * c->hl[level];
   const void* src = nullptr;
   switch (what) {
@@ -620,6 +634,7 @@ extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float
 extern "C" int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_host, float cov_scale) {
   if (!f || !depth_host) return LSDHIP_E_ARG;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   int n0 = c->w * c->h;
   float* d_depth = nullptr;
   HIPCHK(hipMalloc((void**)&d_depth, (size_t)n0 * 4));
@@ -634,6 +649,7 @@ extern "C" int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_hos
 extern "C" int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* id, const float* var) {
   if (!f || !id || !var) return LSDHIP_E_ARG;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   size_t n0 = (size_t)c->w * c->h;
   HIPCHK(hipMemcpyAsync(f->d_idepth[0], id, n0 * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(f->d_idepthVar[0], var, n0 * 4, hipMemcpyHostToDevice, c->stream));
@@ -646,6 +662,7 @@ extern "C" int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* id, c
 extern "C" int lsdhip_frame_set_maxgrad(lsdhip_frame* f, const float* maxgrad_host) {
   if (!f || !maxgrad_host) return LSDHIP_E_ARG;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpyAsync(f->d_maxgrad, maxgrad_host, (size_t)c->w * c->h * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -655,6 +672,7 @@ extern "C" int lsdhip_frame_get_wasgood(lsdhip_frame* f, uint8_t* out) {
   if (!f || !out) return LSDHIP_E_ARG;
   if (!f->wasGoodValid) return 0;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipMemcpyAsync(out, f->d_wasGood, (size_t)c->wl[1] * c->hl[1], hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 1;
@@ -662,6 +680,7 @@ extern "C" int lsdhip_frame_get_wasgood(lsdhip_frame* f, uint8_t* out) {
 extern "C" int lsdhip_frame_set_wasgood(lsdhip_frame* f, const uint8_t* in) {
   if (!f || !in) return LSDHIP_E_ARG;
   lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipMemcpyAsync(f->d_wasGood, in, (size_t)c->wl[1] * c->hl[1], hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   f->wasGoodValid = true;
@@ -715,6 +734,7 @@ extern "C" int lsdhip_ref_pointcloud(lsdhip_frame* kf, int level, float* pos, fl
   if (!kf || level < 0 || level >= LSD_LEVELS) { lsd_set_error("lsdhip_ref_pointcloud: bad arguments"); return LSDHIP_E_ARG; }
   if (!kf->hasIDepth) { lsd_set_error("lsdhip_ref_pointcloud: keyframe has no depth"); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = kf->ctx;
+  LSD_CTX_LOCK(c);
   int w = c->wl[level], h = c->hl[level];
   size_t nmax = (size_t)w * h;
   char* scratch = nullptr;

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/lsdhip.h"
@@ -119,7 +120,14 @@ struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_NUM_SLOTS 32
 struct lsdhip_frame;
 
+// Host-side state of a context (arena free list, deferred-result slot ring and its owner tables, profiling events, the
+// staging blocks of the objects created on it) is shared by every Frame / SE3Tracker / DepthMap of that context, and the
+// reference drives them from two threads (tracking and mapping, C/SlamSystem.h:124-131).  Every C-ABI entry that touches it
+// holds the context's mutex (recursive: entries call each other, and the tracker's enqueue hook re-enters from the same
+// thread); lsdhip_tracker_track releases it while it waits for the device, so the mapping thread can keep enqueueing.
+#define LSD_CTX_LOCK(c) std::lock_guard<std::recursive_mutex> lsd_ctx_lock_((c)->mtx)
 struct lsdhip_ctx {
+  std::recursive_mutex mtx;
   int device = 0;
   bool async = false;                    // lsdhip_ctx_set_async: mapping calls return after enqueueing
   DeferredSlot* h_slots = nullptr;       // pinned, device-mapped ring

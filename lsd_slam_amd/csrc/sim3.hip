@@ -468,6 +468,7 @@ extern "C" int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int i
 static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsdhip_frame* frame, const Sim3H& referenceToFrame, int level,
                           float aff_a, float aff_b, Sim3Job* out) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   Sim3Job a;
   a.kf_idepth = kf->d_idepth[level]; a.kf_idepthVar = kf->d_idepthVar[level]; a.kf_image = kf->d_image[level]; a.kf_grad = kf->d_grad[level];
   a.fr_grad = frame->d_grad[level]; a.fr_idepth = frame->d_idepth[level]; a.fr_idepthVar = frame->d_idepthVar[level];
@@ -521,6 +522,7 @@ static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsd
 // launches the slots with nblocks > 0 and waits until each of them has raised the launch's sequence number
 static int sim3_run_batch(lsdhip_sim3tracker* t, Sim3Batch& batch, int nslots) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   const int seq = ++t->seq;
   int grid = 0;
   for (int k = 0; k < S3_MAXB; k++) {
@@ -713,6 +715,7 @@ void sim3_iteration(lsdhip_sim3tracker* t, Sim3Track& J) {
 // the requested evaluation has arrived
 void sim3_advance(lsdhip_sim3tracker* t, Sim3Track& J, const Eval& ev) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   const bool useAffine = c->params.useAffineLightningEstimation != 0;
   J.numEvaluations++;
   if (J.phase == Sim3Track::FINAL) {

@@ -1772,6 +1772,7 @@ static const float MIN_GOODPERALL_PIXEL_ABSMIN = 0.01f;
 static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame* kf, lsdhip_frame* frame, const float* pts_pos,
                        const float* pts_colvar, int npts) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   TrackLevel& L = job.lv[level];
   const LevelIntr& in = c->intr[level];
   L.w = c->wl[level]; L.h = c->hl[level];
@@ -1809,6 +1810,7 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
 }
 static void fill_job_common(lsdhip_tracker* t, TrackJob& job) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   memset(&job, 0, sizeof(job));
   job.cameraPixelNoise2 = c->params.cameraPixelNoise2;
   job.var_weight = t->var_weight;
@@ -1832,6 +1834,7 @@ static TrackScratch scratch_of(lsdhip_tracker* t) {
 }
 static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int parity, int first) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   TrackScratch sc = scratch_of(t);
   hipLaunchKernelGGL((k_track_step<256, false>), dim3(grid), dim3(256), 0, c->stream, job, (const TrackJob*)nullptr, t->d_state, sc,
                      t->d_summary, parity, first);
@@ -1861,6 +1864,7 @@ struct EvalOut {       // what one evaluation leaves behind, in the reference's 
 // one evaluation with a host round trip (evalOnly job): kernel-level parity hook and host-LM debugging path
 static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T, int level, EvalOut* eo) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   job.evalOnly = 1;
   job.lastLevel = level;
   job.topLevel = level;
@@ -1908,6 +1912,7 @@ static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T,
 // host-driven LM for one level (debugging path): SE3Tracker.cpp:323-449
 static int lm_level_host(lsdhip_tracker* t, TrackJob& job, int lvl, lsdm::SE3fH& referenceToFrame, float* lastResidualOut) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   const TrackLevel& L = job.lv[lvl];
   EvalOut ev;
   int rc = evaluate_pose(t, job, referenceToFrame, lvl, &ev);
@@ -1979,6 +1984,7 @@ int lsd_prof_collect(lsdhip_ctx* c) { return prof_collect(c); }
 // launches that did work.
 static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const lsdm::SE3fH& T0, lsdm::SE3fH* Tout) {
   lsdhip_ctx* c = t->ctx;
+  // (the caller — an extern "C" entry — holds the context mutex once; it is released below while the host waits)
   job.evalOnly = 0;
   job.topLevel = topLevel;
   job.T0 = T0;
@@ -2050,6 +2056,10 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
     // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.
+    c->mtx.unlock();    // nothing below touches context state until the result is in: let the mapping thread enqueue
+    struct Relock { std::recursive_mutex& m; ~Relock() { m.lock(); } };
+    {
+    Relock relock_{c->mtx};
     if (t->spinWait) {
       volatile const int* done = &S->done;
       const auto tStart = std::chrono::steady_clock::now();
@@ -2066,6 +2076,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       std::atomic_thread_fence(std::memory_order_acquire);
     } else {
       HIPCHK(hipStreamSynchronize(c->stream));
+    }
     }
     if (S->done == 2) {
       // the persistent kernel gave up on a spin (it never should): rerun the job with the launch-per-evaluation chain
@@ -2138,6 +2149,7 @@ static int fill_trackframe_job(lsdhip_tracker* t, TrackJob& job, lsdhip_frame* k
 // epilogue of trackFrame (SE3Tracker.cpp:451-485) from the job's summary: flags, frame / keyframe side effects, result
 static int finish_trackframe(lsdhip_tracker* t, const TrackSummary* S, lsdhip_frame* kf, lsdhip_frame* frame, lsdhip_track_result* out) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   t->numEvaluations = S->numEvaluations;
   t->numWarpUpdates = S->numWarpUpdates;
   t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;
@@ -2173,6 +2185,7 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   if (!t || !kf || !frame || !init || !out) return LSDHIP_E_ARG;
   if (!kf->hasIDepth) { lsd_set_error("lsdhip_tracker_track: keyframe %d has no depth", kf->id); return LSDHIP_E_STATE; }
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   t->diverged = false;
   t->trackingWasGood = true;
@@ -2215,6 +2228,7 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
 // ---- batches: n independent jobs in the same launches (job = blockIdx.y) -------------------------------------------
 static int batch_reserve(lsdhip_tracker* t, int n) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   if (n <= t->batch_capacity) return LSDHIP_OK;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
@@ -2240,6 +2254,7 @@ static void batch_begin(lsdhip_tracker* t, int n) {
 // runs the n jobs described in t->h_bjobs[0..n) to completion; summaries in t->h_bsummary
 static int batch_run(lsdhip_tracker* t, int n) {
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   t->cap_override = 0;
   t->batch_jobs = 0;
   int grid = 1;
@@ -2307,6 +2322,7 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
                                           const double* inits, lsdhip_track_result* results) {
   if (!t || n <= 0 || !keyframes || !frames || !inits || !results) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   for (int j = 0; j < n; j++) {
     if (!keyframes[j] || !frames[j]) return LSDHIP_E_ARG;
@@ -2382,6 +2398,7 @@ extern "C" int lsdhip_tracker_track_permaref(lsdhip_tracker* t, const float* pos
                                              const double refToFrame[7], lsdhip_track_result* out) {
   if (!t || !pos || !colvar || n <= 0 || !frame || !refToFrame || !out) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
     int rc = upload_points(t, pos, colvar, n);
   if (rc) return rc;
@@ -2424,6 +2441,7 @@ extern "C" int lsdhip_tracker_track_permaref_batch(lsdhip_tracker* t, int n, con
                                                    lsdhip_frame** frames, const double* refToFrame, lsdhip_track_result* results) {
   if (!t || n <= 0 || !pos || !colvar || !counts || !frames || !refToFrame || !results) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   int total = 0;
   for (int j = 0; j < n; j++) { if (counts[j] <= 0 || !frames[j]) return LSDHIP_E_ARG; total += counts[j]; }
@@ -2477,6 +2495,7 @@ extern "C" int lsdhip_tracker_track_permaref_batch(lsdhip_tracker* t, int n, con
 extern "C" int lsdhip_tracker_check_overlap(lsdhip_tracker* t, const float* pos, int n, const double refToFrame[7], float* usage_out) {
   if (!t || !pos || n <= 0 || !refToFrame || !usage_out) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   int rc = upload_points(t, pos, nullptr, n);
   if (rc) return rc;
