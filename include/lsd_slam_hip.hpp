@@ -240,9 +240,15 @@ inline void Frame::setPermaRef(TrackingReference* reference) {
   permaRefNumPts = reference->makePointCloud(4 /* QUICK_KF_CHECK_LVL */, &permaRef_posData, &permaRef_colorAndVarData);
 }
 
-// util/settings.h:355-402 (the fields the C ABI exposes)
+// util/settings.h:355-402, every field with the reference's defaults (settings.h:360-400)
 struct DenseDepthTrackerSettings {
+  float lambdaSuccessFac = 0.5f, lambdaFailFac = 2.0f;
+  float lambdaInitial[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};
+  float stepSizeMin[LSDHIP_PYRAMID_LEVELS] = {1e-8f, 1e-8f, 1e-8f, 1e-8f, 1e-8f};
+  float convergenceEps[LSDHIP_PYRAMID_LEVELS] = {0.999f, 0.999f, 0.999f, 0.999f, 0.999f};
   int maxItsPerLvl[LSDHIP_PYRAMID_LEVELS] = {5, 20, 50, 100, 100};
+  float lambdaInitialTestTrack = 0, stepSizeMinTestTrack = 1e-3f, convergenceEpsTestTrack = 0.98f, maxItsTestTrack = 5;
+  float huber_d = 3, var_weight = 1.0f;
 };
 
 // Tracking/SE3Tracker.h:41-93
@@ -260,7 +266,7 @@ class SE3Tracker {
   ~SE3Tracker() { lsdhip_tracker_destroy(h_); }
 
   SE3 trackFrame(TrackingReference* reference, Frame* frame, const SE3& frameToReference_initialEstimate) {
-    check(lsdhip_tracker_set_max_its(h_, settings.maxItsPerLvl), "lsdhip_tracker_set_max_its");
+    pushSettings();
     double init[7];
     frameToReference_initialEstimate.to7(init);
     lsdhip_track_result r;
@@ -271,6 +277,7 @@ class SE3Tracker {
     return SE3::from7(r.frameToReference);
   }
   SE3 trackFrameOnPermaref(Frame* reference, Frame* frame, SE3 referenceToFrame) {
+    pushSettings();
     double init[7];
     referenceToFrame.to7(init);
     lsdhip_track_result r;
@@ -304,6 +311,18 @@ class SE3Tracker {
   void setPersistent(int maxStrips) { check(lsdhip_tracker_set_persistent(h_, maxStrips), "lsdhip_tracker_set_persistent"); }
 
  private:
+  void pushSettings() {   // the public `settings` member is plain data in the reference: hand it over before every job
+    lsdhip_tracker_settings st;
+    st.lambdaSuccessFac = settings.lambdaSuccessFac; st.lambdaFailFac = settings.lambdaFailFac;
+    for (int l = 0; l < LSDHIP_PYRAMID_LEVELS; l++) {
+      st.lambdaInitial[l] = settings.lambdaInitial[l]; st.stepSizeMin[l] = settings.stepSizeMin[l];
+      st.convergenceEps[l] = settings.convergenceEps[l]; st.maxItsPerLvl[l] = settings.maxItsPerLvl[l];
+    }
+    st.lambdaInitialTestTrack = settings.lambdaInitialTestTrack; st.stepSizeMinTestTrack = settings.stepSizeMinTestTrack;
+    st.convergenceEpsTestTrack = settings.convergenceEpsTestTrack; st.maxItsTestTrack = settings.maxItsTestTrack;
+    st.huber_d = settings.huber_d; st.var_weight = settings.var_weight;
+    check(lsdhip_tracker_set_settings(h_, &st), "lsdhip_tracker_set_settings");
+  }
   void publish(const lsdhip_track_result& r) {
     pointUsage = r.pointUsage; lastGoodCount = r.lastGoodCount; lastMeanRes = r.lastMeanRes; lastBadCount = r.lastBadCount;
     lastResidual = r.lastResidual; affineEstimation_a = r.affineEstimation_a; affineEstimation_b = r.affineEstimation_b;

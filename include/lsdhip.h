@@ -139,6 +139,17 @@ typedef struct lsdhip_residual_record {
 int lsdhip_tracker_create(lsdhip_ctx* ctx, lsdhip_tracker** out);
 void lsdhip_tracker_destroy(lsdhip_tracker* t);
 int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int maxItsPerLvl[LSDHIP_PYRAMID_LEVELS]);
+/* DenseDepthTrackerSettings, every field (C/util/settings.h:355-402; defaults C/util/settings.h:360-400): the reference exposes
+ * `settings` as a public member of SE3Tracker (C/Tracking/SE3Tracker.h:49) and SlamSystem edits it (SlamSystem.cpp:80-81). */
+typedef struct lsdhip_tracker_settings {
+  float lambdaSuccessFac, lambdaFailFac;
+  float lambdaInitial[LSDHIP_PYRAMID_LEVELS], stepSizeMin[LSDHIP_PYRAMID_LEVELS], convergenceEps[LSDHIP_PYRAMID_LEVELS];
+  int maxItsPerLvl[LSDHIP_PYRAMID_LEVELS];
+  float lambdaInitialTestTrack, stepSizeMinTestTrack, convergenceEpsTestTrack, maxItsTestTrack;   /* trackFrameOnPermaref */
+  float huber_d, var_weight;
+} lsdhip_tracker_settings;
+int lsdhip_tracker_get_settings(const lsdhip_tracker* t, lsdhip_tracker_settings* out);
+int lsdhip_tracker_set_settings(lsdhip_tracker* t, const lsdhip_tracker_settings* in);
 /* Execution strategy of trackFrame on the device (no reference counterpart; results are the same up to summation order).
  * Default: one kernel launch per residual evaluation (k_track_step).  maxStrips > 0: pyramid levels that fit maxStrips strips
  * of 640 pixels (one workgroup each, at most 128) run inside ONE persistent launch whose workgroups exchange their partial

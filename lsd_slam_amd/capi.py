@@ -24,6 +24,14 @@ class Params(C.Structure):
                 ("useAffineLightningEstimation", C.c_int)]
 
 
+class TrackerSettings(C.Structure):
+    """lsdhip_tracker_settings = DenseDepthTrackerSettings (C/util/settings.h:355-402)"""
+    _fields_ = [("lambdaSuccessFac", C.c_float), ("lambdaFailFac", C.c_float), ("lambdaInitial", C.c_float * 5), ("stepSizeMin", C.c_float * 5),
+                ("convergenceEps", C.c_float * 5), ("maxItsPerLvl", C.c_int * 5), ("lambdaInitialTestTrack", C.c_float),
+                ("stepSizeMinTestTrack", C.c_float), ("convergenceEpsTestTrack", C.c_float), ("maxItsTestTrack", C.c_float),
+                ("huber_d", C.c_float), ("var_weight", C.c_float)]
+
+
 class TrackResult(C.Structure):
     _fields_ = [("frameToReference", C.c_double * 7), ("pointUsage", C.c_float), ("lastGoodCount", C.c_float),
                 ("lastBadCount", C.c_float), ("lastMeanRes", C.c_float), ("lastResidual", C.c_float),
@@ -86,6 +94,8 @@ def _signatures():
         "lsdhip_tracker_create": (i, [vp, pvp]),
         "lsdhip_tracker_destroy": (None, [vp]),
         "lsdhip_tracker_set_max_its": (i, [vp, vp]),
+        "lsdhip_tracker_get_settings": (i, [vp, C.POINTER(TrackerSettings)]),
+        "lsdhip_tracker_set_settings": (i, [vp, C.POINTER(TrackerSettings)]),
         "lsdhip_tracker_set_persistent": (i, [vp, i]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_phase_cycles": (i, [vp, vp]),

@@ -1746,6 +1746,30 @@ extern "C" int lsdhip_tracker_phase_cycles(const lsdhip_tracker* t, unsigned lon
   for (int k = 0; k < 10; k++) out[k] = t->h_summary->phase[k];
   return LSDHIP_OK;
 }
+extern "C" int lsdhip_tracker_get_settings(const lsdhip_tracker* t, lsdhip_tracker_settings* o) {
+  if (!t || !o) return LSDHIP_E_ARG;
+  o->lambdaSuccessFac = t->lambdaSuccessFac; o->lambdaFailFac = t->lambdaFailFac;
+  for (int l = 0; l < LSD_LEVELS; l++) {
+    o->lambdaInitial[l] = t->lambdaInitial[l]; o->stepSizeMin[l] = t->stepSizeMin[l]; o->convergenceEps[l] = t->convergenceEps[l];
+    o->maxItsPerLvl[l] = t->maxItsPerLvl[l];
+  }
+  o->lambdaInitialTestTrack = t->lambdaInitialTestTrack; o->stepSizeMinTestTrack = t->stepSizeMinTestTrack;
+  o->convergenceEpsTestTrack = t->convergenceEpsTestTrack; o->maxItsTestTrack = t->maxItsTestTrack;
+  o->huber_d = t->huber_d; o->var_weight = t->var_weight;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_tracker_set_settings(lsdhip_tracker* t, const lsdhip_tracker_settings* in) {
+  if (!t || !in) return LSDHIP_E_ARG;
+  t->lambdaSuccessFac = in->lambdaSuccessFac; t->lambdaFailFac = in->lambdaFailFac;
+  for (int l = 0; l < LSD_LEVELS; l++) {
+    t->lambdaInitial[l] = in->lambdaInitial[l]; t->stepSizeMin[l] = in->stepSizeMin[l]; t->convergenceEps[l] = in->convergenceEps[l];
+    t->maxItsPerLvl[l] = in->maxItsPerLvl[l];
+  }
+  t->lambdaInitialTestTrack = in->lambdaInitialTestTrack; t->stepSizeMinTestTrack = in->stepSizeMinTestTrack;
+  t->convergenceEpsTestTrack = in->convergenceEpsTestTrack; t->maxItsTestTrack = in->maxItsTestTrack;
+  t->huber_d = in->huber_d; t->var_weight = in->var_weight;
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_tracker_set_persistent(lsdhip_tracker* t, int maxStrips) {
   if (!t || maxStrips < 0) return LSDHIP_E_ARG;
   t->persist = maxStrips > 0;

@@ -222,6 +222,15 @@ class SE3Tracker:
         its = np.ascontiguousarray(its, dtype=np.int32)
         check(self.L.lsdhip_tracker_set_max_its(self.h_, its.ctypes.data))
 
+    def settings(self):
+        """DenseDepthTrackerSettings of this tracker (a copy; write back with set_settings)"""
+        st = capi.TrackerSettings()
+        check(self.L.lsdhip_tracker_get_settings(self.h_, C.byref(st)))
+        return st
+
+    def set_settings(self, st):
+        check(self.L.lsdhip_tracker_set_settings(self.h_, C.byref(st)))
+
     def set_persistent(self, max_strips):
         """coarse pyramid levels in one persistent launch (0 = off, the default); see include/lsdhip.h"""
         check(self.L.lsdhip_tracker_set_persistent(self.h_, int(max_strips)))

@@ -152,6 +152,7 @@ void orc_tracker_level_stats(void* t, long long out[15]) {
   SE3Tracker* tr = (SE3Tracker*)t;
   for (int l = 0; l < 5; l++) { out[l] = tr->levelEvaluations[l]; out[5 + l] = tr->levelPoints[l]; out[10 + l] = tr->levelWarped[l]; }
 }
+void orc_tracker_set_huber(void* t, float huber_d) { ((SE3Tracker*)t)->settings.huber_d = huber_d; }
 void orc_tracker_set_mode(void* t, int mode) { ((SE3Tracker*)t)->mode = (TrackerMode)mode; }
 void orc_tracker_set_max_its(void* t, const int its[5]) {
   for (int i = 0; i < 5; i++) ((SE3Tracker*)t)->settings.maxItsPerLvl[i] = its[i];

@@ -103,3 +103,62 @@ def test_cpp_adapter_header_compiles_standalone(tmp_path):
                    "void (TrackingReference::*p8)(Frame*) = &TrackingReference::importFrame;\n"
                    "int main() { return 0; }\n")
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_sophus_adapter_compiles_against_reference_typedefs(tmp_path):
+    """include/lsd_slam_hip_sophus.hpp against the REFERENCE's own headers: C/util/SophusUtil.h (SE3 / Sim3 typedefs,
+    sim3FromSE3 / se3FromSim3) and C/DataStructures/FramePoseStruct.h, included unchanged from /root/reference.  Eigen and the
+    Eigen-based vendored Sophus are absent from this machine, so the types behind the typedefs come from the stand-in headers
+    of oracle/ref/shim (the header says which Sophus / Eigen members it needs: all of them exist in the real libraries with the
+    same signatures).  The program also round-trips poses through the adapter at run time (host only, no GPU)."""
+    import subprocess
+    refsrc = "/root/reference/lsd_slam_core/src"
+    if not os.path.isdir(refsrc):
+        pytest.skip("/root/reference is not on this machine")
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include "util/SophusUtil.h"                 // the reference's typedefs: SE3 = Sophus::SE3d, Sim3 = Sophus::Sim3d
+#include "DataStructures/FramePoseStruct.h"  // the reference's pose node (thisToParent_raw is a Sim3)
+#include "util/settings.h"                   // DenseDepthTrackerSettings
+#include "lsd_slam_hip_sophus.hpp"
+#include <cmath>
+#include <cstdio>
+using namespace lsd_slam_hip;
+namespace orc { Sim3d sim3_exp(const double*) { return Sim3d(); } }   // the stand-in Sim3 exponential lives in the oracle; unused here
+int main() {
+  // SlamSystem.cpp:932 style call site: SE3 in, SE3 out
+  ::SE3 init(Eigen::Quaterniond(0.9998, 0.01, -0.012, 0.008), Eigen::Vector3d(0.1, -0.2, 0.3));
+  lsd_slam_hip::SE3 pod = toHip(init);
+  ::SE3 back = fromHip<::SE3>(pod);
+  double e = 0;
+  for (int i = 0; i < 3; i++) e += std::fabs(back.translation()[i] - init.translation()[i]);
+  e += std::fabs(back.unit_quaternion().w() - init.unit_quaternion().w()) + std::fabs(back.unit_quaternion().z() - init.unit_quaternion().z());
+  // createKeyFrame writes a scaled Sim3 into the pose node (DepthMap.cpp:1305)
+  ::Sim3 s = lsd_slam::sim3FromSE3(init, 1.7);
+  lsd_slam_hip::Sim3 spod = toHipSim3(s);
+  ::Sim3 sback = fromHipSim3<::Sim3>(spod);
+  e += std::fabs(sback.scale() - 1.7) + std::fabs(spod.s - 1.7);
+  for (int i = 0; i < 3; i++) e += std::fabs(sback.translation()[i] - s.translation()[i]);
+  Eigen::Matrix3f K;
+  K << 500.f, 0.f, 320.f, 0.f, 510.f, 240.f, 0.f, 0.f, 1.f;
+  Mat3f Kp = toHipK(K);
+  e += std::fabs(Kp.fx() - 500.f) + std::fabs(Kp.cy() - 240.f);
+  // the adapter's settings mirror DenseDepthTrackerSettings field for field (util/settings.h:355-402)
+  lsd_slam::DenseDepthTrackerSettings refSettings;
+  lsd_slam_hip::DenseDepthTrackerSettings mine;
+  e += std::fabs(refSettings.lambdaSuccessFac - mine.lambdaSuccessFac) + std::fabs(refSettings.lambdaFailFac - mine.lambdaFailFac);
+  for (int l = 0; l < 5; l++)
+    e += std::fabs(refSettings.lambdaInitial[l] - mine.lambdaInitial[l]) + std::fabs(refSettings.stepSizeMin[l] - mine.stepSizeMin[l]) +
+         std::fabs(refSettings.convergenceEps[l] - mine.convergenceEps[l]) + std::abs(refSettings.maxItsPerLvl[l] - mine.maxItsPerLvl[l]);
+  e += std::fabs(refSettings.huber_d - mine.huber_d) + std::fabs(refSettings.var_weight - mine.var_weight) +
+       std::fabs(refSettings.stepSizeMinTestTrack - mine.stepSizeMinTestTrack) + std::fabs(refSettings.convergenceEpsTestTrack - mine.convergenceEpsTestTrack) +
+       std::fabs(refSettings.maxItsTestTrack - mine.maxItsTestTrack) + std::fabs(refSettings.lambdaInitialTestTrack - mine.lambdaInitialTestTrack);
+  std::printf("err %.3e\n", e);
+  return e < 1e-9 ? 0 : 1;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=gnu++17", "-w", "-I", os.path.join(ROOT, "oracle", "ref", "shim"), "-I", refsrc, "-I", os.path.join(ROOT, "include"),
+                           str(src), refsrc + "/util/settings.cpp", refsrc + "/util/SophusUtil.cpp", "-o", str(exe), "-L" + os.path.join(ROOT, "lsd_slam_amd"), "-llsdhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "lsd_slam_amd")])
+    subprocess.check_call([str(exe)])

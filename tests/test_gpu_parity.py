@@ -795,3 +795,41 @@ def test_persistent_kernel_matches_launch_per_evaluation(oracle, hip, strips):
     bad = oracle.se3_exp(np.array([5.0, 0, 0, 0, 0, 0]))
     est = tr_b.trackFrame(ref, hip.Frame(ctx, 9, frames[1]), bad)
     assert tr_b.diverged and not tr_b.trackingWasGood and np.array_equal(est, IDENT7)
+
+
+@pytest.mark.gpu
+def test_tracker_settings_block_reaches_the_device(oracle, hip):
+    """lsdhip_tracker_set_settings: every DenseDepthTrackerSettings field (C/util/settings.h:355-402).  Defaults equal the
+    reference's; changed fields change the run the way they change the oracle's."""
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4)
+    kfo, kfg = oracle.Frame(0, frames[0], K), hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    ro, rg = oracle.TrackingReference(), hip.TrackingReference()
+    ro.import_frame(kfo)
+    rg.importFrame(kfg)
+    trg = hip.SE3Tracker(ctx)
+    st = trg.settings()
+    assert (st.lambdaSuccessFac, st.lambdaFailFac, st.huber_d, st.var_weight) == (0.5, 2.0, 3.0, 1.0)
+    assert list(st.maxItsPerLvl) == [5, 20, 50, 100, 100] and list(st.convergenceEps) == [pytest.approx(0.999)] * 5
+    assert (st.stepSizeMinTestTrack, st.convergenceEpsTestTrack, st.maxItsTestTrack) == (pytest.approx(1e-3), pytest.approx(0.98), 5.0)
+    # one iteration per level, Huber threshold 1: fewer evaluations, another (but oracle-consistent) pose
+    for l in range(5):
+        st.maxItsPerLvl[l] = 1
+    st.huber_d = 1.0
+    trg.set_settings(st)
+    tro = oracle.SE3Tracker(w, h, K, mode=oracle.SSE)
+    tro.set_max_its([1, 1, 1, 1, 1])
+    L = oracle.lib()
+    import ctypes
+    if hasattr(L, "orc_tracker_set_huber"):
+        L.orc_tracker_set_huber.argtypes = [ctypes.c_void_p, ctypes.c_float]
+        L.orc_tracker_set_huber(tro.h_, 1.0)
+    est = trg.trackFrame(rg, hip.Frame(ctx, 2, frames[2]), IDENT7)
+    assert trg.last.numEvaluations <= 8
+    if hasattr(L, "orc_tracker_set_huber"):
+        r = tro.track(ro, oracle.Frame(2, frames[2], K), IDENT7)
+        dt, dr = pose_distance(est, np.array(r.frameToRef), oracle)
+        assert max(dt, dr) < 5e-4, (dt, dr)
+        assert r.numEvaluations == trg.last.numEvaluations
