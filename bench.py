@@ -235,6 +235,18 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # ONE JSON line on stdout: everything the libraries print meanwhile (RCCL's version banner goes to stdout) is sent to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(line)
+        sys.stdout.flush()
+        os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -253,9 +265,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             assert int(t.item()) == world
         if rank == 0:
-            print(json.dumps({"metric": "tracked frames/sec (full track+map loop) at %dx%d" % (args.width, args.height), "value": None,
-                              "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                              "scaling": "weak"}))
+            emit(json.dumps({"metric": "tracked frames/sec (full track+map loop) at %dx%d" % (args.width, args.height), "value": None,
+                             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                             "scaling": "weak"}))
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -265,6 +277,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # LSD_FORCE_DIST=1 without a launcher
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import lsd_slam_amd as la
@@ -301,7 +317,31 @@ def main():
     RING = 32
     ring = torch.empty((RING, 2, h, w), dtype=torch.float32, device=torch.device("cuda", local_rank))
     loop.set_keyframe_ring(ring.data_ptr(), RING)
-    recv = [torch.empty_like(ring) for _ in range(world)] if (distributed and rank == 0) else None
+    # The gather itself is issued by the C++ loop: RCCL send/recv on the loop's own stream, no host synchronisation
+    # (lsdloop_gather_keyframes).  torch.distributed only carries the rendezvous (the 128-byte ncclUniqueId), the barriers and the
+    # max-over-ranks of the timing.  LSD_GATHER=torch (or a failed communicator) falls back to a torch.distributed gather.
+    gather_impl = "none"
+    recv = None
+    recv_all = None
+    if distributed:
+        gather_impl = "torch.distributed"
+        if os.environ.get("LSD_GATHER", "rccl") != "torch":
+            try:
+                uid = [DriverLoop.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                loop.comm_init(uid[0], rank, world)
+                gather_impl = "rccl (C++ loop, ncclSend/ncclRecv on the loop's stream)"
+            except Exception as e:   # keep the run alive on the fallback
+                sys.stderr.write("RCCL gather in the C++ loop unavailable (%s): falling back to torch.distributed\n" % e)
+                gather_impl = "torch.distributed"
+        ok = torch.tensor([1 if gather_impl.startswith("rccl") else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # all ranks or none
+        if int(ok.item()) == 0:
+            gather_impl = "torch.distributed"
+        if gather_impl.startswith("rccl"):
+            recv_all = torch.empty((world,) + tuple(ring.shape), dtype=torch.float32, device=ring.device) if rank == 0 else None
+        else:
+            recv = [torch.empty_like(ring) for _ in range(world)] if rank == 0 else None
     state = {"fi": 0, "exported": 0, "gathered_bytes": 0, "poses": []}
 
     def run_frames(n):
@@ -317,7 +357,10 @@ def main():
             left -= done
             new = loop.keyframes_exported()
             state["exported"] += new
-            if distributed:
+            if distributed and gather_impl.startswith("rccl"):
+                loop.gather_keyframes(new, 0, recv_all.data_ptr() if rank == 0 else None, ring.numel())
+                state["gathered_bytes"] += new * ring[0].numel() * 4
+            elif distributed:
                 state["gathered_bytes"] += gather_keyframe_ring(ring, new, recv)
 
     run_frames(args.warmup)
@@ -375,7 +418,8 @@ def main():
             "config": {"workload": "%dx%d 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
                                    "(BASELINE.json configs[%d]); synthetic scene %s, GT-depth init, new keyframe every %d frames"
                                    % (w, h, 1 if (w, h) == (640, 480) else 2, args.scene, KF_EVERY),
-                       "width": w, "height": h, "parallelism": "1 sequence per GPU; finished keyframes' depth planes exported to a device ring and gathered to rank 0 (RCCL) once per batch"},
+                       "width": w, "height": h, "parallelism": "1 sequence per GPU; finished keyframes' depth planes exported to a device ring and gathered to rank 0 once per batch",
+                       "gather": gather_impl},
             "track_fps": st.frames / st.seconds_track if st.seconds_track > 0 else None,
             "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,
             "keyframe_ms": st.seconds_keyframe / st.keyframes * 1e3 if st.keyframes > 0 else None,
@@ -431,9 +475,10 @@ def main():
                 out["cpu_baseline_port"] = port
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(json.dumps(out))
     if distributed:
+        if gather_impl.startswith("rccl"):
+            loop.comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
 

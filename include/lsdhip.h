@@ -18,6 +18,7 @@
 #ifndef LSDHIP_H
 #define LSDHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -275,6 +276,8 @@ int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame** refs, int 
 /* smoothed idepth / variance planes of the active keyframe (what setDepth produced), device to device —
  * the payload the multi-GPU gather collects per keyframe. */
 int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* idepthVar_dev);
+/* device-to-device copy ordered on the context's stream (no host synchronisation): the root's own share of a keyframe gather */
+int lsdhip_ctx_copy_dev(lsdhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 /* (returns after the copies have finished; on an asynchronous context — lsdhip_ctx_set_async — after they are queued) */
 /* rows [row0, row0+nrows) of the eight hypothesis planes <-> one packed device buffer (29 bytes per pixel, plane after
  * plane in the order of lsdhip_hypothesis): halo exchange of the row-band decomposition.

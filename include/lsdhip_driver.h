@@ -50,6 +50,18 @@ int lsdloop_set_live_queue(lsdloop* l, int frames);
 int lsdloop_set_persistent(lsdloop* l, int max_strips);
 /* lsdhip_depth_observe_time of the loop's depth map */
 int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out);
+/* ---- RCCL over xGMI, issued from the C++ loop on its own stream (BASELINE.json configs[3]: independent sequences, one per GPU,
+ * results collected on rank 0).  The library binds the ncclXxx entry points of the RCCL already loaded into the process (the one
+ * torch.distributed uses) or of librccl.so, by name.  Rendezvous: rank 0 calls lsdloop_comm_unique_id and hands the 128 bytes to
+ * the other ranks by any means (bench.py: torch.distributed object broadcast); every rank then calls lsdloop_comm_init.
+ * lsdloop_gather_keyframes enqueues, on the loop's stream and without any host synchronisation, the collection of the first
+ * `count` ring slots (lsdloop_set_keyframe_ring) of every rank into recv_dev on rank `root`: recv_dev holds world x stride_floats
+ * floats, rank r's slots land at recv_dev + r * stride_floats (ncclGroupStart; ncclSend / ncclRecv per peer; ncclGroupEnd; the
+ * root's own slots are a device copy).  All ranks pass the same count.  Returns 0, or a negative status (lsdloop_last_error). */
+int lsdloop_comm_unique_id(unsigned char out128[128]);
+int lsdloop_comm_init(lsdloop* l, const unsigned char id128[128], int rank, int world);
+int lsdloop_comm_destroy(lsdloop* l);
+int lsdloop_gather_keyframes(lsdloop* l, int count, int root, float* recv_dev, long long stride_floats);
 void* lsdloop_ctx(lsdloop* l);   /* the lsdhip_ctx* the loop runs on (prof hooks, stream) */
 const char* lsdloop_last_error(void);
 #ifdef __cplusplus

@@ -133,6 +133,7 @@ def _signatures():
         "lsdhip_depth_copy_planes_dev": (i, [vp, vp, vp]),
         "lsdhip_depth_copy_rows_dev": (i, [vp, i, i, vp, i]),
         "lsdhip_depth_timings": (i, [vp, vp]),
+        "lsdhip_ctx_copy_dev": (i, [vp, vp, vp, C.c_size_t]),
         "lsdhip_depth_gpu_times": (i, [vp, vp, vp]),
         "lsdhip_depth_observe_time": (i, [vp, vp, vp]),
         "lsdhip_prof_enable": (i, [vp, i]),

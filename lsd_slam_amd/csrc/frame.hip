@@ -410,6 +410,13 @@ extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
 }
+extern "C" int lsdhip_ctx_copy_dev(lsdhip_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || !dst || !src) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_ctx_set_async(lsdhip_ctx* c, int on) {
   if (!c) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);

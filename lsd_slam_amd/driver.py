@@ -20,7 +20,8 @@ class LoopStats(C.Structure):
 
 EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop_get_stats", "lsdloop_reset_stats",
                     "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
-                    "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_persistent", "lsdloop_observe_time"]
+                    "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_persistent", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
+                    "lsdloop_gather_keyframes"]
 
 
 def lib():
@@ -57,6 +58,14 @@ def lib():
         L.lsdloop_set_persistent.argtypes = [vp, i]
         L.lsdloop_observe_time.restype = i
         L.lsdloop_observe_time.argtypes = [vp, vp, vp]
+        L.lsdloop_comm_unique_id.restype = i
+        L.lsdloop_comm_unique_id.argtypes = [vp]
+        L.lsdloop_comm_init.restype = i
+        L.lsdloop_comm_init.argtypes = [vp, vp, i, i]
+        L.lsdloop_comm_destroy.restype = i
+        L.lsdloop_comm_destroy.argtypes = [vp]
+        L.lsdloop_gather_keyframes.restype = i
+        L.lsdloop_gather_keyframes.argtypes = [vp, i, i, vp, C.c_longlong]
         L.lsdloop_ctx.restype = vp
         L.lsdloop_ctx.argtypes = [vp]
         L.lsdloop_last_error.restype = C.c_char_p
@@ -138,6 +147,24 @@ class DriverLoop:
         ms, n = C.c_double(), C.c_longlong()
         _check(self.L.lsdloop_observe_time(self.h_, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId (call on one rank, hand to the others)"""
+        buf = (C.c_ubyte * 128)()
+        _check(lib().lsdloop_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        _check(self.L.lsdloop_comm_init(self.h_, buf, rank, world))
+
+    def comm_destroy(self):
+        _check(self.L.lsdloop_comm_destroy(self.h_))
+
+    def gather_keyframes(self, count, root, recv_ptr, stride_floats):
+        """RCCL send/recv of the first `count` ring slots to `root`, enqueued on the loop's stream (no host synchronisation)"""
+        _check(self.L.lsdloop_gather_keyframes(self.h_, int(count), int(root), C.c_void_p(recv_ptr) if recv_ptr else None, int(stride_floats)))
 
     def keyframes_exported(self):
         return int(self.L.lsdloop_keyframes_exported(self.h_))

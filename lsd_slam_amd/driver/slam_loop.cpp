@@ -2,6 +2,8 @@
 // Plain host C++ (g++): everything that touches pixels is a liblsdhip.so call.
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
 #include <string>
 
 #include "../../include/lsd_slam_hip.hpp"
@@ -10,6 +12,7 @@
 using namespace lsd_slam_hip;
 
 static thread_local std::string g_err;
+typedef void* NcclComm;   // ncclComm_t (rccl.h), opaque
 
 struct lsdloop {
   std::unique_ptr<SlamLoop> loop;
@@ -20,7 +23,50 @@ struct lsdloop {
   float* ring = nullptr;                 // lsdloop_set_keyframe_ring
   int ring_slots = 0;
   long long ring_count = 0;
+  NcclComm comm = nullptr;               // lsdloop_comm_init
+  int comm_rank = 0, comm_world = 1;
 };
+
+// ---- RCCL, bound by name (prototypes: /opt/rocm/include/rccl/rccl.h:43,187,220,260,339 and the ncclSend / ncclRecv /
+// ncclGroupStart / ncclGroupEnd declarations there; ncclFloat = 7, ncclSuccess = 0) -------------------------------------------
+namespace {
+struct NcclId { char internal[128]; };
+struct Rccl {
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, NcclComm, void*) = nullptr;
+  int (*Recv)(void*, size_t, int, int, NcclComm, void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  void* h = RTLD_DEFAULT;                       // the RCCL torch.distributed already loaded, if any
+  if (!dlsym(h, "ncclCommInitRank")) {
+    h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { r.why = "no RCCL in the process and librccl.so not found"; return r; }
+  }
+  auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) r.why = std::string("RCCL symbol missing: ") + n; return p; };
+  r.GetUniqueId = (int (*)(NcclId*))sym("ncclGetUniqueId");
+  r.CommInitRank = (int (*)(NcclComm*, int, NcclId, int))sym("ncclCommInitRank");
+  r.CommDestroy = (int (*)(NcclComm))sym("ncclCommDestroy");
+  r.GroupStart = (int (*)())sym("ncclGroupStart");
+  r.GroupEnd = (int (*)())sym("ncclGroupEnd");
+  r.Send = (int (*)(const void*, size_t, int, int, NcclComm, void*))sym("ncclSend");
+  r.Recv = (int (*)(void*, size_t, int, int, NcclComm, void*))sym("ncclRecv");
+  r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+  return r;
+}
+}  // namespace
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -46,7 +92,10 @@ extern "C" int lsdloop_create(int device, int w, int h, const float K4[4], const
     return LSDHIP_E_STATE;
   }
 }
-extern "C" void lsdloop_destroy(lsdloop* l) { delete l; }
+extern "C" void lsdloop_destroy(lsdloop* l) {
+  if (l && l->comm) { rccl().CommDestroy(l->comm); l->comm = nullptr; }
+  delete l;
+}
 
 extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int stop_at_keyframe, double* out7) {
   if (!l || !images || n < 0) return LSDHIP_E_ARG;
@@ -157,6 +206,62 @@ extern "C" int lsdloop_set_persistent(lsdloop* l, int max_strips) {
 extern "C" int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out) {
   if (!l) return LSDHIP_E_ARG;
   return lsdhip_depth_observe_time(l->loop->map.handle(), ms_out, calls_out);
+}
+extern "C" int lsdloop_comm_unique_id(unsigned char out128[128]) {
+  Rccl& R = rccl();
+  if (!R.ok) { g_err = "RCCL unavailable: " + R.why; return LSDHIP_E_STATE; }
+  NcclId id;
+  const int rc = R.GetUniqueId(&id);
+  if (rc != 0) { g_err = std::string("ncclGetUniqueId: ") + (R.GetErrorString ? R.GetErrorString(rc) : "?"); return LSDHIP_E_HIP; }
+  std::memcpy(out128, id.internal, 128);
+  return LSDHIP_OK;
+}
+extern "C" int lsdloop_comm_init(lsdloop* l, const unsigned char id128[128], int rank, int world) {
+  if (!l || !id128 || rank < 0 || rank >= world) return LSDHIP_E_ARG;
+  Rccl& R = rccl();
+  if (!R.ok) { g_err = "RCCL unavailable: " + R.why; return LSDHIP_E_STATE; }
+  if (l->comm) { R.CommDestroy(l->comm); l->comm = nullptr; }
+  NcclId id;
+  std::memcpy(id.internal, id128, 128);
+  const int rc = R.CommInitRank(&l->comm, world, id, rank);
+  if (rc != 0) { l->comm = nullptr; g_err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(rc) : "?"); return LSDHIP_E_HIP; }
+  l->comm_rank = rank;
+  l->comm_world = world;
+  return LSDHIP_OK;
+}
+extern "C" int lsdloop_comm_destroy(lsdloop* l) {
+  if (!l) return LSDHIP_E_ARG;
+  if (l->comm) { rccl().CommDestroy(l->comm); l->comm = nullptr; }
+  return LSDHIP_OK;
+}
+extern "C" int lsdloop_gather_keyframes(lsdloop* l, int count, int root, float* recv_dev, long long stride_floats) {
+  if (!l || count < 0 || !l->ring) return LSDHIP_E_ARG;
+  if (count == 0) return LSDHIP_OK;
+  if (count > l->ring_slots) { g_err = "gather: more keyframes than ring slots"; return LSDHIP_E_ARG; }
+  const size_t n = (size_t)count * 2 * (size_t)l->ctx->width() * l->ctx->height();   // floats per rank
+  void* stream = lsdhip_ctx_stream(l->ctx->handle());
+  try {
+    if (l->comm_world == 1 || !l->comm) {
+      if (l->comm_world != 1) { g_err = "gather: no communicator (lsdloop_comm_init)"; return LSDHIP_E_STATE; }
+      if (recv_dev) check(lsdhip_ctx_copy_dev(l->ctx->handle(), recv_dev, l->ring, n * sizeof(float)), "lsdhip_ctx_copy_dev");
+      return LSDHIP_OK;
+    }
+    Rccl& R = rccl();
+    auto nc = [&](int rc, const char* what) { if (rc != 0) throw Error(LSDHIP_E_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(rc) : "?")); };
+    if (l->comm_rank == root) {
+      if (!recv_dev) return LSDHIP_E_ARG;
+      check(lsdhip_ctx_copy_dev(l->ctx->handle(), recv_dev + (size_t)root * stride_floats, l->ring, n * sizeof(float)), "lsdhip_ctx_copy_dev");
+      nc(R.GroupStart(), "ncclGroupStart");
+      for (int r = 0; r < l->comm_world; r++)
+        if (r != root) nc(R.Recv(recv_dev + (size_t)r * stride_floats, n, 7 /* ncclFloat */, r, l->comm, stream), "ncclRecv");
+      nc(R.GroupEnd(), "ncclGroupEnd");
+    } else {
+      nc(R.GroupStart(), "ncclGroupStart");
+      nc(R.Send(l->ring, n, 7 /* ncclFloat */, root, l->comm, stream), "ncclSend");
+      nc(R.GroupEnd(), "ncclGroupEnd");
+    }
+    return LSDHIP_OK;
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
 }
 extern "C" long long lsdloop_keyframes_exported(lsdloop* l) { return l ? l->ring_count : -1; }
 extern "C" void* lsdloop_ctx(lsdloop* l) { return l ? (void*)l->ctx->handle() : nullptr; }

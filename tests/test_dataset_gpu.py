@@ -68,3 +68,30 @@ def test_dataset_slam_on_pgm_sequence(tmp_path):
     assert np.all(c2[:, 22] == 0) and np.all(c2[:, 18] > 0)
     assert np.allclose(c2[:, 17], c2[:, 9], rtol=5e-2)                    # estimated scale ~ the rescale it started from
     assert np.all(np.linalg.norm(c2[:, 14:17] - c2[:, 6:9], axis=1) < 2e-2)
+
+
+@pytest.mark.gpu
+def test_cpp_loop_rccl_gather_single_rank():
+    """lsdloop_comm_* / lsdloop_gather_keyframes: RCCL bound by name inside the C++ driver.  One rank is all a 1-GPU box offers: the
+    communicator is created from an ncclUniqueId, the gather runs on the loop's stream without a host synchronisation, and rank 0
+    receives its own ring slots."""
+    import torch
+    from common import sequence
+    from lsd_slam_amd.driver import DriverLoop
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 26)
+    imgs = [np.ascontiguousarray(f) for f in frames]
+    drv = DriverLoop(w, h, K, imgs[0].ctypes.data, depth0, kf_every=10, images_on_device=False)
+    ring = torch.zeros((4, 2, h, w), dtype=torch.float32, device="cuda")
+    recv = torch.full((1, 4, 2, h, w), -7.0, dtype=torch.float32, device="cuda")
+    drv.set_keyframe_ring(ring.data_ptr(), 4)
+    uid = DriverLoop.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    drv.comm_init(uid, 0, 1)
+    done, _ = drv.run([imgs[i].ctypes.data for i in range(1, 26)])
+    assert done == 25 and drv.keyframes_exported() == 2
+    drv.gather_keyframes(2, 0, recv.data_ptr(), ring.numel())
+    torch.cuda.synchronize()
+    assert torch.equal(recv[0, :2], ring[:2]) and float(ring[:2].abs().sum()) > 0
+    assert float(recv[0, 2:].min()) == -7.0          # untouched beyond `count`
+    drv.comm_destroy()
