@@ -290,6 +290,8 @@ struct lsdhip_depthmap {
   double gpu_ms[4] = {0, 0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame, k_observe alone (sampled while profiling)
   long long gpu_calls[4] = {0, 0, 0, 0};
   unsigned obs_tick = 0;
+  int* d_qcount = nullptr;         // [2][OBS_NQ] walk-queue counters
+  int obs_parity = 0;              // which of the two walk-queue counters the next observe call uses
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
         msSetDepth = 0;
 };

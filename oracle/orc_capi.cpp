@@ -330,3 +330,9 @@ extern "C" void orc_depth_line_stereo(void* d, void* ref, int x, int y, float mi
   out[3] = dm->doLineStereo((float)x, (float)y, epx, epy, min_idepth, prior_idepth, max_idepth, rf, rf->image(0), ri, rv, rl);
   out[4] = ri; out[5] = rv; out[6] = rl;
 }
+
+namespace orc { extern long long orc_walk_hist[64]; }
+// instrumentation: histogram of epipolar-walk lengths (steps) since the last call with reset != 0
+extern "C" void orc_walk_histogram(long long out[64], int reset) {
+  for (int i = 0; i < 64; i++) { out[i] = orc::orc_walk_hist[i]; if (reset) orc::orc_walk_hist[i] = 0; }
+}

@@ -12,6 +12,7 @@
 #include "lsd_oracle.hpp"
 
 namespace orc {
+long long orc_walk_hist[64] = {0};
 
 // ---- C/util/settings.h:34-35, :50-174 ---------------------------------------------------------
 #define DIVISION_EPS 1e-10f
@@ -758,6 +759,7 @@ float DepthMap::doLineStereo(const float u, const float v, const float epxn, con
     loopCounter++;
   }
 
+  orc_walk_hist[loopCounter < 63 ? loopCounter : 63]++;   // instrumentation (tools: walk-length distribution)
   if (best_match_err > 4.0f * (float)MAX_ERROR_STEREO) return -3;
   if (abs(loopCBest - loopCSecond) > 1.0f && MIN_DISTANCE_ERROR_STEREO * best_match_err > second_best_match_err) return -2;
 

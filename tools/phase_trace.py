@@ -21,6 +21,7 @@ loop = la.SlamLoop(ctx, d_frames[0].data_ptr(), depth0, kf_every=10, device_fram
 for i in range(1, 40):
     loop.step(d_frames[i % 50].data_ptr(), time.perf_counter)
 ctx.synchronize()
+loop.map.close()      # the observe trace (LSDHIP_OBS_TRACE_FILE) is written when the depth map goes away
 loop.tracker.close()
 path = os.environ.get("LSDHIP_TRACE_FILE")
 if path and os.path.exists(path):
