@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--live-queue", type=int, default=1,
                     help="frames handed to updateKeyframe per mapping iteration (1 = blockUntilMapped as BASELINE configs[1]; K > 1 "
                          "restates live operation, C/SlamSystem.cpp:559-571)")
+    ap.add_argument("--trials", type=int, default=-1, help="LM retries evaluated per k_track_step launch (lsdhip_tracker_set_speculation); -1 = library default")
+    ap.add_argument("--trial-cap", type=int, default=0, help="workgroups per trial at the finest level (0 = library default)")
     ap.add_argument("--persistent", type=int, default=0, help="lsdhip_tracker_set_persistent(max strips); 0 = launch per evaluation")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra host-image (PCIe-inclusive) measurement")
     ap.add_argument("--dry-run", action="store_true",
@@ -304,6 +306,8 @@ def main():
     loop = DriverLoop(w, h, K, ptr(0), depth0, kf_every=KF_EVERY, images_on_device=True, device=local_rank)
     if args.persistent > 0:
         loop.set_persistent(args.persistent)
+    if args.trials > 0:
+        loop.set_speculation(args.trials, args.trial_cap)
     if args.live_queue > 1:
         loop.set_live_queue(args.live_queue)
     loop.keep_keyframes(True)          # validation: the rescale factor of every keyframe, read back after the timed region
@@ -424,6 +428,7 @@ def main():
             "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,
             "keyframe_ms": st.seconds_keyframe / st.keyframes * 1e3 if st.keyframes > 0 else None,
             "lm_evaluations_per_frame": st.evaluations / max(1, st.frames),
+            "track_launches_per_frame": st.track_launches / max(1, st.frames),
             "lm_evaluations_per_frame_by_level": {"L%d" % l: st.level_evaluations[l] / max(1, st.frames) for l in (4, 3, 2, 1)},
             # self-validation: a loop that diverged or drifted shows here, not only in frames/s
             "validation": {"frames": int(st.frames), "tracked_good": int(st.tracked_good), "keyframes": int(st.keyframes),
@@ -457,6 +462,8 @@ def main():
                 loop2 = DriverLoop(w, h, K, hptr(0), depth0, kf_every=KF_EVERY, images_on_device=False, device=local_rank)
                 if args.persistent > 0:
                     loop2.set_persistent(args.persistent)
+                if args.trials > 0:
+                    loop2.set_speculation(args.trials, args.trial_cap)
                 n2 = min(args.steps, 200)
                 loop2.run([hptr(1 + k) for k in range(args.warmup)])
                 capi.check(L.lsdhip_ctx_synchronize(ctx_h))

@@ -307,6 +307,8 @@ class SE3Tracker {
   bool diverged = false, trackingWasGood = false;
   int numEvaluations = 0, numWarpUpdates = 0;  // instrumentation (residual-kernel launches, LM outer iterations)
   int levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};   // evaluations of the last trackFrame per pyramid level
+  int numLaunches = 0;                         // evaluating launches of the last job (< numEvaluations: retries share launches)
+  void setSpeculation(int trials, int finestLevelWorkgroups = 0) { check(lsdhip_tracker_set_speculation(h_, trials, finestLevelWorkgroups), "lsdhip_tracker_set_speculation"); }
   // execution strategy on the device (lsdhip_tracker_set_persistent): 0 = one launch per evaluation
   void setPersistent(int maxStrips) { check(lsdhip_tracker_set_persistent(h_, maxStrips), "lsdhip_tracker_set_persistent"); }
 
@@ -330,6 +332,8 @@ class SE3Tracker {
     numEvaluations = r.numEvaluations; numWarpUpdates = r.numWarpUpdates;
     int st[8];
     if (lsdhip_tracker_exec_stats(h_, st) == 0) for (int l = 0; l < LSDHIP_PYRAMID_LEVELS; l++) levelEvaluations[l] = st[3 + l];
+    int ls[2];
+    if (lsdhip_tracker_launch_stats(h_, ls) == 0) numLaunches = ls[0];
   }
   static void hookTrampoline(void* self) {
     SE3Tracker* t = static_cast<SE3Tracker*>(self);
@@ -522,6 +526,7 @@ class SlamLoop {
     SE3 est = tracker.trackFrame(&reference, frame.get(), lastFrameToKF_);
     pendingNext_ = nullptr;
     evaluations += tracker.numEvaluations;
+    launches += tracker.numLaunches;
     for (int l = 0; l < LSDHIP_PYRAMID_LEVELS; l++) levelEvaluations[l] += tracker.levelEvaluations[l];
     if (tracker.trackingWasGood) numTrackedGood++;
     numTracked++;
@@ -569,7 +574,7 @@ class SlamLoop {
   TrackingReference reference;
   std::shared_ptr<Frame> keyframe;
   bool newKeyframe = false;
-  long evaluations = 0, numTracked = 0, numUpdates = 0, numTrackedGood = 0;
+  long evaluations = 0, launches = 0, numTracked = 0, numUpdates = 0, numTrackedGood = 0;
   long levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};
   double lastTrackEnd = 0;
   int liveQueueLength = 1;                           // frames handed to updateKeyframe per mapping iteration

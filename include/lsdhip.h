@@ -163,6 +163,14 @@ int lsdhip_tracker_set_persistent(lsdhip_tracker* t, int maxStrips);
  * that were rerun launch-per-evaluation, out[2] = 1 if the persistent kernel has been switched off, out[3] = evaluations of
  * the last job per pyramid level 0..4 follow in out[3..7]. */
 int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
+/* Execution strategy of the launch-per-evaluation chain: the LM loop's "increase lambda and retry" sequence
+ * (C/Tracking/SE3Tracker.cpp:341-447) depends only on A, b and lambda, so a launch evaluates the next `trials` (1..6, default 5)
+ * retries side by side and the following launch consumes them in the reference's order — same decisions, same evaluation
+ * counts, fewer dependent launches.  trials = 1: one evaluation per launch.  finestLevelWorkgroups: workgroups per trial at the
+ * finest level while trials > 1 (0 = default, half the single-trial grid). */
+int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups);
+/* out[0] = k_track_step launches of the last job that evaluated (<= its numEvaluations), out[1] = trials per launch. */
+int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
 /* Diagnostics: shader cycles workgroup 0 of the persistent kernel spent in each phase of the last job (0 level entry, 1 warp +
  * texel issue, 2 workgroup top-3, 3 residual arithmetic, 4 reduction + publish, 5 all-gather, 6 totals + tail, 7 LM step). */
 int lsdhip_tracker_phase_cycles(const lsdhip_tracker* t, unsigned long long out[10]);

@@ -19,6 +19,7 @@ typedef struct lsdloop_stats {
   long long evaluations;     /* residual evaluations (k_track_step launches that did work) */
   long long tracked_good;    /* frames whose trackFrame ended with trackingWasGood (C/Tracking/SE3Tracker.cpp:472-477) */
   long long level_evaluations[5];   /* residual evaluations per pyramid level 0..4 */
+  long long track_launches;  /* k_track_step launches that evaluated (several LM retries share one launch) */
 } lsdloop_stats;
 /* K4 = fx, fy, cx, cy.  first_image / images: uint8 w*h, host memory or (images_on_device != 0) memory of `device`. */
 int lsdloop_create(int device, int w, int h, const float K4[4], const uint8_t* first_image, int images_on_device,
@@ -48,6 +49,8 @@ int lsdloop_keyframe_log(lsdloop* l, double* scales_out, long long* points_out, 
 int lsdloop_set_live_queue(lsdloop* l, int frames);
 /* trackFrame execution strategy on the device (lsdhip_tracker_set_persistent) */
 int lsdloop_set_persistent(lsdloop* l, int max_strips);
+/* LM retries evaluated per k_track_step launch (lsdhip_tracker_set_speculation); default 5, 1 = one evaluation per launch. */
+int lsdloop_set_speculation(lsdloop* l, int trials, int finest_level_workgroups);
 /* lsdhip_depth_observe_time of the loop's depth map */
 int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out);
 /* ---- RCCL over xGMI, issued from the C++ loop on its own stream (BASELINE.json configs[3]: independent sequences, one per GPU,

@@ -98,6 +98,8 @@ def _signatures():
         "lsdhip_tracker_set_settings": (i, [vp, C.POINTER(TrackerSettings)]),
         "lsdhip_tracker_set_persistent": (i, [vp, i]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
+        "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
+        "lsdhip_tracker_launch_stats": (i, [vp, vp]),
         "lsdhip_tracker_phase_cycles": (i, [vp, vp]),
         "lsdhip_tracker_set_enqueue_hook": (i, [vp, vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),

@@ -253,7 +253,7 @@ LSD_HD void stereo_walk_serial(const float* __restrict__ refImg, const int width
   float val_cp_p1 = interp1(refImg, cpx + incx, cpy + incy, width);
   float val_cp_p2;
 
-  OBS_MARK(4);
+
   int loopCounter = 0;
   float best_match_x = -1;
   float best_match_y = -1;
@@ -321,8 +321,8 @@ LSD_HD void stereo_walk_serial(const float* __restrict__ refImg, const int width
     cpy += incy;
     loopCounter++;
   }
-  OBS_MARK(5);
-  OBS_VAL(8, loopCounter);
+
+
   W.best_match_err = best_match_err; W.second_best_match_err = second_best_match_err;
   W.best_match_errPre = best_match_errPre; W.best_match_errPost = best_match_errPost;
   W.best_match_DiffErrPre = best_match_DiffErrPre; W.best_match_DiffErrPost = best_match_DiffErrPost;

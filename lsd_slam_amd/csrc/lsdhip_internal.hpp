@@ -81,8 +81,19 @@ struct TrackJob {
   int evalOnly;              // 1: a step only finalises the sums of one evaluation (kernel-level parity hook / host LM)
   int trackFrameSemantics;   // lastResidual bookkeeping of trackFrame (1) vs trackFrameOnPermaref (0)
 };
+// Reject-chain speculation (k_track_step, single jobs): a launch evaluates the next trials of the LM loop's "increase lambda
+// and retry" chain (SE3Tracker.cpp:341-447) side by side — they depend only on A, b and lambda, not on each other's
+// residuals — and the next launch consumes them in the reference's order.
+struct TrackSpec {
+  int specC;                 // <= 1: one evaluation per launch
+  int specGrid;              // workgroups per trial (grid = specGrid x most trials of any level)
+  int trials[LSD_LEVELS];    // trials per launch at each level
+  uint8_t* wasGoodSide;      // refPixelWasGood planes of trials 1 .. (trial 0 writes the frame's own plane)
+  unsigned maskStride;
+};
 
 // Levenberg-Marquardt state of a tracking job, resident in HBM, advanced by k_lm_step.
+#define LSD_SPEC_MAX 6
 struct TrackState {
   lsdm::SE3fH T;             // last accepted referenceToFrame
   lsdm::SE3fH Tn;            // pose being evaluated
@@ -98,6 +109,9 @@ struct TrackState {
   int numEvaluations, numWarpUpdates;
   float pointUsage, goodCount, badCount, meanRes;
   int levelEvals[LSD_LEVELS];  // evaluations per pyramid level (diagnostics / bench line)
+  int ncand;                 // trials the launch that produced the pending sums evaluated (>= 1)
+  int lastCand;              // which of them was the last one the LM loop actually executed
+  int numLaunches;           // launches that did an evaluation so far
 };
 
 // What the host reads back (pinned, device-mapped): written by k_lm_step when the job finishes (or every step in
@@ -109,7 +123,8 @@ struct TrackSummary {
   float sums[RS_NUM];        // raw sums of the last evaluation (tail-drop corrected)
   double bytes;              // algorithmic bytes of all evaluations of the job
   int levelEvals[LSD_LEVELS];
-  int pad2_[3];
+  int numLaunches;           // k_track_step launches that evaluated (< numEvaluations with reject-chain speculation)
+  int pad2_[2];
   unsigned long long phase[10];   // k_track_persist: shader cycles workgroup 0 spent per phase, summed over the job's evaluations
 };
 
@@ -219,7 +234,15 @@ struct lsdhip_tracker {
   int grid_cap = 304;             // most workgroups one evaluation uses (LSDHIP_TRACK_CAP); larger levels grid-stride
   int batch_jobs = 0;             // > 1 while the jobs of a batch are being described
   int cap_override = 0;           // batch tracking: per-job workgroup cap while the jobs of a batch are being described
-  int recent[4] = {0, 0, 0, 0};   // evaluations of the last jobs: size the launch budget of the next one
+  int recent[4] = {0, 0, 0, 0};   // evaluating launches of the last jobs: size the launch budget of the next one
+  int specC = 5;                  // trials per launch (LSDHIP_SPEC; 1 = no speculation)
+  int specCaps[LSD_LEVELS] = {0, 0, 0, 0, 0};    // per-level workgroups per trial (LSDHIP_SPEC_CAPS; 0 = automatic)
+  int specLevel[LSD_LEVELS] = {0, 0, 0, 0, 0};   // per-level override (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = specC)
+  int specCap = 0;                // workgroups per trial at the finest level when speculating (0 = grid_cap / 2)
+  uint8_t* d_maskSide = nullptr;  // (SPEC_MAX - 1) mask planes of (w >> 1) x (h >> 1) bytes
+  size_t maskStride = 0;
+  int numLaunches = 0;
+  TrackSpec spec = {};             // of the job being launched
   int recentChain[4] = {0, 0, 0, 0};   // same, counting only the levels the k_track_step chain ran behind the persistent kernel
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary

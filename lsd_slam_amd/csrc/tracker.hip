@@ -462,6 +462,7 @@ __device__ __forceinline__ void write_summary(const TrackState& s, const float* 
   for (int i = 0; i < RS_NUM; i++) out->sums[i] = tot[i];
   out->bytes = s.bytes;
   for (int l = 0; l < LSD_LEVELS; l++) out->levelEvals[l] = s.levelEvals[l];
+  out->numLaunches = s.numLaunches;
   __threadfence_system();
   out->done = s.done;
 }
@@ -474,15 +475,16 @@ struct LmShared {
 // (fetched field by field from the kernel-argument segment they cost one scalar-cache round trip each).
 struct LmPar {
   float lambdaInitial, stepSizeMin, convergenceEps, minWarped, lambdaSuccessFac, lambdaFailFac;
-  int maxIts, w, h, writeMask, evalOnly, useAffine, tfSemantics, lastLevel;
+  int maxIts, w, h, writeMask, evalOnly, useAffine, tfSemantics, lastLevel, trials;
 };
-__device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmPar& p) {
+__device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmPar& p, const int trials = 1) {
   const TrackLevel& L = job.lv[level];
   LmPar v;
   v.lambdaInitial = L.lambdaInitial; v.stepSizeMin = L.stepSizeMin; v.convergenceEps = L.convergenceEps; v.minWarped = L.minWarped;
   v.lambdaSuccessFac = job.lambdaSuccessFac; v.lambdaFailFac = job.lambdaFailFac;
   v.maxIts = L.maxIts; v.w = L.w; v.h = L.h; v.writeMask = L.writeMask; v.evalOnly = job.evalOnly; v.useAffine = job.useAffine;
   v.tfSemantics = job.trackFrameSemantics; v.lastLevel = job.lastLevel;
+  v.trials = trials;
   p = v;
 }
 
@@ -497,9 +499,21 @@ __device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmP
 #else
 #define LM_MARK(k) do { } while (0)
 #endif
-__device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const float col, float* tot, const int lane,
-                                        TrackSummary* out, unsigned long long* trp) {
+// Reject-chain speculation: `consumed` = index (within the launch that produced the sums) of the trial being finished (the
+// caller has already advanced lambda / incTry / counters past the plain rejections before it), `mycand` = the trial this
+// workgroup evaluates next: `mycand` retries further down the chain that starts at the proposal made here.
+__device__ __forceinline__ float lm_lambda_fail(float LM_lambda, int incTry, float lambdaFailFac) {
+  if (LM_lambda == 0) return 0.2f;
+  double p = 1.0;
+  for (int i = 0; i < incTry; i++) p *= (double)lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
+  return (float)((double)LM_lambda * p);
+}
+template <bool SPEC = false>
+__device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const float col, float* tot, const int lane,
+                                        TrackSummary* out, unsigned long long* trp, const int consumed = 0, const int mycand = 0) {
   float* const s_gj = tot - 48;   // LmShared::gj precedes tot
+  S.lastCand = consumed;
+  S.ncand = 1;
   const LmPar L = par;
   const int maxIts = L.maxIts;
   // calcResidualAndBuffers epilogue (:1016-1028)
@@ -528,12 +542,12 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
   }
   S.pending = 0;
   LM_MARK(12);
-  if (L.evalOnly) { S.done = 1; if (out && lane == 0) write_summary(S, tot, out); return; }
+  if (L.evalOnly) { S.done = 1; if (out && lane == 0) write_summary(S, tot, out); return false; }
 
   if (M < L.minWarped) {   // :324-329 / :369-374
     S.diverged = 1; S.done = 1;
     if (out && lane == 0) write_summary(S, tot, out);
-    return;
+    return false;
   }
   // calcWeightsAndResidualSSE epilogue (:572-574)
   const float werr = rl(col, RS_WERR) / ((M >> 2) << 2);
@@ -543,7 +557,7 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
   float LM_lambda = S.LM_lambda, lastErr = S.lastErr;
   int iteration = S.iteration, incTry = S.incTry;
   lsdm::SE3fH T = S.T;
-  bool propose = false, start_iteration = false, accepted = false;
+  bool propose = false, start_iteration = false, accepted = false, rejected = false;
   if (S.phase == 0) {
     accepted = true;
     lastErr = werr;
@@ -571,13 +585,9 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
         iteration++;
         start_iteration = true;
       } else {
-        if (LM_lambda == 0) LM_lambda = 0.2;
-        else {
-          double p = 1.0;
-          for (int i = 0; i < incTry; i++) p *= (double)L.lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
-          LM_lambda = (float)((double)LM_lambda * p);
-        }
+        LM_lambda = lm_lambda_fail(LM_lambda, incTry, L.lambdaFailFac);
         propose = true;
+        rejected = true;
       }
     }
   }
@@ -602,6 +612,10 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
   S.iteration = iteration;
   LM_MARK(13);
   if (propose) {
+    // this workgroup's own trial: `mycand` retries further down the chain (each retry: incTry++, lambda as after a rejection)
+    const int extra = SPEC ? mycand : 0;
+    for (int j = 0; j < extra; j++) { incTry++; LM_lambda = lm_lambda_fail(LM_lambda, incTry, L.lambdaFailFac); }
+    S.ncand = L.trials;
     float inc[6];
     const float damp = 1 + LM_lambda;
     LM_MARK(14);
@@ -619,7 +633,7 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
     S.t[0] = Tn.t[0]; S.t[1] = Tn.t[1]; S.t[2] = Tn.t[2];
     S.phase = 1;
     LM_MARK(16);
-    return;
+    return true;
   }
   S.incTry = incTry;
   // level finished
@@ -637,6 +651,7 @@ __device__ __forceinline__ void lm_wave(const LmPar& par, TrackState& S, const f
     for (int i = 0; i < 9; i++) S.R[i] = R[i];
     S.t[0] = T.t[0]; S.t[1] = T.t[1]; S.t[2] = T.t[2];
   }
+  return false;
 }
 
 // one in-image point's contribution to the running sums (K1 statistics, K2 weighted error, K3 normal equations)
@@ -694,6 +709,8 @@ struct TrackScratch {
   int4* topkey;    // [2][max_rows]           each tile's three largest reference-order keys among in-image points (x>=y>=z)
   float* topval;   // [2][max_rows][3][32]    K2/K3 contributions of those points (single-pass levels only)
   int max_rows;    // multiple of 4
+  int cmax;        // trial slots per parity (reject-chain speculation): sums [2][cmax][RS_COLS][max_rows], topkey / topval likewise
+  float* recs;     // [2][cmax][32]  increment / pose of the trials > 0 of a launch (null when cmax == 1)
 #ifdef LSD_PHASE_TRACE
   unsigned long long* trace;   // [0] = launch counter, then 20 words per launch (developer build only, tools/phase_trace.py)
 #endif
@@ -722,7 +739,7 @@ struct TrackScratch {
 enum { TS_FUSED = 0, TS_LM = 1, TS_EVAL = 2 };
 template <int BLOCK, bool BATCH, int MODE>
 __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
-                                                TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
+                                                TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first, const TrackSpec& spec) {
   const TrackJob& job = BATCH ? jobs[blockIdx.y] : jobv;
   // The job description travels in the kernel arguments, which the host has just written: the first touch of each of its
   // cache lines misses down to HBM (~1 us), and the fields of lv[level] are addressed only once the level is known, i.e. in
@@ -757,19 +774,27 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   __shared__ float s_red[CPP * (BLOCK + 1) + 8];
   __shared__ int s_wtop[WAVES][3];
   __shared__ int s_top[3];
-  __shared__ float s_sub[3][32];
-  __shared__ int s_nsub;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int max_rows = sc.max_rows;
+  // reject-chain speculation (single jobs): workgroup = (trial `cand`, tile `bx`)
+  const int gridPer = (!BATCH && MODE == TS_FUSED && spec.specGrid > 0) ? spec.specGrid : (int)gridDim.x;
+  const int cand = (int)blockIdx.x / gridPer;
+  const int bx = (int)blockIdx.x - cand * gridPer;
+  const bool leader = blockIdx.x == 0;
+  const int cmax = sc.cmax;
   TrackState* next = st2 + (1 - parity);
   const int outp = MODE == TS_EVAL ? parity : 1 - parity;
-  const float* sums_in = sc.sums + (size_t)parity * RS_COLS * max_rows;
-  float* sums_out = sc.sums + (size_t)outp * RS_COLS * max_rows;
-  const int4* topkey_in = sc.topkey + (size_t)parity * max_rows;
-  int4* topkey_out = sc.topkey + (size_t)outp * max_rows;
-  const float* topval_in = sc.topval + (size_t)parity * max_rows * 96;
-  float* topval_out = sc.topval + (size_t)outp * max_rows * 96;
+  const float* sums_in0 = sc.sums + (size_t)parity * cmax * RS_COLS * max_rows;
+  float* sums_out = sc.sums + ((size_t)outp * cmax + cand) * RS_COLS * max_rows;
+  const int4* topkey_in0 = sc.topkey + (size_t)parity * cmax * max_rows;
+  int4* topkey_out = sc.topkey + ((size_t)outp * cmax + cand) * max_rows;
+  const float* topval_in0 = sc.topval + (size_t)parity * cmax * max_rows * 96;
+  float* topval_out = sc.topval + ((size_t)outp * cmax + cand) * max_rows * 96;
+  __shared__ float s_sumT[LSD_SPEC_MAX][NSLICE][RS_COLS];   // per pending trial: column sums by row slice
+  __shared__ float s_subT[LSD_SPEC_MAX][3][32];             // ... K2/K3 contributions of its (up to 3) tail points
+  __shared__ int s_nsubT[LSD_SPEC_MAX];
+  __shared__ float s_rec[LSD_SPEC_MAX][32];                 // ... increment [0..5], pose [6..12], R [13..21], t [22..24] (trials > 0)
 #ifdef LSD_PHASE_TRACE
   __shared__ unsigned long long* s_trp;
   unsigned long long* tr_ = sc.trace;
@@ -794,131 +819,219 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
       S.bytes = 0;
       for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
+      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
     }
     if (tid < 36) S.A[tid] = 0;
     if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
   } else {
     copy_words<sizeof(TrackState) / 4>(&S, st2 + parity, tid, BLOCK);
+    if (cmax > 1 && tid < 32 * LSD_SPEC_MAX) (&s_rec[0][0])[tid] = sc.recs[(size_t)parity * cmax * 32 + (tid < 32 * cmax ? tid : 0)];
   }
   __syncthreads();
   PHASE_MARK(1);
   if (S.done) {
-    if (MODE != TS_EVAL && blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // keep both buffers "done"
+    if (MODE != TS_EVAL && leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // keep both buffers "done"
     return;
+  }
+  if (!BATCH && MODE == TS_FUSED) {
+    // the launch is sized for the largest level and the most trials; this one evaluates at S.level (trials 0 ..) or, if the
+    // pending decision ends the level, at S.level - 1 (trial 0 only): workgroups that have no work either way leave before
+    // the finishing phase (whose loads they would only add to everybody else's)
+    const int lvl = S.level;
+    int need = job.lv[lvl].nblocks;
+    if (cand == 0 && S.pending && lvl > job.lastLevel && job.lv[lvl - 1].nblocks > need) need = job.lv[lvl - 1].nblocks;
+    const int tr = (spec.specC > 1 && spec.trials[lvl] > 1) ? spec.trials[lvl] : 1;
+    if (!leader && (bx >= need || cand >= tr || (cand > 0 && !S.pending))) return;
   }
 
   if (MODE != TS_EVAL && S.pending) {
+    // Finish the trials of the previous launch, in the order the LM loop would have run them.  All their partial sums, order
+    // keys and tail contributions are fetched TOGETHER (one memory round trip, whatever the number of trials), then wave 0 walks
+    // through them without further barriers: totals -> LM decision -> (rejected, retry waiting) next trial, whose increment
+    // and pose come from the record the workgroups that evaluated it left behind.
+    const int ncandPending = S.ncand < 1 ? 1 : (S.ncand > LSD_SPEC_MAX ? LSD_SPEC_MAX : S.ncand);
     const int level = S.level;
     const int nb = job.lv[level].nblocks;
+    const size_t trialStrideF4 = (size_t)RS_COLS * max_rows / 4;
     if (wave < SUMW) {
-      // fixed-order column sums: thread t < NSLICE * RS_END takes rows [slice R, slice R + R) of column col
+      // fixed-order column sums: thread t < NSLICE * RS_END takes rows [slice R, slice R + R) of column col, for every trial
       const int t = tid;
       const int slice = t / RS_END, col = t - slice * RS_END;
       if (slice < NSLICE) {
         const int R = (((nb + NSLICE - 1) / NSLICE) + 3) & ~3;
         const int row0 = slice * R;
-        const float4* p = (const float4*)(sums_in + (size_t)col * max_rows + (row0 < max_rows ? row0 : 0));
+        const float4* p = (const float4*)(sums_in0 + (size_t)col * max_rows + (row0 < max_rows ? row0 : 0));
         const int qlast = (max_rows - row0) / 4 - 1;   // loads stay inside the column (rows < max_rows are allocated)
-        float s = 0.f;
-        // the loads are unconditional and issued together; coarse levels (few tiles) take the short form so that they do
-        // not pay for 20 vector loads per thread when 5 cover their rows
-        auto colsum = [&](auto qn) {
-          constexpr int Q = decltype(qn)::value;
-          float4 v[Q];
+        // the loads are unconditional and issued together (trials past the last one re-read it); coarse levels (few tiles)
+        // take the short forms so that they do not pay for 20 vector loads per thread and trial when 2 or 5 cover their rows
+        auto colsum = [&](auto qn, auto ntn, const int base) {
+          constexpr int Q = decltype(qn)::value, NT = decltype(ntn)::value;
+          float4 v[NT][Q];
 #pragma unroll
-          for (int q = 0; q < Q; q++) v[q] = p[q < qlast ? q : (qlast > 0 ? qlast : 0)];
+          for (int c = 0; c < NT; c++) {
+            const int pc = base + c < ncandPending ? base + c : ncandPending - 1;
+            const float4* pp = p + (size_t)pc * trialStrideF4;
 #pragma unroll
-          for (int q = 0; q < Q; q++) {
-            const int r = row0 + 4 * q;
-            if (4 * q < R) {
-              s += (r < nb) ? v[q].x : 0.f;
-              s += (r + 1 < nb) ? v[q].y : 0.f;
-              s += (r + 2 < nb) ? v[q].z : 0.f;
-              s += (r + 3 < nb) ? v[q].w : 0.f;
+            for (int q = 0; q < Q; q++) v[c][q] = pp[q < qlast ? q : (qlast > 0 ? qlast : 0)];
+          }
+#pragma unroll
+          for (int c = 0; c < NT; c++) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+              const int r = row0 + 4 * q;
+              if (4 * q < R) {
+                s += (r < nb) ? v[c][q].x : 0.f;
+                s += (r + 1 < nb) ? v[c][q].y : 0.f;
+                s += (r + 2 < nb) ? v[c][q].z : 0.f;
+                s += (r + 3 < nb) ? v[c][q].w : 0.f;
+              }
             }
+            if (base + c < ncandPending) s_sumT[base + c][slice][col] = s;
           }
         };
-        if (R <= 8) colsum(std::integral_constant<int, 2>());
-        else if (R <= 20) colsum(std::integral_constant<int, 5>());
-        else colsum(std::integral_constant<int, QMAX>());
-        s_sum[slice][col] = s;
+        typedef std::integral_constant<int, 1> I1;
+        typedef std::integral_constant<int, 3> I3;
+        typedef std::integral_constant<int, LSD_SPEC_MAX> IM;
+        if (ncandPending == 1) {
+          if (R <= 8) colsum(std::integral_constant<int, 2>(), I1(), 0);
+          else if (R <= 20) colsum(std::integral_constant<int, 5>(), I1(), 0);
+          else if (R <= 40) colsum(std::integral_constant<int, 10>(), I1(), 0);
+          else colsum(std::integral_constant<int, QMAX>(), I1(), 0);
+        } else if (R <= 8) colsum(std::integral_constant<int, 2>(), IM(), 0);
+        else if (R <= 20) colsum(std::integral_constant<int, 5>(), IM(), 0);
+        else if (R <= 40) { for (int base = 0; base < ncandPending; base += 3) colsum(std::integral_constant<int, 10>(), I3(), base); }
+        else { for (int base = 0; base < ncandPending; base++) colsum(std::integral_constant<int, QMAX>(), I1(), base); }
 #ifdef LSD_PHASE_TRACE
         if (blockIdx.x == 0 && tid == 0) tr_[17] = clock64();
 #endif
       } else if (t == SUMW * 64 - 1) {
-        stage_lm_par(job, level, s_par);
+        stage_lm_par(job, level, s_par, (spec.specC > 1 && spec.trials[level] > 1) ? spec.trials[level] : 1);
       }
-    } else {
+    }
+    {
       // the last (M % 4) in-image points in reference order = the largest keys (x * h + y, or list index) over all
-      // tiles' top-3 lists left behind by the residual pass
-      int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
-      {
-        constexpr int KROWS = 5;   // rows per lane: max_rows <= 320
-        int4 kv[KROWS];
+      // tiles' top-3 lists left behind by the residual pass — per trial, one wave per trial (two when there are more than
+      // four), the last wave first: it has no column sums to add
+      // a wave takes up to two trials (ca, cb; cb < 0: one): both key loads travel together, the second merge runs while the
+      // first trial's contributions travel, and on multi-pass levels the (up to 6) tail points are re-evaluated side by side
+      auto tail_two = [&](const int ca, const int cb, auto krn) {
+        constexpr int KROWS = decltype(krn)::value;   // rows per lane: KROWS * 64 >= nb
+        const int cbb = cb < 0 ? ca : cb;
+        const int4* tka = topkey_in0 + (size_t)ca * max_rows;
+        const int4* tkb = topkey_in0 + (size_t)cbb * max_rows;
+        int4 kva[KROWS], kvb[KROWS];
 #pragma unroll
         for (int q = 0; q < KROWS; q++) {
           const int row = lane + 64 * q;
-          const int4 kq = topkey_in[row < max_rows ? row : 0];   // unconditional, issued together
-          kv[q] = row < nb ? kq : make_int4(-1, -1, -1, -1);
+          const int4 ka = tka[row < max_rows ? row : 0];   // unconditional, issued together
+          const int4 kb = tkb[row < max_rows ? row : 0];
+          kva[q] = row < nb ? ka : make_int4(-1, -1, -1, -1);
+          kvb[q] = row < nb ? kb : make_int4(-1, -1, -1, -1);
         }
+        auto merge = [&](const int4 (&kv)[KROWS], int (&keys)[3], int (&src)[3]) {
+          int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
 #pragma unroll
-        for (int q = 0; q < KROWS; q++) {
-          const int e = (lane + 64 * q) * 3;
-          const int ks[3] = {kv[q].x, kv[q].y, kv[q].z};
+          for (int q = 0; q < KROWS; q++) {
+            const int e = (lane + 64 * q) * 3;
+            const int ks[3] = {kv[q].x, kv[q].y, kv[q].z};
 #pragma unroll
-          for (int rr = 0; rr < 3; rr++) {
-            const int k = ks[rr], ek = e + rr;
-            const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
-            k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? ek : e2);
-            k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? ek : e1);
-            k0 = g0 ? k : k0; e0 = g0 ? ek : e0;
+            for (int rr = 0; rr < 3; rr++) {
+              const int k = ks[rr], ek = e + rr;
+              const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
+              k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? ek : e2);
+              k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? ek : e1);
+              k0 = g0 ? k : k0; e0 = g0 ? ek : e0;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            const int m = __builtin_amdgcn_readlane(wave_max_to_lane63(k0), 63);
+            const unsigned long long own = __ballot(k0 == m && m >= 0);
+            const int owner = own ? (int)__ffsll((long long)own) - 1 : 0;
+            keys[r] = m;
+            src[r] = __builtin_amdgcn_readlane(e0, owner);
+            if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
+          }
+        };
+        const bool single = job.lv[level].singlePass != 0;
+        const int j = lane & 31, rj = lane >> 5;
+        int keysA[3], srcA[3], keysB[3], srcB[3];
+        float a0 = 0.f, a2 = 0.f, b0 = 0.f, b2 = 0.f;
+        merge(kva, keysA, srcA);
+        if (single && j < 29) {
+          // the owners left their K2/K3 contributions next to the keys
+          const float* tv = topval_in0 + (size_t)ca * max_rows * 96;
+          if (keysA[rj] >= 0) a0 = tv[(size_t)srcA[rj] * 32 + j];
+          if (rj == 0 && keysA[2] >= 0) a2 = tv[(size_t)srcA[2] * 32 + j];
+        }
+        if (cb >= 0) {
+          merge(kvb, keysB, srcB);
+          if (single && j < 29) {
+            const float* tv = topval_in0 + (size_t)cb * max_rows * 96;
+            if (keysB[rj] >= 0) b0 = tv[(size_t)srcB[rj] * 32 + j];
+            if (rj == 0 && keysB[2] >= 0) b2 = tv[(size_t)srcB[2] * 32 + j];
           }
         }
-      }
-      int keys[3], src[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const int m = __builtin_amdgcn_readlane(wave_max_to_lane63(k0), 63);
-        const unsigned long long own = __ballot(k0 == m && m >= 0);
-        const int owner = own ? (int)__ffsll((long long)own) - 1 : 0;
-        keys[r] = m;
-        src[r] = __builtin_amdgcn_readlane(e0, owner);
-        if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
-      }
-      if (lane == 0) s_nsub = (keys[0] >= 0) + (keys[1] >= 0) + (keys[2] >= 0);
-      if (job.lv[level].singlePass) {
-        // the owners left their K2/K3 contributions next to the keys
-        const int j = lane & 31;
-        if (j < 29) {
-          const int r = lane >> 5;
-          if (keys[r] >= 0) s_sub[r][j] = topval_in[(size_t)src[r] * 32 + j];
-          if (r == 0 && keys[2] >= 0) s_sub[2][j] = topval_in[(size_t)src[2] * 32 + j];
+        if (lane == 0) {
+          s_nsubT[ca] = (keysA[0] >= 0) + (keysA[1] >= 0) + (keysA[2] >= 0);
+          if (cb >= 0) s_nsubT[cb] = (keysB[0] >= 0) + (keysB[1] >= 0) + (keysB[2] >= 0);
         }
-      } else {
-        // multi-pass level: re-evaluate the tail points
-        EvalCtx a;
-        make_ctx_dev(job, S, level, a);
-        const int key = lane == 0 ? keys[0] : (lane == 1 ? keys[1] : keys[2]);
-        if (lane < 3 && key >= 0) {
-          const int idx = (a.npts >= 0) ? key : ((key / a.h) + (key % a.h) * a.w);
-          float px, py, pz, I_ref, var;
-          int maskIdx;
-          fetch_point(a, idx, px, py, pz, I_ref, var, maskIdx);
-          PointOut o;
-          eval_point(a, px, py, pz, I_ref, var, o);
-          float* sub = s_sub[lane];
-          sub[0] = o.werr;
-          int k = 1;
-#pragma unroll
-          for (int r = 0; r < 6; r++) {
-            float Jw = o.J[r] * o.w;
-#pragma unroll
-            for (int c = r; c < 6; c++) sub[k++] = Jw * o.J[c];
+        if (single) {
+          if (j < 29) {
+            if (keysA[rj] >= 0) s_subT[ca][rj][j] = a0;
+            if (rj == 0 && keysA[2] >= 0) s_subT[ca][2][j] = a2;
+            if (cb >= 0) {
+              if (keysB[rj] >= 0) s_subT[cb][rj][j] = b0;
+              if (rj == 0 && keysB[2] >= 0) s_subT[cb][2][j] = b2;
+            }
           }
-          float resw = o.res * o.w;
+        } else {
+          // multi-pass level: re-evaluate the tail points at their trial's pose: lanes 0..2 trial ca, 3..5 trial cb
+          const bool second = lane >= 3;
+          const int r = second ? lane - 3 : lane;
+          const int c = second ? cb : ca;
+          int key = -1;
+          if (lane < 6 && c >= 0) key = second ? (r == 0 ? keysB[0] : (r == 1 ? keysB[1] : keysB[2])) : (r == 0 ? keysA[0] : (r == 1 ? keysA[1] : keysA[2]));
+          if (key >= 0) {
+            EvalCtx a;
+            make_ctx_dev(job, S, level, a);
+            if (c > 0) {
+              const float* rec = s_rec[c];
 #pragma unroll
-          for (int r = 0; r < 6; r++) sub[k++] = resw * o.J[r];
-          sub[k++] = resw * o.res;
+              for (int i = 0; i < 9; i++) a.R[i] = rec[13 + i];
+#pragma unroll
+              for (int i = 0; i < 3; i++) a.t[i] = rec[22 + i];
+            }
+            const int idx = (a.npts >= 0) ? key : ((key / a.h) + (key % a.h) * a.w);
+            float px, py, pz, I_ref, var;
+            int maskIdx;
+            fetch_point(a, idx, px, py, pz, I_ref, var, maskIdx);
+            PointOut o;
+            eval_point(a, px, py, pz, I_ref, var, o);
+            float* sub = s_subT[c][r];
+            sub[0] = o.werr;
+            int k = 1;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++) {
+              float Jw = o.J[rr] * o.w;
+#pragma unroll
+              for (int cc = rr; cc < 6; cc++) sub[k++] = Jw * o.J[cc];
+            }
+            float resw = o.res * o.w;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++) sub[k++] = resw * o.J[rr];
+            sub[k++] = resw * o.res;
+          }
+        }
+      };
+      {
+        // trial c -> wave WAVES-1 - (c mod WAVES): the last wave first (it has no column sums to add)
+        const int ca = WAVES - 1 - wave;
+        const int cb = ca + WAVES < ncandPending ? ca + WAVES : -1;
+        if (ca < ncandPending) {
+          if (nb <= 128) tail_two(ca, cb, std::integral_constant<int, 2>());
+          else tail_two(ca, cb, std::integral_constant<int, 5>());
         }
       }
     }
@@ -928,40 +1041,118 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     __syncthreads();
     PHASE_MARK(2);
     if (wave == 0) {
-      // column totals and tail-drop correction, one column per lane; then the LM decision in the same wave
-      float Mf = s_sum[0][RS_M];
+      // Which pending trial does the LM loop stop at?  Trial c stops it when it diverges (M < minWarped), is accepted
+      // (error < lastErr) or is rejected with a step below stepSizeMin — each test needs only that trial's own totals and
+      // increment, so lane c answers for trial c and the first "yes" wins.  The trials before it were plain rejections: they
+      // leave nothing behind but lambda, incTry and the counters, which are advanced in closed form; then ONE LM step runs,
+      // on the totals of the trial that stopped the loop (or of the last pending one).
+      int pc = 0;
+      if (ncandPending > 1) {
+        const int c = tid < ncandPending ? tid : 0;
+        float Mf = s_sumT[c][0][RS_M], ws = s_sumT[c][0][RS_WERR];
 #pragma unroll
-      for (int k = 1; k < NSLICE; k++) Mf += s_sum[k][RS_M];
-      float s = 0.f;
-      if (tid < RS_END) {
-        s = s_sum[0][tid];
+        for (int k = 1; k < NSLICE; k++) { Mf += s_sumT[c][k][RS_M]; ws += s_sumT[c][k][RS_WERR]; }
+        const int Mc = (int)Mf;
+        int needc = Mc & 3;
+        if (needc > s_nsubT[c]) needc = s_nsubT[c];
+        if (needc > 0) ws -= s_subT[c][0][0];
+        if (needc > 1) ws -= s_subT[c][1][0];
+        if (needc > 2) ws -= s_subT[c][2][0];
+        const float werrc = ws / ((Mc >> 2) << 2);
+        const float* ic = c == 0 ? S.inc : s_rec[c];
+        const float i0 = ic[0], i1 = ic[1], i2 = ic[2], i3 = ic[3], i4 = ic[4], i5 = ic[5];
+        const float incdot = (i0 * i0 + (i1 * i1 + i2 * i2)) + (i3 * i3 + (i4 * i4 + i5 * i5));
+        const bool stop = Mc < s_par.minWarped || werrc < S.lastErr || !(incdot > s_par.stepSizeMin);
+        const unsigned long long sm = __ballot(stop && tid < ncandPending);
+        pc = sm ? (int)__ffsll((long long)sm) - 1 : ncandPending - 1;
+        if (pc > 0) {
+          float lam = S.LM_lambda;
+          const int it0 = S.incTry;
+          for (int j = 0; j < pc; j++) lam = lm_lambda_fail(lam, it0 + j, s_par.lambdaFailFac);
+          // algorithmic bytes of the skipped evaluations (as in lm_wave)
+          float skipped;
+          {
+            float NR = s_sumT[0][0][RS_NREF];
 #pragma unroll
-        for (int k = 1; k < NSLICE; k++) s += s_sum[k][tid];
+            for (int k = 1; k < NSLICE; k++) NR += s_sumT[0][k][RS_NREF];
+            const float wh = (float)s_par.w * (float)s_par.h;
+            const float texels = 4.0f * NR < wh ? 4.0f * NR : wh;
+            skipped = 20.0f * NR + (s_par.writeMask ? 5.0f * NR : 0.0f) + 12.0f * texels;
+          }
+          const float* rec = s_rec[pc];
+          const float bytes0 = S.bytes;
+          const int ne0 = S.numEvaluations, le0 = S.levelEvals[level];
+          float bytes1 = bytes0;
+          for (int j = 0; j < pc; j++) bytes1 = bytes1 + skipped;
+          S.LM_lambda = lam;
+          S.incTry = it0 + pc;
+          S.numEvaluations = ne0 + pc;
+          if (tid == 0) S.levelEvals[level] = le0 + pc;
+          S.bytes = bytes1;
+          if (tid < 6) S.inc[tid] = rec[tid];
+          if (tid < 7) ((float*)&S.Tn)[tid] = rec[6 + tid];
+          if (tid < 9) S.R[tid] = rec[13 + tid];
+          if (tid < 3) S.t[tid] = rec[22 + tid];
+        }
       }
-      const int M = (int)Mf;
-      int need = M & 3;
-      if (need > s_nsub) need = s_nsub;
-      // RS_WERR -> 0, RS_A0.. -> 1..21, RS_B0.. -> 22..27, RS_ERR -> 28
-      const int subIdx = (tid == RS_WERR) ? 0 : ((tid >= RS_A0 && tid < RS_B0) ? 1 + tid - RS_A0 : ((tid >= RS_B0 && tid < RS_ERR) ? 22 + tid - RS_B0 : (tid == RS_ERR ? 28 : -1)));
-      const float sub0 = s_sub[0][subIdx < 0 ? 0 : subIdx], sub1 = s_sub[1][subIdx < 0 ? 0 : subIdx], sub2 = s_sub[2][subIdx < 0 ? 0 : subIdx];
-      if (subIdx >= 0) {
-        if (need > 0) s -= sub0;
-        if (need > 1) s -= sub1;
-        if (need > 2) s -= sub2;
-      }
-      if (tid < RS_NUM) sh.tot[tid] = s;
-      PHASE_MARK(3);
+      {
+        // column totals and tail-drop correction, one column per lane; then the LM decision in the same wave
+        float Mf = s_sumT[pc][0][RS_M];
+#pragma unroll
+        for (int k = 1; k < NSLICE; k++) Mf += s_sumT[pc][k][RS_M];
+        float s = 0.f;
+        if (tid < RS_END) {
+          s = s_sumT[pc][0][tid];
+#pragma unroll
+          for (int k = 1; k < NSLICE; k++) s += s_sumT[pc][k][tid];
+        }
+        const int M = (int)Mf;
+        int need = M & 3;
+        if (need > s_nsubT[pc]) need = s_nsubT[pc];
+        // RS_WERR -> 0, RS_A0.. -> 1..21, RS_B0.. -> 22..27, RS_ERR -> 28
+        const int subIdx = (tid == RS_WERR) ? 0 : ((tid >= RS_A0 && tid < RS_B0) ? 1 + tid - RS_A0 : ((tid >= RS_B0 && tid < RS_ERR) ? 22 + tid - RS_B0 : (tid == RS_ERR ? 28 : -1)));
+        const float sub0 = s_subT[pc][0][subIdx < 0 ? 0 : subIdx], sub1 = s_subT[pc][1][subIdx < 0 ? 0 : subIdx], sub2 = s_subT[pc][2][subIdx < 0 ? 0 : subIdx];
+        if (subIdx >= 0) {
+          if (need > 0) s -= sub0;
+          if (need > 1) s -= sub1;
+          if (need > 2) s -= sub2;
+        }
+        if (tid < RS_NUM) sh.tot[tid] = s;
+        PHASE_MARK(3);
 #ifdef LSD_PHASE_TRACE
-      lm_wave(s_par, S, s, sh.tot, tid, blockIdx.x == 0 ? out : nullptr, blockIdx.x == 0 ? tr_ : nullptr);
+        if (blockIdx.x == 0 && tid == 0) { tr_[19] = (unsigned long long)ncandPending; tr_[7] = (unsigned long long)pc; }
+        lm_wave<!BATCH && MODE == TS_FUSED>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, leader ? tr_ : nullptr, pc, cand);
 #else
-      lm_wave(s_par, S, s, sh.tot, tid, blockIdx.x == 0 ? out : nullptr, nullptr);
+        lm_wave<!BATCH && MODE == TS_FUSED>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, nullptr, pc, cand);
 #endif
+      }
     }
     __syncthreads();
     PHASE_MARK(4);
     if (S.done) {
-      if (blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
+      // the frame's refPixelWasGood must be what the last trial the LM loop executed wrote: trials > 0 wrote side planes
+      if (!BATCH && MODE == TS_FUSED && S.lastCand > 0 && job.lv[level].writeMask && cand == 0 && bx < nb) {
+        const uint8_t* side = spec.wasGoodSide + (size_t)(S.lastCand - 1) * spec.maskStride;
+        EvalCtx a;
+        make_ctx_dev(job, S, level, a);
+        const int work = a.npts >= 0 ? a.npts : a.w * a.h;
+        for (int i = bx * BLOCK + tid; i < work; i += nb * BLOCK) {
+          float px, py, pz, I_ref, var;
+          int maskIdx;
+          if (fetch_point(a, i, px, py, pz, I_ref, var, maskIdx) && maskIdx >= 0) job.wasGood[maskIdx] = side[maskIdx];
+        }
+      }
+      if (leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
       return;
+    }
+    // a workgroup that evaluates trial c > 0 leaves that trial's increment and pose for the launch that finishes it
+    if (cand > 0 && bx == 0 && S.phase == 1 && cand < S.ncand && tid < 25) {
+      float v;
+      if (tid < 6) v = S.inc[tid];
+      else if (tid < 13) v = ((const float*)&S.Tn)[tid - 6];
+      else if (tid < 22) v = S.R[tid - 13];
+      else v = S.t[tid - 22];
+      sc.recs[((size_t)outp * cmax + cand) * 32 + tid] = v;
     }
   }
 
@@ -974,13 +1165,13 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 
   // ---- residual evaluation at S.level / S.R, S.t ------------------------------------------------------------------
   const int level = S.level;
-  if (MODE == TS_FUSED && tid == 0) S.pending = 1;
+  if (MODE == TS_FUSED && tid == 0) { S.pending = 1; S.numLaunches = S.numLaunches + 1; }
   const int nb = job.lv[level].nblocks;
-  if ((int)blockIdx.x >= nb) return;   // workgroup 0 always has work: it publishes the state at the end
-  const int tile = xcd_tile(blockIdx.x, nb);
+  if (bx >= nb || cand >= S.ncand) return;   // workgroup 0 always has work: it publishes the state at the end
+  const int tile = xcd_tile(bx, nb);
   EvalCtx a;
   make_ctx_dev(job, S, level, a);
-  uint8_t* wasGood = job.lv[level].writeMask ? job.wasGood : nullptr;
+  uint8_t* wasGood = job.lv[level].writeMask ? (cand == 0 ? job.wasGood : spec.wasGoodSide + (size_t)(cand - 1) * spec.maskStride) : nullptr;
   const int work = a.npts >= 0 ? a.npts : a.w * a.h;
   float acc[RS_END];
 #pragma unroll
@@ -1169,7 +1360,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       dst[28] = acc[RS_ERR];
     }
   }
-  if (MODE == TS_FUSED && blockIdx.x == 0) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // S.pending was set before the barriers above
+  if (MODE == TS_FUSED && leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // S.pending was set before the barriers above
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
   if (blockIdx.x == 0 && tid == 0) tr_[9] = wall_clock64();
@@ -1178,8 +1369,8 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 
 template <int BLOCK, bool BATCH, int MODE = TS_FUSED>
 __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
-                                                       TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first) {
-  track_step_impl<BLOCK, BATCH, MODE>(jobv, jobs, st2, sc, out, parity, first);
+                                                       TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first, TrackSpec spec) {
+  track_step_impl<BLOCK, BATCH, MODE>(jobv, jobs, st2, sc, out, parity, first, spec);
 }
 
 // =====================================================================================================================
@@ -1280,6 +1471,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_track_persist(TrackJob job, Persis
       S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
       S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
       S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
+      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
       S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
       S.bytes = 0;
       for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
@@ -1681,7 +1873,24 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   }
   t->max_blocks = t->grid_cap;
   const size_t rows = (size_t)t->max_blocks;
-  const size_t scratch_bytes = 2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4;
+  const size_t scratch_bytes = (size_t)LSD_SPEC_MAX * (2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4 + 2 * 32 * 4);
+  if (const char* e = getenv("LSDHIP_SPEC")) t->specC = atoi(e);
+  if (t->specC < 1) t->specC = 1;
+  if (t->specC > LSD_SPEC_MAX) t->specC = LSD_SPEC_MAX;
+  if (const char* e = getenv("LSDHIP_SPEC_CAP")) t->specCap = atoi(e) & ~7;
+  if (const char* e = getenv("LSDHIP_SPEC_CAPS")) {
+    int v[LSD_LEVELS] = {0, 0, 0, 0, 0};
+    sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+    for (int l = 0; l < LSD_LEVELS; l++) t->specCaps[l] = v[l] < 0 ? 0 : (v[l] & ~7);
+  }
+  if (const char* e = getenv("LSDHIP_SPEC_LEVELS")) {
+    int v[LSD_LEVELS] = {0, 0, 0, 0, 0};
+    sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+    for (int l = 0; l < LSD_LEVELS; l++) t->specLevel[l] = v[l] < 0 ? 0 : (v[l] > LSD_SPEC_MAX ? LSD_SPEC_MAX : v[l]);
+  }
+  t->maskStride = (((size_t)c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) + 255) & ~(size_t)255;
+  HIPCHK(hipMalloc((void**)&t->d_maskSide, t->maskStride * (LSD_SPEC_MAX - 1)));
+  HIPCHK(hipMemsetAsync(t->d_maskSide, 0, t->maskStride * (LSD_SPEC_MAX - 1), c->stream));
   HIPCHK(hipMalloc((void**)&t->d_partials, scratch_bytes));
   HIPCHK(hipMemsetAsync(t->d_partials, 0, scratch_bytes, c->stream));
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
@@ -1728,6 +1937,7 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
 #endif
   if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   (void)hipFree(t->d_partials);
+  (void)hipFree(t->d_maskSide);
   (void)hipFree(t->d_ptrows);
   (void)hipFree(t->d_state);
   (void)hipHostFree(t->h_summary);
@@ -1781,6 +1991,19 @@ extern "C" int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]) {
   if (!t || !out) return LSDHIP_E_ARG;
   out[0] = t->persistJobs; out[1] = t->persistFallbacks; out[2] = t->persistOff ? 1 : 0;
   for (int l = 0; l < LSD_LEVELS; l++) out[3 + l] = t->levelEvaluations[l];
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups) {
+  if (!t || trials < 1 || trials > LSD_SPEC_MAX || finestLevelWorkgroups < 0) { lsd_set_error("lsdhip_tracker_set_speculation: trials must be 1..%d", LSD_SPEC_MAX); return LSDHIP_E_ARG; }
+  LSD_CTX_LOCK(t->ctx);
+  t->specC = trials;
+  t->specCap = finestLevelWorkgroups & ~7;
+  for (int i = 0; i < 4; i++) t->recent[i] = 0;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]) {
+  if (!t || !out) return LSDHIP_E_ARG;
+  out[0] = t->numLaunches; out[1] = t->specC;
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int its[LSD_LEVELS]) {
@@ -1846,11 +2069,13 @@ static void fill_job_common(lsdhip_tracker* t, TrackJob& job) {
 
 static TrackScratch scratch_of(lsdhip_tracker* t) {
   TrackScratch sc;
-  const size_t rows = (size_t)t->max_blocks;
+  const size_t rows = (size_t)t->max_blocks, C = LSD_SPEC_MAX;
   sc.sums = t->d_partials;
-  sc.topkey = (int4*)(t->d_partials + 2 * RS_COLS * rows);
-  sc.topval = t->d_partials + 2 * RS_COLS * rows + 2 * 4 * rows;
+  sc.topkey = (int4*)(t->d_partials + C * 2 * RS_COLS * rows);
+  sc.topval = t->d_partials + C * 2 * RS_COLS * rows + C * 2 * 4 * rows;
+  sc.recs = t->d_partials + C * 2 * RS_COLS * rows + C * 2 * 4 * rows + C * 2 * 96 * rows;
   sc.max_rows = t->max_blocks;
+  sc.cmax = LSD_SPEC_MAX;
 #ifdef LSD_PHASE_TRACE
   sc.trace = t->d_trace;
 #endif
@@ -1861,12 +2086,19 @@ static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int pa
   LSD_CTX_LOCK(c);
   TrackScratch sc = scratch_of(t);
   hipLaunchKernelGGL((k_track_step<256, false>), dim3(grid), dim3(256), 0, c->stream, job, (const TrackJob*)nullptr, t->d_state, sc,
-                     t->d_summary, parity, first);
+                     t->d_summary, parity, first, t->spec);
 }
 // launch `steps` fused k_track_step kernels (alternating parity); grid = the largest level the job can still visit.
-static int launch_steps(lsdhip_tracker* t, const TrackJob& job, int steps, int* parity, int* first) {
+static int launch_steps(lsdhip_tracker* t, TrackJob& job, int steps, int* parity, int* first) {
   int grid = 1;
   for (int l = job.lastLevel; l <= job.topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
+  t->spec.specGrid = 0;
+  if (t->spec.specC > 1) {
+    int mt = 1;
+    for (int l = job.lastLevel; l <= job.topLevel; l++) if (t->spec.trials[l] > mt) mt = t->spec.trials[l];
+    t->spec.specGrid = grid;
+    grid *= mt;
+  }
   for (int i = 0; i < steps; i++) {
     launch_step(t, job, grid, *parity, *first);
     *first = 0;
@@ -1895,6 +2127,7 @@ static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T,
   job.T0 = T;
   job.aff_a0 = t->affineEstimation_a; job.aff_b0 = t->affineEstimation_b;
   t->h_summary->done = 0;
+  t->spec = TrackSpec{};                              // one evaluation, one trial
   if (int rcp = prof_collect(c)) return rcp;
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
   launch_step(t, job, job.lv[level].nblocks, 0, 1);   // residual evaluation
@@ -2013,6 +2246,25 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   job.topLevel = topLevel;
   job.T0 = T0;
   job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
+  t->spec.specC = t->specC;
+  t->spec.specGrid = 0;
+  t->spec.wasGoodSide = t->d_maskSide;
+  t->spec.maskStride = (unsigned)t->maskStride;
+  for (int l = 0; l < LSD_LEVELS; l++) t->spec.trials[l] = t->specC > 1 ? (t->specLevel[l] > 0 ? t->specLevel[l] : t->specC) : 1;
+  if (t->specC > 1) {
+    // several trials share the chip: fewer workgroups per trial where trials x workgroups would not fit it (the level's
+    // pixels then grid-stride)
+    for (int l = job.lastLevel; l <= topLevel; l++) {
+      TrackLevel& L = job.lv[l];
+      int cap = t->specCaps[l];
+      if (cap <= 0 && l == job.lastLevel) cap = t->specCap > 0 ? t->specCap : ((t->grid_cap / 2 + 7) & ~7);
+      if (cap > 0 && L.nblocks > cap && L.tilePx == 0) {
+        L.nblocks = cap;
+        const long long work = L.npts >= 0 ? L.npts : (long long)L.w * L.h;
+        L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
+      }
+    }
+  }
   t->h_summary->done = 0;
   const TrackSummary* S = t->h_summary;
   // launches a job needs = its evaluations + the finalising step; budget = the most of the recent jobs + 1
@@ -2128,9 +2380,10 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   }
   if (sample) {
     c->prof_bytes += S->bytes;
-    c->prof_launches += S->numEvaluations;
+    c->prof_launches += usedPersist ? S->numEvaluations : S->numLaunches;
   }
-  t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = S->numEvaluations;
+  t->numLaunches = usedPersist ? S->numEvaluations : S->numLaunches;
+  t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = t->numLaunches;
   for (int l = 0; l < LSD_LEVELS; l++) t->levelEvaluations[l] = S->levelEvals[l];
   if (usedPersist) {
     int ce = 0;
@@ -2299,6 +2552,8 @@ static int batch_run(lsdhip_tracker* t, int n) {
     sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
     sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
     sc.max_rows = t->max_blocks;
+    sc.cmax = 1;
+    sc.recs = nullptr;
 #ifdef LSD_PHASE_TRACE
     sc.trace = nullptr;
 #endif
@@ -2313,12 +2568,12 @@ static int batch_run(lsdhip_tracker* t, int n) {
       if (split) {
         // throughput mode: one LM workgroup per job, then a pure evaluation launch over all jobs' strips
         hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
-                           t->d_bstate, sc, d_sum, parity, first);
+                           t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
         hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
-                           t->d_bstate, sc, d_sum, 1 - parity, 0);
+                           t->d_bstate, sc, d_sum, 1 - parity, 0, TrackSpec{});
       } else {
         hipLaunchKernelGGL((k_track_step<256, true>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
-                           t->d_bstate, sc, d_sum, parity, first);
+                           t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
       }
       first = 0;
       parity ^= 1;

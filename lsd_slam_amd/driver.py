@@ -15,12 +15,12 @@ _lib = None
 class LoopStats(C.Structure):
     _fields_ = [("seconds_track", C.c_double), ("seconds_map", C.c_double), ("seconds_keyframe", C.c_double), ("frames", C.c_longlong),
                 ("updates", C.c_longlong), ("keyframes", C.c_longlong), ("evaluations", C.c_longlong), ("tracked_good", C.c_longlong),
-                ("level_evaluations", C.c_longlong * 5)]
+                ("level_evaluations", C.c_longlong * 5), ("track_launches", C.c_longlong)]
 
 
 EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop_get_stats", "lsdloop_reset_stats",
                     "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
-                    "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_persistent", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
+                    "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_persistent", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
                     "lsdloop_gather_keyframes"]
 
 
@@ -56,6 +56,8 @@ def lib():
         L.lsdloop_set_live_queue.argtypes = [vp, i]
         L.lsdloop_set_persistent.restype = i
         L.lsdloop_set_persistent.argtypes = [vp, i]
+        L.lsdloop_set_speculation.restype = i
+        L.lsdloop_set_speculation.argtypes = [vp, i, i]
         L.lsdloop_observe_time.restype = i
         L.lsdloop_observe_time.argtypes = [vp, vp, vp]
         L.lsdloop_comm_unique_id.restype = i
@@ -138,6 +140,9 @@ class DriverLoop:
 
     def set_live_queue(self, frames):
         _check(self.L.lsdloop_set_live_queue(self.h_, int(frames)))
+
+    def set_speculation(self, trials, finest_level_workgroups=0):
+        _check(self.L.lsdloop_set_speculation(self.h_, int(trials), int(finest_level_workgroups)))
 
     def set_persistent(self, max_strips):
         _check(self.L.lsdloop_set_persistent(self.h_, int(max_strips)))

@@ -107,6 +107,7 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       SlamLoop& L = *l->loop;
       const long upd0 = L.numUpdates;
       const long ev0 = L.evaluations;
+      const long la0 = L.launches;
       const long good0 = L.numTrackedGood;
       long lev0[5];
       for (int k = 0; k < 5; k++) lev0[k] = L.levelEvaluations[k];
@@ -114,6 +115,7 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       l->st.frames++;
       l->st.updates += L.numUpdates - upd0;
       l->st.evaluations += L.evaluations - ev0;
+      l->st.track_launches += L.launches - la0;
       l->st.tracked_good += L.numTrackedGood - good0;
       for (int k = 0; k < 5; k++) l->st.level_evaluations[k] += L.levelEvaluations[k] - lev0[k];
       if (L.newKeyframe) l->st.keyframes++;
@@ -201,6 +203,11 @@ extern "C" int lsdloop_set_live_queue(lsdloop* l, int frames) {
 extern "C" int lsdloop_set_persistent(lsdloop* l, int max_strips) {
   if (!l) return LSDHIP_E_ARG;
   try { l->loop->tracker.setPersistent(max_strips); return LSDHIP_OK; }
+  catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+extern "C" int lsdloop_set_speculation(lsdloop* l, int trials, int finest_level_workgroups) {
+  if (!l) return LSDHIP_E_ARG;
+  try { l->loop->tracker.setSpeculation(trials, finest_level_workgroups); return LSDHIP_OK; }
   catch (const Error& e) { g_err = e.what(); return e.status; }
 }
 extern "C" int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out) {

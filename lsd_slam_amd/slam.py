@@ -235,6 +235,16 @@ class SE3Tracker:
         """coarse pyramid levels in one persistent launch (0 = off, the default); see include/lsdhip.h"""
         check(self.L.lsdhip_tracker_set_persistent(self.h_, int(max_strips)))
 
+    def set_speculation(self, trials, finest_level_workgroups=0):
+        """LM retries evaluated per launch (1 = one evaluation per launch); see include/lsdhip.h"""
+        check(self.L.lsdhip_tracker_set_speculation(self.h_, int(trials), int(finest_level_workgroups)))
+
+    def launch_stats(self):
+        """(evaluating launches of the last job, trials per launch)"""
+        out = np.zeros(2, np.int32)
+        check(self.L.lsdhip_tracker_launch_stats(self.h_, out.ctypes.data))
+        return int(out[0]), int(out[1])
+
     def exec_stats(self):
         """diagnostics: (persistent-kernel jobs, give-ups rerun launch-per-evaluation, switched off, evaluations per level 0..4)"""
         out = np.zeros(8, np.int32)

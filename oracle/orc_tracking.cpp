@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include "lsd_oracle.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 namespace orc {
 
@@ -380,6 +382,8 @@ SE3d SE3Tracker::trackFrame(TrackingReference* reference, Frame* frame, const SE
           return SE3d();
         }
         float error = callWeights(new_referenceToFrame);
+        static const bool lmTrace = getenv("ORC_LM_TRACE") != nullptr;   // developer diagnostics: accept / reject pattern per level
+        if (lmTrace) fprintf(stderr, "LMT %d %c %g %d\n", lvl, error < lastErr ? 'A' : 'R', (double)LM_lambda, incTry);
         if (error < lastErr) {
           referenceToFrame = new_referenceToFrame;
           if (params.useAffineLightningEstimation) {

@@ -848,6 +848,7 @@ def test_observe_alternative_execution_forms_bit_exact(oracle, hip, mode, monkey
         "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import test_gpu_parity as T, lsd_slam_amd as hip\n"
         "from oracle import pyoracle as oracle\n"
+        "oracle.build()\n"
         "w, h = 320, 240\n"
         "frames, depth0, K, gt, ctx = T.make_pair(oracle, hip, w, h, 8)\n"
         "kfo, kfg, dmo, dmg = T._noisy_map(oracle, hip, ctx, frames, depth0, K, w, h)\n"
@@ -863,3 +864,83 @@ def test_observe_alternative_execution_forms_bit_exact(oracle, hip, mode, monkey
     env["LSDHIP_OBS_SPLIT" if mode == "split" else "LSDHIP_OBS_SHORT"] = "1"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trials", [2, 5, 6])
+def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip, trials):
+    """lsdhip_tracker_set_speculation: a launch evaluates the next `trials` poses of the LM loop's retry chain side by side and the
+    next launch consumes them in the reference's order.  With the same workgroups per trial as the one-evaluation-per-launch run
+    (identical partial-sum tiling) every output is the same BIT FOR BIT — pose, counters, residual, the frame's refPixelWasGood
+    (which must be what the last trial the LM loop executed wrote, not what a later speculative one did) — in fewer launches."""
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8)
+    kf = hip.Frame(ctx, 0, frames[0])
+    kf.setDepthFromGroundTruth(depth0)
+    ref = hip.TrackingReference()
+    ref.importFrame(kf)
+    tr_a, tr_b = hip.SE3Tracker(ctx), hip.SE3Tracker(ctx)
+    tr_a.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr_b.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr_a.set_speculation(1)
+    tr_b.set_speculation(trials, 304)       # 304 = the single-trial grid at 320x240 (level 1)
+    init = IDENT7.copy()
+    saved = 0
+    for i in range(1, 8):
+        fa, fb = hip.Frame(ctx, i, frames[i]), hip.Frame(ctx, i, frames[i])
+        pa = tr_a.trackFrame(ref, fa, init)
+        pb = tr_b.trackFrame(ref, fb, init)
+        assert np.array_equal(pa, pb), (i, pa, pb)
+        for k in ("numEvaluations", "numWarpUpdates", "lastResidual", "pointUsage", "lastGoodCount", "lastBadCount", "lastMeanRes",
+                  "affineEstimation_a", "affineEstimation_b", "diverged", "trackingWasGood"):
+            assert getattr(tr_a.last, k) == getattr(tr_b.last, k), (i, k)
+        assert tr_a.exec_stats()[3] == tr_b.exec_stats()[3]
+        assert_bit_equal(fa.refPixelWasGoodNoCreate(), fb.refPixelWasGoodNoCreate(), "refPixelWasGood")
+        la, _ = tr_a.launch_stats()
+        lb, cb = tr_b.launch_stats()
+        assert cb == trials and la == tr_a.last.numEvaluations and lb <= la
+        saved += la - lb
+        init = pa
+    assert saved >= 7 * 3, saved           # the retry chains that end every level collapse into single launches
+    # divergence: the trial that diverges first in the reference's order decides, not a speculative one
+    bad = oracle.se3_exp(np.array([5.0, 0, 0, 0, 0, 0]))
+    est = tr_b.trackFrame(ref, hip.Frame(ctx, 9, frames[1]), bad)
+    assert tr_b.diverged and not tr_b.trackingWasGood and np.array_equal(est, IDENT7)
+    # permanent-reference path (no mask) through the same chain
+    kfo = oracle.Frame(0, frames[0], K)
+    kfo.set_depth_gt(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(kfo)
+    pos, cv, _, _ = ro.pointcloud(4)
+    T0 = oracle.se3_exp(np.array([0.01, 0.0, 0.0, 0, 0, 0.002]))
+    ua = tr_a.trackFrameOnPermaref(pos, cv, hip.Frame(ctx, 3, frames[3]), T0)
+    ub = tr_b.trackFrameOnPermaref(pos, cv, hip.Frame(ctx, 3, frames[3]), T0)
+    assert np.array_equal(ua, ub) and tr_a.last.numEvaluations == tr_b.last.numEvaluations
+
+
+@pytest.mark.gpu
+def test_speculation_default_matches_oracle_sequence(oracle, hip):
+    """the library default (5 trials, half the workgroups per trial at level 1) against the oracle over a few frames"""
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
+    kfo, kfg = oracle.Frame(0, frames[0], K), hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    ro, rg = oracle.TrackingReference(), hip.TrackingReference()
+    ro.import_frame(kfo)
+    rg.importFrame(kfg)
+    tro, trg = oracle.SE3Tracker(w, h, K, mode=oracle.SSE), hip.SE3Tracker(ctx)
+    tro.set_max_its(ODOMETRY_ITS)
+    trg.set_maxItsPerLvl(ODOMETRY_ITS)
+    assert trg.launch_stats()[1] == 5
+    init = IDENT7.copy()
+    for i in range(1, 6):
+        fo, fg = oracle.Frame(i, frames[i], K), hip.Frame(ctx, i, frames[i])
+        r = tro.track(ro, fo, init)
+        est = trg.trackFrame(rg, fg, init)
+        dt, dr = pose_distance(est, np.array(r.frameToRef), oracle)
+        assert max(dt, dr) < 5e-4, (i, dt, dr)
+        assert abs(r.numEvaluations - trg.last.numEvaluations) <= 3
+        assert (fo.wasgood() != fg.refPixelWasGoodNoCreate()).mean() < 2e-3
+        assert trg.launch_stats()[0] < trg.last.numEvaluations
+        init = np.array(r.frameToRef)

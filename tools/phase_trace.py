@@ -54,3 +54,12 @@ if path and os.path.exists(path):
         m = full[:, 10].astype(int) == lvl
         print("level %d (nb=%d, %d launches): " % (lvl, int(full[m][0, 11]), m.sum()) +
               ", ".join("%s %.2f us" % (n, np.median(d[m][:, k]) / ghz / 1e3) for k, n in enumerate(names)))
+
+    if a.shape[1] >= 20:
+        print("by (level evaluated, trials pending, trial the LM loop stopped at):")
+        key = np.stack([full[:, 10], full[:, 19], full[:, 7]], axis=1).astype(int)
+        for k in sorted(set(map(tuple, key))):
+            m = (key == np.array(k)).all(axis=1)
+            print("   L%d pending %d stop %d (%3d launches): " % (k[0], k[1], k[2], m.sum()) +
+                  ", ".join("%s %.2f" % (n, np.median(d[m][:, j]) / ghz / 1e3) for j, n in enumerate(names)) +
+                  " | body %.2f us" % (np.median(wall[m]) / 1e3))
