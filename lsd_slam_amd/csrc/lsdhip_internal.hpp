@@ -237,8 +237,9 @@ struct lsdhip_tracker {
   int recent[4] = {0, 0, 0, 0};   // evaluating launches of the last jobs: size the launch budget of the next one
   int specC = 5;                  // trials per launch (LSDHIP_SPEC; 1 = no speculation)
   int specCaps[LSD_LEVELS] = {0, 0, 0, 0, 0};    // per-level workgroups per trial (LSDHIP_SPEC_CAPS; 0 = automatic)
-  int specLevel[LSD_LEVELS] = {0, 0, 0, 0, 0};   // per-level override (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = specC)
-  int specCap = 0;                // workgroups per trial at the finest level when speculating (0 = grid_cap / 2)
+  int specLevel[LSD_LEVELS] = {0, 4, 5, 6, 0};   // per-level trials (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = specC): the retry chains
+                                                 // that end a level are 4-6 evaluations long (profiles/r02_notes.md)
+  int specCap = 104;              // workgroups per trial at the finest level when speculating (0 = grid_cap / 2)
   uint8_t* d_maskSide = nullptr;  // (SPEC_MAX - 1) mask planes of (w >> 1) x (h >> 1) bytes
   size_t maskStride = 0;
   int numLaunches = 0;

@@ -791,7 +791,8 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   int4* topkey_out = sc.topkey + ((size_t)outp * cmax + cand) * max_rows;
   const float* topval_in0 = sc.topval + (size_t)parity * cmax * max_rows * 96;
   float* topval_out = sc.topval + ((size_t)outp * cmax + cand) * max_rows * 96;
-  __shared__ float s_sumT[LSD_SPEC_MAX][NSLICE][RS_COLS];   // per pending trial: column sums by row slice
+  constexpr int NSLOT = 16;                                  // row slots of the column sums: slot s adds rows s, s + 16, ...
+  __shared__ __attribute__((aligned(16))) float s_sumT[LSD_SPEC_MAX][NSLOT][RS_COLS];    // per pending trial: column sums by row slot
   __shared__ float s_subT[LSD_SPEC_MAX][3][32];             // ... K2/K3 contributions of its (up to 3) tail points
   __shared__ int s_nsubT[LSD_SPEC_MAX];
   __shared__ float s_rec[LSD_SPEC_MAX][32];                 // ... increment [0..5], pose [6..12], R [13..21], t [22..24] (trials > 0)
@@ -853,63 +854,6 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     const int level = S.level;
     const int nb = job.lv[level].nblocks;
     const size_t trialStrideF4 = (size_t)RS_COLS * max_rows / 4;
-    if (wave < SUMW) {
-      // fixed-order column sums: thread t < NSLICE * RS_END takes rows [slice R, slice R + R) of column col, for every trial
-      const int t = tid;
-      const int slice = t / RS_END, col = t - slice * RS_END;
-      if (slice < NSLICE) {
-        const int R = (((nb + NSLICE - 1) / NSLICE) + 3) & ~3;
-        const int row0 = slice * R;
-        const float4* p = (const float4*)(sums_in0 + (size_t)col * max_rows + (row0 < max_rows ? row0 : 0));
-        const int qlast = (max_rows - row0) / 4 - 1;   // loads stay inside the column (rows < max_rows are allocated)
-        // the loads are unconditional and issued together (trials past the last one re-read it); coarse levels (few tiles)
-        // take the short forms so that they do not pay for 20 vector loads per thread and trial when 2 or 5 cover their rows
-        auto colsum = [&](auto qn, auto ntn, const int base) {
-          constexpr int Q = decltype(qn)::value, NT = decltype(ntn)::value;
-          float4 v[NT][Q];
-#pragma unroll
-          for (int c = 0; c < NT; c++) {
-            const int pc = base + c < ncandPending ? base + c : ncandPending - 1;
-            const float4* pp = p + (size_t)pc * trialStrideF4;
-#pragma unroll
-            for (int q = 0; q < Q; q++) v[c][q] = pp[q < qlast ? q : (qlast > 0 ? qlast : 0)];
-          }
-#pragma unroll
-          for (int c = 0; c < NT; c++) {
-            float s = 0.f;
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-              const int r = row0 + 4 * q;
-              if (4 * q < R) {
-                s += (r < nb) ? v[c][q].x : 0.f;
-                s += (r + 1 < nb) ? v[c][q].y : 0.f;
-                s += (r + 2 < nb) ? v[c][q].z : 0.f;
-                s += (r + 3 < nb) ? v[c][q].w : 0.f;
-              }
-            }
-            if (base + c < ncandPending) s_sumT[base + c][slice][col] = s;
-          }
-        };
-        typedef std::integral_constant<int, 1> I1;
-        typedef std::integral_constant<int, 3> I3;
-        typedef std::integral_constant<int, LSD_SPEC_MAX> IM;
-        if (ncandPending == 1) {
-          if (R <= 8) colsum(std::integral_constant<int, 2>(), I1(), 0);
-          else if (R <= 20) colsum(std::integral_constant<int, 5>(), I1(), 0);
-          else if (R <= 40) colsum(std::integral_constant<int, 10>(), I1(), 0);
-          else colsum(std::integral_constant<int, QMAX>(), I1(), 0);
-        } else if (R <= 8) colsum(std::integral_constant<int, 2>(), IM(), 0);
-        else if (R <= 20) colsum(std::integral_constant<int, 5>(), IM(), 0);
-        else if (R <= 40) { for (int base = 0; base < ncandPending; base += 3) colsum(std::integral_constant<int, 10>(), I3(), base); }
-        else { for (int base = 0; base < ncandPending; base++) colsum(std::integral_constant<int, QMAX>(), I1(), base); }
-#ifdef LSD_PHASE_TRACE
-        if (blockIdx.x == 0 && tid == 0) tr_[17] = clock64();
-#endif
-      } else if (t == SUMW * 64 - 1) {
-        stage_lm_par(job, level, s_par, (spec.specC > 1 && spec.trials[level] > 1) ? spec.trials[level] : 1);
-      }
-    }
-    {
       // the last (M % 4) in-image points in reference order = the largest keys (x * h + y, or list index) over all
       // tiles' top-3 lists left behind by the residual pass — per trial, one wave per trial (two when there are more than
       // four), the last wave first: it has no column sums to add
@@ -1025,16 +969,76 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
           }
         }
       };
+    // this wave's share of the tail work, run between the issue of the column-sum loads and their additions
+    auto wave_tail = [&]() {
+      // trial c -> wave WAVES-1 - (c mod WAVES): the last wave first (it has no column sums to add)
+      const int ca = WAVES - 1 - wave;
+      const int cb = ca + WAVES < ncandPending ? ca + WAVES : -1;
+      if (ca < ncandPending) {
+        if (nb <= 128) tail_two(ca, cb, std::integral_constant<int, 2>());
+        else tail_two(ca, cb, std::integral_constant<int, 5>());
+      }
+    };
+    if (tid == SUMW * 64 - 1) stage_lm_par(job, level, s_par, (spec.specC > 1 && spec.trials[level] > 1) ? spec.trials[level] : 1);
+    if (wave < SUMW) {
+      // fixed-order column sums over the tiles' partial rows (row-major [tile][RS_COLS]: a wave's load covers whole rows, i.e.
+      // contiguous memory): thread t < NSLOT * 11 takes columns 4 c4 .. 4 c4 + 3 of rows slot, slot + NSLOT, ... , for every
+      // trial (the other lanes of these waves run along and store nothing: the tail work in the middle is wave-wide)
+      const int t = tid;
+      const int slot_ = t / (RS_COLS / 4);
+      const bool sumLane = slot_ < NSLOT;
+      const int slot = sumLane ? slot_ : 0, c4 = sumLane ? t - slot_ * (RS_COLS / 4) : 0;
       {
-        // trial c -> wave WAVES-1 - (c mod WAVES): the last wave first (it has no column sums to add)
-        const int ca = WAVES - 1 - wave;
-        const int cb = ca + WAVES < ncandPending ? ca + WAVES : -1;
-        if (ca < ncandPending) {
-          if (nb <= 128) tail_two(ca, cb, std::integral_constant<int, 2>());
-          else tail_two(ca, cb, std::integral_constant<int, 5>());
-        }
+        const int K = (nb + NSLOT - 1) / NSLOT;                // rows per slot
+        const float4* p = (const float4*)sums_in0 + c4;
+        const size_t trialStrideF4 = (size_t)RS_COLS * max_rows / 4;
+        // the loads are unconditional and issued together (trials past the last one re-read it, rows past the last one re-read
+        // the slot's first row); coarse levels (few tiles) take the short forms
+        auto colsum = [&](auto qn, auto ntn, const int base) {
+          constexpr int Q = decltype(qn)::value, NT = decltype(ntn)::value;
+          float4 v[NT][Q];
+#pragma unroll
+          for (int c = 0; c < NT; c++) {
+            const int pc = base + c < ncandPending ? base + c : ncandPending - 1;
+            const float4* pp = p + (size_t)pc * trialStrideF4;
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+              const int r = slot + NSLOT * q;
+              v[c][q] = pp[(size_t)(r < nb ? r : slot) * (RS_COLS / 4)];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < NT; c++) {
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+              const bool live = q < K && slot + NSLOT * q < nb;
+              a4.x += live ? v[c][q].x : 0.f;
+              a4.y += live ? v[c][q].y : 0.f;
+              a4.z += live ? v[c][q].z : 0.f;
+              a4.w += live ? v[c][q].w : 0.f;
+            }
+            if (sumLane && base + c < ncandPending) *(float4*)&s_sumT[base + c][slot][c4 * 4] = a4;
+          }
+        };
+        typedef std::integral_constant<int, 1> I1;
+        typedef std::integral_constant<int, 3> I3;
+        typedef std::integral_constant<int, LSD_SPEC_MAX> IM;
+        if (ncandPending == 1) {
+          if (K <= 2) colsum(std::integral_constant<int, 2>(), I1(), 0);
+          else if (K <= 5) colsum(std::integral_constant<int, 5>(), I1(), 0);
+          else if (K <= 10) colsum(std::integral_constant<int, 10>(), I1(), 0);
+          else colsum(std::integral_constant<int, QMAX>(), I1(), 0);
+        } else if (K <= 2) colsum(std::integral_constant<int, 2>(), IM(), 0);
+        else if (K <= 5) colsum(std::integral_constant<int, 5>(), IM(), 0);
+        else if (K <= 10) { for (int base = 0; base < ncandPending; base += 3) colsum(std::integral_constant<int, 10>(), I3(), base); }
+        else { for (int base = 0; base < ncandPending; base++) colsum(std::integral_constant<int, QMAX>(), I1(), base); }
+#ifdef LSD_PHASE_TRACE
+        if (blockIdx.x == 0 && tid == 0) tr_[17] = clock64();
+#endif
       }
     }
+    wave_tail();
 #ifdef LSD_PHASE_TRACE
     if (blockIdx.x == 0 && tid == SUMW * 64) s_trp[18] = clock64();
 #endif
@@ -1051,7 +1055,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         const int c = tid < ncandPending ? tid : 0;
         float Mf = s_sumT[c][0][RS_M], ws = s_sumT[c][0][RS_WERR];
 #pragma unroll
-        for (int k = 1; k < NSLICE; k++) { Mf += s_sumT[c][k][RS_M]; ws += s_sumT[c][k][RS_WERR]; }
+        for (int k = 1; k < NSLOT; k++) { Mf += s_sumT[c][k][RS_M]; ws += s_sumT[c][k][RS_WERR]; }
         const int Mc = (int)Mf;
         int needc = Mc & 3;
         if (needc > s_nsubT[c]) needc = s_nsubT[c];
@@ -1074,7 +1078,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
           {
             float NR = s_sumT[0][0][RS_NREF];
 #pragma unroll
-            for (int k = 1; k < NSLICE; k++) NR += s_sumT[0][k][RS_NREF];
+            for (int k = 1; k < NSLOT; k++) NR += s_sumT[0][k][RS_NREF];
             const float wh = (float)s_par.w * (float)s_par.h;
             const float texels = 4.0f * NR < wh ? 4.0f * NR : wh;
             skipped = 20.0f * NR + (s_par.writeMask ? 5.0f * NR : 0.0f) + 12.0f * texels;
@@ -1099,12 +1103,12 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         // column totals and tail-drop correction, one column per lane; then the LM decision in the same wave
         float Mf = s_sumT[pc][0][RS_M];
 #pragma unroll
-        for (int k = 1; k < NSLICE; k++) Mf += s_sumT[pc][k][RS_M];
+        for (int k = 1; k < NSLOT; k++) Mf += s_sumT[pc][k][RS_M];
         float s = 0.f;
         if (tid < RS_END) {
           s = s_sumT[pc][0][tid];
 #pragma unroll
-          for (int k = 1; k < NSLICE; k++) s += s_sumT[pc][k][tid];
+          for (int k = 1; k < NSLOT; k++) s += s_sumT[pc][k][tid];
         }
         const int M = (int)Mf;
         int need = M & 3;
@@ -1342,7 +1346,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       float s = s_sum[0][tid];
 #pragma unroll
       for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
-      sums_out[(size_t)(hp * CPP + tid) * max_rows + tile] = s;
+      sums_out[(size_t)tile * RS_COLS + (hp * CPP + tid)] = s;
     }
   }
   block_top3(key0, key1, key2, s_wtop, s_top);
@@ -1997,7 +2001,8 @@ extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int
   if (!t || trials < 1 || trials > LSD_SPEC_MAX || finestLevelWorkgroups < 0) { lsd_set_error("lsdhip_tracker_set_speculation: trials must be 1..%d", LSD_SPEC_MAX); return LSDHIP_E_ARG; }
   LSD_CTX_LOCK(t->ctx);
   t->specC = trials;
-  t->specCap = finestLevelWorkgroups & ~7;
+  if (finestLevelWorkgroups > 0) t->specCap = finestLevelWorkgroups & ~7;
+  for (int l = 0; l < LSD_LEVELS; l++) t->specLevel[l] = 0;   // the same number of trials at every level
   for (int i = 0; i < 4; i++) t->recent[i] = 0;
   return LSDHIP_OK;
 }
