@@ -90,6 +90,7 @@ struct TrackSpec {
   int trials[LSD_LEVELS];    // trials per launch at each level
   uint8_t* wasGoodSide;      // refPixelWasGood planes of trials 1 .. (trial 0 writes the frame's own plane)
   unsigned maskStride;
+  int seq;                   // progress tag this launch reports to the host (TrackSummary::seq); 0 = none
 };
 
 // Levenberg-Marquardt state of a tracking job, resident in HBM, advanced by k_lm_step.
@@ -124,7 +125,8 @@ struct TrackSummary {
   double bytes;              // algorithmic bytes of all evaluations of the job
   int levelEvals[LSD_LEVELS];
   int numLaunches;           // k_track_step launches that evaluated (< numEvaluations with reject-chain speculation)
-  int pad2_[2];
+  int seq;                   // (job tag << 12) | ordinal of the latest k_track_step launch of the chain that has started
+  int pad2_[1];
   unsigned long long phase[10];   // k_track_persist: shader cycles workgroup 0 spent per phase, summed over the job's evaluations
 };
 
@@ -244,6 +246,10 @@ struct lsdhip_tracker {
   size_t maskStride = 0;
   int numLaunches = 0;
   TrackSpec spec = {};             // of the job being launched
+  int jobTag = 0, launchOrdinal = 0;   // progress reporting of the launch chain (host tops the chain up while it waits)
+  int topUps = 0;
+  bool topUp = false;                  // LSDHIP_TOPUP=1: start with the shortest recent job's launches and append while waiting
+                                       // (measured slower than the fixed budget: the host's launches land late — r02_notes.md)
   int recentChain[4] = {0, 0, 0, 0};   // same, counting only the levels the k_track_step chain ran behind the persistent kernel
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary

@@ -809,6 +809,8 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   }
 #endif
   PHASE_MARK(0);
+  if (!BATCH && MODE == TS_FUSED && !first && !leader && st2[parity].done) return;   // launches queued behind the finishing one
+  if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.seq != 0) out->seq = spec.seq;   // pinned host memory: fire and forget
   if (first) {
     if (tid == 0) {
       S.T = job.T0;
@@ -1916,6 +1918,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   const char* env = getenv("LSDHIP_HOST_LM");
   t->hostLM = env && env[0] == '1';
   if (const char* e = getenv("LSDHIP_SPIN")) t->spinWait = e[0] != '0';
+  if (const char* e = getenv("LSDHIP_TOPUP")) t->topUp = e[0] != '0';
   *out = t;
   return LSDHIP_OK;
 }
@@ -2090,6 +2093,8 @@ static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int pa
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
   TrackScratch sc = scratch_of(t);
+  t->launchOrdinal++;
+  t->spec.seq = t->jobTag ? ((t->jobTag << 12) | (t->launchOrdinal & 0xFFF)) : 0;
   hipLaunchKernelGGL((k_track_step<256, false>), dim3(grid), dim3(256), 0, c->stream, job, (const TrackJob*)nullptr, t->d_state, sc,
                      t->d_summary, parity, first, t->spec);
 }
@@ -2133,6 +2138,7 @@ static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T,
   job.aff_a0 = t->affineEstimation_a; job.aff_b0 = t->affineEstimation_b;
   t->h_summary->done = 0;
   t->spec = TrackSpec{};                              // one evaluation, one trial
+  t->jobTag = 0;
   if (int rcp = prof_collect(c)) return rcp;
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
   launch_step(t, job, job.lv[level].nblocks, 0, 1);   // residual evaluation
@@ -2272,18 +2278,31 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   }
   t->h_summary->done = 0;
   const TrackSummary* S = t->h_summary;
-  // launches a job needs = its evaluations + the finalising step; budget = the most of the recent jobs + 1
-  int budget = 26;
+  // Launches a job needs = its evaluating launches + the finalising step; budget = the most of the recent jobs + 2 (launches
+  // queued behind the finishing one leave at once, ~4 us each).  Opt-in alternative (LSDHIP_TOPUP=1): start with what the
+  // shortest of the recent jobs needed and, while the host waits, watch the chain's progress (TrackSummary::seq, written by
+  // every launch as it starts) and append a launch whenever fewer than two are left in the queue.
+  int budget = 12;
   if (t->recent[0] > 0) {
+    budget = 1 << 30;
+    for (int i = 0; i < 4; i++) if (t->recent[i] > 0 && t->recent[i] < budget) budget = t->recent[i];
+    budget += 1;
+  }
+  // timing events on every 8th job only: two event packets and a host-side event query per job cost ~5 % of a frame; a timed
+  // job runs on the fixed budget, so that the two events bracket all of its launches
+  const bool sample = c->prof_on && ((c->prof_tick++ & 7) == 0);
+  const bool topUp = t->topUp && t->spinWait && !sample;
+  if (!topUp && t->recent[0] > 0) {   // fixed budget: the most of the recent jobs + 2
     budget = 0;
     for (int i = 0; i < 4; i++) if (t->recent[i] > budget) budget = t->recent[i];
     budget += 2;
   }
+  t->jobTag = (t->jobTag % 0x7FFFF) + 1;
+  t->launchOrdinal = 0;
+  t->h_summary->seq = 0;
   int guard = 0;
   int parity = 0, first = 1;
   if (int rc = prof_collect(c)) return rc;
-  // timing events on every 8th job only: two event packets and a host-side event query per job cost ~5 % of a frame
-  const bool sample = c->prof_on && ((c->prof_tick++ & 7) == 0);
   // Persistent kernel (k_track_persist): the levels whose strips fit PT_MAXG workgroups run inside ONE launch; finer levels
   // (if any) continue in the launch-per-evaluation chain from the state it leaves in d_state[0].
   PersistPlan plan;
@@ -2332,7 +2351,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       rc = launch_steps(t, job, budget, &parity, &first);
     }
     if (rc) return rc;
-    if (sample) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
+    if (sample && !topUp) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
     if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) t->enqueueHook(t->enqueueHookUser);
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
@@ -2345,7 +2364,19 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       volatile const int* done = &S->done;
       const auto tStart = std::chrono::steady_clock::now();
       unsigned spins = 0;
+      volatile const int* seqp = &S->seq;
       while (!*done) {
+        if (topUp) {
+          const int sq = *seqp;
+          const int started = (sq >> 12) == t->jobTag ? (sq & 0xFFF) : 0;
+          if (t->launchOrdinal - started < 2 && t->launchOrdinal < 2000) {
+            c->mtx.lock();
+            const int rcu = launch_steps(t, job, 1, &parity, &first);
+            c->mtx.unlock();
+            t->topUps++;
+            if (rcu) return rcu;
+          }
+        }
         if ((++spins & 1023u) == 0) {
           hipError_t q = hipStreamQuery(c->stream);
           if (q == hipSuccess) break;                       // budget consumed (done or not)
