@@ -237,10 +237,10 @@ struct lsdhip_tracker {
   int batch_jobs = 0;             // > 1 while the jobs of a batch are being described
   int cap_override = 0;           // batch tracking: per-job workgroup cap while the jobs of a batch are being described
   int recent[4] = {0, 0, 0, 0};   // evaluating launches of the last jobs: size the launch budget of the next one
-  int specC = 5;                  // trials per launch (LSDHIP_SPEC; 1 = no speculation)
+  int specC = 6;                  // most trials per launch (LSDHIP_SPEC; 1 = no speculation)
+  bool specAuto = true;           // trials per level from the level's size (see track_device); false after set_speculation
   int specCaps[LSD_LEVELS] = {0, 0, 0, 0, 0};    // per-level workgroups per trial (LSDHIP_SPEC_CAPS; 0 = automatic)
-  int specLevel[LSD_LEVELS] = {0, 4, 5, 6, 0};   // per-level trials (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = specC): the retry chains
-                                                 // that end a level are 4-6 evaluations long (profiles/r02_notes.md)
+  int specLevel[LSD_LEVELS] = {0, 0, 0, 0, 0};   // per-level trials (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = automatic / specC)
   int specCap = 104;              // workgroups per trial at the finest level when speculating (0 = grid_cap / 2)
   uint8_t* d_maskSide = nullptr;  // (SPEC_MAX - 1) mask planes of (w >> 1) x (h >> 1) bytes
   size_t maskStride = 0;
@@ -248,6 +248,7 @@ struct lsdhip_tracker {
   TrackSpec spec = {};             // of the job being launched
   int jobTag = 0, launchOrdinal = 0;   // progress reporting of the launch chain (host tops the chain up while it waits)
   int topUps = 0;
+  long long dbgJobs = 0, dbgEnqueued = 0, dbgMisses = 0, dbgWaitNs = 0, dbgLaunchNs = 0;   // LSDHIP_TRACK_DEBUG=1: printed at destroy
   bool topUp = false;                  // LSDHIP_TOPUP=1: start with the shortest recent job's launches and append while waiting
                                        // (measured slower than the fixed budget: the host's launches land late — r02_notes.md)
   int recentChain[4] = {0, 0, 0, 0};   // same, counting only the levels the k_track_step chain ran behind the persistent kernel

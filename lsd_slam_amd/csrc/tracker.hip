@@ -777,20 +777,19 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int max_rows = sc.max_rows;
-  // reject-chain speculation (single jobs): workgroup = (trial `cand`, tile `bx`)
-  const int gridPer = (!BATCH && MODE == TS_FUSED && spec.specGrid > 0) ? spec.specGrid : (int)gridDim.x;
-  const int cand = (int)blockIdx.x / gridPer;
-  const int bx = (int)blockIdx.x - cand * gridPer;
+  // reject-chain speculation (single jobs): workgroup = (trial `cand`, tile `bx`) of the level of the pending evaluation —
+  // fixed below, once the state says which level that is
+  int cand = 0, bx = (int)blockIdx.x;
   const bool leader = blockIdx.x == 0;
   const int cmax = sc.cmax;
   TrackState* next = st2 + (1 - parity);
   const int outp = MODE == TS_EVAL ? parity : 1 - parity;
   const float* sums_in0 = sc.sums + (size_t)parity * cmax * RS_COLS * max_rows;
-  float* sums_out = sc.sums + ((size_t)outp * cmax + cand) * RS_COLS * max_rows;
+  float* sums_out = sc.sums + (size_t)outp * cmax * RS_COLS * max_rows;              // + the trial's slot, below
   const int4* topkey_in0 = sc.topkey + (size_t)parity * cmax * max_rows;
-  int4* topkey_out = sc.topkey + ((size_t)outp * cmax + cand) * max_rows;
+  int4* topkey_out = sc.topkey + (size_t)outp * cmax * max_rows;
   const float* topval_in0 = sc.topval + (size_t)parity * cmax * max_rows * 96;
-  float* topval_out = sc.topval + ((size_t)outp * cmax + cand) * max_rows * 96;
+  float* topval_out = sc.topval + (size_t)outp * cmax * max_rows * 96;
   constexpr int NSLOT = 16;                                  // row slots of the column sums: slot s adds rows s, s + 16, ...
   __shared__ __attribute__((aligned(16))) float s_sumT[LSD_SPEC_MAX][NSLOT][RS_COLS];    // per pending trial: column sums by row slot
   __shared__ float s_subT[LSD_SPEC_MAX][3][32];             // ... K2/K3 contributions of its (up to 3) tail points
@@ -836,15 +835,19 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     if (MODE != TS_EVAL && leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // keep both buffers "done"
     return;
   }
+  const int lvlPending = S.level;
   if (!BATCH && MODE == TS_FUSED) {
-    // the launch is sized for the largest level and the most trials; this one evaluates at S.level (trials 0 ..) or, if the
-    // pending decision ends the level, at S.level - 1 (trial 0 only): workgroups that have no work either way leave before
-    // the finishing phase (whose loads they would only add to everybody else's)
-    const int lvl = S.level;
-    int need = job.lv[lvl].nblocks;
-    if (cand == 0 && S.pending && lvl > job.lastLevel && job.lv[lvl - 1].nblocks > need) need = job.lv[lvl - 1].nblocks;
-    const int tr = (spec.specC > 1 && spec.trials[lvl] > 1) ? spec.trials[lvl] : 1;
-    if (!leader && (bx >= need || cand >= tr || (cand > 0 && !S.pending))) return;
+    // The launch is sized for the level with the most (tiles x trials).  This one either evaluates trials at S.level —
+    // workgroup = (trial, tile) of that level — or, if the pending decision ends the level, the first evaluation of
+    // S.level - 1 (workgroup = tile).  Workgroups that have no work either way leave before the finishing phase (whose loads
+    // they would only add to everybody else's).
+    const int nbl = job.lv[lvlPending].nblocks;
+    const int tr = (spec.specC > 1 && spec.trials[lvlPending] > 1) ? spec.trials[lvlPending] : 1;
+    cand = (int)blockIdx.x / nbl;
+    bx = (int)blockIdx.x - cand * nbl;
+    const bool needTrial = S.pending ? cand < tr : cand == 0;
+    const bool needNext = S.pending && lvlPending > job.lastLevel && (int)blockIdx.x < job.lv[lvlPending - 1].nblocks;
+    if (!leader && !needTrial && !needNext) return;
   }
 
   if (MODE != TS_EVAL && S.pending) {
@@ -1173,7 +1176,11 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   const int level = S.level;
   if (MODE == TS_FUSED && tid == 0) { S.pending = 1; S.numLaunches = S.numLaunches + 1; }
   const int nb = job.lv[level].nblocks;
+  if (!BATCH && MODE == TS_FUSED && level != lvlPending) { cand = 0; bx = (int)blockIdx.x; }   // first evaluation of the next level
   if (bx >= nb || cand >= S.ncand) return;   // workgroup 0 always has work: it publishes the state at the end
+  sums_out += (size_t)cand * RS_COLS * max_rows;
+  topkey_out += (size_t)cand * max_rows;
+  topval_out += (size_t)cand * max_rows * 96;
   const int tile = xcd_tile(bx, nb);
   EvalCtx a;
   make_ctx_dev(job, S, level, a);
@@ -1924,6 +1931,9 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
 }
 extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   if (!t) return;
+  if (getenv("LSDHIP_TRACK_DEBUG") && t->dbgJobs > 0)
+    fprintf(stderr, "TRACKDBG jobs %lld launches enqueued %.2f/job, budget misses %lld, host launch %.1f us/job, host wait %.1f us/job, top-ups %d\n", t->dbgJobs,
+            (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs, t->topUps);
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
 #ifdef LSD_PHASE_TRACE
@@ -2004,8 +2014,9 @@ extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int
   if (!t || trials < 1 || trials > LSD_SPEC_MAX || finestLevelWorkgroups < 0) { lsd_set_error("lsdhip_tracker_set_speculation: trials must be 1..%d", LSD_SPEC_MAX); return LSDHIP_E_ARG; }
   LSD_CTX_LOCK(t->ctx);
   t->specC = trials;
+  t->specAuto = false;                                        // the same number of trials at every level
   if (finestLevelWorkgroups > 0) t->specCap = finestLevelWorkgroups & ~7;
-  for (int l = 0; l < LSD_LEVELS; l++) t->specLevel[l] = 0;   // the same number of trials at every level
+  for (int l = 0; l < LSD_LEVELS; l++) t->specLevel[l] = 0;
   for (int i = 0; i < 4; i++) t->recent[i] = 0;
   return LSDHIP_OK;
 }
@@ -2104,16 +2115,21 @@ static int launch_steps(lsdhip_tracker* t, TrackJob& job, int steps, int* parity
   for (int l = job.lastLevel; l <= job.topLevel; l++) if (job.lv[l].nblocks > grid) grid = job.lv[l].nblocks;
   t->spec.specGrid = 0;
   if (t->spec.specC > 1) {
-    int mt = 1;
-    for (int l = job.lastLevel; l <= job.topLevel; l++) if (t->spec.trials[l] > mt) mt = t->spec.trials[l];
+    // workgroup = (trial, tile) of the level being evaluated: the launch needs the most tiles x trials of any level
+    for (int l = job.lastLevel; l <= job.topLevel; l++) {
+      const int g = job.lv[l].nblocks * (t->spec.trials[l] > 1 ? t->spec.trials[l] : 1);
+      if (g > grid) grid = g;
+    }
     t->spec.specGrid = grid;
-    grid *= mt;
   }
+  const auto tl0 = std::chrono::steady_clock::now();
   for (int i = 0; i < steps; i++) {
     launch_step(t, job, grid, *parity, *first);
     *first = 0;
     *parity ^= 1;
   }
+  t->dbgEnqueued += steps;
+  t->dbgLaunchNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tl0).count();
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }
@@ -2261,17 +2277,25 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   t->spec.specGrid = 0;
   t->spec.wasGoodSide = t->d_maskSide;
   t->spec.maskStride = (unsigned)t->maskStride;
-  for (int l = 0; l < LSD_LEVELS; l++) t->spec.trials[l] = t->specC > 1 ? (t->specLevel[l] > 0 ? t->specLevel[l] : t->specC) : 1;
+  // Trials per launch and workgroups per trial, per level.  Speculation pays where a level is latency-bound, i.e. small: the
+  // automatic policy goes by the level's pixel (or point) count — <= 6 K: 6 trials, <= 24 K: 5, <= 88 K: 4 trials on specCap (104)
+  // workgroups each (multi-pass), larger: one evaluation per launch on the full grid (such levels are work-bound: at
+  // 1280x1024 speculating on level 1 cost 15 % of the frame rate).  An explicit lsdhip_tracker_set_speculation / the
+  // LSDHIP_SPEC_LEVELS / _CAPS environment overrides it.
+  for (int l = 0; l < LSD_LEVELS; l++) t->spec.trials[l] = 1;
   if (t->specC > 1) {
-    // several trials share the chip: fewer workgroups per trial where trials x workgroups would not fit it (the level's
-    // pixels then grid-stride)
     for (int l = job.lastLevel; l <= topLevel; l++) {
       TrackLevel& L = job.lv[l];
-      int cap = t->specCaps[l];
-      if (cap <= 0 && l == job.lastLevel) cap = t->specCap > 0 ? t->specCap : ((t->grid_cap / 2 + 7) & ~7);
-      if (cap > 0 && L.nblocks > cap && L.tilePx == 0) {
+      const long long work = L.npts >= 0 ? L.npts : (long long)L.w * L.h;
+      int trials, cap = t->specCaps[l];
+      if (t->specLevel[l] > 0) trials = t->specLevel[l];
+      else if (!t->specAuto) trials = t->specC;
+      else trials = work <= 6144 ? 6 : (work <= 24576 ? 5 : (work <= 90112 ? 4 : 1));
+      if (trials > t->specC) trials = t->specC;
+      if (cap <= 0 && trials > 1 && (t->specAuto ? work > 24576 : l == job.lastLevel)) cap = t->specCap > 0 ? t->specCap : ((t->grid_cap / 2 + 7) & ~7);
+      t->spec.trials[l] = trials;
+      if (trials > 1 && cap > 0 && L.nblocks > cap && L.tilePx == 0) {
         L.nblocks = cap;
-        const long long work = L.npts >= 0 ? L.npts : (long long)L.w * L.h;
         L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
       }
     }
@@ -2297,6 +2321,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     for (int i = 0; i < 4; i++) if (t->recent[i] > budget) budget = t->recent[i];
     budget += 2;
   }
+  t->dbgJobs++;
   t->jobTag = (t->jobTag % 0x7FFFF) + 1;
   t->launchOrdinal = 0;
   t->h_summary->seq = 0;
@@ -2356,6 +2381,8 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
     // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.
+    const auto tw0 = std::chrono::steady_clock::now();
+    struct WaitClock { lsdhip_tracker* t; std::chrono::steady_clock::time_point t0; ~WaitClock() { t->dbgWaitNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } waitClock_{t, tw0};
     c->mtx.unlock();    // nothing below touches context state until the result is in: let the mapping thread enqueue
     struct Relock { std::recursive_mutex& m; ~Relock() { m.lock(); } };
     {
@@ -2402,6 +2429,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       continue;
     }
     if (S->done) break;
+    t->dbgMisses++;
     HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
     if (S->done == 2) continue;
     if (S->done) break;

@@ -920,7 +920,7 @@ def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip,
 
 @pytest.mark.gpu
 def test_speculation_default_matches_oracle_sequence(oracle, hip):
-    """the library default (5 trials, half the workgroups per trial at level 1) against the oracle over a few frames"""
+    """the library default (4 / 5 / 6 trials at levels 1 / 2 / 3 of a 640x480 frame) against the oracle over a few frames"""
     w, h = 640, 480
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
     kfo, kfg = oracle.Frame(0, frames[0], K), hip.Frame(ctx, 0, frames[0])
@@ -932,7 +932,7 @@ def test_speculation_default_matches_oracle_sequence(oracle, hip):
     tro, trg = oracle.SE3Tracker(w, h, K, mode=oracle.SSE), hip.SE3Tracker(ctx)
     tro.set_max_its(ODOMETRY_ITS)
     trg.set_maxItsPerLvl(ODOMETRY_ITS)
-    assert trg.launch_stats()[1] == 5
+    assert trg.launch_stats()[1] == 6          # most trials per launch; per level by its size
     init = IDENT7.copy()
     for i in range(1, 6):
         fo, fg = oracle.Frame(i, frames[i], K), hip.Frame(ctx, i, frames[i])
