@@ -532,10 +532,30 @@ class SlamLoop {
     numTracked++;
     lastTrackEnd = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     onTrackEnd(lastTrackEnd);
-    if (tracker.diverged) throw Error(LSDHIP_DIVERGED, "SlamLoop: tracking diverged at frame " + std::to_string(frameId_));
+    // SlamSystem::trackFrame (SlamSystem.cpp:946-966): tracking is lost when the tracker diverged, or — once the initialisation
+    // phase is over (more than INITIALIZATION_PHASE_COUNT = 5 keyframes in the graph) — when trackingWasGood is false.  The
+    // frame is then neither mapped nor promoted; doMappingIteration's lost branch (:809-817) finalises the current keyframe if
+    // it has been mapped on at least MIN_NUM_MAPPED = 5 times, discards it otherwise, and invalidates the map.  What follows in
+    // the reference is the relocaliser (out of scope): the loop reports the loss.
+    if (tracker.diverged || (numKeyframesFinished_ > 5 /* INITIALIZATION_PHASE_COUNT */ && !tracker.trackingWasGood)) {
+      trackingLost = true;
+      reference.invalidate();
+      if (map.isValid()) {
+        if (mappedOnKF_ >= 5 /* MIN_NUM_MAPPED */) {
+          map.finalizeKeyFrame();
+          numKeyframesFinished_++;
+          if (onKeyframeFinished) onKeyframeFinished(*keyframe, map);
+        }   // else discardCurrentKeyframe (:428-456): nothing of it is kept
+        map.invalidate();
+      }
+      throw Error(LSDHIP_DIVERGED, std::string("SlamLoop: tracking lost at frame ") + std::to_string(frameId_) +
+                                       (tracker.diverged ? " (diverged)" : " (trackingWasGood false)"));
+    }
     ++sinceKF_;
     bool createNewKeyFrame = kfEvery_ > 0 && sinceKF_ >= kfEvery_;
-    if (kfEvery_ == 0 && keyframe->stats().numMappedOnThisTotal > 5 /* MIN_NUM_MAPPED */) {
+    // numMappedOnThisTotal of the current keyframe = updateKeyframe calls since it was created: counted here, so that the
+    // asynchronous pipeline is not drained every frame by Frame::stats()
+    if (kfEvery_ == 0 && mappedOnKF_ > 5 /* MIN_NUM_MAPPED */) {
       // SlamSystem.cpp:997-1015: dist = translation * meanIdepth; keyframesAll is empty without the pose graph, so
       // minVal = 0.2 * 0.7 (SURVEY.md §8(d) driver notes)
       const float mi = keyframe->meanIdepth();
@@ -544,6 +564,8 @@ class SlamLoop {
     }
     if (createNewKeyFrame) {
       map.finalizeKeyFrame();
+      numKeyframesFinished_++;
+      mappedOnKF_ = 0;
       if (onKeyframeFinished) onKeyframeFinished(*keyframe, map);
       map.createKeyFrame(frame.get());
       keyframe = frame;
@@ -562,6 +584,7 @@ class SlamLoop {
       while ((int)liveQueue_.size() > (liveQueueLength > 1 ? liveQueueLength : 1)) liveQueue_.pop_front();
       std::deque<std::shared_ptr<Frame>> q(liveQueue_.begin(), liveQueue_.end());
       map.updateKeyframe(q);
+      mappedOnKF_++;
       frame->clear_refPixelWasGood();
       lastFrameToKF_ = est;
       numUpdates++;
@@ -574,6 +597,7 @@ class SlamLoop {
   TrackingReference reference;
   std::shared_ptr<Frame> keyframe;
   bool newKeyframe = false;
+  bool trackingLost = false;                         // set before step() throws: SlamSystem::trackingIsGood == false
   long evaluations = 0, launches = 0, numTracked = 0, numUpdates = 0, numTrackedGood = 0;
   long levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};
   double lastTrackEnd = 0;
@@ -590,6 +614,8 @@ class SlamLoop {
   Mat3f K_;
   bool onDevice_;
   int kfEvery_, sinceKF_ = 0, frameId_ = 0;
+  int mappedOnKF_ = 0;            // Frame::numMappedOnThisTotal of the current keyframe
+  int numKeyframesFinished_ = 0;  // keyFrameGraph->keyframesAll.size()
   SE3 lastFrameToKF_;
   std::shared_ptr<Frame> prefetched_;
   const unsigned char* prefetchedSrc_ = nullptr;

@@ -1261,7 +1261,10 @@ struct PropArgs {
   float4* cand;
   int* slotCount;
   int* slots;
-  int* flags;
+  int* flags;      // [0] error (chain storage exhausted), [1] chain entries handed out
+  int* ovfHead;    // per target: newest chain entry or -1
+  int2* ovf;       // (source index, next entry)
+  int ovfCap;
   int w, h;
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
   float R[9], t[3];
@@ -1301,7 +1304,36 @@ __global__ __launch_bounds__(256) void k_prop_candidates(PropArgs a) {
   a.cand[idx] = make_float4(new_idepth, new_var, __int_as_float(a.src.validity[idx]), 0.f);
   int pos = atomicAdd(&a.slotCount[newIDX], 1);
   if (pos < PROP_SLOT_CAP) a.slots[(size_t)newIDX * PROP_SLOT_CAP + pos] = idx;
-  else atomicExch(&a.flags[0], 1);
+  else {
+    // more sources than slots for this target (zoom-out / backward motion): the rest go on a per-target chain
+    const int o = atomicAdd(&a.flags[1], 1);
+    if (o < a.ovfCap) a.ovf[o] = make_int2(idx, atomicExch(&a.ovfHead[newIDX], o));
+    else atomicExch(&a.flags[0], 1);
+  }
+}
+// one step of the reference's per-target merge (DepthMap.cpp:587-640), sources replayed in the order its double loop visits them
+__device__ __forceinline__ void prop_merge(const float4 c, bool& tValid, float& t_idepth, float& t_var, int& t_validity) {
+  float new_idepth = c.x, new_var = c.y;
+  int src_validity = __float_as_int(c.z);
+  if (tValid) {
+    float diff = t_idepth - new_idepth;
+    if (DIFF_FAC_PROP_MERGE * diff * diff > new_var + t_var) {
+      if (new_idepth < t_idepth) return;
+      else tValid = false;
+    }
+  }
+  if (!tValid) {
+    tValid = true;
+    t_idepth = new_idepth; t_var = new_var; t_validity = src_validity;
+  } else {
+    float w = new_var / (t_var + new_var);
+    float merged_new_idepth = w * t_idepth + (1.0f - w) * new_idepth;
+    int merged_validity = src_validity + t_validity;
+    if (merged_validity > VALIDITY_COUNTER_MAX + (VALIDITY_COUNTER_MAX_VARIABLE))
+      merged_validity = VALIDITY_COUNTER_MAX + (VALIDITY_COUNTER_MAX_VARIABLE);
+    float mv = 1.0f / (1.0f / t_var + 1.0f / new_var);
+    t_idepth = merged_new_idepth; t_var = mv; t_validity = merged_validity;
+  }
 }
 // phase B: per target, replay its candidates in source order (row-major, as the reference's double loop visits them)
 __global__ __launch_bounds__(256) void k_prop_resolve(PropArgs a) {
@@ -1320,28 +1352,22 @@ __global__ __launch_bounds__(256) void k_prop_resolve(PropArgs a) {
   bool tValid = false;
   float t_idepth = 0, t_var = 0;
   int t_validity = 0;
-  for (int k = 0; k < n; k++) {
-    float4 c = a.cand[srcs[k]];
-    float new_idepth = c.x, new_var = c.y;
-    int src_validity = __float_as_int(c.z);
-    if (tValid) {
-      float diff = t_idepth - new_idepth;
-      if (DIFF_FAC_PROP_MERGE * diff * diff > new_var + t_var) {
-        if (new_idepth < t_idepth) continue;
-        else tValid = false;
+  if (a.slotCount[i] <= PROP_SLOT_CAP) {
+    for (int k = 0; k < n; k++) prop_merge(a.cand[srcs[k]], tValid, t_idepth, t_var, t_validity);
+  } else {
+    // rare: slots + chain, replayed in ascending source order by repeated selection (no per-thread list needed)
+    int last = -1;
+    while (true) {
+      int best = 0x7fffffff;
+      for (int k = 0; k < PROP_SLOT_CAP; k++) if (srcs[k] > last && srcs[k] < best) best = srcs[k];
+      for (int o = a.ovfHead[i]; o >= 0;) {
+        const int2 e = a.ovf[o];
+        if (e.x > last && e.x < best) best = e.x;
+        o = e.y;
       }
-    }
-    if (!tValid) {
-      tValid = true;
-      t_idepth = new_idepth; t_var = new_var; t_validity = src_validity;
-    } else {
-      float w = new_var / (t_var + new_var);
-      float merged_new_idepth = w * t_idepth + (1.0f - w) * new_idepth;
-      int merged_validity = src_validity + t_validity;
-      if (merged_validity > VALIDITY_COUNTER_MAX + (VALIDITY_COUNTER_MAX_VARIABLE))
-        merged_validity = VALIDITY_COUNTER_MAX + (VALIDITY_COUNTER_MAX_VARIABLE);
-      float mv = 1.0f / (1.0f / t_var + 1.0f / new_var);
-      t_idepth = merged_new_idepth; t_var = mv; t_validity = merged_validity;
+      if (best == 0x7fffffff) break;
+      prop_merge(a.cand[best], tValid, t_idepth, t_var, t_validity);
+      last = best;
     }
   }
   a.dst.valid[i] = tValid ? 1 : 0;
@@ -1413,11 +1439,7 @@ static int alloc_planes(HypPlanes& p, size_t n, void** base_out) {
   return LSDHIP_OK;
 }
 
-extern "C" int lsdhip_depth_create(lsdhip_ctx* c, lsdhip_depthmap** out) {
-  if (!c || !out) return LSDHIP_E_ARG;
-  HIPCHK(hipSetDevice(c->device));
-  lsdhip_depthmap* dm = new lsdhip_depthmap();
-  dm->ctx = c;
+static int depth_create_impl(lsdhip_ctx* c, lsdhip_depthmap* dm) {
   size_t n = (size_t)c->w * c->h;
   int rc = alloc_planes(dm->cur, n, &dm->bases[0]);
   if (rc) return rc;
@@ -1428,6 +1450,8 @@ extern "C" int lsdhip_depth_create(lsdhip_ctx* c, lsdhip_depthmap** out) {
   HIPCHK(hipMemset(dm->d_validSnap, 0, n));
   HIPCHK(hipMalloc((void**)&dm->d_slotCount, n * 4));
   HIPCHK(hipMalloc((void**)&dm->d_slots, n * 4 * PROP_SLOT_CAP));
+  HIPCHK(hipMalloc((void**)&dm->d_ovfHead, n * 4));
+  HIPCHK(hipMalloc((void**)&dm->d_ovf, n * sizeof(int2)));
   HIPCHK(hipMalloc((void**)&dm->d_cand, (n + 64 * OBS_NQ) * 16));   // also the walk queues of k_observe_select (OBS_NQ x qcap items)
   HIPCHK(hipMalloc((void**)&dm->d_qcount, 2 * OBS_NQ * sizeof(int)));
   HIPCHK(hipMemsetAsync(dm->d_qcount, 0, 2 * OBS_NQ * sizeof(int), c->stream));
@@ -1437,16 +1461,39 @@ extern "C" int lsdhip_depth_create(lsdhip_ctx* c, lsdhip_depthmap** out) {
   const int ntiles = ((c->w + 31) / 32) * ((c->h + 7) / 8);   // partials of the fused regulariser: one pair per 32x8 tile
   HIPCHK(hipMalloc((void**)&dm->d_red, (size_t)(2 * (nb > ntiles ? nb : ntiles) + 16) * sizeof(double)));
   HIPCHK(hipHostMalloc((void**)&dm->h_red, 16 * sizeof(double), hipHostMallocMapped));
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_depth_create(lsdhip_ctx* c, lsdhip_depthmap** out) {
+  if (!c || !out) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  LSD_CTX_LOCK(c);
+  lsdhip_depthmap* dm = new lsdhip_depthmap();
+  dm->ctx = c;
+  c->depthmaps.push_back(dm);
+  const int rc = depth_create_impl(c, dm);
+  if (rc) { lsdhip_depth_destroy(dm); return rc; }   // frees whatever was allocated (null pointers are fine)
   *out = dm;
   return LSDHIP_OK;
 }
+// a frame is going away: no depth map may keep it as its active keyframe (a later frame can get the same heap address)
+void lsd_depthmaps_forget_frame(lsdhip_ctx* c, lsdhip_frame* f) {
+  for (lsdhip_depthmap* dm : c->depthmaps)
+    if (dm->activeKeyFrame == f) { dm->activeKeyFrame = nullptr; dm->activeKeyFrameIsReactivated = false; }
+}
 extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
   if (!dm) return;
+  {
+    LSD_CTX_LOCK(dm->ctx);
+    auto& v = dm->ctx->depthmaps;
+    for (size_t i = 0; i < v.size(); i++) if (v[i] == dm) { v.erase(v.begin() + i); break; }
+  }
   (void)hipSetDevice(dm->ctx->device);
   (void)hipStreamSynchronize(dm->ctx->stream);
   for (int i = 0; i < 3; i++) (void)hipFree(dm->bases[i]);  // plane pointers get swapped around; free the arenas
   (void)hipFree(dm->d_slotCount);
   (void)hipFree(dm->d_slots);
+  (void)hipFree(dm->d_ovfHead);
+  (void)hipFree(dm->d_ovf);
   (void)hipFree(dm->d_cand);
   (void)hipFree(dm->d_qcount);
   (void)hipFree(dm->d_flags);
@@ -1595,7 +1642,8 @@ static void prepare_stereo(lsdhip_depthmap* dm, lsdhip_frame* fr, StereoRef& s) 
   for (int i = 0; i < 9; i++) R2f[i] = (float)R2[i] * (float)thisToOther.s;
   for (int i = 0; i < 3; i++) { s.row0[i] = R2f[i * 3 + 0]; s.row1[i] = R2f[i * 3 + 1]; s.row2[i] = R2f[i * 3 + 2]; }
   s.image = fr->d_image[0];
-  s.parentIsKF = (fr->trackingParent == dm->activeKeyFrame) ? 1 : 0;
+  // (pointer AND id: a destroyed frame's heap address can be handed out again)
+  s.parentIsKF = (fr->trackingParent == dm->activeKeyFrame && fr->trackingParentID == dm->activeKeyFrame->id) ? 1 : 0;
   s.wasGood = fr->wasGoodValid ? fr->d_wasGood : nullptr;
   s.id = fr->id;
   s.initialTrackedResidual = fr->initialTrackedResidual;
@@ -1636,11 +1684,13 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
     const size_t need = refsBytes + sizeof(int) * byIDCount;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (need > dm->stage_bytes) {
-      if (dm->h_stage) HIPCHK(hipHostFree(dm->h_stage));
-      if (dm->d_stage) HIPCHK(hipFree(dm->d_stage));
-      dm->stage_bytes = need > 65536 ? need * 2 : 65536;
-      HIPCHK(hipHostMalloc((void**)&dm->h_stage, dm->stage_bytes, hipHostMallocDefault));
-      HIPCHK(hipMalloc((void**)&dm->d_stage, dm->stage_bytes));
+      if (dm->h_stage) { (void)hipHostFree(dm->h_stage); dm->h_stage = nullptr; }   // never leave a freed pointer behind
+      if (dm->d_stage) { (void)hipFree(dm->d_stage); dm->d_stage = nullptr; }
+      dm->stage_bytes = 0;
+      const size_t want = need > 65536 ? need * 2 : 65536;
+      HIPCHK(hipHostMalloc((void**)&dm->h_stage, want, hipHostMallocDefault));
+      HIPCHK(hipMalloc((void**)&dm->d_stage, want));
+      dm->stage_bytes = want;
     }
     StereoRef* hrefs = (StereoRef*)dm->h_stage;
     int* byID = (int*)(dm->h_stage + refsBytes);
@@ -1740,11 +1790,14 @@ static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNo
   a.oldKFImage = old->d_image[0];
   a.newKFImage = nk->d_image[0];
   a.newKFMaxGrad = nk->d_maxgrad;
-  a.trackingWasGood = (nk->trackingParent == old && nk->wasGoodValid) ? nk->d_wasGood : nullptr;
+  a.trackingWasGood = (nk->trackingParent == old && nk->trackingParentID == old->id && nk->wasGoodValid) ? nk->d_wasGood : nullptr;
   a.cand = dm->d_cand;
   a.slotCount = dm->d_slotCount;
   a.slots = dm->d_slots;
   a.flags = dm->d_flags;
+  a.ovfHead = dm->d_ovfHead;
+  a.ovf = dm->d_ovf;
+  a.ovfCap = (int)n;
   a.w = c->w; a.h = c->h;
   const LevelIntr& in = c->intr[0];
   a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
@@ -1760,6 +1813,7 @@ static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNo
   for (int i = 0; i < 3; i++) a.t[i] = (float)oldToNew.t[i];
 
   HIPCHK(hipMemsetAsync(dm->d_slotCount, 0, n * 4, c->stream));
+  HIPCHK(hipMemsetAsync(dm->d_ovfHead, 0xFF, n * 4, c->stream));
   HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, c->stream));
   hipLaunchKernelGGL(k_prop_candidates, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_prop_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
@@ -1768,7 +1822,7 @@ static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNo
     HIPCHK(hipMemcpyAsync(&flag, dm->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (flag) {
-      lsd_set_error("propagateDepth: more than %d source hypotheses mapped to one target pixel", PROP_SLOT_CAP);
+      lsd_set_error("propagateDepth: overflow chains exhausted (more than w*h sources beyond %d per target)", PROP_SLOT_CAP);
       return LSDHIP_E_CAPACITY;
     }
   }   // otherwise the flag travels with the rescale sums of createKeyFrame (one synchronisation for the whole call)

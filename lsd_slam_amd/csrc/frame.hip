@@ -391,6 +391,7 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   for (void* p : c->free_arenas) (void)hipFree(p);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->h_slots) (void)hipHostFree(c->h_slots);
+  if (c->d_gtStage) (void)hipFree(c->d_gtStage);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   (void)hipStreamDestroy(c->stream);
@@ -595,10 +596,12 @@ extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_ho
   lsdhip_frame* f = nullptr;
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(f->d_gray, gray_host, (size_t)c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  hipError_t e = hipMemcpyAsync(f->d_gray, gray_host, (size_t)c->w * c->h, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create: upload failed: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
   rc = lsd_frame_build_pyramids(f, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
-  HIPCHK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
+  e = hipStreamSynchronize(c->stream);  // the host buffer may be reused by the caller
+  if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
   *out = f;
   return LSDHIP_OK;
 }
@@ -615,6 +618,7 @@ extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   }
   if (f->pendStats >= 0) c->slot_stats_owner[f->pendStats] = nullptr;
   if (f->pendRescale >= 0) c->slot_rescale_owner[f->pendRescale] = nullptr;
+  lsd_depthmaps_forget_frame(c, f);   // a depth map whose active keyframe this is becomes "no active keyframe"
   delete f;
 }
 extern "C" int lsdhip_frame_id(lsdhip_frame* f) { return f ? f->id : -1; }
@@ -643,14 +647,14 @@ extern "C" int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_hos
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
   int n0 = c->w * c->h;
-  float* d_depth = nullptr;
-  HIPCHK(hipMalloc((void**)&d_depth, (size_t)n0 * 4));
+  // staging plane kept by the context (ground-truth depth arrives once per keyframe in the GT-initialised modes)
+  if (!c->d_gtStage) HIPCHK(hipMalloc((void**)&c->d_gtStage, (size_t)n0 * 4));
+  float* d_depth = c->d_gtStage;
   HIPCHK(hipMemcpyAsync(d_depth, depth_host, (size_t)n0 * 4, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_set_depth_gt, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, d_depth, f->d_maxgrad, f->d_idepth[0],
                      f->d_idepthVar[0], c->w, c->h, cov_scale, c->params.minUseGrad);
   int rc = lsd_frame_build_idepth_pyramid(f);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipFree(d_depth));
+  HIPCHK(hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
   return rc;
 }
 extern "C" int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* id, const float* var) {

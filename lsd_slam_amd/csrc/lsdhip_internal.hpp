@@ -168,6 +168,8 @@ struct lsdhip_ctx {
   // recycled frame arenas (the FrameMemory idea, C/DataStructures/FrameMemory.cpp:67-127, for device buffers);
   // reuse is stream-ordered, so no synchronisation is needed when a frame dies
   std::vector<void*> free_arenas;
+  float* d_gtStage = nullptr;                        // w x h floats: staging of lsdhip_frame_set_depth_gt
+  std::vector<struct lsdhip_depthmap*> depthmaps;   // alive on this context: a destroyed frame is unhooked from them
   size_t arena_bytes = 0;
 };
 
@@ -307,6 +309,8 @@ struct lsdhip_depthmap {
   // K7 scratch
   int* d_slotCount = nullptr;      // per target
   int* d_slots = nullptr;          // per target x capacity source indices
+  int* d_ovfHead = nullptr;        // per target: head of the chain of sources beyond the capacity (-1: none)
+  int2* d_ovf = nullptr;           // chain entries (source index, next entry), w*h of them
   float4* d_cand = nullptr;        // per source candidate (new_idepth, new_var, validity as float bits, target)
   int* d_flags = nullptr;          // overflow flag etc.
   double* d_red = nullptr;         // reduction scratch (sum, count)
@@ -332,6 +336,7 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);
+void lsd_depthmaps_forget_frame(lsdhip_ctx* c, lsdhip_frame* f);   // depthmap.hip: unhook a frame that is being destroyed
 int lsd_prof_collect(lsdhip_ctx* c);
 int lsd_frame_resolve(lsdhip_frame* f);        // reads the frame's deferred results (synchronises the stream if any)
 int lsd_ctx_take_slot(lsdhip_ctx* c);          // next slot of the ring (resolving whoever still waits on it)

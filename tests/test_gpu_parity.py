@@ -502,6 +502,30 @@ def test_propagate_and_create_keyframe(oracle, hip, use_mask):
     assert nkg.stats()["numPoints"] == nko.stats()["numPoints"]
 
 
+def test_propagate_zoom_out_more_sources_than_slots(oracle, hip):
+    """propagateDepth when the new keyframe looks at the scene from much further away: up to ~16 source hypotheses land on one
+    target pixel, more than the 8 slots a target has — the rest travel on per-target chains and the merge still replays them in
+    the reference's order (bit-exact; round 1 reported LSDHIP_E_CAPACITY here)."""
+    w, h = 320, 240
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4)
+    kfo, kfg, dmo, dmg = _noisy_map(oracle, hip, ctx, frames, depth0, K, w, h, sigma=0.02, seed=33)
+    dmo.stage("regularize")
+    dmg.stage("regularize")
+    fo, fg = oracle.Frame(2, frames[2], K), hip.Frame(ctx, 2, frames[2])
+    # camera of the new keyframe 3.5 depth units behind the old one (scene depth ~2): image of the old map shrinks ~2.7x
+    back = oracle.se3_exp(np.array([0.0, 0.0, -3.5, 0.0, 0.0, 0.0]))
+    sim3 = np.concatenate([back, [1.0]])
+    fo.set_pose(sim3, kfo, 0.5)
+    fg.setPose(sim3, kfg, 0.5)
+    n_src = int((dmo.get()["isValid"] > 0).sum())
+    dmo.stage("propagate", [fo])
+    dmg.stage("propagate", [fg])
+    go, gg = dmo.get(), dmg.currentDepthMap()
+    n_dst = int((go["isValid"] > 0).sum())
+    assert n_dst > 1000 and n_src > 8 * n_dst, (n_src, n_dst)     # more than 8 sources per target on average: the chains are in use
+    assert_hyp_equal(gg, go, "propagateDepth (zoom-out)")
+
+
 def test_finalize_and_reactivation(oracle, hip):
     w, h = 320, 240
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 3)
