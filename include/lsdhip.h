@@ -288,11 +288,26 @@ int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame** refs, int 
 int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* idepthVar_dev);
 /* device-to-device copy ordered on the context's stream (no host synchronisation): the root's own share of a keyframe gather */
 int lsdhip_ctx_copy_dev(lsdhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+/* device buffers on the context's device for callers that do not link the HIP runtime themselves (the C++ drivers: staging
+ * of halo rows, keyframe rings); free waits for the context's stream */
+int lsdhip_ctx_alloc_dev(lsdhip_ctx* ctx, size_t bytes, void** out_dev);
+int lsdhip_ctx_free_dev(lsdhip_ctx* ctx, void* dev);
 /* (returns after the copies have finished; on an asynchronous context — lsdhip_ctx_set_async — after they are queued) */
 /* rows [row0, row0+nrows) of the eight hypothesis planes <-> one packed device buffer (29 bytes per pixel, plane after
  * plane in the order of lsdhip_hypothesis): halo exchange of the row-band decomposition.
  * to_map != 0 copies the buffer into the map. */
 int lsdhip_depth_copy_rows_dev(lsdhip_depthmap* dm, int row0, int nrows, void* packed_dev, int to_map);
+/* The same for several row ranges in ONE launch, ordered on the context's stream (no host synchronisation in asynchronous
+ * contexts): each item copies nrows rows from its source to its destination, where a side is either rows [row0, row0 + nrows)
+ * of a depth map of this context (map != NULL) or a packed device buffer (map == NULL, layout as above).  Map -> map refreshes the
+ * halo of a window from the window that owns those rows when both live on one GPU; map -> packed / packed -> map bracket the
+ * ncclSend / ncclRecv of the multi-GPU exchange. */
+typedef struct lsdhip_row_copy {
+  lsdhip_depthmap* src_map; int src_row0; void* src_packed;
+  lsdhip_depthmap* dst_map; int dst_row0; void* dst_packed;
+  int nrows;
+} lsdhip_row_copy;
+int lsdhip_depth_copy_rows_batch(lsdhip_ctx* c, int n, const lsdhip_row_copy* items);
 /* timing fields DepthMap keeps public (DepthMap.h:86-93): msUpdate, msCreate, msFinalize, msObserve, msRegularize,
  * msPropagate, msFillHoles, msSetDepth (exponential moving averages, ms) */
 int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);

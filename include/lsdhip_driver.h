@@ -67,6 +67,28 @@ int lsdloop_comm_destroy(lsdloop* l);
 int lsdloop_gather_keyframes(lsdloop* l, int count, int root, float* recv_dev, long long stride_floats);
 void* lsdloop_ctx(lsdloop* l);   /* the lsdhip_ctx* the loop runs on (prof hooks, stream) */
 const char* lsdloop_last_error(void);
+/* ---- row-band decomposition of the regulariser (BASELINE.json configs[4]) ----------------------------
+ * `world` bands over an H-row map; this process holds bands [first_band, first_band + n_local) as windows of
+ * lsdband_window_rows() rows on `device` (index arithmetic: lsd_slam_amd/bands.py BandPlan).  lsdband_run queues `passes`
+ * fused fill-holes + regularise passes over every local window with a halo refresh between passes and returns without
+ * waiting: windows of this process refresh each other with one map -> map copy launch, rows of other processes travel packed
+ * through ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the context's stream (lsdband_comm_init: communicator over
+ * processes from an ncclUniqueId, lsdloop_comm_unique_id makes one).  hyp rows use lsdhip_hypothesis (32 bytes per pixel). */
+typedef struct lsdband lsdband;
+int lsdband_create(int device, int w, int H, int world, int first_band, int n_local, lsdband** out);
+void lsdband_destroy(lsdband* b);
+int lsdband_window_rows(const lsdband* b);
+int lsdband_layout(const lsdband* b, int band, int out4[4]);   /* owned [y0, y1), window [a, b) */
+int lsdband_load(lsdband* b, int local, const void* hyp_window, const float* maxgrad_window);
+int lsdband_get(lsdband* b, int local, void* hyp_window_out);   /* synchronises */
+int lsdband_comm_init(lsdband* b, const void* unique_id128, int nprocs, int proc, const int* proc_of_band);
+int lsdband_run(lsdband* b, int passes);
+int lsdband_synchronize(lsdband* b);
+long long lsdband_halo_bytes_per_pass(const lsdband* b);
+/* test hook: windows of this process also exchange through the packed path (pack launch, device copy in place of
+ * ncclSend / ncclRecv, unpack launch) — RCCL refuses two ranks on one GPU, so this is how a one-GPU box exercises it */
+int lsdband_set_packed_exchange(lsdband* b, int on);
+
 #ifdef __cplusplus
 }
 #endif

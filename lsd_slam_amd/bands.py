@@ -183,6 +183,80 @@ class BandRegularizer:
         return out
 
 
+class NativeBandRegularizer:
+    """The same decomposition run by the C++ loop (liblsdhip_driver.so, `lsdband_*`): every window's pass and every halo
+    refresh is queued on the context's stream and nothing synchronises the host between passes.  Windows of this process
+    refresh each other with one map -> map copy launch per pass; rows owned by other processes travel packed through RCCL
+    (grouped ncclSend / ncclRecv on the same stream).  `ranks`: the consecutive bands this process holds."""
+
+    def __init__(self, w, H, world, ranks, device=0):
+        import ctypes as C
+        from . import driver
+        self.C, self.L = C, driver.lib()
+        self.w, self.H, self.world, self.ranks = w, H, world, list(ranks)
+        assert self.ranks == list(range(self.ranks[0], self.ranks[0] + len(self.ranks)))
+        h = C.c_void_p()
+        driver._check(self.L.lsdband_create(device, w, H, world, self.ranks[0], len(self.ranks), C.byref(h)))
+        self.h_ = h
+        self.window_rows = self.L.lsdband_window_rows(h)
+        self.plan = BandPlan(H, world)
+        assert self.plan.window_rows == self.window_rows
+        for r in range(world):      # the C++ index arithmetic is the Python plan's
+            out = (C.c_int * 4)()
+            driver._check(self.L.lsdband_layout(h, r, out))
+            assert (out[0], out[1]) == self.plan.owned[r] and (out[2], out[3]) == self.plan.window[r], (r, list(out))
+        self._check = driver._check
+
+    def comm_init(self, unique_id, nprocs, proc, proc_of_band):
+        C = self.C
+        arr = (C.c_int * self.world)(*proc_of_band)
+        uid = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._check(self.L.lsdband_comm_init(self.h_, uid, nprocs, proc, arr))
+
+    def load(self, hyp_full, maxgrad_full):
+        from .capi import HYP_DTYPE
+        for i, r in enumerate(self.ranks):
+            a, b = self.plan.window[r]
+            hyp = np.ascontiguousarray(hyp_full[a:b], dtype=HYP_DTYPE)
+            mg = np.ascontiguousarray(maxgrad_full[a:b], dtype=np.float32)
+            self._check(self.L.lsdband_load(self.h_, i, hyp.ctypes.data, mg.ctypes.data))
+
+    def run(self, passes):
+        self._check(self.L.lsdband_run(self.h_, int(passes)))
+
+    def synchronize(self):
+        self._check(self.L.lsdband_synchronize(self.h_))
+
+    def set_packed_exchange(self, on):
+        """test hook: local windows exchange through pack -> copy -> unpack (the multi-GPU wire format) instead of map -> map"""
+        self._check(self.L.lsdband_set_packed_exchange(self.h_, int(on)))
+
+    def halo_bytes_per_pass(self):
+        return int(self.L.lsdband_halo_bytes_per_pass(self.h_))
+
+    def owned_rows(self):
+        from .capi import HYP_DTYPE
+        out = {}
+        for i, r in enumerate(self.ranks):
+            buf = np.zeros((self.window_rows, self.w), HYP_DTYPE)
+            self._check(self.L.lsdband_get(self.h_, i, buf.ctypes.data))
+            a = self.plan.window[r][0]
+            y0, y1 = self.plan.owned[r]
+            out[r] = buf[y0 - a:y1 - a]
+        return out
+
+    def close(self):
+        if self.h_:
+            self.L.lsdband_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def synth_s3(w, h, seed=0xC5):
     """Scene S3: hypothesis planes generated directly — validity Bernoulli(0.3) clustered along
     edges of a blocky pattern, idepth = 1/Z + N(0, 0.02^2), idepth_var in U[1e-4, 0.05], validity_counter in {0..50},

@@ -97,6 +97,9 @@ def _signatures():
         "lsdhip_tracker_get_settings": (i, [vp, C.POINTER(TrackerSettings)]),
         "lsdhip_tracker_set_settings": (i, [vp, C.POINTER(TrackerSettings)]),
         "lsdhip_tracker_set_persistent": (i, [vp, i]),
+        "lsdhip_depth_copy_rows_batch": (i, [vp, i, vp]),
+        "lsdhip_ctx_alloc_dev": (i, [vp, C.c_size_t, vp]),
+        "lsdhip_ctx_free_dev": (i, [vp, vp]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
         "lsdhip_tracker_launch_stats": (i, [vp, vp]),

@@ -2136,7 +2136,7 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
     default: return LSDHIP_E_ARG;
   }
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));   // asynchronous contexts: ordered on the stream
   return LSDHIP_OK;
 }
 
@@ -2174,6 +2174,90 @@ extern "C" int lsdhip_depth_copy_rows_dev(lsdhip_depthmap* dm, int row0, int nro
     p += bytes;
   }
   HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+
+// Several row ranges in ONE launch: map rows -> map rows of another window (halo refresh between windows that live on the same
+// GPU), map rows -> packed buffer (before an ncclSend), packed buffer -> map rows (after an ncclRecv).  Everything is ordered
+// on the context's stream; nothing synchronises the host.
+struct CopyPlanes { char* p[8]; };
+struct CopyItem { CopyPlanes src, dst; int npx; };
+#define LSD_COPY_ITEMS 16
+struct CopyBatch { CopyItem it[LSD_COPY_ITEMS]; };
+__global__ __launch_bounds__(256) void k_copy_rows(CopyBatch b, int vec) {
+  // the item is picked by blockIdx.y: its 16 plane pointers and its size are read from the kernel-argument segment directly
+  // (indexing the by-value struct with a runtime index would copy it to scratch)
+  typedef const unsigned long long __attribute__((address_space(4))) cu64;
+  cu64* q = (cu64*)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)blockIdx.y * (sizeof(CopyItem) / 8);
+  const char* s0 = (const char*)q[0]; const char* s1 = (const char*)q[1]; const char* s2 = (const char*)q[2]; const char* s3 = (const char*)q[3];
+  const char* s4 = (const char*)q[4]; const char* s5 = (const char*)q[5]; const char* s6 = (const char*)q[6]; const char* s7 = (const char*)q[7];
+  char* d0 = (char*)q[8]; char* d1 = (char*)q[9]; char* d2 = (char*)q[10]; char* d3 = (char*)q[11];
+  char* d4 = (char*)q[12]; char* d5 = (char*)q[13]; char* d6 = (char*)q[14]; char* d7 = (char*)q[15];
+  const int npx = (int)(unsigned)q[16];
+  if (vec) {   // 4 pixels per lane: one 4-byte word of the validity plane, one 16-byte vector of each 4-byte plane
+    const int n4 = npx >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+      const unsigned v0 = ((const unsigned*)s0)[i];
+      const uint4 v1 = ((const uint4*)s1)[i], v2 = ((const uint4*)s2)[i], v3 = ((const uint4*)s3)[i], v4 = ((const uint4*)s4)[i];
+      const uint4 v5 = ((const uint4*)s5)[i], v6 = ((const uint4*)s6)[i], v7 = ((const uint4*)s7)[i];
+      ((unsigned*)d0)[i] = v0;
+      ((uint4*)d1)[i] = v1; ((uint4*)d2)[i] = v2; ((uint4*)d3)[i] = v3; ((uint4*)d4)[i] = v4;
+      ((uint4*)d5)[i] = v5; ((uint4*)d6)[i] = v6; ((uint4*)d7)[i] = v7;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+      d0[i] = s0[i];
+      ((unsigned*)d1)[i] = ((const unsigned*)s1)[i]; ((unsigned*)d2)[i] = ((const unsigned*)s2)[i]; ((unsigned*)d3)[i] = ((const unsigned*)s3)[i];
+      ((unsigned*)d4)[i] = ((const unsigned*)s4)[i]; ((unsigned*)d5)[i] = ((const unsigned*)s5)[i]; ((unsigned*)d6)[i] = ((const unsigned*)s6)[i];
+      ((unsigned*)d7)[i] = ((const unsigned*)s7)[i];
+    }
+  }
+}
+static_assert(sizeof(CopyItem) == 17 * 8, "k_copy_rows reads a CopyItem as 17 quadwords");
+static bool copy_planes_of(lsdhip_ctx* c, lsdhip_depthmap* dm, int row0, void* packed, int nrows, CopyPlanes& out) {
+  const size_t px = (size_t)nrows * c->w;
+  if (dm) {
+    if (dm->ctx != c || row0 < 0 || row0 + nrows > c->h) return false;
+    const size_t off = (size_t)row0 * c->w;
+    void* planes[8] = {dm->cur.valid, dm->cur.blacklisted, dm->cur.nextID, dm->cur.validity, dm->cur.idepth, dm->cur.var, dm->cur.idepth_s, dm->cur.var_s};
+    for (int k = 0; k < 8; k++) out.p[k] = (char*)planes[k] + off * (k == 0 ? 1 : 4);
+  } else {
+    if (!packed) return false;
+    char* p = (char*)packed;
+    for (int k = 0; k < 8; k++) { out.p[k] = p; p += px * (k == 0 ? 1 : 4); }
+  }
+  return true;
+}
+extern "C" int lsdhip_depth_copy_rows_batch(lsdhip_ctx* c, int n, const lsdhip_row_copy* items) {
+  if (!c || n < 0 || (n > 0 && !items)) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  for (int base = 0; base < n; base += LSD_COPY_ITEMS) {
+    CopyBatch b;
+    memset(&b, 0, sizeof(b));
+    const int m = n - base < LSD_COPY_ITEMS ? n - base : LSD_COPY_ITEMS;
+    int maxpx = 0, vec = 1;
+    for (int i = 0; i < m; i++) {
+      const lsdhip_row_copy& r = items[base + i];
+      if (r.nrows <= 0 || !copy_planes_of(c, r.src_map, r.src_row0, r.src_packed, r.nrows, b.it[i].src) ||
+          !copy_planes_of(c, r.dst_map, r.dst_row0, r.dst_packed, r.nrows, b.it[i].dst)) {
+        lsd_set_error("lsdhip_depth_copy_rows_batch: item %d is not a row range of a depth map of this context / a packed buffer", base + i);
+        return LSDHIP_E_ARG;
+      }
+      b.it[i].npx = r.nrows * c->w;
+      if (b.it[i].npx > maxpx) maxpx = b.it[i].npx;
+      if (b.it[i].npx & 3) vec = 0;
+      for (int k = 0; k < 8; k++)
+        if (((uintptr_t)b.it[i].src.p[k] | (uintptr_t)b.it[i].dst.p[k]) & (k == 0 ? 3 : 15)) vec = 0;
+    }
+    const int per = vec ? maxpx / 4 : maxpx;
+    int gx = (per + 255) / 256;
+    if (gx > 512) gx = 512;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_copy_rows, dim3(gx, m), dim3(256), 0, c->stream, b, vec);
+  }
+  HIPCHK(hipGetLastError());
+  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
 }
 

@@ -398,6 +398,20 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   delete c;
 }
 extern "C" void* lsdhip_ctx_stream(lsdhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int lsdhip_ctx_alloc_dev(lsdhip_ctx* c, size_t bytes, void** out) {
+  if (!c || !out || bytes == 0) return LSDHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(out, bytes));
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_free_dev(lsdhip_ctx* c, void* p) {
+  if (!c) return LSDHIP_E_ARG;
+  if (!p) return LSDHIP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(p));
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
   if (!c) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);

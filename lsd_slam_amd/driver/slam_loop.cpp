@@ -272,3 +272,223 @@ extern "C" int lsdloop_gather_keyframes(lsdloop* l, int count, int root, float* 
 }
 extern "C" long long lsdloop_keyframes_exported(lsdloop* l) { return l ? l->ring_count : -1; }
 extern "C" void* lsdloop_ctx(lsdloop* l) { return l ? (void*)l->ctx->handle() : nullptr; }
+
+// =====================================================================================================================
+// Row-band decomposition of the depth-map regulariser (BASELINE.json configs[4]: 3840x2160 maps tiled
+// across 8 GPUs).  The index arithmetic is lsd_slam_amd/bands.py's BandPlan (the CPU tests check both against each other);
+// this is the native loop: every window's pass and every halo refresh is queued on the context's stream, nothing
+// synchronises the host between passes.
+//   * windows held by this process refresh each other's halo rows with ONE map -> map copy launch per pass;
+//   * rows owned by another process travel packed (29 B per pixel): one pack launch, ncclGroupStart / ncclSend / ncclRecv /
+//     ncclGroupEnd on the same stream, one unpack launch;
+//   * not done yet: issuing a window's boundary tile rows first and running the exchange on a second stream under the interior
+//     rows (needs a multi-GPU box to measure; on one GPU the exchange is one 10 us launch per pass).
+// One pass = regularizeDepthMapFillHoles + regularizeDepthMap(false, VAL_SUM_MIN_FOR_KEEP) (C/DepthEstimation/DepthMap.cpp:
+// 656-720, :758-880), the fused launch behind lsdhip_depth_stage(dm, 5).
+namespace {
+const int BAND_HALO_TOP = 5, BAND_HALO_BOTTOM = 4, BAND_PACK_BYTES = 29;
+struct BandSeg { int peer, row0, nrows; };   // global rows [row0, row0 + nrows) exchanged with band `peer`
+}
+struct lsdband {
+  int device = 0, w = 0, H = 0, world = 0, first = 0, nlocal = 0, window_rows = 0;
+  std::vector<std::pair<int, int>> owned, window;   // per band: [y0, y1) and [a, b)
+  lsdhip_ctx* ctx = nullptr;
+  std::vector<lsdhip_frame*> kf;
+  std::vector<lsdhip_depthmap*> dm;
+  // communicator over PROCESSES (one per GPU); band r lives in process proc_of[r]
+  NcclComm comm = nullptr;
+  int nprocs = 1, proc = 0;
+  std::vector<int> proc_of;
+  std::vector<char*> sendbuf, recvbuf;   // one packed device buffer per remote segment
+  long long passes_run = 0;
+  bool packedLocal = false;              // test hook: windows of this process exchange through pack -> copy -> unpack as well
+  std::vector<BandSeg> recv_list(int r) const {
+    std::vector<BandSeg> out;
+    const int a = window[r].first, b = window[r].second;
+    for (int s = 0; s < world; s++) {
+      if (s == r) continue;
+      const int lo = std::max(a, owned[s].first), hi = std::min(b, owned[s].second);
+      if (hi > lo) out.push_back({s, lo, hi - lo});
+    }
+    return out;
+  }
+  bool local(int r) const { return r >= first && r < first + nlocal; }
+};
+
+extern "C" int lsdband_create(int device, int w, int H, int world, int first_band, int n_local, lsdband** out) {
+  if (!out || w <= 0 || H <= 0 || world < 1 || first_band < 0 || n_local < 1 || first_band + n_local > world || (H % 16) != 0) return LSDHIP_E_ARG;
+  lsdband* b = new lsdband();
+  b->device = device; b->w = w; b->H = H; b->world = world; b->first = first_band; b->nlocal = n_local;
+  const int base = H / world, extra = H % world;
+  int y = 0, need = 0;
+  for (int r = 0; r < world; r++) {
+    const int n = base + (r < extra ? 1 : 0);
+    if (n < 1) { delete b; g_err = "lsdband_create: more bands than rows"; return LSDHIP_E_ARG; }
+    b->owned.push_back({y, y + n});
+    y += n;
+    need = std::max(need, n + BAND_HALO_TOP + BAND_HALO_BOTTOM);
+  }
+  b->window_rows = std::min(H, (need + 15) / 16 * 16);
+  for (int r = 0; r < world; r++) {
+    const int a = std::min(std::max(b->owned[r].first - BAND_HALO_TOP, 0), H - b->window_rows);
+    b->window.push_back({a, a + b->window_rows});
+  }
+  b->proc_of.assign(world, 0);
+  const float K4[4] = {0.5f * w, 0.5f * w, 0.5f * w, 0.5f * b->window_rows};   // unused by the regulariser
+  int rc = lsdhip_ctx_create(device, w, b->window_rows, K4, nullptr, &b->ctx);
+  if (rc == LSDHIP_OK) rc = lsdhip_ctx_set_async(b->ctx, 1);
+  std::vector<uint8_t> zeros((size_t)w * b->window_rows, 0);
+  for (int i = 0; i < n_local && rc == LSDHIP_OK; i++) {
+    lsdhip_frame* f = nullptr;
+    lsdhip_depthmap* d = nullptr;
+    rc = lsdhip_frame_create(b->ctx, first_band + i, zeros.data(), &f);
+    if (rc == LSDHIP_OK) { b->kf.push_back(f); rc = lsdhip_depth_create(b->ctx, &d); }
+    if (rc == LSDHIP_OK) b->dm.push_back(d);
+  }
+  if (rc != LSDHIP_OK) { g_err = lsdhip_last_error(); lsdband_destroy(b); return rc; }
+  *out = b;
+  return LSDHIP_OK;
+}
+extern "C" void lsdband_destroy(lsdband* b) {
+  if (!b) return;
+  if (b->ctx) (void)lsdhip_ctx_synchronize(b->ctx);
+  if (b->comm && rccl().ok) (void)rccl().CommDestroy(b->comm);
+  for (char* p : b->sendbuf) if (p) (void)lsdhip_ctx_free_dev(b->ctx, p);
+  for (char* p : b->recvbuf) if (p) (void)lsdhip_ctx_free_dev(b->ctx, p);
+  for (auto* d : b->dm) lsdhip_depth_destroy(d);
+  for (auto* f : b->kf) lsdhip_frame_destroy(f);
+  if (b->ctx) lsdhip_ctx_destroy(b->ctx);
+  delete b;
+}
+extern "C" int lsdband_window_rows(const lsdband* b) { return b ? b->window_rows : -1; }
+extern "C" int lsdband_layout(const lsdband* b, int band, int out4[4]) {
+  if (!b || !out4 || band < 0 || band >= b->world) return LSDHIP_E_ARG;
+  out4[0] = b->owned[band].first; out4[1] = b->owned[band].second; out4[2] = b->window[band].first; out4[3] = b->window[band].second;
+  return LSDHIP_OK;
+}
+// rows [a, b) of the full map for local window `local`: hypotheses in the reference's 32-byte AoS layout + maxGradients
+extern "C" int lsdband_load(lsdband* b, int local, const void* hyp_window, const float* maxgrad_window) {
+  if (!b || local < 0 || local >= b->nlocal || !hyp_window || !maxgrad_window) return LSDHIP_E_ARG;
+  int rc = lsdhip_frame_set_maxgrad(b->kf[local], maxgrad_window);
+  if (rc == LSDHIP_OK) rc = lsdhip_depth_upload(b->dm[local], b->kf[local], (const lsdhip_hypothesis*)hyp_window, 0);
+  if (rc != LSDHIP_OK) g_err = lsdhip_last_error();
+  return rc;
+}
+extern "C" int lsdband_get(lsdband* b, int local, void* hyp_window_out) {
+  if (!b || local < 0 || local >= b->nlocal || !hyp_window_out) return LSDHIP_E_ARG;
+  int rc = lsdhip_ctx_synchronize(b->ctx);
+  if (rc == LSDHIP_OK) rc = lsdhip_depth_download(b->dm[local], (lsdhip_hypothesis*)hyp_window_out);
+  if (rc != LSDHIP_OK) g_err = lsdhip_last_error();
+  return rc;
+}
+extern "C" int lsdband_synchronize(lsdband* b) { return b ? lsdhip_ctx_synchronize(b->ctx) : LSDHIP_E_ARG; }
+// one process per GPU: process p of nprocs holds the bands with proc_of_band[r] == p (must match its lsdband_create range)
+extern "C" int lsdband_comm_init(lsdband* b, const void* unique_id128, int nprocs, int proc, const int* proc_of_band) {
+  if (!b || !unique_id128 || nprocs < 1 || proc < 0 || proc >= nprocs || !proc_of_band) return LSDHIP_E_ARG;
+  for (int r = 0; r < b->world; r++) {
+    b->proc_of[r] = proc_of_band[r];
+    if ((proc_of_band[r] == proc) != b->local(r)) { g_err = "lsdband_comm_init: band ownership does not match lsdband_create"; return LSDHIP_E_ARG; }
+  }
+  b->nprocs = nprocs; b->proc = proc;
+  if (nprocs == 1) return LSDHIP_OK;
+  Rccl& R = rccl();
+  if (!R.ok) { g_err = "RCCL not available: " + R.why; return LSDHIP_E_STATE; }
+  NcclId id;
+  std::memcpy(&id, unique_id128, sizeof(id));
+  int rc = R.CommInitRank(&b->comm, nprocs, id, proc);
+  if (rc != 0) { g_err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(rc) : "?"); return LSDHIP_E_HIP; }
+  return LSDHIP_OK;
+}
+extern "C" int lsdband_set_packed_exchange(lsdband* b, int on) {
+  if (!b) return LSDHIP_E_ARG;
+  b->packedLocal = on != 0;
+  return LSDHIP_OK;
+}
+extern "C" long long lsdband_halo_bytes_per_pass(const lsdband* b) {
+  if (!b) return -1;
+  long long rows = 0;
+  for (int r = 0; r < b->world; r++) for (const BandSeg& s : b->recv_list(r)) rows += s.nrows;
+  return rows * b->w * BAND_PACK_BYTES;
+}
+// `passes` passes over every local window, halo refresh between passes.  Returns after everything is QUEUED.
+extern "C" int lsdband_run(lsdband* b, int passes) {
+  if (!b || passes < 0) return LSDHIP_E_ARG;
+  try {
+    Rccl& R = rccl();
+    auto nc = [&](int rc, const char* what) { if (rc != 0) throw Error(LSDHIP_E_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(rc) : "?")); };
+    void* stream = lsdhip_ctx_stream(b->ctx);
+    // exchange plan of this process (fixed for the object's lifetime): local copies, remote sends, remote receives
+    std::vector<lsdhip_row_copy> localCopies, packs, unpacks;
+    struct Wire { int peerProc; size_t bytes; char* buf; char* buf2; };
+    std::vector<Wire> sends, recvs, loop;
+    size_t si = 0, ri = 0;
+    for (int r = 0; r < b->world; r++) {
+      for (const BandSeg& s : b->recv_list(r)) {          // band r receives rows owned by band s.peer
+        const bool dstLocal = b->local(r), srcLocal = b->local(s.peer);
+        const size_t bytes = (size_t)s.nrows * b->w * BAND_PACK_BYTES;
+        if (dstLocal && srcLocal && b->packedLocal) {
+          // the wire path without the wire: pack into a send buffer, device copy in place of ncclSend / ncclRecv, unpack
+          if (b->sendbuf.size() <= si) b->sendbuf.push_back(nullptr);
+          if (!b->sendbuf[si]) check(lsdhip_ctx_alloc_dev(b->ctx, bytes, (void**)&b->sendbuf[si]), "lsdhip_ctx_alloc_dev");
+          if (b->recvbuf.size() <= ri) b->recvbuf.push_back(nullptr);
+          if (!b->recvbuf[ri]) check(lsdhip_ctx_alloc_dev(b->ctx, bytes, (void**)&b->recvbuf[ri]), "lsdhip_ctx_alloc_dev");
+          lsdhip_row_copy c{};
+          c.src_map = b->dm[s.peer - b->first]; c.src_row0 = s.row0 - b->window[s.peer].first;
+          c.dst_packed = b->sendbuf[si]; c.nrows = s.nrows;
+          packs.push_back(c);
+          lsdhip_row_copy u{};
+          u.src_packed = b->recvbuf[ri];
+          u.dst_map = b->dm[r - b->first]; u.dst_row0 = s.row0 - b->window[r].first; u.nrows = s.nrows;
+          unpacks.push_back(u);
+          loop.push_back({0, bytes, b->sendbuf[si], b->recvbuf[ri]});
+          si++; ri++;
+        } else if (dstLocal && srcLocal) {
+          lsdhip_row_copy c{};
+          c.src_map = b->dm[s.peer - b->first]; c.src_row0 = s.row0 - b->window[s.peer].first;
+          c.dst_map = b->dm[r - b->first]; c.dst_row0 = s.row0 - b->window[r].first;
+          c.nrows = s.nrows;
+          localCopies.push_back(c);
+        } else if (srcLocal) {                             // we own the rows: pack + send to r's process
+          if (b->sendbuf.size() <= si) b->sendbuf.push_back(nullptr);
+          if (!b->sendbuf[si]) check(lsdhip_ctx_alloc_dev(b->ctx, bytes, (void**)&b->sendbuf[si]), "lsdhip_ctx_alloc_dev");
+          lsdhip_row_copy c{};
+          c.src_map = b->dm[s.peer - b->first]; c.src_row0 = s.row0 - b->window[s.peer].first;
+          c.dst_packed = b->sendbuf[si]; c.nrows = s.nrows;
+          packs.push_back(c);
+          sends.push_back({b->proc_of[r], bytes, b->sendbuf[si], nullptr});
+          si++;
+        } else if (dstLocal) {                             // we need the rows: receive from the owner's process + unpack
+          if (b->recvbuf.size() <= ri) b->recvbuf.push_back(nullptr);
+          if (!b->recvbuf[ri]) check(lsdhip_ctx_alloc_dev(b->ctx, bytes, (void**)&b->recvbuf[ri]), "lsdhip_ctx_alloc_dev");
+          lsdhip_row_copy c{};
+          c.src_packed = b->recvbuf[ri];
+          c.dst_map = b->dm[r - b->first]; c.dst_row0 = s.row0 - b->window[r].first; c.nrows = s.nrows;
+          unpacks.push_back(c);
+          recvs.push_back({b->proc_of[s.peer], bytes, b->recvbuf[ri], nullptr});
+          ri++;
+        }
+      }
+    }
+    if ((!sends.empty() || !recvs.empty()) && !b->comm) throw Error(LSDHIP_E_STATE, "lsdband_run: bands of other processes but no communicator (lsdband_comm_init)");
+    for (int p = 0; p < passes; p++) {
+      for (int i = 0; i < b->nlocal; i++) check(lsdhip_depth_stage(b->dm[i], 5, nullptr, 0), "lsdhip_depth_stage");
+      b->passes_run++;
+      if (p + 1 == passes) break;
+      // the halo rows a window receives are never rows it owns, and sources are always owned rows: the copies of one
+      // exchange cannot overwrite each other's inputs, so one launch serves all of them
+      if (!packs.empty()) check(lsdhip_depth_copy_rows_batch(b->ctx, (int)packs.size(), packs.data()), "lsdhip_depth_copy_rows_batch");
+      if (!localCopies.empty()) check(lsdhip_depth_copy_rows_batch(b->ctx, (int)localCopies.size(), localCopies.data()), "lsdhip_depth_copy_rows_batch");
+      for (const Wire& l : loop) check(lsdhip_ctx_copy_dev(b->ctx, l.buf2, l.buf, l.bytes), "lsdhip_ctx_copy_dev");
+      if (!loop.empty() && sends.empty() && recvs.empty())
+        check(lsdhip_depth_copy_rows_batch(b->ctx, (int)unpacks.size(), unpacks.data()), "lsdhip_depth_copy_rows_batch");
+      if (!sends.empty() || !recvs.empty()) {
+        nc(R.GroupStart(), "ncclGroupStart");
+        for (const Wire& s : sends) nc(R.Send(s.buf, s.bytes, 0 /* ncclInt8 */, s.peerProc, b->comm, stream), "ncclSend");
+        for (const Wire& r : recvs) nc(R.Recv(r.buf, r.bytes, 0 /* ncclInt8 */, r.peerProc, b->comm, stream), "ncclRecv");
+        nc(R.GroupEnd(), "ncclGroupEnd");
+        check(lsdhip_depth_copy_rows_batch(b->ctx, (int)unpacks.size(), unpacks.data()), "lsdhip_depth_copy_rows_batch");
+      }
+    }
+    return LSDHIP_OK;
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+}

@@ -66,3 +66,48 @@ def test_full_size_3840x2160_hip_vs_oracle_and_8_bands(oracle):
     for r, rows in br.owned_rows().items():
         y0, y1 = plan.owned[r]
         _rows_equal(rows, ref[y0:y1], "3840x2160 band %d of %d" % (r, world))
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_native_band_loop_equals_full_frame(world):
+    """The C++ loop (liblsdhip_driver.so lsdband_*): same decomposition, everything queued on the context's stream, one map -> map
+    copy launch per exchange — bit-exact against the full-frame HIP pass after several passes."""
+    from lsd_slam_amd.bands import NativeBandRegularizer
+    w, H, passes = 320, 256 if world < 8 else 384, 4
+    hyp, maxgrad = synth_s3(w, H)
+    full = HipBandEngine(w, H)
+    full.load(hyp, maxgrad)
+    for _ in range(passes):
+        full.run_pass()
+    ref = full.get()
+    nb = NativeBandRegularizer(w, H, world, list(range(world)))
+    nb.load(hyp, maxgrad)
+    nb.run(passes)
+    assert nb.halo_bytes_per_pass() == nb.plan.halo_bytes_per_pass(w)
+    for r, rows in nb.owned_rows().items():
+        y0, y1 = nb.plan.owned[r]
+        _rows_equal(rows, ref[y0:y1], "native band %d of %d" % (r, world))
+    nb.close()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_native_band_loop_packed_wire_format(world):
+    """The multi-GPU exchange without the wire: rows are packed (29 B per pixel, plane after plane), copied buffer to buffer in
+    place of ncclSend / ncclRecv, and unpacked — everything of the RCCL path except the two RCCL calls (RCCL refuses two ranks on
+    the one GPU of this box; the 8-GPU run is the driver's).  Bit-exact against the full frame."""
+    from lsd_slam_amd.bands import NativeBandRegularizer
+    w, H, passes = 320, 384, 3
+    hyp, maxgrad = synth_s3(w, H)
+    full = HipBandEngine(w, H)
+    full.load(hyp, maxgrad)
+    for _ in range(passes):
+        full.run_pass()
+    ref = full.get()
+    nb = NativeBandRegularizer(w, H, world, list(range(world)))
+    nb.set_packed_exchange(True)
+    nb.load(hyp, maxgrad)
+    nb.run(passes)
+    for r, rows in nb.owned_rows().items():
+        y0, y1 = nb.plan.owned[r]
+        _rows_equal(rows, ref[y0:y1], "packed band %d of %d" % (r, world))
+    nb.close()

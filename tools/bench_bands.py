@@ -20,6 +20,7 @@ ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--bands", type=int, default=1)
 ap.add_argument("--passes", type=int, default=20)
+ap.add_argument("--native", action="store_true", help="the C++ loop (liblsdhip_driver.so lsdband_*): nothing synchronises the host between passes")
 args = ap.parse_args()
 
 import torch
@@ -31,26 +32,54 @@ local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local_rank)
 w, H = args.width, args.height
 hyp, maxgrad = synth_s3(w, H)
-if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    plan = BandPlan(H, world)
-    br = BandRegularizer(plan, [HipBandEngine(w, plan.window_rows, device=local_rank)], DistComm(), [rank])
+if args.native:
+    from lsd_slam_amd.bands import NativeBandRegularizer
+    from lsd_slam_amd import driver
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")            # rendezvous + barriers only: the halo rows go through RCCL inside the C++ loop
+        uid = [driver.DriverLoop.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        br = NativeBandRegularizer(w, H, world, [rank], device=local_rank)
+        br.comm_init(uid[0], world, rank, list(range(world)))
+    else:
+        br = NativeBandRegularizer(w, H, args.bands, list(range(args.bands)), device=local_rank)
+    plan = br.plan
+    br.load(hyp, maxgrad)
+    br.run(2)
+    br.synchronize()
+    br.load(hyp, maxgrad)
+    br.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    br.run(args.passes)
+    br.synchronize()
+    if world > 1:
+        dist.barrier()
 else:
-    plan = BandPlan(H, args.bands)
-    br = BandRegularizer(plan, [HipBandEngine(w, plan.window_rows) for _ in range(args.bands)], LocalComm(), list(range(args.bands)))
-br.load(hyp, maxgrad)
-br.run(2)          # warm-up
-br.load(hyp, maxgrad)
-torch.cuda.synchronize()
-if world > 1:
-    dist.barrier()
-t0 = time.perf_counter()
-br.run(args.passes)
-torch.cuda.synchronize()
-if world > 1:
-    dist.barrier()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        plan = BandPlan(H, world)
+        br = BandRegularizer(plan, [HipBandEngine(w, plan.window_rows, device=local_rank)], DistComm(), [rank])
+    else:
+        plan = BandPlan(H, args.bands)
+        br = BandRegularizer(plan, [HipBandEngine(w, plan.window_rows) for _ in range(args.bands)], LocalComm(), list(range(args.bands)))
+    br.load(hyp, maxgrad)
+    br.run(2)          # warm-up
+    br.load(hyp, maxgrad)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    br.run(args.passes)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
 dt = time.perf_counter() - t0
 if rank == 0:
     px = w * H * args.passes
