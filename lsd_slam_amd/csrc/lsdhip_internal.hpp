@@ -250,6 +250,7 @@ struct lsdhip_tracker {
   TrackSpec spec = {};             // of the job being launched
   int jobTag = 0, launchOrdinal = 0;   // progress reporting of the launch chain (host tops the chain up while it waits)
   int topUps = 0;
+  int budgetExtra = 2;                 // launches queued beyond the most the recent jobs needed (finishing step + margin; LSDHIP_BUDGET_EXTRA)
   long long dbgJobs = 0, dbgEnqueued = 0, dbgMisses = 0, dbgWaitNs = 0, dbgLaunchNs = 0;   // LSDHIP_TRACK_DEBUG=1: printed at destroy
   bool topUp = false;                  // LSDHIP_TOPUP=1: start with the shortest recent job's launches and append while waiting
                                        // (measured slower than the fixed budget: the host's launches land late — r02_notes.md)

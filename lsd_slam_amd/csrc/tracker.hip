@@ -1926,6 +1926,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   t->hostLM = env && env[0] == '1';
   if (const char* e = getenv("LSDHIP_SPIN")) t->spinWait = e[0] != '0';
   if (const char* e = getenv("LSDHIP_TOPUP")) t->topUp = e[0] != '0';
+  if (const char* e = getenv("LSDHIP_BUDGET_EXTRA")) { t->budgetExtra = atoi(e); if (t->budgetExtra < 1) t->budgetExtra = 1; }
   *out = t;
   return LSDHIP_OK;
 }
@@ -2319,7 +2320,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   if (!topUp && t->recent[0] > 0) {   // fixed budget: the most of the recent jobs + 2
     budget = 0;
     for (int i = 0; i < 4; i++) if (t->recent[i] > budget) budget = t->recent[i];
-    budget += 2;
+    budget += t->budgetExtra;
   }
   t->dbgJobs++;
   t->jobTag = (t->jobTag % 0x7FFFF) + 1;
