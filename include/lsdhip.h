@@ -166,10 +166,10 @@ int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
 /* Execution strategy of the launch-per-evaluation chain: the LM loop's "increase lambda and retry" sequence
  * (C/Tracking/SE3Tracker.cpp:341-447) depends only on A, b and lambda, so a launch evaluates the next `trials` (1..6, default 5)
  * retries side by side and the following launch consumes them in the reference's order — same decisions, same evaluation
- * counts, fewer dependent launches.  Default: by the size of the level — 6 trials up to 6 K pixels, 5 up to 24 K, 4 up to 88 K
- * (levels 3 / 2 / 1 of a 640x480 frame), one evaluation per launch on larger (work-bound) levels; this call sets the same
+ * counts, fewer dependent launches.  Default: by the size of the level — 6 trials up to 6 K pixels, 5 up to 88 K
+ * (levels 3 / 2, 1 of a 640x480 frame), one evaluation per launch on larger (work-bound) levels; this call sets the same
  * number at every level; trials = 1: one evaluation per launch.  finestLevelWorkgroups: workgroups per
- * trial at the finest level while trials > 1 (0 = keep the current value, default 104). */
+ * trial at the finest level while trials > 1 (0 = keep the current value, default 80). */
 int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups);
 /* out[0] = k_track_step launches of the last job that evaluated (<= its numEvaluations), out[1] = trials per launch. */
 int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);

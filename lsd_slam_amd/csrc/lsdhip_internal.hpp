@@ -243,7 +243,7 @@ struct lsdhip_tracker {
   bool specAuto = true;           // trials per level from the level's size (see track_device); false after set_speculation
   int specCaps[LSD_LEVELS] = {0, 0, 0, 0, 0};    // per-level workgroups per trial (LSDHIP_SPEC_CAPS; 0 = automatic)
   int specLevel[LSD_LEVELS] = {0, 0, 0, 0, 0};   // per-level trials (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = automatic / specC)
-  int specCap = 104;              // workgroups per trial at the finest level when speculating (0 = grid_cap / 2)
+  int specCap = 80;               // workgroups per trial on levels of 24 K - 88 K pixels when speculating (0 = grid_cap / 2)
   uint8_t* d_maskSide = nullptr;  // (SPEC_MAX - 1) mask planes of (w >> 1) x (h >> 1) bytes
   size_t maskStride = 0;
   int numLaunches = 0;

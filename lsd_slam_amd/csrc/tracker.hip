@@ -2279,8 +2279,8 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   t->spec.wasGoodSide = t->d_maskSide;
   t->spec.maskStride = (unsigned)t->maskStride;
   // Trials per launch and workgroups per trial, per level.  Speculation pays where a level is latency-bound, i.e. small: the
-  // automatic policy goes by the level's pixel (or point) count — <= 6 K: 6 trials, <= 24 K: 5, <= 88 K: 4 trials on specCap (104)
-  // workgroups each (multi-pass), larger: one evaluation per launch on the full grid (such levels are work-bound: at
+  // automatic policy goes by the level's pixel (or point) count — <= 6 K: 6 trials, <= 24 K: 5, <= 88 K: 5 trials on specCap (80)
+  // workgroups each (multi-pass; 4 x 104 measured 1.5 % slower), larger: one evaluation per launch on the full grid (such levels are work-bound: at
   // 1280x1024 speculating on level 1 cost 15 % of the frame rate).  An explicit lsdhip_tracker_set_speculation / the
   // LSDHIP_SPEC_LEVELS / _CAPS environment overrides it.
   for (int l = 0; l < LSD_LEVELS; l++) t->spec.trials[l] = 1;
@@ -2291,7 +2291,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       int trials, cap = t->specCaps[l];
       if (t->specLevel[l] > 0) trials = t->specLevel[l];
       else if (!t->specAuto) trials = t->specC;
-      else trials = work <= 6144 ? 6 : (work <= 24576 ? 5 : (work <= 90112 ? 4 : 1));
+      else trials = work <= 6144 ? 6 : (work <= 90112 ? 5 : 1);
       if (trials > t->specC) trials = t->specC;
       if (cap <= 0 && trials > 1 && (t->specAuto ? work > 24576 : l == job.lastLevel)) cap = t->specCap > 0 ? t->specCap : ((t->grid_cap / 2 + 7) & ~7);
       t->spec.trials[l] = trials;

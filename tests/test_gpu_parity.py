@@ -944,7 +944,7 @@ def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip,
 
 @pytest.mark.gpu
 def test_speculation_default_matches_oracle_sequence(oracle, hip):
-    """the library default (4 / 5 / 6 trials at levels 1 / 2 / 3 of a 640x480 frame) against the oracle over a few frames"""
+    """the library default (5 / 5 / 6 trials at levels 1 / 2 / 3 of a 640x480 frame) against the oracle over a few frames"""
     w, h = 640, 480
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 6)
     kfo, kfg = oracle.Frame(0, frames[0], K), hip.Frame(ctx, 0, frames[0])
