@@ -722,14 +722,20 @@ struct TrackScratch {
 #endif
 #define RS_COLS 44   // RS_END rounded up
 
-// Fused tracking step, one launch per evaluation:
-//   (1) every workgroup finishes the *previous* evaluation from its partial sums: fixed-order column sums (float4 loads
-//       of the column-major rows, all issued before the first add), SSE tail drop, LGS6::finish, then lm_advance on one
-//       lane — identical inputs, identical code, hence identical state in every workgroup without any inter-workgroup
-//       communication inside the launch (no atomics, no fences, run-to-run deterministic).  The last wave fetches (or,
-//       on multi-pass levels, re-evaluates) the at most 3 tail points while the other waves sum;
-//   (2) the residual evaluation (K0+K1+K2+K3) of the pose that decision produced, grid-stride over the level's pixels,
-//       41 sums reduced wave (DPP) -> workgroup (LDS) -> sums[.][tile].
+// Fused tracking step, one launch per step of the LM loop:
+//   (1) every workgroup finishes the *previous* launch's evaluation(s) from the tiles' partial rows: fixed-order column sums
+//       (row-major rows, whole rows per wave load, all loads issued before the first add), SSE tail drop, LGS6::finish, then
+//       the LM decision in wave 0 — identical inputs, identical code, hence identical state in every workgroup without any
+//       inter-workgroup communication inside the launch (no atomics, no fences, run-to-run deterministic).  The waves fetch
+//       (or, on multi-pass levels, re-evaluate) the at most 3 tail points of every pending trial while the sums travel;
+//   (2) the residual evaluation (K0+K1+K2+K3) of the pose(s) that decision produced, grid-stride over the level's pixels,
+//       41 sums reduced lane -> workgroup (LDS, transposed) -> sums[.][trial][tile].
+// Reject-chain speculation (single jobs, TS_FUSED; TrackSpec): the LM loop's retries after a rejection depend only on A, b
+// and lambda, so (2) evaluates the next `trials` of them side by side — workgroup = (trial, tile); each trial group derives its
+// lambda by the closed-form recurrence and solves for its own increment — and (1) of the next launch picks, lane-parallel, the
+// first pending trial at which the reference's loop stops (diverged / accepted / step below stepSizeMin), advances lambda,
+// incTry and the counters past the plain rejections before it, and runs ONE LM step on that trial's totals.  Same decisions,
+// same evaluation counts, same refPixelWasGood as one evaluation per launch, in about half the dependent launches.
 // The first launch of a job (first = 1) builds the initial state from the job instead of loading it.
 // BATCH: blockIdx.y selects one of several independent jobs (tracking a batch of frames / permanent references in the
 // same launches): the job descriptions then live in HBM (`jobs`), and state / scratch / summary are arrays over jobs.
