@@ -11,12 +11,13 @@
 // oracle/ref/shim).  tests/test_ref_pin_cpu.py runs this restatement against that build — pyramids, point
 // clouds, K1/K2/K3 buffers and normal equations (SSE and scalar paths), whole trackFrame calls, every
 // depth-map stage, doLineStereo pixel by pixel with its status codes, updateKeyframe / createKeyFrame /
-// finalizeKeyFrame and a 30-frame sequence fed forward — all BIT-EXACT.  What is NOT the reference's own
+// finalizeKeyFrame, a 30-frame sequence fed forward, and Sim3Tracker (buffers / weights / LGS7 at fixed transformations and
+// whole trackFrameSim3 calls) — all BIT-EXACT.  What is NOT the reference's own
 // code in that build, and therefore still rests on restatement: the Eigen fixed-size arithmetic
 // (3x3 products / inverse, 6x6 LDL^T) and the Sophus SE3 / Sim3 group operations, which oracle/_ref
 // shares with this oracle (orc_math.hpp); Sophus exp / log are checked against the element list of the
-// reference's own sophus/test_se3.cpp (tests/test_oracle_cpu.py).  Sim3Tracker (orc_sim3.cpp) is not
-// part of oracle/_ref: PARITY UNPINNED for that file.
+// reference's own sophus/test_se3.cpp (tests/test_oracle_cpu.py); Sim3::exp (orc_sim3_exp.hpp), the 7x7 LDL^T and
+// Quaternionf::setFromTwoVectors are shared stand-in algebra in the same sense.
 //
 // Conventions: unwritten pool memory is defined as 0 (the reference recycles FrameMemory buffers,
 // C/DataStructures/FrameMemory.cpp:80-86); float op order is the *written* order of the reference and

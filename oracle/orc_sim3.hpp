@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Sim3Tracker restatement (C/Tracking/Sim3Tracker.{h,cpp}); see orc_sim3.cpp.
 #pragma once
 #include "lsd_oracle.hpp"
+#include "orc_sim3_exp.hpp"
 
 namespace orc {
 
@@ -20,7 +21,6 @@ struct Sim3EvalRecord {
   float A[49], b[7];        // LGS7 after initializeFrom (not divided by num_constraints)
   double num_constraints;
 };
-Sim3d sim3_exp(const double a[7]);
 void sim3_ldlt7_solve(const float A[49], const float b[7], float x[7]);
 
 class Sim3Tracker {

@@ -2,7 +2,7 @@
 //
 // oracle/_ref/liblsd_ref_{sse,scalar}.so = the reference's OWN hot-path translation units
 //   C/util/settings.cpp, util/SophusUtil.cpp, DataStructures/{Frame,FramePoseStruct,FrameMemory}.cpp,
-//   DepthEstimation/{DepthMap,DepthMapPixelHypothesis}.cpp, Tracking/{SE3Tracker,TrackingReference}.cpp
+//   DepthEstimation/{DepthMap,DepthMapPixelHypothesis}.cpp, Tracking/{SE3Tracker,Sim3Tracker,TrackingReference}.cpp
 // compiled UNCHANGED from where they lie under /root/reference/lsd_slam_core/src (C/), plus this file, which exports
 // the same orc_* C symbols as oracle/orc_capi.cpp so that oracle/pyoracle.py can drive either library with the same
 // Python classes and tests/test_ref_pin_cpu.py can compare them call for call.  The external dependencies the
@@ -37,6 +37,7 @@
 #include "DepthEstimation/DepthMap.h"
 #include "DepthEstimation/DepthMapPixelHypothesis.h"
 #include "Tracking/SE3Tracker.h"
+#include "Tracking/Sim3Tracker.h"
 #include "Tracking/TrackingReference.h"
 #undef private
 #undef protected
@@ -55,11 +56,6 @@ int waitKeyNoConsume(int) { return 0; }
 void closeAllWindows() {}
 }  // namespace Util
 }  // namespace lsd_slam
-namespace orc {
-// Sim3 exponential of the oracle (oracle/orc_sim3.cpp) — declared by shim/sophus/sim3.hpp; the SE3 path never calls it
-Sim3d sim3_exp(const double*) { return Sim3d(); }
-}
-
 extern "C" {
 
 struct orc_params {
@@ -520,3 +516,82 @@ extern "C" void orc_depth_line_stereo(void* d, void* ref, int x, int y, float mi
   out[3] = dm->doLineStereo((float)x, (float)y, epx, epy, min_idepth, prior_idepth, max_idepth, rf, rf->image(0), ri, rv, rl, &st);
   out[4] = ri; out[5] = rv; out[6] = rl;
 }
+
+// ---- Sim3Tracker (C/Tracking/Sim3Tracker.{h,cpp}, compiled unchanged) --------------------------------------------------------
+// Sim3 as double[8] = (qw, qx, qy, qz, tx, ty, tz, scale); the stand-in Sophus::Sim3d keeps (unit quaternion, scale, translation).
+extern "C" {
+struct orc_sim3_result {
+  double frameToRef[8];
+  float lastResidual, lastDepthResidual, lastPhotometricResidual, pointUsage, affine_a, affine_b;
+  int diverged, numEvaluations;
+  float hessian[49];
+};
+struct Sim3ResidualRec { float sumResD, sumResP; int numTermsD, numTermsP; float meanD, meanP, mean; };
+struct Sim3EvalRecord {
+  int warped_size;
+  float pointUsage, affine_a_lastIt, affine_b_lastIt;
+  Sim3ResidualRec res;
+  float A[49], b[7];
+  double num_constraints;
+};
+struct Sim3Box {
+  Sim3Tracker tr;
+  orc_params p;
+  Sim3Box(int w, int h, const float K[4], const orc_params* pp) : tr(w, h, Kmat(K)), p(pp ? *pp : default_params_()) {}
+};
+static Sim3 sim3_in(const double p[8]) {
+  Sim3 T;
+  T.q.w = p[0]; T.q.x = p[1]; T.q.y = p[2]; T.q.z = p[3];     // bits as given (the oracle's hook does not re-normalise either)
+  T.translation() = Eigen::Vector3d(p[4], p[5], p[6]);
+  T.s = p[7];
+  return T;
+}
+void* orc_sim3tracker_create(int w, int h, const float K[4], const orc_params* p) { return new Sim3Box(w, h, K, p); }
+void orc_sim3tracker_destroy(void* t) { delete (Sim3Box*)t; }
+void orc_sim3tracker_set_mode(void*, int) {}   // compile-time in the reference (ENABLE_SSE)
+void orc_sim3tracker_set_max_its(void* t, const int its[5]) { for (int i = 0; i < 5; i++) ((Sim3Box*)t)->tr.settings.maxItsPerLvl[i] = its[i]; }
+void orc_sim3tracker_track(void* t, void* ref, void* frame, const double init_frameToRef[8], int startLevel, int finalLevel, orc_sim3_result* out) {
+  Sim3Box* b = (Sim3Box*)t;
+  apply(b->p);
+  Sim3Tracker* tr = &b->tr;
+  Sim3 T = tr->trackFrameSim3(&((RefBox*)ref)->ref, F(frame), sim3_in(init_frameToRef), startLevel, finalLevel);
+  out->frameToRef[0] = T.q.w; out->frameToRef[1] = T.q.x; out->frameToRef[2] = T.q.y; out->frameToRef[3] = T.q.z;
+  out->frameToRef[4] = T.translation()[0]; out->frameToRef[5] = T.translation()[1]; out->frameToRef[6] = T.translation()[2];
+  out->frameToRef[7] = T.s;
+  out->lastResidual = tr->lastResidual; out->lastDepthResidual = tr->lastDepthResidual; out->lastPhotometricResidual = tr->lastPhotometricResidual;
+  out->pointUsage = tr->pointUsage; out->affine_a = tr->affineEstimation_a; out->affine_b = tr->affineEstimation_b;
+  out->diverged = tr->diverged; out->numEvaluations = -1;   // the reference does not count them
+  for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) out->hessian[i * 7 + j] = tr->lastSim3Hessian(i, j);
+}
+#if defined(ENABLE_SSE)
+#define REF_CALL3(function, arguments) function##SSE arguments
+#else
+#define REF_CALL3(function, arguments) function arguments
+#endif
+// buffers + weights + LGS once at a fixed transformation: the three private members in the order trackFrameSim3 calls them
+void orc_sim3tracker_evaluate(void* t, void* ref, void* frame, const double refToFrame[8], int level, float a, float b, Sim3EvalRecord* out) {
+  Sim3Box* bx = (Sim3Box*)t;
+  apply(bx->p);
+  Sim3Tracker* tr = &bx->tr;
+  TrackingReference* reference = &((RefBox*)ref)->ref;
+  Sim3 T = sim3_in(refToFrame);
+  tr->affineEstimation_a = a; tr->affineEstimation_b = b;
+  reference->makePointCloud(level);
+  tr->REF_CALL3(calcSim3Buffers, (reference, F(frame), T, level));
+  Sim3ResidualStruct r = tr->REF_CALL3(calcSim3WeightsAndResidual, (T));
+  LGS7 ls7;
+  tr->REF_CALL3(calcSim3LGS, (ls7));
+  out->warped_size = tr->buf_warped_size;
+  out->pointUsage = tr->pointUsage;
+  out->affine_a_lastIt = tr->affineEstimation_a_lastIt; out->affine_b_lastIt = tr->affineEstimation_b_lastIt;
+  out->res.sumResD = r.sumResD; out->res.sumResP = r.sumResP; out->res.numTermsD = r.numTermsD; out->res.numTermsP = r.numTermsP;
+  out->res.meanD = r.meanD; out->res.meanP = r.meanP; out->res.mean = r.mean;
+  for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) out->A[i * 7 + j] = ls7.A(i, j);
+  for (int i = 0; i < 7; i++) out->b[i] = ls7.b[i];
+  out->num_constraints = (double)ls7.num_constraints;
+}
+void orc_sim3_exp(const double a[7], double out[8]) {
+  orc::Sim3d T = orc::sim3_exp(a);
+  out[0] = T.q.w; out[1] = T.q.x; out[2] = T.q.y; out[3] = T.q.z; out[4] = T.t[0]; out[5] = T.t[1]; out[6] = T.t[2]; out[7] = T.s;
+}
+}  // extern "C"

@@ -4,7 +4,7 @@
 #pragma once
 #include "se3.hpp"
 
-namespace orc { Sim3d sim3_exp(const double a[7]); }
+#include "../../../orc_sim3_exp.hpp"   // orc::sim3_exp: Sophus Sim3::exp restated once, shared with the oracle
 
 namespace Sophus {
 
@@ -33,6 +33,17 @@ template <typename T, int Options = 0> class Sim3Group {
     Eigen::Matrix<T, 3, 3> r;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = R.m[i][j];
     return r;
+  }
+  // RxSO3::matrix() (rxso3.hpp:164-170): scale * (normalised quaternion).toRotationMatrix()
+  struct RxSO3View {
+    Eigen::Matrix<T, 3, 3> m;
+    const Eigen::Matrix<T, 3, 3>& matrix() const { return m; }
+  };
+  RxSO3View rxso3() const {
+    RxSO3View v;
+    orc::Mat3<T> R = orc::qrot(q);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v.m(i, j) = s * R.m[i][j];
+    return v;
   }
   // oracle/orc_math.hpp Sim3d::inverse
   Sim3Group inverse() const {

@@ -124,7 +124,6 @@ def test_sophus_adapter_compiles_against_reference_typedefs(tmp_path):
 #include <cmath>
 #include <cstdio>
 using namespace lsd_slam_hip;
-namespace orc { Sim3d sim3_exp(const double*) { return Sim3d(); } }   // the stand-in Sim3 exponential lives in the oracle; unused here
 int main() {
   // SlamSystem.cpp:932 style call site: SE3 in, SE3 out
   ::SE3 init(Eigen::Quaterniond(0.9998, 0.01, -0.012, 0.008), Eigen::Vector3d(0.1, -0.2, 0.3));

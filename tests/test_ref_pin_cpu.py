@@ -1,6 +1,6 @@
 """PINNING THE ORACLE AGAINST THE REFERENCE ITSELF.
 
-oracle/_ref/liblsd_ref_{sse,scalar}.so are the reference's own hot-path translation units (SE3Tracker.cpp, DepthMap.cpp,
+oracle/_ref/liblsd_ref_{sse,scalar}.so are the reference's own hot-path translation units (SE3Tracker.cpp, Sim3Tracker.cpp, DepthMap.cpp,
 Frame.cpp, TrackingReference.cpp, DepthMapPixelHypothesis.cpp, FrameMemory.cpp, FramePoseStruct.cpp, settings.cpp)
 compiled unchanged from /root/reference against stand-in headers for the absent external dependencies (oracle/ref/shim:
 Eigen, Sophus-on-Eigen, boost, OpenCV, g2o), behind the same orc_* entry points as the oracle (oracle/ref/ref_capi.cpp).
@@ -416,3 +416,76 @@ def test_sequence_fed_forward(oracle, ref, build, mode, ov):
     assert a.good == b.good and a.diverged == b.diverged and a.usage == b.usage and a.residual == b.residual
     assert a.rescale == b.rescale and a.semidense == b.semidense
     assert_hyp_bits(a.final_map, b.final_map, "final map after %d frames" % n)
+
+
+# ---- Sim3Tracker: the reference's Tracking/Sim3Tracker.cpp, compiled unchanged ---------------------------------
+def _sim3_pair(oracle, L, w, h, k, scale):
+    """keyframe A = frame 0 with its GT depth; keyframe B = frame k with its own GT depth divided by `scale`; expected B -> A Sim3"""
+    from lsd_slam_amd import synth
+    sc = synth.Scene(0)
+    K = synth.intrinsics(w, h)
+    imgA, depthA = sc.render(0, w, h)
+    imgB, depthB = sc.render(k, w, h)
+    out = []
+    for lib in (None, L):
+        fa = oracle.Frame(0, imgA, K, L=lib)
+        fa.set_depth_gt(depthA)
+        fb = oracle.Frame(k, imgB, K, L=lib)
+        fb.set_depth_gt((depthB / scale).astype(np.float32))
+        ra = oracle.TrackingReference(L=lib)
+        ra.import_frame(fa)
+        out.append((ra, fb, fa))
+    R, t = sc.frame_to_ref(k, 0)
+    exp = np.concatenate([synth.rot_to_quat(R), t, [scale]])
+    return K, out[0], out[1], exp
+
+
+SIM3_FIELDS = ("warped_size", "pointUsage", "affine_a_lastIt", "affine_b_lastIt", "sumResD", "sumResP", "numTermsD", "numTermsP",
+               "meanD", "meanP", "mean", "num_constraints")
+
+
+@pytest.mark.parametrize("affine", [1, 0])
+@pytest.mark.parametrize("build,mode", MODES)
+def test_sim3_buffers_weights_and_lgs7(oracle, ref, build, mode, affine):
+    """calcSim3Buffers + calcSim3WeightsAndResidual + calcSim3LGS at fixed transformations (levels 3..1, with and without a roll
+    and a scale): warped count, usage, affine estimate, the residual struct and the 7x7 system bit for bit."""
+    w, h = 320, 240
+    L = ref[build]
+    K, (ra, fb, fa), (rar, fbr, far), exp = _sim3_pair(oracle, L, w, h, 3, 1.25)
+    ov = {"useAffineLightningEstimation": affine}
+    tro = oracle.Sim3Tracker(w, h, K, params=params_of(oracle, None, ov), mode=mode)
+    trr = oracle.Sim3Tracker(w, h, K, params=params_of(oracle, L, ov), L=L)
+    Ts = [oracle.sim3_inv(exp), np.array([1.0, 0, 0, 0, 0, 0, 0, 1.0]),
+          oracle.sim3_exp(np.array([0.03, -0.02, 0.01, 0.01, -0.015, 0.2, 0.1])),     # a roll about the optical axis and a scale
+          oracle.sim3_exp(np.array([0.6, 0.1, 0.0, 0.0, 0.3, 0.0, -0.3]))]
+    for ti, T in enumerate(Ts):
+        for lvl in (3, 2, 1):
+            a, b = (1.0, 0.0) if ti % 2 == 0 else (1.04, -1.5)
+            r_o, r_r = tro.evaluate(ra, fb, T, lvl, a, b), trr.evaluate(rar, fbr, T, lvl, a, b)
+            tag = "T%d level %d" % (ti, lvl)
+            for k in SIM3_FIELDS:
+                assert np.float64(getattr(r_o, k)).tobytes() == np.float64(getattr(r_r, k)).tobytes(), (tag, k, getattr(r_o, k), getattr(r_r, k))
+            assert_bit_equal(np.array(r_o.A, np.float32), np.array(r_r.A, np.float32), tag + " A")
+            assert_bit_equal(np.array(r_o.b, np.float32), np.array(r_r.b, np.float32), tag + " b")
+        assert r_o.warped_size > 0 or ti == 3
+
+
+@pytest.mark.parametrize("build,mode", MODES)
+def test_sim3_trackframe(oracle, ref, build, mode):
+    """trackFrameSim3 end to end (levels 3..1, the constraint search's call): pose, scale, residuals, usage, affine parameters, the
+    7x7 Hessian and the divergence verdict bit for bit (LDLT 7x7 and Sim3::exp are the shared stand-in algebra)."""
+    w, h = 320, 240
+    L = ref[build]
+    K, (ra, fb, fa), (rar, fbr, far), exp = _sim3_pair(oracle, L, w, h, 3, 1.25)
+    tro, trr = oracle.Sim3Tracker(w, h, K, mode=mode), oracle.Sim3Tracker(w, h, K, L=L)
+    for init in (exp * np.array([1, 1, 1, 1, 1, 1, 1, 1 / 1.25]), exp, np.array([1.0, 0, 0, 0, 0, 0, 0, 1.0])):
+        r_o, r_r = tro.track(ra, fb, init, 3, 1), trr.track(rar, fbr, init, 3, 1)
+        assert r_o.diverged == r_r.diverged
+        assert np.array(r_o.frameToRef).tobytes() == np.array(r_r.frameToRef).tobytes(), (list(r_o.frameToRef), list(r_r.frameToRef))
+        for k in ("lastResidual", "lastDepthResidual", "lastPhotometricResidual", "pointUsage", "affine_a", "affine_b"):
+            assert np.float32(getattr(r_o, k)).tobytes() == np.float32(getattr(r_r, k)).tobytes(), k
+        assert_bit_equal(np.array(r_o.hessian, np.float32), np.array(r_r.hessian, np.float32), "lastSim3Hessian")
+    # a transformation that leaves too few points: both give up (identity, diverged)
+    bad = oracle.sim3_exp(np.array([5.0, 0, 0, 0, 0, 0, 0]))
+    r_o, r_r = tro.track(ra, fb, bad, 3, 1), trr.track(rar, fbr, bad, 3, 1)
+    assert r_o.diverged and r_r.diverged and list(r_o.frameToRef) == list(r_r.frameToRef)
