@@ -29,12 +29,12 @@ if kt:
     rows = list(csv.DictReader(open(kt)))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if r["Kernel_Name"].startswith("void k_track_step")]
     d.sort()
-    work = [x for x in d if x > 4.0]
+    work = [x for x in d if x > 5.5]   # launches queued behind the finishing one leave in 4-5 us (416 workgroups, one scalar load each)
     with open(os.path.join(dst, tag + "_track_step_durations.txt"), "w") as f:
         f.write("k_track_step launches: %d, mean %.2f us, median %.2f us\n" % (len(d), sum(d) / len(d), d[len(d) // 2]))
-        f.write("launches > 4 us (did an evaluation): %d, mean %.2f us, median %.2f us, p90 %.2f us\n" %
+        f.write("launches > 5.5 us (did an evaluation): %d, mean %.2f us, median %.2f us, p90 %.2f us\n" %
                 (len(work), sum(work) / len(work), work[len(work) // 2], work[int(len(work) * 0.9)]))
-        f.write("launches <= 4 us (job already finished, early exit): %d\n" % (len(d) - len(work)))
+        f.write("launches <= 5.5 us (job already finished, early exit): %d\n" % (len(d) - len(work)))
 
 traffic = {}
 for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
