@@ -377,6 +377,11 @@ extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], con
     if (l == 0) { memcpy(c->K0, Kl, sizeof(Kl)); memcpy(c->K0inv, Ki, sizeof(Ki)); }
   }
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (const char* e = getenv("LSDHIP_PREFETCH_STREAM")) c->prefetchOn = e[0] == '1';
+  if (c->prefetchOn) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->evPrefetchDone, hipEventDisableTiming));
+  }
   HIPCHK(hipEventCreate(&c->ev_a));
   HIPCHK(hipEventCreate(&c->ev_b));
   HIPCHK(hipHostMalloc((void**)&c->h_slots, LSD_NUM_SLOTS * sizeof(DeferredSlot), hipHostMallocMapped));
@@ -388,7 +393,9 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (void* p : c->free_arenas) (void)hipFree(p);
+  for (auto& a : c->free_arenas) { (void)hipFree(a.base); if (a.freed) (void)hipEventDestroy(a.freed); }
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->evPrefetchDone) (void)hipEventDestroy(c->evPrefetchDone);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->h_slots) (void)hipHostFree(c->h_slots);
   if (c->d_gtStage) (void)hipFree(c->d_gtStage);
@@ -523,7 +530,8 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   char* base = nullptr;
   c->arena_bytes = align_up(off, 256);
   if (!c->free_arenas.empty()) {
-    base = (char*)c->free_arenas.back();
+    base = (char*)c->free_arenas.back().base;
+    f->arenaFreed = c->free_arenas.back().freed;
     c->free_arenas.pop_back();
   } else {
     hipError_t e = hipMalloc((void**)&base, c->arena_bytes);
@@ -545,11 +553,12 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   return LSDHIP_OK;
 }
 
-int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src) {
+int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream) {
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
+  if (!stream) stream = c->stream;
   dim3 grid(c->w / 16, c->h / 16);
-  hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, c->stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
+  hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
                      f->d_image[3], f->d_image[4], c->w, c->h, f->d_grad[0], f->d_absgrad);
   GradMaxArgs ga;
   int nb = 0;
@@ -562,7 +571,7 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src) {
   ga.absg = f->d_absgrad; ga.maxgrad = f->d_maxgrad;
   ga.wasGoodWords = (uint32_t*)f->d_wasGood; ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
   int n0 = c->w * c->h;
-  hipLaunchKernelGGL(k_gradients_max, dim3(nb + (n0 + 255) / 256), dim3(256), 0, c->stream, ga);
+  hipLaunchKernelGGL(k_gradients_max, dim3(nb + (n0 + 255) / 256), dim3(256), 0, stream, ga);
   HIPCHK(hipGetLastError());
   f->wasGoodPristine = true;
   return LSDHIP_OK;
@@ -598,7 +607,23 @@ extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
   // the pyramid kernel reads the caller's device image directly (stream-ordered; nothing else needs the uint8 plane)
-  rc = lsd_frame_build_pyramids(f, gray_dev);
+  if (c->prefetchOn && c->inHook) {
+    // called from the tracker's enqueue hook: the main stream is busy with the tracking chain; build on the prefetch stream
+    // (after the arena's last user on the main stream), and make the main stream wait for the result before whatever is
+    // enqueued next — by then it is long done
+    hipError_t e = hipSuccess;
+    if (f->arenaFreed) e = hipStreamWaitEvent(c->stream2, f->arenaFreed, 0);
+    if (e == hipSuccess) {
+      rc = lsd_frame_build_pyramids(f, gray_dev, c->stream2);
+      if (rc) { lsdhip_frame_destroy(f); return rc; }
+      e = hipEventRecord(c->evPrefetchDone, c->stream2);
+    }
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->evPrefetchDone, 0);
+    if (e != hipSuccess) { lsd_set_error("prefetch stream: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
+    *out = f;
+    return LSDHIP_OK;
+  }
+  rc = lsd_frame_build_pyramids(f, gray_dev, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
   *out = f;
   return LSDHIP_OK;
@@ -612,7 +637,7 @@ extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_ho
   if (rc) return rc;
   hipError_t e = hipMemcpyAsync(f->d_gray, gray_host, (size_t)c->w * c->h, hipMemcpyHostToDevice, c->stream);
   if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create: upload failed: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
-  rc = lsd_frame_build_pyramids(f, nullptr);
+  rc = lsd_frame_build_pyramids(f, nullptr, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
   e = hipStreamSynchronize(c->stream);  // the host buffer may be reused by the caller
   if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
@@ -624,11 +649,18 @@ extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
   if (c->free_arenas.size() < 16) {
-    c->free_arenas.push_back(f->d_gray);  // arena base; reuse is ordered on the context's stream
+    // arena base; reuse on the main stream is ordered by the stream itself, reuse from the prefetch stream waits for this event
+    if (c->prefetchOn) {
+      (void)hipSetDevice(c->device);
+      if (!f->arenaFreed) (void)hipEventCreateWithFlags(&f->arenaFreed, hipEventDisableTiming);
+      if (f->arenaFreed) (void)hipEventRecord(f->arenaFreed, c->stream);
+    }
+    c->free_arenas.push_back({f->d_gray, f->arenaFreed});
   } else {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(f->d_gray);
+    if (f->arenaFreed) (void)hipEventDestroy(f->arenaFreed);
   }
   if (f->pendStats >= 0) c->slot_stats_owner[f->pendStats] = nullptr;
   if (f->pendRescale >= 0) c->slot_rescale_owner[f->pendRescale] = nullptr;

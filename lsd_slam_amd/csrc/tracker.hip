@@ -2384,7 +2384,11 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     }
     if (rc) return rc;
     if (sample && !topUp) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
-    if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) t->enqueueHook(t->enqueueHookUser);
+    if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) {
+      c->inHook = true;     // frames created in there may build their pyramids on the prefetch stream (frame.hip)
+      t->enqueueHook(t->enqueueHookUser);
+      c->inHook = false;
+    }
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
     // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.
