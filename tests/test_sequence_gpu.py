@@ -29,7 +29,16 @@ def test_sequence_50_frames_hip_vs_oracle(oracle, params):
     o_sc = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SCALAR, params=op)
     ctx = la.Context(w, h, K, params=params)
     g = sl.run_hip(la, ctx, frames, depth0, N_FRAMES)
+    try:
+        _compare(g, o_sse, o_sc, gt)
+    except AssertionError as e:
+        # diagnosis: a second HIP run on a fresh context tells a nondeterministic device path from a real disagreement with the oracle
+        g2 = sl.run_hip(la, la.Context(w, h, K, params=params), frames, depth0, N_FRAMES)
+        same = len(g2.frameToKF) == len(g.frameToKF) and all(np.array_equal(a, b) for a, b in zip(g.frameToKF, g2.frameToKF))
+        raise AssertionError("%s | a second HIP run gives %s poses" % (e, "IDENTICAL" if same else "DIFFERENT")) from e
 
+
+def _compare(g, o_sse, o_sc, gt):
     assert len(g.frameToKF) == len(o_sse.frameToKF) == N_FRAMES
     # identical verdicts, frame for frame
     assert g.diverged == o_sse.diverged and not any(g.diverged)
@@ -48,12 +57,18 @@ def test_sequence_50_frames_hip_vs_oracle(oracle, params):
     # per-frame relative poses
     for i, (a, b) in enumerate(zip(g.frameToKF, o_sse.frameToKF)):
         assert np.linalg.norm(a[4:7] - b[4:7]) < 5e-4 and min(np.linalg.norm(a[:4] - b[:4]), np.linalg.norm(a[:4] + b[:4])) < 5e-4, i
-    for a, b in zip(g.usage, o_sse.usage):
-        assert a == pytest.approx(b, rel=5e-3)
+    du = max(abs(a - b) / abs(b) for a, b in zip(g.usage, o_sse.usage))
+    du_ref = max(abs(a - b) / abs(b) for a, b in zip(o_sc.usage, o_sse.usage))
+    print("pointUsage: max relative difference HIP vs oracle-SSE %.2e (oracle scalar vs SSE %.2e)" % (du, du_ref))
+    for i, (a, b) in enumerate(zip(g.usage, o_sse.usage)):
+        assert a == pytest.approx(b, rel=5e-3), ("pointUsage of frame %d" % (i + 1), a, b)
 
     # keyframe changes: rescale factors and semi-dense counts (within 1 %)
-    for a, b in zip(g.rescale, o_sse.rescale):
-        assert a == pytest.approx(b, rel=1e-3)
+    dr = max(abs(a - b) / abs(b) for a, b in zip(g.rescale, o_sse.rescale))
+    dr_ref = max(abs(a - b) / abs(b) for a, b in zip(o_sc.rescale, o_sse.rescale))
+    print("keyframe rescale factors: max relative difference HIP vs oracle-SSE %.2e (oracle scalar vs SSE %.2e)" % (dr, dr_ref))
+    for i, (a, b) in enumerate(zip(g.rescale, o_sse.rescale)):
+        assert a == pytest.approx(b, rel=1e-3), ("rescale factor of keyframe %d" % (i + 1), a, b)
     for a, b in zip(g.semidense + [g.final_semidense], o_sse.semidense + [o_sse.final_semidense]):
         assert abs(a - b) <= 0.01 * b, (a, b)
     # the final map itself: validity masks nearly identical, inverse depths close where both are valid
