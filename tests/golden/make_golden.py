@@ -6,7 +6,8 @@ counts, the trackFrame result and the updateKeyframe result come from oracle/_re
 SE3Tracker.cpp / DepthMap.cpp / Frame.cpp compiled against stand-in dependency headers (oracle/ref/, `make -C oracle ref`;
 needs /root/reference, so the fixture is generated in the build container and committed).  Two groups have no reference
 counterpart and come from the oracle: the fixed-pose residual records in the exact-reciprocal arithmetic a GPU can match
-(the reference's SSE path uses _mm_rcp_ps) and the Sim3 records (Sim3Tracker is not part of oracle/_ref).
+(the reference's SSE path uses _mm_rcp_ps) and the exact-reciprocal Sim3 records; `sim3_ref_*` is a whole trackFrameSim3
+call through the reference's own Sim3Tracker.cpp.
 The CPU suite checks that the ORACLE reproduces every entry (so oracle == reference on this input, and no drift); the GPU
 suite checks the HIP path against them with no oracle involved at run time.  Run from the repository root:
     python tests/golden/make_golden.py
@@ -103,6 +104,18 @@ def compute(frames, depth0, K, L=None):
     rs = s3.track(refa, fb, np.array([1.0, 0, 0, 0, 0, 0, 0, 1.0]), 3, 1)
     g["sim3_track_pose"] = np.array(rs.frameToRef, np.float64)
     g["sim3_track_scalars"] = np.array([rs.lastResidual, rs.lastDepthResidual, rs.lastPhotometricResidual, rs.pointUsage, rs.diverged], np.float64)
+    # the same call through the REFERENCE's own Sim3Tracker.cpp (SSE path, _mm_rcp_ps): pose, residuals, usage, 7x7 Hessian
+    kfr = po.Frame(0, frames[0], K, L=L)
+    kfr.set_depth_gt(depth0)
+    refr = po.TrackingReference(L=L)
+    refr.import_frame(kfr)
+    fbr = po.Frame(3, frames[3], K, L=L)
+    fbr.set_depth_gt((depth0 / 1.1).astype(np.float32))
+    s3r = po.Sim3Tracker(W, H, K, mode=po.SSE, L=L)
+    rr = s3r.track(refr, fbr, np.array([1.0, 0, 0, 0, 0, 0, 0, 1.0]), 3, 1)
+    g["sim3_ref_track_pose"] = np.array(rr.frameToRef, np.float64)
+    g["sim3_ref_track_scalars"] = np.array([rr.lastResidual, rr.lastDepthResidual, rr.lastPhotometricResidual, rr.pointUsage, rr.affine_a, rr.affine_b, rr.diverged], np.float64)
+    g["sim3_ref_hessian"] = np.array(rr.hessian, np.float32)
     return g
 
 
@@ -112,7 +125,7 @@ def main():
         raise SystemExit("oracle/_ref is needed to make the fixture (make -C oracle ref; needs /root/reference)")
     frames, depth0, K, gt = synth.make_sequence(W, H, N)
     g = compute(frames, depth0, K, L=po.lib(ref="sse"))
-    g["generated_by"] = np.array("oracle/_ref/liblsd_ref_sse.so (reference sources, -DENABLE_SSE -DNDEBUG) + oracle for residual_records / sim3_*")
+    g["generated_by"] = np.array("oracle/_ref/liblsd_ref_sse.so (reference sources, -DENABLE_SSE -DNDEBUG) + oracle for residual_records / sim3_records / sim3_track_*")
     np.savez_compressed(OUT, frames=frames, depth0=depth0.astype(np.float32), K=np.asarray(K, np.float32), **g)
     print("wrote %s (%d bytes, %d entries)" % (OUT, os.path.getsize(OUT), len(g)))
 
