@@ -76,6 +76,9 @@ const char* lsdloop_last_error(void);
  * processes from an ncclUniqueId, lsdloop_comm_unique_id makes one).  hyp rows use lsdhip_hypothesis (32 bytes per pixel). */
 typedef struct lsdband lsdband;
 int lsdband_create(int device, int w, int H, int world, int first_band, int n_local, lsdband** out);
+/* the index arithmetic alone (no GPU): layout4[4 r ..] = owned [y0, y1), window [a, b) of band r; segments4 = (receiving band,
+ * owning band, first global row, rows) per halo segment, at most cap of them written; returns the number of segments */
+int lsdband_plan(int H, int world, int* window_rows_out, int* layout4, int* segments4, int cap);
 void lsdband_destroy(lsdband* b);
 int lsdband_window_rows(const lsdband* b);
 int lsdband_layout(const lsdband* b, int band, int out4[4]);   /* owned [y0, y1), window [a, b) */

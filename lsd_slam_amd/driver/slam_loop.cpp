@@ -315,15 +315,15 @@ struct lsdband {
   bool local(int r) const { return r >= first && r < first + nlocal; }
 };
 
-extern "C" int lsdband_create(int device, int w, int H, int world, int first_band, int n_local, lsdband** out) {
-  if (!out || w <= 0 || H <= 0 || world < 1 || first_band < 0 || n_local < 1 || first_band + n_local > world || (H % 16) != 0) return LSDHIP_E_ARG;
-  lsdband* b = new lsdband();
-  b->device = device; b->w = w; b->H = H; b->world = world; b->first = first_band; b->nlocal = n_local;
+// owned rows and windows of every band (lsd_slam_amd/bands.py BandPlan.__init__): pure index arithmetic, no device
+static bool band_fill_layout(lsdband* b) {
+  const int H = b->H, world = b->world;
   const int base = H / world, extra = H % world;
   int y = 0, need = 0;
+  b->owned.clear(); b->window.clear();
   for (int r = 0; r < world; r++) {
     const int n = base + (r < extra ? 1 : 0);
-    if (n < 1) { delete b; g_err = "lsdband_create: more bands than rows"; return LSDHIP_E_ARG; }
+    if (n < 1) return false;
     b->owned.push_back({y, y + n});
     y += n;
     need = std::max(need, n + BAND_HALO_TOP + BAND_HALO_BOTTOM);
@@ -334,6 +334,34 @@ extern "C" int lsdband_create(int device, int w, int H, int world, int first_ban
     b->window.push_back({a, a + b->window_rows});
   }
   b->proc_of.assign(world, 0);
+  return true;
+}
+// The plan alone, no GPU needed (CPU tests compare it with BandPlan): layout4[4 r .. 4 r + 3] = owned [y0, y1), window [a, b) of
+// band r; segments: up to cap triples (receiving band, sending band, first global row, rows) -> 4 ints each; returns their number.
+extern "C" int lsdband_plan(int H, int world, int* window_rows_out, int* layout4, int* segments4, int cap) {
+  if (H <= 0 || world < 1 || (H % 16) != 0) return LSDHIP_E_ARG;
+  lsdband b;
+  b.H = H; b.world = world;
+  if (!band_fill_layout(&b)) return LSDHIP_E_ARG;
+  if (window_rows_out) *window_rows_out = b.window_rows;
+  if (layout4)
+    for (int r = 0; r < world; r++) {
+      layout4[4 * r] = b.owned[r].first; layout4[4 * r + 1] = b.owned[r].second;
+      layout4[4 * r + 2] = b.window[r].first; layout4[4 * r + 3] = b.window[r].second;
+    }
+  int n = 0;
+  for (int r = 0; r < world; r++)
+    for (const BandSeg& s : b.recv_list(r)) {
+      if (segments4 && n < cap) { segments4[4 * n] = r; segments4[4 * n + 1] = s.peer; segments4[4 * n + 2] = s.row0; segments4[4 * n + 3] = s.nrows; }
+      n++;
+    }
+  return n;
+}
+extern "C" int lsdband_create(int device, int w, int H, int world, int first_band, int n_local, lsdband** out) {
+  if (!out || w <= 0 || H <= 0 || world < 1 || first_band < 0 || n_local < 1 || first_band + n_local > world || (H % 16) != 0) return LSDHIP_E_ARG;
+  lsdband* b = new lsdband();
+  b->device = device; b->w = w; b->H = H; b->world = world; b->first = first_band; b->nlocal = n_local;
+  if (!band_fill_layout(b)) { delete b; g_err = "lsdband_create: more bands than rows"; return LSDHIP_E_ARG; }
   const float K4[4] = {0.5f * w, 0.5f * w, 0.5f * w, 0.5f * b->window_rows};   // unused by the regulariser
   int rc = lsdhip_ctx_create(device, w, b->window_rows, K4, nullptr, &b->ctx);
   if (rc == LSDHIP_OK) rc = lsdhip_ctx_set_async(b->ctx, 1);

@@ -101,3 +101,35 @@ def test_banded_passes_two_gloo_ranks(oracle, tmp_path):
     for r in range(2):
         y0, y1 = plan.owned[r]
         _assert_rows_equal(np.load(tmp_path / ("band%d.npy" % r)), ref[y0:y1], "rank %d" % r)
+
+
+def test_native_band_plan_equals_python_plan():
+    """The index arithmetic of the C++ band loop (liblsdhip_driver.so lsdband_plan: owned rows, windows, halo segments) against
+    BandPlan for a sweep of map heights and band counts — no GPU involved (what the multi-GPU exchange sends where cannot be run
+    on a one-GPU box, so at least its plan is pinned here)."""
+    import ctypes as C
+    from lsd_slam_amd import driver
+    from lsd_slam_amd.bands import BandPlan
+    L = driver.lib()
+    for H in (64, 256, 384, 480, 1024, 2160 - 2160 % 16, 2160):
+        if H % 16:
+            continue
+        for world in (1, 2, 3, 5, 8, 13):
+            if world > H // 16:
+                continue
+            plan = BandPlan(H, world)
+            wr = C.c_int()
+            lay = (C.c_int * (4 * world))()
+            cap = 8 * world
+            seg = (C.c_int * (4 * cap))()
+            n = L.lsdband_plan(H, world, C.byref(wr), lay, seg, cap)
+            assert n >= 0 and wr.value == plan.window_rows, (H, world)
+            for r in range(world):
+                assert (lay[4 * r], lay[4 * r + 1]) == plan.owned[r] and (lay[4 * r + 2], lay[4 * r + 3]) == plan.window[r], (H, world, r)
+            want = [(r, s, lo, cnt) for r in range(world) for (s, lo, cnt) in plan.recv_list(r)]
+            got = [(seg[4 * k], seg[4 * k + 1], seg[4 * k + 2], seg[4 * k + 3]) for k in range(n)]
+            assert got == want, (H, world)
+            # what a band sends is what the others receive from it
+            for r in range(world):
+                sends = sorted((d, lo, cnt) for (d, s, lo, cnt) in got if s == r)
+                assert sends == sorted(plan.send_list(r)), (H, world, r)
