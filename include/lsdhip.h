@@ -152,15 +152,18 @@ typedef struct lsdhip_tracker_settings {
 int lsdhip_tracker_get_settings(const lsdhip_tracker* t, lsdhip_tracker_settings* out);
 int lsdhip_tracker_set_settings(lsdhip_tracker* t, const lsdhip_tracker_settings* in);
 /* Execution strategy of trackFrame on the device (no reference counterpart; results are the same up to summation order).
- * Default: one kernel launch per residual evaluation (k_track_step).  maxStrips > 0: pyramid levels that fit maxStrips strips
- * of 640 pixels (one workgroup each, at most 128) run inside ONE persistent launch whose workgroups exchange their partial
- * sums through memory (k_track_persist); finer levels continue launch-per-evaluation.  maxStrips = 0 switches it off.
- * Measured on MI355X at 640x480: the exchange costs 1.5 us at 8 strips, 4.8 us at 30, 10 us at 120 (profiles/r02_notes.md),
- * so only the two coarsest levels profit; environment LSDHIP_PERSIST=1 / LSDHIP_PT_MAXG=n set the same at creation. */
-int lsdhip_tracker_set_persistent(lsdhip_tracker* t, int maxStrips);
+ * enable = 1 (default): the coarsest pyramid levels of a trackFrame job — those whose pixel counts together fit 6400 LDS list
+ * entries (levels 4 + 3 of a 640x480 frame), never the finest level of the job — run their whole LM loops in ONE launch of
+ * k_track_coarse: one 512-lane workgroup per speculative trial evaluates the whole level from an LDS-resident point list, one
+ * {tag, value}-granule exchange per step, the same decision taken in every workgroup.  The k_track_step chain (one launch per
+ * step) continues with the finer levels.  fold = 1 (default, only with more than one trial per step): a further workgroup
+ * evaluates the next level's first evaluation at the last accepted pose while a trial set is being evaluated, so a level that
+ * ends in a chain of rejections costs no extra step.  enable = 0: every level on the chain.  Environment at creation:
+ * LSDHIP_COARSE=0 / LSDHIP_COARSE_FOLD=0. */
+int lsdhip_tracker_set_coarse(lsdhip_tracker* t, int enable, int fold);
 /* Diagnostics (no reference counterpart): how trackFrame jobs were executed on the device so far.
- * out[0] = jobs run by the persistent kernel (one launch for the whole coarse-to-fine loop), out[1] = jobs it gave up on and
- * that were rerun launch-per-evaluation, out[2] = 1 if the persistent kernel has been switched off, out[3] = evaluations of
+ * out[0] = jobs whose coarse levels ran in the cluster kernel, out[1] = jobs it gave up on (bounded spins) and that were rerun on
+ * the chain, out[2] = 1 if the cluster kernel has been switched off after repeated give-ups; evaluations of
  * the last job per pyramid level 0..4 follow in out[3..7]. */
 int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
 /* Execution strategy of the launch-per-evaluation chain: the LM loop's "increase lambda and retry" sequence
@@ -171,11 +174,13 @@ int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
  * number at every level; trials = 1: one evaluation per launch.  finestLevelWorkgroups: workgroups per
  * trial at the finest level while trials > 1 (0 = keep the current value, default 80). */
 int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups);
-/* out[0] = k_track_step launches of the last job that evaluated (<= its numEvaluations), out[1] = trials per launch. */
+/* out[0] = kernel launches of the last job that evaluated (k_track_step launches + 1 if the cluster kernel ran; <= its
+ * numEvaluations), out[1] = most trials per step (the per-level numbers follow the automatic policy above). */
 int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
-/* Diagnostics: shader cycles workgroup 0 of the persistent kernel spent in each phase of the last job (0 level entry, 1 warp +
- * texel issue, 2 workgroup top-3, 3 residual arithmetic, 4 reduction + publish, 5 all-gather, 6 totals + tail, 7 LM step). */
-int lsdhip_tracker_phase_cycles(const lsdhip_tracker* t, unsigned long long out[10]);
+/* out[0] = k_track_step launches of the last job that evaluated, out[1] = steps (evaluate -> exchange -> decide) inside the
+ * cluster kernel, out[2] = cluster-kernel launches (0 / 1), out[3] = most trials per step.  Dependent steps of the job =
+ * out[0] + out[1]. */
+int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]);
 /* Host-side pipelining: `fn(user)` is called on the calling thread by lsdhip_tracker_track once the job's launches are
  * queued and before the host waits for the result — the place to queue independent work on the same context (the next
  * image's upload and pyramids, what the reference's image-loader thread does ahead of the tracking thread,

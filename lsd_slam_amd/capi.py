@@ -96,14 +96,14 @@ def _signatures():
         "lsdhip_tracker_set_max_its": (i, [vp, vp]),
         "lsdhip_tracker_get_settings": (i, [vp, C.POINTER(TrackerSettings)]),
         "lsdhip_tracker_set_settings": (i, [vp, C.POINTER(TrackerSettings)]),
-        "lsdhip_tracker_set_persistent": (i, [vp, i]),
+        "lsdhip_tracker_set_coarse": (i, [vp, i, i]),
         "lsdhip_depth_copy_rows_batch": (i, [vp, i, vp]),
         "lsdhip_ctx_alloc_dev": (i, [vp, C.c_size_t, vp]),
         "lsdhip_ctx_free_dev": (i, [vp, vp]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
         "lsdhip_tracker_launch_stats": (i, [vp, vp]),
-        "lsdhip_tracker_phase_cycles": (i, [vp, vp]),
+        "lsdhip_tracker_step_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_enqueue_hook": (i, [vp, vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_track_batch": (i, [vp, i, pvp, pvp, vp, C.POINTER(TrackResult)]),

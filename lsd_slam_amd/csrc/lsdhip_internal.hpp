@@ -112,7 +112,9 @@ struct TrackState {
   int levelEvals[LSD_LEVELS];  // evaluations per pyramid level (diagnostics / bench line)
   int ncand;                 // trials the launch that produced the pending sums evaluated (>= 1)
   int lastCand;              // which of them was the last one the LM loop actually executed
-  int numLaunches;           // launches that did an evaluation so far
+  int numLaunches;           // k_track_step launches that did an evaluation so far
+  int coarseSteps;           // steps (evaluate -> exchange -> decide) the coarse-level cluster kernel ran for this job
+  float coarseBytes;         // algorithmic bytes of the evaluations that ran inside the cluster kernel (part of `bytes`)
 };
 
 // What the host reads back (pinned, device-mapped): written by k_lm_step when the job finishes (or every step in
@@ -126,8 +128,8 @@ struct TrackSummary {
   int levelEvals[LSD_LEVELS];
   int numLaunches;           // k_track_step launches that evaluated (< numEvaluations with reject-chain speculation)
   int seq;                   // (job tag << 12) | ordinal of the latest k_track_step launch of the chain that has started
-  int pad2_[1];
-  unsigned long long phase[10];   // k_track_persist: shader cycles workgroup 0 spent per phase, summed over the job's evaluations
+  int coarseSteps;           // steps of the coarse-level cluster kernel (k_track_coarse); 0 when the chain ran every level
+  double coarseBytes;        // algorithmic bytes of the evaluations inside the cluster kernel (included in `bytes`)
 };
 
 // A result the host needs eventually but not now (mean inverse depth / point count of a setDepth, the rescale factor
@@ -234,13 +236,15 @@ struct lsdhip_tracker {
   float* d_partials = nullptr;    // TrackScratch arena (sums | topkey | topval), see tracker.hip
   int max_blocks = 0;
   TrackState* d_state = nullptr;  // [2], double-buffered by launch parity
-  unsigned long long* d_ptrows = nullptr;   // k_track_persist: published rows [2][PT_MAXG][PT_ROW] + state record [128] (granules)
-  unsigned ptSalt = 0;            // per-launch tag salt (20 bits)
-  int ptMaxG = 8;                 // levels needing more strips than this continue in the k_track_step chain (LSDHIP_PT_MAXG)
-  bool persist = false;           // run trackFrame's coarse levels in the persistent kernel (lsdhip_tracker_set_persistent / LSDHIP_PERSIST=1)
-  bool persistOff = false;        // switched off after repeated give-ups
-  int persistFallbacks = 0;       // jobs the persistent kernel gave up on (rerun with k_track_step)
-  int persistJobs = 0;            // jobs launched on the persistent kernel
+  unsigned long long* d_ctrows = nullptr;   // k_track_coarse: published rows [2][LSD_SPEC_MAX + 1][CT_ROW] ({tag, value} granules)
+  unsigned ctSalt = 0;            // per-launch tag salt (20 bits)
+  bool coarse = false;            // run trackFrame's coarsest levels in the cluster kernel (lsdhip_tracker_set_coarse / LSDHIP_COARSE=0)
+  bool coarseFold = true;         // level-boundary speculation inside it (only with more than one trial per step)
+  bool coarseOff = false;         // switched off after repeated give-ups
+  int coarseFallbacks = 0;        // jobs the cluster kernel gave up on (rerun on the k_track_step chain)
+  int coarseJobs = 0;             // jobs whose coarse levels ran in the cluster kernel
+  int coarseSteps = 0;            // steps of the cluster kernel in the last job
+  double coarseBytes = 0;         // algorithmic bytes of the last job's evaluations inside the cluster kernel
   int levelEvaluations[LSD_LEVELS] = {};   // evaluations of the last job per pyramid level
   int block = 256;                // workgroup size of k_track_step (LSDHIP_TRACK_BLOCK)
   int grid_cap = 304;             // most workgroups one evaluation uses (LSDHIP_TRACK_CAP); larger levels grid-stride
@@ -256,16 +260,13 @@ struct lsdhip_tracker {
   size_t maskStride = 0;
   int numLaunches = 0;
   TrackSpec spec = {};             // of the job being launched
-  int jobTag = 0, launchOrdinal = 0;   // progress reporting of the launch chain (host tops the chain up while it waits)
-  int topUps = 0;
+  int jobTag = 0, launchOrdinal = 0;   // progress tag of the launch chain (TrackSummary::seq)
   int budgetExtra = 2;                 // launches queued beyond the most the recent jobs needed (finishing step + margin; LSDHIP_BUDGET_EXTRA)
   long long dbgJobs = 0, dbgEnqueued = 0, dbgMisses = 0, dbgWaitNs = 0, dbgLaunchNs = 0;   // LSDHIP_TRACK_DEBUG=1: printed at destroy
-  bool topUp = false;                  // LSDHIP_TOPUP=1: start with the shortest recent job's launches and append while waiting
-                                       // (measured slower than the fixed budget: the host's launches land late — r02_notes.md)
-  int recentChain[4] = {0, 0, 0, 0};   // same, counting only the levels the k_track_step chain ran behind the persistent kernel
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary
   unsigned long long* d_trace = nullptr;  // LSD_PHASE_TRACE developer build only
+  unsigned long long* d_ctrace = nullptr; // ... per-step marks of k_track_coarse
   // batch tracking (lsdhip_tracker_track_batch): per-job descriptions, states, scratch and summaries
   int batch_capacity = 0;
   TrackJob* d_bjobs = nullptr;

@@ -463,6 +463,7 @@ __device__ __forceinline__ void write_summary(const TrackState& s, const float* 
   out->bytes = s.bytes;
   for (int l = 0; l < LSD_LEVELS; l++) out->levelEvals[l] = s.levelEvals[l];
   out->numLaunches = s.numLaunches;
+  out->coarseSteps = s.coarseSteps; out->coarseBytes = s.coarseBytes;
   __threadfence_system();
   out->done = s.done;
 }
@@ -827,7 +828,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
       S.bytes = 0;
       for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
-      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
+      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0; S.coarseSteps = 0; S.coarseBytes = 0;
     }
     if (tid < 36) S.A[tid] = 0;
     if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
@@ -1393,45 +1394,54 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 }
 
 // =====================================================================================================================
-// Persistent tracking kernel: ONE launch runs SE3Tracker::trackFrame's whole coarse-to-fine loop.
+// Coarse-level cluster kernel: ONE launch runs the LM loops of the coarsest pyramid levels of SE3Tracker::trackFrame
+// (SE3Tracker.cpp:316-447), reject-chain speculation included, and no evaluation ever leaves its workgroup.
 //
-// The launch-per-evaluation chain above pays, per evaluation, a kernel boundary (~2.3 us), a re-read of every tile's
-// partial row by every workgroup (~3 us at level 1) and a cold start of the workgroup (state, job description).  Here
-// the workgroups stay resident and exchange their partial rows INSIDE the launch:
-//   * level l is cut into strips of <= PT_STRIP consecutive pixels, strip g owned by workgroup g < G_l (G_l = plan.pg[l],
-//     growing as the levels get finer).  On entering a level a workgroup compacts the valid reference pixels of its strip
-//     into an LDS point list ONCE (position, colour, variance: the pose-independent part of K0) — evaluations only read LDS
-//     and the tracked frame's texels;
-//   * one evaluation = warp + texel fetch of the list (two entries per lane in flight), workgroup top-3 order keys while
-//     the texels travel, residual / weights / normal equations, workgroup reduction, then ONE all-gather: every participant
-//     publishes a row of 8-byte {tag, value} granules (write-through relaxed agent-scope stores: the data is its own flag,
-//     no fences — cdna_hip_programming.md Guideline 16, form R2) and sweeps the rows of all participants;
-//   * every participant then runs the same Levenberg-Marquardt step on the same totals (lm_wave, as in k_track_step), so
-//     no second hop is needed to distribute the pose;
-//   * workgroups a level does not need yet sleep on a state record that workgroup 0 publishes at each level change.
-// The SSE tail drop needs the globally last (M mod 4) in-image points: a row carries its workgroup's 3 largest order keys and
-// the K2/K3 contributions of those points; the readers merge the keys and subtract the contributions of the winners.
-// Every spin is bounded: on a time-out the kernel reports done = 2 and the host reruns the job with k_track_step.
-// Levels too large for PT_MAXG strips (plan.pg[l] == 0) are handed to the k_track_step chain through st_out.
+// The launch-per-evaluation chain above pays per step a kernel boundary and dispatch (~4.5 us), a re-read of every tile's
+// partial row written by other XCDs (2-3.5 us) and the cold start of a few hundred workgroups — for levels of a few
+// thousand pixels whose evaluation itself takes ~1 us.  Here:
+//   * workgroup c < nt (512 lanes) owns trial c of every speculative set: it evaluates the WHOLE level at its trial's pose.
+//     The valid reference pixels of all cluster levels are compacted ONCE per job into an LDS list (x, y, 1 / idepth, colour,
+//     variance: the pose-independent part of TrackingReference::makePointCloud), so an evaluation reads LDS and the tracked
+//     frame's texels only; its 41 sums are reduced inside the workgroup and the SSE tail drop (last M mod 4 in-image points
+//     in the reference's x-outer order) is applied there as well — a trial's totals are complete when they leave the CU;
+//   * one exchange per step: every active workgroup publishes ONE row of 8-byte {tag, value} granules (41 totals + the
+//     increment / pose of its trial; relaxed agent-scope stores, the datum is its own flag: cdna_hip_programming.md G16 form
+//     R2) and every workgroup reads the <= 7 rows (one granule per lane, one round trip);
+//   * every workgroup then takes the same decision from the same numbers — which trial stops the reference's loop, lambda /
+//     incTry / counters advanced past the plain rejections before it, ONE LM step (lm_wave) — and workgroup c derives the
+//     pose of trial c of the next set by the closed-form lambda recurrence: no second hop;
+//   * level-boundary speculation ("fold"): workgroup nt evaluates the FIRST evaluation of the next finer level at the last
+//     accepted pose while the trial workgroups evaluate a set (or the single evaluation of a level whose maxIts is 0, as
+//     SlamSystem.cpp:80-81 sets for level 4).  If the level then ends without the pose having moved — the usual end: a chain
+//     of rejected retries — that evaluation is exactly the one the reference would run next and it is consumed in the same
+//     step (its row carries the pose and affine parameters it was made for; any mismatch discards it).
+// Decisions, evaluation counts and poses are those of running the same kernel with one trial per step and no fold, bit for
+// bit (same lists, same in-workgroup summation order).  Every spin is bounded: on a time-out the kernel reports done = 2 and
+// the host reruns the job on the k_track_step chain.  The finest level of a job never runs here (it writes refPixelWasGood):
+// the kernel hands the state to the chain through st_out.
 // =====================================================================================================================
-#define PT_BLOCK 256
-#define PT_STRIP 640           // pixels per strip = capacity of the LDS point list
-#define PT_MAXG 128            // most workgroups (strips) per level
-#define PT_ROW 136             // granules per published row: 41 sums | 3 keys | pad | 3 x 29 contributions
-#define PT_KEY0 RS_END
-#define PT_SUB0 48
-typedef unsigned long long pt_u64;
-typedef __attribute__((address_space(1))) pt_u64 pt_gu64;
-struct PersistPlan { int pg[LSD_LEVELS]; };
-__device__ __forceinline__ void pt_store(pt_u64* p, unsigned tag, unsigned val) {
-  __hip_atomic_store((pt_gu64*)p, ((pt_u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define CT_BLOCK 512
+#define CT_POOL 6400            // LDS list entries for all cluster levels of a job together
+#define CT_ROW 72               // granules per published row: [0, 41) totals | [44, 69) record
+#define CT_REC0 44              // record: inc[6] | Tn (q, t)[7] | R[9] | t[3]; fold row: aff_a, aff_b at [0, 1], T at [6, 13)
+#define CT_SPIN_LIMIT (1u << 19)     // polls of one lane before the kernel gives up (~1 s)
+typedef unsigned long long ct_u64;
+typedef __attribute__((address_space(1))) ct_u64 ct_gu64;
+struct CoarsePlan {
+  int nt;                    // trial workgroups (the launch has nt + 1 workgroups: the last one evaluates the fold)
+  int low;                   // lowest level that runs in this kernel (> job.lastLevel)
+  int fold;                  // level-boundary speculation on / off
+  int trials[LSD_LEVELS];    // trials per set at each level (<= nt)
+};
+__device__ __forceinline__ void ct_store(ct_u64* p, unsigned tag, unsigned val) {
+  __hip_atomic_store((ct_gu64*)p, ((ct_u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ pt_u64 pt_load(const pt_u64* p) {
-  return __hip_atomic_load((pt_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ ct_u64 ct_load(const ct_u64* p) {
+  return __hip_atomic_load((ct_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#define PT_SPIN_LIMIT (1u << 21)     // polls of one wave before it gives up (~1 s)
 
-// the K2/K3 contributions of one point, in the order of s_sub (werr | 21 A | 6 b | err)
+// the K2/K3 contributions of one point, in the order of the tail-drop tables (werr | 21 A | 6 b | err)
 __device__ __forceinline__ void point_contrib(const PointOut& o, float* dst) {
   dst[0] = o.werr;
   int k = 1;
@@ -1447,144 +1457,98 @@ __device__ __forceinline__ void point_contrib(const PointOut& o, float* dst) {
   dst[k] = resw * o.res;
 }
 
-__global__ __launch_bounds__(PT_BLOCK) void k_track_persist(TrackJob job, PersistPlan plan, TrackState* __restrict__ st_out,
-                                                            pt_u64* __restrict__ rows, pt_u64* __restrict__ stg, unsigned salt,
-                                                            TrackSummary* __restrict__ out) {
-  constexpr int BLOCK = PT_BLOCK;
-  constexpr int WAVES = BLOCK / 64;
+#ifdef LSD_PHASE_TRACE
+#define CT_MARK(k) do { if (b == 0 && tid == 0) ctr_[k] = clock64(); } while (0)
+#else
+#define CT_MARK(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(CT_BLOCK) void k_track_coarse(TrackJob job, CoarsePlan plan, TrackState* __restrict__ st_out,
+                                                           ct_u64* __restrict__ rows, unsigned salt, TrackSummary* __restrict__ out
+#ifdef LSD_PHASE_TRACE
+                                                           , unsigned long long* __restrict__ ctrace
+#endif
+                                                           ) {
+  constexpr int BLOCK = CT_BLOCK, WAVES = BLOCK / 64, HALF = 256;
   constexpr int SW = sizeof(TrackState) / 4;
-  static_assert(SW <= 126, "state record too large for the state granules");
+  constexpr int P = 4;                                   // list entries per lane whose texels travel together
   __shared__ TrackState S;
   __shared__ LmShared sh;
-  __shared__ LmPar s_par;
-  __shared__ float s_sum[(PT_BLOCK / RS_END) > 4 ? (PT_BLOCK / RS_END) : 4][64];
-  __shared__ float s_red[RS_END * (BLOCK + 1) + 8];     // workgroup reduction; afterwards the gathered rows [44][PT_MAXG + 1]
-  __shared__ int s_keys[PT_MAXG * 3];
+  __shared__ LmPar s_par[2];                             // [0]: the level being iterated, [1]: the level below it (fold)
+  __shared__ float s_red[RS_END * (HALF + 1) + 8];       // workgroup reduction (transposed, conflict-free both ways)
+  __shared__ float s_sum[HALF / RS_END][64];
+  __shared__ unsigned l_xy[CT_POOL];                     // x | y << 16
+  __shared__ float l_inv[CT_POOL], l_I[CT_POOL], l_var[CT_POOL];
+  __shared__ float s_tot[LSD_SPEC_MAX + 1][CT_ROW];      // the gathered rows: trial c -> [c], fold -> [nt]
   __shared__ int s_wtop[WAVES][3];
   __shared__ int s_top[3];
   __shared__ float s_contrib[3][32];
-  __shared__ float s_sub[3][32];
-  __shared__ int s_nsub;
   __shared__ int s_cnt[WAVES];
   __shared__ int s_flag;
-  __shared__ float l_px[PT_STRIP], l_py[PT_STRIP], l_pz[PT_STRIP], l_I[PT_STRIP], l_var[PT_STRIP];
-  __shared__ unsigned l_xy[PT_STRIP];
-  static_assert(44 * (PT_MAXG + 1) + 16 * 87 <= RS_END * (BLOCK + 1) + 8, "gather area must fit the reduction scratch");
+  __shared__ int s_listOff[LSD_LEVELS], s_listN[LSD_LEVELS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x;
+  const int nt = plan.nt;
+  const bool isFold = b == nt;
+  const int mycand = isFold ? 0 : b;
   const unsigned tagbase = salt << 12;
-  if (tid == 0) s_flag = 1;
+#ifdef LSD_PHASE_TRACE
+  // developer build: 16 words per step — 0 step start, 1 evaluated, 2 published, 3 gathered, 4 decided (shader clock), 5 level,
+  // 6 trials, 7 list length, 8 / 9 wall clock at kernel entry / step end, 10 lists built, 11 step ordinal
+  unsigned long long* ctr_ = ctrace + 1;
+  unsigned long long ct_t0 = 0, ct_tl = 0, ct_w0 = 0;
+  if (b == 0 && tid == 0) { ct_t0 = clock64(); ct_w0 = wall_clock64(); }
+#endif
 
-  // ---- which level does this workgroup join at? ----------------------------------------------------------------------
-  int joinLevel = -1;
-  for (int l = job.topLevel; l >= job.lastLevel; l--) {
-    if (plan.pg[l] == 0) break;            // from here on the k_track_step chain takes over
-    if (b < plan.pg[l]) { joinLevel = l; break; }
+  // ---- every workgroup starts from the same state ---------------------------------------------------------------------
+  if (tid == 0) {
+    S.T = job.T0;
+    set_eval_pose(S, job.T0);
+    S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
+    S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
+    S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
+    S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
+    S.ncand = 1; S.lastCand = 0; S.numLaunches = 0; S.coarseSteps = 0; S.coarseBytes = 0;
+    S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
+    S.bytes = 0;
+    for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
+    s_flag = 1;
   }
-  if (joinLevel < 0) return;
-  if (joinLevel == job.topLevel) {
-    if (tid == 0) {
-      S.T = job.T0;
-      set_eval_pose(S, job.T0);
-      S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
-      S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
-      S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
-      S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
-      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
-      S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
-      S.bytes = 0;
-      for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
-    }
-    if (tid < 36) S.A[tid] = 0;
-    if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
-  } else {
-    // sleep until workgroup 0 publishes the state at the start of `joinLevel` (or the end of the job)
-    const unsigned want = tagbase | (0xF00u + (unsigned)joinLevel), fin = tagbase | 0xFFFu;
-    if (wave == 0) {
-      int st = 0;   // 1 = state there, 2 = job over, 3 = time-out
-      for (unsigned spins = 0; st == 0; spins++) {
-        const unsigned t0 = (unsigned)(pt_load(stg) >> 32), t1 = (unsigned)(pt_load(stg + 127) >> 32);
-        if (t1 == fin) st = 2;
-        else if (t0 == want) st = 1;
-        else if (spins > PT_SPIN_LIMIT) st = 3;
-        else __builtin_amdgcn_s_sleep(32);
-      }
-      if (lane == 0) s_flag = st;
-    }
-    __syncthreads();
-    if (s_flag != 1) return;
-    if (wave == 0) {
-      // every word of the record carries the tag: re-read until complete
-      unsigned* Sw = (unsigned*)&S;
-      bool bad = false;
-      for (unsigned spins = 0;; spins++) {
-        bool ok = true;
-        for (int i = lane; i < SW; i += 64) {
-          const pt_u64 x = pt_load(stg + i);
-          ok &= (unsigned)(x >> 32) == want;
-          Sw[i] = (unsigned)x;
-        }
-        if (__all(ok)) break;
-        if (spins > PT_SPIN_LIMIT) { bad = true; break; }
-      }
-      if (lane == 0) s_flag = bad ? 3 : 1;
-    }
-    __syncthreads();
-    if (s_flag != 1) return;
-  }
-  __syncthreads();
+  if (tid < 36) S.A[tid] = 0;
+  if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
 
-  int curLevel = -1, n_list = 0, G = 0;
-  EvalCtx a;
-  uint8_t* wasGood = nullptr;
-  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
-#define PT_MARK(k) do { const unsigned long long tn_ = clock64(); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
-  while (true) {
-    // leaving (job finished, or the next level belongs to the k_track_step chain, which reads st_out[0] with pending = 0):
-    // both state buffers get the final state, so that steps queued behind a finished job exit at once
-    if (S.done || plan.pg[S.level] == 0) {
-      if (b == 0) { copy_words<SW>(st_out, &S, tid, BLOCK); copy_words<SW>(st_out + 1, &S, tid, BLOCK); }
-      if (b == 0 && tid == 0) {
-        out->pad_[0] = 4; out->pad_[1] = S.level; out->pad_[2] = S.done * 1000 + S.numEvaluations;
-        for (int k = 0; k < 10; k++) out->phase[k] = ph[k];
-      }
-      break;
-    }
-    const int level = S.level;
-    if (level != curLevel) {
-      G = plan.pg[level];
-      curLevel = level;
-      make_ctx_dev(job, S, level, a);
-      wasGood = job.lv[level].writeMask ? job.wasGood : nullptr;
-      if (tid == BLOCK - 1) stage_lm_par(job, level, s_par);
-      // ---- the strip's valid reference pixels -> LDS point list (TrackingReference::makePointCloud, pose-independent) --
-      const int work = a.w * a.h;
-      const int strip = (work + G - 1) / G;
-      const int base = b * strip;
-      const int end = min(base + strip, work);
-      constexpr int KMAX = (PT_STRIP + BLOCK - 1) / BLOCK;
-      unsigned vmask = 0;
+  // ---- the valid reference pixels of every cluster level -> LDS lists (pose-independent; once per job) -----------------
+  // order within a level: wave, then 512-pixel chunk, then lane — fixed, so every workgroup builds the same list; all plane
+  // loads of a level are issued together (one memory round trip per level)
+  {
+    constexpr int KMAX = (CT_POOL + BLOCK - 1) / BLOCK;   // 13 chunks of 512 pixels at most per level
+    int off = 0;
+    for (int l = job.topLevel; l >= plan.low; l--) {
+      const TrackLevel& L = job.lv[l];
+      const int w = L.w, h = L.h, work = w * h;
       float vv[KMAX], dd[KMAX], ii[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; k++) {
+        const int i = k * BLOCK + tid;
+        const bool in = i < work;
+        vv[k] = in ? L.kf_idepthVar[i] : 0.f;
+        dd[k] = in ? L.kf_idepth[i] : 0.f;
+        ii[k] = in ? L.kf_image[i] : 0.f;
+      }
+      unsigned vmask = 0;
+      unsigned xys[KMAX];
       int wcount = 0;
 #pragma unroll
       for (int k = 0; k < KMAX; k++) {
-        const int i = base + k * BLOCK + tid;
-        const bool in = i < end;
-        vv[k] = in ? a.kf_idepthVar[i] : 0.f;
-        dd[k] = in ? a.kf_idepth[i] : 0.f;
-        ii[k] = in ? a.kf_image[i] : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < KMAX; k++) {
-        const int i = base + k * BLOCK + tid;
-        const int x = i % a.w, y = i / a.w;
-        const bool ok = i < end && !(x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) && !(vv[k] <= 0 || dd[k] == 0);
+        const int i = k * BLOCK + tid;
+        const int y = i / w, x = i - y * w;
+        xys[k] = (unsigned)x | ((unsigned)y << 16);
+        const bool ok = i < work && !(x < 1 || x >= w - 1 || y < 1 || y >= h - 1) && !(vv[k] <= 0 || dd[k] == 0);
         vmask |= (ok ? 1u : 0u) << k;
         wcount += __popcll(__ballot(ok));
       }
       if (lane == 0) s_cnt[wave] = wcount;
       __syncthreads();
-      int pos = 0, total = 0;
+      int pos = off, total = 0;
 #pragma unroll
       for (int wv = 0; wv < WAVES; wv++) { const int cw = s_cnt[wv]; if (wv < wave) pos += cw; total += cw; }
 #pragma unroll
@@ -1592,254 +1556,292 @@ __global__ __launch_bounds__(PT_BLOCK) void k_track_persist(TrackJob job, Persis
         const bool ok = (vmask >> k) & 1u;
         const unsigned long long bal = __ballot(ok);
         if (ok) {
-          const int i = base + k * BLOCK + tid;
-          const int x = i % a.w, y = i / a.w;
           const int p = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          const float inv = 1.0f / dd[k];
-          l_px[p] = inv * (a.fxi * x + a.cxi);
-          l_py[p] = inv * (a.fyi * y + a.cyi);
-          l_pz[p] = inv * 1.0f;
+          l_xy[p] = xys[k];
+          l_inv[p] = 1.0f / dd[k];
           l_I[p] = ii[k];
           l_var[p] = vv[k];
-          l_xy[p] = (unsigned)x | ((unsigned)y << 16);
         }
         pos += __popcll(bal);
       }
-      n_list = total;
+      if (tid == 0) { s_listOff[l] = off; s_listN[l] = total; }
+      off += total;
       __syncthreads();
-      PT_MARK(0);     // level entry (point list)
     }
-    // ---- pose of this evaluation ------------------------------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 9; i++) a.R[i] = S.R[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) a.t[i] = S.t[i];
-    a.aff_a = S.aff_a; a.aff_b = S.aff_b;
-    const unsigned epoch = tagbase | ((unsigned)(S.numEvaluations + 1) & 0xFFFu);
+  }
 
+  // evaluates list [off, off + n) at the pose / affine parameters in `a`; leaves the tail-corrected totals in lanes 0..40
+  // of wave 0 (return value; other lanes / waves: unspecified)
+  auto eval_list = [&](const EvalCtx& a, const int off, const int n) -> float {
     float acc[RS_END];
 #pragma unroll
     for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
     int key0 = -1, key1 = -1, key2 = -1;
-    // entries tid and tid + BLOCK: warp + texel fetch now, finish after the key exchange
-    PointWarp q0, q1;
-    PointTexels t0, t1;
-    const bool live0 = tid < n_list, live1 = tid + BLOCK < n_list;
-    {
-      const int e0 = live0 ? tid : 0, e1 = live1 ? tid + BLOCK : 0;
-      eval_warp(a, l_px[e0], l_py[e0], l_pz[e0], q0);
-      eval_warp(a, l_px[e1], l_py[e1], l_pz[e1], q1);
-      eval_fetch(a, q0, live0 && q0.in_image, t0);
-      eval_fetch(a, q1, live1 && q1.in_image, t1);
-      if (live0 && q0.in_image) { const unsigned xy = l_xy[e0]; top3_insert((int)(xy & 0xffffu) * a.h + (int)(xy >> 16), key0, key1, key2); }
-      if (live1 && q1.in_image) { const unsigned xy = l_xy[e1]; top3_insert((int)(xy & 0xffffu) * a.h + (int)(xy >> 16), key0, key1, key2); }
+    PointWarp q[P];
+    PointTexels tx[P];
+    bool live[P];
+    // warp + texel issue of the first P entries of this lane; order keys of all of them
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const int e = tid + p * BLOCK;
+      live[p] = e < n;
+      const int ee = off + (live[p] ? e : 0);
+      const unsigned xy = l_xy[ee];
+      const float inv = l_inv[ee];
+      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+      eval_warp(a, inv * (a.fxi * x + a.cxi), inv * (a.fyi * y + a.cyi), inv * 1.0f, q[p]);
+      eval_fetch(a, q[p], live[p] && q[p].in_image, tx[p]);
+      if (live[p] && q[p].in_image) top3_insert(x * a.h + y, key0, key1, key2);
     }
-    for (int e = tid + 2 * BLOCK; e < n_list; e += BLOCK) {      // strips denser than 2 points per lane: keys only
-      PointWarp q;
-      eval_warp(a, l_px[e], l_py[e], l_pz[e], q);
-      if (q.in_image) { const unsigned xy = l_xy[e]; top3_insert((int)(xy & 0xffffu) * a.h + (int)(xy >> 16), key0, key1, key2); }
+    for (int e = tid + P * BLOCK; e < n; e += BLOCK) {        // denser lists: keys now, the rest after the first P
+      const unsigned xy = l_xy[off + e];
+      const float inv = l_inv[off + e];
+      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+      PointWarp qq;
+      eval_warp(a, inv * (a.fxi * x + a.cxi), inv * (a.fyi * y + a.cyi), inv * 1.0f, qq);
+      if (qq.in_image) top3_insert(x * a.h + y, key0, key1, key2);
     }
-    PT_MARK(1);       // pose, warp, texel issue
-    block_top3(key0, key1, key2, s_wtop, s_top);                 // two barriers, in the shadow of the texel loads
-    PT_MARK(2);       // workgroup top-3
+    block_top3(key0, key1, key2, s_wtop, s_top);               // two barriers, in the shadow of the texel loads
     const int top0 = s_top[0], top1 = s_top[1], top2 = s_top[2];
-    auto finish_entry = [&](int e, const PointWarp& q, const PointTexels& t) {
-      const unsigned xy = l_xy[e];
-      const int x_ = (int)(xy & 0xffffu), y_ = (int)(xy >> 16);
+    auto finish_entry = [&](const int e, const PointWarp& qq, const PointTexels& tt) {
+      const int ee = off + e;
+      const unsigned xy = l_xy[ee];
+      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
       acc[RS_NREF] += 1.f;
-      if (!q.in_image) {
-        if (wasGood) wasGood[y_ * a.w + x_] = 0;
-        return;
-      }
+      if (!qq.in_image) return;
       PointOut o;
-      eval_finish(a, q, t, l_pz[e], l_I[e], l_var[e], o);
-      if (wasGood) wasGood[y_ * a.w + x_] = o.good ? 1 : 0;
+      eval_finish(a, qq, tt, l_inv[ee] * 1.0f, l_I[ee], l_var[ee], o);
       accumulate_point(o, acc);
-      const int key = x_ * a.h + y_;
+      const int key = x * a.h + y;
       const int r = key == top0 ? 0 : (key == top1 ? 1 : (key == top2 ? 2 : -1));
       if (r >= 0) point_contrib(o, s_contrib[r]);
     };
-    if (live0) finish_entry(tid, q0, t0);
-    if (live1) finish_entry(tid + BLOCK, q1, t1);
-    for (int e = tid + 2 * BLOCK; e < n_list; e += BLOCK) {
-      PointWarp q;
-      PointTexels t;
-      eval_warp(a, l_px[e], l_py[e], l_pz[e], q);
-      eval_fetch(a, q, q.in_image, t);
-      finish_entry(e, q, t);
-    }
-
-    PT_MARK(3);       // texel wait + residual / weights / normal equations
-    // ---- workgroup reduction (as k_track_step) --------------------------------------------------------------------
-    constexpr int CPP = RS_END;
-    constexpr int RSLICE = BLOCK / CPP;
-    constexpr int RRUN = (BLOCK + RSLICE - 1) / RSLICE;
 #pragma unroll
-    for (int k = 0; k < CPP; k++) s_red[k * (BLOCK + 1) + tid] = acc[k];
+    for (int p = 0; p < P; p++)
+      if (live[p]) finish_entry(tid + p * BLOCK, q[p], tx[p]);
+    for (int e = tid + P * BLOCK; e < n; e += BLOCK) {
+      const unsigned xy = l_xy[off + e];
+      const float inv = l_inv[off + e];
+      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+      PointWarp qq;
+      PointTexels tt;
+      eval_warp(a, inv * (a.fxi * x + a.cxi), inv * (a.fyi * y + a.cyi), inv * 1.0f, qq);
+      eval_fetch(a, qq, qq.in_image, tt);
+      finish_entry(e, qq, tt);
+    }
+    // ---- workgroup reduction: upper half onto lower half (only if it had work), then the transposed 256-lane form of
+    // k_track_step: thread (slice, k) adds a run of 43 lanes of column k, 41 threads add the 6 slices ----------------------
+    if (n > HALF) {
+      if (tid >= HALF) {
+#pragma unroll
+        for (int k = 0; k < RS_END; k++) s_red[k * (HALF + 1) + (tid - HALF)] = acc[k];
+      }
+      __syncthreads();
+      if (tid < HALF) {
+#pragma unroll
+        for (int k = 0; k < RS_END; k++) acc[k] += s_red[k * (HALF + 1) + tid];
+      }
+      __syncthreads();
+    }
+    if (tid < HALF) {
+#pragma unroll
+      for (int k = 0; k < RS_END; k++) s_red[k * (HALF + 1) + tid] = acc[k];
+    }
     __syncthreads();
+    constexpr int RSLICE = HALF / RS_END;                  // 6
+    constexpr int RRUN = (HALF + RSLICE - 1) / RSLICE;     // 43
     {
-      const int slice = tid / CPP, k = tid - slice * CPP;
+      const int slice = tid / RS_END, k = tid - slice * RS_END;
       if (slice < RSLICE) {
-        const float* row = s_red + k * (BLOCK + 1);
+        const float* row = s_red + k * (HALF + 1);
         const int j0 = slice * RRUN;
         float v[RRUN];
 #pragma unroll
-        for (int j = 0; j < RRUN; j++) v[j] = row[j0 + j];
+        for (int j = 0; j < RRUN; j++) v[j] = row[j0 + j];   // the last run reads 2 words of the next row (allocated)
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < RRUN; j++) s += (j0 + j < BLOCK) ? v[j] : 0.f;
+        for (int j = 0; j < RRUN; j++) s += (j0 + j < HALF) ? v[j] : 0.f;
         s_sum[slice][k] = s;
       }
     }
     __syncthreads();
-    // ---- publish this workgroup's row -------------------------------------------------------------------------------
-    // rows are double-buffered by evaluation parity: a workgroup can run at most one evaluation ahead of the slowest
-    // reader of its row (its next-but-one publication needs that reader's next row), so two buffers never collide
-    pt_u64* const rowsE = rows + (size_t)(S.numEvaluations & 1) * PT_MAXG * PT_ROW;
-    pt_u64* myrow = rowsE + (size_t)b * PT_ROW;
-    if (tid < RS_END) {
-      float s = s_sum[0][tid];
-#pragma unroll
-      for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
-      pt_store(myrow + tid, epoch, __float_as_uint(s));
-    } else if (tid >= 64 && tid < 67) {
-      pt_store(myrow + PT_KEY0 + (tid - 64), epoch, (unsigned)s_top[tid - 64]);
-    } else if (tid >= 128 && tid < 128 + 87) {
-      const int r = (tid - 128) / 29, j = (tid - 128) - r * 29;
-      pt_store(myrow + PT_SUB0 + r * 29 + j, epoch, __float_as_uint(s_top[r] >= 0 ? s_contrib[r][j] : 0.f));
-    }
-    PT_MARK(4);       // workgroup reduction + publish
-    // ---- gather the rows of all G participants: sums and keys ------------------------------------------------------------
-    float* s_g = s_red;                    // [col][PT_MAXG + 1]; the reduction scratch is dead (barrier above)
-    {
-      // per row: 41 sums and 3 keys; with few participants also the 87 tail contributions, so that the winners' values are
-      // already here when the keys have been merged (no second, dependent round trip)
-      constexpr int NC = RS_END + 3;
-      // (measured: at 8 participants the 87 extra granules per row cost more in the sweep — 3.7k -> 7.1k cycles — than the
-      // dependent fetch they save, 0.7k; kept for a single participant only)
-      constexpr int PT_EAGER_G = 16;
-      const bool eager = G <= 1;
-      const int per_row = eager ? NC + 87 : NC;
-      const int totalg = G * per_row;
-      float* s_csub = s_red + 44 * (PT_MAXG + 1);     // [PT_EAGER_G][87]
-      bool bad = false;
-      for (unsigned spins = 0;; spins++) {
-        bool ok = true;
-        for (int idx = tid; idx < totalg; idx += BLOCK) {
-          const int r = idx / per_row, e = idx - r * per_row;
-          const int c = e < NC ? e : PT_SUB0 + (e - NC);
-          const pt_u64 x = pt_load(rowsE + (size_t)r * PT_ROW + c);
-          ok &= (unsigned)(x >> 32) == epoch;
-          if (e < RS_END) s_g[e * (PT_MAXG + 1) + r] = __uint_as_float((unsigned)x);
-          else if (e < NC) s_keys[r * 3 + (e - RS_END)] = (int)(unsigned)x;
-          else s_csub[r * 87 + (e - NC)] = __uint_as_float((unsigned)x);
-        }
-        if (__all(ok)) break;
-        if (spins > PT_SPIN_LIMIT) { bad = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (bad) s_flag = 3;
-    }
-    __syncthreads();
-    if (s_flag == 3) {                     // give up: the host reruns the job with the launch-per-evaluation chain
-      if (b == 0 && tid == 0) { out->diverged = 0; __threadfence_system(); out->done = 2; }
-      return;
-    }
-    { const unsigned long long tn_ = clock64(); if (level == 1) ph[8] += tn_ - tprev; if (level == 3) ph[9] += tn_ - tprev; }
-    PT_MARK(5);       // all-gather (waiting for the slowest participant included)
-    // ---- column totals (waves 0..2) and the global tail points (wave 3) ----------------------------------------------------
-    if (wave < 3) {
-      constexpr int NSL = 4;
-      const int slice = tid / RS_END, col = tid - slice * RS_END;
-      if (slice < NSL) {
-        const int R = (G + NSL - 1) / NSL;
-        const float* colp = s_g + col * (PT_MAXG + 1);
-        float s = 0.f;
-        for (int r = slice * R; r < min(slice * R + R, G); r++) s += colp[r];
-        s_sum[slice][col] = s;
-      }
-    } else {
-      int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
-#pragma unroll
-      for (int qq = 0; qq < (PT_MAXG + 63) / 64; qq++) {
-        const int row = lane + 64 * qq;
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++) {
-          const int k = row < G ? s_keys[row * 3 + rr] : -1, ek = row * 3 + rr;
-          const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
-          k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? ek : e2);
-          k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? ek : e1);
-          k0 = g0 ? k : k0; e0 = g0 ? ek : e0;
-        }
-      }
-      int keys[3], src[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const int m = __builtin_amdgcn_readlane(wave_max_to_lane63(k0), 63);
-        const unsigned long long own = __ballot(k0 == m && m >= 0);
-        const int owner = own ? (int)__ffsll((long long)own) - 1 : 0;
-        keys[r] = m;
-        src[r] = __builtin_amdgcn_readlane(e0, owner);
-        if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
-      }
-      if (lane == 0) s_nsub = (keys[0] >= 0) + (keys[1] >= 0) + (keys[2] >= 0);
-      // the winners' contributions: 29 granules each, published with the rows (same epoch)
-      const int j = lane & 31;
-      if (j < 29 && G <= 1) {
-        const float* s_csub = s_red + 44 * (PT_MAXG + 1);
-        const int r = lane >> 5;
-        for (int rr = r; rr < 3; rr += 2)
-          if (keys[rr] >= 0) s_sub[rr][j] = s_csub[(src[rr] / 3) * 87 + (src[rr] % 3) * 29 + j];
-      } else if (j < 29) {
-        const int r = lane >> 5;
-        for (int rr = r; rr < 3; rr += 2) {
-          if (keys[rr] < 0) continue;
-          const pt_u64* p = rowsE + (size_t)(src[rr] / 3) * PT_ROW + PT_SUB0 + (src[rr] % 3) * 29 + j;
-          pt_u64 x = pt_load(p);
-          for (unsigned spins = 0; (unsigned)(x >> 32) != epoch && spins < PT_SPIN_LIMIT; spins++) x = pt_load(p);
-          s_sub[rr][j] = __uint_as_float((unsigned)x);
-        }
-      }
-    }
-    __syncthreads();
-    PT_MARK(6);       // column totals, key merge, tail contributions
+    float s = 0.f;
     if (wave == 0) {
-      float Mf = s_sum[0][RS_M];
-#pragma unroll
-      for (int k = 1; k < 4; k++) Mf += s_sum[k][RS_M];
-      float s = 0.f;
       if (tid < RS_END) {
         s = s_sum[0][tid];
 #pragma unroll
-        for (int k = 1; k < 4; k++) s += s_sum[k][tid];
+        for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
       }
-      const int M = (int)Mf;
+      // SSE tail drop: the reference's K2 / K3 loops never visit the last M mod 4 in-image points
+      const int M = (int)rl(s, RS_M);
       int need = M & 3;
-      if (need > s_nsub) need = s_nsub;
+      const int nsub = (top0 >= 0) + (top1 >= 0) + (top2 >= 0);
+      if (need > nsub) need = nsub;
       const int subIdx = (tid == RS_WERR) ? 0 : ((tid >= RS_A0 && tid < RS_B0) ? 1 + tid - RS_A0 : ((tid >= RS_B0 && tid < RS_ERR) ? 22 + tid - RS_B0 : (tid == RS_ERR ? 28 : -1)));
-      const float sub0 = s_sub[0][subIdx < 0 ? 0 : subIdx], sub1 = s_sub[1][subIdx < 0 ? 0 : subIdx], sub2 = s_sub[2][subIdx < 0 ? 0 : subIdx];
+      const int si = subIdx < 0 ? 0 : subIdx;
+      const float sub0 = s_contrib[0][si], sub1 = s_contrib[1][si], sub2 = s_contrib[2][si];
       if (subIdx >= 0) {
         if (need > 0) s -= sub0;
         if (need > 1) s -= sub1;
         if (need > 2) s -= sub2;
       }
-      if (tid < RS_NUM) sh.tot[tid] = s;
-      lm_wave(s_par, S, s, sh.tot, tid, b == 0 ? out : nullptr, nullptr);
     }
-    __syncthreads();
-    PT_MARK(7);       // Levenberg-Marquardt step
-    // ---- level change / end of job: wake the workgroups that join next (or tell them it is over) -----------------------------
-    if (b == 0 && (S.done || S.level != level)) {
-      bool later = false;        // does any workgroup still sleep?
-      for (int l = level - 1; l >= job.lastLevel && plan.pg[l] > 0; l--) later = later || plan.pg[l] > G;
-      if (S.done) {
-        if (later && tid == 0) pt_store(stg + 127, tagbase | 0xFFFu, 0u);
-      } else if (plan.pg[S.level] > G) {
-        const unsigned tg = tagbase | (0xF00u + (unsigned)S.level);
-        const unsigned* Sw = (const unsigned*)&S;
-        for (int i = tid; i < SW; i += BLOCK) pt_store(stg + i, tg, Sw[i]);
+    return s;
+  };
+
+  __syncthreads();
+#ifdef LSD_PHASE_TRACE
+  if (b == 0 && tid == 0) ct_tl = clock64();
+#endif
+  int step = 0;
+  while (true) {
+    // ---- leaving: job finished, or the next level belongs to the k_track_step chain (reads st_out[0], pending = 0) -------
+    if (S.done || S.level < plan.low) {
+      if (b == 0) {
+        copy_words<SW>(st_out, &S, tid, BLOCK);
+        copy_words<SW>(st_out + 1, &S, tid, BLOCK);
+      }
+      break;
+    }
+    const int level = S.level;
+#ifdef LSD_PHASE_TRACE
+    if (b == 0 && tid == 0) {
+      const unsigned long long n = ctrace[0];
+      ctrace[0] = n + 1;
+      ctr_ = ctrace + 1 + (n % 4096) * 16;
+      for (int k = 0; k < 16; k++) ctr_[k] = 0;
+      ctr_[5] = (unsigned long long)level; ctr_[8] = ct_w0; ctr_[10] = step == 0 ? ct_tl - ct_t0 : 0; ctr_[11] = (unsigned long long)step;
+    }
+    CT_MARK(0);
+#endif
+    const bool trialPhase = S.phase == 1;
+    const int ncand = trialPhase ? (S.ncand < 1 ? 1 : (S.ncand > nt ? nt : S.ncand)) : 1;
+    // the fold evaluates level - 1 at the last accepted pose whenever this step may end the level without moving it
+    const bool foldActive = plan.fold != 0 && level - 1 >= plan.low && (trialPhase || job.lv[level].maxIts <= 0);
+    const unsigned epoch = tagbase | ((unsigned)(step + 1) & 0xFFFu);
+    ct_u64* const rowsE = rows + (size_t)(step & 1) * (LSD_SPEC_MAX + 1) * CT_ROW;   // double-buffered by step parity
+    if (tid == BLOCK - 1) stage_lm_par(job, level, s_par[0], plan.trials[level] > 1 ? plan.trials[level] : 1);
+    if (tid == BLOCK - 2 && foldActive) stage_lm_par(job, level - 1, s_par[1], plan.trials[level - 1] > 1 ? plan.trials[level - 1] : 1);
+
+    const bool active = isFold ? foldActive : b < ncand;
+    if (active) {
+      const int lv = isFold ? level - 1 : level;
+      EvalCtx a;
+      make_ctx_dev(job, S, lv, a);
+      if (isFold) {
+        float R[9];
+        lsdm::quatf_to_rot(S.T.q, R);
+#pragma unroll
+        for (int i = 0; i < 9; i++) a.R[i] = R[i];
+        a.t[0] = S.T.t[0]; a.t[1] = S.T.t[1]; a.t[2] = S.T.t[2];
+      }
+      const float tot = eval_list(a, s_listOff[lv], s_listN[lv]);
+      CT_MARK(1);
+#ifdef LSD_PHASE_TRACE
+      if (b == 0 && tid == 0) { ctr_[6] = (unsigned long long)ncand; ctr_[7] = (unsigned long long)s_listN[lv]; }
+#endif
+      ct_u64* myrow = rowsE + (size_t)b * CT_ROW;
+      if (tid < RS_END) ct_store(myrow + tid, epoch, __float_as_uint(tot));
+      else if (tid >= 64 && tid < 64 + 25) {
+        const int j = tid - 64;
+        float v;
+        if (isFold) v = j == 0 ? S.aff_a : (j == 1 ? S.aff_b : ((j >= 6 && j < 13) ? ((const float*)&S.T)[j - 6] : 0.f));
+        else if (j < 6) v = S.inc[j];
+        else if (j < 13) v = ((const float*)&S.Tn)[j - 6];
+        else if (j < 22) v = S.R[j - 13];
+        else v = S.t[j - 22];
+        ct_store(myrow + CT_REC0 + j, epoch, __float_as_uint(v));
       }
     }
+    CT_MARK(2);
+    // ---- gather: one granule per lane, every lane polls its own ---------------------------------------------------------------
+    {
+      const int nrows = ncand + (foldActive ? 1 : 0);
+      constexpr int PER = RS_END + 25;
+      bool bad = false;
+      for (int idx = tid; idx < nrows * PER; idx += BLOCK) {
+        const int r = idx / PER, j = idx - r * PER;
+        const int slot = r < ncand ? r : nt;
+        const int e = j < RS_END ? j : CT_REC0 + (j - RS_END);
+        const ct_u64* p = rowsE + (size_t)slot * CT_ROW + e;
+        ct_u64 x = ct_load(p);
+        for (unsigned spins = 0; (unsigned)(x >> 32) != epoch; spins++) {
+          if (spins > CT_SPIN_LIMIT) { bad = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+          x = ct_load(p);
+        }
+        s_tot[slot][e] = __uint_as_float((unsigned)x);
+      }
+      if (bad) s_flag = 3;
+    }
+    __syncthreads();
+    if (s_flag == 3) {                     // give up: the host reruns the job on the launch-per-evaluation chain
+      if (b == 0 && tid == 0) { out->diverged = 0; __threadfence_system(); out->done = 2; }
+      return;
+    }
+    CT_MARK(3);
+    // ---- the decision, identically in every workgroup ---------------------------------------------------------------------
+    if (wave == 0) {
+      int pc = 0;
+      if (trialPhase) {
+        // back to the common view of the state: this workgroup's own trial moved incTry / inc / Tn / R / t
+        const int it0 = S.incTry - mycand;
+        const int c = tid < ncand ? tid : 0;
+        const int Mc = (int)s_tot[c][RS_M];
+        const float werrc = s_tot[c][RS_WERR] / ((Mc >> 2) << 2);
+        const float* ic = &s_tot[c][CT_REC0];
+        const float i0 = ic[0], i1 = ic[1], i2 = ic[2], i3 = ic[3], i4 = ic[4], i5 = ic[5];
+        const float incdot = (i0 * i0 + (i1 * i1 + i2 * i2)) + (i3 * i3 + (i4 * i4 + i5 * i5));
+        const bool stop = Mc < s_par[0].minWarped || werrc < S.lastErr || !(incdot > s_par[0].stepSizeMin);
+        const unsigned long long sm = __ballot(stop && tid < ncand);
+        pc = sm ? (int)__ffsll((long long)sm) - 1 : ncand - 1;
+        float lam = S.LM_lambda;
+        for (int j = 0; j < pc; j++) lam = lm_lambda_fail(lam, it0 + j, s_par[0].lambdaFailFac);
+        float skipped;
+        {
+          const float NR = s_tot[0][RS_NREF];
+          const float wh = (float)s_par[0].w * (float)s_par[0].h;
+          const float texels = 4.0f * NR < wh ? 4.0f * NR : wh;
+          skipped = 20.0f * NR + (s_par[0].writeMask ? 5.0f * NR : 0.0f) + 12.0f * texels;
+        }
+        const float* rec = &s_tot[pc][CT_REC0];
+        const int ne0 = S.numEvaluations, le0 = S.levelEvals[level];
+        float bytes1 = S.bytes;
+        for (int j = 0; j < pc; j++) bytes1 = bytes1 + skipped;
+        const float r0 = rec[tid < 25 ? tid : 0];
+        S.LM_lambda = lam;
+        S.incTry = it0 + pc;
+        S.numEvaluations = ne0 + pc;
+        if (tid == 0) S.levelEvals[level] = le0 + pc;
+        S.bytes = bytes1;
+        if (tid < 6) S.inc[tid] = r0;
+        else if (tid < 13) ((float*)&S.Tn)[tid - 6] = r0;
+        else if (tid < 22) S.R[tid - 13] = r0;
+        else if (tid < 25) S.t[tid - 22] = r0;
+      }
+      const float col = tid < RS_END ? s_tot[pc][tid] : 0.f;
+      if (tid < RS_NUM) sh.tot[tid] = col;
+      S.coarseSteps = step + 1;
+      lm_wave<true>(s_par[0], S, col, sh.tot, tid, b == 0 ? out : nullptr, nullptr, pc, mycand);
+      if (foldActive && !S.done && S.level == level - 1 && S.phase == 0) {
+        // the level ended: is the fold's evaluation the one the reference runs next (same pose, same affine parameters)?
+        const float* fr = &s_tot[nt][CT_REC0];
+        const float want = tid == 0 ? S.aff_a : (tid == 1 ? S.aff_b : ((tid >= 6 && tid < 13) ? ((const float*)&S.T)[tid - 6] : 0.f));
+        const bool same = (tid < 2 || (tid >= 6 && tid < 13)) ? (__float_as_uint(fr[tid < 25 ? tid : 0]) == __float_as_uint(want)) : true;
+        if (__all(same)) {
+          const float colf = tid < RS_END ? s_tot[nt][tid] : 0.f;
+          if (tid < RS_NUM) sh.tot[tid] = colf;
+          lm_wave<true>(s_par[1], S, colf, sh.tot, tid, b == 0 ? out : nullptr, nullptr, 0, mycand);
+        }
+      }
+      S.coarseBytes = S.bytes;
+    }
+    __syncthreads();
+    CT_MARK(4);
+#ifdef LSD_PHASE_TRACE
+    if (b == 0 && tid == 0) ctr_[9] = wall_clock64();
+#endif
+    step++;
   }
 }
 
@@ -1916,14 +1918,16 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
 #ifdef LSD_PHASE_TRACE
   HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 20) * 8));
   HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 20) * 8, c->stream));
+  HIPCHK(hipMalloc((void**)&t->d_ctrace, (1 + 4096 * 16) * 8));
+  HIPCHK(hipMemsetAsync(t->d_ctrace, 0, (1 + 4096 * 16) * 8, c->stream));
 #endif
   {
-    // persistent kernel: published rows (two parities) and the state record for late joiners, all {tag, value} granules
-    const size_t pt_bytes = ((size_t)2 * PT_MAXG * PT_ROW + 128) * sizeof(pt_u64);
-    HIPCHK(hipMalloc((void**)&t->d_ptrows, pt_bytes));
-    HIPCHK(hipMemsetAsync(t->d_ptrows, 0, pt_bytes, c->stream));
-    if (const char* e = getenv("LSDHIP_PERSIST")) t->persist = e[0] != '0';
-    if (const char* e = getenv("LSDHIP_PT_MAXG")) { t->ptMaxG = atoi(e); if (t->ptMaxG > PT_MAXG) t->ptMaxG = PT_MAXG; if (t->ptMaxG < 1) t->ptMaxG = 1; }
+    // cluster kernel (k_track_coarse): published rows, two step parities, {tag, value} granules
+    const size_t ct_bytes = (size_t)2 * (LSD_SPEC_MAX + 1) * CT_ROW * sizeof(ct_u64);
+    HIPCHK(hipMalloc((void**)&t->d_ctrows, ct_bytes));
+    HIPCHK(hipMemsetAsync(t->d_ctrows, 0, ct_bytes, c->stream));
+    if (const char* e = getenv("LSDHIP_COARSE")) t->coarse = e[0] != '0';
+    if (const char* e = getenv("LSDHIP_COARSE_FOLD")) t->coarseFold = e[0] != '0';
   }
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
@@ -1931,7 +1935,6 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   const char* env = getenv("LSDHIP_HOST_LM");
   t->hostLM = env && env[0] == '1';
   if (const char* e = getenv("LSDHIP_SPIN")) t->spinWait = e[0] != '0';
-  if (const char* e = getenv("LSDHIP_TOPUP")) t->topUp = e[0] != '0';
   if (const char* e = getenv("LSDHIP_BUDGET_EXTRA")) { t->budgetExtra = atoi(e); if (t->budgetExtra < 1) t->budgetExtra = 1; }
   *out = t;
   return LSDHIP_OK;
@@ -1939,8 +1942,8 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
 extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   if (!t) return;
   if (getenv("LSDHIP_TRACK_DEBUG") && t->dbgJobs > 0)
-    fprintf(stderr, "TRACKDBG jobs %lld launches enqueued %.2f/job, budget misses %lld, host launch %.1f us/job, host wait %.1f us/job, top-ups %d\n", t->dbgJobs,
-            (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs, t->topUps);
+    fprintf(stderr, "TRACKDBG jobs %lld launches enqueued %.2f/job, budget misses %lld, host launch %.1f us/job, host wait %.1f us/job, cluster jobs %d (fallbacks %d)\n", t->dbgJobs,
+            (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs, t->coarseJobs, t->coarseFallbacks);
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
 #ifdef LSD_PHASE_TRACE
@@ -1958,11 +1961,25 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
     }
   }
   (void)hipFree(t->d_trace);
+  if (const char* path = getenv("LSDHIP_CTRACE_FILE")) {
+    std::vector<unsigned long long> h(1 + 4096 * 16);
+    if (hipMemcpy(h.data(), t->d_ctrace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE* f = fopen(path, "w")) {
+        unsigned long long n = h[0] < 4096 ? h[0] : 4096;
+        for (unsigned long long i = 0; i < n; i++) {
+          for (int k = 0; k < 16; k++) fprintf(f, "%llu ", h[1 + i * 16 + k]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    }
+  }
+  (void)hipFree(t->d_ctrace);
 #endif
   if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   (void)hipFree(t->d_partials);
   (void)hipFree(t->d_maskSide);
-  (void)hipFree(t->d_ptrows);
+  (void)hipFree(t->d_ctrows);
   (void)hipFree(t->d_state);
   (void)hipHostFree(t->h_summary);
   if (t->d_pts) (void)hipFree(t->d_pts);
@@ -1972,12 +1989,6 @@ extern "C" int lsdhip_tracker_set_enqueue_hook(lsdhip_tracker* t, lsdhip_enqueue
   if (!t) return LSDHIP_E_ARG;
   t->enqueueHook = fn;
   t->enqueueHookUser = user;
-  return LSDHIP_OK;
-}
-// developer hook (tools/pt_check.py): shader cycles per phase of the last persistent job
-extern "C" int lsdhip_tracker_phase_cycles(const lsdhip_tracker* t, unsigned long long out[10]) {
-  if (!t || !out) return LSDHIP_E_ARG;
-  for (int k = 0; k < 10; k++) out[k] = t->h_summary->phase[k];
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_tracker_get_settings(const lsdhip_tracker* t, lsdhip_tracker_settings* o) {
@@ -2004,16 +2015,18 @@ extern "C" int lsdhip_tracker_set_settings(lsdhip_tracker* t, const lsdhip_track
   t->huber_d = in->huber_d; t->var_weight = in->var_weight;
   return LSDHIP_OK;
 }
-extern "C" int lsdhip_tracker_set_persistent(lsdhip_tracker* t, int maxStrips) {
-  if (!t || maxStrips < 0) return LSDHIP_E_ARG;
-  t->persist = maxStrips > 0;
-  t->persistOff = false;
-  if (maxStrips > 0) t->ptMaxG = maxStrips > PT_MAXG ? PT_MAXG : maxStrips;
+extern "C" int lsdhip_tracker_set_coarse(lsdhip_tracker* t, int enable, int fold) {
+  if (!t) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(t->ctx);
+  t->coarse = enable != 0;
+  t->coarseFold = fold != 0;
+  t->coarseOff = false;
+  for (int i = 0; i < 4; i++) t->recent[i] = 0;
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]) {
   if (!t || !out) return LSDHIP_E_ARG;
-  out[0] = t->persistJobs; out[1] = t->persistFallbacks; out[2] = t->persistOff ? 1 : 0;
+  out[0] = t->coarseJobs; out[1] = t->coarseFallbacks; out[2] = t->coarseOff ? 1 : 0;
   for (int l = 0; l < LSD_LEVELS; l++) out[3 + l] = t->levelEvaluations[l];
   return LSDHIP_OK;
 }
@@ -2029,7 +2042,12 @@ extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int
 }
 extern "C" int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]) {
   if (!t || !out) return LSDHIP_E_ARG;
-  out[0] = t->numLaunches; out[1] = t->specC;
+  out[0] = t->numLaunches + (t->coarseSteps > 0 ? 1 : 0); out[1] = t->specC;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]) {
+  if (!t || !out) return LSDHIP_E_ARG;
+  out[0] = t->numLaunches; out[1] = t->coarseSteps; out[2] = t->coarseSteps > 0 ? 1 : 0; out[3] = t->specC;
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int its[LSD_LEVELS]) {
@@ -2309,25 +2327,16 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   }
   t->h_summary->done = 0;
   const TrackSummary* S = t->h_summary;
-  // Launches a job needs = its evaluating launches + the finalising step; budget = the most of the recent jobs + 2 (launches
-  // queued behind the finishing one leave at once, ~4 us each).  Opt-in alternative (LSDHIP_TOPUP=1): start with what the
-  // shortest of the recent jobs needed and, while the host waits, watch the chain's progress (TrackSummary::seq, written by
-  // every launch as it starts) and append a launch whenever fewer than two are left in the queue.
+  // Launches of the k_track_step chain a job needs = its evaluating launches + the finalising step; budget = the most of the
+  // recent jobs + 2 (launches queued behind the finishing one leave at once, ~4 us each).
   int budget = 12;
   if (t->recent[0] > 0) {
-    budget = 1 << 30;
-    for (int i = 0; i < 4; i++) if (t->recent[i] > 0 && t->recent[i] < budget) budget = t->recent[i];
-    budget += 1;
-  }
-  // timing events on every 8th job only: two event packets and a host-side event query per job cost ~5 % of a frame; a timed
-  // job runs on the fixed budget, so that the two events bracket all of its launches
-  const bool sample = c->prof_on && ((c->prof_tick++ & 7) == 0);
-  const bool topUp = t->topUp && t->spinWait && !sample;
-  if (!topUp && t->recent[0] > 0) {   // fixed budget: the most of the recent jobs + 2
     budget = 0;
     for (int i = 0; i < 4; i++) if (t->recent[i] > budget) budget = t->recent[i];
     budget += t->budgetExtra;
   }
+  // timing events on every 8th job only: two event packets and a host-side event query per job cost ~5 % of a frame
+  const bool sample = c->prof_on && ((c->prof_tick++ & 7) == 0);
   t->dbgJobs++;
   t->jobTag = (t->jobTag % 0x7FFFF) + 1;
   t->launchOrdinal = 0;
@@ -2335,60 +2344,60 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   int guard = 0;
   int parity = 0, first = 1;
   if (int rc = prof_collect(c)) return rc;
-  // Persistent kernel (k_track_persist): the levels whose strips fit PT_MAXG workgroups run inside ONE launch; finer levels
-  // (if any) continue in the launch-per-evaluation chain from the state it leaves in d_state[0].
-  PersistPlan plan;
-  int ptGrid = 0;
-  bool ptHandoff = false;
-  for (int l = 0; l < LSD_LEVELS; l++) plan.pg[l] = 0;
-  if (t->persist && !t->persistOff) {
-    for (int l = topLevel; l >= job.lastLevel; l--) {
-      const long long work = (long long)job.lv[l].w * job.lv[l].h;
-      const int G = (int)((work + PT_STRIP - 1) / PT_STRIP);
-      if (job.lv[l].npts >= 0 || G > t->ptMaxG || (job.lv[l].w > 65535 || job.lv[l].h > 65535)) { ptHandoff = true; break; }
-      plan.pg[l] = G < 1 ? 1 : G;
-      if (l < topLevel && plan.pg[l] < plan.pg[l + 1]) plan.pg[l] = plan.pg[l + 1];   // participants never leave
-      if (plan.pg[l] > ptGrid) ptGrid = plan.pg[l];
+  // Cluster kernel (k_track_coarse): the coarsest levels of a trackFrame job — dense keyframe planes whose pixel counts
+  // together fit the LDS lists (CT_POOL), never the job's finest level — run in ONE launch; the k_track_step chain continues
+  // from the state it leaves in d_state[0 / 1].
+  CoarsePlan plan;
+  memset(&plan, 0, sizeof(plan));
+  bool useCoarse = false;
+  if (t->coarse && !t->coarseOff && job.trackFrameSemantics && topLevel > job.lastLevel) {
+    long long px = 0;
+    int low = topLevel + 1;
+    for (int l = topLevel; l > job.lastLevel; l--) {
+      const TrackLevel& L = job.lv[l];
+      const long long work = (long long)L.w * L.h;
+      if (L.npts >= 0 || px + work > CT_POOL || L.w > 65535 || L.h > 65535) break;
+      px += work;
+      low = l;
     }
-    if (plan.pg[topLevel] == 0) ptGrid = 0;
+    if (low <= topLevel) {
+      useCoarse = true;
+      plan.low = low;
+      plan.nt = 1;
+      for (int l = low; l <= topLevel; l++) {
+        plan.trials[l] = t->spec.trials[l] > 1 ? t->spec.trials[l] : 1;
+        if (plan.trials[l] > plan.nt) plan.nt = plan.trials[l];
+      }
+      plan.fold = (t->coarseFold && t->specC > 1) ? 1 : 0;
+    }
   }
-  bool usedPersist = false;
+  bool usedCoarse = false;
   while (true) {
     if (sample) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     int rc = LSDHIP_OK;
-    if (ptGrid > 0 && guard == 0) {
-      t->ptSalt = (t->ptSalt + 1) & 0xFFFFFu;
-      if (t->ptSalt == 0) {   // tags wrap: clear the granules so that no stale tag can match
-        HIPCHK(hipMemsetAsync(t->d_ptrows, 0, ((size_t)2 * PT_MAXG * PT_ROW + 128) * sizeof(pt_u64), c->stream));
-        t->ptSalt = 1;
+    if (useCoarse && guard == 0) {
+      t->ctSalt = (t->ctSalt + 1) & 0xFFFFFu;
+      if (t->ctSalt == 0) {   // tags wrap: clear the granules so that no stale tag can match
+        HIPCHK(hipMemsetAsync(t->d_ctrows, 0, (size_t)2 * (LSD_SPEC_MAX + 1) * CT_ROW * sizeof(ct_u64), c->stream));
+        t->ctSalt = 1;
       }
-      hipLaunchKernelGGL(k_track_persist, dim3(ptGrid), dim3(PT_BLOCK), 0, c->stream, job, plan, t->d_state, t->d_ptrows,
-                         t->d_ptrows + (size_t)2 * PT_MAXG * PT_ROW, t->ptSalt, t->d_summary);
+#ifdef LSD_PHASE_TRACE
+      hipLaunchKernelGGL(k_track_coarse, dim3(plan.nt + 1), dim3(CT_BLOCK), 0, c->stream, job, plan, t->d_state, t->d_ctrows, t->ctSalt,
+                         t->d_summary, t->d_ctrace);
+#else
+      hipLaunchKernelGGL(k_track_coarse, dim3(plan.nt + 1), dim3(CT_BLOCK), 0, c->stream, job, plan, t->d_state, t->d_ctrows, t->ctSalt,
+                         t->d_summary);
+#endif
       HIPCHK(hipGetLastError());
-      usedPersist = true;
-      t->persistJobs++;
+      usedCoarse = true;
+      t->coarseJobs++;
       first = 0;
       parity = 0;
-      if (ptHandoff) {
-        // budget of the chain = what the finer levels alone needed recently (+ the finishing step and a margin)
-        int cb = 26;
-        if (t->recentChain[0] > 0) {
-          cb = 0;
-          for (int i = 0; i < 4; i++) if (t->recentChain[i] > cb) cb = t->recentChain[i];
-          cb += 2;
-        }
-        rc = launch_steps(t, job, cb, &parity, &first);
-      }
-    } else {
-      rc = launch_steps(t, job, budget, &parity, &first);
     }
+    rc = launch_steps(t, job, budget, &parity, &first);
     if (rc) return rc;
-    if (sample && !topUp) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
-    if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) {
-      c->inHook = true;     // frames created in there may build their pyramids on the prefetch stream (frame.hip)
-      t->enqueueHook(t->enqueueHookUser);
-      c->inHook = false;
-    }
+    if (sample) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
+    if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) t->enqueueHook(t->enqueueHookUser);
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
     // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.
@@ -2402,19 +2411,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       volatile const int* done = &S->done;
       const auto tStart = std::chrono::steady_clock::now();
       unsigned spins = 0;
-      volatile const int* seqp = &S->seq;
       while (!*done) {
-        if (topUp) {
-          const int sq = *seqp;
-          const int started = (sq >> 12) == t->jobTag ? (sq & 0xFFF) : 0;
-          if (t->launchOrdinal - started < 2 && t->launchOrdinal < 2000) {
-            c->mtx.lock();
-            const int rcu = launch_steps(t, job, 1, &parity, &first);
-            c->mtx.unlock();
-            t->topUps++;
-            if (rcu) return rcu;
-          }
-        }
         if ((++spins & 1023u) == 0) {
           hipError_t q = hipStreamQuery(c->stream);
           if (q == hipSuccess) break;                       // budget consumed (done or not)
@@ -2429,14 +2426,15 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     }
     }
     if (S->done == 2) {
-      // the persistent kernel gave up on a spin (it never should): rerun the job with the launch-per-evaluation chain
+      // the cluster kernel gave up on a spin (it never should): rerun the job on the launch-per-evaluation chain
       HIPCHK(hipStreamSynchronize(c->stream));
-      t->persistFallbacks++;
-      if (t->persistFallbacks >= 3) t->persistOff = true;
-      ptGrid = 0;
+      t->coarseFallbacks++;
+      if (t->coarseFallbacks >= 3) t->coarseOff = true;
+      useCoarse = false;
       t->h_summary->done = 0;
       parity = 0; first = 1; guard = 1;
-      usedPersist = false;
+      usedCoarse = false;
+      budget = 12;
       continue;
     }
     if (S->done) break;
@@ -2444,27 +2442,21 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
     if (S->done == 2) continue;
     if (S->done) break;
-    if (usedPersist && !ptHandoff) {
-      lsd_set_error("persistent tracking kernel ended without a result (exit %d, level %d, state %d, grid %d, plan %d %d %d %d %d)", S->pad_[0], S->pad_[1],
-                    S->pad_[2], ptGrid, plan.pg[0], plan.pg[1], plan.pg[2], plan.pg[3], plan.pg[4]);
-      return LSDHIP_E_STATE;
-    }
     if (int rc2 = prof_collect(c)) return rc2;
     budget = 6;
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
   }
   if (sample) {
-    c->prof_bytes += S->bytes;
-    c->prof_launches += usedPersist ? S->numEvaluations : S->numLaunches;
+    // the roofline leg describes k_track_step: the cluster kernel's evaluations are neither in its bytes nor in its launches
+    // (their time is inside the bracket: a stated, small over-count of the chain's time)
+    c->prof_bytes += S->bytes - S->coarseBytes;
+    c->prof_launches += S->numLaunches;
   }
-  t->numLaunches = usedPersist ? S->numEvaluations : S->numLaunches;
+  t->numLaunches = S->numLaunches;
+  t->coarseSteps = usedCoarse ? S->coarseSteps : 0;
+  t->coarseBytes = usedCoarse ? S->coarseBytes : 0;
   t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = t->numLaunches;
   for (int l = 0; l < LSD_LEVELS; l++) t->levelEvaluations[l] = S->levelEvals[l];
-  if (usedPersist) {
-    int ce = 0;
-    for (int l = job.lastLevel; l <= topLevel; l++) if (plan.pg[l] == 0) ce += S->levelEvals[l];
-    t->recentChain[3] = t->recentChain[2]; t->recentChain[2] = t->recentChain[1]; t->recentChain[1] = t->recentChain[0]; t->recentChain[0] = ce;
-  }
   t->numEvaluations = S->numEvaluations;
   t->numWarpUpdates = S->numWarpUpdates;
   t->pointUsage = S->pointUsage; t->lastGoodCount = S->goodCount; t->lastBadCount = S->badCount; t->lastMeanRes = S->meanRes;

@@ -108,6 +108,7 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       const long upd0 = L.numUpdates;
       const long ev0 = L.evaluations;
       const long la0 = L.launches;
+      const long cs0 = L.coarseSteps;
       const long good0 = L.numTrackedGood;
       long lev0[5];
       for (int k = 0; k < 5; k++) lev0[k] = L.levelEvaluations[k];
@@ -116,6 +117,7 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       l->st.updates += L.numUpdates - upd0;
       l->st.evaluations += L.evaluations - ev0;
       l->st.track_launches += L.launches - la0;
+      l->st.coarse_steps += L.coarseSteps - cs0;
       l->st.tracked_good += L.numTrackedGood - good0;
       for (int k = 0; k < 5; k++) l->st.level_evaluations[k] += L.levelEvaluations[k] - lev0[k];
       if (L.newKeyframe) l->st.keyframes++;
@@ -200,9 +202,9 @@ extern "C" int lsdloop_set_live_queue(lsdloop* l, int frames) {
   l->loop->liveQueueLength = frames;
   return LSDHIP_OK;
 }
-extern "C" int lsdloop_set_persistent(lsdloop* l, int max_strips) {
+extern "C" int lsdloop_set_coarse(lsdloop* l, int enable, int fold) {
   if (!l) return LSDHIP_E_ARG;
-  try { l->loop->tracker.setPersistent(max_strips); return LSDHIP_OK; }
+  try { l->loop->tracker.setCoarse(enable != 0, fold != 0); return LSDHIP_OK; }
   catch (const Error& e) { g_err = e.what(); return e.status; }
 }
 extern "C" int lsdloop_set_speculation(lsdloop* l, int trials, int finest_level_workgroups) {

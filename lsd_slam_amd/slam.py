@@ -231,9 +231,9 @@ class SE3Tracker:
     def set_settings(self, st):
         check(self.L.lsdhip_tracker_set_settings(self.h_, C.byref(st)))
 
-    def set_persistent(self, max_strips):
-        """coarse pyramid levels in one persistent launch (0 = off, the default); see include/lsdhip.h"""
-        check(self.L.lsdhip_tracker_set_persistent(self.h_, int(max_strips)))
+    def set_coarse(self, enable, fold=True):
+        """coarsest pyramid levels in one launch of the cluster kernel (default on) / level-boundary speculation; see include/lsdhip.h"""
+        check(self.L.lsdhip_tracker_set_coarse(self.h_, int(bool(enable)), int(bool(fold))))
 
     def set_speculation(self, trials, finest_level_workgroups=0):
         """LM retries evaluated per launch (1 = one evaluation per launch); see include/lsdhip.h"""
@@ -245,8 +245,14 @@ class SE3Tracker:
         check(self.L.lsdhip_tracker_launch_stats(self.h_, out.ctypes.data))
         return int(out[0]), int(out[1])
 
+    def step_stats(self):
+        """(k_track_step launches of the last job, steps inside the cluster kernel, cluster-kernel launches, most trials per step)"""
+        out = np.zeros(4, np.int32)
+        check(self.L.lsdhip_tracker_step_stats(self.h_, out.ctypes.data))
+        return tuple(int(v) for v in out)
+
     def exec_stats(self):
-        """diagnostics: (persistent-kernel jobs, give-ups rerun launch-per-evaluation, switched off, evaluations per level 0..4)"""
+        """diagnostics: (cluster-kernel jobs, give-ups rerun on the chain, switched off, evaluations per level 0..4)"""
         out = np.zeros(8, np.int32)
         check(self.L.lsdhip_tracker_exec_stats(self.h_, out.ctypes.data))
         return int(out[0]), int(out[1]), bool(out[2]), out[3:8].tolist()
