@@ -28,681 +28,9 @@
 // (SURVEY.md §8(d)): 20 N_l + [l==1] 5 N_l + 12 min(w_l h_l, 4 N_l).
 #include <atomic>
 #include <chrono>
-#include "lsdhip_internal.hpp"
-#include <type_traits>
+#include "track_device.hpp"
+#include "tracker_coarse.hpp"
 
-
-// ---- wave64 sum via DPP (row_shr 1,2,3 / 4 / 8, row_bcast 15 / 31); result valid in lane 63 ----------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true));
-}
-__device__ __forceinline__ int dpp_max_i(int a, int b) { return a > b ? a : b; }
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ int dpp_i(int v) {   // masked-off / out-of-row lanes read INT_MIN-like identity (-1)
-  return __builtin_amdgcn_update_dpp(-1, v, CTRL, ROW_MASK, BANK_MASK, false);
-}
-// wave64 max of non-negative keys (identity -1); result valid in lane 63
-__device__ __forceinline__ int wave_max_to_lane63(int v) {
-  int t = dpp_max_i(v, dpp_i<0x111, 0xf, 0xf>(v));
-  t = dpp_max_i(t, dpp_i<0x112, 0xf, 0xf>(v));
-  t = dpp_max_i(t, dpp_i<0x113, 0xf, 0xf>(v));
-  t = dpp_max_i(t, dpp_i<0x114, 0xf, 0xe>(t));
-  t = dpp_max_i(t, dpp_i<0x118, 0xf, 0xc>(t));
-  t = dpp_max_i(t, dpp_i<0x142, 0xa, 0xf>(t));
-  t = dpp_max_i(t, dpp_i<0x143, 0xc, 0xf>(t));
-  return t;
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  float t = v + dpp_f<0x111, 0xf, 0xf>(v);  // row_shr:1
-  t = t + dpp_f<0x112, 0xf, 0xf>(v);        // row_shr:2
-  t = t + dpp_f<0x113, 0xf, 0xf>(v);        // row_shr:3
-  t = t + dpp_f<0x114, 0xf, 0xe>(t);        // row_shr:4 bank_mask:0xe
-  t = t + dpp_f<0x118, 0xf, 0xc>(t);        // row_shr:8 bank_mask:0xc
-  t = t + dpp_f<0x142, 0xa, 0xf>(t);        // row_bcast:15 row_mask:0xa
-  t = t + dpp_f<0x143, 0xc, 0xf>(t);        // row_bcast:31 row_mask:0xc
-  return t;
-}
-
-// Workgroup-wide top-3 of non-negative unique integer keys.  Every lane contributes up to three candidates sorted
-// descending (c0 >= c1 >= c2, -1 = none).  Result in s_out[0..2] (descending, -1 = none) after the final barrier.
-__device__ __forceinline__ void block_top3(int c0, int c1, int c2, int (*s_wave)[3], int* s_out) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    int m = __builtin_amdgcn_readlane(wave_max_to_lane63(c0), 63);
-    if (lane == 0) s_wave[wave][r] = m;
-    if (c0 == m && m >= 0) { c0 = c1; c1 = c2; c2 = -1; }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    const int nw = blockDim.x >> 6;
-    int v = (lane < nw * 3) ? s_wave[lane / 3][lane % 3] : -1;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      int m = __builtin_amdgcn_readlane(wave_max_to_lane63(v), 63);
-      if (lane == 0) s_out[r] = m;
-      if (v == m) v = -1;
-    }
-  }
-  __syncthreads();
-}
-// index of (r, c), c >= r, in the row-major upper triangle of the 6x6 normal matrix, as a constant expression (a running
-// counter keeps the accumulator array from being promoted to registers)
-__device__ __forceinline__ constexpr int tri_index(int r, int c) { return RS_A0 + r * 6 - (r * (r - 1)) / 2 + (c - r); }
-
-// branch-free (a branchy version gets turned into an indexed store, which drags the three keys into scratch memory)
-__device__ __forceinline__ void top3_insert(int k, int& c0, int& c1, int& c2) {
-  const int n0 = max(c0, k);
-  int t = min(c0, k);
-  const int n1 = max(c1, t);
-  t = min(c1, t);
-  c2 = max(c2, t);
-  c1 = n1;
-  c0 = n0;
-}
-
-// ---- per-point arithmetic -----------------------------------------------------------------------------------------
-struct EvalCtx {            // one level of a job + the pose under evaluation, in registers / SGPRs
-  const float* kf_idepth;
-  const float* kf_idepthVar;
-  const float* kf_image;
-  const float4* fr_grad;
-  const float* pts_pos;
-  const float* pts_colvar;
-  int npts, w, h;
-  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
-  float R[9], t[3];
-  float aff_a, aff_b;
-  float cameraPixelNoise2, var_weight, huber_half;
-};
-struct PointOut {
-  bool in_image;
-  bool good;
-  float res, c1, c2, hw;      // residual, affine terms, Huber weight of the affine estimator
-  float usage;                // min(1, z_ref / z_new)
-  float werr;                 // wh * w_p * r^2 (K2)
-  float w;                    // wh * w_p
-  float J[6];
-};
-
-// The evaluation of one point in three steps, so that a caller may interleave the steps of different points (the batch
-// throughput mode keeps the texel fetches of the next point in flight while it finishes the current one).  eval_point
-// below is the plain composition; operation order is that of the reference (see the comments inside).
-struct PointWarp { float Wx, Wy, Wz, u_new, v_new; bool in_image; };
-struct Texel3 { float x, y, z; };   // (gx, gy, I) of a 16-byte texel; the fourth word is never read
-struct PointTexels { Texel3 t00, t10, t01, t11; };
-__device__ __forceinline__ void eval_warp(const EvalCtx& a, float px, float py, float pz, PointWarp& q) {
-  // Wxp = rotMat * p + transVec (Eigen coefficient product: ((r0*x + r1*y) + r2*z), then + t)
-  q.Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
-  q.Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
-  q.Wz = ((a.R[6] * px + a.R[7] * py) + a.R[8] * pz) + a.t[2];
-  q.u_new = (q.Wx / q.Wz) * a.fx + a.cx;
-  q.v_new = (q.Wy / q.Wz) * a.fy + a.cy;
-  q.in_image = (q.u_new > 1 && q.v_new > 1 && q.u_new < a.w - 2 && q.v_new < a.h - 2);
-}
-// the four texels of getInterpolatedElement43 (C/util/globalFuncs.h:63-77); `fetch` = false reads texel 0 instead
-__device__ __forceinline__ void eval_fetch(const EvalCtx& a, const PointWarp& q, bool fetch, PointTexels& t) {
-  const int ix = fetch ? (int)q.u_new : 0;
-  const int iy = fetch ? (int)q.v_new : 0;
-  const float4* bp = a.fr_grad + ix + iy * a.w;
-  auto ld = [](const float4* p) { const float* f = (const float*)p; Texel3 r = {f[0], f[1], f[2]}; return r; };
-  t.t00 = ld(bp); t.t10 = ld(bp + 1); t.t01 = ld(bp + a.w); t.t11 = ld(bp + 1 + a.w);
-}
-__device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q, const PointTexels& t, float pz, float I_ref, float var,
-                                            PointOut& o) {
-  const float Wx = q.Wx, Wy = q.Wy, Wz = q.Wz, u_new = q.u_new, v_new = q.v_new;
-  const Texel3 t00 = t.t00, t10 = t.t10, t01 = t.t01, t11 = t.t11;
-  int ix = (int)u_new;
-  int iy = (int)v_new;
-  float dx = u_new - ix;
-  float dy = v_new - iy;
-  float dxdy = dx * dy;
-  float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-  float rx = w11 * t11.x + w01 * t01.x + w10 * t10.x + w00 * t00.x;
-  float ry = w11 * t11.y + w01 * t01.y + w10 * t10.y + w00 * t00.y;
-  float rz = w11 * t11.z + w01 * t01.z + w10 * t10.z + w00 * t00.z;
-
-  float c1 = a.aff_a * I_ref + a.aff_b;
-  float c2 = rz;
-  float residual = c1 - c2;
-  o.res = residual; o.c1 = c1; o.c2 = c2;
-  o.hw = fabsf(residual) < 5.0f ? 1 : 5.0f / fabsf(residual);
-  o.good = residual * residual / (40.0f * 40.0f + 0.5f * 0.5f * (rx * rx + ry * ry)) < 1;
-  float gx = a.fx * rx;   // buf_warped_dx
-  float gy = a.fy * ry;   // buf_warped_dy
-  float d = 1.0f / pz;    // buf_d
-  float depthChange = pz / Wz;
-  o.usage = depthChange < 1 ? depthChange : 1;
-
-  // K2, SSE operation order with an IEEE reciprocal
-  float pz2d = 1.0f / ((Wz * Wz) * d);
-  float g0 = (Wz * a.t[0] - Wx * a.t[2]) * pz2d;
-  float g1 = (Wz * a.t[1] - Wy * a.t[2]) * pz2d;
-  float drpdd = g0 * gx + g1 * gy;
-  float w_p = 1.0f / (a.cameraPixelNoise2 + drpdd * (drpdd * (a.var_weight * var)));
-  float wr = residual * sqrtf(w_p);
-  wr = fmaxf(wr, 0.0f - wr);
-  float wh = (wr < a.huber_half) ? 1.0f : a.huber_half * (1.0f / wr);
-  o.werr = wh * (wr * wr);
-  o.w = wh * w_p;
-
-  // K3, SSE operation order
-  float z = 1.0f / Wz;
-  o.J[0] = z * gx;
-  o.J[1] = z * gy;
-  float v1 = (Wx * gy) * z;
-  float v2 = (Wy * gx) * z;
-  o.J[5] = v1 - v2;
-  float z2 = z * z;
-  v1 = (Wx * gx) * z2;
-  v2 = (Wy * gy) * z2;
-  o.J[2] = 0.0f - (v1 + v2);
-  o.J[3] = 0.0f - ((v2 * Wy) + (gy + v1 * Wy));
-  o.J[4] = (gx + v1 * Wx) + v2 * Wx;
-}
-// (px,py,pz) = reference point, I_ref / var = its colour and inverse-depth variance.
-__device__ __forceinline__ void eval_point(const EvalCtx& a, float px, float py, float pz, float I_ref, float var, PointOut& o) {
-  PointWarp q;
-  eval_warp(a, px, py, pz, q);
-  o.in_image = q.in_image;
-  if (!o.in_image) return;
-  PointTexels t;
-  eval_fetch(a, q, true, t);
-  eval_finish(a, q, t, pz, I_ref, var, o);
-}
-
-// fetch the reference point `i` (dense index into the keyframe level, or index into the explicit list)
-__device__ __forceinline__ bool fetch_point(const EvalCtx& a, int i, float& px, float& py, float& pz, float& I_ref,
-                                            float& var, int& maskIdx) {
-  if (a.npts >= 0) {
-    if (i >= a.npts) return false;
-    px = a.pts_pos[3 * i]; py = a.pts_pos[3 * i + 1]; pz = a.pts_pos[3 * i + 2];
-    I_ref = a.pts_colvar[2 * i]; var = a.pts_colvar[2 * i + 1];
-    maskIdx = -1;
-    return true;
-  }
-  if (i >= a.w * a.h) return false;
-  int x = i % a.w, y = i / a.w;
-  if (x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) return false;
-  var = a.kf_idepthVar[i];
-  float id = a.kf_idepth[i];
-  if (var <= 0 || id == 0) return false;
-  float inv = 1.0f / id;
-  px = inv * (a.fxi * x + a.cxi);
-  py = inv * (a.fyi * y + a.cyi);
-  pz = inv * 1.0f;
-  I_ref = a.kf_image[i];
-  maskIdx = i;
-  return true;
-}
-
-// ---- Levenberg-Marquardt step, wave-parallel ------------------------------------------------------------------------
-// Runs in wave 0 of every workgroup with all 64 lanes active.  "Uniform" values are computed redundantly by every lane
-// (same inputs, same instructions); the 6x6 factorisation keeps row i of the matrix in lane i and exchanges data with
-// v_readlane; the two sincos evaluations and the four quaternion divisions of a normalisation run in different lanes.
-__device__ __forceinline__ void set_eval_pose(TrackState& s, const lsdm::SE3fH& T) {
-  s.Tn = T;
-  lsdm::quatf_to_rot(T.q, s.R);
-  s.t[0] = T.t[0]; s.t[1] = T.t[1]; s.t[2] = T.t[2];
-}
-__device__ __forceinline__ float rl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-
-// 6x6 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics), arithmetic and operation order exactly those
-// of lsdm::ldlt6_solve (pose_math.hpp) / the oracle's ldlt6_solve.  Lane i < 6 holds row i in m[0..5]; lanes >= 6 carry
-// a copy of row 5 and compute discarded values.  bl = right-hand side, entry j in lane j.  Result x[0..5] uniform.
-// (The right-hand side is deliberately not a local array: a select chain over array elements gets folded into a
-// dynamically indexed load, which drags the array into LDS/scratch and costs a dispatch-packet read per launch.)
-__device__ __forceinline__ void ldlt6_solve_wave(float (&m)[6], const float bl, const int lane, float (&x)[6]) {
-  int perm = lane;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    float dg = m[0];
-#pragma unroll
-    for (int j = 1; j < 6; j++) dg = (lane == j) ? m[j] : dg;
-    const float ad = fabsf(dg);
-    int piv = k;
-    float best = rl(ad, k);
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      const float v = rl(ad, i);
-      const bool g = v > best;
-      best = g ? v : best;
-      piv = g ? i : piv;
-    }
-    piv = __builtin_amdgcn_readfirstlane(piv);
-    if (piv != k) {
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const float a = rl(m[c], k), b = rl(m[c], piv);
-        m[c] = (lane == k) ? b : ((lane == piv) ? a : m[c]);
-      }
-      {
-        const int a = rli(perm, k), b = rli(perm, piv);
-        perm = (lane == k) ? b : ((lane == piv) ? a : perm);
-      }
-#pragma unroll
-      for (int i = k + 1; i < 6; i++) {
-        const bool c = (piv == i);
-        const float t = m[k];
-        m[k] = c ? m[i] : m[k];
-        m[i] = c ? t : m[i];
-      }
-    }
-    float v = m[k];
-#pragma unroll
-    for (int j = 0; j < k; j++) {
-      const float Lkj = rl(m[j], k), Dj = rl(m[j], j);
-      v -= (m[j] * Lkj) * Dj;
-    }
-    const float d = rl(v, k);
-    const float q = (d != 0.0f) ? v / d : 0.0f;
-    m[k] = (lane == k) ? d : ((lane > k) ? q : m[k]);
-  }
-  float y = rl(bl, 0);
-#pragma unroll
-  for (int j = 1; j < 6; j++) { const float bj = rl(bl, j); y = (perm == j) ? bj : y; }
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const float yj = rl(y, j);
-    const float t = y - m[j] * yj;
-    y = (lane > j) ? t : y;
-  }
-  {
-    float dg = m[0];
-#pragma unroll
-    for (int j = 1; j < 6; j++) dg = (lane == j) ? m[j] : dg;
-    y = (dg != 0.0f) ? y / dg : 0.0f;
-  }
-#pragma unroll
-  for (int i = 4; i >= 0; i--) {
-    const float prod = m[i] * y;
-    float acc = rl(y, i);
-#pragma unroll
-    for (int j = i + 1; j < 6; j++) acc -= rl(prod, j);
-    y = (lane == i) ? acc : y;
-  }
-  float xl = 0.f;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    const int pi = rli(perm, i);
-    const float yi = rl(y, i);
-    xl = (pi == lane) ? yi : xl;
-  }
-#pragma unroll
-  for (int j = 0; j < 6; j++) x[j] = rl(xl, j);
-}
-
-// 6x6 solve for the LM step, Gauss-Jordan on the augmented 6x7 system with ONE ELEMENT PER LANE (lane = 8 i + j, i < 6 rows,
-// j < 7 columns) and the pivot row / pivot column read back through LDS: six steps of (write own element, read pivot, pivot-row
-// and pivot-column entries, divide, multiply-subtract) instead of the ~460 dependent lane-exchange instructions of the
-// row-per-lane LDL^T above (3800 -> ~1300 cycles of the single wave the whole launch waits for).  No pivoting: the matrix
-// is J^T W J with its diagonal scaled by (1 + lambda), symmetric positive definite.  Same solution as A.ldlt().solve(b) up
-// to rounding (tolerance-level, like every reduction feeding it); the pivoted LDL^T stays in pose_math.hpp for the host
-// paths and as the CPU-checked reference of this routine (tests/test_host_math_cpu.py).
-__device__ __forceinline__ void gj6_solve_wave(const float* A /*LDS, 6x6*/, const float* bvec /*LDS*/, const float damp, float* s_m /*LDS [6][8]*/,
-                                               const int lane, float (&x)[6]) {
-  const int i = lane >> 3, j = lane & 7;
-  const bool act = i < 6 && j < 7;
-  const int ii = act ? i : 0, jj = act ? (j < 6 ? j : 0) : 0;
-  float m = (j == 6) ? -bvec[ii] : A[ii * 6 + jj];
-  if (i == j) m *= damp;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    if (act) s_m[i * 8 + j] = m;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const float d = s_m[k * 8 + k], rk = s_m[k * 8 + (act ? j : 0)], ck = s_m[ii * 8 + k];
-    const float f = ck / d;
-    const float upd = m - f * rk;
-    m = (i == k) ? m : upd;
-    __builtin_amdgcn_wave_barrier();
-  }
-  // now diagonal: x_i = rhs_i / m_ii
-  if (act) s_m[i * 8 + j] = m;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-  for (int r = 0; r < 6; r++) x[r] = s_m[r * 8 + 6] / s_m[r * 8 + r];
-}
-
-// sin / cos for the small angles of an LM increment: Taylor polynomials (|x| < 0.5: truncation error < 2e-10 relative),
-// the library routine beyond
-__device__ __forceinline__ void sincos_small(const float xx, float* sn, float* cs) {
-  if (fabsf(xx) < 0.5f) {
-    const float x2 = xx * xx;
-    *sn = xx * (1.0f + x2 * (-1.0f / 6.0f + x2 * (1.0f / 120.0f + x2 * (-1.0f / 5040.0f + x2 * (1.0f / 362880.0f + x2 * (-1.0f / 39916800.0f))))));
-    *cs = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24.0f + x2 * (-1.0f / 720.0f + x2 * (1.0f / 40320.0f + x2 * (-1.0f / 3628800.0f + x2 * (1.0f / 479001600.0f))))));
-  } else {
-    sincosf(xx, sn, cs);
-  }
-}
-
-// Quaternion normalisation, the four divisions in four lanes (lsdm::q_normalize arithmetic)
-__device__ __forceinline__ void q_normalize_wave(lsdm::Quatf& q, const int lane) {
-  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  const float c = (lane & 3) == 0 ? q.w : ((lane & 3) == 1 ? q.x : ((lane & 3) == 2 ? q.y : q.z));
-  const float r = c / n;
-  q.w = rl(r, 0); q.x = rl(r, 1); q.y = rl(r, 2); q.z = rl(r, 3);
-}
-
-// Sophus SE3Group<float>::exp (lsdm::se3f_exp arithmetic), sincos(theta/2) in even lanes and sincos(theta) in odd lanes
-__device__ __forceinline__ lsdm::SE3fH se3f_exp_wave(const float (&a)[6], const int lane) {
-  const float eps = static_cast<float>(1e-5);
-  const float ox = a[3], oy = a[4], oz = a[5];
-  const float theta_sq = ox * ox + (oy * oy + oz * oz);
-  const float theta = sqrtf(theta_sq);
-  const float half_theta = 0.5f * theta;
-  float sn, cs;
-  sincos_small((lane & 1) ? theta : half_theta, &sn, &cs);
-  const float sin_half = rl(sn, 0), cos_half = rl(cs, 0), sin_theta = rl(sn, 1), cos_theta = rl(cs, 1);
-  float imag, real;
-  if (theta < eps) {
-    const float theta_po4 = theta_sq * theta_sq;
-    imag = 0.5f - static_cast<float>(1.0 / 48.0) * theta_sq + static_cast<float>(1.0 / 3840.0) * theta_po4;
-    real = 1.0f - 0.5f * theta_sq + static_cast<float>(1.0 / 384.0) * theta_po4;
-  } else {
-    imag = sin_half / theta;
-    real = cos_half;
-  }
-  lsdm::SE3fH r;
-  r.q = {real, imag * ox, imag * oy, imag * oz};
-  q_normalize_wave(r.q, lane);
-  const float Om[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
-  float Om2[9];
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      float acc = Om[i * 3 + 0] * Om[0 * 3 + j];
-      acc += Om[i * 3 + 1] * Om[1 * 3 + j];
-      acc += Om[i * 3 + 2] * Om[2 * 3 + j];
-      Om2[i * 3 + j] = acc;
-    }
-  float V[9];
-  if (theta < eps) {
-    lsdm::q_to_rot<lsdm::Quatf, float>(r.q, V);
-  } else {
-    const float tsq = theta * theta;
-    const float ca = (1.0f - cos_theta) / tsq;
-    const float cb = (theta - sin_theta) / (tsq * theta);
-#pragma unroll
-    for (int i = 0; i < 9; i++) V[i] = (((i % 4) == 0 ? 1.0f : 0.0f) + ca * Om[i]) + cb * Om2[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    float acc = V[i * 3 + 0] * a[0];
-    acc += V[i * 3 + 1] * a[1];
-    acc += V[i * 3 + 2] * a[2];
-    r.t[i] = acc;
-  }
-  return r;
-}
-// Sophus operator*: fastMultiply + normalize (lsdm::se3f_mul arithmetic)
-__device__ __forceinline__ lsdm::SE3fH se3f_mul_wave(const lsdm::SE3fH& a, const lsdm::SE3fH& b, const int lane) {
-  lsdm::SE3fH r = a;
-  float rt[3];
-  lsdm::q_rotate<lsdm::Quatf, float>(a.q, b.t, rt);
-#pragma unroll
-  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
-  r.q = lsdm::q_mul(a.q, b.q);
-  q_normalize_wave(r.q, lane);
-  return r;
-}
-
-__device__ __forceinline__ void write_summary(const TrackState& s, const float* tot, TrackSummary* out) {
-  out->diverged = s.diverged; out->level = s.level; out->numEvaluations = s.numEvaluations; out->numWarpUpdates = s.numWarpUpdates;
-  out->q[0] = s.T.q.w; out->q[1] = s.T.q.x; out->q[2] = s.T.q.y; out->q[3] = s.T.q.z;
-  out->t[0] = s.T.t[0]; out->t[1] = s.T.t[1]; out->t[2] = s.T.t[2];
-  out->lastResidual = s.last_residual; out->pointUsage = s.pointUsage; out->goodCount = s.goodCount; out->badCount = s.badCount;
-  out->meanRes = s.meanRes; out->aff_a = s.aff_a; out->aff_b = s.aff_b; out->aff_a_lastIt = s.aff_a_lastIt; out->aff_b_lastIt = s.aff_b_lastIt;
-  for (int i = 0; i < RS_NUM; i++) out->sums[i] = tot[i];
-  out->bytes = s.bytes;
-  for (int l = 0; l < LSD_LEVELS; l++) out->levelEvals[l] = s.levelEvals[l];
-  out->numLaunches = s.numLaunches;
-  out->coarseSteps = s.coarseSteps; out->coarseBytes = s.coarseBytes;
-  __threadfence_system();
-  out->done = s.done;
-}
-
-struct LmShared {
-  float gj[48];        // scratch of the 6x6 solve
-  float tot[RS_NUM];   // corrected raw sums of the evaluation being finished (what the summary reports)
-};
-// Job parameters the LM wave needs, staged in LDS by an otherwise idle lane while the partial sums are being added
-// (fetched field by field from the kernel-argument segment they cost one scalar-cache round trip each).
-struct LmPar {
-  float lambdaInitial, stepSizeMin, convergenceEps, minWarped, lambdaSuccessFac, lambdaFailFac;
-  int maxIts, w, h, writeMask, evalOnly, useAffine, tfSemantics, lastLevel, trials;
-};
-__device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmPar& p, const int trials = 1) {
-  const TrackLevel& L = job.lv[level];
-  LmPar v;
-  v.lambdaInitial = L.lambdaInitial; v.stepSizeMin = L.stepSizeMin; v.convergenceEps = L.convergenceEps; v.minWarped = L.minWarped;
-  v.lambdaSuccessFac = job.lambdaSuccessFac; v.lambdaFailFac = job.lambdaFailFac;
-  v.maxIts = L.maxIts; v.w = L.w; v.h = L.h; v.writeMask = L.writeMask; v.evalOnly = job.evalOnly; v.useAffine = job.useAffine;
-  v.tfSemantics = job.trackFrameSemantics; v.lastLevel = job.lastLevel;
-  v.trials = trials;
-  p = v;
-}
-
-// The control flow of SE3Tracker::trackFrame between two evaluations (SE3Tracker.cpp:324-447), run by wave 0 of every
-// workgroup on identical inputs (so every workgroup reaches the same decision without talking to the others).
-//   col  : this lane's column total of the evaluation's raw sums, tail-drop corrected (lane c < RS_END <-> column c)
-//   S    : the job state in LDS (read and updated in place; every lane writes the same values)
-//   tot  : LDS copy of the corrected sums (what the summary reports)
-// `out` is non-null in workgroup 0 only.
-#ifdef LSD_PHASE_TRACE
-#define LM_MARK(k) do { if (trp && lane == 0) trp[k] = clock64(); } while (0)
-#else
-#define LM_MARK(k) do { } while (0)
-#endif
-// Reject-chain speculation: `consumed` = index (within the launch that produced the sums) of the trial being finished (the
-// caller has already advanced lambda / incTry / counters past the plain rejections before it), `mycand` = the trial this
-// workgroup evaluates next: `mycand` retries further down the chain that starts at the proposal made here.
-__device__ __forceinline__ float lm_lambda_fail(float LM_lambda, int incTry, float lambdaFailFac) {
-  if (LM_lambda == 0) return 0.2f;
-  double p = 1.0;
-  for (int i = 0; i < incTry; i++) p *= (double)lambdaFailFac;   // std::pow(lambdaFailFac, incTry)
-  return (float)((double)LM_lambda * p);
-}
-template <bool SPEC = false>
-__device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const float col, float* tot, const int lane,
-                                        TrackSummary* out, unsigned long long* trp, const int consumed = 0, const int mycand = 0) {
-  float* const s_gj = tot - 48;   // LmShared::gj precedes tot
-  S.lastCand = consumed;
-  S.ncand = 1;
-  const LmPar L = par;
-  const int maxIts = L.maxIts;
-  // calcResidualAndBuffers epilogue (:1016-1028)
-  const int M = (int)rl(col, RS_M);
-  const float refNum = rl(col, RS_NREF);
-  const float goodCount = rl(col, RS_GOOD), badCount = rl(col, RS_BAD);
-  float aff_a_lastIt, aff_b_lastIt;
-  {
-    const float sxx = rl(col, RS_SXX), syy = rl(col, RS_SYY), sx = rl(col, RS_SX), sy = rl(col, RS_SY), sw = rl(col, RS_SW);
-    aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
-    aff_b_lastIt = (sy - aff_a_lastIt * sx) / sw;
-  }
-  S.pointUsage = rl(col, RS_USAGE) / refNum;
-  S.goodCount = goodCount;
-  S.badCount = badCount;
-  S.meanRes = rl(col, RS_SUMSIGNED) / goodCount;
-  S.aff_a_lastIt = aff_a_lastIt;
-  S.aff_b_lastIt = aff_b_lastIt;
-  S.numEvaluations = S.numEvaluations + 1;
-  if (lane == 0) S.levelEvals[S.level] = S.levelEvals[S.level] + 1;
-  {
-    // algorithmic bytes of this evaluation: 20 N + [mask] 5 N + 12 min(w h, 4 N)
-    const float N = refNum, wh = (float)L.w * (float)L.h;
-    const float texels = 4.0f * N < wh ? 4.0f * N : wh;
-    S.bytes = S.bytes + (20.0f * N + (L.writeMask ? 5.0f * N : 0.0f) + 12.0f * texels);
-  }
-  S.pending = 0;
-  LM_MARK(12);
-  if (L.evalOnly) { S.done = 1; if (out && lane == 0) write_summary(S, tot, out); return false; }
-
-  if (M < L.minWarped) {   // :324-329 / :369-374
-    S.diverged = 1; S.done = 1;
-    if (out && lane == 0) write_summary(S, tot, out);
-    return false;
-  }
-  // calcWeightsAndResidualSSE epilogue (:572-574)
-  const float werr = rl(col, RS_WERR) / ((M >> 2) << 2);
-  const bool useAffine = L.useAffine != 0;
-  const bool tfSemantics = L.tfSemantics != 0;
-
-  float LM_lambda = S.LM_lambda, lastErr = S.lastErr;
-  int iteration = S.iteration, incTry = S.incTry;
-  lsdm::SE3fH T = S.T;
-  bool propose = false, start_iteration = false, accepted = false, rejected = false;
-  if (S.phase == 0) {
-    accepted = true;
-    lastErr = werr;
-    LM_lambda = L.lambdaInitial;
-    iteration = 0;
-    start_iteration = true;
-  } else {
-    const float error = werr;
-    if (error < lastErr) {
-      accepted = true;
-      T = S.Tn;
-      S.T = T;
-      if (error / lastErr > L.convergenceEps) iteration = maxIts;
-      lastErr = error;
-      if (tfSemantics) S.last_residual = error;
-      if (LM_lambda <= 0.2) LM_lambda = 0;
-      else LM_lambda *= L.lambdaSuccessFac;
-      iteration++;
-      start_iteration = true;
-    } else {
-      const float i0 = S.inc[0], i1 = S.inc[1], i2 = S.inc[2], i3 = S.inc[3], i4 = S.inc[4], i5 = S.inc[5];
-      const float incdot = (i0 * i0 + (i1 * i1 + i2 * i2)) + (i3 * i3 + (i4 * i4 + i5 * i5));
-      if (!(incdot > L.stepSizeMin)) {
-        iteration = maxIts;
-        iteration++;
-        start_iteration = true;
-      } else {
-        LM_lambda = lm_lambda_fail(LM_lambda, incTry, L.lambdaFailFac);
-        propose = true;
-        rejected = true;
-      }
-    }
-  }
-  if (accepted) {
-    if (useAffine) { S.aff_a = aff_a_lastIt; S.aff_b = aff_b_lastIt; }
-    // the accepted (or first) evaluation's normal equations are what calculateWarpUpdate would build next: LGS6::finish
-    // (A / n, b / n with the SSE constraint count n = 6 (M / 4), LGSX.h:319-325, :385), one entry per lane
-    const float n = (float)((size_t)6 * (size_t)(M >> 2));
-    const int k = lane - RS_A0;
-    if (k >= 0 && k < 21) {
-      const int i = (k >= 6) + (k >= 11) + (k >= 15) + (k >= 18) + (k >= 20);
-      const int j = k - (i * 6 - (i * (i - 1)) / 2) + i;
-      const float v = (0.0f + col) / n;
-      S.A[i * 6 + j] = v;
-      S.A[j * 6 + i] = v;
-    }
-    if (lane >= RS_B0 && lane < RS_B0 + 6) S.b[lane - RS_B0] = (0.0f - col) / n;
-  }
-  if (start_iteration && iteration < maxIts) { S.numWarpUpdates = S.numWarpUpdates + 1; incTry = 0; propose = true; }
-  S.lastErr = lastErr;
-  S.LM_lambda = LM_lambda;
-  S.iteration = iteration;
-  LM_MARK(13);
-  if (propose) {
-    // this workgroup's own trial: `mycand` retries further down the chain (each retry: incTry++, lambda as after a rejection)
-    const int extra = SPEC ? mycand : 0;
-    for (int j = 0; j < extra; j++) { incTry++; LM_lambda = lm_lambda_fail(LM_lambda, incTry, L.lambdaFailFac); }
-    S.ncand = L.trials;
-    float inc[6];
-    const float damp = 1 + LM_lambda;
-    LM_MARK(14);
-    gj6_solve_wave(S.A, S.b, damp, s_gj, lane, inc);
-    LM_MARK(15);
-    S.incTry = incTry + 1;
-#pragma unroll
-    for (int i = 0; i < 6; i++) S.inc[i] = inc[i];
-    const lsdm::SE3fH Tn = se3f_mul_wave(se3f_exp_wave(inc, lane), T, lane);
-    S.Tn = Tn;
-    float R[9];
-    lsdm::quatf_to_rot(Tn.q, R);
-#pragma unroll
-    for (int i = 0; i < 9; i++) S.R[i] = R[i];
-    S.t[0] = Tn.t[0]; S.t[1] = Tn.t[1]; S.t[2] = Tn.t[2];
-    S.phase = 1;
-    LM_MARK(16);
-    return true;
-  }
-  S.incTry = incTry;
-  // level finished
-  if (!tfSemantics) S.last_residual = lastErr;   // trackFrameOnPermaref: lastResidual = lastErr (:265)
-  if (S.level == L.lastLevel) {
-    S.done = 1;
-    if (out && lane == 0) write_summary(S, tot, out);
-  } else {
-    S.level = S.level - 1;
-    S.phase = 0;
-    S.Tn = T;
-    float R[9];
-    lsdm::quatf_to_rot(T.q, R);
-#pragma unroll
-    for (int i = 0; i < 9; i++) S.R[i] = R[i];
-    S.t[0] = T.t[0]; S.t[1] = T.t[1]; S.t[2] = T.t[2];
-  }
-  return false;
-}
-
-// one in-image point's contribution to the running sums (K1 statistics, K2 weighted error, K3 normal equations)
-__device__ __forceinline__ void accumulate_point(const PointOut& o, float (&acc)[RS_END]) {
-  acc[RS_M] += 1.f;
-  acc[RS_SXX] += o.c1 * o.c1 * o.hw;
-  acc[RS_SYY] += o.c2 * o.c2 * o.hw;
-  acc[RS_SX] += o.c1 * o.hw;
-  acc[RS_SY] += o.c2 * o.hw;
-  acc[RS_SW] += o.hw;
-  if (o.good) { acc[RS_GOOD] += 1.f; acc[RS_SUMRES2] += o.res * o.res; acc[RS_SUMSIGNED] += o.res; }
-  else acc[RS_BAD] += 1.f;
-  acc[RS_USAGE] += o.usage;
-  acc[RS_WERR] += o.werr;
-#pragma unroll
-  for (int r = 0; r < 6; r++) {
-    float Jw = o.J[r] * o.w;
-#pragma unroll
-    for (int c = r; c < 6; c++) acc[tri_index(r, c)] += Jw * o.J[c];
-  }
-  float resw = o.res * o.w;
-#pragma unroll
-  for (int r = 0; r < 6; r++) acc[RS_B0 + r] += resw * o.J[r];
-  acc[RS_ERR] += resw * o.res;
-}
-
-__device__ __forceinline__ void make_ctx_dev(const TrackJob& jobr, const TrackState& S, int level, EvalCtx& a) {
-  const TrackJob* job = &jobr;
-  const TrackLevel& L = job->lv[level];
-  a.kf_idepth = L.kf_idepth; a.kf_idepthVar = L.kf_idepthVar; a.kf_image = L.kf_image; a.fr_grad = L.fr_grad;
-  a.pts_pos = L.pts_pos; a.pts_colvar = L.pts_colvar; a.npts = L.npts; a.w = L.w; a.h = L.h;
-  a.fx = L.fx; a.fy = L.fy; a.cx = L.cx; a.cy = L.cy; a.fxi = L.fxi; a.fyi = L.fyi; a.cxi = L.cxi; a.cyi = L.cyi;
-#pragma unroll
-  for (int i = 0; i < 9; i++) a.R[i] = S.R[i];
-#pragma unroll
-  for (int i = 0; i < 3; i++) a.t[i] = S.t[i];
-  a.aff_a = S.aff_a; a.aff_b = S.aff_b;
-  a.cameraPixelNoise2 = job->cameraPixelNoise2; a.var_weight = job->var_weight; a.huber_half = job->huber_half;
-}
-
-template <int N>
-__device__ __forceinline__ void copy_words(void* dst, const void* src, int tid, int nthreads) {
-  const unsigned* s = (const unsigned*)src;
-  unsigned* d = (unsigned*)dst;
-  for (int i = tid; i < N; i += nthreads) d[i] = s[i];
-}
-
-// logical tile of workgroup b among nb participating ones: workgroups are dealt round-robin to the 8 XCDs, so giving
-// XCD x the contiguous tile range [x nb/8, (x+1) nb/8) keeps the texels one band of the frame touches in one L2.
-__device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b; }
 
 // Scratch of a tracker in HBM, double-buffered by launch parity (a launch reads [parity], writes [1 - parity]).
 struct TrackScratch {
@@ -1393,458 +721,6 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
   track_step_impl<BLOCK, BATCH, MODE>(jobv, jobs, st2, sc, out, parity, first, spec);
 }
 
-// =====================================================================================================================
-// Coarse-level cluster kernel: ONE launch runs the LM loops of the coarsest pyramid levels of SE3Tracker::trackFrame
-// (SE3Tracker.cpp:316-447), reject-chain speculation included, and no evaluation ever leaves its workgroup.
-//
-// The launch-per-evaluation chain above pays per step a kernel boundary and dispatch (~4.5 us), a re-read of every tile's
-// partial row written by other XCDs (2-3.5 us) and the cold start of a few hundred workgroups — for levels of a few
-// thousand pixels whose evaluation itself takes ~1 us.  Here:
-//   * workgroup c < nt (512 lanes) owns trial c of every speculative set: it evaluates the WHOLE level at its trial's pose.
-//     The valid reference pixels of all cluster levels are compacted ONCE per job into an LDS list (x, y, 1 / idepth, colour,
-//     variance: the pose-independent part of TrackingReference::makePointCloud), so an evaluation reads LDS and the tracked
-//     frame's texels only; its 41 sums are reduced inside the workgroup and the SSE tail drop (last M mod 4 in-image points
-//     in the reference's x-outer order) is applied there as well — a trial's totals are complete when they leave the CU;
-//   * one exchange per step: every active workgroup publishes ONE row of 8-byte {tag, value} granules (41 totals + the
-//     increment / pose of its trial; relaxed agent-scope stores, the datum is its own flag: cdna_hip_programming.md G16 form
-//     R2) and every workgroup reads the <= 7 rows (one granule per lane, one round trip);
-//   * every workgroup then takes the same decision from the same numbers — which trial stops the reference's loop, lambda /
-//     incTry / counters advanced past the plain rejections before it, ONE LM step (lm_wave) — and workgroup c derives the
-//     pose of trial c of the next set by the closed-form lambda recurrence: no second hop;
-//   * level-boundary speculation ("fold"): workgroup nt evaluates the FIRST evaluation of the next finer level at the last
-//     accepted pose while the trial workgroups evaluate a set (or the single evaluation of a level whose maxIts is 0, as
-//     SlamSystem.cpp:80-81 sets for level 4).  If the level then ends without the pose having moved — the usual end: a chain
-//     of rejected retries — that evaluation is exactly the one the reference would run next and it is consumed in the same
-//     step (its row carries the pose and affine parameters it was made for; any mismatch discards it).
-// Decisions, evaluation counts and poses are those of running the same kernel with one trial per step and no fold, bit for
-// bit (same lists, same in-workgroup summation order).  Every spin is bounded: on a time-out the kernel reports done = 2 and
-// the host reruns the job on the k_track_step chain.  The finest level of a job never runs here (it writes refPixelWasGood):
-// the kernel hands the state to the chain through st_out.
-// =====================================================================================================================
-#define CT_BLOCK 512
-#define CT_POOL 6400            // LDS list entries for all cluster levels of a job together
-#define CT_ROW 72               // granules per published row: [0, 41) totals | [44, 69) record
-#define CT_REC0 44              // record: inc[6] | Tn (q, t)[7] | R[9] | t[3]; fold row: aff_a, aff_b at [0, 1], T at [6, 13)
-#define CT_SPIN_LIMIT (1u << 19)     // polls of one lane before the kernel gives up (~1 s)
-typedef unsigned long long ct_u64;
-typedef __attribute__((address_space(1))) ct_u64 ct_gu64;
-struct CoarsePlan {
-  int nt;                    // trial workgroups (the launch has nt + 1 workgroups: the last one evaluates the fold)
-  int low;                   // lowest level that runs in this kernel (> job.lastLevel)
-  int fold;                  // level-boundary speculation on / off
-  int trials[LSD_LEVELS];    // trials per set at each level (<= nt)
-};
-__device__ __forceinline__ void ct_store(ct_u64* p, unsigned tag, unsigned val) {
-  __hip_atomic_store((ct_gu64*)p, ((ct_u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ ct_u64 ct_load(const ct_u64* p) {
-  return __hip_atomic_load((ct_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// the K2/K3 contributions of one point, in the order of the tail-drop tables (werr | 21 A | 6 b | err)
-__device__ __forceinline__ void point_contrib(const PointOut& o, float* dst) {
-  dst[0] = o.werr;
-  int k = 1;
-#pragma unroll
-  for (int r = 0; r < 6; r++) {
-    const float Jw = o.J[r] * o.w;
-#pragma unroll
-    for (int c = r; c < 6; c++) dst[k++] = Jw * o.J[c];
-  }
-  const float resw = o.res * o.w;
-#pragma unroll
-  for (int r = 0; r < 6; r++) dst[k++] = resw * o.J[r];
-  dst[k] = resw * o.res;
-}
-
-#ifdef LSD_PHASE_TRACE
-#define CT_MARK(k) do { if (b == 0 && tid == 0) ctr_[k] = clock64(); } while (0)
-#else
-#define CT_MARK(k) do { } while (0)
-#endif
-__global__ __launch_bounds__(CT_BLOCK) void k_track_coarse(TrackJob job, CoarsePlan plan, TrackState* __restrict__ st_out,
-                                                           ct_u64* __restrict__ rows, unsigned salt, TrackSummary* __restrict__ out
-#ifdef LSD_PHASE_TRACE
-                                                           , unsigned long long* __restrict__ ctrace
-#endif
-                                                           ) {
-  constexpr int BLOCK = CT_BLOCK, WAVES = BLOCK / 64, HALF = 256;
-  constexpr int SW = sizeof(TrackState) / 4;
-  constexpr int P = 4;                                   // list entries per lane whose texels travel together
-  __shared__ TrackState S;
-  __shared__ LmShared sh;
-  __shared__ LmPar s_par[2];                             // [0]: the level being iterated, [1]: the level below it (fold)
-  __shared__ float s_red[RS_END * (HALF + 1) + 8];       // workgroup reduction (transposed, conflict-free both ways)
-  __shared__ float s_sum[HALF / RS_END][64];
-  __shared__ unsigned l_xy[CT_POOL];                     // x | y << 16
-  __shared__ float l_inv[CT_POOL], l_I[CT_POOL], l_var[CT_POOL];
-  __shared__ float s_tot[LSD_SPEC_MAX + 1][CT_ROW];      // the gathered rows: trial c -> [c], fold -> [nt]
-  __shared__ int s_wtop[WAVES][3];
-  __shared__ int s_top[3];
-  __shared__ float s_contrib[3][32];
-  __shared__ int s_cnt[WAVES];
-  __shared__ int s_flag;
-  __shared__ int s_listOff[LSD_LEVELS], s_listN[LSD_LEVELS];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.x;
-  const int nt = plan.nt;
-  const bool isFold = b == nt;
-  const int mycand = isFold ? 0 : b;
-  const unsigned tagbase = salt << 12;
-#ifdef LSD_PHASE_TRACE
-  // developer build: 16 words per step — 0 step start, 1 evaluated, 2 published, 3 gathered, 4 decided (shader clock), 5 level,
-  // 6 trials, 7 list length, 8 / 9 wall clock at kernel entry / step end, 10 lists built, 11 step ordinal
-  unsigned long long* ctr_ = ctrace + 1;
-  unsigned long long ct_t0 = 0, ct_tl = 0, ct_w0 = 0;
-  if (b == 0 && tid == 0) { ct_t0 = clock64(); ct_w0 = wall_clock64(); }
-#endif
-
-  // ---- every workgroup starts from the same state ---------------------------------------------------------------------
-  if (tid == 0) {
-    S.T = job.T0;
-    set_eval_pose(S, job.T0);
-    S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
-    S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
-    S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
-    S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
-    S.ncand = 1; S.lastCand = 0; S.numLaunches = 0; S.coarseSteps = 0; S.coarseBytes = 0;
-    S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
-    S.bytes = 0;
-    for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
-    s_flag = 1;
-  }
-  if (tid < 36) S.A[tid] = 0;
-  if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
-
-  // ---- the valid reference pixels of every cluster level -> LDS lists (pose-independent; once per job) -----------------
-  // order within a level: wave, then 512-pixel chunk, then lane — fixed, so every workgroup builds the same list; all plane
-  // loads of a level are issued together (one memory round trip per level)
-  {
-    constexpr int KMAX = (CT_POOL + BLOCK - 1) / BLOCK;   // 13 chunks of 512 pixels at most per level
-    int off = 0;
-    for (int l = job.topLevel; l >= plan.low; l--) {
-      const TrackLevel& L = job.lv[l];
-      const int w = L.w, h = L.h, work = w * h;
-      float vv[KMAX], dd[KMAX], ii[KMAX];
-#pragma unroll
-      for (int k = 0; k < KMAX; k++) {
-        const int i = k * BLOCK + tid;
-        const bool in = i < work;
-        vv[k] = in ? L.kf_idepthVar[i] : 0.f;
-        dd[k] = in ? L.kf_idepth[i] : 0.f;
-        ii[k] = in ? L.kf_image[i] : 0.f;
-      }
-      unsigned vmask = 0;
-      unsigned xys[KMAX];
-      int wcount = 0;
-#pragma unroll
-      for (int k = 0; k < KMAX; k++) {
-        const int i = k * BLOCK + tid;
-        const int y = i / w, x = i - y * w;
-        xys[k] = (unsigned)x | ((unsigned)y << 16);
-        const bool ok = i < work && !(x < 1 || x >= w - 1 || y < 1 || y >= h - 1) && !(vv[k] <= 0 || dd[k] == 0);
-        vmask |= (ok ? 1u : 0u) << k;
-        wcount += __popcll(__ballot(ok));
-      }
-      if (lane == 0) s_cnt[wave] = wcount;
-      __syncthreads();
-      int pos = off, total = 0;
-#pragma unroll
-      for (int wv = 0; wv < WAVES; wv++) { const int cw = s_cnt[wv]; if (wv < wave) pos += cw; total += cw; }
-#pragma unroll
-      for (int k = 0; k < KMAX; k++) {
-        const bool ok = (vmask >> k) & 1u;
-        const unsigned long long bal = __ballot(ok);
-        if (ok) {
-          const int p = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          l_xy[p] = xys[k];
-          l_inv[p] = 1.0f / dd[k];
-          l_I[p] = ii[k];
-          l_var[p] = vv[k];
-        }
-        pos += __popcll(bal);
-      }
-      if (tid == 0) { s_listOff[l] = off; s_listN[l] = total; }
-      off += total;
-      __syncthreads();
-    }
-  }
-
-  // evaluates list [off, off + n) at the pose / affine parameters in `a`; leaves the tail-corrected totals in lanes 0..40
-  // of wave 0 (return value; other lanes / waves: unspecified)
-  auto eval_list = [&](const EvalCtx& a, const int off, const int n) -> float {
-    float acc[RS_END];
-#pragma unroll
-    for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
-    int key0 = -1, key1 = -1, key2 = -1;
-    PointWarp q[P];
-    PointTexels tx[P];
-    bool live[P];
-    // warp + texel issue of the first P entries of this lane; order keys of all of them
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-      const int e = tid + p * BLOCK;
-      live[p] = e < n;
-      const int ee = off + (live[p] ? e : 0);
-      const unsigned xy = l_xy[ee];
-      const float inv = l_inv[ee];
-      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-      eval_warp(a, inv * (a.fxi * x + a.cxi), inv * (a.fyi * y + a.cyi), inv * 1.0f, q[p]);
-      eval_fetch(a, q[p], live[p] && q[p].in_image, tx[p]);
-      if (live[p] && q[p].in_image) top3_insert(x * a.h + y, key0, key1, key2);
-    }
-    for (int e = tid + P * BLOCK; e < n; e += BLOCK) {        // denser lists: keys now, the rest after the first P
-      const unsigned xy = l_xy[off + e];
-      const float inv = l_inv[off + e];
-      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-      PointWarp qq;
-      eval_warp(a, inv * (a.fxi * x + a.cxi), inv * (a.fyi * y + a.cyi), inv * 1.0f, qq);
-      if (qq.in_image) top3_insert(x * a.h + y, key0, key1, key2);
-    }
-    block_top3(key0, key1, key2, s_wtop, s_top);               // two barriers, in the shadow of the texel loads
-    const int top0 = s_top[0], top1 = s_top[1], top2 = s_top[2];
-    auto finish_entry = [&](const int e, const PointWarp& qq, const PointTexels& tt) {
-      const int ee = off + e;
-      const unsigned xy = l_xy[ee];
-      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-      acc[RS_NREF] += 1.f;
-      if (!qq.in_image) return;
-      PointOut o;
-      eval_finish(a, qq, tt, l_inv[ee] * 1.0f, l_I[ee], l_var[ee], o);
-      accumulate_point(o, acc);
-      const int key = x * a.h + y;
-      const int r = key == top0 ? 0 : (key == top1 ? 1 : (key == top2 ? 2 : -1));
-      if (r >= 0) point_contrib(o, s_contrib[r]);
-    };
-#pragma unroll
-    for (int p = 0; p < P; p++)
-      if (live[p]) finish_entry(tid + p * BLOCK, q[p], tx[p]);
-    for (int e = tid + P * BLOCK; e < n; e += BLOCK) {
-      const unsigned xy = l_xy[off + e];
-      const float inv = l_inv[off + e];
-      const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-      PointWarp qq;
-      PointTexels tt;
-      eval_warp(a, inv * (a.fxi * x + a.cxi), inv * (a.fyi * y + a.cyi), inv * 1.0f, qq);
-      eval_fetch(a, qq, qq.in_image, tt);
-      finish_entry(e, qq, tt);
-    }
-    // ---- workgroup reduction: upper half onto lower half (only if it had work), then the transposed 256-lane form of
-    // k_track_step: thread (slice, k) adds a run of 43 lanes of column k, 41 threads add the 6 slices ----------------------
-    if (n > HALF) {
-      if (tid >= HALF) {
-#pragma unroll
-        for (int k = 0; k < RS_END; k++) s_red[k * (HALF + 1) + (tid - HALF)] = acc[k];
-      }
-      __syncthreads();
-      if (tid < HALF) {
-#pragma unroll
-        for (int k = 0; k < RS_END; k++) acc[k] += s_red[k * (HALF + 1) + tid];
-      }
-      __syncthreads();
-    }
-    if (tid < HALF) {
-#pragma unroll
-      for (int k = 0; k < RS_END; k++) s_red[k * (HALF + 1) + tid] = acc[k];
-    }
-    __syncthreads();
-    constexpr int RSLICE = HALF / RS_END;                  // 6
-    constexpr int RRUN = (HALF + RSLICE - 1) / RSLICE;     // 43
-    {
-      const int slice = tid / RS_END, k = tid - slice * RS_END;
-      if (slice < RSLICE) {
-        const float* row = s_red + k * (HALF + 1);
-        const int j0 = slice * RRUN;
-        float v[RRUN];
-#pragma unroll
-        for (int j = 0; j < RRUN; j++) v[j] = row[j0 + j];   // the last run reads 2 words of the next row (allocated)
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < RRUN; j++) s += (j0 + j < HALF) ? v[j] : 0.f;
-        s_sum[slice][k] = s;
-      }
-    }
-    __syncthreads();
-    float s = 0.f;
-    if (wave == 0) {
-      if (tid < RS_END) {
-        s = s_sum[0][tid];
-#pragma unroll
-        for (int sl = 1; sl < RSLICE; sl++) s += s_sum[sl][tid];
-      }
-      // SSE tail drop: the reference's K2 / K3 loops never visit the last M mod 4 in-image points
-      const int M = (int)rl(s, RS_M);
-      int need = M & 3;
-      const int nsub = (top0 >= 0) + (top1 >= 0) + (top2 >= 0);
-      if (need > nsub) need = nsub;
-      const int subIdx = (tid == RS_WERR) ? 0 : ((tid >= RS_A0 && tid < RS_B0) ? 1 + tid - RS_A0 : ((tid >= RS_B0 && tid < RS_ERR) ? 22 + tid - RS_B0 : (tid == RS_ERR ? 28 : -1)));
-      const int si = subIdx < 0 ? 0 : subIdx;
-      const float sub0 = s_contrib[0][si], sub1 = s_contrib[1][si], sub2 = s_contrib[2][si];
-      if (subIdx >= 0) {
-        if (need > 0) s -= sub0;
-        if (need > 1) s -= sub1;
-        if (need > 2) s -= sub2;
-      }
-    }
-    return s;
-  };
-
-  __syncthreads();
-#ifdef LSD_PHASE_TRACE
-  if (b == 0 && tid == 0) ct_tl = clock64();
-#endif
-  int step = 0;
-  while (true) {
-    // ---- leaving: job finished, or the next level belongs to the k_track_step chain (reads st_out[0], pending = 0) -------
-    if (S.done || S.level < plan.low) {
-      if (b == 0) {
-        copy_words<SW>(st_out, &S, tid, BLOCK);
-        copy_words<SW>(st_out + 1, &S, tid, BLOCK);
-      }
-      break;
-    }
-    const int level = S.level;
-#ifdef LSD_PHASE_TRACE
-    if (b == 0 && tid == 0) {
-      const unsigned long long n = ctrace[0];
-      ctrace[0] = n + 1;
-      ctr_ = ctrace + 1 + (n % 4096) * 16;
-      for (int k = 0; k < 16; k++) ctr_[k] = 0;
-      ctr_[5] = (unsigned long long)level; ctr_[8] = ct_w0; ctr_[10] = step == 0 ? ct_tl - ct_t0 : 0; ctr_[11] = (unsigned long long)step;
-    }
-    CT_MARK(0);
-#endif
-    const bool trialPhase = S.phase == 1;
-    const int ncand = trialPhase ? (S.ncand < 1 ? 1 : (S.ncand > nt ? nt : S.ncand)) : 1;
-    // the fold evaluates level - 1 at the last accepted pose whenever this step may end the level without moving it
-    const bool foldActive = plan.fold != 0 && level - 1 >= plan.low && (trialPhase || job.lv[level].maxIts <= 0);
-    const unsigned epoch = tagbase | ((unsigned)(step + 1) & 0xFFFu);
-    ct_u64* const rowsE = rows + (size_t)(step & 1) * (LSD_SPEC_MAX + 1) * CT_ROW;   // double-buffered by step parity
-    if (tid == BLOCK - 1) stage_lm_par(job, level, s_par[0], plan.trials[level] > 1 ? plan.trials[level] : 1);
-    if (tid == BLOCK - 2 && foldActive) stage_lm_par(job, level - 1, s_par[1], plan.trials[level - 1] > 1 ? plan.trials[level - 1] : 1);
-
-    const bool active = isFold ? foldActive : b < ncand;
-    if (active) {
-      const int lv = isFold ? level - 1 : level;
-      EvalCtx a;
-      make_ctx_dev(job, S, lv, a);
-      if (isFold) {
-        float R[9];
-        lsdm::quatf_to_rot(S.T.q, R);
-#pragma unroll
-        for (int i = 0; i < 9; i++) a.R[i] = R[i];
-        a.t[0] = S.T.t[0]; a.t[1] = S.T.t[1]; a.t[2] = S.T.t[2];
-      }
-      const float tot = eval_list(a, s_listOff[lv], s_listN[lv]);
-      CT_MARK(1);
-#ifdef LSD_PHASE_TRACE
-      if (b == 0 && tid == 0) { ctr_[6] = (unsigned long long)ncand; ctr_[7] = (unsigned long long)s_listN[lv]; }
-#endif
-      ct_u64* myrow = rowsE + (size_t)b * CT_ROW;
-      if (tid < RS_END) ct_store(myrow + tid, epoch, __float_as_uint(tot));
-      else if (tid >= 64 && tid < 64 + 25) {
-        const int j = tid - 64;
-        float v;
-        if (isFold) v = j == 0 ? S.aff_a : (j == 1 ? S.aff_b : ((j >= 6 && j < 13) ? ((const float*)&S.T)[j - 6] : 0.f));
-        else if (j < 6) v = S.inc[j];
-        else if (j < 13) v = ((const float*)&S.Tn)[j - 6];
-        else if (j < 22) v = S.R[j - 13];
-        else v = S.t[j - 22];
-        ct_store(myrow + CT_REC0 + j, epoch, __float_as_uint(v));
-      }
-    }
-    CT_MARK(2);
-    // ---- gather: one granule per lane, every lane polls its own ---------------------------------------------------------------
-    {
-      const int nrows = ncand + (foldActive ? 1 : 0);
-      constexpr int PER = RS_END + 25;
-      bool bad = false;
-      for (int idx = tid; idx < nrows * PER; idx += BLOCK) {
-        const int r = idx / PER, j = idx - r * PER;
-        const int slot = r < ncand ? r : nt;
-        const int e = j < RS_END ? j : CT_REC0 + (j - RS_END);
-        const ct_u64* p = rowsE + (size_t)slot * CT_ROW + e;
-        ct_u64 x = ct_load(p);
-        for (unsigned spins = 0; (unsigned)(x >> 32) != epoch; spins++) {
-          if (spins > CT_SPIN_LIMIT) { bad = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-          x = ct_load(p);
-        }
-        s_tot[slot][e] = __uint_as_float((unsigned)x);
-      }
-      if (bad) s_flag = 3;
-    }
-    __syncthreads();
-    if (s_flag == 3) {                     // give up: the host reruns the job on the launch-per-evaluation chain
-      if (b == 0 && tid == 0) { out->diverged = 0; __threadfence_system(); out->done = 2; }
-      return;
-    }
-    CT_MARK(3);
-    // ---- the decision, identically in every workgroup ---------------------------------------------------------------------
-    if (wave == 0) {
-      int pc = 0;
-      if (trialPhase) {
-        // back to the common view of the state: this workgroup's own trial moved incTry / inc / Tn / R / t
-        const int it0 = S.incTry - mycand;
-        const int c = tid < ncand ? tid : 0;
-        const int Mc = (int)s_tot[c][RS_M];
-        const float werrc = s_tot[c][RS_WERR] / ((Mc >> 2) << 2);
-        const float* ic = &s_tot[c][CT_REC0];
-        const float i0 = ic[0], i1 = ic[1], i2 = ic[2], i3 = ic[3], i4 = ic[4], i5 = ic[5];
-        const float incdot = (i0 * i0 + (i1 * i1 + i2 * i2)) + (i3 * i3 + (i4 * i4 + i5 * i5));
-        const bool stop = Mc < s_par[0].minWarped || werrc < S.lastErr || !(incdot > s_par[0].stepSizeMin);
-        const unsigned long long sm = __ballot(stop && tid < ncand);
-        pc = sm ? (int)__ffsll((long long)sm) - 1 : ncand - 1;
-        float lam = S.LM_lambda;
-        for (int j = 0; j < pc; j++) lam = lm_lambda_fail(lam, it0 + j, s_par[0].lambdaFailFac);
-        float skipped;
-        {
-          const float NR = s_tot[0][RS_NREF];
-          const float wh = (float)s_par[0].w * (float)s_par[0].h;
-          const float texels = 4.0f * NR < wh ? 4.0f * NR : wh;
-          skipped = 20.0f * NR + (s_par[0].writeMask ? 5.0f * NR : 0.0f) + 12.0f * texels;
-        }
-        const float* rec = &s_tot[pc][CT_REC0];
-        const int ne0 = S.numEvaluations, le0 = S.levelEvals[level];
-        float bytes1 = S.bytes;
-        for (int j = 0; j < pc; j++) bytes1 = bytes1 + skipped;
-        const float r0 = rec[tid < 25 ? tid : 0];
-        S.LM_lambda = lam;
-        S.incTry = it0 + pc;
-        S.numEvaluations = ne0 + pc;
-        if (tid == 0) S.levelEvals[level] = le0 + pc;
-        S.bytes = bytes1;
-        if (tid < 6) S.inc[tid] = r0;
-        else if (tid < 13) ((float*)&S.Tn)[tid - 6] = r0;
-        else if (tid < 22) S.R[tid - 13] = r0;
-        else if (tid < 25) S.t[tid - 22] = r0;
-      }
-      const float col = tid < RS_END ? s_tot[pc][tid] : 0.f;
-      if (tid < RS_NUM) sh.tot[tid] = col;
-      S.coarseSteps = step + 1;
-      lm_wave<true>(s_par[0], S, col, sh.tot, tid, b == 0 ? out : nullptr, nullptr, pc, mycand);
-      if (foldActive && !S.done && S.level == level - 1 && S.phase == 0) {
-        // the level ended: is the fold's evaluation the one the reference runs next (same pose, same affine parameters)?
-        const float* fr = &s_tot[nt][CT_REC0];
-        const float want = tid == 0 ? S.aff_a : (tid == 1 ? S.aff_b : ((tid >= 6 && tid < 13) ? ((const float*)&S.T)[tid - 6] : 0.f));
-        const bool same = (tid < 2 || (tid >= 6 && tid < 13)) ? (__float_as_uint(fr[tid < 25 ? tid : 0]) == __float_as_uint(want)) : true;
-        if (__all(same)) {
-          const float colf = tid < RS_END ? s_tot[nt][tid] : 0.f;
-          if (tid < RS_NUM) sh.tot[tid] = colf;
-          lm_wave<true>(s_par[1], S, colf, sh.tot, tid, b == 0 ? out : nullptr, nullptr, 0, mycand);
-        }
-      }
-      S.coarseBytes = S.bytes;
-    }
-    __syncthreads();
-    CT_MARK(4);
-#ifdef LSD_PHASE_TRACE
-    if (b == 0 && tid == 0) ctr_[9] = wall_clock64();
-#endif
-    step++;
-  }
-}
-
 // checkPermaRefOverlap (SE3Tracker.cpp:121-157): usage only, explicit point list
 __global__ __launch_bounds__(256) void k_overlap(const float* __restrict__ pos, int n, EvalCtx a, float* __restrict__ out) {
   __shared__ float s_w[4];
@@ -1923,7 +799,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
 #endif
   {
     // cluster kernel (k_track_coarse): published rows, two step parities, {tag, value} granules
-    const size_t ct_bytes = (size_t)2 * (LSD_SPEC_MAX + 1) * CT_ROW * sizeof(ct_u64);
+    const size_t ct_bytes = lsd_track_coarse_rows_bytes();
     HIPCHK(hipMalloc((void**)&t->d_ctrows, ct_bytes));
     HIPCHK(hipMemsetAsync(t->d_ctrows, 0, ct_bytes, c->stream));
     if (const char* e = getenv("LSDHIP_COARSE")) t->coarse = e[0] != '0';
@@ -2351,13 +1227,14 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   memset(&plan, 0, sizeof(plan));
   bool useCoarse = false;
   if (t->coarse && !t->coarseOff && job.trackFrameSemantics && topLevel > job.lastLevel) {
-    long long px = 0;
     int low = topLevel + 1;
-    for (int l = topLevel; l > job.lastLevel; l--) {
+    plan.gmax = 1;
+    for (int l = topLevel; l > job.lastLevel && l > topLevel - CT_LEVELS; l--) {
       const TrackLevel& L = job.lv[l];
       const long long work = (long long)L.w * L.h;
-      if (L.npts >= 0 || px + work > CT_POOL || L.w > 65535 || L.h > 65535) break;
-      px += work;
+      if (L.npts >= 0 || work > CT_POOL || L.w > 32767 || L.h > 32767) break;
+      const int G = (int)((work + CT_BLOCK - 1) / CT_BLOCK);
+      if (G > plan.gmax) plan.gmax = G;
       low = l;
     }
     if (low <= topLevel) {
@@ -2368,7 +1245,6 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
         plan.trials[l] = t->spec.trials[l] > 1 ? t->spec.trials[l] : 1;
         if (plan.trials[l] > plan.nt) plan.nt = plan.trials[l];
       }
-      plan.fold = (t->coarseFold && t->specC > 1) ? 1 : 0;
     }
   }
   bool usedCoarse = false;
@@ -2376,19 +1252,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     if (sample) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     int rc = LSDHIP_OK;
     if (useCoarse && guard == 0) {
-      t->ctSalt = (t->ctSalt + 1) & 0xFFFFFu;
-      if (t->ctSalt == 0) {   // tags wrap: clear the granules so that no stale tag can match
-        HIPCHK(hipMemsetAsync(t->d_ctrows, 0, (size_t)2 * (LSD_SPEC_MAX + 1) * CT_ROW * sizeof(ct_u64), c->stream));
-        t->ctSalt = 1;
-      }
-#ifdef LSD_PHASE_TRACE
-      hipLaunchKernelGGL(k_track_coarse, dim3(plan.nt + 1), dim3(CT_BLOCK), 0, c->stream, job, plan, t->d_state, t->d_ctrows, t->ctSalt,
-                         t->d_summary, t->d_ctrace);
-#else
-      hipLaunchKernelGGL(k_track_coarse, dim3(plan.nt + 1), dim3(CT_BLOCK), 0, c->stream, job, plan, t->d_state, t->d_ctrows, t->ctSalt,
-                         t->d_summary);
-#endif
-      HIPCHK(hipGetLastError());
+      if (int rcc = lsd_track_coarse_launch(t, job, plan)) return rcc;
       usedCoarse = true;
       t->coarseJobs++;
       first = 0;

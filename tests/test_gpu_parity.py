@@ -819,7 +819,7 @@ def test_coarse_cluster_kernel_matches_the_chain(oracle, hip, size, fold):
         assert (fa.refPixelWasGoodNoCreate() != fb.refPixelWasGoodNoCreate()).mean() < 1e-3
         chain_a, steps_a, launches_a, _ = tr_a.step_stats()
         chain_b, steps_b, launches_b, _ = tr_b.step_stats()
-        assert (steps_a, launches_a) == (0, 0) and launches_b == 1 and steps_b >= 2
+        assert (steps_a, launches_a) == (0, 0) and launches_b == 1 and steps_b >= 1
         assert chain_b < chain_a                      # the coarse levels' launches are gone from the chain
         init = pa
     jobs, fallbacks, off, levels = tr_b.exec_stats()

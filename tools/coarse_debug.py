@@ -52,17 +52,17 @@ path = os.environ.get("LSDHIP_CTRACE_FILE")
 if path and os.path.exists(path):
     a = np.loadtxt(path, dtype=np.float64)
     a = a[a[:, 4] > 0]
-    ghz = 2.1
+    ghz = 2.4
     print("cluster kernel steps traced: %d" % len(a))
-    names = ["eval+reduce", "publish", "gather", "decision"]
+    names = ["eval+reduce", "publish", "gather+sum", "scan+tail", "LM"]
     for lvl in sorted(set(a[:, 5].astype(int))):
         for nc in sorted(set(a[a[:, 5] == lvl][:, 6].astype(int))):
             m = (a[:, 5] == lvl) & (a[:, 6] == nc) & (a[:, 1] > 0)
             if m.sum() == 0:
                 continue
-            d = np.diff(a[m][:, 0:5], axis=1)
-            print("  level %d trials %d list %d (%3d steps): " % (lvl, nc, int(np.median(a[m][:, 7])), m.sum()) +
+            d = np.diff(a[m][:, [0, 1, 2, 3, 12, 4]], axis=1)
+            print("  level %d trials %d strips %d (%3d steps): " % (lvl, nc, int(np.median(a[m][:, 7])), m.sum()) +
                   ", ".join("%s %.2f" % (n, np.median(d[:, k]) / ghz / 1e3) for k, n in enumerate(names)) + " | step %.2f us (at %.1f GHz)" % (np.median(d.sum(axis=1)) / ghz / 1e3, ghz))
     first = a[a[:, 11] == 0]
     if len(first):
-        print("  list build (kernel entry -> first step): %.2f us median" % (np.median(first[:, 10]) / ghz / 1e3))
+        print("  point load (kernel entry -> first step): %.2f us median" % (np.median(first[:, 10]) / ghz / 1e3))
