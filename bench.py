@@ -103,33 +103,34 @@ def _cpu_loop(po, L, frames, depth0, K, n_frames, w, h, mode):
 
 
 def cpu_baseline(frames, depth0, K, n_frames, w, h):
-    """CPU baseline on this box's host cores, bounded sample of the same workload.  Preferred: the REFERENCE's own hot-path
-    sources (oracle/_ref/liblsd_ref_sse.so: SE3Tracker.cpp / DepthMap.cpp / Frame.cpp compiled with -DENABLE_SSE against the
-    stand-in dependency headers of oracle/ref; tracking on 1 thread, mapping on the reference's own 4-worker
-    IndexThreadReduce pool) -> kind "reference".  Also reported: the oracle's restatement in its timing build for THIS host
-    (-O3 -march=native, the reference's flags) -> cpu_baseline_port."""
+    """CPU baseline on this box's host cores, bounded sample of the same workload, two candidates:
+      * kind "reference": the REFERENCE's own hot-path sources (SE3Tracker.cpp / DepthMap.cpp / Frame.cpp ... compiled where they lie,
+        against the stand-in dependency headers of oracle/ref) in their TIMING build — -O3 -DENABLE_SSE -DNDEBUG, contraction at the
+        compiler default, as lsd_slam_core/CMakeLists.txt:11,36-43 builds it, at the highest portable -march level this host's cpuid
+        supports (x86-64-v4 / -v3 instead of -march=native: /root/reference does not travel, the library is prebuilt).  Tracking on 1
+        thread, mapping on the reference's own IndexThreadReduce pool of 4 workers (settings.h:94);
+      * kind "port": the oracle's restatement built on this host with -O3 -march=native (persistent worker pool).
+    `cpu_baseline` is the FASTER of the two; the other one is returned second."""
     from oracle import pyoracle as po
     po.build()
     info = host_cpu()
     native = po.build_native()
     Lp = po.lib(native=True) if native else po.lib(fast=True)
     port = _cpu_loop(po, Lp, frames, depth0, K, n_frames, w, h, po.SSE)
-    port.update({"cores": 4, "kind": "port", "build": "-O3 -march=native" if native else "-O3 -march=x86-64-v3 (prebuilt)",
+    port.update({"cores": 4, "kind": "port", "build": "-O3 -march=native (built on this host)" if native else "-O3 -march=x86-64-v3 (prebuilt)",
                  "sample": "%d frames of the same %dx%d track+map loop (oracle: SSE tracker on 1 thread, depth map on a persistent "
                            "pool of 4 workers x 10-row chunks as the reference)" % (n_frames, w, h)})
     port.update(info)
-    out = port
-    extra = None
-    if po.have_ref():
-        Lr = po.lib(ref="sse")
-        refb = _cpu_loop(po, Lr, frames, depth0, K, n_frames, w, h, po.SSE)
-        refb.update({"cores": 4, "kind": "reference",
-                     "build": "reference sources, -O2 -march=x86-64-v2 -DENABLE_SSE -DNDEBUG, stand-in Eigen/Sophus/boost/OpenCV headers (prebuilt where /root/reference exists)",
-                     "sample": "%d frames of the same %dx%d track+map loop through the reference's own SE3Tracker / DepthMap / Frame code "
-                               "(tracking 1 thread, mapping: IndexThreadReduce pool of 4 workers)" % (n_frames, w, h)})
-        refb.update(info)
-        out, extra = refb, port
-    return out, extra
+    key, flags = po.ref_timing_variant()
+    if key is None:
+        return port, None
+    refb = _cpu_loop(po, po.lib(ref=key), frames, depth0, K, n_frames, w, h, po.SSE)
+    refb.update({"cores": 4, "kind": "reference",
+                 "build": "reference sources, " + flags + "; stand-in Eigen/Sophus/boost/OpenCV headers; prebuilt where /root/reference exists",
+                 "sample": "%d frames of the same %dx%d track+map loop through the reference's own SE3Tracker / DepthMap / Frame code "
+                           "(tracking 1 thread, mapping: IndexThreadReduce pool of 4 workers)" % (n_frames, w, h)})
+    refb.update(info)
+    return (refb, port) if refb["value"] >= port["value"] else (port, refb)
 
 
 def quat_to_rot(q):
@@ -200,6 +201,79 @@ def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
             "kernel": "k_track_step<TS_LM> + k_track_step<TS_EVAL>, all launches of %d rounds of %d jobs" % (rounds, jobs)}
 
 
+def extra_configs(la, torch, device):
+    """Two short legs after the timed region (not the bench metric): BASELINE.json configs[2] — the full track+map loop at 1280x1024 on
+    the edge-texture scene S2 — and configs[4] — the 3840x2160 depth regularisation (fill holes + regularise fused), full frame and as
+    8 row bands with halo refreshes on this one GPU through the C++ band loop."""
+    import ctypes as C
+    from lsd_slam_amd import synth, capi
+    from lsd_slam_amd.driver import DriverLoop
+    out = {}
+    # ---- configs[2]: 1280x1024, scene S2 ---------------------------------------------------------------------------------------
+    w, h, n = 1280, 1024, 12
+    frames, depth0, K, gt = synth.make_sequence(w, h, n, kind="S2")
+    d_frames = torch.from_numpy(frames).cuda(device)
+    order = list(range(n)) + list(range(n - 2, 0, -1))
+    ptr = lambda i: d_frames[order[i % len(order)]].data_ptr()
+    loop = DriverLoop(w, h, K, ptr(0), depth0, kf_every=KF_EVERY, images_on_device=True, device=device)
+    L = capi.lib()
+    ctx_h = loop.ctx_handle()
+    loop.run([ptr(1 + k) for k in range(12)])
+    loop.reset_stats()
+    capi.check(L.lsdhip_prof_reset(ctx_h))
+    capi.check(L.lsdhip_prof_enable(ctx_h, 1))
+    capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+    steps = 66
+    t0 = time.perf_counter()
+    loop.run([ptr(13 + k) for k in range(steps)])
+    capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+    dt = time.perf_counter() - t0
+    capi.check(L.lsdhip_prof_enable(ctx_h, 0))
+    st = loop.stats()
+    ms_, n_, b_ = C.c_double(), C.c_longlong(), C.c_double()
+    capi.check(L.lsdhip_prof_read(ctx_h, C.byref(ms_), C.byref(n_), C.byref(b_)))
+    roof = None
+    if n_.value > 0 and ms_.value > 0:
+        ach = (b_.value / n_.value) / (ms_.value / n_.value * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_track_step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "avg_launch_us": ms_.value / n_.value * 1e3, "algorithmic_bytes_per_launch": b_.value / n_.value, "launches": int(n_.value)}
+    out["s2_1280x1024"] = {"workload": "1280x1024 track+map loop, edge-texture scene S2 (BASELINE.json configs[2]), %d timed frames" % steps,
+                           "frames_s": steps / dt, "ms_per_step": dt / steps * 1e3, "tracked_good": int(st.tracked_good), "frames": int(st.frames),
+                           "lm_evaluations_per_frame": st.evaluations / max(1, st.frames),
+                           "track_launches_per_frame": st.track_launches / max(1, st.frames),
+                           "depth_mpix_per_s": (w * h * st.updates) / st.seconds_map / 1e6 if st.seconds_map > 0 else None,
+                           "roofline": roof}
+    loop.close()
+    del d_frames
+    # ---- configs[4]: 3840x2160 regularisation, full frame and 8 row bands on this one GPU -------------------------------------------
+    from lsd_slam_amd.bands import NativeBandRegularizer, synth_s3
+    W, H, passes = 3840, 2160, 20
+    hyp, maxgrad = synth_s3(W, H)
+    reg = {"workload": "3840x2160 depth-map regularisation (fill holes + regularise fused per pass), scene S3 (BASELINE.json configs[4]), "
+                       "%d passes; 64 algorithmic B/px (SURVEY.md 8(d): K5 ~34 + K6 30)" % passes}
+    for bands in (1, 8):
+        br = NativeBandRegularizer(W, H, bands, list(range(bands)), device=device)
+        br.load(hyp, maxgrad)
+        br.run(2)
+        br.synchronize()
+        br.load(hyp, maxgrad)
+        br.synchronize()
+        t0 = time.perf_counter()
+        br.run(passes)
+        br.synchronize()
+        dt = time.perf_counter() - t0
+        ach = W * H * passes * 64.0 / dt / 1e9
+        key = "full_frame" if bands == 1 else "bands_%d_one_gpu" % bands
+        reg[key] = {"ms_per_pass": dt / passes * 1e3, "mpix_per_s": W * H * passes / dt / 1e6, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS}
+        if bands > 1:
+            reg[key]["halo_bytes_per_pass"] = br.plan.halo_bytes_per_pass(W)
+        br.close() if hasattr(br, "close") else None
+    reg["bands_vs_full_frame"] = reg["bands_8_one_gpu"]["ms_per_pass"] / reg["full_frame"]["ms_per_pass"]
+    out["reg_3840x2160"] = reg
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +297,10 @@ def main():
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra host-image (PCIe-inclusive) measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work, gloo when there is no GPU): prints the JSON skeleton")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of exactly --steps steps is run this many times back to back (each between barriers); `value` and "
+                         "`ms_per_step` are those of the MEDIAN region, so one 5 ms window does not decide the line")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the two short extra legs (BASELINE.json configs[2] and configs[4])")
     ap.add_argument("--seq-frames", type=int, default=50,
                     help="synthetic frames to render (one camera revolution = 50); fewer are played back and forth")
     args = ap.parse_args()
@@ -380,18 +458,24 @@ def main():
     if distributed:
         dist.barrier()
     clock = time.perf_counter
-    t0 = clock()
-    run_frames(args.steps)
-    capi.check(L.lsdhip_ctx_synchronize(ctx_h))
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = clock() - t0
+    repeats = max(1, args.repeats)
+    elapsed_all = []
+    for rep_i in range(repeats):
+        # every region: barrier + synchronize, exactly K steps, synchronize + barrier; max over ranks
+        t0 = clock()
+        run_frames(args.steps)
+        capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        e = clock() - t0
+        if distributed:
+            t = torch.tensor([e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        elapsed_all.append(e)
     capi.check(L.lsdhip_prof_enable(ctx_h, 0))
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(np.median(elapsed_all))
 
     st = loop.stats()
     obs_ms, obs_calls = loop.observe_time()
@@ -419,6 +503,7 @@ def main():
         out = {
             "metric": "tracked frames/sec (full track+map loop) at %dx%d" % (w, h), "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": repeats, "ms_per_step_all_regions": [e / args.steps * 1e3 for e in elapsed_all],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
                                    "(BASELINE.json configs[%d]); synthetic scene %s, GT-depth init, new keyframe every %d frames"
@@ -455,6 +540,11 @@ def main():
                 out["roofline_throughput_mode"] = throughput_mode(la, w, h, K, d_frames, depth0, local_rank)
             except Exception as e:   # an extra: never let it take the bench line down
                 out["roofline_throughput_mode"] = {"error": str(e)}
+        if world == 1 and (w, h) == (640, 480) and not args.no_extra_configs:
+            try:
+                out["extra_configs"] = extra_configs(la, torch, local_rank)
+            except Exception as e:   # extras: never let them take the bench line down
+                out["extra_configs"] = {"error": str(e)}
         if world == 1 and not args.no_pcie_leg:
             # SURVEY.md §8(d) counts the 8-bit upload inside tracked frames/s: the same loop fed from (pinned) host memory, every frame
             # crossing PCIe inside lsdhip_frame_create.  Reported beside `value`, never as `value`.
@@ -479,9 +569,10 @@ def main():
             except Exception as e:
                 out["value_pcie_inclusive"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], port = cpu_baseline(frames, depth0, K, args.cpu_frames, w, h)
-            if port is not None:
-                out["cpu_baseline_port"] = port
+            out["cpu_baseline"], other = cpu_baseline(frames, depth0, K, args.cpu_frames, w, h)
+            if other is not None:
+                out["cpu_baseline_other"] = other
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
         emit(json.dumps(out))

@@ -271,6 +271,7 @@ class SE3Tracker {
     frameToReference_initialEstimate.to7(init);
     lsdhip_track_result r;
     hookError_ = nullptr;
+    if (!reference || !reference->keyframe || !frame) throw Error(LSDHIP_E_STATE, "SE3Tracker::trackFrame: the tracking reference holds no keyframe");
     check(lsdhip_tracker_track(h_, reference->keyframe->handle(), frame->handle(), init, &r), "lsdhip_tracker_track");
     publish(r);
     if (hookError_) std::rethrow_exception(hookError_);
@@ -369,6 +370,7 @@ class Sim3Tracker {
                       frameToReference_initialEstimate.q[3], frameToReference_initialEstimate.t[0], frameToReference_initialEstimate.t[1],
                       frameToReference_initialEstimate.t[2], frameToReference_initialEstimate.s};
     lsdhip_sim3_result r;
+    if (!reference || !reference->keyframe || !frame) throw Error(LSDHIP_E_STATE, "Sim3Tracker::trackFrameSim3: the tracking reference holds no keyframe");
     check(lsdhip_sim3tracker_track(h_, reference->keyframe->handle(), frame->handle(), init, startLevel, finalLevel, &r),
           "lsdhip_sim3tracker_track");
     pointUsage = r.pointUsage; lastResidual = r.lastResidual; lastDepthResidual = r.lastDepthResidual;
@@ -516,6 +518,9 @@ class SlamLoop {
   // trip.  The bytes behind nextImage must stay unchanged until that following call (same pointer) has returned.
   template <typename F>
   SE3 step(const unsigned char* image, F&& onTrackEnd, const unsigned char* nextImage = nullptr) {
+    // after a tracking loss the keyframe and the map are gone (SlamSystem::trackingIsGood == false until the relocaliser — out of
+    // scope — finds a pose again): every further step fails the same way instead of touching the invalidated reference
+    if (trackingLost) throw Error(LSDHIP_E_STATE, "SlamLoop: tracking lost (no relocaliser here): create a new loop");
     frameId_++;
     std::shared_ptr<Frame> frame;
     if (prefetched_ && prefetchedSrc_ == image) frame = std::move(prefetched_);

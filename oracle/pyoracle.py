@@ -73,6 +73,27 @@ def build_ref():
     return have_ref()
 
 
+def ref_timing_variant():
+    """Which timing build of the reference (oracle/_ref/liblsd_ref_sse_o3v{3,4}.so: -O3 -DENABLE_SSE -DNDEBUG, contraction at the
+    compiler default — the way lsd_slam_core/CMakeLists.txt builds it, with a portable -march level instead of -march=native) this
+    host can run: the highest level its cpuid supports.  Returns (lib key, flags string) or (None, None)."""
+    flags = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = line
+                break
+    except Exception:
+        pass
+    have = set(flags.split())
+    v3 = {"avx2", "fma", "bmi2", "movbe", "f16c"} <= have
+    v4 = v3 and {"avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"} <= have
+    for key, ok, march in (("sse_o3v4", v4, "x86-64-v4"), ("sse_o3v3", v3, "x86-64-v3")):
+        if ok and os.path.exists(os.path.join(REF_DIR, "liblsd_ref_%s.so" % key)):
+            return key, "-O3 -march=%s -DENABLE_SSE -DNDEBUG (floating-point contraction at the compiler default)" % march
+    return None, None
+
+
 def build_native():
     """-O3 -march=native timing build for the host this runs on (falls back to the portable -march=x86-64-v3 build)"""
     try:

@@ -47,7 +47,7 @@ class Record:
         return np.array(self.centres)
 
 
-def run_oracle(po, frames, depth0, K, n, kf_every=10, mode=None, params=None, L=None):
+def run_oracle(po, frames, depth0, K, n, kf_every=10, mode=None, params=None, L=None, live_queue=1):
     h, w = frames[0].shape
     mode = po.SSE if mode is None else mode
     kf = po.Frame(0, frames[0], K, L=L)
@@ -60,6 +60,7 @@ def run_oracle(po, frames, depth0, K, n, kf_every=10, mode=None, params=None, L=
     tr.set_max_its(ODOMETRY_ITS)
     rec, world = Record(), Sim3World()
     last, since = IDENT7.copy(), 0
+    queue = []          # live_queue > 1: the mapper finds several tracked frames waiting (C/SlamSystem.cpp:559-571) — as SlamLoop models it
     for i in range(1, n + 1):
         f = po.Frame(i, frames[i % len(frames)], K, L=L)
         ref.import_frame(kf)                       # the keyframe's depth changed in the last mapping iteration
@@ -83,8 +84,10 @@ def run_oracle(po, frames, depth0, K, n, kf_every=10, mode=None, params=None, L=
             rec.semidense.append(int((dm.get()["isValid"] > 0).sum()))
             kf = f
             last, since = IDENT7.copy(), 0
+            queue = []
         else:
-            dm.update([f])
+            queue = (queue + [f])[-max(1, live_queue):]
+            dm.update(list(queue))
             f.clear_wasgood()
             last = est
     m = dm.get()
@@ -94,7 +97,7 @@ def run_oracle(po, frames, depth0, K, n, kf_every=10, mode=None, params=None, L=
     return rec
 
 
-def run_hip(la, ctx, frames, depth0, n, kf_every=10):
+def run_hip(la, ctx, frames, depth0, n, kf_every=10, live_queue=1):
     kf = la.Frame(ctx, 0, frames[0])
     kf.setDepthFromGroundTruth(depth0)
     dm = la.DepthMap(ctx)
@@ -105,6 +108,7 @@ def run_hip(la, ctx, frames, depth0, n, kf_every=10):
     tr.set_maxItsPerLvl(ODOMETRY_ITS)
     rec, world = Record(), Sim3World()
     last, since = IDENT7.copy(), 0
+    queue = []
     for i in range(1, n + 1):
         f = la.Frame(ctx, i, frames[i % len(frames)])
         ref.importFrame(kf)
@@ -127,8 +131,10 @@ def run_hip(la, ctx, frames, depth0, n, kf_every=10):
             rec.semidense.append(int((dm.currentDepthMap()["isValid"] > 0).sum()))
             kf = f
             last, since = IDENT7.copy(), 0
+            queue = []
         else:
-            dm.updateKeyframe([f])
+            queue = (queue + [f])[-max(1, live_queue):]
+            dm.updateKeyframe(list(queue))
             f.clear_refPixelWasGood()
             last = est
     m = dm.currentDepthMap()

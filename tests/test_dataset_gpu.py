@@ -95,3 +95,29 @@ def test_cpp_loop_rccl_gather_single_rank():
     assert torch.equal(recv[0, :2], ring[:2]) and float(ring[:2].abs().sum()) > 0
     assert float(recv[0, 2:].min()) == -7.0          # untouched beyond `count`
     drv.comm_destroy()
+
+
+@pytest.mark.gpu
+def test_cpp_loop_stays_lost_after_a_tracking_loss():
+    """SlamLoop::step after a tracking loss (SlamSystem.cpp:946-966, :809-817): the keyframe and the map are invalidated, the call
+    reports LSDHIP_DIVERGED — and every FURTHER call fails with a state error instead of dereferencing the invalidated reference
+    (there is no relocaliser here).  The loss is forced with a frame without any gradient: the normal equations are singular, the
+    increment is not finite, no point warps into the image."""
+    from common import sequence
+    from lsd_slam_amd.driver import DriverLoop
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 6)
+    imgs = [np.ascontiguousarray(f) for f in frames]
+    flat = np.full((h, w), 128, np.uint8)
+    drv = DriverLoop(w, h, K, imgs[0].ctypes.data, depth0, kf_every=10, images_on_device=False)
+    done, _ = drv.run([imgs[i].ctypes.data for i in range(1, 4)])
+    assert done == 3
+    with pytest.raises(RuntimeError) as e1:
+        drv.run([flat.ctypes.data])
+    assert "lost" in str(e1.value).lower()
+    for _ in range(2):          # twice more: same clean error, no crash, no silent re-import of the discarded keyframe
+        with pytest.raises(RuntimeError) as e2:
+            drv.run([imgs[4].ctypes.data, imgs[5].ctypes.data])
+        assert "lost" in str(e2.value).lower()
+    assert drv.stats().frames == 3
+    drv.close()

@@ -13,27 +13,34 @@ from common import sequence
 pytestmark = pytest.mark.gpu
 
 N_FRAMES = 50
-CONFIGS = [pytest.param({}, id="defaults"),
-           pytest.param({"useAffineLightningEstimation": 0, "allowNegativeIdepths": 0, "useSubpixelStereo": 0}, id="ros-all0")]
+ROS_ALL0 = {"useAffineLightningEstimation": 0, "allowNegativeIdepths": 0, "useSubpixelStereo": 0}
+# (parameters, sequence index = seed of the synthetic scene — BASELINE.json configs[3] runs indices 0..7 —, frames handed to
+#  updateKeyframe per mapping iteration: 1 = blockUntilMapped, 4 = the reference's live operation, C/SlamSystem.cpp:559-571)
+CONFIGS = [pytest.param({}, 0, 1, id="defaults"),
+           pytest.param(ROS_ALL0, 0, 1, id="ros-all0"),
+           pytest.param({}, 3, 1, id="defaults-seq3"),
+           pytest.param({}, 7, 1, id="defaults-seq7"),
+           pytest.param({}, 0, 4, id="defaults-livequeue4"),
+           pytest.param(ROS_ALL0, 3, 4, id="ros-all0-seq3-livequeue4")]
 
 
-@pytest.mark.parametrize("params", CONFIGS)
-def test_sequence_50_frames_hip_vs_oracle(oracle, params):
+@pytest.mark.parametrize("params,seq_index,live_queue", CONFIGS)
+def test_sequence_50_frames_hip_vs_oracle(oracle, params, seq_index, live_queue):
     import lsd_slam_amd as la
     w, h = 640, 480
-    frames, depth0, K, gt = sequence(w, h, N_FRAMES)
+    frames, depth0, K, gt = sequence(w, h, N_FRAMES, seq_index)
     op = oracle.default_params()
     for k, v in params.items():
         setattr(op, k, v)
-    o_sse = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SSE, params=op)
-    o_sc = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SCALAR, params=op)
+    o_sse = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SSE, params=op, live_queue=live_queue)
+    o_sc = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SCALAR, params=op, live_queue=live_queue)
     ctx = la.Context(w, h, K, params=params)
-    g = sl.run_hip(la, ctx, frames, depth0, N_FRAMES)
+    g = sl.run_hip(la, ctx, frames, depth0, N_FRAMES, live_queue=live_queue)
     try:
         _compare(g, o_sse, o_sc, gt)
     except AssertionError as e:
         # diagnosis: a second HIP run on a fresh context tells a nondeterministic device path from a real disagreement with the oracle
-        g2 = sl.run_hip(la, la.Context(w, h, K, params=params), frames, depth0, N_FRAMES)
+        g2 = sl.run_hip(la, la.Context(w, h, K, params=params), frames, depth0, N_FRAMES, live_queue=live_queue)
         same = len(g2.frameToKF) == len(g.frameToKF) and all(np.array_equal(a, b) for a, b in zip(g.frameToKF, g2.frameToKF))
         raise AssertionError("%s | a second HIP run gives %s poses" % (e, "IDENTICAL" if same else "DIFFERENT")) from e
 
@@ -62,6 +69,15 @@ def _compare(g, o_sse, o_sc, gt):
     print("pointUsage: max relative difference HIP vs oracle-SSE %.2e (oracle scalar vs SSE %.2e)" % (du, du_ref))
     for i, (a, b) in enumerate(zip(g.usage, o_sse.usage)):
         assert a == pytest.approx(b, rel=5e-3), ("pointUsage of frame %d" % (i + 1), a, b)
+
+    # lastResidual, frame by frame: within 10x the reference's own scalar-vs-SSE spread on that frame (floor 2e-3)
+    worst = (0.0, 0, 0.0)
+    for i, (a, b, c) in enumerate(zip(g.residual, o_sse.residual, o_sc.residual)):
+        d, sp = abs(a - b) / abs(b), abs(c - b) / abs(b)
+        if d / max(10 * sp, 2e-3) > worst[0]:
+            worst = (d / max(10 * sp, 2e-3), i + 1, d)
+        assert d <= max(10 * sp, 2e-3), ("lastResidual of frame %d" % (i + 1), a, b, c)
+    print("lastResidual: tightest frame %d at %.0f %% of its bound (relative difference %.2e)" % (worst[1], 100 * worst[0], worst[2]))
 
     # keyframe changes: rescale factors and semi-dense counts (within 1 %)
     dr = max(abs(a - b) / abs(b) for a, b in zip(g.rescale, o_sse.rescale))
