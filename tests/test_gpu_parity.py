@@ -229,11 +229,16 @@ def test_trackframe_parity(oracle, hip, w, h, params):
         # within 10x the reference's own scalar-vs-SSE spread on this input (and an absolute 5e-4 floor)
         assert max(dt, dr) <= max(10 * spread, 5e-4), (i, dt, dr, spread)
         assert trg.diverged == bool(r_sse.diverged) and trg.trackingWasGood == bool(r_sse.trackingWasGood)
-        # lastResidual / initialTrackedResidual: within 10x the reference's own scalar-vs-SSE spread on this input (floor 2e-3)
+        # lastResidual / initialTrackedResidual: within 10x the reference's own scalar-vs-SSE spread on this input, floor 2e-3 —
+        # 2e-2 with affine lighting on: the estimate (a, b) is a difference of float32 sums of ~1e4 products of magnitude 1e4
+        # (SE3Tracker.cpp:1016-1024); both oracle paths add them in the same sequential order, the device adds them as a tree, and a
+        # shift of b by 0.07 grey levels (measured) moves a residual of 0.3 grey levels RMS by a percent
+        affine_on = params.get("useAffineLightningEstimation", 1) != 0
+        res_floor = 2e-2 if affine_on else 2e-3
         res_spread = abs(r_sc.lastResidual - r_sse.lastResidual) / abs(r_sse.lastResidual)
         res_diff = abs(trg.lastResidual - r_sse.lastResidual) / abs(r_sse.lastResidual)
-        print("frame %d lastResidual: HIP vs oracle-SSE %.2e, oracle scalar vs SSE %.2e (bound %.2e)" % (i, res_diff, res_spread, max(10 * res_spread, 2e-3)))
-        assert res_diff <= max(10 * res_spread, 2e-3), (i, trg.lastResidual, r_sse.lastResidual, r_sc.lastResidual)
+        print("frame %d lastResidual: HIP vs oracle-SSE %.2e, oracle scalar vs SSE %.2e (bound %.2e)" % (i, res_diff, res_spread, max(10 * res_spread, res_floor)))
+        assert res_diff <= max(10 * res_spread, res_floor), (i, trg.lastResidual, r_sse.lastResidual, r_sc.lastResidual)
         assert trg.pointUsage == pytest.approx(r_sse.pointUsage, rel=1e-3)
         if params.get("useAffineLightningEstimation", 1) == 0:
             # the estimate is never applied (C/Tracking/SE3Tracker.cpp:331-335,393-397): (a, b) stay (1, 0)
@@ -246,7 +251,7 @@ def test_trackframe_parity(oracle, hip, w, h, params):
             assert trg.affineEstimation_a == pytest.approx(r_sse.affine_a, rel=2e-3 if same_history else 1e-2)
         # frame side effects
         so, sg = fo.stats(), fg.stats()
-        assert sg["initialTrackedResidual"] == pytest.approx(so["initialTrackedResidual"], rel=max(10 * res_spread, 2e-3) + 1e-3)
+        assert sg["initialTrackedResidual"] == pytest.approx(so["initialTrackedResidual"], rel=max(10 * res_spread, res_floor) + 1e-3)
         mg, mo = fg.refPixelWasGoodNoCreate(), fo.wasgood()
         assert mg is not None and mo is not None
         assert (mg != mo).mean() < 2e-3   # masks are those of the last evaluated pose; poses differ by ~1e-5
