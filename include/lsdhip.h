@@ -181,6 +181,12 @@ int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
  * cluster kernel, out[2] = cluster-kernel launches (0 / 1), out[3] = most trials per step.  Dependent steps of the job =
  * out[0] + out[1]. */
 int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]);
+/* Measurement hook (no reference counterpart): the throughput-mode residual evaluation launch alone — n >= 8 jobs
+ * (keyframes[j], frames[j]) at pyramid level `level` and poses refToFrame (n x 7 floats: q w x y z, t), `repeats` identical launches
+ * between two HIP events.  Reports the mean launch time and the algorithmic bytes of one launch over all jobs (SURVEY.md 8(d)
+ * formula): bytes / time is the kernel's position against the HBM roofline (profiles/r03_sizes.md, bench.py). */
+int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames, const float* refToFrame,
+                                   int level, int repeats, double* ms_per_launch, double* bytes_per_launch);
 /* Host-side pipelining: `fn(user)` is called on the calling thread by lsdhip_tracker_track once the job's launches are
  * queued and before the host waits for the result — the place to queue independent work on the same context (the next
  * image's upload and pyramids, what the reference's image-loader thread does ahead of the tracking thread,

@@ -82,13 +82,20 @@ __device__ __forceinline__ void top3_insert(int k, int& c0, int& c1, int& c2) {
 }
 
 // ---- per-point arithmetic -----------------------------------------------------------------------------------------
+// Pointers into HBM carry the global address space explicitly.  A job description that lives in memory (batches) hands the
+// kernel generic pointers, and loads through a generic pointer are FLAT instructions: they count against the LDS counter
+// (lgkmcnt) as well as vmcnt, so every wait for an LDS read also drains the global loads a software pipeline wants in flight.
+typedef const __attribute__((address_space(1))) float gfloat;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4f gv4f;
+typedef __attribute__((address_space(1))) uint8_t gbyte;
 struct EvalCtx {            // one level of a job + the pose under evaluation, in registers / SGPRs
-  const float* kf_idepth;
-  const float* kf_idepthVar;
-  const float* kf_image;
-  const float4* fr_grad;
-  const float* pts_pos;
-  const float* pts_colvar;
+  gfloat* kf_idepth;
+  gfloat* kf_idepthVar;
+  gfloat* kf_image;
+  gfloat* fr_grad;          // texels (gx, gy, I, 0): 4 floats per pixel
+  gfloat* pts_pos;
+  gfloat* pts_colvar;
   int npts, w, h;
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
   float R[9], t[3];
@@ -124,10 +131,16 @@ __device__ __forceinline__ void eval_warp(const EvalCtx& a, float px, float py, 
 __device__ __forceinline__ void eval_fetch(const EvalCtx& a, const PointWarp& q, bool fetch, PointTexels& t) {
   const int ix = fetch ? (int)q.u_new : 0;
   const int iy = fetch ? (int)q.v_new : 0;
-  const float4* bp = a.fr_grad + ix + iy * a.w;
-  auto ld = [](const float4* p) { const float* f = (const float*)p; Texel3 r = {f[0], f[1], f[2]}; return r; };
-  t.t00 = ld(bp); t.t10 = ld(bp + 1); t.t01 = ld(bp + a.w); t.t11 = ld(bp + 1 + a.w);
+  gfloat* bp = a.fr_grad + 4 * (ix + iy * a.w);
+  auto ld = [](gfloat* f) { Texel3 r = {f[0], f[1], f[2]}; return r; };
+  t.t00 = ld(bp); t.t10 = ld(bp + 4); t.t01 = ld(bp + 4 * a.w); t.t11 = ld(bp + 4 + 4 * a.w);
 }
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the quantities that only feed sums held to a tolerance —
+// K2's weights and K3's Jacobian (the reference's SSE path uses the 12-bit _mm_rcp_ps there, SE3Tracker.cpp:519-553), the usage and
+// affine-lighting statistics.  Everything that decides a mask bit or a count (the projection, the bilinear sample, isGood) stays
+// IEEE-exact: an IEEE division is a ~12-instruction dependent chain, and eleven of them made up a third of the evaluation.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q, const PointTexels& t, float pz, float I_ref, float var,
                                             PointOut& o) {
   const float Wx = q.Wx, Wy = q.Wy, Wz = q.Wz, u_new = q.u_new, v_new = q.v_new;
@@ -146,28 +159,31 @@ __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q
   float c2 = rz;
   float residual = c1 - c2;
   o.res = residual; o.c1 = c1; o.c2 = c2;
-  o.hw = fabsf(residual) < 5.0f ? 1 : 5.0f / fabsf(residual);
-  o.good = residual * residual / (40.0f * 40.0f + 0.5f * 0.5f * (rx * rx + ry * ry)) < 1;
+  o.hw = fabsf(residual) < 5.0f ? 1 : 5.0f * frcp(fabsf(residual));
+  // isGood = residual^2 / (MAX_DIFF_CONSTANT + MAX_DIFF_GRAD_MULT * |grad|^2) < 1 (SE3Tracker.cpp:996-1001): for a positive finite
+  // denominator the rounded quotient is below 1 exactly when the numerator is below the denominator (the largest quotient of
+  // floats x < y is 1 - ulp/2, which is representable), so the comparison needs no division
+  o.good = residual * residual < (40.0f * 40.0f + 0.5f * 0.5f * (rx * rx + ry * ry));
   float gx = a.fx * rx;   // buf_warped_dx
   float gy = a.fy * ry;   // buf_warped_dy
-  float d = 1.0f / pz;    // buf_d
-  float depthChange = pz / Wz;
+  float d = frcp(pz);     // buf_d
+  float z = frcp(Wz);
+  float depthChange = pz * z;
   o.usage = depthChange < 1 ? depthChange : 1;
 
-  // K2, SSE operation order with an IEEE reciprocal
-  float pz2d = 1.0f / ((Wz * Wz) * d);
+  // K2, SSE operation order
+  float pz2d = frcp((Wz * Wz) * d);
   float g0 = (Wz * a.t[0] - Wx * a.t[2]) * pz2d;
   float g1 = (Wz * a.t[1] - Wy * a.t[2]) * pz2d;
   float drpdd = g0 * gx + g1 * gy;
-  float w_p = 1.0f / (a.cameraPixelNoise2 + drpdd * (drpdd * (a.var_weight * var)));
-  float wr = residual * sqrtf(w_p);
+  float w_p = frcp(a.cameraPixelNoise2 + drpdd * (drpdd * (a.var_weight * var)));
+  float wr = residual * fsqrt(w_p);
   wr = fmaxf(wr, 0.0f - wr);
-  float wh = (wr < a.huber_half) ? 1.0f : a.huber_half * (1.0f / wr);
+  float wh = (wr < a.huber_half) ? 1.0f : a.huber_half * frcp(wr);
   o.werr = wh * (wr * wr);
   o.w = wh * w_p;
 
   // K3, SSE operation order
-  float z = 1.0f / Wz;
   o.J[0] = z * gx;
   o.J[1] = z * gy;
   float v1 = (Wx * gy) * z;
@@ -551,13 +567,15 @@ __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const f
 
 // one in-image point's contribution to the running sums (K1 statistics, K2 weighted error, K3 normal equations)
 __device__ __forceinline__ void accumulate_point(const PointOut& o, float (&acc)[RS_END]) {
+  // running sums: the product is fused into the addition (one rounding instead of two, one instruction instead of two) — these are
+  // reductions held to a tolerance, not per-pixel outputs; the counts stay plain additions of 1
   acc[RS_M] += 1.f;
-  acc[RS_SXX] += o.c1 * o.c1 * o.hw;
-  acc[RS_SYY] += o.c2 * o.c2 * o.hw;
-  acc[RS_SX] += o.c1 * o.hw;
-  acc[RS_SY] += o.c2 * o.hw;
+  acc[RS_SXX] = __builtin_fmaf(o.c1 * o.c1, o.hw, acc[RS_SXX]);
+  acc[RS_SYY] = __builtin_fmaf(o.c2 * o.c2, o.hw, acc[RS_SYY]);
+  acc[RS_SX] = __builtin_fmaf(o.c1, o.hw, acc[RS_SX]);
+  acc[RS_SY] = __builtin_fmaf(o.c2, o.hw, acc[RS_SY]);
   acc[RS_SW] += o.hw;
-  if (o.good) { acc[RS_GOOD] += 1.f; acc[RS_SUMRES2] += o.res * o.res; acc[RS_SUMSIGNED] += o.res; }
+  if (o.good) { acc[RS_GOOD] += 1.f; acc[RS_SUMRES2] = __builtin_fmaf(o.res, o.res, acc[RS_SUMRES2]); acc[RS_SUMSIGNED] += o.res; }
   else acc[RS_BAD] += 1.f;
   acc[RS_USAGE] += o.usage;
   acc[RS_WERR] += o.werr;
@@ -565,19 +583,19 @@ __device__ __forceinline__ void accumulate_point(const PointOut& o, float (&acc)
   for (int r = 0; r < 6; r++) {
     float Jw = o.J[r] * o.w;
 #pragma unroll
-    for (int c = r; c < 6; c++) acc[tri_index(r, c)] += Jw * o.J[c];
+    for (int c = r; c < 6; c++) acc[tri_index(r, c)] = __builtin_fmaf(Jw, o.J[c], acc[tri_index(r, c)]);
   }
   float resw = o.res * o.w;
 #pragma unroll
-  for (int r = 0; r < 6; r++) acc[RS_B0 + r] += resw * o.J[r];
-  acc[RS_ERR] += resw * o.res;
+  for (int r = 0; r < 6; r++) acc[RS_B0 + r] = __builtin_fmaf(resw, o.J[r], acc[RS_B0 + r]);
+  acc[RS_ERR] = __builtin_fmaf(resw, o.res, acc[RS_ERR]);
 }
 
 __device__ __forceinline__ void make_ctx_dev(const TrackJob& jobr, const TrackState& S, int level, EvalCtx& a) {
   const TrackJob* job = &jobr;
   const TrackLevel& L = job->lv[level];
-  a.kf_idepth = L.kf_idepth; a.kf_idepthVar = L.kf_idepthVar; a.kf_image = L.kf_image; a.fr_grad = L.fr_grad;
-  a.pts_pos = L.pts_pos; a.pts_colvar = L.pts_colvar; a.npts = L.npts; a.w = L.w; a.h = L.h;
+  a.kf_idepth = (gfloat*)L.kf_idepth; a.kf_idepthVar = (gfloat*)L.kf_idepthVar; a.kf_image = (gfloat*)L.kf_image; a.fr_grad = (gfloat*)L.fr_grad;
+  a.pts_pos = (gfloat*)L.pts_pos; a.pts_colvar = (gfloat*)L.pts_colvar; a.npts = L.npts; a.w = L.w; a.h = L.h;
   a.fx = L.fx; a.fy = L.fy; a.cx = L.cx; a.cy = L.cy; a.fxi = L.fxi; a.fyi = L.fyi; a.cxi = L.cxi; a.cyi = L.cyi;
 #pragma unroll
   for (int i = 0; i < 9; i++) a.R[i] = S.R[i];

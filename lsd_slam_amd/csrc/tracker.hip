@@ -519,7 +519,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   const int tile = xcd_tile(bx, nb);
   EvalCtx a;
   make_ctx_dev(job, S, level, a);
-  uint8_t* wasGood = job.lv[level].writeMask ? (cand == 0 ? job.wasGood : spec.wasGoodSide + (size_t)(cand - 1) * spec.maskStride) : nullptr;
+  gbyte* wasGood = (gbyte*)(job.lv[level].writeMask ? (cand == 0 ? job.wasGood : spec.wasGoodSide + (size_t)(cand - 1) * spec.maskStride) : nullptr);
   const int work = a.npts >= 0 ? a.npts : a.w * a.h;
   float acc[RS_END];
 #pragma unroll
@@ -537,26 +537,38 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     const float inv_w = 1.0f / (float)a.w;
     unsigned vmask = 0;      // 4 validity bits per chunk
     int wcount = 0;          // valid pixels of this wave (uniform)
-    for (int c = 0; c < nchunk; c++) {
+    // all validity loads of the strip are issued together (one memory round trip instead of one per 1024-pixel chunk)
+    constexpr int CHMAX = 8;                       // tilePx <= 8192 (fill_level)
+    v4f v4s[CHMAX], d4s[CHMAX];
+#pragma unroll
+    for (int c = 0; c < CHMAX; c++) {
       const int i0 = base + (c << 10) + (tid << 2);
-      if (i0 < work) {
-        // work is a multiple of 4 whenever the level width is (checked on the host): the 4 pixels exist together
-        const float4 v4 = *(const float4*)(a.kf_idepthVar + i0);
-        const float4 d4 = *(const float4*)(a.kf_idepth + i0);
-        int y = (int)((float)i0 * inv_w);
-        int x = i0 - y * a.w;
-        if (x < 0) { y--; x += a.w; }
-        if (x >= a.w) { y++; x -= a.w; }
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+      // work is a multiple of 4 whenever the level width is (checked on the host): the 4 pixels exist together
+      const bool in = c < nchunk && i0 < work;
+      const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+      v4s[c] = in ? *(gv4f*)(a.kf_idepthVar + i0) : zero4;
+      d4s[c] = in ? *(gv4f*)(a.kf_idepth + i0) : zero4;
+    }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool ok = !(x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) && !(vv[k] <= 0 || dd[k] == 0);
-          vmask |= (ok ? 1u : 0u) << (c * 4 + k);
-          if (++x >= a.w) { x = 0; y++; }
+    for (int c = 0; c < CHMAX; c++) {
+      if (c < nchunk) {
+        const int i0 = base + (c << 10) + (tid << 2);
+        if (i0 < work) {
+          int y = (int)((float)i0 * inv_w);
+          int x = i0 - y * a.w;
+          if (x < 0) { y--; x += a.w; }
+          if (x >= a.w) { y++; x -= a.w; }
+          const float vv[4] = {v4s[c].x, v4s[c].y, v4s[c].z, v4s[c].w}, dd[4] = {d4s[c].x, d4s[c].y, d4s[c].z, d4s[c].w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const bool ok = !(x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) && !(vv[k] <= 0 || dd[k] == 0);
+            vmask |= (ok ? 1u : 0u) << (c * 4 + k);
+            if (++x >= a.w) { x = 0; y++; }
+          }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 4; k++) wcount += __popcll(__ballot((vmask >> (c * 4 + k)) & 1u));
+        for (int k = 0; k < 4; k++) wcount += __popcll(__ballot((vmask >> (c * 4 + k)) & 1u));
+      }
     }
     if (lane == 0) s_wtop[wave][0] = wcount;
     __syncthreads();
@@ -615,25 +627,31 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       stageA(tid, A1);
       stageB(A1, B0);
       stageA(tid + BLOCK, A1);
-      for (int r = 0; r < rounds; r++) {
-        stageB(A1, B1);
-        stageA(tid + (r + 2) * BLOCK, A2);
-        if (B0.live) {
-          const int x_ = (int)(B0.xy & 0xffffu), y_ = (int)(B0.xy >> 16);
+      auto stageC = [&](const StB& B) {
+        if (B.live) {
+          const int x_ = (int)(B.xy & 0xffffu), y_ = (int)(B.xy >> 16);
           const int i = y_ * a.w + x_;
           acc[RS_NREF] += 1.f;
-          if (!B0.q.in_image) {
+          if (!B.q.in_image) {
             if (wasGood) wasGood[i] = 0;
           } else {
             PointOut o;
-            eval_finish(a, B0.q, B0.t, B0.pz, B0.I_ref, B0.var, o);
+            eval_finish(a, B.q, B.t, B.pz, B.I_ref, B.var, o);
             if (wasGood) wasGood[i] = o.good ? 1 : 0;
             top3_insert(x_ * a.h + y_, key0, key1, key2);
             accumulate_point(o, acc);
           }
         }
-        B0 = B1;
-        A1 = A2;
+      };
+      // two rounds per trip with the roles of (A1, A2) and (B0, B1) swapped in the second half: a rotating pipeline written with
+      // struct copies costs ~30 register moves per round
+      for (int r = 0; r < rounds; r += 2) {
+        stageB(A1, B1);
+        stageA(tid + (r + 2) * BLOCK, A2);
+        stageC(B0);
+        stageB(A2, B0);
+        stageA(tid + (r + 3) * BLOCK, A1);
+        stageC(B1);                       // entry r + 1: not live past the end of the list
       }
     }
     __syncthreads();   // the list aliases s_red
@@ -962,7 +980,8 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   L.tilePx = 0;
   if (t->batch_jobs >= 8 && npts < 0 && (L.w & 3) == 0) {
     // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
-    long long px = ((long long)work * t->batch_jobs / 512 + 1023) & ~1023LL;
+    static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : 512;   // developer sweep
+    long long px = ((long long)work * t->batch_jobs / wgTarget + 1023) & ~1023LL;
     if (px < 1024) px = 1024;
     if (px > 8192) px = 8192;                                  // the strip's list lives in the reduction's LDS (10545 words)
     while ((work + px - 1) / px > t->max_blocks) px += 1024;   // cannot happen below 2.6 Mpixel levels
@@ -1559,6 +1578,94 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
     else if (rc) return rc;
   }
   return rcAll;
+}
+
+// Measurement hook (profiles/r03_sizes.md, bench.py's roofline_throughput_mode): the throughput-mode evaluation launch alone.
+// n jobs (keyframes[j], frames[j]) are evaluated at pyramid level `level` at the poses refToFrame[j] (7 floats each: q w x y z, t):
+// one LM launch builds the states, then `repeats` identical evaluation launches (k_track_step<.., TS_EVAL>: idempotent — it reads
+// the published state and rewrites the same partial rows) are timed with one HIP event pair, and a closing LM launch finalises the
+// sums so that the algorithmic bytes of ONE evaluation launch (sum over the jobs, SURVEY.md 8(d) formula as counted by lm_wave)
+// can be reported.  Needs n >= 8 (throughput mode).
+extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames, const float* refToFrame,
+                                              int level, int repeats, double* ms_per_launch, double* bytes_per_launch) {
+  if (!t || n < 8 || !keyframes || !frames || !refToFrame || level < 0 || level >= LSD_LEVELS || repeats < 1 || !ms_per_launch || !bytes_per_launch)
+    return LSDHIP_E_ARG;
+  lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  int rc = batch_reserve(t, n);
+  if (rc) return rc;
+  batch_begin(t, n);
+  int grid = 1;
+  for (int j = 0; j < n; j++) {
+    if (!keyframes[j] || !frames[j] || !keyframes[j]->hasIDepth) { t->cap_override = 0; t->batch_jobs = 0; return LSDHIP_E_ARG; }
+    TrackJob& job = t->h_bjobs[j];
+    fill_job_common(t, job);
+    fill_level(t, job, level, keyframes[j], frames[j], nullptr, nullptr, -1);
+    if (level == LSD_TRACK_MIN_LEVEL) {
+      rc = lsd_frame_ensure_wasgood(frames[j]);
+      if (rc) { t->cap_override = 0; t->batch_jobs = 0; return rc; }
+      job.wasGood = frames[j]->d_wasGood;
+      job.lv[level].writeMask = 1;
+    }
+    job.trackFrameSemantics = 1;
+    job.evalOnly = 1;
+    job.lastLevel = level;
+    job.topLevel = level;
+    const float* T7 = refToFrame + 7 * (size_t)j;
+    job.T0.q = {T7[0], T7[1], T7[2], T7[3]};
+    job.T0.t[0] = T7[4]; job.T0.t[1] = T7[5]; job.T0.t[2] = T7[6];
+    job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
+    if (job.lv[level].nblocks > grid) grid = job.lv[level].nblocks;
+    if (job.lv[level].tilePx == 0) { t->cap_override = 0; t->batch_jobs = 0; lsd_set_error("lsdhip_tracker_eval_throughput: level %d is not in throughput mode", level); return LSDHIP_E_STATE; }
+    t->h_bsummary[j].done = 0;
+  }
+  t->cap_override = 0;
+  t->batch_jobs = 0;
+  HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
+  TrackScratch sc;
+  {
+    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
+    sc.sums = t->d_bscratch;
+    sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
+    sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
+    sc.max_rows = t->max_blocks;
+    sc.cmax = 1;
+    sc.recs = nullptr;
+#ifdef LSD_PHASE_TRACE
+    sc.trace = nullptr;
+#endif
+  }
+  TrackSummary* d_sum = nullptr;
+  HIPCHK(hipHostGetDevicePointer((void**)&d_sum, t->h_bsummary, 0));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
+                     d_sum, 0, 1, TrackSpec{});
+  hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
+                     d_sum, 1, 0, TrackSpec{});     // warm-up
+  HIPCHK(hipEventRecord(e0, c->stream));
+  for (int r = 0; r < repeats; r++)
+    hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate,
+                       sc, d_sum, 1, 0, TrackSpec{});
+  HIPCHK(hipEventRecord(e1, c->stream));
+  hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
+                     d_sum, 1, 0, TrackSpec{});
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  double bytes = 0;
+  for (int j = 0; j < n; j++) {
+    if (!t->h_bsummary[j].done) { lsd_set_error("lsdhip_tracker_eval_throughput: job %d did not finish", j); return LSDHIP_E_STATE; }
+    bytes += t->h_bsummary[j].bytes;
+  }
+  *ms_per_launch = ms / repeats;
+  *bytes_per_launch = bytes;
+  return LSDHIP_OK;
 }
 
 extern "C" int lsdhip_tracker_evaluate(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_frame* frame, const float T7[7], int level,

@@ -293,6 +293,17 @@ class SE3Tracker:
                 f._parent = ref.keyframe
         return np.array([list(r.frameToReference) for r in res]), list(res)
 
+    def evalThroughput(self, references, frames, referenceToFrames, level, repeats=20):
+        """measurement hook: the throughput-mode evaluation launch at `level` for n >= 8 jobs; returns (ms per launch, algorithmic
+        bytes per launch)"""
+        n = len(frames)
+        kfs = (C.c_void_p * n)(*[r.keyframe.h_ for r in references])
+        frs = (C.c_void_p * n)(*[f.h_ for f in frames])
+        T = np.ascontiguousarray(referenceToFrames, dtype=np.float32).reshape(n, 7)
+        ms, nb = C.c_double(), C.c_double()
+        check(self.L.lsdhip_tracker_eval_throughput(self.h_, n, kfs, frs, T.ctypes.data, int(level), int(repeats), C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
+
     def evaluate(self, reference, frame, referenceToFrame, level, a=1.0, b=0.0):
         T = np.ascontiguousarray(referenceToFrame, dtype=np.float32)
         r = capi.ResidualRecord()
