@@ -196,9 +196,22 @@ def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
     ctx.prof_enable(False)
     ms, n_eval, nbytes = ctx.prof_read()
     achieved = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "jobs_per_launch": jobs, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "evaluations": int(n_eval), "stream_ms": ms,
-            "kernel": "k_track_step<TS_LM> + k_track_step<TS_EVAL>, all launches of %d rounds of %d jobs" % (rounds, jobs)}
+    out = {"bound": "hbm", "jobs_per_launch": jobs, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "evaluations": int(n_eval), "stream_ms": ms,
+           "kernel": "k_track_step<TS_LM> + k_track_step<TS_EVAL>, all launches of %d rounds of %d jobs (LM launches and coarse levels carry almost no bytes)" % (rounds, jobs)}
+    # the residual evaluation launch alone, per pyramid level, at fixed poses (lsdhip_tracker_eval_throughput: 20 identical launches
+    # between two HIP events): level 1 is where the bytes are
+    T = np.zeros((jobs, 7), np.float32)
+    T[:, 0] = 1.0
+    frs = [la.Frame(ctx, 300000 + j, device_ptr=d_frames[1 + j % 5].data_ptr()) for j in range(jobs)]
+    per_level = {}
+    for lvl in (3, 2, 1):
+        ms_l, nb_l = tr.evalThroughput(refs, frs, T, lvl, 20)
+        ach = nb_l / (ms_l * 1e-3) / 1e9
+        per_level["L%d" % lvl] = {"us_per_launch": ms_l * 1e3, "algorithmic_bytes_per_launch": nb_l, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+    out["evaluation_launch_by_level"] = per_level
+    out["level1_evaluation"] = dict(per_level["L1"], bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", kernel="k_track_step<256, true, TS_EVAL>, %d jobs per launch" % jobs)
+    return out
 
 
 def extra_configs(la, torch, device):

@@ -181,6 +181,14 @@ int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
  * cluster kernel, out[2] = cluster-kernel launches (0 / 1), out[3] = most trials per step.  Dependent steps of the job =
  * out[0] + out[1]. */
 int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]);
+/* Execution form of the throughput-mode evaluation (batches of >= 8 jobs; no reference counterpart, same results up to summation
+ * order).  on = 0 (default): k_track_step<.., TS_EVAL> — the strip's valid pixels compacted into an LDS list, keyframe planes and the
+ * four bilinear taps gathered through L1 / L2 behind a three-stage software pipeline.  on = 1: k_track_eval_tiles — per 1024-pixel
+ * chunk the planes are read coalesced, the image rows the chunk's warped points sample are staged into LDS (the "LDS-staged image
+ * tile" of BASELINE.json's north_star) and the taps are LDS reads.  Measured on MI355X at 64 jobs x 640x480 level 1: 66 us against
+ * 41-45 us per launch for the default (profiles/r03_sizes.md): the per-chunk barriers and the exposed staging latency cost more than
+ * the gathers they replace.  Environment at creation: LSDHIP_BATCH_TILES=1. */
+int lsdhip_tracker_set_batch_tiles(lsdhip_tracker* t, int on);
 /* Measurement hook (no reference counterpart): the throughput-mode residual evaluation launch alone — n >= 8 jobs
  * (keyframes[j], frames[j]) at pyramid level `level` and poses refToFrame (n x 7 floats: q w x y z, t), `repeats` identical launches
  * between two HIP events.  Reports the mean launch time and the algorithmic bytes of one launch over all jobs (SURVEY.md 8(d)

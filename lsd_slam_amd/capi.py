@@ -107,6 +107,7 @@ def _signatures():
         "lsdhip_tracker_set_enqueue_hook": (i, [vp, vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_track_batch": (i, [vp, i, pvp, pvp, vp, C.POINTER(TrackResult)]),
+        "lsdhip_tracker_set_batch_tiles": (i, [vp, i]),
         "lsdhip_tracker_eval_throughput": (i, [vp, i, pvp, pvp, vp, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "lsdhip_tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(ResidualRecord)]),
         "lsdhip_tracker_track_permaref": (i, [vp, vp, vp, i, vp, vp, C.POINTER(TrackResult)]),

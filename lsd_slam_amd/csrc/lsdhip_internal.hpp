@@ -268,6 +268,7 @@ struct lsdhip_tracker {
   unsigned long long* d_trace = nullptr;  // LSD_PHASE_TRACE developer build only
   unsigned long long* d_ctrace = nullptr; // ... per-step marks of k_track_coarse
   // batch tracking (lsdhip_tracker_track_batch): per-job descriptions, states, scratch and summaries
+  bool batchTiles = false;            // throughput mode evaluates with k_track_eval_tiles (LDS-staged image tiles; lsdhip_tracker_set_batch_tiles)
   int batch_capacity = 0;
   TrackJob* d_bjobs = nullptr;
   TrackJob* h_bjobs = nullptr;        // pinned staging

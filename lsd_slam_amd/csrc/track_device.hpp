@@ -131,7 +131,7 @@ __device__ __forceinline__ void eval_warp(const EvalCtx& a, float px, float py, 
 __device__ __forceinline__ void eval_fetch(const EvalCtx& a, const PointWarp& q, bool fetch, PointTexels& t) {
   const int ix = fetch ? (int)q.u_new : 0;
   const int iy = fetch ? (int)q.v_new : 0;
-  gfloat* bp = a.fr_grad + 4 * (ix + iy * a.w);
+  gfloat* bp = a.fr_grad + 4 * (ix + __mul24(iy, a.w));     // 24-bit multiply: full rate (a 32-bit integer multiply is quarter rate)
   auto ld = [](gfloat* f) { Texel3 r = {f[0], f[1], f[2]}; return r; };
   t.t00 = ld(bp); t.t10 = ld(bp + 4); t.t01 = ld(bp + 4 * a.w); t.t11 = ld(bp + 4 + 4 * a.w);
 }
@@ -616,3 +616,17 @@ __device__ __forceinline__ void copy_words(void* dst, const void* src, int tid, 
 // XCD x the contiguous tile range [x nb/8, (x+1) nb/8) keeps the texels one band of the frame touches in one L2.
 __device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b; }
 
+
+#define RS_COLS 44   // RS_END rounded up: floats per partial-sum row
+// Scratch of a tracker in HBM, double-buffered by launch parity (a launch reads [parity], writes [1 - parity]).
+struct TrackScratch {
+  float* sums;     // [2][RS_COLS][max_rows]  column-major partial sums: one row per workgroup tile
+  int4* topkey;    // [2][max_rows]           each tile's three largest reference-order keys among in-image points (x>=y>=z)
+  float* topval;   // [2][max_rows][3][32]    K2/K3 contributions of those points (single-pass levels only)
+  int max_rows;    // multiple of 4
+  int cmax;        // trial slots per parity (reject-chain speculation): sums [2][cmax][RS_COLS][max_rows], topkey / topval likewise
+  float* recs;     // [2][cmax][32]  increment / pose of the trials > 0 of a launch (null when cmax == 1)
+#ifdef LSD_PHASE_TRACE
+  unsigned long long* trace;   // [0] = launch counter, then 20 words per launch (developer build only, tools/phase_trace.py)
+#endif
+};

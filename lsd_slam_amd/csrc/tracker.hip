@@ -30,26 +30,14 @@
 #include <chrono>
 #include "track_device.hpp"
 #include "tracker_coarse.hpp"
+#include "tracker_batch.hpp"
 
 
-// Scratch of a tracker in HBM, double-buffered by launch parity (a launch reads [parity], writes [1 - parity]).
-struct TrackScratch {
-  float* sums;     // [2][RS_COLS][max_rows]  column-major partial sums: one row per workgroup tile
-  int4* topkey;    // [2][max_rows]           each tile's three largest reference-order keys among in-image points (x>=y>=z)
-  float* topval;   // [2][max_rows][3][32]    K2/K3 contributions of those points (single-pass levels only)
-  int max_rows;    // multiple of 4
-  int cmax;        // trial slots per parity (reject-chain speculation): sums [2][cmax][RS_COLS][max_rows], topkey / topval likewise
-  float* recs;     // [2][cmax][32]  increment / pose of the trials > 0 of a launch (null when cmax == 1)
-#ifdef LSD_PHASE_TRACE
-  unsigned long long* trace;   // [0] = launch counter, then 20 words per launch (developer build only, tools/phase_trace.py)
-#endif
-};
 #ifdef LSD_PHASE_TRACE
 #define PHASE_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) tr_[k] = clock64(); } while (0)
 #else
 #define PHASE_MARK(k) do { } while (0)
 #endif
-#define RS_COLS 44   // RS_END rounded up
 
 // Fused tracking step, one launch per step of the LM loop:
 //   (1) every workgroup finishes the *previous* launch's evaluation(s) from the tiles' partial rows: fixed-order column sums
@@ -533,7 +521,8 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     unsigned* s_list = (unsigned*)s_red;   // (x | y << 16); s_red is not live before the reduction
     const int tilePx = job.lv[level].tilePx;
     const int base = tile * tilePx;
-    const int nchunk = tilePx >> 10;
+    const int nchunk = (tilePx + 1023) >> 10;     // strips are multiples of 256 pixels: the last chunk may be partial
+    const int stripEnd = min(base + tilePx, work);
     const float inv_w = 1.0f / (float)a.w;
     unsigned vmask = 0;      // 4 validity bits per chunk
     int wcount = 0;          // valid pixels of this wave (uniform)
@@ -544,7 +533,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     for (int c = 0; c < CHMAX; c++) {
       const int i0 = base + (c << 10) + (tid << 2);
       // work is a multiple of 4 whenever the level width is (checked on the host): the 4 pixels exist together
-      const bool in = c < nchunk && i0 < work;
+      const bool in = c < nchunk && i0 < stripEnd;
       const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
       v4s[c] = in ? *(gv4f*)(a.kf_idepthVar + i0) : zero4;
       d4s[c] = in ? *(gv4f*)(a.kf_idepth + i0) : zero4;
@@ -553,7 +542,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     for (int c = 0; c < CHMAX; c++) {
       if (c < nchunk) {
         const int i0 = base + (c << 10) + (tid << 2);
-        if (i0 < work) {
+        if (i0 < stripEnd) {
           int y = (int)((float)i0 * inv_w);
           int x = i0 - y * a.w;
           if (x < 0) { y--; x += a.w; }
@@ -605,7 +594,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       auto stageA = [&](int p, StA& A) {
         A.live = p < total;
         A.xy = s_list[A.live ? p : 0];
-        const int i = (int)(A.xy >> 16) * a.w + (int)(A.xy & 0xffffu);
+        const int i = __mul24((int)(A.xy >> 16), a.w) + (int)(A.xy & 0xffffu);
         A.var = a.kf_idepthVar[i];
         A.id = a.kf_idepth[i];
         A.img = a.kf_image[i];
@@ -630,7 +619,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       auto stageC = [&](const StB& B) {
         if (B.live) {
           const int x_ = (int)(B.xy & 0xffffu), y_ = (int)(B.xy >> 16);
-          const int i = y_ * a.w + x_;
+          const int i = __mul24(y_, a.w) + x_;
           acc[RS_NREF] += 1.f;
           if (!B.q.in_image) {
             if (wasGood) wasGood[i] = 0;
@@ -638,7 +627,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
             PointOut o;
             eval_finish(a, B.q, B.t, B.pz, B.I_ref, B.var, o);
             if (wasGood) wasGood[i] = o.good ? 1 : 0;
-            top3_insert(x_ * a.h + y_, key0, key1, key2);
+            top3_insert(__mul24(x_, a.h) + y_, key0, key1, key2);
             accumulate_point(o, acc);
           }
         }
@@ -822,6 +811,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
     HIPCHK(hipMemsetAsync(t->d_ctrows, 0, ct_bytes, c->stream));
     if (const char* e = getenv("LSDHIP_COARSE")) t->coarse = e[0] != '0';
     if (const char* e = getenv("LSDHIP_COARSE_FOLD")) t->coarseFold = e[0] != '0';
+    if (const char* e = getenv("LSDHIP_BATCH_TILES")) t->batchTiles = e[0] == '1';
   }
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
@@ -980,11 +970,13 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   L.tilePx = 0;
   if (t->batch_jobs >= 8 && npts < 0 && (L.w & 3) == 0) {
     // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
-    static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : 512;   // developer sweep
-    long long px = ((long long)work * t->batch_jobs / wgTarget + 1023) & ~1023LL;
+    static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : 768;   // developer sweep
+    // strips x jobs = the chip's 768 workgroup slots (3 per CU) where the level is large enough: one full round of equal strips;
+    // a strip is a multiple of 256 pixels (the lanes take 4 consecutive pixels each)
+    long long px = (((long long)work * t->batch_jobs + wgTarget - 1) / wgTarget + 255) & ~255LL;
     if (px < 1024) px = 1024;
     if (px > 8192) px = 8192;                                  // the strip's list lives in the reduction's LDS (10545 words)
-    while ((work + px - 1) / px > t->max_blocks) px += 1024;   // cannot happen below 2.6 Mpixel levels
+    while ((work + px - 1) / px > t->max_blocks) px += 256;    // cannot happen below 2.6 Mpixel levels
     L.tilePx = (int)px;
     L.nblocks = (int)((work + px - 1) / px);
     L.singlePass = 0;
@@ -1453,6 +1445,12 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
 }
 
 // ---- batches: n independent jobs in the same launches (job = blockIdx.y) -------------------------------------------
+extern "C" int lsdhip_tracker_set_batch_tiles(lsdhip_tracker* t, int on) {
+  if (!t) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(t->ctx);
+  t->batchTiles = on != 0;
+  return LSDHIP_OK;
+}
 static int batch_reserve(lsdhip_tracker* t, int n) {
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
@@ -1519,6 +1517,8 @@ static int batch_run(lsdhip_tracker* t, int n) {
         // throughput mode: one LM workgroup per job, then a pure evaluation launch over all jobs' strips
         hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
+        if (t->batchTiles) { if (int rct = lsd_track_eval_tiles_launch(t, grid, n, sc, 1 - parity)) return rct; }
+        else
         hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, 1 - parity, 0, TrackSpec{});
       } else {
@@ -1643,12 +1643,16 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
   HIPCHK(hipEventCreate(&e1));
   hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
                      d_sum, 0, 1, TrackSpec{});
-  hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
-                     d_sum, 1, 0, TrackSpec{});     // warm-up
+  auto eval_launch = [&]() -> int {
+    if (t->batchTiles) return lsd_track_eval_tiles_launch(t, grid, n, sc, 1);
+    hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
+                       d_sum, 1, 0, TrackSpec{});
+    return LSDHIP_OK;
+  };
+  if (int rcw = eval_launch()) return rcw;     // warm-up
   HIPCHK(hipEventRecord(e0, c->stream));
   for (int r = 0; r < repeats; r++)
-    hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate,
-                       sc, d_sum, 1, 0, TrackSpec{});
+    if (int rce = eval_launch()) return rce;
   HIPCHK(hipEventRecord(e1, c->stream));
   hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
                      d_sum, 1, 0, TrackSpec{});
