@@ -265,7 +265,7 @@ __device__ __forceinline__ void gj6_solve_wave(const float* A /*LDS, 6x6*/, cons
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float d = s_m[k * 8 + k], rk = s_m[k * 8 + (act ? j : 0)], ck = s_m[ii * 8 + k];
-    const float f = ck / d;
+    const float f = ck * frcp(d);                  // 1-ulp reciprocal: the solve is tolerance-level by construction (see above)
     const float upd = m - f * rk;
     m = (i == k) ? m : upd;
     __builtin_amdgcn_wave_barrier();
@@ -276,7 +276,7 @@ __device__ __forceinline__ void gj6_solve_wave(const float* A /*LDS, 6x6*/, cons
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int r = 0; r < 6; r++) x[r] = s_m[r * 8 + 6] / s_m[r * 8 + r];
+  for (int r = 0; r < 6; r++) x[r] = s_m[r * 8 + 6] * frcp(s_m[r * 8 + r]);
 }
 
 // sin / cos for the small angles of an LM increment: Taylor polynomials (|x| < 0.5: truncation error < 2e-10 relative),
@@ -293,9 +293,9 @@ __device__ __forceinline__ void sincos_small(const float xx, float* sn, float* c
 
 // Quaternion normalisation, the four divisions in four lanes (lsdm::q_normalize arithmetic)
 __device__ __forceinline__ void q_normalize_wave(lsdm::Quatf& q, const int lane) {
-  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const float rn = __builtin_amdgcn_rsqf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);   // 1 / norm, 1 ulp
   const float c = (lane & 3) == 0 ? q.w : ((lane & 3) == 1 ? q.x : ((lane & 3) == 2 ? q.y : q.z));
-  const float r = c / n;
+  const float r = c * rn;
   q.w = rl(r, 0); q.x = rl(r, 1); q.y = rl(r, 2); q.z = rl(r, 3);
 }
 
@@ -304,7 +304,7 @@ __device__ __forceinline__ lsdm::SE3fH se3f_exp_wave(const float (&a)[6], const 
   const float eps = static_cast<float>(1e-5);
   const float ox = a[3], oy = a[4], oz = a[5];
   const float theta_sq = ox * ox + (oy * oy + oz * oz);
-  const float theta = sqrtf(theta_sq);
+  const float theta = fsqrt(theta_sq);
   const float half_theta = 0.5f * theta;
   float sn, cs;
   sincos_small((lane & 1) ? theta : half_theta, &sn, &cs);
@@ -315,7 +315,7 @@ __device__ __forceinline__ lsdm::SE3fH se3f_exp_wave(const float (&a)[6], const 
     imag = 0.5f - static_cast<float>(1.0 / 48.0) * theta_sq + static_cast<float>(1.0 / 3840.0) * theta_po4;
     real = 1.0f - 0.5f * theta_sq + static_cast<float>(1.0 / 384.0) * theta_po4;
   } else {
-    imag = sin_half / theta;
+    imag = sin_half * frcp(theta);
     real = cos_half;
   }
   lsdm::SE3fH r;
@@ -337,8 +337,8 @@ __device__ __forceinline__ lsdm::SE3fH se3f_exp_wave(const float (&a)[6], const 
     lsdm::q_to_rot<lsdm::Quatf, float>(r.q, V);
   } else {
     const float tsq = theta * theta;
-    const float ca = (1.0f - cos_theta) / tsq;
-    const float cb = (theta - sin_theta) / (tsq * theta);
+    const float ca = (1.0f - cos_theta) * frcp(tsq);
+    const float cb = (theta - sin_theta) * frcp(tsq * theta);
 #pragma unroll
     for (int i = 0; i < 9; i++) V[i] = (((i % 4) == 0 ? 1.0f : 0.0f) + ca * Om[i]) + cb * Om2[i];
   }
@@ -413,6 +413,9 @@ __device__ __forceinline__ void stage_lm_par(const TrackJob& job, int level, LmP
 // Reject-chain speculation: `consumed` = index (within the launch that produced the sums) of the trial being finished (the
 // caller has already advanced lambda / incTry / counters past the plain rejections before it), `mycand` = the trial this
 // workgroup evaluates next: `mycand` retries further down the chain that starts at the proposal made here.
+// calcWeightsAndResidualSSE's return value: the weighted error over the points its loop visits (SE3Tracker.cpp:572-574).  One
+// definition: the speculation scans and lm_wave must agree on it bit for bit.
+__device__ __forceinline__ float lm_werr(float sumWeightedErr, int M) { return sumWeightedErr * frcp((float)((M >> 2) << 2)); }
 __device__ __forceinline__ float lm_lambda_fail(float LM_lambda, int incTry, float lambdaFailFac) {
   if (LM_lambda == 0) return 0.2f;
   double p = 1.0;
@@ -434,13 +437,16 @@ __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const f
   float aff_a_lastIt, aff_b_lastIt;
   {
     const float sxx = rl(col, RS_SXX), syy = rl(col, RS_SYY), sx = rl(col, RS_SX), sy = rl(col, RS_SY), sw = rl(col, RS_SW);
-    aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
-    aff_b_lastIt = (sy - aff_a_lastIt * sx) / sw;
+    // (1-ulp reciprocals / square roots throughout the LM step: one wave, every dependent IEEE division is ~100 cycles the whole
+    // launch waits for; the quantities are reductions and a pose increment, all held to a tolerance)
+    const float isw = frcp(sw);
+    aff_a_lastIt = fsqrt((syy - sy * sy * isw) * frcp(sxx - sx * sx * isw));
+    aff_b_lastIt = (sy - aff_a_lastIt * sx) * isw;
   }
-  S.pointUsage = rl(col, RS_USAGE) / refNum;
+  S.pointUsage = rl(col, RS_USAGE) * frcp(refNum);
   S.goodCount = goodCount;
   S.badCount = badCount;
-  S.meanRes = rl(col, RS_SUMSIGNED) / goodCount;
+  S.meanRes = rl(col, RS_SUMSIGNED) * frcp(goodCount);
   S.aff_a_lastIt = aff_a_lastIt;
   S.aff_b_lastIt = aff_b_lastIt;
   S.numEvaluations = S.numEvaluations + 1;
@@ -461,7 +467,7 @@ __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const f
     return false;
   }
   // calcWeightsAndResidualSSE epilogue (:572-574)
-  const float werr = rl(col, RS_WERR) / ((M >> 2) << 2);
+  const float werr = lm_werr(rl(col, RS_WERR), M);
   const bool useAffine = L.useAffine != 0;
   const bool tfSemantics = L.tfSemantics != 0;
 
@@ -481,7 +487,7 @@ __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const f
       accepted = true;
       T = S.Tn;
       S.T = T;
-      if (error / lastErr > L.convergenceEps) iteration = maxIts;
+      if (error > L.convergenceEps * lastErr) iteration = maxIts;     // error / lastErr > convergenceEps (both positive)
       lastErr = error;
       if (tfSemantics) S.last_residual = error;
       if (LM_lambda <= 0.2) LM_lambda = 0;
@@ -506,16 +512,16 @@ __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const f
     if (useAffine) { S.aff_a = aff_a_lastIt; S.aff_b = aff_b_lastIt; }
     // the accepted (or first) evaluation's normal equations are what calculateWarpUpdate would build next: LGS6::finish
     // (A / n, b / n with the SSE constraint count n = 6 (M / 4), LGSX.h:319-325, :385), one entry per lane
-    const float n = (float)((size_t)6 * (size_t)(M >> 2));
+    const float rn = frcp((float)((size_t)6 * (size_t)(M >> 2)));
     const int k = lane - RS_A0;
     if (k >= 0 && k < 21) {
       const int i = (k >= 6) + (k >= 11) + (k >= 15) + (k >= 18) + (k >= 20);
       const int j = k - (i * 6 - (i * (i - 1)) / 2) + i;
-      const float v = (0.0f + col) / n;
+      const float v = (0.0f + col) * rn;
       S.A[i * 6 + j] = v;
       S.A[j * 6 + i] = v;
     }
-    if (lane >= RS_B0 && lane < RS_B0 + 6) S.b[lane - RS_B0] = (0.0f - col) / n;
+    if (lane >= RS_B0 && lane < RS_B0 + 6) S.b[lane - RS_B0] = (0.0f - col) * rn;
   }
   if (start_iteration && iteration < maxIts) { S.numWarpUpdates = S.numWarpUpdates + 1; incTry = 0; propose = true; }
   S.lastErr = lastErr;

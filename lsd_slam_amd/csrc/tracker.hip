@@ -390,7 +390,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         if (needc > 0) ws -= s_subT[c][0][0];
         if (needc > 1) ws -= s_subT[c][1][0];
         if (needc > 2) ws -= s_subT[c][2][0];
-        const float werrc = ws / ((Mc >> 2) << 2);
+        const float werrc = lm_werr(ws, Mc);
         const float* ic = c == 0 ? S.inc : s_rec[c];
         const float i0 = ic[0], i1 = ic[1], i2 = ic[2], i3 = ic[3], i4 = ic[4], i5 = ic[5];
         const float incdot = (i0 * i0 + (i1 * i1 + i2 * i2)) + (i3 * i3 + (i4 * i4 + i5 * i5));

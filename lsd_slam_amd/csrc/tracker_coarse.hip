@@ -352,7 +352,7 @@ __global__ __launch_bounds__(CT_BLOCK) void k_track_coarse(TrackJob job, CoarseP
         if (needc > 0) ws -= s_kw[cc][e0 / 3][e0 % 3];
         if (needc > 1) ws -= s_kw[cc][e1 / 3][e1 % 3];
         if (needc > 2) ws -= s_kw[cc][e2 / 3][e2 % 3];
-        const float werrc = ws / ((Mc >> 2) << 2);
+        const float werrc = lm_werr(ws, Mc);
         const float* ic = s_rec[cc];
         const float i0 = ic[0], i1 = ic[1], i2 = ic[2], i3 = ic[3], i4 = ic[4], i5 = ic[5];
         const float incdot = (i0 * i0 + (i1 * i1 + i2 * i2)) + (i3 * i3 + (i4 * i4 + i5 * i5));
