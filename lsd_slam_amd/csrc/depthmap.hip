@@ -100,15 +100,8 @@ struct ObserveArgs {
 #ifdef LSD_PHASE_TRACE
   unsigned long long* trace;   // developer build: per-stage timestamps of one traced pixel per workgroup
 #endif
-  // two-kernel form (k_observe_select / k_observe_walk): the pixels that reach the epipolar search
-  struct WalkItem* queue;
-  int* qcount;       // items queued by this call
-  int* qcount_next;  // the other counter, cleared by the walk kernel for the next call
-  int qcap;
-  int shortWalks;    // fused kernel: walks of <= 8 steps load all their samples up front
   StereoRef one;   // nRefs == 1 (the blockUntilMapped case): the reference travels in the kernel arguments, no staging copy
 };
-struct WalkItem { int idx, refIdx; float epx, epy; };
 
 // DepthMap::doLineStereo (DepthMap.cpp:1442-1972) in three parts.  Status codes as in the reference: >= 0 matching error,
 // -1 out of bounds, -2 ambiguous / negative, -3 error too large, -4 arithmetic.
@@ -121,7 +114,7 @@ struct StereoSetup {
   float rescaleFactor;
   float realVal_m2, realVal_m1, realVal, realVal_p1, realVal_p2;
   float pFar0, pFar1, pClose0, pClose1, incx, incy, eplLength;
-  float4 gt00, gt10, gt01, gt11;     // keyframe gradient taps of the geometric error term
+  float gI0, gI1;                    // keyframe gradient at (u, v) (getInterpolatedElement42) for the geometric error term
 };
 struct WalkResult {
   float best_match_err, second_best_match_err, best_match_errPre, best_match_errPost, best_match_DiffErrPre, best_match_DiffErrPost;
@@ -136,7 +129,7 @@ LSD_HD float stereo_setup(const ObserveArgs& a, const StereoRef& rf, const float
   // the keyframe gradient taps of the geometric-error term (used after the search) depend on (u, v) only: issue their loads
   // now so that they do not add a memory round trip after the walk
   const float4* const gbp = a.kfGrad + (int)u + (int)v * width;
-  S.gt00 = gbp[0]; S.gt10 = gbp[1]; S.gt01 = gbp[width]; S.gt11 = gbp[1 + width];
+  const float4 gt00 = gbp[0], gt10 = gbp[1], gt01 = gbp[width], gt11 = gbp[1 + width];
   float KinvP0 = a.fxi * u + a.cxi, KinvP1 = a.fyi * v + a.cyi, KinvP2 = 1.0f;
   S.KinvP0 = KinvP0; S.KinvP1 = KinvP1;
   float pInf0 = (rf.K_otherToThis_R[0] * KinvP0 + rf.K_otherToThis_R[1] * KinvP1) + rf.K_otherToThis_R[2] * KinvP2;
@@ -225,20 +218,17 @@ LSD_HD float stereo_setup(const ObserveArgs& a, const StereoRef& rf, const float
       return -1;
   }
   S.pFar0 = pFar0; S.pFar1 = pFar1; S.pClose0 = pClose0; S.pClose1 = pClose1; S.incx = incx; S.incy = incy; S.eplLength = eplLength;
+  {
+    // getInterpolatedElement42 on the keyframe gradients (globalFuncs.h:95-109): interpolated here, where the taps have long
+    // arrived, so that two values instead of eight stay live across the walk
+    const int ix = (int)u, iy = (int)v;
+    const float dx = u - ix, dy = v - iy;
+    const float dxdy = dx * dy;
+    S.gI0 = dxdy * gt11.x + (dy - dxdy) * gt01.x + (dx - dxdy) * gt10.x + (1 - dx - dy + dxdy) * gt00.x;
+    S.gI1 = dxdy * gt11.y + (dy - dxdy) * gt01.y + (dx - dxdy) * gt10.y + (1 - dx - dy + dxdy) * gt00.y;
+  }
   OBS_MARK(3);
   return 0;
-}
-
-// number of steps the walk will take (its loop condition only involves positions formed by repeated addition)
-LSD_HD int stereo_walk_steps(const StereoSetup& S) {
-  float cpx = S.pFar0, cpy = S.pFar1;
-  int n = 0;
-  while ((((S.incx < 0) == (cpx > S.pClose0) && (S.incy < 0) == (cpy > S.pClose1)) || n == 0) && n < 1000) {
-    cpx += S.incx;
-    cpy += S.incy;
-    n++;
-  }
-  return n;
 }
 
 // the walk, one lane per search (the reference's loop; two steps of samples kept in flight)
@@ -330,90 +320,6 @@ LSD_HD void stereo_walk_serial(const float* __restrict__ refImg, const int width
   W.loopCBest = loopCBest; W.loopCSecond = loopCSecond; W.loopCounter = loopCounter;
 }
 
-// the same walk for N <= OBS_SERIAL_MAX steps with every sample loaded up front (their positions do not depend on the sampled
-// values): one memory round trip instead of one per step; the fold over the steps is the reference's, statement for statement
-#define OBS_SERIAL_MAX 8        // longer walks are evaluated by the whole wave (k_observe_walk)
-LSD_HD void stereo_walk_short(const float* __restrict__ refImg, const int width, const StereoSetup& S, const int N, WalkResult& W) {
-  const float incx = S.incx, incy = S.incy;
-  const float realVal_p2 = S.realVal_p2, realVal_p1 = S.realVal_p1, realVal = S.realVal, realVal_m1 = S.realVal_m1, realVal_m2 = S.realVal_m2;
-  float s[OBS_SERIAL_MAX + 4], px[OBS_SERIAL_MAX], py[OBS_SERIAL_MAX];
-  {
-    float cpx = S.pFar0, cpy = S.pFar1;
-    s[0] = interp1(refImg, cpx - 2.0f * incx, cpy - 2.0f * incy, width);
-    s[1] = interp1(refImg, cpx - incx, cpy - incy, width);
-    s[2] = interp1(refImg, cpx, cpy, width);
-    s[3] = interp1(refImg, cpx + incx, cpy + incy, width);
-#pragma unroll
-    for (int k = 0; k < OBS_SERIAL_MAX; k++) {
-      px[k] = cpx; py[k] = cpy;
-      const bool live = k < N;
-      s[4 + k] = interp1(refImg, live ? cpx + 2 * incx : S.pFar0, live ? cpy + 2 * incy : S.pFar1, width);
-      cpx += incx;
-      cpy += incy;
-    }
-  }
-  int loopCounter = 0;
-  float best_match_x = -1;
-  float best_match_y = -1;
-  float best_match_err = INFINITY;
-  float second_best_match_err = INFINITY;
-  float best_match_errPre = NAN, best_match_errPost = NAN, best_match_DiffErrPre = NAN, best_match_DiffErrPost = NAN;
-  bool bestWasLastLoop = false;
-  float eeLast = -1;
-  float e1A = NAN, e1B = NAN, e2A = NAN, e2B = NAN, e3A = NAN, e3B = NAN, e4A = NAN, e4B = NAN, e5A = NAN, e5B = NAN;
-  int loopCBest = -1, loopCSecond = -1;
-#pragma unroll
-  for (int k = 0; k < OBS_SERIAL_MAX; k++) {
-    if (k < N) {
-      const float val_cp_m2 = s[k], val_cp_m1 = s[k + 1], val_cp = s[k + 2], val_cp_p1 = s[k + 3], val_cp_p2 = s[k + 4];
-      float ee = 0;
-      if (k % 2 == 0) {
-        e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
-        e2A = val_cp_p1 - realVal_p1; ee += e2A * e2A;
-        e3A = val_cp - realVal;       ee += e3A * e3A;
-        e4A = val_cp_m1 - realVal_m1; ee += e4A * e4A;
-        e5A = val_cp_m2 - realVal_m2; ee += e5A * e5A;
-      } else {
-        e1B = val_cp_p2 - realVal_p2; ee += e1B * e1B;
-        e2B = val_cp_p1 - realVal_p1; ee += e2B * e2B;
-        e3B = val_cp - realVal;       ee += e3B * e3B;
-        e4B = val_cp_m1 - realVal_m1; ee += e4B * e4B;
-        e5B = val_cp_m2 - realVal_m2; ee += e5B * e5B;
-      }
-      if (ee < best_match_err) {
-        second_best_match_err = best_match_err;
-        loopCSecond = loopCBest;
-        best_match_err = ee;
-        loopCBest = k;
-        best_match_errPre = eeLast;
-        best_match_DiffErrPre = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
-        best_match_errPost = -1;
-        best_match_DiffErrPost = -1;
-        best_match_x = px[k];
-        best_match_y = py[k];
-        bestWasLastLoop = true;
-      } else {
-        if (bestWasLastLoop) {
-          best_match_errPost = ee;
-          best_match_DiffErrPost = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
-          bestWasLastLoop = false;
-        }
-        if (ee < second_best_match_err) {
-          second_best_match_err = ee;
-          loopCSecond = k;
-        }
-      }
-      eeLast = ee;
-      loopCounter++;
-    }
-  }
-  W.best_match_err = best_match_err; W.second_best_match_err = second_best_match_err;
-  W.best_match_errPre = best_match_errPre; W.best_match_errPost = best_match_errPost;
-  W.best_match_DiffErrPre = best_match_DiffErrPre; W.best_match_DiffErrPost = best_match_DiffErrPost;
-  W.best_match_x = best_match_x; W.best_match_y = best_match_y;
-  W.loopCBest = loopCBest; W.loopCSecond = loopCSecond; W.loopCounter = loopCounter;
-}
-
 LSD_HD float stereo_finish(const ObserveArgs& a, const StereoRef& rf, const float u, const float v, const float epxn, const float epyn,
                            const StereoSetup& S, const WalkResult& W, float& result_idepth, float& result_var, float& result_eplLength) {
   float best_match_err = W.best_match_err, best_match_x = W.best_match_x, best_match_y = W.best_match_y;
@@ -492,18 +398,7 @@ LSD_HD float stereo_finish(const ObserveArgs& a, const StereoRef& rf, const floa
 
   float photoDispError = 4.0f * a.cameraPixelNoise2 / (gradAlongLine + DIVISION_EPS);
   float trackingErrorFac = 0.25f * (1.0f + rf.initialTrackedResidual);
-  // getInterpolatedElement42 on the keyframe gradients (globalFuncs.h:95-109)
-  float gI0, gI1;
-  {
-    int ix = (int)u;
-    int iy = (int)v;
-    float dx = u - ix;
-    float dy = v - iy;
-    float dxdy = dx * dy;
-    const float4 t00 = S.gt00, t10 = S.gt10, t01 = S.gt01, t11 = S.gt11;
-    gI0 = dxdy * t11.x + (dy - dxdy) * t01.x + (dx - dxdy) * t10.x + (1 - dx - dy + dxdy) * t00.x;
-    gI1 = dxdy * t11.y + (dy - dxdy) * t01.y + (dx - dxdy) * t10.y + (1 - dx - dy + dxdy) * t00.y;
-  }
+  const float gI0 = S.gI0, gI1 = S.gI1;
   float geoDispError = (gI0 * epxn + gI1 * epyn) + DIVISION_EPS;
   geoDispError = trackingErrorFac * trackingErrorFac * (gI0 * gI0 + gI1 * gI1) / (geoDispError * geoDispError);
   OBS_MARK(6);
@@ -521,11 +416,6 @@ LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, 
   const float st = stereo_setup(a, rf, u, v, epxn, epyn, min_idepth, prior_idepth, max_idepth, S);
   if (st < 0) return st;
   WalkResult W;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(LSD_PHASE_TRACE)
-  const int N = a.shortWalks ? stereo_walk_steps(S) : 1000;
-  if (N <= OBS_SERIAL_MAX) stereo_walk_short(rf.image, a.w, S, N, W);
-  else
-#endif
   stereo_walk_serial(rf.image, a.w, S, W);
   return stereo_finish(a, rf, u, v, epxn, epyn, S, W, result_idepth, result_var, result_eplLength);
 }
@@ -558,9 +448,8 @@ LSD_HD bool make_and_check_epl(const ObserveArgs& a, const StereoRef& rf, int x,
 //   observe_front: everything up to and including makeAndCheckEPL — the cheap rejections every pixel goes through; returns
 //                  true for the ~1 % of pixels that go on to the epipolar search, with the reference frame and EPL direction;
 //   observe_back : doLineStereo and observeDepthCreate / observeDepthUpdate's bookkeeping for such a pixel.
-// k_observe runs both in the same lane; k_observe_select queues the survivors of the front half and k_observe_walk runs the
-// back half over the dense queue, so that the search's long dependent chain no longer holds 63 idle lanes (and their wave
-// slots) hostage.  Same per-pixel arithmetic either way.
+// k_observe runs both in the same lane.  (A select kernel queueing the survivors + a walk kernel over the dense queue, and a form that
+// loads all samples of short walks up front, were built and measured in round 2: 37-52 us and 28 us against 21 us — removed.)
 template <bool ONE>
 LSD_HD bool observe_front(const ObserveArgs& a, const int x, const int y, int& refIdxOut, float& epxOut, float& epyOut) {
   if (x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3) return false;
@@ -713,164 +602,6 @@ __global__ __launch_bounds__(32 * ROWS) void k_observe(ObserveArgs a) {
   OBS_MARK(0);
   observe_pixel<ONE>(a, x, y);
   OBS_MARK(7);
-}
-
-// K4 in two launches.  Select: one pixel per lane, the front half; survivors are appended to one of OBS_NQ dense queues (one
-// atomic per wave on the queue's own counter — a single counter serialises ~2000 atomics, 23 us; the order inside a queue is
-// arbitrary, the per-pixel results do not depend on it).  Walk: one queued pixel per lane.
-#define OBS_NQ 64
-template <bool ONE, int ROWS>
-__global__ __launch_bounds__(32 * ROWS) void k_observe_select(ObserveArgs a) {
-  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int y = blockIdx.y * ROWS + (threadIdx.x >> 5);
-  int refIdx = 0;
-  float epx = 0, epy = 0;
-  const bool go = observe_front<ONE>(a, x, y, refIdx, epx, epy);
-  const unsigned long long bal = __ballot(go);
-  if (bal == 0) return;
-  const int lane = threadIdx.x & 63;
-  const int q = (blockIdx.y * gridDim.x + blockIdx.x) % OBS_NQ;
-  const int leader = __ffsll((long long)bal) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(a.qcount + q, __popcll(bal));
-  base = __builtin_amdgcn_readlane(base, leader);
-  if (go) {
-    const int p = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-    if (p < a.qcap) { WalkItem it; it.idx = x + y * a.w; it.refIdx = refIdx; it.epx = epx; it.epy = epy; a.queue[(size_t)q * a.qcap + p] = it; }
-  }
-}
-
-// The walk of ONE search evaluated by all 64 lanes (device only).  Every quantity of the reference's sequential loop has a
-// closed form in the per-step errors ee_k (tests: tools/ + the bit-exact depth tests, which run long walks through here):
-//   samples      s_-4 .. s_-1 = the four samples taken before the loop, s_k = the sample at cp_k + 2 inc   (cp_k by repeated addition)
-//   step k uses  (m2, m1, c, p1, p2) = (s_k-4 .. s_k),   ee_k = sum of the five squared differences in the loop's order
-//   best         = FIRST minimum of ee; second best = FIRST minimum over the other steps (the fold `if (ee < best) ... else if
-//                  (ee < second)` yields exactly these, ties included);
-//   errPre / DiffErrPre = ee_b-1 (-1 for b = 0) and sum e_i(b) e_i(b-1) (NaN for b = 0: the loop's B buffers still hold NaN);
-//   errPost / DiffErrPost = ee_b+1 and sum e_i(b+1) e_i(b) if step b+1 exists, else the -1 the loop leaves there.
-// Lane j takes sample j - 4; all values come back uniform.  One memory round trip instead of one per step.
-__device__ __forceinline__ float obs_rl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ void stereo_walk_wave(const float* __restrict__ refImg, const int width, const float cp0x, const float cp0y,
-                                                 const float incx, const float incy, const float real_m2, const float real_m1,
-                                                 const float real_c, const float real_p1, const float real_p2, const int N,
-                                                 float* s_s /*LDS, 72 floats*/, const int lane, WalkResult& W) {
-  const int jj = lane - 4;
-  float cx = cp0x, cy = cp0y;
-  for (int t = 0; t < N; t++) {
-    const bool adv = t < jj;
-    const float nx = cx + incx, ny = cy + incy;
-    cx = adv ? nx : cx;
-    cy = adv ? ny : cy;
-  }
-  float sx, sy;
-  if (jj == -4) { sx = cp0x - 2.0f * incx; sy = cp0y - 2.0f * incy; }
-  else if (jj == -3) { sx = cp0x - incx; sy = cp0y - incy; }
-  else if (jj == -2) { sx = cp0x; sy = cp0y; }
-  else if (jj == -1) { sx = cp0x + incx; sy = cp0y + incy; }
-  else { sx = cx + 2 * incx; sy = cy + 2 * incy; }
-  const bool live = lane < N + 4;
-  const float sv = interp1(refImg, live ? sx : cp0x, live ? sy : cp0y, width);
-  __builtin_amdgcn_wave_barrier();
-  s_s[lane] = sv;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int k = lane;                       // step index
-  const bool act = k < N;
-  const int kk = act ? k : 0;
-  const float s0 = s_s[kk], s1 = s_s[kk + 1], s2 = s_s[kk + 2], s3 = s_s[kk + 3], s4 = s_s[kk + 4];
-  const float sp = s_s[kk > 0 ? kk - 1 : 0];
-  const float e1 = s4 - real_p2, e2 = s3 - real_p1, e3 = s2 - real_c, e4 = s1 - real_m1, e5 = s0 - real_m2;
-  float ee = 0;
-  ee += e1 * e1; ee += e2 * e2; ee += e3 * e3; ee += e4 * e4; ee += e5 * e5;
-  // the previous step's residuals
-  const float q1 = s3 - real_p2, q2 = s2 - real_p1, q3 = s1 - real_c, q4 = s0 - real_m1, q5 = sp - real_m2;
-  float diff = e1 * q1 + e2 * q2 + e3 * q3 + e4 * q4 + e5 * q5;
-  if (k == 0) diff = NAN;
-  const float eeA = act ? ee : INFINITY;
-  float mn = eeA;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
-  const unsigned long long balb = __ballot(act && eeA == mn);
-  const int b = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)balb) - 1);
-  const float eeB = (act && k != b) ? ee : INFINITY;
-  float mn2 = eeB;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mn2 = fminf(mn2, __shfl_xor(mn2, o, 64));
-  const unsigned long long bals = __ballot(act && k != b && eeB == mn2);
-  const int sidx = __builtin_amdgcn_readfirstlane(bals ? (int)__ffsll((long long)bals) - 1 : -1);
-  W.best_match_err = mn;
-  W.second_best_match_err = sidx >= 0 ? mn2 : INFINITY;
-  W.loopCBest = b;
-  W.loopCSecond = sidx;
-  W.loopCounter = N;
-  W.best_match_errPre = b > 0 ? obs_rl(ee, b > 0 ? b - 1 : 0) : -1.0f;
-  W.best_match_DiffErrPre = obs_rl(diff, b);
-  const bool hasPost = b < N - 1;
-  W.best_match_errPost = hasPost ? obs_rl(ee, hasPost ? b + 1 : b) : -1.0f;
-  W.best_match_DiffErrPost = hasPost ? obs_rl(diff, hasPost ? b + 1 : b) : -1.0f;
-  W.best_match_x = obs_rl(cx, b + 4);
-  W.best_match_y = obs_rl(cy, b + 4);
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <bool ONE>
-__global__ __launch_bounds__(64) void k_observe_walk(ObserveArgs a) {
-  __shared__ float s_s[72];
-  const int lane = threadIdx.x;
-  const int q = blockIdx.x % OBS_NQ, sub = blockIdx.x / OBS_NQ, nsub = gridDim.x / OBS_NQ;
-  if (sub == 0 && lane == 0) a.qcount_next[q] = 0;
-  int n = a.qcount[q];
-  if (n > a.qcap) n = a.qcap;
-  const WalkItem* queue = a.queue + (size_t)q * a.qcap;
-  for (int base = sub * 64; base < n; base += nsub * 64) {
-    const int i = base + lane;
-    const bool has = i < n;
-    const WalkItem it = queue[has ? i : base];
-    const int idx = it.idx, x = idx % a.w, y = idx / a.w;
-    const StereoRef& rf = ONE ? a.one : a.refs[it.refIdx];
-    ObsPixel P;
-    observe_back_load(a, idx, P);
-    StereoSetup S;
-    float st = stereo_setup(a, rf, x, y, it.epx, it.epy, P.min_idepth, P.prior_idepth, P.max_idepth, S);
-    if (!has) st = -1;
-    const int N = st == 0 ? stereo_walk_steps(S) : 0;
-    const bool isLong = st == 0 && N > OBS_SERIAL_MAX && N <= 60;
-    WalkResult W;
-    // a cooperative walk costs the wave ~1.5 us each, a lane walking alone ~0.6 us per step: right after a keyframe change
-    // most searches are long (new pixels search the whole inverse-depth range) and are better walked side by side
-    unsigned long long todo = __ballot(isLong);
-    {
-      int mx = isLong ? N : 0;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-      if (__popcll(todo) * 5 > 2 * mx) todo = 0;
-    }
-    const bool coop = isLong && ((todo >> lane) & 1ull);
-    if (st == 0 && N <= OBS_SERIAL_MAX) stereo_walk_short(rf.image, a.w, S, N, W);
-    else if (st == 0 && !coop) stereo_walk_serial(rf.image, a.w, S, W);
-    while (todo) {
-      const int L = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const float* img;
-      if (ONE) img = a.one.image;
-      else {
-        const unsigned long long pv = (unsigned long long)rf.image;
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, L), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), L);
-        img = (const float*)(((unsigned long long)hi << 32) | lo);
-      }
-      WalkResult Wu;
-      stereo_walk_wave(img, a.w, obs_rl(S.pFar0, L), obs_rl(S.pFar1, L), obs_rl(S.incx, L), obs_rl(S.incy, L), obs_rl(S.realVal_m2, L),
-                       obs_rl(S.realVal_m1, L), obs_rl(S.realVal, L), obs_rl(S.realVal_p1, L), obs_rl(S.realVal_p2, L),
-                       __builtin_amdgcn_readlane(N, L), s_s, lane, Wu);
-      if (lane == L) W = Wu;
-    }
-    if (has) {
-      float result_idepth = 0, result_var = 0, result_eplLength = 0;
-      const float error = st < 0 ? st : stereo_finish(a, rf, x, y, it.epx, it.epy, S, W, result_idepth, result_var, result_eplLength);
-      observe_back_store(a, rf, idx, P, error, result_idepth, result_var, result_eplLength);
-    }
-  }
 }
 
 struct RegArgs {
@@ -1452,9 +1183,7 @@ static int depth_create_impl(lsdhip_ctx* c, lsdhip_depthmap* dm) {
   HIPCHK(hipMalloc((void**)&dm->d_slots, n * 4 * PROP_SLOT_CAP));
   HIPCHK(hipMalloc((void**)&dm->d_ovfHead, n * 4));
   HIPCHK(hipMalloc((void**)&dm->d_ovf, n * sizeof(int2)));
-  HIPCHK(hipMalloc((void**)&dm->d_cand, (n + 64 * OBS_NQ) * 16));   // also the walk queues of k_observe_select (OBS_NQ x qcap items)
-  HIPCHK(hipMalloc((void**)&dm->d_qcount, 2 * OBS_NQ * sizeof(int)));
-  HIPCHK(hipMemsetAsync(dm->d_qcount, 0, 2 * OBS_NQ * sizeof(int), c->stream));
+  HIPCHK(hipMalloc((void**)&dm->d_cand, n * 16));
   HIPCHK(hipMalloc((void**)&dm->d_flags, 64));
   HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, c->stream));
   int nb = (int)((n + 255) / 256);
@@ -1495,7 +1224,6 @@ extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
   (void)hipFree(dm->d_ovfHead);
   (void)hipFree(dm->d_ovf);
   (void)hipFree(dm->d_cand);
-  (void)hipFree(dm->d_qcount);
   (void)hipFree(dm->d_flags);
   (void)hipFree(dm->d_red);
   (void)hipHostFree(dm->h_red);
@@ -1723,8 +1451,6 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   a.useSubpixelStereo = c->params.useSubpixelStereo;
   a.kfNumFramesTrackedOnThis = kf->numFramesTrackedOnThis;
   a.kfNumMappedOnThis = kf->numMappedOnThis;
-  a.queue = nullptr; a.qcount = a.qcount_next = nullptr; a.qcap = 0;
-  { static const bool sw = [] { const char* e = getenv("LSDHIP_OBS_SHORT"); return e && e[0] == '1'; }(); a.shortWalks = sw ? 1 : 0; }   // opt-in: +3 us per launch in the fused kernel (more VGPRs)
 #ifdef LSD_PHASE_TRACE
   {
     const size_t words = (size_t)((c->w + 31) / 32) * ((c->h + 7) / 8) * 16;
@@ -1741,30 +1467,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
     static const int rows = [] { const char* e = getenv("LSDHIP_OBS_ROWS"); int r = e ? atoi(e) : 2; return (r == 8 || r == 4) ? r : 2; }();   // 64-thread workgroups measured best (+2.5 % Mpixel/s over 256)
 #endif
     const dim3 grid((c->w + 31) / 32, (c->h + rows - 1) / rows);
-    static const bool split = [] { const char* e = getenv("LSDHIP_OBS_SPLIT"); return e && e[0] == '1'; }();   // opt-in: measured slower than the fused kernel (profiles/r02_notes.md)
-#ifdef LSD_PHASE_TRACE
-    const bool useSplit = false;
-#else
-    const bool useSplit = split;
-#endif
-    if (useSplit) {
-      // select + walk: the queue borrows the propagation candidate buffer (16 B per map pixel = one item per pixel at most);
-      // two counters alternate so that the walk kernel can clear the next call's counter instead of a memset per call
-      a.queue = (WalkItem*)dm->d_cand;
-      const int selWG = ((c->w + 31) / 32) * ((c->h + 1) / 2);
-      a.qcap = ((selWG + OBS_NQ - 1) / OBS_NQ) * 64;      // a queue's workgroups cannot produce more
-      a.qcount = dm->d_qcount + OBS_NQ * dm->obs_parity;
-      a.qcount_next = dm->d_qcount + OBS_NQ * (1 - dm->obs_parity);
-      dm->obs_parity ^= 1;
-      const int wgrid = OBS_NQ * ((a.qcap + 63) / 64);   // a lane per possible item; workgroups past their queue's count exit at once
-      if (n == 1) {
-        hipLaunchKernelGGL((k_observe_select<true, 2>), dim3((c->w + 31) / 32, (c->h + 1) / 2), dim3(64), 0, c->stream, a);
-        hipLaunchKernelGGL((k_observe_walk<true>), dim3(wgrid), dim3(64), 0, c->stream, a);
-      } else {
-        hipLaunchKernelGGL((k_observe_select<false, 2>), dim3((c->w + 31) / 32, (c->h + 1) / 2), dim3(64), 0, c->stream, a);
-        hipLaunchKernelGGL((k_observe_walk<false>), dim3(wgrid), dim3(64), 0, c->stream, a);
-      }
-    } else if (rows == 8) {
+    if (rows == 8) {
       if (n == 1) hipLaunchKernelGGL((k_observe<true, 8>), grid, dim3(256), 0, c->stream, a);
       else hipLaunchKernelGGL((k_observe<false, 8>), grid, dim3(256), 0, c->stream, a);
     } else if (rows == 4) {

@@ -377,11 +377,6 @@ extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], con
     if (l == 0) { memcpy(c->K0, Kl, sizeof(Kl)); memcpy(c->K0inv, Ki, sizeof(Ki)); }
   }
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  if (const char* e = getenv("LSDHIP_PREFETCH_STREAM")) c->prefetchOn = e[0] == '1';
-  if (c->prefetchOn) {
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->evPrefetchDone, hipEventDisableTiming));
-  }
   HIPCHK(hipEventCreate(&c->ev_a));
   HIPCHK(hipEventCreate(&c->ev_b));
   HIPCHK(hipHostMalloc((void**)&c->h_slots, LSD_NUM_SLOTS * sizeof(DeferredSlot), hipHostMallocMapped));
@@ -393,9 +388,7 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (auto& a : c->free_arenas) { (void)hipFree(a.base); if (a.freed) (void)hipEventDestroy(a.freed); }
-  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-  if (c->evPrefetchDone) (void)hipEventDestroy(c->evPrefetchDone);
+  for (void* a : c->free_arenas) (void)hipFree(a);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->h_slots) (void)hipHostFree(c->h_slots);
   if (c->d_gtStage) (void)hipFree(c->d_gtStage);
@@ -530,8 +523,7 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   char* base = nullptr;
   c->arena_bytes = align_up(off, 256);
   if (!c->free_arenas.empty()) {
-    base = (char*)c->free_arenas.back().base;
-    f->arenaFreed = c->free_arenas.back().freed;
+    base = (char*)c->free_arenas.back();
     c->free_arenas.pop_back();
   } else {
     hipError_t e = hipMalloc((void**)&base, c->arena_bytes);
@@ -607,22 +599,6 @@ extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
   // the pyramid kernel reads the caller's device image directly (stream-ordered; nothing else needs the uint8 plane)
-  if (c->prefetchOn && c->inHook) {
-    // called from the tracker's enqueue hook: the main stream is busy with the tracking chain; build on the prefetch stream
-    // (after the arena's last user on the main stream), and make the main stream wait for the result before whatever is
-    // enqueued next — by then it is long done
-    hipError_t e = hipSuccess;
-    if (f->arenaFreed) e = hipStreamWaitEvent(c->stream2, f->arenaFreed, 0);
-    if (e == hipSuccess) {
-      rc = lsd_frame_build_pyramids(f, gray_dev, c->stream2);
-      if (rc) { lsdhip_frame_destroy(f); return rc; }
-      e = hipEventRecord(c->evPrefetchDone, c->stream2);
-    }
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->evPrefetchDone, 0);
-    if (e != hipSuccess) { lsd_set_error("prefetch stream: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
-    *out = f;
-    return LSDHIP_OK;
-  }
   rc = lsd_frame_build_pyramids(f, gray_dev, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
   *out = f;
@@ -649,18 +625,11 @@ extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
   if (c->free_arenas.size() < 16) {
-    // arena base; reuse on the main stream is ordered by the stream itself, reuse from the prefetch stream waits for this event
-    if (c->prefetchOn) {
-      (void)hipSetDevice(c->device);
-      if (!f->arenaFreed) (void)hipEventCreateWithFlags(&f->arenaFreed, hipEventDisableTiming);
-      if (f->arenaFreed) (void)hipEventRecord(f->arenaFreed, c->stream);
-    }
-    c->free_arenas.push_back({f->d_gray, f->arenaFreed});
+    c->free_arenas.push_back(f->d_gray);   // arena base; reuse is ordered by the stream itself
   } else {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(f->d_gray);
-    if (f->arenaFreed) (void)hipEventDestroy(f->arenaFreed);
   }
   if (f->pendStats >= 0) c->slot_stats_owner[f->pendStats] = nullptr;
   if (f->pendRescale >= 0) c->slot_rescale_owner[f->pendRescale] = nullptr;

@@ -169,21 +169,13 @@ struct lsdhip_ctx {
   std::vector<hipEvent_t> prof_events;   // per-launch event pairs for the device-resident LM loop
   // recycled frame arenas (the FrameMemory idea, C/DataStructures/FrameMemory.cpp:67-127, for device buffers);
   // reuse is stream-ordered, so no synchronisation is needed when a frame dies
-  struct ArenaSlot { void* base; hipEvent_t freed; };   // freed: position of the main stream when the arena was given back
-  std::vector<ArenaSlot> free_arenas;
-  // Prefetch stream (LSDHIP_PREFETCH_STREAM=1): a frame created from a device image inside the tracker's enqueue hook builds
-  // its pyramids on stream2, concurrently with the tracking chain the main stream is executing; stream2 first waits for the
-  // arena's `freed` event, and the main stream waits for `evPrefetchDone` before anything enqueued after the hook.
-  hipStream_t stream2 = nullptr;
-  hipEvent_t evPrefetchDone = nullptr;
-  bool prefetchOn = false, inHook = false;
+  std::vector<void*> free_arenas;
   float* d_gtStage = nullptr;                        // w x h floats: staging of lsdhip_frame_set_depth_gt
   std::vector<struct lsdhip_depthmap*> depthmaps;   // alive on this context: a destroyed frame is unhooked from them
   size_t arena_bytes = 0;
 };
 
 struct lsdhip_frame {
-  hipEvent_t arenaFreed = nullptr;   // travels with the arena (lsdhip_ctx::ArenaSlot)
   lsdhip_ctx* ctx = nullptr;
   int id = 0;
   uint8_t* d_gray = nullptr;            // level-0 source (uint8)
@@ -336,8 +328,6 @@ struct lsdhip_depthmap {
   double gpu_ms[4] = {0, 0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame, k_observe alone (sampled while profiling)
   long long gpu_calls[4] = {0, 0, 0, 0};
   unsigned obs_tick = 0;
-  int* d_qcount = nullptr;         // [2][OBS_NQ] walk-queue counters
-  int obs_parity = 0;              // which of the two walk-queue counters the next observe call uses
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
         msSetDepth = 0;
 };

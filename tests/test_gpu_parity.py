@@ -884,35 +884,6 @@ def test_tracker_settings_block_reaches_the_device(oracle, hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["split", "short"])
-def test_observe_alternative_execution_forms_bit_exact(oracle, hip, mode, monkeypatch):
-    """K4's other execution forms — LSDHIP_OBS_SPLIT=1: select + walk kernels (survivors of the cheap rejections queued, long
-    epipolar walks evaluated by a whole wave in closed form, short ones with all samples loaded up front); LSDHIP_OBS_SHORT=1: the
-    fused kernel with up-front samples — give the reference's per-pixel results bit for bit, like the default form."""
-    import subprocess, sys, os
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import test_gpu_parity as T, lsd_slam_amd as hip\n"
-        "from oracle import pyoracle as oracle\n"
-        "oracle.build()\n"
-        "w, h = 320, 240\n"
-        "frames, depth0, K, gt, ctx = T.make_pair(oracle, hip, w, h, 8)\n"
-        "kfo, kfg, dmo, dmg = T._noisy_map(oracle, hip, ctx, frames, depth0, K, w, h)\n"
-        "kfo.set_counters(7, 3, 3, 0); kfg.setCounters(7, 3, 3, 0)\n"
-        "fos, fgs = T._ref_frames(oracle, hip, ctx, frames, K, gt, kfo, kfg, [3, 4, 6, 7])\n"
-        "dmo.stage('observe', fos); dmg.stage('observe', fgs)\n"
-        "T.assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), 'observe')\n"
-        "dmo.stage('fillholes'); dmg.stage('fillholes'); dmo.stage('regularize'); dmg.stage('regularize')\n"
-        "dmo.stage('observe', fos[:1]); dmg.stage('observe', fgs[:1])\n"
-        "T.assert_hyp_equal(dmg.currentDepthMap(), dmo.get(), 'observe single reference')\n"
-        "print('ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ)
-    env["LSDHIP_OBS_SPLIT" if mode == "split" else "LSDHIP_OBS_SHORT"] = "1"
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("trials,coarse,params", [(2, 1, {}), (5, 1, {}), (6, 1, {}), (6, 1, {"useAffineLightningEstimation": 0}),
                                                   (2, 0, {}), (5, 0, {}), (6, 0, {})])
 def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip, trials, coarse, params):

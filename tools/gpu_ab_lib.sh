@@ -12,8 +12,8 @@ for rep in 1 2; do
 import json
 try:
     d = json.load(open("gpurun_out/abl_${which}_$rep.json"))
-    print("${which} #$rep: %.0f frames/s, %.4f ms/step, launches/frame %.2f, evals %.2f, us per chain launch %.2f, ok %s" % (
-        d["value"], d["ms_per_step"], d["track_launches_per_frame"], d["lm_evaluations_per_frame"], d["roofline"]["avg_launch_us"], d["validation"]["ok"]))
+    print("${which} #$rep: %.0f frames/s, %.4f ms/step, launches/frame %.2f, evals %.2f, us per chain launch %.2f, depth %.0f Mpx/s, observe %.1f us, ok %s" % (
+        d["value"], d["ms_per_step"], d["track_launches_per_frame"], d["lm_evaluations_per_frame"], d["roofline"]["avg_launch_us"], d["depth_mpix_per_s"], d["roofline_depth"]["avg_launch_us"], d["validation"]["ok"]))
 except Exception as e:
     print("${which} #$rep: FAILED", e); print(open("gpurun_out/abl_${which}_$rep.err").read()[-1500:])
 PY
