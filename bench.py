@@ -313,9 +313,11 @@ def main():
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra host-image (PCIe-inclusive) measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work, gloo when there is no GPU): prints the JSON skeleton")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=0,
                     help="the timed region of exactly --steps steps is run this many times back to back (each between barriers); `value` and "
-                         "`ms_per_step` are those of the MEDIAN region, so one 5 ms window does not decide the line")
+                         "`ms_per_step` are those of the MEDIAN region, so one 5 ms window does not decide the line.  0 = automatic: at least 5 "
+                         "regions and at least ~1000 frames in total (the loop shows ~15 %% slower phases lasting tens of milliseconds on some "
+                         "boxes: profiles/r03_notes.md)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the two short extra legs (BASELINE.json configs[2] and configs[4])")
     ap.add_argument("--seq-frames", type=int, default=50,
                     help="synthetic frames to render (one camera revolution = 50); fewer are played back and forth")
@@ -474,9 +476,11 @@ def main():
     if distributed:
         dist.barrier()
     clock = time.perf_counter
-    repeats = max(1, args.repeats)
+    repeats = args.repeats if args.repeats > 0 else max(5, -(-1000 // max(1, args.steps)))
     elapsed_all = []
+    region_wall = []
     for rep_i in range(repeats):
+        region_wall.append(time.time())
         # every region: barrier + synchronize, exactly K steps, synchronize + barrier; max over ranks
         t0 = clock()
         run_frames(args.steps)
@@ -520,6 +524,7 @@ def main():
             "metric": "tracked frames/sec (full track+map loop) at %dx%d" % (w, h), "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "repeats": repeats, "ms_per_step_all_regions": [e / args.steps * 1e3 for e in elapsed_all],
+            "region_start_unix_s": region_wall,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d 5-level-pyramid SE3 tracking + semi-dense depth update, single sequence per GPU "
                                    "(BASELINE.json configs[%d]); synthetic scene %s, GT-depth init, new keyframe every %d frames"
