@@ -310,6 +310,17 @@ int lsdhip_ctx_copy_dev(lsdhip_ctx* ctx, void* dst_dev, const void* src_dev, siz
 /* device buffers on the context's device for callers that do not link the HIP runtime themselves (the C++ drivers: staging
  * of halo rows, keyframe rings); free waits for the context's stream */
 int lsdhip_ctx_alloc_dev(lsdhip_ctx* ctx, size_t bytes, void** out_dev);
+/* Inter-process exchange on one node without RCCL (the driver library's second transport; no reference counterpart): a device
+ * allocation is exported as a 64-byte hipIpcMemHandle_t and mapped by the peer process; flags are ints inside such an allocation
+ * whose values only grow.  _flag_set / _flag_wait are stream-ordered: set publishes what the stream did before it (system scope),
+ * wait holds the stream until the flag has reached `value` (bounded spin, ~2 s: *fail_dev = value on a time-out). */
+int lsdhip_ctx_ipc_export(lsdhip_ctx* ctx, void* dev, unsigned char handle64[64]);
+int lsdhip_ctx_ipc_open(lsdhip_ctx* ctx, const unsigned char handle64[64], void** out_dev);
+int lsdhip_ctx_ipc_close(lsdhip_ctx* ctx, void* dev);
+int lsdhip_ctx_flag_set(lsdhip_ctx* ctx, int* flag_dev, int value);
+int lsdhip_ctx_flag_wait(lsdhip_ctx* ctx, const int* flag_dev, int value, int* fail_dev);
+int lsdhip_ctx_memset_dev(lsdhip_ctx* ctx, void* dev, int byte, size_t bytes);
+int lsdhip_ctx_read_dev(lsdhip_ctx* ctx, void* host, const void* dev, size_t bytes);   /* synchronises the stream */
 int lsdhip_ctx_free_dev(lsdhip_ctx* ctx, void* dev);
 /* (returns after the copies have finished; on an asynchronous context — lsdhip_ctx_set_async — after they are queued) */
 /* rows [row0, row0+nrows) of the eight hypothesis planes <-> one packed device buffer (29 bytes per pixel, plane after

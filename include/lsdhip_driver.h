@@ -91,6 +91,16 @@ int lsdband_synchronize(lsdband* b);
 long long lsdband_halo_bytes_per_pass(const lsdband* b);
 /* test hook: windows of this process also exchange through the packed path (pack launch, device copy in place of
  * ncclSend / ncclRecv, unpack launch) — RCCL refuses two ranks on one GPU, so this is how a one-GPU box exercises it */
+/* Second transport between the processes of one node, without RCCL (which refuses two ranks on one device): every process exports
+ * one IPC "mailbox" allocation (flags + two packed receive buffers per incoming remote segment) and maps the others'; a sender packs
+ * its halo rows straight into the receiver's buffer and raises the segment's `ready` flag, the receiver unpacks and raises `consumed`.
+ * Same pack -> transfer -> unpack schedule per pass as the RCCL path, all of it queued on the context's stream.
+ *   lsdband_ipc_init: band ownership as lsdband_comm_init; writes this process's 64-byte handle;
+ *   lsdband_ipc_connect: the handles of all processes (nprocs x 64 bytes, process order);
+ *   lsdband_ipc_failed (after lsdband_synchronize): 0, or the flag value a bounded wait gave up on. */
+int lsdband_ipc_init(lsdband* b, int nprocs, int proc, const int* proc_of_band, unsigned char handle64_out[64]);
+int lsdband_ipc_connect(lsdband* b, const unsigned char* handles);
+int lsdband_ipc_failed(lsdband* b);
 int lsdband_set_packed_exchange(lsdband* b, int on);
 
 #ifdef __cplusplus

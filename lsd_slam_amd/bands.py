@@ -213,6 +213,24 @@ class NativeBandRegularizer:
         uid = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         self._check(self.L.lsdband_comm_init(self.h_, uid, nprocs, proc, arr))
 
+    def ipc_init(self, nprocs, proc, proc_of_band):
+        """second transport (processes of one node, IPC-mapped mailboxes, no RCCL): returns this process's 64-byte handle"""
+        C = self.C
+        arr = (C.c_int * self.world)(*proc_of_band)
+        out = (C.c_ubyte * 64)()
+        self._check(self.L.lsdband_ipc_init(self.h_, int(nprocs), int(proc), arr, out))
+        return bytes(out)
+
+    def ipc_connect(self, handles):
+        """handles: the 64-byte handles of all processes in process order"""
+        C = self.C
+        blob = b"".join(handles)
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        self._check(self.L.lsdband_ipc_connect(self.h_, buf))
+
+    def ipc_failed(self):
+        return int(self.L.lsdband_ipc_failed(self.h_))
+
     def load(self, hyp_full, maxgrad_full):
         from .capi import HYP_DTYPE
         for i, r in enumerate(self.ranks):

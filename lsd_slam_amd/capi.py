@@ -99,6 +99,13 @@ def _signatures():
         "lsdhip_tracker_set_coarse": (i, [vp, i, i]),
         "lsdhip_depth_copy_rows_batch": (i, [vp, i, vp]),
         "lsdhip_ctx_alloc_dev": (i, [vp, C.c_size_t, vp]),
+        "lsdhip_ctx_ipc_export": (i, [vp, vp, vp]),
+        "lsdhip_ctx_ipc_open": (i, [vp, vp, vp]),
+        "lsdhip_ctx_ipc_close": (i, [vp, vp]),
+        "lsdhip_ctx_flag_set": (i, [vp, vp, i]),
+        "lsdhip_ctx_flag_wait": (i, [vp, vp, i, vp]),
+        "lsdhip_ctx_memset_dev": (i, [vp, vp, i, C.c_size_t]),
+        "lsdhip_ctx_read_dev": (i, [vp, vp, vp, C.c_size_t]),
         "lsdhip_ctx_free_dev": (i, [vp, vp]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),

@@ -432,6 +432,79 @@ extern "C" int lsdhip_ctx_copy_dev(lsdhip_ctx* c, void* dst, const void* src, si
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
   return LSDHIP_OK;
 }
+// ---- inter-process exchange on one node without RCCL (lsdhip_driver's second transport): IPC-mapped device memory + flags ---------
+// A flag is an int in device memory that both processes map; values only grow.  Both operations are stream-ordered one-lane kernels:
+// set publishes everything the stream did before it (system-scope release), wait spins — bounded — until the flag has reached the
+// value and raises *fail otherwise.
+__global__ void k_flag_set(int* flag, int value) {
+  __threadfence_system();
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_flag_wait(const int* flag, int value, int* fail) {
+  for (unsigned spins = 0; spins < (1u << 24); spins++) {          // ~2 s
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= value) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *fail = value;
+}
+extern "C" int lsdhip_ctx_ipc_export(lsdhip_ctx* c, void* dev, unsigned char handle64[64]) {
+  if (!c || !dev || !handle64) return LSDHIP_E_ARG;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  hipIpcMemHandle_t h;
+  HIPCHK(hipIpcGetMemHandle(&h, dev));
+  memcpy(handle64, &h, 64);
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_ipc_open(lsdhip_ctx* c, const unsigned char handle64[64], void** out_dev) {
+  if (!c || !handle64 || !out_dev) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  HIPCHK(hipIpcOpenMemHandle(out_dev, h, hipIpcMemLazyEnablePeerAccess));
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_ipc_close(lsdhip_ctx* c, void* dev) {
+  if (!c || !dev) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipIpcCloseMemHandle(dev));
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_flag_set(lsdhip_ctx* c, int* flag_dev, int value) {
+  if (!c || !flag_dev) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, c->stream, flag_dev, value);
+  HIPCHK(hipGetLastError());
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_flag_wait(lsdhip_ctx* c, const int* flag_dev, int value, int* fail_dev) {
+  if (!c || !flag_dev || !fail_dev) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, c->stream, flag_dev, value, fail_dev);
+  HIPCHK(hipGetLastError());
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_memset_dev(lsdhip_ctx* c, void* dev, int byte, size_t bytes) {
+  if (!c || !dev) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemsetAsync(dev, byte, bytes, c->stream));
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_read_dev(lsdhip_ctx* c, void* host, const void* dev, size_t bytes) {
+  if (!c || !host || !dev) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_ctx_set_async(lsdhip_ctx* c, int on) {
   if (!c) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);

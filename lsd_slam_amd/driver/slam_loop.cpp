@@ -304,6 +304,34 @@ struct lsdband {
   std::vector<char*> sendbuf, recvbuf;   // one packed device buffer per remote segment
   long long passes_run = 0;
   bool packedLocal = false;              // test hook: windows of this process exchange through pack -> copy -> unpack as well
+  // Second transport between PROCESSES of one node (lsdband_ipc_*): every process exports one "mailbox" allocation — flags and,
+  // twice (two exchange parities), the packed receive buffer of each of its incoming remote segments — and maps the others'.
+  // A sender packs its rows STRAIGHT INTO the receiver's buffer and raises the segment's `ready` flag; the receiver unpacks
+  // and raises `consumed`, which gates the next reuse of that parity.  Same pack -> transfer -> unpack schedule as the RCCL path.
+  bool ipc = false;
+  char* mailbox = nullptr;
+  std::vector<char*> peerMailbox;        // by process; own entry = mailbox
+  long long exchanges = 0;               // exchange ordinal since lsdband_ipc_connect
+  struct IpcSeg { int r, peer, row0, nrows; size_t bytes, off[2]; int flag; };   // flag: index of (ready, consumed) in the flag block
+  // incoming remote segments of process q in canonical order (both ends compute the same layout)
+  std::vector<IpcSeg> ipc_layout(int q, size_t* total = nullptr) const {
+    std::vector<IpcSeg> out;
+    size_t off = 4096;                   // flag block: fail word + (ready, consumed) per segment
+    int k = 0;
+    for (int r = 0; r < world; r++) {
+      if (proc_of[r] != q) continue;
+      for (const BandSeg& sg : recv_list(r)) {
+        if (proc_of[sg.peer] == q) continue;
+        IpcSeg e{r, sg.peer, sg.row0, sg.nrows, (size_t)sg.nrows * w * BAND_PACK_BYTES, {0, 0}, k++};
+        e.bytes = (e.bytes + 255) & ~(size_t)255;
+        e.off[0] = off; off += e.bytes;
+        e.off[1] = off; off += e.bytes;
+        out.push_back(e);
+      }
+    }
+    if (total) *total = off;
+    return out;
+  }
   std::vector<BandSeg> recv_list(int r) const {
     std::vector<BandSeg> out;
     const int a = window[r].first, b = window[r].second;
@@ -383,6 +411,9 @@ extern "C" void lsdband_destroy(lsdband* b) {
   if (!b) return;
   if (b->ctx) (void)lsdhip_ctx_synchronize(b->ctx);
   if (b->comm && rccl().ok) (void)rccl().CommDestroy(b->comm);
+  for (int q = 0; q < (int)b->peerMailbox.size(); q++)
+    if (b->peerMailbox[q] && b->peerMailbox[q] != b->mailbox) (void)lsdhip_ctx_ipc_close(b->ctx, b->peerMailbox[q]);
+  if (b->mailbox) (void)lsdhip_ctx_free_dev(b->ctx, b->mailbox);
   for (char* p : b->sendbuf) if (p) (void)lsdhip_ctx_free_dev(b->ctx, p);
   for (char* p : b->recvbuf) if (p) (void)lsdhip_ctx_free_dev(b->ctx, p);
   for (auto* d : b->dm) lsdhip_depth_destroy(d);
@@ -428,6 +459,47 @@ extern "C" int lsdband_comm_init(lsdband* b, const void* unique_id128, int nproc
   int rc = R.CommInitRank(&b->comm, nprocs, id, proc);
   if (rc != 0) { g_err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(rc) : "?"); return LSDHIP_E_HIP; }
   return LSDHIP_OK;
+}
+// IPC transport, step 1: band ownership as in lsdband_comm_init; allocates this process's mailbox and exports it (64 bytes)
+extern "C" int lsdband_ipc_init(lsdband* b, int nprocs, int proc, const int* proc_of_band, unsigned char handle64_out[64]) {
+  if (!b || nprocs < 2 || proc < 0 || proc >= nprocs || !proc_of_band || !handle64_out) return LSDHIP_E_ARG;
+  for (int r = 0; r < b->world; r++) {
+    b->proc_of[r] = proc_of_band[r];
+    if ((proc_of_band[r] == proc) != b->local(r)) { g_err = "lsdband_ipc_init: band ownership does not match lsdband_create"; return LSDHIP_E_ARG; }
+  }
+  b->nprocs = nprocs; b->proc = proc;
+  size_t total = 0;
+  (void)b->ipc_layout(proc, &total);
+  try {
+    check(lsdhip_ctx_alloc_dev(b->ctx, total, (void**)&b->mailbox), "lsdhip_ctx_alloc_dev");
+    check(lsdhip_ctx_memset_dev(b->ctx, b->mailbox, 0, total), "lsdhip_ctx_memset_dev");
+    check(lsdhip_ctx_synchronize(b->ctx), "lsdhip_ctx_synchronize");
+    check(lsdhip_ctx_ipc_export(b->ctx, b->mailbox, handle64_out), "lsdhip_ctx_ipc_export");
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+  return LSDHIP_OK;
+}
+// step 2: the mailboxes of all processes (nprocs x 64 bytes, in process order; the own entry is ignored)
+extern "C" int lsdband_ipc_connect(lsdband* b, const unsigned char* handles) {
+  if (!b || !handles || !b->mailbox) return LSDHIP_E_ARG;
+  try {
+    b->peerMailbox.assign(b->nprocs, nullptr);
+    for (int q = 0; q < b->nprocs; q++) {
+      if (q == b->proc) { b->peerMailbox[q] = b->mailbox; continue; }
+      void* p = nullptr;
+      check(lsdhip_ctx_ipc_open(b->ctx, handles + 64 * (size_t)q, &p), "lsdhip_ctx_ipc_open");
+      b->peerMailbox[q] = (char*)p;
+    }
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+  b->ipc = true;
+  b->exchanges = 0;
+  return LSDHIP_OK;
+}
+// after lsdband_synchronize: 0 if every flag wait of this process was satisfied, else the flag value a wait gave up on
+extern "C" int lsdband_ipc_failed(lsdband* b) {
+  if (!b || !b->mailbox) return LSDHIP_E_ARG;
+  int v = 0;
+  if (lsdhip_ctx_read_dev(b->ctx, &v, b->mailbox, sizeof(int)) != LSDHIP_OK) { g_err = lsdhip_last_error(); return LSDHIP_E_HIP; }
+  return v;
 }
 extern "C" int lsdband_set_packed_exchange(lsdband* b, int on) {
   if (!b) return LSDHIP_E_ARG;
@@ -478,6 +550,8 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
           c.dst_map = b->dm[r - b->first]; c.dst_row0 = s.row0 - b->window[r].first;
           c.nrows = s.nrows;
           localCopies.push_back(c);
+        } else if (b->ipc) {
+          // remote segment on the IPC transport: planned below from the mailbox layouts
         } else if (srcLocal) {                             // we own the rows: pack + send to r's process
           if (b->sendbuf.size() <= si) b->sendbuf.push_back(nullptr);
           if (!b->sendbuf[si]) check(lsdhip_ctx_alloc_dev(b->ctx, bytes, (void**)&b->sendbuf[si]), "lsdhip_ctx_alloc_dev");
@@ -499,7 +573,22 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
         }
       }
     }
-    if ((!sends.empty() || !recvs.empty()) && !b->comm) throw Error(LSDHIP_E_STATE, "lsdband_run: bands of other processes but no communicator (lsdband_comm_init)");
+    if ((!sends.empty() || !recvs.empty()) && !b->comm && !b->ipc)
+      throw Error(LSDHIP_E_STATE, "lsdband_run: bands of other processes but no communicator (lsdband_comm_init / lsdband_ipc_connect)");
+    // IPC transport: the remote segments of this process, outgoing (rows we own, needed by a band of process q: a slot of q's
+    // mailbox) and incoming (our own mailbox)
+    struct IpcOut { int q; lsdband::IpcSeg seg; };
+    std::vector<IpcOut> ipcOut;
+    std::vector<lsdband::IpcSeg> ipcIn;
+    if (b->ipc) {
+      ipcIn = b->ipc_layout(b->proc);
+      for (int q = 0; q < b->nprocs; q++) {
+        if (q == b->proc) continue;
+        for (const lsdband::IpcSeg& e : b->ipc_layout(q))
+          if (b->local(e.peer)) ipcOut.push_back({q, e});
+      }
+    }
+    auto flagPtr = [](char* box, int k, int which) { return (int*)(box + 64 + (size_t)k * 8 + (size_t)which * 4); };   // (ready, consumed) pairs behind the fail word
     for (int p = 0; p < passes; p++) {
       for (int i = 0; i < b->nlocal; i++) check(lsdhip_depth_stage(b->dm[i], 5, nullptr, 0), "lsdhip_depth_stage");
       b->passes_run++;
@@ -511,7 +600,31 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
       for (const Wire& l : loop) check(lsdhip_ctx_copy_dev(b->ctx, l.buf2, l.buf, l.bytes), "lsdhip_ctx_copy_dev");
       if (!loop.empty() && sends.empty() && recvs.empty())
         check(lsdhip_depth_copy_rows_batch(b->ctx, (int)unpacks.size(), unpacks.data()), "lsdhip_depth_copy_rows_batch");
-      if (!sends.empty() || !recvs.empty()) {
+      if (b->ipc) {
+        const long long x = b->exchanges;
+        const int par = (int)(x & 1);
+        std::vector<lsdhip_row_copy> ipack, iunpack;
+        for (const IpcOut& o : ipcOut) {
+          char* box = b->peerMailbox[o.q];
+          if (x >= 2) check(lsdhip_ctx_flag_wait(b->ctx, flagPtr(box, o.seg.flag, 1), (int)(x - 1), (int*)b->mailbox), "lsdhip_ctx_flag_wait");
+          lsdhip_row_copy c{};
+          c.src_map = b->dm[o.seg.peer - b->first]; c.src_row0 = o.seg.row0 - b->window[o.seg.peer].first;
+          c.dst_packed = box + o.seg.off[par]; c.nrows = o.seg.nrows;
+          ipack.push_back(c);
+        }
+        if (!ipack.empty()) check(lsdhip_depth_copy_rows_batch(b->ctx, (int)ipack.size(), ipack.data()), "lsdhip_depth_copy_rows_batch");
+        for (const IpcOut& o : ipcOut) check(lsdhip_ctx_flag_set(b->ctx, flagPtr(b->peerMailbox[o.q], o.seg.flag, 0), (int)(x + 1)), "lsdhip_ctx_flag_set");
+        for (const lsdband::IpcSeg& e : ipcIn) {
+          check(lsdhip_ctx_flag_wait(b->ctx, flagPtr(b->mailbox, e.flag, 0), (int)(x + 1), (int*)b->mailbox), "lsdhip_ctx_flag_wait");
+          lsdhip_row_copy u{};
+          u.src_packed = b->mailbox + e.off[par];
+          u.dst_map = b->dm[e.r - b->first]; u.dst_row0 = e.row0 - b->window[e.r].first; u.nrows = e.nrows;
+          iunpack.push_back(u);
+        }
+        if (!iunpack.empty()) check(lsdhip_depth_copy_rows_batch(b->ctx, (int)iunpack.size(), iunpack.data()), "lsdhip_depth_copy_rows_batch");
+        for (const lsdband::IpcSeg& e : ipcIn) check(lsdhip_ctx_flag_set(b->ctx, flagPtr(b->mailbox, e.flag, 1), (int)(x + 1)), "lsdhip_ctx_flag_set");
+        b->exchanges++;
+      } else if (!sends.empty() || !recvs.empty()) {
         nc(R.GroupStart(), "ncclGroupStart");
         for (const Wire& s : sends) nc(R.Send(s.buf, s.bytes, 0 /* ncclInt8 */, s.peerProc, b->comm, stream), "ncclSend");
         for (const Wire& r : recvs) nc(R.Recv(r.buf, r.bytes, 0 /* ncclInt8 */, r.peerProc, b->comm, stream), "ncclRecv");

@@ -111,3 +111,25 @@ def test_native_band_loop_packed_wire_format(world):
         y0, y1 = nb.plan.owned[r]
         _rows_equal(rows, ref[y0:y1], "packed band %d of %d" % (r, world))
     nb.close()
+
+
+@pytest.mark.parametrize("bands", [2, 8])
+def test_native_band_loop_two_processes_over_ipc(tmp_path, bands):
+    """The multi-process wire path of the C++ band loop, executed: TWO processes on this one GPU (RCCL refuses two ranks on one
+    device, so the loop's second transport carries the rows: IPC-mapped mailboxes, pack straight into the peer's buffer, ready /
+    consumed flags on the stream — the same pack -> transfer -> unpack schedule per pass as the RCCL path), 2 x 1 and 2 x 4 bands,
+    several passes over two lsdband_run calls.  Owned rows of both processes == the full-frame result, bit for bit."""
+    import json, os, socket, subprocess, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / "ipc.json"
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "band_ipc_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           worker, "640", "512", str(bands), "4", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res["ok"] and res["flag_waits_failed"] == [0, 0] and res["valid"] > 10000, res
