@@ -66,6 +66,19 @@ int lsdloop_comm_unique_id(unsigned char out128[128]);
 int lsdloop_comm_init(lsdloop* l, const unsigned char id128[128], int rank, int world);
 int lsdloop_comm_destroy(lsdloop* l);
 int lsdloop_gather_keyframes(lsdloop* l, int count, int root, float* recv_dev, long long stride_floats);
+/* every rank's keyframe count of the last RCCL gather — the counts travel ahead of the planes (one int per rank, ncclAllGather) and
+ * size the root's receives, so ranks whose sequences finished different numbers of keyframes cannot desynchronise the gather */
+int lsdloop_gather_counts(lsdloop* l, int* counts_out, int cap);
+/* Second transport of the gather for the processes of one node (no RCCL; e.g. two processes on one GPU): the root owns an IPC mailbox
+ * of world x ring_slots keyframe slots plus flags; rank r copies its new ring slots into slot block r, publishes its count and raises
+ * its ready flag; lsdloop_gather_keyframes then takes this path (root / recv_dev / stride arguments are ignored).
+ *   lsdloop_ipc_init (after lsdloop_set_keyframe_ring): the root writes its 64-byte handle, the others zeros;
+ *   lsdloop_ipc_connect: the root's handle;
+ *   lsdloop_ipc_result: synchronises; on the root counts_out[world] and the device pointer of the [world][ring_slots][2][h][w] floats;
+ *     returns 0, or the flag value a bounded wait gave up on. */
+int lsdloop_ipc_init(lsdloop* l, int rank, int world, int root, unsigned char handle64_out[64]);
+int lsdloop_ipc_connect(lsdloop* l, const unsigned char root_handle64[64]);
+int lsdloop_ipc_result(lsdloop* l, int* counts_out, float** data_out);
 void* lsdloop_ctx(lsdloop* l);   /* the lsdhip_ctx* the loop runs on (prof hooks, stream) */
 const char* lsdloop_last_error(void);
 /* ---- row-band decomposition of the regulariser (BASELINE.json configs[4]) ----------------------------

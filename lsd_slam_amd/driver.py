@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop
                     "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
                     "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_coarse", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
                     "lsdloop_gather_keyframes", "lsdband_create", "lsdband_destroy", "lsdband_window_rows", "lsdband_layout", "lsdband_load",
-                    "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed"]
+                    "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result"]
 
 
 def lib():
@@ -79,6 +79,10 @@ def lib():
         L.lsdloop_comm_destroy.argtypes = [vp]
         L.lsdloop_gather_keyframes.restype = i
         L.lsdloop_gather_keyframes.argtypes = [vp, i, i, vp, C.c_longlong]
+        for name, args in (("lsdloop_gather_counts", [vp, vp, i]), ("lsdloop_ipc_init", [vp, i, i, i, vp]), ("lsdloop_ipc_connect", [vp, vp]),
+                           ("lsdloop_ipc_result", [vp, vp, vp])):
+            getattr(L, name).restype = i
+            getattr(L, name).argtypes = args
         L.lsdloop_ctx.restype = vp
         L.lsdloop_ctx.argtypes = [vp]
         L.lsdloop_last_error.restype = C.c_char_p
@@ -137,6 +141,31 @@ class DriverLoop:
     def set_keyframe_ring(self, ring_ptr, slots):
         """finished keyframes' (idepth, idepthVar) planes go to slot (count % slots) of the device buffer; None switches it off"""
         _check(self.L.lsdloop_set_keyframe_ring(self.h_, C.c_void_p(ring_ptr) if ring_ptr else None, slots))
+
+    def gather_counts(self, world):
+        out = (C.c_int * world)()
+        n = _check(self.L.lsdloop_gather_counts(self.h_, out, world))
+        return list(out)[:n]
+
+    def ipc_init(self, rank, world, root=0):
+        """second transport of the gather (processes of one node, no RCCL): returns this rank's 64-byte handle (zeros unless root)"""
+        out = (C.c_ubyte * 64)()
+        _check(self.L.lsdloop_ipc_init(self.h_, rank, world, root, out))
+        self._ipc_world = world
+        return bytes(out)
+
+    def ipc_connect(self, root_handle):
+        buf = (C.c_ubyte * 64).from_buffer_copy(root_handle)
+        _check(self.L.lsdloop_ipc_connect(self.h_, buf))
+
+    def ipc_result(self):
+        """(failed waits, counts per rank, device pointer of the gathered planes) — counts / pointer only on the root"""
+        counts = (C.c_int * self._ipc_world)()
+        ptr = C.c_void_p()
+        fail = self.L.lsdloop_ipc_result(self.h_, counts, C.byref(ptr))
+        if fail < 0:
+            _check(fail)
+        return fail, list(counts), ptr.value
 
     def keep_keyframes(self, on=True):
         _check(self.L.lsdloop_keep_keyframes(self.h_, int(on)))

@@ -25,6 +25,17 @@ struct lsdloop {
   long long ring_count = 0;
   NcclComm comm = nullptr;               // lsdloop_comm_init
   int comm_rank = 0, comm_world = 1;
+  std::vector<int> last_counts;          // every rank's count of the last RCCL gather (lsdloop_gather_counts)
+  int* counts_dev = nullptr;             // [world + 1]: every rank's keyframe count of the gather being issued (+ this rank's own, last)
+  // second transport for the gather (processes of one node, no RCCL): the ROOT owns an IPC mailbox — flag block (fail word, per rank:
+  // ready, consumed, count) followed by world x ring_slots x 2 x w x h floats — and the other ranks map it
+  bool ipc = false;
+  int ipc_root = 0;
+  char* mailbox = nullptr;               // the root's allocation (own or mapped)
+  int* ipc_fail = nullptr;               // non-root: a local fail word for its bounded waits
+  long long gathers = 0;
+  float* ipc_data() const { return (float*)(mailbox + 4096); }
+  int* ipc_flag(int rank, int which) const { return (int*)(mailbox + 64 + (size_t)rank * 16 + (size_t)which * 4); }   // 0 ready, 1 consumed, 2 count
 };
 
 // ---- RCCL, bound by name (prototypes: /opt/rocm/include/rccl/rccl.h:43,187,220,260,339 and the ncclSend / ncclRecv /
@@ -39,6 +50,7 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void*, size_t, int, int, NcclComm, void*) = nullptr;
   int (*Recv)(void*, size_t, int, int, NcclComm, void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, NcclComm, void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
   std::string why;
@@ -62,8 +74,9 @@ Rccl& rccl() {
   r.GroupEnd = (int (*)())sym("ncclGroupEnd");
   r.Send = (int (*)(const void*, size_t, int, int, NcclComm, void*))sym("ncclSend");
   r.Recv = (int (*)(void*, size_t, int, int, NcclComm, void*))sym("ncclRecv");
+  r.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, void*))sym("ncclAllGather");
   r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather;
   return r;
 }
 }  // namespace
@@ -93,7 +106,15 @@ extern "C" int lsdloop_create(int device, int w, int h, const float K4[4], const
   }
 }
 extern "C" void lsdloop_destroy(lsdloop* l) {
-  if (l && l->comm) { rccl().CommDestroy(l->comm); l->comm = nullptr; }
+  if (!l) return;
+  if (l->comm) { rccl().CommDestroy(l->comm); l->comm = nullptr; }
+  if (l->ctx) {
+    lsdhip_ctx* c = l->ctx->handle();
+    (void)lsdhip_ctx_synchronize(c);
+    if (l->mailbox) { if (l->ipc && l->comm_rank != l->ipc_root) (void)lsdhip_ctx_ipc_close(c, l->mailbox); else (void)lsdhip_ctx_free_dev(c, l->mailbox); }
+    if (l->ipc_fail) (void)lsdhip_ctx_free_dev(c, l->ipc_fail);
+    if (l->counts_dev) (void)lsdhip_ctx_free_dev(c, l->counts_dev);
+  }
   delete l;
 }
 
@@ -243,10 +264,87 @@ extern "C" int lsdloop_comm_destroy(lsdloop* l) {
   if (l->comm) { rccl().CommDestroy(l->comm); l->comm = nullptr; }
   return LSDHIP_OK;
 }
+// IPC transport of the gather: rank r copies its ring slots into slot r of the root's mailbox, then publishes its count and raises
+// `ready`; the root waits for every rank's `ready`.  `consumed` (raised by the root when the NEXT gather starts) gates the overwrite.
+static int gather_ipc(lsdloop* l, int count) {
+  const size_t plane2 = (size_t)2 * l->ctx->width() * l->ctx->height();
+  const size_t slot_floats = (size_t)l->ring_slots * plane2;
+  const long long g = l->gathers;
+  try {
+    lsdhip_ctx* c = l->ctx->handle();
+    if (l->comm_rank == l->ipc_root) {
+      for (int r = 0; r < l->comm_world; r++) if (r != l->ipc_root) check(lsdhip_ctx_flag_set(c, l->ipc_flag(r, 1), (int)g), "lsdhip_ctx_flag_set");   // gather g - 1 may be overwritten
+      if (count > 0) check(lsdhip_ctx_copy_dev(c, l->ipc_data() + (size_t)l->ipc_root * slot_floats, l->ring, (size_t)count * plane2 * sizeof(float)), "lsdhip_ctx_copy_dev");
+      check(lsdhip_ctx_flag_set(c, l->ipc_flag(l->ipc_root, 2), count), "lsdhip_ctx_flag_set");
+      for (int r = 0; r < l->comm_world; r++) if (r != l->ipc_root) check(lsdhip_ctx_flag_wait(c, l->ipc_flag(r, 0), (int)(g + 1), (int*)l->mailbox), "lsdhip_ctx_flag_wait");
+    } else {
+      if (g >= 1) check(lsdhip_ctx_flag_wait(c, l->ipc_flag(l->comm_rank, 1), (int)g, l->ipc_fail), "lsdhip_ctx_flag_wait");
+      if (count > 0) check(lsdhip_ctx_copy_dev(c, l->ipc_data() + (size_t)l->comm_rank * slot_floats, l->ring, (size_t)count * plane2 * sizeof(float)), "lsdhip_ctx_copy_dev");
+      check(lsdhip_ctx_flag_set(c, l->ipc_flag(l->comm_rank, 2), count), "lsdhip_ctx_flag_set");
+      check(lsdhip_ctx_flag_set(c, l->ipc_flag(l->comm_rank, 0), (int)(g + 1)), "lsdhip_ctx_flag_set");
+    }
+    l->gathers++;
+    return LSDHIP_OK;
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+// IPC transport, step 1 (after lsdloop_set_keyframe_ring): the root allocates and exports the mailbox (handle64_out), the others get zeros
+extern "C" int lsdloop_ipc_init(lsdloop* l, int rank, int world, int root, unsigned char handle64_out[64]) {
+  if (!l || !handle64_out || world < 2 || rank < 0 || rank >= world || root < 0 || root >= world || !l->ring || world > 250) return LSDHIP_E_ARG;
+  l->comm_rank = rank; l->comm_world = world; l->ipc_root = root;
+  std::memset(handle64_out, 0, 64);
+  try {
+    lsdhip_ctx* c = l->ctx->handle();
+    if (rank == root) {
+      const size_t bytes = 4096 + (size_t)world * l->ring_slots * 2 * l->ctx->width() * l->ctx->height() * sizeof(float);
+      check(lsdhip_ctx_alloc_dev(c, bytes, (void**)&l->mailbox), "lsdhip_ctx_alloc_dev");
+      check(lsdhip_ctx_memset_dev(c, l->mailbox, 0, 4096), "lsdhip_ctx_memset_dev");
+      check(lsdhip_ctx_synchronize(c), "lsdhip_ctx_synchronize");
+      check(lsdhip_ctx_ipc_export(c, l->mailbox, handle64_out), "lsdhip_ctx_ipc_export");
+    } else {
+      check(lsdhip_ctx_alloc_dev(c, 256, (void**)&l->ipc_fail), "lsdhip_ctx_alloc_dev");
+      check(lsdhip_ctx_memset_dev(c, l->ipc_fail, 0, 256), "lsdhip_ctx_memset_dev");
+    }
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+  return LSDHIP_OK;
+}
+// step 2: the root's handle (ignored on the root)
+extern "C" int lsdloop_ipc_connect(lsdloop* l, const unsigned char root_handle64[64]) {
+  if (!l || !root_handle64) return LSDHIP_E_ARG;
+  try {
+    if (l->comm_rank != l->ipc_root) {
+      void* p = nullptr;
+      check(lsdhip_ctx_ipc_open(l->ctx->handle(), root_handle64, &p), "lsdhip_ctx_ipc_open");
+      l->mailbox = (char*)p;
+    }
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+  l->ipc = true;
+  l->gathers = 0;
+  return LSDHIP_OK;
+}
+// root, after lsdloop_gather_keyframes: synchronises, writes every rank's count of the last gather to counts_out[world], returns the
+// device pointer of the gathered planes ([world][ring_slots][2][h][w] floats) through data_out, and the number of failed waits
+extern "C" int lsdloop_ipc_result(lsdloop* l, int* counts_out, float** data_out) {
+  if (!l || !l->ipc || !l->mailbox) return LSDHIP_E_ARG;
+  try {
+    lsdhip_ctx* c = l->ctx->handle();
+    int fail = 0;
+    if (l->comm_rank == l->ipc_root) {
+      std::vector<int> block(64 / 4 + (size_t)l->comm_world * 4);
+      check(lsdhip_ctx_read_dev(c, block.data(), l->mailbox, block.size() * sizeof(int)), "lsdhip_ctx_read_dev");
+      fail = block[0];
+      if (counts_out) for (int r = 0; r < l->comm_world; r++) counts_out[r] = block[16 + 4 * r + 2];
+      if (data_out) *data_out = l->ipc_data();
+    } else {
+      check(lsdhip_ctx_read_dev(c, &fail, l->ipc_fail, sizeof(int)), "lsdhip_ctx_read_dev");
+    }
+    return fail;
+  } catch (const Error& e) { g_err = e.what(); return e.status; }
+}
 extern "C" int lsdloop_gather_keyframes(lsdloop* l, int count, int root, float* recv_dev, long long stride_floats) {
   if (!l || count < 0 || !l->ring) return LSDHIP_E_ARG;
-  if (count == 0) return LSDHIP_OK;
   if (count > l->ring_slots) { g_err = "gather: more keyframes than ring slots"; return LSDHIP_E_ARG; }
+  if (l->ipc) return gather_ipc(l, count);
+  if (count == 0 && (l->comm_world == 1 || !l->comm)) return LSDHIP_OK;
   const size_t n = (size_t)count * 2 * (size_t)l->ctx->width() * l->ctx->height();   // floats per rank
   void* stream = lsdhip_ctx_stream(l->ctx->handle());
   try {
@@ -257,20 +355,39 @@ extern "C" int lsdloop_gather_keyframes(lsdloop* l, int count, int root, float* 
     }
     Rccl& R = rccl();
     auto nc = [&](int rc, const char* what) { if (rc != 0) throw Error(LSDHIP_E_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(rc) : "?")); };
+    // The ranks run independent sequences, so their keyframe counts need not agree (distance-based keyframe selection): every
+    // rank's count travels first (one int per rank, ncclAllGather; the host reads them — one stream synchronisation per gather,
+    // i.e. per batch of frames) and sizes the root's receives.  A rank with nothing to send skips its send.
+    if (!l->counts_dev) check(lsdhip_ctx_alloc_dev(l->ctx->handle(), (size_t)(l->comm_world + 1) * sizeof(int), (void**)&l->counts_dev), "lsdhip_ctx_alloc_dev");
+    check(lsdhip_ctx_flag_set(l->ctx->handle(), l->counts_dev + l->comm_world, count), "lsdhip_ctx_flag_set");
+    nc(R.AllGather(l->counts_dev + l->comm_world, l->counts_dev, 1, 2 /* ncclInt32 */, l->comm, stream), "ncclAllGather");
+    std::vector<int> counts((size_t)l->comm_world, 0);
+    check(lsdhip_ctx_read_dev(l->ctx->handle(), counts.data(), l->counts_dev, counts.size() * sizeof(int)), "lsdhip_ctx_read_dev");
+    l->last_counts = counts;
     if (l->comm_rank == root) {
       if (!recv_dev) return LSDHIP_E_ARG;
       check(lsdhip_ctx_copy_dev(l->ctx->handle(), recv_dev + (size_t)root * stride_floats, l->ring, n * sizeof(float)), "lsdhip_ctx_copy_dev");
       nc(R.GroupStart(), "ncclGroupStart");
-      for (int r = 0; r < l->comm_world; r++)
-        if (r != root) nc(R.Recv(recv_dev + (size_t)r * stride_floats, n, 7 /* ncclFloat */, r, l->comm, stream), "ncclRecv");
+      for (int r = 0; r < l->comm_world; r++) {
+        if (r == root || counts[r] <= 0) continue;
+        if (counts[r] > l->ring_slots) throw Error(LSDHIP_E_ARG, "gather: a rank reports more keyframes than ring slots");
+        nc(R.Recv(recv_dev + (size_t)r * stride_floats, (size_t)counts[r] * 2 * (size_t)l->ctx->width() * l->ctx->height(), 7 /* ncclFloat */, r, l->comm, stream), "ncclRecv");
+      }
       nc(R.GroupEnd(), "ncclGroupEnd");
-    } else {
+    } else if (count > 0) {
       nc(R.GroupStart(), "ncclGroupStart");
       nc(R.Send(l->ring, n, 7 /* ncclFloat */, root, l->comm, stream), "ncclSend");
       nc(R.GroupEnd(), "ncclGroupEnd");
     }
     return LSDHIP_OK;
   } catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+// every rank's keyframe count of the last gather through RCCL (what sized the root's receives); returns the number written
+extern "C" int lsdloop_gather_counts(lsdloop* l, int* counts_out, int cap) {
+  if (!l || !counts_out) return LSDHIP_E_ARG;
+  int n = 0;
+  for (; n < (int)l->last_counts.size() && n < cap; n++) counts_out[n] = l->last_counts[n];
+  return n;
 }
 extern "C" long long lsdloop_keyframes_exported(lsdloop* l) { return l ? l->ring_count : -1; }
 extern "C" void* lsdloop_ctx(lsdloop* l) { return l ? (void*)l->ctx->handle() : nullptr; }

@@ -121,3 +121,24 @@ def test_cpp_loop_stays_lost_after_a_tracking_loss():
         assert "lost" in str(e2.value).lower()
     assert drv.stats().frames == 3
     drv.close()
+
+
+@pytest.mark.gpu
+def test_cpp_loop_keyframe_gather_two_processes_over_ipc(tmp_path):
+    """BASELINE.json configs[3]'s exchange step with world = 2 on this one GPU: two processes, two different sequences with different
+    keyframe intervals (2 vs 3 finished keyframes in the first batch), the C++ loop's gather over its IPC transport (RCCL refuses two ranks on
+    one device): rank r's ring slots land in block r of the root's mailbox, counts travel in-band, two consecutive gathers."""
+    import json, os, socket, subprocess, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / "gather.json"
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gather_ipc_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           worker, str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res["ok"] and res["counts"] == [[2, 3], [3, 3]], res    # 50 frames: keyframes at 10, 20 | 30, 40, 50 and at 8, 16, 24 | 32, 40, 48
