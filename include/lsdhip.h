@@ -166,13 +166,15 @@ int lsdhip_tracker_set_coarse(lsdhip_tracker* t, int enable, int fold);
  * the chain, out[2] = 1 if the cluster kernel has been switched off after repeated give-ups; evaluations of
  * the last job per pyramid level 0..4 follow in out[3..7]. */
 int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
-/* Execution strategy of the launch-per-evaluation chain: the LM loop's "increase lambda and retry" sequence
- * (C/Tracking/SE3Tracker.cpp:341-447) depends only on A, b and lambda, so a launch evaluates the next `trials` (1..6, default 5)
- * retries side by side and the following launch consumes them in the reference's order — same decisions, same evaluation
- * counts, fewer dependent launches.  Default: by the size of the level — 6 trials up to 6 K pixels, 5 up to 88 K
- * (levels 3 / 2, 1 of a 640x480 frame), one evaluation per launch on larger (work-bound) levels; this call sets the same
- * number at every level; trials = 1: one evaluation per launch.  finestLevelWorkgroups: workgroups per
- * trial at the finest level while trials > 1 (0 = keep the current value, default 80). */
+/* Execution strategy of the launch-per-step chain: the LM loop's "increase lambda and retry" sequence
+ * (C/Tracking/SE3Tracker.cpp:341-447) depends only on A, b and lambda, so a step evaluates the next `trials` retries side by side and
+ * the following step consumes them in the reference's order — same decisions, same evaluation counts, fewer dependent steps.
+ * Default (no call): AUTOMATIC, by the size of the level — 6 trials on levels of up to 6 K pixels, 5 up to 88 K (on 80 workgroups per
+ * trial above 24 K), one evaluation per step on larger (work-bound) levels: 5 / 5 / 6 at levels 1 / 2 / 3 of a 640x480 frame.
+ * This call switches the automatic policy off: `trials` (1..6) at every level; trials = 1: one evaluation per step.
+ * finestLevelWorkgroups: workgroups per trial at the job's finest level while trials > 1 — 0 keeps the current value (default 80),
+ * other values are rounded down to a multiple of 8 (one band of tiles per XCD), values below 8 up to 8.  The per-level overrides of
+ * the environment (LSDHIP_SPEC_LEVELS) are cleared by this call. */
 int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups);
 /* out[0] = kernel launches of the last job that evaluated (k_track_step launches + 1 if the cluster kernel ran; <= its
  * numEvaluations), out[1] = most trials per step (the per-level numbers follow the automatic policy above). */

@@ -1507,7 +1507,10 @@ static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNo
   a.minUseGrad = c->params.minUseGrad;
   // oldToNew_SE3 = se3FromSim3(new_keyframe->pose->thisToParent_raw).inverse() (double), cast to float
   lsdm::SE3dH newToOld;
+  // se3FromSim3 = SE3(sim3.quaternion(), translation): the SCALED quaternion, normalised by the SO3 constructor (so3.hpp:630-633)
   newToOld.q = nk->thisToParent_raw.q;
+  { const double s_ = nk->thisToParent_raw.s; newToOld.q.w *= s_; newToOld.q.x *= s_; newToOld.q.y *= s_; newToOld.q.z *= s_; }
+  lsdm::q_normalize(newToOld.q);
   for (int i = 0; i < 3; i++) newToOld.t[i] = nk->thisToParent_raw.t[i];
   lsdm::SE3dH oldToNew = lsdm::se3d_inverse(newToOld);
   double Rd[9];
@@ -1677,7 +1680,10 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
   lsdm::SE3dH newToOld;
+  // se3FromSim3 = SE3(sim3.quaternion(), translation): the SCALED quaternion, normalised by the SO3 constructor (so3.hpp:630-633)
   newToOld.q = nk->thisToParent_raw.q;
+  { const double s_ = nk->thisToParent_raw.s; newToOld.q.w *= s_; newToOld.q.x *= s_; newToOld.q.y *= s_; newToOld.q.z *= s_; }
+  lsdm::q_normalize(newToOld.q);
   for (int i = 0; i < 3; i++) newToOld.t[i] = nk->thisToParent_raw.t[i];
   lsdm::SE3dH oldToNew = lsdm::se3d_inverse(newToOld);
 
@@ -1705,6 +1711,7 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   hipLaunchKernelGGL(k_rescale, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, dm->d_red);
   lsdm::SE3dH back = lsdm::se3d_inverse(oldToNew);
   nk->thisToParent_raw.q = back.q;
+  lsdm::q_normalize(nk->thisToParent_raw.q);   // sim3FromSE3 -> Sim3::setScale normalises the quaternion (rxso3.hpp:332-335)
   for (int i = 0; i < 3; i++) nk->thisToParent_raw.t[i] = back.t[i];
   if (nk->pendRescale >= 0) c->slot_rescale_owner[nk->pendRescale] = nullptr;
   nk->pendRescale = slot;

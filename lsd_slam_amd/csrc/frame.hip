@@ -645,6 +645,7 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, int redN, double* redOut) {
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
+  f->depthVersion++;                    // a tracking job that is topped up after this point would read the new planes (tracker.hip)
   DepthPyrArgs a;
   for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = f->d_idepth[l]; a.var[l] = f->d_idepthVar[l]; }
   a.w0 = c->w;

@@ -186,6 +186,7 @@ struct lsdhip_frame {
   float* d_idepth[LSD_LEVELS] = {};
   float* d_idepthVar[LSD_LEVELS] = {};
   bool hasIDepth = false;
+  unsigned depthVersion = 0;            // incremented whenever the idepth / idepthVar pyramids are rewritten (setDepth)
   uint8_t* d_wasGood = nullptr;         // level-1 mask (lazily created, 0xFF)
   bool wasGoodValid = false;
   bool wasGoodPristine = false;         // the mask still holds the 0xFF fill of frame creation
@@ -252,6 +253,8 @@ struct lsdhip_tracker {
   size_t maskStride = 0;
   int numLaunches = 0;
   TrackSpec spec = {};             // of the job being launched
+  const lsdhip_frame* jobKf = nullptr;   // keyframe whose planes the job being run reads (trackFrame jobs), and their version at its start
+  unsigned jobKfVersion = 0;
   int jobTag = 0, launchOrdinal = 0;   // progress tag of the launch chain (TrackSummary::seq)
   int budgetExtra = 2;                 // launches queued beyond the most the recent jobs needed (finishing step + margin; LSDHIP_BUDGET_EXTRA)
   long long dbgJobs = 0, dbgEnqueued = 0, dbgMisses = 0, dbgWaitNs = 0, dbgLaunchNs = 0;   // LSDHIP_TRACK_DEBUG=1: printed at destroy

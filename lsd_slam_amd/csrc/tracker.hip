@@ -919,7 +919,7 @@ extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int
   LSD_CTX_LOCK(t->ctx);
   t->specC = trials;
   t->specAuto = false;                                        // the same number of trials at every level
-  if (finestLevelWorkgroups > 0) t->specCap = finestLevelWorkgroups & ~7;
+  if (finestLevelWorkgroups > 0) t->specCap = finestLevelWorkgroups < 8 ? 8 : (finestLevelWorkgroups & ~7);   // multiples of 8 (one tile band per XCD), at least 8
   for (int l = 0; l < LSD_LEVELS; l++) t->specLevel[l] = 0;
   for (int i = 0; i < 4; i++) t->recent[i] = 0;
   return LSDHIP_OK;
@@ -1318,6 +1318,17 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     if (S->done == 2) continue;
     if (S->done) break;
     if (int rc2 = prof_collect(c)) return rc2;
+    if (t->jobKf && t->jobKf->depthVersion != t->jobKfVersion && guard < 8) {
+      // While the host waited without the context lock, the mapping thread rewrote the keyframe's depth planes (setDepth): the
+      // launches appended now would read the new planes in the middle of a job that started on the old ones.  The reference's
+      // TrackingReference is a snapshot that cannot change under a job, so run the job again, whole, on the planes as they are now.
+      t->jobKfVersion = t->jobKf->depthVersion;
+      t->h_summary->done = 0;
+      parity = 0; first = 1;
+      budget = 12;
+      ++guard;
+      continue;
+    }
     budget = 6;
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
   }
@@ -1391,6 +1402,7 @@ static int finish_trackframe(lsdhip_tracker* t, const TrackSummary* S, lsdhip_fr
   frame->initialTrackedResidual = t->lastResidual / t->pointUsage;
   lsdm::SE3dH f2r = lsdm::se3d_from_f(lsdm::se3f_inverse(referenceToFrame));
   frame->thisToParent_raw.q = f2r.q;
+  lsdm::q_normalize(frame->thisToParent_raw.q);   // sim3FromSE3 -> Sim3::setScale normalises the quaternion (rxso3.hpp:332-335)
   frame->thisToParent_raw.t[0] = f2r.t[0]; frame->thisToParent_raw.t[1] = f2r.t[1]; frame->thisToParent_raw.t[2] = f2r.t[2];
   frame->thisToParent_raw.s = 1;
   frame->trackingParent = kf;
@@ -1439,7 +1451,10 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
     S.aff_a_lastIt = t->affineEstimation_a_lastIt; S.aff_b_lastIt = t->affineEstimation_b_lastIt;
     return finish_trackframe(t, &S, kf, frame, out);
   }
+  t->jobKf = kf;
+  t->jobKfVersion = kf->depthVersion;
   rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
+  t->jobKf = nullptr;
   if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) return rc;
   return finish_trackframe(t, t->h_summary, kf, frame, out);
 }
