@@ -36,6 +36,32 @@ if kt:
                 (len(work), sum(work) / len(work), work[len(work) // 2], work[int(len(work) * 0.9)]))
         f.write("launches <= 5.5 us (job already finished, early exit): %d\n" % (len(d) - len(work)))
 
+# throughput-mode evaluation launches (tools/bench_eval.py --levels 1 under rocprofv3 --kernel-trace): per-launch durations
+et = find("eval_trace", "*kernel_trace.csv")
+if et:
+    rows = [r for r in csv.DictReader(open(et)) if "k_track_step" in r["Kernel_Name"] and "true, 2>" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    info = {}
+    try:
+        info = json.loads(open(os.path.join(out, "eval_l1.json")).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+    with open(os.path.join(dst, tag + "_eval_launches.txt"), "w") as f:
+        f.write("k_track_step<256, true, TS_EVAL> launches at level 1, 64 jobs (tools/bench_eval.py --levels 1 --repeats 20 under rocprofv3 --kernel-trace)\n")
+        if d:
+            mb = info.get("algorithmic_MB_per_launch")
+            f.write("launches: %d, durations us: %s\n" % (len(d), " ".join("%.1f" % x for x in d)))
+            f.write("mean %.2f us, median %.2f us\n" % (sum(d) / len(d), sorted(d)[len(d) // 2]))
+            if mb:
+                f.write("algorithmic bytes per launch %.3f MB -> %.0f GB/s at the median duration = %.1f %% of the 8 TB/s HBM peak\n" %
+                        (mb, mb * 1e6 / (sorted(d)[len(d) // 2] * 1e-6) / 1e9, mb * 1e6 / (sorted(d)[len(d) // 2] * 1e-6) / 8e12 * 100))
+        if info:
+            f.write("HIP-event figure of the same run (profiled): %s\n" % json.dumps(info))
+for fn in ("eval_levels.json", "eval_levels_tiles.json"):
+    pth = os.path.join(out, fn)
+    if os.path.exists(pth):
+        shutil.copy(pth, os.path.join(dst, tag + "_" + fn))
+
 traffic = {}
 for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     cc = find(sub, "*counter_collection.csv")
