@@ -521,6 +521,7 @@ class SlamLoop {
     // after a tracking loss the keyframe and the map are gone (SlamSystem::trackingIsGood == false until the relocaliser — out of
     // scope — finds a pose again): every further step fails the same way instead of touching the invalidated reference
     if (trackingLost) throw Error(LSDHIP_E_STATE, "SlamLoop: tracking lost (no relocaliser here): create a new loop");
+    lsdhip_host_mark(0);
     frameId_++;
     std::shared_ptr<Frame> frame;
     if (prefetched_ && prefetchedSrc_ == image) frame = std::move(prefetched_);
@@ -531,7 +532,9 @@ class SlamLoop {
       reference.importFrame(keyframe.get());
       keyframe->clearDepthHasBeenUpdatedFlag();
     }
+    lsdhip_host_mark(1);
     SE3 est = tracker.trackFrame(&reference, frame.get(), lastFrameToKF_);
+    lsdhip_host_mark(8);
     pendingNext_ = nullptr;
     evaluations += tracker.numEvaluations;
     launches += tracker.numLaunches;
@@ -592,12 +595,15 @@ class SlamLoop {
       liveQueue_.push_back(frame);
       while ((int)liveQueue_.size() > (liveQueueLength > 1 ? liveQueueLength : 1)) liveQueue_.pop_front();
       std::deque<std::shared_ptr<Frame>> q(liveQueue_.begin(), liveQueue_.end());
+      lsdhip_host_mark(9);
       map.updateKeyframe(q);
+      lsdhip_host_mark(13);
       mappedOnKF_++;
       frame->clear_refPixelWasGood();
       lastFrameToKF_ = est;
       numUpdates++;
       newKeyframe = false;
+      lsdhip_host_mark(14);
     }
     return est;
   }

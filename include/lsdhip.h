@@ -323,6 +323,7 @@ int lsdhip_ctx_flag_set(lsdhip_ctx* ctx, int* flag_dev, int value);
 int lsdhip_ctx_flag_wait(lsdhip_ctx* ctx, const int* flag_dev, int value, int* fail_dev);
 int lsdhip_ctx_memset_dev(lsdhip_ctx* ctx, void* dev, int byte, size_t bytes);
 int lsdhip_ctx_read_dev(lsdhip_ctx* ctx, void* host, const void* dev, size_t bytes);   /* synchronises the stream */
+void lsdhip_host_mark(int id);   /* developer instrumentation (LSDHIP_HOST_TRACE=1): host time between consecutive marks, printed at context destruction */
 int lsdhip_ctx_free_dev(lsdhip_ctx* ctx, void* dev);
 /* (returns after the copies have finished; on an asynchronous context — lsdhip_ctx_set_async — after they are queued) */
 /* rows [row0, row0+nrows) of the eight hypothesis planes <-> one packed device buffer (29 bytes per pixel, plane after
@@ -343,8 +344,9 @@ int lsdhip_depth_copy_rows_batch(lsdhip_ctx* c, int n, const lsdhip_row_copy* it
 /* timing fields DepthMap keeps public (DepthMap.h:86-93): msUpdate, msCreate, msFinalize, msObserve, msRegularize,
  * msPropagate, msFillHoles, msSetDepth (exponential moving averages, ms) */
 int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);
-/* GPU time (HIP events on the context's stream, ms, summed since creation) and call counts of updateKeyframe [0],
- * createKeyFrame [1], finalizeKeyFrame [2]; synchronises the stream */
+/* GPU time (HIP events on the context's stream, ms, summed since creation) of the TIMED calls of updateKeyframe [0],
+ * createKeyFrame [1], finalizeKeyFrame [2] and how many calls were timed: every 8th updateKeyframe and every 2nd createKeyFrame /
+ * finalizeKeyFrame is bracketed (an event record delays the kernel behind it by ~10 us); mean = ms / calls; synchronises the stream */
 int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]);
 /* GPU time (ms, summed) and count of the observe kernel alone (DepthMap::observeDepth, C/DepthEstimation/DepthMap.cpp:147-150),
  * sampled on every 8th updateKeyframe while lsdhip_prof_enable is on; synchronises the stream. */

@@ -107,6 +107,7 @@ def _signatures():
         "lsdhip_ctx_memset_dev": (i, [vp, vp, i, C.c_size_t]),
         "lsdhip_ctx_read_dev": (i, [vp, vp, vp, C.c_size_t]),
         "lsdhip_ctx_free_dev": (i, [vp, vp]),
+        "lsdhip_host_mark": (None, [i]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
         "lsdhip_tracker_launch_stats": (i, [vp, vp]),

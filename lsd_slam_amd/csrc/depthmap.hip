@@ -719,8 +719,8 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
   __shared__ int s_validity[TN];
   __shared__ float s_id[TN];
   __shared__ float s_var[TN];
-  __shared__ double s_sum[256];
-  __shared__ int s_cnt[256];
+  __shared__ double s_sum[4];
+  __shared__ int s_cnt[4];
   const int tid = threadIdx.x;
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and every tile re-reads a 4-pixel halo of its
   // neighbours: give XCD x the contiguous tile range [x nt/8, (x+1) nt/8) (whole bands of tile rows), so that a halo line is
@@ -753,6 +753,19 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
       s_var[e] = var;
     }
   }
+  // K5's gradient test reads the keyframe's maxGradients at the pixels of its region: issued with the tile loads (one memory round
+  // trip for the workgroup instead of two; the lines are needed by nearly every wave of a semi-dense map anyway)
+  constexpr int FW_ = TW - 4, FN_ = FW_ * (TH - 4);
+  float mg[FILL ? (FN_ + 255) / 256 : 1];
+  if (FILL) {
+#pragma unroll
+    for (int it = 0; it < (FN_ + 255) / 256; it++) {
+      const int f = tid + it * 256;
+      const int x = x0 + 2 + f % FW_, y = y0 + 2 + f / FW_;
+      const bool inb = f < FN_ && x >= 0 && x < w && y >= 0 && y < h;
+      mg[it] = a.kfMaxGrad[inb ? x + y * w : 0];
+    }
+  }
   __syncthreads();
 
   if (FILL) {
@@ -767,7 +780,7 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
         const int x = x0 + lx, y = y0 + ly;
         if (x >= 3 && x < w - 2 && y >= 3 && y < h - 2 && !s_valid[e]) {
           const int idx = x + y * w;
-          if (!(a.kfMaxGrad[idx] < a.minUseGrad)) {
+          if (!(mg[it] < a.minUseGrad)) {
             int val = 0;
 #pragma unroll
             for (int dy = -2; dy <= 2; dy++)
@@ -877,8 +890,8 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
     if (inImage) {
       float ids, vars;
       if (smoothed) { ids = out_ids; vars = out_vars; }
-      else if (created) { ids = -1.f; vars = -1.f; }
-      else { ids = a.m.idepth_s[idx]; vars = a.m.var_s[idx]; }
+      else if (created || !nowValid) { ids = -1.f; vars = -1.f; }    // (not valid: the value is not looked at)
+      else { ids = a.m.idepth_s[idx]; vars = a.m.var_s[idx]; }      // valid, not smoothed: the 2-pixel border only
       if (nowValid && (double)ids >= -0.05) {
         id0[idx] = ids;
         var0[idx] = vars;
@@ -889,17 +902,19 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
         var0[idx] = -1.f;
       }
     }
-    s_sum[tid] = s;
-    s_cnt[tid] = c;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (tid < off) { s_sum[tid] += s_sum[tid + off]; s_cnt[tid] += s_cnt[tid + off]; }
-      __syncthreads();
+    // (sum, count) of the workgroup: butterfly inside each wave, then four partials through LDS.  The sum of at most 256 floats
+    // of one sign and a dynamic range below 2^20 is exact in double, so its value does not depend on the order.
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off);
+      c += __shfl_xor(c, off);
     }
+    if ((tid & 63) == 0) { s_sum[tid >> 6] = s; s_cnt[tid >> 6] = c; }
+    __syncthreads();
     if (tid == 0) {
       const int b = tIdx;
-      partials[2 * b] = s_sum[0];
-      partials[2 * b + 1] = (double)s_cnt[0];
+      partials[2 * b] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+      partials[2 * b + 1] = (double)(((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3]);
     }
   }
 }
@@ -1558,7 +1573,17 @@ static void timing_collect(lsdhip_depthmap* dm, bool all) {
     dm->ev_pending[i] = false;
   }
 }
+// GPU time of the DepthMap calls, SAMPLED: an event record is a barrier packet with a completion signal, and the kernel behind it
+// starts ~10 us late (rocprofv3 timeline, profiles/r03_notes.md §2b) — two of them around every updateKeyframe cost 9 % of the
+// track + map loop.  Every 8th updateKeyframe and every 2nd createKeyFrame / finalizeKeyFrame is bracketed (kind 3, k_observe
+// alone, is sampled by its caller); gpu_ms / gpu_calls describe the bracketed calls only.  Returns EV_SKIP when the call is not sampled.
+constexpr int EV_SKIP = -1000;
 static int timing_begin(lsdhip_depthmap* dm, int kind) {
+  if (kind < 3) {
+    static const bool every = getenv("LSDHIP_DEPTH_EVENTS_ALL") != nullptr;   // developer switch: A/B of the sampling itself
+    const unsigned period = every ? 1u : (kind == 0 ? 8u : 2u);
+    if ((dm->ev_tick[kind]++ % period) != 0) return EV_SKIP;
+  }
   const int i = dm->ev_next;
   dm->ev_next = (dm->ev_next + 1) % 8;
   if (dm->ev_pending[i]) {
@@ -1571,6 +1596,7 @@ static int timing_begin(lsdhip_depthmap* dm, int kind) {
   return i;
 }
 static int timing_end(lsdhip_depthmap* dm, int i) {
+  if (i == EV_SKIP) return LSDHIP_OK;
   HIPCHK(hipEventRecord(dm->ev[i][1], dm->ctx->stream));
   dm->ev_pending[i] = true;
   return LSDHIP_OK;
@@ -1650,18 +1676,21 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
   const int ev = timing_begin(dm, 0);
-  if (ev < 0) return ev;
+  if (ev < 0 && ev != EV_SKIP) return ev;
   // while profiling, every 8th call brackets the observe kernel alone with a second event pair (bench.py roofline_depth)
   const bool sampleObs = c->prof_on && ((dm->obs_tick++ & 7) == 0);
   int evo = -1;
   if (sampleObs) { evo = timing_begin(dm, 3); if (evo < 0) return evo; }
+  lsdhip_host_mark(10);
   int rc = observe(dm, refs, n);
   if (rc) return rc;
+  lsdhip_host_mark(11);
   if (sampleObs) { rc = timing_end(dm, evo); if (rc) return rc; }
   lsdhip_frame* kf = dm->activeKeyFrame;
   const bool setDepth = !kf->depthHasBeenUpdatedFlag;
   rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, setDepth);
   if (rc) return rc;
+  lsdhip_host_mark(12);
   rc = timing_end(dm, ev);
   if (rc) return rc;
   if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
@@ -1688,7 +1717,7 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   lsdm::SE3dH oldToNew = lsdm::se3d_inverse(newToOld);
 
   const int ev = timing_begin(dm, 1);
-  if (ev < 0) return ev;
+  if (ev < 0 && ev != EV_SKIP) return ev;
   int rc = propagate(dm, nk, false);
   if (rc) return rc;
   dm->msPropagate = ema(dm->msPropagate, now_ms() - t0);
@@ -1737,7 +1766,7 @@ extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
   const int ev = timing_begin(dm, 2);
-  if (ev < 0) return ev;
+  if (ev < 0 && ev != EV_SKIP) return ev;
   int rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, true);
   if (rc) return rc;
   lsdhip_frame* kf = dm->activeKeyFrame;

@@ -11,6 +11,8 @@
 //   Frame::setDepthFromGroundTruth Frame.cpp:245-293
 //   TrackingReference::makePointCloud C/Tracking/TrackingReference.cpp:96-147
 // Unwritten pool memory of the reference is defined as 0 here (rows 0 / h-1 of gradients etc.).
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include "lsdhip_internal.hpp"
 
@@ -384,8 +386,36 @@ extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], con
   *out = c;
   return LSDHIP_OK;
 }
+// Developer instrumentation (LSDHIP_HOST_TRACE=1): host-side time between consecutive marks of the calling thread, summed per mark
+// id and printed when a context is destroyed.  Costs one steady_clock read per mark when on, one branch when off.
+static const bool g_hostTraceOn = getenv("LSDHIP_HOST_TRACE") != nullptr;
+static long long g_htNs[32], g_htN[32], g_htHist[32][9];
+static thread_local long long g_htLast = 0;
+extern "C" void lsdhip_host_mark(int k) {
+  if (!g_hostTraceOn) return;
+  const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  if (k > 0 && k < 32 && g_htLast) {
+    const long long d = now - g_htLast;
+    g_htNs[k] += d; g_htN[k]++;
+    static const long long edges[8] = {2000, 5000, 10000, 20000, 50000, 100000, 200000, 500000};
+    int b = 0;
+    while (b < 8 && d >= edges[b]) b++;
+    g_htHist[k][b]++;
+  }
+  g_htLast = now;
+}
+static void host_trace_print() {
+  if (!g_hostTraceOn) return;
+  for (int k = 0; k < 32; k++)
+    if (g_htN[k]) {
+      fprintf(stderr, "HOSTTRACE mark %2d: n %6lld  mean %7.2f us   <2 <5 <10 <20 <50 <100 <200 <500 >=500 us:", k, g_htN[k], g_htNs[k] / 1e3 / g_htN[k]);
+      for (int b = 0; b < 9; b++) fprintf(stderr, " %lld", g_htHist[k][b]);
+      fprintf(stderr, "\n");
+    }
+}
 extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   if (!c) return;
+  host_trace_print();
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (void* a : c->free_arenas) (void)hipFree(a);
@@ -517,6 +547,7 @@ int lsd_ctx_take_slot(lsdhip_ctx* c) {
   c->slot_next = (c->slot_next + 1) % LSD_NUM_SLOTS;
   if (c->slot_stats_owner[i]) { int rc = lsd_frame_resolve(c->slot_stats_owner[i]); if (rc) return rc; }
   if (c->slot_rescale_owner[i]) { int rc = lsd_frame_resolve(c->slot_rescale_owner[i]); if (rc) return rc; }
+  c->slot_epoch[i] = c->enqEpoch;
   return i;
 }
 int lsd_frame_resolve(lsdhip_frame* f) {
@@ -524,7 +555,16 @@ int lsd_frame_resolve(lsdhip_frame* f) {
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  // the values are in pinned host memory once the kernels that write them have completed: known without a synchronisation when a
+  // tracking job enqueued after them has been seen to finish (the ring of slots wraps onto a retired keyframe's every few keyframes)
+  const bool landed = (f->pendRescale < 0 || c->doneEpoch > c->slot_epoch[f->pendRescale]) &&
+                      (f->pendStats < 0 || c->doneEpoch > c->slot_epoch[f->pendStats]);
+  if (!landed) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->enqEpoch++;
+    c->doneEpoch = c->enqEpoch;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   int rc = LSDHIP_OK;
   if (f->pendRescale >= 0) {
     const DeferredSlot& s = c->h_slots[f->pendRescale];
@@ -623,6 +663,7 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
   LSD_CTX_LOCK(c);
   if (!stream) stream = c->stream;
   dim3 grid(c->w / 16, c->h / 16);
+  lsdhip_host_mark(21);
   hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
                      f->d_image[3], f->d_image[4], c->w, c->h, f->d_grad[0], f->d_absgrad);
   GradMaxArgs ga;
@@ -636,7 +677,9 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
   ga.absg = f->d_absgrad; ga.maxgrad = f->d_maxgrad;
   ga.wasGoodWords = (uint32_t*)f->d_wasGood; ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
   int n0 = c->w * c->h;
+  lsdhip_host_mark(22);
   hipLaunchKernelGGL(k_gradients_max, dim3(nb + (n0 + 255) / 256), dim3(256), 0, stream, ga);
+  lsdhip_host_mark(23);
   HIPCHK(hipGetLastError());
   f->wasGoodPristine = true;
   return LSDHIP_OK;

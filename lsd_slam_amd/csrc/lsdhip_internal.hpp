@@ -153,6 +153,11 @@ struct lsdhip_ctx {
   lsdhip_frame* slot_stats_owner[LSD_NUM_SLOTS] = {};
   lsdhip_frame* slot_rescale_owner[LSD_NUM_SLOTS] = {};
   int slot_next = 0;
+  // Which deferred results have landed without asking the stream: a tracking job whose completion the host has observed proves
+  // that everything enqueued before it has completed.  enqEpoch counts the jobs enqueued, doneEpoch is the newest one seen done,
+  // slot_epoch[i] the value of enqEpoch when the slot's kernel was enqueued: the slot is complete once doneEpoch > slot_epoch[i].
+  long long enqEpoch = 0, doneEpoch = 0;
+  long long slot_epoch[LSD_NUM_SLOTS] = {};
   int w = 0, h = 0;
   int wl[LSD_LEVELS], hl[LSD_LEVELS];
   LevelIntr intr[LSD_LEVELS];
@@ -331,6 +336,7 @@ struct lsdhip_depthmap {
   double gpu_ms[4] = {0, 0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame, k_observe alone (sampled while profiling)
   long long gpu_calls[4] = {0, 0, 0, 0};
   unsigned obs_tick = 0;
+  unsigned ev_tick[3] = {0, 0, 0};   // calls per kind: every 8th updateKeyframe / 2nd createKeyFrame, finalizeKeyFrame is timed
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
         msSetDepth = 0;
 };

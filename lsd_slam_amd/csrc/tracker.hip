@@ -1037,6 +1037,7 @@ static int launch_steps(lsdhip_tracker* t, TrackJob& job, int steps, int* parity
   const auto tl0 = std::chrono::steady_clock::now();
   for (int i = 0; i < steps; i++) {
     launch_step(t, job, grid, *parity, *first);
+    lsdhip_host_mark(20);
     *first = 0;
     *parity ^= 1;
   }
@@ -1214,6 +1215,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   }
   t->h_summary->done = 0;
   const TrackSummary* S = t->h_summary;
+  const long long myEpoch = ++c->enqEpoch;   // everything enqueued on the stream so far precedes this job
   // Launches of the k_track_step chain a job needs = its evaluating launches + the finalising step; budget = the most of the
   // recent jobs + 2 (launches queued behind the finishing one leave at once, ~4 us each).
   int budget = 12;
@@ -1259,6 +1261,11 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     }
   }
   bool usedCoarse = false;
+  lsdhip_host_mark(2);
+  {
+    static const int delayUs = getenv("LSDHIP_DELAY_BEFORE_TRACK") ? atoi(getenv("LSDHIP_DELAY_BEFORE_TRACK")) : 0;   // experiment
+    if (delayUs > 0) { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(delayUs)) {} }
+  }
   while (true) {
     if (sample) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     int rc = LSDHIP_OK;
@@ -1272,7 +1279,9 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     rc = launch_steps(t, job, budget, &parity, &first);
     if (rc) return rc;
     if (sample) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
+    lsdhip_host_mark(3);
     if (guard == 0 && t->enqueueHook && job.trackFrameSemantics) t->enqueueHook(t->enqueueHookUser);
+    lsdhip_host_mark(4);
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
     // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.
@@ -1299,6 +1308,18 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     } else {
       HIPCHK(hipStreamSynchronize(c->stream));
     }
+    }
+    lsdhip_host_mark(5);
+    {
+      static const int delayUs = getenv("LSDHIP_DELAY_AFTER_DONE") ? atoi(getenv("LSDHIP_DELAY_AFTER_DONE")) : 0;   // experiment
+      if (delayUs > 0) { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(delayUs)) {} }
+    }
+    if (getenv("LSDHIP_HOST_TRACE")) {
+      static long long nIdle = 0, nBusy = 0, n = 0;
+      if (hipStreamQuery(c->stream) == hipSuccess) nIdle++; else nBusy++;
+      if ((++n % 200) == 0) fprintf(stderr, "HOSTTRACE after done: stream idle %lld busy %lld\n", nIdle, nBusy);
+      lsdhip_host_mark(15);
+      if (getenv("LSDHIP_HOST_TRACE_DRAIN")) { while (hipStreamQuery(c->stream) != hipSuccess) {} lsdhip_host_mark(16); }
     }
     if (S->done == 2) {
       // the cluster kernel gave up on a spin (it never should): rerun the job on the launch-per-evaluation chain
@@ -1338,6 +1359,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     c->prof_bytes += S->bytes - S->coarseBytes;
     c->prof_launches += S->numLaunches;
   }
+  if (myEpoch > c->doneEpoch) c->doneEpoch = myEpoch;
   t->numLaunches = S->numLaunches;
   t->coarseSteps = usedCoarse ? S->coarseSteps : 0;
   t->coarseBytes = usedCoarse ? S->coarseBytes : 0;
@@ -1456,7 +1478,10 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
   t->jobKf = nullptr;
   if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) return rc;
-  return finish_trackframe(t, t->h_summary, kf, frame, out);
+  lsdhip_host_mark(6);
+  rc = finish_trackframe(t, t->h_summary, kf, frame, out);
+  lsdhip_host_mark(7);
+  return rc;
 }
 
 // ---- batches: n independent jobs in the same launches (job = blockIdx.y) -------------------------------------------

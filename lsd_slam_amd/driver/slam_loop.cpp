@@ -20,6 +20,7 @@ struct lsdloop {
   lsdloop_stats st{};
   double wall = 0;                       // wall time inside lsdloop_run since the last reset
   double gpu0[3] = {0, 0, 0};            // DepthMap GPU times at the last reset
+  long long calls0[3] = {0, 0, 0};       // ... and the number of calls they were measured on (the calls are sampled)
   float* ring = nullptr;                 // lsdloop_set_keyframe_ring
   int ring_slots = 0;
   long long ring_count = 0;
@@ -165,8 +166,15 @@ extern "C" int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out) {
     double ms[3];
     long long calls[3];
     l->loop->map.gpuTimes(ms, calls);
-    l->st.seconds_map = (ms[0] - l->gpu0[0]) * 1e-3;
-    l->st.seconds_keyframe = ((ms[1] - l->gpu0[1]) + (ms[2] - l->gpu0[2])) * 1e-3;
+    // the DepthMap calls are timed by sampling (every 8th updateKeyframe, every 2nd createKeyFrame / finalizeKeyFrame): mean of
+    // the bracketed calls since the last reset x the calls the loop made
+    auto scaled = [&](int k, long n) {
+      const long long sampled = calls[k] - l->calls0[k];
+      if (sampled > 0) return (ms[k] - l->gpu0[k]) / (double)sampled * (double)n * 1e-3;
+      return calls[k] > 0 ? ms[k] / (double)calls[k] * (double)n * 1e-3 : 0.0;   // nothing bracketed since the reset: all-time mean
+    };
+    l->st.seconds_map = scaled(0, l->st.updates);
+    l->st.seconds_keyframe = scaled(1, l->st.keyframes) + scaled(2, l->st.keyframes);
     l->st.seconds_track = l->wall - l->st.seconds_map - l->st.seconds_keyframe;
     *out = l->st;
     return LSDHIP_OK;
@@ -175,8 +183,7 @@ extern "C" int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out) {
 extern "C" int lsdloop_reset_stats(lsdloop* l) {
   if (!l) return LSDHIP_E_ARG;
   try {
-    long long calls[3];
-    l->loop->map.gpuTimes(l->gpu0, calls);
+    l->loop->map.gpuTimes(l->gpu0, l->calls0);
     l->st = lsdloop_stats{};
     l->wall = 0;
     return LSDHIP_OK;
