@@ -1262,10 +1262,6 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   }
   bool usedCoarse = false;
   lsdhip_host_mark(2);
-  {
-    static const int delayUs = getenv("LSDHIP_DELAY_BEFORE_TRACK") ? atoi(getenv("LSDHIP_DELAY_BEFORE_TRACK")) : 0;   // experiment
-    if (delayUs > 0) { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(delayUs)) {} }
-  }
   while (true) {
     if (sample) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     int rc = LSDHIP_OK;
@@ -1310,17 +1306,6 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     }
     }
     lsdhip_host_mark(5);
-    {
-      static const int delayUs = getenv("LSDHIP_DELAY_AFTER_DONE") ? atoi(getenv("LSDHIP_DELAY_AFTER_DONE")) : 0;   // experiment
-      if (delayUs > 0) { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(delayUs)) {} }
-    }
-    if (getenv("LSDHIP_HOST_TRACE")) {
-      static long long nIdle = 0, nBusy = 0, n = 0;
-      if (hipStreamQuery(c->stream) == hipSuccess) nIdle++; else nBusy++;
-      if ((++n % 200) == 0) fprintf(stderr, "HOSTTRACE after done: stream idle %lld busy %lld\n", nIdle, nBusy);
-      lsdhip_host_mark(15);
-      if (getenv("LSDHIP_HOST_TRACE_DRAIN")) { while (hipStreamQuery(c->stream) != hipSuccess) {} lsdhip_host_mark(16); }
-    }
     if (S->done == 2) {
       // the cluster kernel gave up on a spin (it never should): rerun the job on the launch-per-evaluation chain
       HIPCHK(hipStreamSynchronize(c->stream));
