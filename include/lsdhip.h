@@ -304,6 +304,11 @@ int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const lsdhip_hypo
  * 2 regularizeDepthMap(false,24), 3 regularizeDepthMap(true,24), 4 propagateDepth(refs[0] = new keyframe),
  * 5 regularizeDepthMapFillHoles + regularizeDepthMap(false,24) fused in one launch (what updateKeyframe runs) */
 int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame** refs, int n);
+/* stage 5 (the fused fill-holes + regularise pass, regularizeDepthMapFillHoles + regularizeDepthMap, DepthMap.cpp:656-720, :758-880) on
+ * tile rows [tile_row0, tile_row0 + n_tile_rows) only; a tile row = 8 map rows.  The parts of one pass may be issued in any order;
+ * last != 0 on the final part of the pass (it swaps the validity planes).  Rows no part covers must be refreshed by the caller before
+ * the next pass reads them (row-band decomposition: they are another band's rows and arrive with the halo exchange). */
+int lsdhip_depth_stage_rows(lsdhip_depthmap* dm, int stage, int tile_row0, int n_tile_rows, int last);
 /* smoothed idepth / variance planes of the active keyframe (what setDepth produced), device to device —
  * the payload the multi-GPU gather collects per keyframe. */
 int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* idepthVar_dev);
@@ -323,6 +328,14 @@ int lsdhip_ctx_flag_set(lsdhip_ctx* ctx, int* flag_dev, int value);
 int lsdhip_ctx_flag_wait(lsdhip_ctx* ctx, const int* flag_dev, int value, int* fail_dev);
 int lsdhip_ctx_memset_dev(lsdhip_ctx* ctx, void* dev, int byte, size_t bytes);
 int lsdhip_ctx_read_dev(lsdhip_ctx* ctx, void* host, const void* dev, size_t bytes);   /* synchronises the stream */
+/* Transport stream (exchange under compute): between _aux_begin and _aux_end the transport primitives of this context
+ * (lsdhip_depth_copy_rows_batch, lsdhip_ctx_copy_dev, lsdhip_ctx_flag_set / _wait; a caller's RCCL calls on lsdhip_ctx_aux_stream) are
+ * queued on a second stream, ordered behind everything the main stream held at _aux_begin; _aux_join makes the main stream wait for
+ * them.  lsdband_run sends a pass's boundary rows this way while the interior rows of the same pass are computed. */
+int lsdhip_ctx_aux_begin(lsdhip_ctx* ctx);
+int lsdhip_ctx_aux_end(lsdhip_ctx* ctx);
+int lsdhip_ctx_aux_join(lsdhip_ctx* ctx);
+void* lsdhip_ctx_aux_stream(lsdhip_ctx* ctx);   /* hipStream_t; null before the first lsdhip_ctx_aux_begin */
 void lsdhip_host_mark(int id);   /* developer instrumentation (LSDHIP_HOST_TRACE=1): host time between consecutive marks, printed at context destruction */
 int lsdhip_ctx_free_dev(lsdhip_ctx* ctx, void* dev);
 /* (returns after the copies have finished; on an asynchronous context — lsdhip_ctx_set_async — after they are queued) */

@@ -114,7 +114,13 @@ long long lsdband_halo_bytes_per_pass(const lsdband* b);
 int lsdband_ipc_init(lsdband* b, int nprocs, int proc, const int* proc_of_band, unsigned char handle64_out[64]);
 int lsdband_ipc_connect(lsdband* b, const unsigned char* handles);
 int lsdband_ipc_failed(lsdband* b);
+/* index arithmetic of the overlapped pass, no GPU needed: the tile rows (8 map rows each, window coordinates) of band `band` that hold
+ * owned rows, as runs (first tile row, tile rows, edge) -> 3 ints each; edge = 1: issued before the exchange forks */
+int lsdband_tile_runs(int H, int world, int band, int* runs3, int cap);
 int lsdband_set_packed_exchange(lsdband* b, int on);
+/* 1 (default): when the object exchanges rows with other processes, a pass is issued as edge tile rows + interior tile rows and the
+ * exchange runs on the context's transport stream under the interior part; 0: one launch per window and pass, then the exchange */
+int lsdband_set_overlap(lsdband* b, int on);
 
 #ifdef __cplusplus
 }

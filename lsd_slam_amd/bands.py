@@ -249,6 +249,10 @@ class NativeBandRegularizer:
         """test hook: local windows exchange through pack -> copy -> unpack (the multi-GPU wire format) instead of map -> map"""
         self._check(self.L.lsdband_set_packed_exchange(self.h_, int(on)))
 
+    def set_overlap(self, on):
+        """exchange with other processes under the interior rows of a pass (default) / after the pass"""
+        self._check(self.L.lsdband_set_overlap(self.h_, int(on)))
+
     def halo_bytes_per_pass(self):
         return int(self.L.lsdband_halo_bytes_per_pass(self.h_))
 

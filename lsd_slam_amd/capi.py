@@ -108,6 +108,11 @@ def _signatures():
         "lsdhip_ctx_read_dev": (i, [vp, vp, vp, C.c_size_t]),
         "lsdhip_ctx_free_dev": (i, [vp, vp]),
         "lsdhip_host_mark": (None, [i]),
+        "lsdhip_ctx_aux_begin": (i, [vp]),
+        "lsdhip_ctx_aux_end": (i, [vp]),
+        "lsdhip_ctx_aux_join": (i, [vp]),
+        "lsdhip_ctx_aux_stream": (vp, [vp]),
+        "lsdhip_depth_stage_rows": (i, [vp, i, i, i, i]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
         "lsdhip_tracker_launch_stats": (i, [vp, vp]),

@@ -612,6 +612,7 @@ struct RegArgs {
   int w, h;
   float minUseGrad, regDistVar;
   int validityTH;
+  int tileRow0;             // k_reg_fused on a range of tile rows (8 rows each): first tile row of the launch (0: whole map)
 };
 
 // K5: regularizeDepthMapFillHolesRow (DepthMap.cpp:656-703); 5x5 validity sum replaces the integral image.
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
   const int nt = gridDim.x * gridDim.y;
   const int lin = blockIdx.x + blockIdx.y * gridDim.x;
   const int tIdx = (nt & 7) == 0 ? (lin & 7) * (nt >> 3) + (lin >> 3) : lin;
-  const int tbx = tIdx % gridDim.x, tby = tIdx / gridDim.x;
+  const int tbx = tIdx % gridDim.x, tby = tIdx / gridDim.x + a.tileRow0;
   const int x0 = tbx * 32 - HALO, y0 = tby * 8 - HALO;
   const int w = a.w, h = a.h;
 
@@ -1311,6 +1312,7 @@ static RegArgs reg_args(lsdhip_depthmap* dm, int validityTH) {
   a.minUseGrad = c->params.minUseGrad;
   a.regDistVar = 0.075f * 0.075f * c->params.depthSmoothingFactor * c->params.depthSmoothingFactor;  // REG_DIST_VAR
   a.validityTH = validityTH;
+  a.tileRow0 = 0;
   return a;
 }
 static void swap_valid(lsdhip_depthmap* dm) { std::swap(dm->cur.valid, dm->d_validSnap); }
@@ -1349,6 +1351,27 @@ static int fill_regularize(lsdhip_depthmap* dm, int validityTH, bool setDepth) {
   HIPCHK(hipGetLastError());
   swap_valid(dm);
   if (setDepth) return set_depth_finish(dm, (int)(grid.x * grid.y));
+  return LSDHIP_OK;
+}
+
+// The fused pass on tile rows [tileRow0, tileRow0 + nTileRows) only (a tile row = 8 map rows).  The parts of one pass may be issued
+// in any order and on different streams: every part reads the snapshot validity plane and the pre-pass hypotheses (a pixel K5 creates
+// was invalid in the snapshot, so nobody reads the fields its owner rewrites) and writes the other validity plane; `last` swaps the
+// two once all parts are queued.  Rows outside the parts keep whatever the second validity plane held: the caller refreshes them
+// (row-band decomposition: rows another band owns arrive with the halo exchange).
+static int fill_regularize_rows(lsdhip_depthmap* dm, int validityTH, int tileRow0, int nTileRows, bool last) {
+  lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
+  const int T = (c->h + 7) / 8;
+  if (tileRow0 < 0 || nTileRows < 0 || tileRow0 + nTileRows > T) { lsd_set_error("depth stage rows: tile rows [%d, %d) outside [0, %d)", tileRow0, tileRow0 + nTileRows, T); return LSDHIP_E_ARG; }
+  if (nTileRows > 0) {
+    RegArgs a = reg_args(dm, validityTH);
+    a.tileRow0 = tileRow0;
+    dim3 grid((c->w + 31) / 32, nTileRows);
+    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
+    HIPCHK(hipGetLastError());
+  }
+  if (last) swap_valid(dm);
   return LSDHIP_OK;
 }
 
@@ -1879,6 +1902,18 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
   return LSDHIP_OK;
 }
 
+extern "C" int lsdhip_depth_stage_rows(lsdhip_depthmap* dm, int stage, int tile_row0, int n_tile_rows, int last) {
+  if (!dm || stage != 5) return LSDHIP_E_ARG;
+  if (!dm->activeKeyFrame) { lsd_set_error("depth stage: no active keyframe"); return LSDHIP_E_STATE; }
+  lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  int rc = fill_regularize_rows(dm, VAL_SUM_MIN_FOR_KEEP, tile_row0, n_tile_rows, last != 0);
+  if (rc) return rc;
+  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
+  return LSDHIP_OK;
+}
+
 extern "C" int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* var_dev) {
   if (!dm || !idepth_dev || !var_dev) return LSDHIP_E_ARG;
   if (!dm->activeKeyFrame || !dm->activeKeyFrame->hasIDepth) return LSDHIP_E_STATE;
@@ -1993,10 +2028,10 @@ extern "C" int lsdhip_depth_copy_rows_batch(lsdhip_ctx* c, int n, const lsdhip_r
     int gx = (per + 255) / 256;
     if (gx > 512) gx = 512;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(k_copy_rows, dim3(gx, m), dim3(256), 0, c->stream, b, vec);
+    hipLaunchKernelGGL(k_copy_rows, dim3(gx, m), dim3(256), 0, lsd_transport_stream(c), b, vec);
   }
   HIPCHK(hipGetLastError());
-  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
+  if (!c->async) HIPCHK(hipStreamSynchronize(lsd_transport_stream(c)));
   return LSDHIP_OK;
 }
 

@@ -418,6 +418,7 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   host_trace_print();
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipEventDestroy(c->aux_fork); (void)hipEventDestroy(c->aux_done); (void)hipStreamDestroy(c->aux_stream); }
   for (void* a : c->free_arenas) (void)hipFree(a);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->h_slots) (void)hipHostFree(c->h_slots);
@@ -452,6 +453,7 @@ extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
     }
   }
   if (!c) return LSDHIP_E_ARG;
+  if (c->aux_stream) HIPCHK(hipStreamSynchronize(c->aux_stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
 }
@@ -459,9 +461,46 @@ extern "C" int lsdhip_ctx_copy_dev(lsdhip_ctx* c, void* dst, const void* src, si
   if (!c || !dst || !src) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, lsd_transport_stream(c)));
   return LSDHIP_OK;
 }
+// ---- transport stream: exchange under compute (halo rows of the row-band loop travel while the interior rows are computed) -------
+extern "C" int lsdhip_ctx_aux_begin(lsdhip_ctx* c) {
+  if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  if (c->aux_active) { lsd_set_error("lsdhip_ctx_aux_begin: already between begin and end"); return LSDHIP_E_STATE; }
+  if (!c->aux_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(c->aux_fork, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+  c->aux_active = true;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_aux_end(lsdhip_ctx* c) {
+  if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  if (!c->aux_active) { lsd_set_error("lsdhip_ctx_aux_end without lsdhip_ctx_aux_begin"); return LSDHIP_E_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->aux_done, c->aux_stream));
+  c->aux_active = false;
+  c->aux_pending = true;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_aux_join(lsdhip_ctx* c) {
+  if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  if (c->aux_active) { lsd_set_error("lsdhip_ctx_aux_join between begin and end"); return LSDHIP_E_STATE; }
+  if (!c->aux_pending) return LSDHIP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->aux_done, 0));
+  c->aux_pending = false;
+  return LSDHIP_OK;
+}
+extern "C" void* lsdhip_ctx_aux_stream(lsdhip_ctx* c) { return c ? (void*)c->aux_stream : nullptr; }
 // ---- inter-process exchange on one node without RCCL (lsdhip_driver's second transport): IPC-mapped device memory + flags ---------
 // A flag is an int in device memory that both processes map; values only grow.  Both operations are stream-ordered one-lane kernels:
 // set publishes everything the stream did before it (system-scope release), wait spins — bounded — until the flag has reached the
@@ -508,7 +547,7 @@ extern "C" int lsdhip_ctx_flag_set(lsdhip_ctx* c, int* flag_dev, int value) {
   if (!c || !flag_dev) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, c->stream, flag_dev, value);
+  hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, lsd_transport_stream(c), flag_dev, value);
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }
@@ -516,7 +555,7 @@ extern "C" int lsdhip_ctx_flag_wait(lsdhip_ctx* c, const int* flag_dev, int valu
   if (!c || !flag_dev || !fail_dev) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, c->stream, flag_dev, value, fail_dev);
+  hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, lsd_transport_stream(c), flag_dev, value, fail_dev);
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }

@@ -164,6 +164,12 @@ struct lsdhip_ctx {
   float K0[9], K0inv[9];
   lsdhip_params params;
   hipStream_t stream = nullptr;
+  // Second stream for the transport primitives of the multi-process loops (row copies, flags, device copies, the caller's RCCL
+  // calls): between lsdhip_ctx_aux_begin and lsdhip_ctx_aux_end they are queued there, ordered behind what the main stream held at
+  // `begin`; lsdhip_ctx_aux_join makes the main stream wait for them.  Created on first use.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_done = nullptr;
+  bool aux_active = false, aux_pending = false;
   // profiling of the residual kernel (bench.py roofline leg)
   bool prof_on = false;
   unsigned prof_tick = 0;                // trackFrame jobs seen while profiling (every 8th is timed)
@@ -342,6 +348,7 @@ struct lsdhip_depthmap {
 };
 
 // kernels / launchers implemented in the .hip files
+inline hipStream_t lsd_transport_stream(lsdhip_ctx* c) { return c->aux_active ? c->aux_stream : c->stream; }
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);

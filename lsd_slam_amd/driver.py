@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop
                     "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
                     "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_coarse", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
                     "lsdloop_gather_keyframes", "lsdband_create", "lsdband_destroy", "lsdband_window_rows", "lsdband_layout", "lsdband_load",
-                    "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result"]
+                    "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_set_overlap", "lsdband_tile_runs", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result"]
 
 
 def lib():
@@ -65,7 +65,7 @@ def lib():
         L.lsdloop_comm_unique_id.argtypes = [vp]
         for name, args in (("lsdband_create", [i, i, i, i, i, i, C.POINTER(vp)]), ("lsdband_window_rows", [vp]), ("lsdband_layout", [vp, i, vp]),
                            ("lsdband_load", [vp, i, vp, vp]), ("lsdband_get", [vp, i, vp]), ("lsdband_comm_init", [vp, vp, i, i, vp]),
-                           ("lsdband_run", [vp, i]), ("lsdband_synchronize", [vp]), ("lsdband_set_packed_exchange", [vp, i]), ("lsdband_plan", [i, i, vp, vp, vp, i]),
+                           ("lsdband_run", [vp, i]), ("lsdband_synchronize", [vp]), ("lsdband_set_packed_exchange", [vp, i]), ("lsdband_set_overlap", [vp, i]), ("lsdband_tile_runs", [i, i, i, vp, i]), ("lsdband_plan", [i, i, vp, vp, vp, i]),
                            ("lsdband_ipc_init", [vp, i, i, vp, vp]), ("lsdband_ipc_connect", [vp, vp]), ("lsdband_ipc_failed", [vp])):
             getattr(L, name).restype = i
             getattr(L, name).argtypes = args

@@ -407,8 +407,12 @@ extern "C" void* lsdloop_ctx(lsdloop* l) { return l ? (void*)l->ctx->handle() : 
 //   * windows held by this process refresh each other's halo rows with ONE map -> map copy launch per pass;
 //   * rows owned by another process travel packed (29 B per pixel): one pack launch, ncclGroupStart / ncclSend / ncclRecv /
 //     ncclGroupEnd on the same stream, one unpack launch;
-//   * not done yet: issuing a window's boundary tile rows first and running the exchange on a second stream under the interior
-//     rows (needs a multi-GPU box to measure; on one GPU the exchange is one 10 us launch per pass).
+//   * with other processes to talk to, a pass is issued in two parts: first the tile rows that produce rows another band needs or
+//     that read rows another band sends ("edge": a few tile rows at the top and bottom of the owned range), then the rest
+//     ("interior").  The exchange (pack, send / receive or mailbox + flags, unpack) runs on the context's transport stream behind
+//     the edge part and beside the interior part; the next pass's edge part waits for it.  Interior tile rows neither read received
+//     rows nor produce sent ones, and the parts of a pass are order-independent (lsdhip_depth_stage_rows), so the result is the
+//     full frame's, bit for bit, either way.  Tile rows without an owned row are not computed at all (their rows arrive).
 // One pass = regularizeDepthMapFillHoles + regularizeDepthMap(false, VAL_SUM_MIN_FOR_KEEP) (C/DepthEstimation/DepthMap.cpp:
 // 656-720, :758-880), the fused launch behind lsdhip_depth_stage(dm, 5).
 namespace {
@@ -428,6 +432,7 @@ struct lsdband {
   std::vector<char*> sendbuf, recvbuf;   // one packed device buffer per remote segment
   long long passes_run = 0;
   bool packedLocal = false;              // test hook: windows of this process exchange through pack -> copy -> unpack as well
+  bool overlap = true;                   // exchange with other processes under the interior rows of the pass (lsdband_set_overlap)
   // Second transport between PROCESSES of one node (lsdband_ipc_*): every process exports one "mailbox" allocation — flags and,
   // twice (two exchange parities), the packed receive buffer of each of its incoming remote segments — and maps the others'.
   // A sender packs its rows STRAIGHT INTO the receiver's buffer and raises the segment's `ready` flag; the receiver unpacks
@@ -489,6 +494,40 @@ static bool band_fill_layout(lsdband* b) {
   }
   b->proc_of.assign(world, 0);
   return true;
+}
+// Tile rows (8 map rows each) of band r's window that hold at least one owned row, as runs of equal kind.  `edge`: the tile row
+// produces a row some other band's window holds, or its tiles read (the fused pass's tile halo: 4 rows above its first row, 4 below
+// its last) a row this band does not own — such tile rows wait for the previous exchange and are issued before the next one;
+// the others ("interior") neither read received rows nor produce sent ones.
+struct BandRun { int t0, n; bool edge; };
+static std::vector<BandRun> band_tile_runs(const lsdband& b, int r) {
+  std::vector<BandRun> runs;
+  const int wf = b.window[r].first, WR = b.window_rows;
+  const int o0 = b.owned[r].first - wf, o1 = b.owned[r].second - wf;
+  std::vector<char> sent(WR, 0);
+  for (int q = 0; q < b.world; q++) {
+    if (q == r) continue;
+    const int lo = std::max(b.window[q].first, b.owned[r].first), hi = std::min(b.window[q].second, b.owned[r].second);
+    for (int y = lo; y < hi; y++) sent[y - wf] = 1;
+  }
+  for (int t = o0 / 8; t < (o1 + 7) / 8; t++) {
+    bool edge = false;
+    for (int y = 8 * t; y < 8 * t + 8 && y < WR; y++) edge = edge || sent[y];
+    for (int y = 8 * t - 4; y < 8 * t + 12; y++) edge = edge || (y >= 0 && y < WR && (y < o0 || y >= o1));
+    if (!runs.empty() && runs.back().edge == edge) runs.back().n++;
+    else runs.push_back({t, 1, edge});
+  }
+  return runs;
+}
+// the runs of band `band` of an H-row map cut into `world` bands: (first tile row, tile rows, edge) triples; returns their number
+extern "C" int lsdband_tile_runs(int H, int world, int band, int* runs3, int cap) {
+  if (H <= 0 || world < 1 || (H % 16) != 0 || band < 0 || band >= world) return LSDHIP_E_ARG;
+  lsdband b;
+  b.H = H; b.world = world;
+  if (!band_fill_layout(&b)) return LSDHIP_E_ARG;
+  const std::vector<BandRun> runs = band_tile_runs(b, band);
+  for (int k = 0; k < (int)runs.size() && k < cap && runs3; k++) { runs3[3 * k] = runs[k].t0; runs3[3 * k + 1] = runs[k].n; runs3[3 * k + 2] = runs[k].edge ? 1 : 0; }
+  return (int)runs.size();
 }
 // The plan alone, no GPU needed (CPU tests compare it with BandPlan): layout4[4 r .. 4 r + 3] = owned [y0, y1), window [a, b) of
 // band r; segments: up to cap triples (receiving band, sending band, first global row, rows) -> 4 ints each; returns their number.
@@ -713,10 +752,30 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
       }
     }
     auto flagPtr = [](char* box, int k, int which) { return (int*)(box + 64 + (size_t)k * 8 + (size_t)which * 4); };   // (ready, consumed) pairs behind the fail word
+    std::vector<std::vector<BandRun>> runs(b->nlocal);
+    for (int i = 0; i < b->nlocal; i++) runs[i] = band_tile_runs(*b, b->first + i);
+    const bool remote = b->ipc || !sends.empty() || !recvs.empty();
+    const bool overlap = b->overlap && remote;
     for (int p = 0; p < passes; p++) {
-      for (int i = 0; i < b->nlocal; i++) check(lsdhip_depth_stage(b->dm[i], 5, nullptr, 0), "lsdhip_depth_stage");
+      if (overlap) {
+        // edge parts first (they wait for the previous exchange), the exchange forks behind them, interior parts run beside it
+        check(lsdhip_ctx_aux_join(b->ctx), "lsdhip_ctx_aux_join");
+        for (int i = 0; i < b->nlocal; i++)
+          for (const BandRun& u : runs[i]) if (u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
+        if (p + 1 < passes) check(lsdhip_ctx_aux_begin(b->ctx), "lsdhip_ctx_aux_begin");
+        for (int i = 0; i < b->nlocal; i++) {
+          for (const BandRun& u : runs[i]) if (!u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
+          check(lsdhip_depth_stage_rows(b->dm[i], 5, 0, 0, 1), "lsdhip_depth_stage_rows");   // validity planes swapped: the pass is queued
+        }
+      } else {
+        for (int i = 0; i < b->nlocal; i++) {
+          const int t0 = runs[i].front().t0, t1 = runs[i].back().t0 + runs[i].back().n;
+          check(lsdhip_depth_stage_rows(b->dm[i], 5, t0, t1 - t0, 1), "lsdhip_depth_stage_rows");
+        }
+      }
       b->passes_run++;
       if (p + 1 == passes) break;
+      void* xstream = overlap ? lsdhip_ctx_aux_stream(b->ctx) : stream;
       // the halo rows a window receives are never rows it owns, and sources are always owned rows: the copies of one
       // exchange cannot overwrite each other's inputs, so one launch serves all of them
       if (!packs.empty()) check(lsdhip_depth_copy_rows_batch(b->ctx, (int)packs.size(), packs.data()), "lsdhip_depth_copy_rows_batch");
@@ -750,12 +809,21 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
         b->exchanges++;
       } else if (!sends.empty() || !recvs.empty()) {
         nc(R.GroupStart(), "ncclGroupStart");
-        for (const Wire& s : sends) nc(R.Send(s.buf, s.bytes, 0 /* ncclInt8 */, s.peerProc, b->comm, stream), "ncclSend");
-        for (const Wire& r : recvs) nc(R.Recv(r.buf, r.bytes, 0 /* ncclInt8 */, r.peerProc, b->comm, stream), "ncclRecv");
+        for (const Wire& s : sends) nc(R.Send(s.buf, s.bytes, 0 /* ncclInt8 */, s.peerProc, b->comm, xstream), "ncclSend");
+        for (const Wire& r : recvs) nc(R.Recv(r.buf, r.bytes, 0 /* ncclInt8 */, r.peerProc, b->comm, xstream), "ncclRecv");
         nc(R.GroupEnd(), "ncclGroupEnd");
         check(lsdhip_depth_copy_rows_batch(b->ctx, (int)unpacks.size(), unpacks.data()), "lsdhip_depth_copy_rows_batch");
       }
+      if (overlap) check(lsdhip_ctx_aux_end(b->ctx), "lsdhip_ctx_aux_end");
     }
+    if (overlap) check(lsdhip_ctx_aux_join(b->ctx), "lsdhip_ctx_aux_join");
     return LSDHIP_OK;
-  } catch (const Error& e) { g_err = e.what(); return e.status; }
+  } catch (const Error& e) { (void)lsdhip_ctx_aux_end(b->ctx); g_err = e.what(); return e.status; }
+}
+// 1 (default): with other processes to exchange with, the exchange of a pass runs under its interior rows; 0: one launch per
+// window and pass, then the exchange, all on one stream
+extern "C" int lsdband_set_overlap(lsdband* b, int on) {
+  if (!b) return LSDHIP_E_ARG;
+  b->overlap = on != 0;
+  return LSDHIP_OK;
 }

@@ -2,7 +2,7 @@
 holding a contiguous range of row bands of the regulariser; the halo rows travel through the C++ band loop's IPC transport
 (lsdband_ipc_*: pack into the peer's mapped mailbox, ready / consumed flags on the stream).  torch.distributed (gloo) only carries
 the 64-byte handles and collects the owned rows on rank 0, which compares them with the full-frame result, bit for bit.
-Usage: python -m torch.distributed.run --nproc-per-node N tests/band_ipc_worker.py <w> <H> <bands> <passes> <out.json>"""
+Usage: python -m torch.distributed.run --nproc-per-node N tests/band_ipc_worker.py <w> <H> <bands> <passes> <out.json> [overlap]"""
 import json
 import os
 import sys
@@ -15,6 +15,7 @@ import torch.distributed as dist  # noqa: E402
 from lsd_slam_amd.bands import NativeBandRegularizer, synth_s3  # noqa: E402
 
 w, H, bands, passes, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+overlap = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -27,6 +28,7 @@ handle = br.ipc_init(world, rank, proc_of)
 handles = [None] * world
 dist.all_gather_object(handles, handle)
 br.ipc_connect(handles)
+br.set_overlap(overlap)
 br.load(hyp, maxgrad)
 br.synchronize()
 dist.barrier()

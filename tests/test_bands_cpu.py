@@ -133,3 +133,49 @@ def test_native_band_plan_equals_python_plan():
             for r in range(world):
                 sends = sorted((d, lo, cnt) for (d, s, lo, cnt) in got if s == r)
                 assert sends == sorted(plan.send_list(r)), (H, world, r)
+
+
+def test_native_band_tile_runs_separate_edge_from_interior():
+    """The overlapped pass of the C++ band loop issues a window's tile rows (8 map rows) in two parts: `edge` runs before the halo
+    exchange forks, `interior` runs beside it.  Race-freedom is index arithmetic, checked here without a GPU for a sweep of heights
+    and band counts, from BandPlan's lists alone: the runs cover exactly the tile rows that hold owned rows, once; an interior tile
+    row contains no row any other band receives (send_list) and its tiles' read footprint (4 rows above the tile row, 4 below: the
+    fused pass's tile halo) contains no row this band receives (recv_list) — so the exchange may write those while it runs."""
+    import ctypes as C
+    from lsd_slam_amd import driver
+    from lsd_slam_amd.bands import BandPlan
+    L = driver.lib()
+    seen_interior = 0
+    for H in (64, 256, 384, 512, 1024, 2160):
+        if H % 16:
+            continue
+        for world in (1, 2, 3, 5, 8, 13):
+            if world > H // 16:
+                continue
+            plan = BandPlan(H, world)
+            for r in range(world):
+                buf = (C.c_int * (3 * 64))()
+                n = L.lsdband_tile_runs(H, world, r, buf, 64)
+                assert 0 < n <= 64, (H, world, r, n)
+                runs = [(buf[3 * k], buf[3 * k + 1], buf[3 * k + 2]) for k in range(n)]
+                a, _ = plan.window[r]
+                y0, y1 = plan.owned[r]
+                o0, o1 = y0 - a, y1 - a
+                tiles = [t for (t0, cnt, _) in runs for t in range(t0, t0 + cnt)]
+                assert tiles == list(range(o0 // 8, (o1 + 7) // 8)), (H, world, r)          # every owned row, once, in order
+                assert all(runs[k][2] != runs[k + 1][2] for k in range(n - 1)), (H, world, r)  # runs are maximal
+                sent = set()
+                for (_, lo, cnt) in plan.send_list(r):
+                    sent.update(range(lo - a, lo - a + cnt))
+                received = set()
+                for (_, lo, cnt) in plan.recv_list(r):
+                    received.update(range(lo - a, lo - a + cnt))
+                assert received == set(range(plan.window_rows)) - set(range(o0, o1)), (H, world, r)   # all non-owned rows arrive
+                for (t0, cnt, edge) in runs:
+                    for t in range(t0, t0 + cnt):
+                        produces = set(range(8 * t, 8 * t + 8))
+                        reads = set(range(8 * t - 4, 8 * t + 12))
+                        clean = not (produces & sent) and not (reads & received)
+                        assert clean == (edge == 0), (H, world, r, t, edge)
+                        seen_interior += (edge == 0)
+    assert seen_interior > 100

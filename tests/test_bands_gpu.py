@@ -113,12 +113,14 @@ def test_native_band_loop_packed_wire_format(world):
     nb.close()
 
 
-@pytest.mark.parametrize("bands", [2, 8])
-def test_native_band_loop_two_processes_over_ipc(tmp_path, bands):
+@pytest.mark.parametrize("bands,overlap", [(2, 1), (8, 1), (8, 0)])
+def test_native_band_loop_two_processes_over_ipc(tmp_path, bands, overlap):
     """The multi-process wire path of the C++ band loop, executed: TWO processes on this one GPU (RCCL refuses two ranks on one
     device, so the loop's second transport carries the rows: IPC-mapped mailboxes, pack straight into the peer's buffer, ready /
     consumed flags on the stream — the same pack -> transfer -> unpack schedule per pass as the RCCL path), 2 x 1 and 2 x 4 bands,
-    several passes over two lsdband_run calls.  Owned rows of both processes == the full-frame result, bit for bit."""
+    several passes over two lsdband_run calls.  overlap = 1 (the default): every pass is issued as edge tile rows + interior tile rows
+    and the exchange runs on the transport stream under the interior part; 0: exchange after the pass on one stream.  Owned rows of
+    both processes == the full-frame result, bit for bit."""
     import json, os, socket, subprocess, sys
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -128,7 +130,7 @@ def test_native_band_loop_two_processes_over_ipc(tmp_path, bands):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "band_ipc_worker.py")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           worker, "640", "512", str(bands), "4", str(out)]
+           worker, "640", "512", str(bands), "4", str(out), str(overlap)]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.load(open(out))
