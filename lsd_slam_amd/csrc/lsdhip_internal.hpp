@@ -91,6 +91,7 @@ struct TrackSpec {
   uint8_t* wasGoodSide;      // refPixelWasGood planes of trials 1 .. (trial 0 writes the frame's own plane)
   unsigned maskStride;
   int seq;                   // progress tag this launch reports to the host (TrackSummary::seq); 0 = none
+  int last;                  // 1: the last launch of the enqueued budget — if the job is not finished when it ends it says so (TrackSummary::exhausted)
 };
 
 // Levenberg-Marquardt state of a tracking job, resident in HBM, advanced by k_lm_step.
@@ -130,6 +131,8 @@ struct TrackSummary {
   int seq;                   // (job tag << 12) | ordinal of the latest k_track_step launch of the chain that has started
   int coarseSteps;           // steps of the coarse-level cluster kernel (k_track_coarse); 0 when the chain ran every level
   double coarseBytes;        // algorithmic bytes of the evaluations inside the cluster kernel (included in `bytes`)
+  int exhausted;             // seq of the budget's last launch, written when that launch ends with the job unfinished: the host tops up
+  int pad2_;
 };
 
 // A result the host needs eventually but not now (mean inverse depth / point count of a setDepth, the rescale factor
@@ -268,6 +271,7 @@ struct lsdhip_tracker {
   unsigned jobKfVersion = 0;
   int jobTag = 0, launchOrdinal = 0;   // progress tag of the launch chain (TrackSummary::seq)
   int budgetExtra = 2;                 // launches queued beyond the most the recent jobs needed (finishing step + margin; LSDHIP_BUDGET_EXTRA)
+  int budgetFixed = 0;   // LSDHIP_BUDGET_FIXED (test hook): launches per budget, however many the job needs
   long long dbgJobs = 0, dbgEnqueued = 0, dbgMisses = 0, dbgWaitNs = 0, dbgLaunchNs = 0;   // LSDHIP_TRACK_DEBUG=1: printed at destroy
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary

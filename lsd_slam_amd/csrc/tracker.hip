@@ -716,6 +716,10 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     }
   }
   if (MODE == TS_FUSED && leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // S.pending was set before the barriers above
+  // the budget's last launch ends with the job unfinished: tell the host (pinned memory), which polls this next to `done` and
+  // appends launches — the stream order makes them follow; no hipStreamQuery in the wait loop (each one puts a marker packet into
+  // the queue the chain runs through: ~3 us per frame)
+  if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.last != 0) out->exhausted = spec.seq;
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
   if (blockIdx.x == 0 && tid == 0) tr_[9] = wall_clock64();
@@ -820,6 +824,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   t->hostLM = env && env[0] == '1';
   if (const char* e = getenv("LSDHIP_SPIN")) t->spinWait = e[0] != '0';
   if (const char* e = getenv("LSDHIP_BUDGET_EXTRA")) { t->budgetExtra = atoi(e); if (t->budgetExtra < 1) t->budgetExtra = 1; }
+  if (const char* e = getenv("LSDHIP_BUDGET_FIXED")) { t->budgetFixed = atoi(e); if (t->budgetFixed < 1) t->budgetFixed = 0; }   // test hook: every job runs out of budget
   *out = t;
   return LSDHIP_OK;
 }
@@ -1036,6 +1041,7 @@ static int launch_steps(lsdhip_tracker* t, TrackJob& job, int steps, int* parity
   }
   const auto tl0 = std::chrono::steady_clock::now();
   for (int i = 0; i < steps; i++) {
+    t->spec.last = (i + 1 == steps) ? 1 : 0;
     launch_step(t, job, grid, *parity, *first);
     lsdhip_host_mark(20);
     *first = 0;
@@ -1070,6 +1076,7 @@ static int evaluate_pose(lsdhip_tracker* t, TrackJob& job, const lsdm::SE3fH& T,
   t->jobTag = 0;
   if (int rcp = prof_collect(c)) return rcp;
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
+  t->spec.last = 0;
   launch_step(t, job, job.lv[level].nblocks, 0, 1);   // residual evaluation
   if (c->prof_on) HIPCHK(hipEventRecord(c->ev_b, c->stream));
   launch_step(t, job, 1, 1, 0);                       // finalises the sums (evalOnly)
@@ -1224,12 +1231,14 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     for (int i = 0; i < 4; i++) if (t->recent[i] > budget) budget = t->recent[i];
     budget += t->budgetExtra;
   }
+  if (t->budgetFixed > 0) budget = t->budgetFixed;
   // timing events on every 8th job only: two event packets and a host-side event query per job cost ~5 % of a frame
   const bool sample = c->prof_on && ((c->prof_tick++ & 7) == 0);
   t->dbgJobs++;
   t->jobTag = (t->jobTag % 0x7FFFF) + 1;
   t->launchOrdinal = 0;
   t->h_summary->seq = 0;
+  t->h_summary->exhausted = 0;
   int guard = 0;
   int parity = 0, first = 1;
   if (int rc = prof_collect(c)) return rc;
@@ -1289,10 +1298,13 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     Relock relock_{c->mtx};
     if (t->spinWait) {
       volatile const int* done = &S->done;
+      volatile const int* exhausted = &S->exhausted;
+      const int lastSeq = t->spec.seq;                      // tag of the last launch enqueued
       const auto tStart = std::chrono::steady_clock::now();
       unsigned spins = 0;
       while (!*done) {
-        if ((++spins & 1023u) == 0) {
+        if (*exhausted == lastSeq) break;                   // budget consumed, job unfinished (the last launch said so)
+        if ((++spins & 0xFFFFFu) == 0) {                    // safety net only (a faulted launch never reports): every ~30 ms
           hipError_t q = hipStreamQuery(c->stream);
           if (q == hipSuccess) break;                       // budget consumed (done or not)
           if (q != hipErrorNotReady) { lsd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return LSDHIP_E_HIP; }
@@ -1335,7 +1347,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       ++guard;
       continue;
     }
-    budget = 6;
+    budget = t->budgetFixed > 0 ? t->budgetFixed : 6;
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
   }
   if (sample) {

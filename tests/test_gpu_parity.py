@@ -943,6 +943,40 @@ def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("budget", [1, 3])
+def test_running_out_of_launch_budget_changes_nothing(oracle, hip, budget, monkeypatch):
+    """A job that needs more k_track_step launches than the host enqueued: the budget's last launch reports it (TrackSummary::exhausted,
+    pinned memory — the wait loop polls that next to `done`, no hipStreamQuery), the host appends launches and the chain continues
+    from the state in HBM.  LSDHIP_BUDGET_FIXED makes every job run out several times; pose, counters, residual and the frame's
+    refPixelWasGood are those of the normally budgeted run, bit for bit."""
+    w, h = 640, 480
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 5)
+    kf = hip.Frame(ctx, 0, frames[0])
+    kf.setDepthFromGroundTruth(depth0)
+    ref = hip.TrackingReference()
+    ref.importFrame(kf)
+    tr_a = hip.SE3Tracker(ctx)
+    monkeypatch.setenv("LSDHIP_BUDGET_FIXED", str(budget))
+    tr_b = hip.SE3Tracker(ctx)                  # the environment is read when the tracker is created
+    monkeypatch.delenv("LSDHIP_BUDGET_FIXED")
+    tr_a.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr_b.set_maxItsPerLvl(ODOMETRY_ITS)
+    init = IDENT7.copy()
+    for i in range(1, 5):
+        fa, fb = hip.Frame(ctx, i, frames[i]), hip.Frame(ctx, i, frames[i])
+        pa = tr_a.trackFrame(ref, fa, init)
+        pb = tr_b.trackFrame(ref, fb, init)
+        assert np.array_equal(pa, pb), (i, pa, pb)
+        for k in ("numEvaluations", "numWarpUpdates", "lastResidual", "pointUsage", "lastGoodCount", "lastBadCount", "lastMeanRes",
+                  "affineEstimation_a", "affineEstimation_b", "diverged", "trackingWasGood"):
+            assert getattr(tr_a.last, k) == getattr(tr_b.last, k), (i, k)
+        assert_bit_equal(fa.refPixelWasGoodNoCreate(), fb.refPixelWasGoodNoCreate(), "refPixelWasGood")
+        la, lb = tr_a.launch_stats()[0], tr_b.launch_stats()[0]
+        assert la == lb and la > 2 * budget, (la, lb)        # same launches that did work; more than two budgets' worth
+        init = pa
+
+
+@pytest.mark.gpu
 def test_speculation_default_matches_oracle_sequence(oracle, hip):
     """the library default (5 / 5 / 6 trials at levels 1 / 2 / 3 of a 640x480 frame) against the oracle over a few frames"""
     w, h = 640, 480
