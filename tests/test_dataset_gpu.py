@@ -98,6 +98,33 @@ def test_cpp_loop_rccl_gather_single_rank():
 
 
 @pytest.mark.gpu
+def test_cpp_loop_is_deterministic_run_to_run():
+    """The C++ track + map loop (asynchronous mapping behind tracking, next frame's pyramids queued by the enqueue hook, launch budgets
+    from the recent jobs, top-ups) gives the same poses, evaluation and launch counts, bit for bit, in every run: no result depends on
+    timing.  (An experiment that built the next frame's pyramids on a second stream with a pinned-memory flag instead of an event
+    failed exactly this check once in five runs — profiles/r03_notes.md — and was dropped.)"""
+    import torch
+    from lsd_slam_amd.driver import DriverLoop
+    w, h, n = 640, 480, 150
+    frames, depth0, K, gt = sequence(w, h, 41)
+    dev = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+    ptr = lambda i: dev[i % dev.shape[0]].data_ptr()
+    base = None
+    for rep in range(4):
+        drv = DriverLoop(w, h, K, ptr(0), depth0, kf_every=10, images_on_device=True)
+        done, poses = drv.run([ptr(1 + k) for k in range(n)], want_poses=True)
+        st = drv.stats()
+        sig = (np.asarray(poses).tobytes(), int(st.track_launches), int(st.evaluations), int(st.keyframes))
+        drv.close()
+        assert done == n
+        if base is None:
+            base = sig
+        else:
+            assert sig[1:] == base[1:], (rep, sig[1:], base[1:])
+            assert sig[0] == base[0], "run %d: poses differ from run 0" % rep
+
+
+@pytest.mark.gpu
 def test_cpp_loop_stays_lost_after_a_tracking_loss():
     """SlamLoop::step after a tracking loss (SlamSystem.cpp:946-966, :809-817): the keyframe and the map are invalidated, the call
     reports LSDHIP_DIVERGED — and every FURTHER call fails with a state error instead of dereferencing the invalidated reference
