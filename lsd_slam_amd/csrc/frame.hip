@@ -423,6 +423,7 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->h_slots) (void)hipHostFree(c->h_slots);
   if (c->d_gtStage) (void)hipFree(c->d_gtStage);
+  if (c->d_flagArrive) (void)hipFree(c->d_flagArrive);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   (void)hipStreamDestroy(c->stream);
@@ -505,13 +506,27 @@ extern "C" void* lsdhip_ctx_aux_stream(lsdhip_ctx* c) { return c ? (void*)c->aux
 // A flag is an int in device memory that both processes map; values only grow.  Both operations are stream-ordered one-lane kernels:
 // set publishes everything the stream did before it (system-scope release), wait spins — bounded — until the flag has reached the
 // value and raises *fail otherwise.
-__global__ void k_flag_set(int* flag, int value) {
+// Both run as LSD_FLAG_WGS one-wave workgroups, dealt round-robin over the chip's 8 XCDs: the writes a set publishes may sit dirty in
+// any XCD's L2 and the data a wait is followed by may be cached stale in any XCD's L2 — and the other side is another process, whose
+// accesses this runtime's own cache bookkeeping between consecutive launches knows nothing about.  So every XCD runs the
+// system-scope release (set: before the last arriving workgroup raises the flag) or acquire (wait: after it has seen the flag).
+#define LSD_FLAG_WGS 16
+__global__ void k_flag_set(int* flag, int value, unsigned* arrive) {
+  if (threadIdx.x != 0) return;
   __threadfence_system();
-  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned n = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (n + 1 == gridDim.x) {
+    __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next set on this stream starts from zero
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 __global__ void k_flag_wait(const int* flag, int value, int* fail) {
+  if (threadIdx.x != 0) return;
   for (unsigned spins = 0; spins < (1u << 24); spins++) {          // ~2 s
-    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= value) return;
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= value) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                // system scope: this XCD's L2 drops what it cached of foreign memory
+      return;
+    }
     __builtin_amdgcn_s_sleep(8);
   }
   *fail = value;
@@ -547,7 +562,12 @@ extern "C" int lsdhip_ctx_flag_set(lsdhip_ctx* c, int* flag_dev, int value) {
   if (!c || !flag_dev) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, lsd_transport_stream(c), flag_dev, value);
+  if (!c->d_flagArrive) {
+    HIPCHK(hipMalloc((void**)&c->d_flagArrive, 64));
+    HIPCHK(hipMemset(c->d_flagArrive, 0, 64));
+  }
+  // (sets of one context are stream-ordered, on either of its streams in turn: one arrival counter serves them all)
+  hipLaunchKernelGGL(k_flag_set, dim3(LSD_FLAG_WGS), dim3(64), 0, lsd_transport_stream(c), flag_dev, value, c->d_flagArrive);
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }
@@ -555,7 +575,7 @@ extern "C" int lsdhip_ctx_flag_wait(lsdhip_ctx* c, const int* flag_dev, int valu
   if (!c || !flag_dev || !fail_dev) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, lsd_transport_stream(c), flag_dev, value, fail_dev);
+  hipLaunchKernelGGL(k_flag_wait, dim3(LSD_FLAG_WGS), dim3(64), 0, lsd_transport_stream(c), flag_dev, value, fail_dev);
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }

@@ -171,6 +171,7 @@ struct lsdhip_ctx {
   // calls): between lsdhip_ctx_aux_begin and lsdhip_ctx_aux_end they are queued there, ordered behind what the main stream held at
   // `begin`; lsdhip_ctx_aux_join makes the main stream wait for them.  Created on first use.
   hipStream_t aux_stream = nullptr;
+  unsigned* d_flagArrive = nullptr;      // arrival counter of k_flag_set's workgroups
   hipEvent_t aux_fork = nullptr, aux_done = nullptr;
   bool aux_active = false, aux_pending = false;
   // profiling of the residual kernel (bench.py roofline leg)
