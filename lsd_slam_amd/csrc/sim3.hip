@@ -540,7 +540,7 @@ static int sim3_run_batch(lsdhip_sim3tracker* t, Sim3Batch& batch, int nslots) {
     volatile const int* flag = (volatile const int*)(t->h_record + (size_t)k * 64) + 63;
     unsigned spins = 0;
     while (*flag != seq) {
-      if ((++spins & 4095u) == 0) {
+      if ((++spins & 0xFFFFFu) == 0) {   // safety net only: a stream query puts a marker packet into the queue (profiles/r03_notes.md §2b)
         hipError_t q = hipStreamQuery(c->stream);
         if (q != hipSuccess && q != hipErrorNotReady) { lsd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return LSDHIP_E_HIP; }
         if (std::chrono::steady_clock::now() - tStart > std::chrono::seconds(5)) { HIPCHK(hipStreamSynchronize(c->stream)); break; }
