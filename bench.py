@@ -198,7 +198,7 @@ def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
     achieved = nbytes / (ms * 1e-3) / 1e9
     out = {"bound": "hbm", "jobs_per_launch": jobs, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "evaluations": int(n_eval), "stream_ms": ms,
-           "kernel": "k_track_step<TS_LM> + k_track_step<TS_EVAL>, all launches of %d rounds of %d jobs (LM launches and coarse levels carry almost no bytes)" % (rounds, jobs)}
+           "kernel": "k_track_step<TS_LM> + k_track_step<TS_EVAL>, all launches of %d rounds of %d jobs (LM launches and the small pyramid levels carry almost no bytes)" % (rounds, jobs)}
     # the residual evaluation launch alone, per pyramid level, at fixed poses (lsdhip_tracker_eval_throughput: 20 identical launches
     # between two HIP events): level 1 is where the bytes are
     T = np.zeros((jobs, 7), np.float32)
@@ -308,8 +308,6 @@ def main():
                          "restates live operation, C/SlamSystem.cpp:559-571)")
     ap.add_argument("--trials", type=int, default=-1, help="LM retries evaluated per k_track_step launch (lsdhip_tracker_set_speculation); -1 = library default")
     ap.add_argument("--trial-cap", type=int, default=0, help="workgroups per trial at the finest level (0 = library default)")
-    ap.add_argument("--coarse", type=int, default=-1, help="lsdhip_tracker_set_coarse: 1 = coarsest levels in the cluster kernel, 0 = every level on the k_track_step chain, -1 = library default")
-    ap.add_argument("--fold", type=int, default=1, help="level-boundary speculation inside the cluster kernel (default 1)")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra host-image (PCIe-inclusive) measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work, gloo when there is no GPU): prints the JSON skeleton")
@@ -401,8 +399,6 @@ def main():
     from lsd_slam_amd.driver import DriverLoop
     from lsd_slam_amd import capi
     loop = DriverLoop(w, h, K, ptr(0), depth0, kf_every=KF_EVERY, images_on_device=True, device=local_rank)
-    if args.coarse >= 0:
-        loop.set_coarse(args.coarse, args.fold)
     if args.trials > 0:
         loop.set_speculation(args.trials, args.trial_cap)
     if args.live_queue > 1:
@@ -536,7 +532,6 @@ def main():
             "keyframe_ms": st.seconds_keyframe / st.keyframes * 1e3 if st.keyframes > 0 else None,
             "lm_evaluations_per_frame": st.evaluations / max(1, st.frames),
             "track_launches_per_frame": st.track_launches / max(1, st.frames),
-            "coarse_steps_per_frame": st.coarse_steps / max(1, st.frames),
             "lm_evaluations_per_frame_by_level": {"L%d" % l: st.level_evaluations[l] / max(1, st.frames) for l in (4, 3, 2, 1)},
             # self-validation: a loop that diverged or drifted shows here, not only in frames/s
             "validation": {"frames": int(st.frames), "tracked_good": int(st.tracked_good), "keyframes": int(st.keyframes),
@@ -544,7 +539,7 @@ def main():
                            "semidense_px": float(np.mean(kf_points)) if len(kf_points) else None,
                            "semidense_px_last": int(kf_points[-1]) if len(kf_points) else None,
                            "ok": bool(st.tracked_good == st.frames and rmse is not None and rmse < 5e-3 and len(kf_points) > 0 and np.min(kf_points) > 0.05 * w * h)},
-            "live_queue": args.live_queue, "coarse_cluster": args.coarse, "coarse_fold": args.fold,
+            "live_queue": args.live_queue,
             "roofline": roofline,
         }
         if obs_calls > 0 and obs_ms > 0:
@@ -573,8 +568,6 @@ def main():
                 h_frames = torch.from_numpy(frames).pin_memory()
                 hptr = lambda i: h_frames[order[i % len(order)]].data_ptr()
                 loop2 = DriverLoop(w, h, K, hptr(0), depth0, kf_every=KF_EVERY, images_on_device=False, device=local_rank)
-                if args.coarse >= 0:
-                    loop2.set_coarse(args.coarse, args.fold)
                 if args.trials > 0:
                     loop2.set_speculation(args.trials, args.trial_cap)
                 n2 = min(args.steps, 200)

@@ -309,10 +309,7 @@ class SE3Tracker {
   int numEvaluations = 0, numWarpUpdates = 0;  // instrumentation (residual-kernel launches, LM outer iterations)
   int levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};   // evaluations of the last trackFrame per pyramid level
   int numLaunches = 0;                         // evaluating launches of the last job (< numEvaluations: retries share launches)
-  int numCoarseSteps = 0;                      // steps the coarse-level cluster kernel ran inside its one launch (last job)
   void setSpeculation(int trials, int finestLevelWorkgroups = 0) { check(lsdhip_tracker_set_speculation(h_, trials, finestLevelWorkgroups), "lsdhip_tracker_set_speculation"); }
-  // execution strategy on the device (lsdhip_tracker_set_coarse): coarsest levels in one launch of the cluster kernel (default)
-  void setCoarse(bool enable, bool fold = true) { check(lsdhip_tracker_set_coarse(h_, enable ? 1 : 0, fold ? 1 : 0), "lsdhip_tracker_set_coarse"); }
 
  private:
   void pushSettings() {   // the public `settings` member is plain data in the reference: hand it over before every job
@@ -336,8 +333,6 @@ class SE3Tracker {
     if (lsdhip_tracker_exec_stats(h_, st) == 0) for (int l = 0; l < LSDHIP_PYRAMID_LEVELS; l++) levelEvaluations[l] = st[3 + l];
     int ls[2];
     if (lsdhip_tracker_launch_stats(h_, ls) == 0) numLaunches = ls[0];
-    int ss[4];
-    if (lsdhip_tracker_step_stats(h_, ss) == 0) numCoarseSteps = ss[1];
   }
   static void hookTrampoline(void* self) {
     SE3Tracker* t = static_cast<SE3Tracker*>(self);
@@ -538,7 +533,6 @@ class SlamLoop {
     pendingNext_ = nullptr;
     evaluations += tracker.numEvaluations;
     launches += tracker.numLaunches;
-    coarseSteps += tracker.numCoarseSteps;
     for (int l = 0; l < LSDHIP_PYRAMID_LEVELS; l++) levelEvaluations[l] += tracker.levelEvaluations[l];
     if (tracker.trackingWasGood) numTrackedGood++;
     numTracked++;
@@ -613,7 +607,7 @@ class SlamLoop {
   std::shared_ptr<Frame> keyframe;
   bool newKeyframe = false;
   bool trackingLost = false;                         // set before step() throws: SlamSystem::trackingIsGood == false
-  long evaluations = 0, launches = 0, coarseSteps = 0, numTracked = 0, numUpdates = 0, numTrackedGood = 0;
+  long evaluations = 0, launches = 0, numTracked = 0, numUpdates = 0, numTrackedGood = 0;
   long levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};
   double lastTrackEnd = 0;
   int liveQueueLength = 1;                           // frames handed to updateKeyframe per mapping iteration

@@ -151,20 +151,9 @@ typedef struct lsdhip_tracker_settings {
 } lsdhip_tracker_settings;
 int lsdhip_tracker_get_settings(const lsdhip_tracker* t, lsdhip_tracker_settings* out);
 int lsdhip_tracker_set_settings(lsdhip_tracker* t, const lsdhip_tracker_settings* in);
-/* Execution strategy of trackFrame on the device (no reference counterpart; results are the same up to summation order).
- * enable = 1 (default): the coarsest pyramid levels of a trackFrame job — those whose pixel counts together fit 6400 LDS list
- * entries (levels 4 + 3 of a 640x480 frame), never the finest level of the job — run their whole LM loops in ONE launch of
- * k_track_coarse: one 512-lane workgroup per speculative trial evaluates the whole level from an LDS-resident point list, one
- * {tag, value}-granule exchange per step, the same decision taken in every workgroup.  The k_track_step chain (one launch per
- * step) continues with the finer levels.  fold = 1 (default, only with more than one trial per step): a further workgroup
- * evaluates the next level's first evaluation at the last accepted pose while a trial set is being evaluated, so a level that
- * ends in a chain of rejections costs no extra step.  enable = 0: every level on the chain.  Environment at creation:
- * LSDHIP_COARSE=0 / LSDHIP_COARSE_FOLD=0. */
-int lsdhip_tracker_set_coarse(lsdhip_tracker* t, int enable, int fold);
-/* Diagnostics (no reference counterpart): how trackFrame jobs were executed on the device so far.
- * out[0] = jobs whose coarse levels ran in the cluster kernel, out[1] = jobs it gave up on (bounded spins) and that were rerun on
- * the chain, out[2] = 1 if the cluster kernel has been switched off after repeated give-ups; evaluations of
- * the last job per pyramid level 0..4 follow in out[3..7]. */
+/* Diagnostics (no reference counterpart): out[0..2] = 0 (reserved: the counters of round 3's coarse-level cluster kernel, removed in
+ * round 4 after it measured slower than the launch chain, profiles/r03_notes.md section 3); residual evaluations of the last job per
+ * pyramid level 0..4 in out[3..7]. */
 int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
 /* Execution strategy of the launch-per-step chain: the LM loop's "increase lambda and retry" sequence
  * (C/Tracking/SE3Tracker.cpp:341-447) depends only on A, b and lambda, so a step evaluates the next `trials` retries side by side and
@@ -176,12 +165,11 @@ int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
  * other values are rounded down to a multiple of 8 (one band of tiles per XCD), values below 8 up to 8.  The per-level overrides of
  * the environment (LSDHIP_SPEC_LEVELS) are cleared by this call. */
 int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups);
-/* out[0] = kernel launches of the last job that evaluated (k_track_step launches + 1 if the cluster kernel ran; <= its
- * numEvaluations), out[1] = most trials per step (the per-level numbers follow the automatic policy above). */
+/* out[0] = k_track_step launches of the last job that evaluated (<= its numEvaluations), out[1] = most trials per step (the
+ * per-level numbers follow the automatic policy above). */
 int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
-/* out[0] = k_track_step launches of the last job that evaluated, out[1] = steps (evaluate -> exchange -> decide) inside the
- * cluster kernel, out[2] = cluster-kernel launches (0 / 1), out[3] = most trials per step.  Dependent steps of the job =
- * out[0] + out[1]. */
+/* out[0] = k_track_step launches of the last job that evaluated = its dependent steps, out[1] = out[2] = 0 (reserved), out[3] = most
+ * trials per step. */
 int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]);
 /* Execution form of the throughput-mode evaluation (batches of >= 8 jobs; no reference counterpart, same results up to summation
  * order).  on = 0 (default): k_track_step<.., TS_EVAL> — the strip's valid pixels compacted into an LDS list, keyframe planes and the
@@ -194,7 +182,9 @@ int lsdhip_tracker_set_batch_tiles(lsdhip_tracker* t, int on);
 /* Measurement hook (no reference counterpart): the throughput-mode residual evaluation launch alone — n >= 8 jobs
  * (keyframes[j], frames[j]) at pyramid level `level` and poses refToFrame (n x 7 floats: q w x y z, t), `repeats` identical launches
  * between two HIP events.  Reports the mean launch time and the algorithmic bytes of one launch over all jobs (SURVEY.md 8(d)
- * formula): bytes / time is the kernel's position against the HBM roofline (profiles/r03_sizes.md, bench.py). */
+ * formula): bytes / time is the kernel's position against the HBM roofline (profiles/r03_sizes.md, bench.py).
+ * Side effect: at level 1 the launches write frames[j]'s refPixelWasGood plane like a trackFrame job does (those bytes are part of the
+ * measured evaluation): do not run it on frames whose mask a later DepthMap::updateKeyframe is still to read. */
 int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames, const float* refToFrame,
                                    int level, int repeats, double* ms_per_launch, double* bytes_per_launch);
 /* Host-side pipelining: `fn(user)` is called on the calling thread by lsdhip_tracker_track once the job's launches are

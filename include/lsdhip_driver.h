@@ -19,8 +19,8 @@ typedef struct lsdloop_stats {
   long long evaluations;     /* residual evaluations (k_track_step launches that did work) */
   long long tracked_good;    /* frames whose trackFrame ended with trackingWasGood (C/Tracking/SE3Tracker.cpp:472-477) */
   long long level_evaluations[5];   /* residual evaluations per pyramid level 0..4 */
-  long long track_launches;  /* kernel launches of the tracking jobs that evaluated (k_track_step launches + the cluster kernel's one) */
-  long long coarse_steps;    /* steps the cluster kernel (k_track_coarse) ran inside its launches */
+  long long track_launches;  /* k_track_step launches of the tracking jobs that evaluated */
+  long long reserved0;
 } lsdloop_stats;
 /* K4 = fx, fy, cx, cy.  first_image / images: uint8 w*h, host memory or (images_on_device != 0) memory of `device`. */
 int lsdloop_create(int device, int w, int h, const float K4[4], const uint8_t* first_image, int images_on_device,
@@ -48,8 +48,6 @@ int lsdloop_keyframe_log(lsdloop* l, double* scales_out, long long* points_out, 
 /* frames handed to DepthMap::updateKeyframe per mapping iteration (1 = blockUntilMapped, the default; K > 1 restates live
  * operation where the mapper finds up to K tracked frames queued, C/SlamSystem.cpp:559-571) */
 int lsdloop_set_live_queue(lsdloop* l, int frames);
-/* trackFrame execution strategy on the device (lsdhip_tracker_set_coarse) */
-int lsdloop_set_coarse(lsdloop* l, int enable, int fold);
 /* LM retries evaluated per k_track_step launch (lsdhip_tracker_set_speculation); default 5, 1 = one evaluation per launch. */
 int lsdloop_set_speculation(lsdloop* l, int trials, int finest_level_workgroups);
 /* lsdhip_depth_observe_time of the loop's depth map */

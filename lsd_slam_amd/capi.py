@@ -96,7 +96,6 @@ def _signatures():
         "lsdhip_tracker_set_max_its": (i, [vp, vp]),
         "lsdhip_tracker_get_settings": (i, [vp, C.POINTER(TrackerSettings)]),
         "lsdhip_tracker_set_settings": (i, [vp, C.POINTER(TrackerSettings)]),
-        "lsdhip_tracker_set_coarse": (i, [vp, i, i]),
         "lsdhip_depth_copy_rows_batch": (i, [vp, i, vp]),
         "lsdhip_ctx_alloc_dev": (i, [vp, C.c_size_t, vp]),
         "lsdhip_ctx_ipc_export": (i, [vp, vp, vp]),

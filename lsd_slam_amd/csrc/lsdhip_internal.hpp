@@ -114,8 +114,6 @@ struct TrackState {
   int ncand;                 // trials the launch that produced the pending sums evaluated (>= 1)
   int lastCand;              // which of them was the last one the LM loop actually executed
   int numLaunches;           // k_track_step launches that did an evaluation so far
-  int coarseSteps;           // steps (evaluate -> exchange -> decide) the coarse-level cluster kernel ran for this job
-  float coarseBytes;         // algorithmic bytes of the evaluations that ran inside the cluster kernel (part of `bytes`)
 };
 
 // What the host reads back (pinned, device-mapped): written by k_lm_step when the job finishes (or every step in
@@ -129,8 +127,7 @@ struct TrackSummary {
   int levelEvals[LSD_LEVELS];
   int numLaunches;           // k_track_step launches that evaluated (< numEvaluations with reject-chain speculation)
   int seq;                   // (job tag << 12) | ordinal of the latest k_track_step launch of the chain that has started
-  int coarseSteps;           // steps of the coarse-level cluster kernel (k_track_coarse); 0 when the chain ran every level
-  double coarseBytes;        // algorithmic bytes of the evaluations inside the cluster kernel (included in `bytes`)
+  int pad1_;
   int exhausted;             // seq of the budget's last launch, written when that launch ends with the job unfinished: the host tops up
   int pad2_;
 };
@@ -244,15 +241,6 @@ struct lsdhip_tracker {
   float* d_partials = nullptr;    // TrackScratch arena (sums | topkey | topval), see tracker.hip
   int max_blocks = 0;
   TrackState* d_state = nullptr;  // [2], double-buffered by launch parity
-  unsigned long long* d_ctrows = nullptr;   // k_track_coarse: published rows [2][LSD_SPEC_MAX + 1][CT_ROW] ({tag, value} granules)
-  unsigned ctSalt = 0;            // per-launch tag salt (20 bits)
-  bool coarse = false;            // run trackFrame's coarsest levels in the cluster kernel (lsdhip_tracker_set_coarse / LSDHIP_COARSE=0)
-  bool coarseFold = true;         // level-boundary speculation inside it (only with more than one trial per step)
-  bool coarseOff = false;         // switched off after repeated give-ups
-  int coarseFallbacks = 0;        // jobs the cluster kernel gave up on (rerun on the k_track_step chain)
-  int coarseJobs = 0;             // jobs whose coarse levels ran in the cluster kernel
-  int coarseSteps = 0;            // steps of the cluster kernel in the last job
-  double coarseBytes = 0;         // algorithmic bytes of the last job's evaluations inside the cluster kernel
   int levelEvaluations[LSD_LEVELS] = {};   // evaluations of the last job per pyramid level
   int block = 256;                // workgroup size of k_track_step (LSDHIP_TRACK_BLOCK)
   int grid_cap = 304;             // most workgroups one evaluation uses (LSDHIP_TRACK_CAP); larger levels grid-stride
@@ -277,7 +265,6 @@ struct lsdhip_tracker {
   TrackSummary* h_summary = nullptr;  // pinned, device-mapped
   TrackSummary* d_summary = nullptr;  // device alias of h_summary
   unsigned long long* d_trace = nullptr;  // LSD_PHASE_TRACE developer build only
-  unsigned long long* d_ctrace = nullptr; // ... per-step marks of k_track_coarse
   // batch tracking (lsdhip_tracker_track_batch): per-job descriptions, states, scratch and summaries
   bool batchTiles = false;            // throughput mode evaluates with k_track_eval_tiles (LDS-staged image tiles; lsdhip_tracker_set_batch_tiles)
   int batch_capacity = 0;

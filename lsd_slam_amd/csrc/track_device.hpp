@@ -1,4 +1,4 @@
-// Device code shared by the tracking kernels (k_track_step in tracker.hip, k_track_coarse in tracker_coarse.hip): per-point
+// Device code shared by the tracking kernels (k_track_step in tracker.hip, the batch evaluation in tracker_batch.hip): per-point
 // arithmetic of K0-K3 in the reference's operation order, the wave-parallel Levenberg-Marquardt step, small reductions.  gfx950 only.
 //
 // Reference behaviour restated:
@@ -373,7 +373,6 @@ __device__ __forceinline__ void write_summary(const TrackState& s, const float* 
   out->bytes = s.bytes;
   for (int l = 0; l < LSD_LEVELS; l++) out->levelEvals[l] = s.levelEvals[l];
   out->numLaunches = s.numLaunches;
-  out->coarseSteps = s.coarseSteps; out->coarseBytes = s.coarseBytes;
   __threadfence_system();
   out->done = s.done;
 }

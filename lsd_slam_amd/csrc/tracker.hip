@@ -29,7 +29,6 @@
 #include <atomic>
 #include <chrono>
 #include "track_device.hpp"
-#include "tracker_coarse.hpp"
 #include "tracker_batch.hpp"
 
 
@@ -144,7 +143,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
       S.bytes = 0;
       for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
-      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0; S.coarseSteps = 0; S.coarseBytes = 0;
+      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
     }
     if (tid < 36) S.A[tid] = 0;
     if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
@@ -802,21 +801,12 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   HIPCHK(hipMalloc((void**)&t->d_partials, scratch_bytes));
   HIPCHK(hipMemsetAsync(t->d_partials, 0, scratch_bytes, c->stream));
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
+  HIPCHK(hipMemsetAsync(t->d_state, 0, 2 * sizeof(TrackState), c->stream));
 #ifdef LSD_PHASE_TRACE
   HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 20) * 8));
   HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 20) * 8, c->stream));
-  HIPCHK(hipMalloc((void**)&t->d_ctrace, (1 + 4096 * 16) * 8));
-  HIPCHK(hipMemsetAsync(t->d_ctrace, 0, (1 + 4096 * 16) * 8, c->stream));
 #endif
-  {
-    // cluster kernel (k_track_coarse): published rows, two step parities, {tag, value} granules
-    const size_t ct_bytes = lsd_track_coarse_rows_bytes();
-    HIPCHK(hipMalloc((void**)&t->d_ctrows, ct_bytes));
-    HIPCHK(hipMemsetAsync(t->d_ctrows, 0, ct_bytes, c->stream));
-    if (const char* e = getenv("LSDHIP_COARSE")) t->coarse = e[0] != '0';
-    if (const char* e = getenv("LSDHIP_COARSE_FOLD")) t->coarseFold = e[0] != '0';
-    if (const char* e = getenv("LSDHIP_BATCH_TILES")) t->batchTiles = e[0] == '1';
-  }
+  if (const char* e = getenv("LSDHIP_BATCH_TILES")) t->batchTiles = e[0] == '1';
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
   memset(t->h_summary, 0, sizeof(TrackSummary));
@@ -831,8 +821,8 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
 extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   if (!t) return;
   if (getenv("LSDHIP_TRACK_DEBUG") && t->dbgJobs > 0)
-    fprintf(stderr, "TRACKDBG jobs %lld launches enqueued %.2f/job, budget misses %lld, host launch %.1f us/job, host wait %.1f us/job, cluster jobs %d (fallbacks %d)\n", t->dbgJobs,
-            (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs, t->coarseJobs, t->coarseFallbacks);
+    fprintf(stderr, "TRACKDBG jobs %lld launches enqueued %.2f/job, budget misses %lld, host launch %.1f us/job, host wait %.1f us/job\n", t->dbgJobs,
+            (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs);
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
 #ifdef LSD_PHASE_TRACE
@@ -850,25 +840,10 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
     }
   }
   (void)hipFree(t->d_trace);
-  if (const char* path = getenv("LSDHIP_CTRACE_FILE")) {
-    std::vector<unsigned long long> h(1 + 4096 * 16);
-    if (hipMemcpy(h.data(), t->d_ctrace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-      if (FILE* f = fopen(path, "w")) {
-        unsigned long long n = h[0] < 4096 ? h[0] : 4096;
-        for (unsigned long long i = 0; i < n; i++) {
-          for (int k = 0; k < 16; k++) fprintf(f, "%llu ", h[1 + i * 16 + k]);
-          fprintf(f, "\n");
-        }
-        fclose(f);
-      }
-    }
-  }
-  (void)hipFree(t->d_ctrace);
 #endif
   if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   (void)hipFree(t->d_partials);
   (void)hipFree(t->d_maskSide);
-  (void)hipFree(t->d_ctrows);
   (void)hipFree(t->d_state);
   (void)hipHostFree(t->h_summary);
   if (t->d_pts) (void)hipFree(t->d_pts);
@@ -904,18 +879,9 @@ extern "C" int lsdhip_tracker_set_settings(lsdhip_tracker* t, const lsdhip_track
   t->huber_d = in->huber_d; t->var_weight = in->var_weight;
   return LSDHIP_OK;
 }
-extern "C" int lsdhip_tracker_set_coarse(lsdhip_tracker* t, int enable, int fold) {
-  if (!t) return LSDHIP_E_ARG;
-  LSD_CTX_LOCK(t->ctx);
-  t->coarse = enable != 0;
-  t->coarseFold = fold != 0;
-  t->coarseOff = false;
-  for (int i = 0; i < 4; i++) t->recent[i] = 0;
-  return LSDHIP_OK;
-}
 extern "C" int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]) {
   if (!t || !out) return LSDHIP_E_ARG;
-  out[0] = t->coarseJobs; out[1] = t->coarseFallbacks; out[2] = t->coarseOff ? 1 : 0;
+  out[0] = 0; out[1] = 0; out[2] = 0;   // (were: cluster-kernel job counts — the kernel was removed in round 4, profiles/r03_notes.md §3)
   for (int l = 0; l < LSD_LEVELS; l++) out[3 + l] = t->levelEvaluations[l];
   return LSDHIP_OK;
 }
@@ -931,12 +897,12 @@ extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int
 }
 extern "C" int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]) {
   if (!t || !out) return LSDHIP_E_ARG;
-  out[0] = t->numLaunches + (t->coarseSteps > 0 ? 1 : 0); out[1] = t->specC;
+  out[0] = t->numLaunches; out[1] = t->specC;
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]) {
   if (!t || !out) return LSDHIP_E_ARG;
-  out[0] = t->numLaunches; out[1] = t->coarseSteps; out[2] = t->coarseSteps > 0 ? 1 : 0; out[3] = t->specC;
+  out[0] = t->numLaunches; out[1] = 0; out[2] = 0; out[3] = t->specC;
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_tracker_set_max_its(lsdhip_tracker* t, const int its[LSD_LEVELS]) {
@@ -1242,45 +1208,10 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   int guard = 0;
   int parity = 0, first = 1;
   if (int rc = prof_collect(c)) return rc;
-  // Cluster kernel (k_track_coarse): the coarsest levels of a trackFrame job — dense keyframe planes whose pixel counts
-  // together fit the LDS lists (CT_POOL), never the job's finest level — run in ONE launch; the k_track_step chain continues
-  // from the state it leaves in d_state[0 / 1].
-  CoarsePlan plan;
-  memset(&plan, 0, sizeof(plan));
-  bool useCoarse = false;
-  if (t->coarse && !t->coarseOff && job.trackFrameSemantics && topLevel > job.lastLevel) {
-    int low = topLevel + 1;
-    plan.gmax = 1;
-    for (int l = topLevel; l > job.lastLevel && l > topLevel - CT_LEVELS; l--) {
-      const TrackLevel& L = job.lv[l];
-      const long long work = (long long)L.w * L.h;
-      if (L.npts >= 0 || work > CT_POOL || L.w > 32767 || L.h > 32767) break;
-      const int G = (int)((work + CT_BLOCK - 1) / CT_BLOCK);
-      if (G > plan.gmax) plan.gmax = G;
-      low = l;
-    }
-    if (low <= topLevel) {
-      useCoarse = true;
-      plan.low = low;
-      plan.nt = 1;
-      for (int l = low; l <= topLevel; l++) {
-        plan.trials[l] = t->spec.trials[l] > 1 ? t->spec.trials[l] : 1;
-        if (plan.trials[l] > plan.nt) plan.nt = plan.trials[l];
-      }
-    }
-  }
-  bool usedCoarse = false;
   lsdhip_host_mark(2);
   while (true) {
     if (sample) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     int rc = LSDHIP_OK;
-    if (useCoarse && guard == 0) {
-      if (int rcc = lsd_track_coarse_launch(t, job, plan)) return rcc;
-      usedCoarse = true;
-      t->coarseJobs++;
-      first = 0;
-      parity = 0;
-    }
     rc = launch_steps(t, job, budget, &parity, &first);
     if (rc) return rc;
     if (sample) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
@@ -1318,22 +1249,9 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     }
     }
     lsdhip_host_mark(5);
-    if (S->done == 2) {
-      // the cluster kernel gave up on a spin (it never should): rerun the job on the launch-per-evaluation chain
-      HIPCHK(hipStreamSynchronize(c->stream));
-      t->coarseFallbacks++;
-      if (t->coarseFallbacks >= 3) t->coarseOff = true;
-      useCoarse = false;
-      t->h_summary->done = 0;
-      parity = 0; first = 1; guard = 1;
-      usedCoarse = false;
-      budget = 12;
-      continue;
-    }
     if (S->done) break;
     t->dbgMisses++;
     HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
-    if (S->done == 2) continue;
     if (S->done) break;
     if (int rc2 = prof_collect(c)) return rc2;
     if (t->jobKf && t->jobKf->depthVersion != t->jobKfVersion && guard < 8) {
@@ -1351,15 +1269,11 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
   }
   if (sample) {
-    // the roofline leg describes k_track_step: the cluster kernel's evaluations are neither in its bytes nor in its launches
-    // (their time is inside the bracket: a stated, small over-count of the chain's time)
-    c->prof_bytes += S->bytes - S->coarseBytes;
+    c->prof_bytes += S->bytes;
     c->prof_launches += S->numLaunches;
   }
   if (myEpoch > c->doneEpoch) c->doneEpoch = myEpoch;
   t->numLaunches = S->numLaunches;
-  t->coarseSteps = usedCoarse ? S->coarseSteps : 0;
-  t->coarseBytes = usedCoarse ? S->coarseBytes : 0;
   t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = t->numLaunches;
   for (int l = 0; l < LSD_LEVELS; l++) t->levelEvaluations[l] = S->levelEvals[l];
   t->numEvaluations = S->numEvaluations;
@@ -1675,9 +1589,13 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
   }
   TrackSummary* d_sum = nullptr;
   HIPCHK(hipHostGetDevicePointer((void**)&d_sum, t->h_bsummary, 0));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  struct EventPair {      // destroyed on every exit path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } evp;
+  HIPCHK(hipEventCreate(&evp.a));
+  HIPCHK(hipEventCreate(&evp.b));
+  const hipEvent_t e0 = evp.a, e1 = evp.b;
   hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
                      d_sum, 0, 1, TrackSpec{});
   auto eval_launch = [&]() -> int {
@@ -1697,8 +1615,6 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
   HIPCHK(hipStreamSynchronize(c->stream));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   double bytes = 0;
   for (int j = 0; j < n; j++) {
     if (!t->h_bsummary[j].done) { lsd_set_error("lsdhip_tracker_eval_throughput: job %d did not finish", j); return LSDHIP_E_STATE; }

@@ -130,7 +130,6 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       const long upd0 = L.numUpdates;
       const long ev0 = L.evaluations;
       const long la0 = L.launches;
-      const long cs0 = L.coarseSteps;
       const long good0 = L.numTrackedGood;
       long lev0[5];
       for (int k = 0; k < 5; k++) lev0[k] = L.levelEvaluations[k];
@@ -139,7 +138,6 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       l->st.updates += L.numUpdates - upd0;
       l->st.evaluations += L.evaluations - ev0;
       l->st.track_launches += L.launches - la0;
-      l->st.coarse_steps += L.coarseSteps - cs0;
       l->st.tracked_good += L.numTrackedGood - good0;
       for (int k = 0; k < 5; k++) l->st.level_evaluations[k] += L.levelEvaluations[k] - lev0[k];
       if (L.newKeyframe) l->st.keyframes++;
@@ -229,11 +227,6 @@ extern "C" int lsdloop_set_live_queue(lsdloop* l, int frames) {
   if (!l || frames < 1) return LSDHIP_E_ARG;
   l->loop->liveQueueLength = frames;
   return LSDHIP_OK;
-}
-extern "C" int lsdloop_set_coarse(lsdloop* l, int enable, int fold) {
-  if (!l) return LSDHIP_E_ARG;
-  try { l->loop->tracker.setCoarse(enable != 0, fold != 0); return LSDHIP_OK; }
-  catch (const Error& e) { g_err = e.what(); return e.status; }
 }
 extern "C" int lsdloop_set_speculation(lsdloop* l, int trials, int finest_level_workgroups) {
   if (!l) return LSDHIP_E_ARG;
@@ -593,19 +586,37 @@ extern "C" int lsdband_layout(const lsdband* b, int band, int out4[4]) {
 // rows [a, b) of the full map for local window `local`: hypotheses in the reference's 32-byte AoS layout + maxGradients
 extern "C" int lsdband_load(lsdband* b, int local, const void* hyp_window, const float* maxgrad_window) {
   if (!b || local < 0 || local >= b->nlocal || !hyp_window || !maxgrad_window) return LSDHIP_E_ARG;
+  b->passes_run = 0;   // fresh data in the window, halo rows included: no refresh is owed before the next call's first pass
   int rc = lsdhip_frame_set_maxgrad(b->kf[local], maxgrad_window);
   if (rc == LSDHIP_OK) rc = lsdhip_depth_upload(b->dm[local], b->kf[local], (const lsdhip_hypothesis*)hyp_window, 0);
   if (rc != LSDHIP_OK) g_err = lsdhip_last_error();
   return rc;
 }
+static int band_check_fail(lsdband* b);
 extern "C" int lsdband_get(lsdband* b, int local, void* hyp_window_out) {
   if (!b || local < 0 || local >= b->nlocal || !hyp_window_out) return LSDHIP_E_ARG;
   int rc = lsdhip_ctx_synchronize(b->ctx);
+  if (rc == LSDHIP_OK && (rc = band_check_fail(b)) != LSDHIP_OK) return rc;
   if (rc == LSDHIP_OK) rc = lsdhip_depth_download(b->dm[local], (lsdhip_hypothesis*)hyp_window_out);
   if (rc != LSDHIP_OK) g_err = lsdhip_last_error();
   return rc;
 }
-extern "C" int lsdband_synchronize(lsdband* b) { return b ? lsdhip_ctx_synchronize(b->ctx) : LSDHIP_E_ARG; }
+// Waits for everything queued.  On the IPC transport a flag wait that gave up (a wedged or dead peer: k_flag_wait's bounded spin)
+// leaves the value it waited for in the mailbox's fail word and the stream carries on with stale rows: the maps are then INVALID and
+// this returns LSDHIP_E_STATE (lsdband_last error text names the flag value); lsdband_get refuses likewise.
+static int band_check_fail(lsdband* b) {
+  if (!b->ipc || !b->mailbox) return LSDHIP_OK;
+  int v = 0;
+  if (lsdhip_ctx_read_dev(b->ctx, &v, b->mailbox, sizeof(int)) != LSDHIP_OK) { g_err = lsdhip_last_error(); return LSDHIP_E_HIP; }
+  if (v != 0) { g_err = "lsdband: a halo flag wait timed out at value " + std::to_string(v) + " (peer process wedged or gone): results are invalid"; return LSDHIP_E_STATE; }
+  return LSDHIP_OK;
+}
+extern "C" int lsdband_synchronize(lsdband* b) {
+  if (!b) return LSDHIP_E_ARG;
+  const int rc = lsdhip_ctx_synchronize(b->ctx);
+  if (rc != LSDHIP_OK) { g_err = lsdhip_last_error(); return rc; }
+  return band_check_fail(b);
+}
 // one process per GPU: process p of nprocs holds the bands with proc_of_band[r] == p (must match its lsdband_create range)
 extern "C" int lsdband_comm_init(lsdband* b, const void* unique_id128, int nprocs, int proc, const int* proc_of_band) {
   if (!b || !unique_id128 || nprocs < 1 || proc < 0 || proc >= nprocs || !proc_of_band) return LSDHIP_E_ARG;
@@ -756,26 +767,10 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
     for (int i = 0; i < b->nlocal; i++) runs[i] = band_tile_runs(*b, b->first + i);
     const bool remote = b->ipc || !sends.empty() || !recvs.empty();
     const bool overlap = b->overlap && remote;
-    for (int p = 0; p < passes; p++) {
-      if (overlap) {
-        // edge parts first (they wait for the previous exchange), the exchange forks behind them, interior parts run beside it
-        check(lsdhip_ctx_aux_join(b->ctx), "lsdhip_ctx_aux_join");
-        for (int i = 0; i < b->nlocal; i++)
-          for (const BandRun& u : runs[i]) if (u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
-        if (p + 1 < passes) check(lsdhip_ctx_aux_begin(b->ctx), "lsdhip_ctx_aux_begin");
-        for (int i = 0; i < b->nlocal; i++) {
-          for (const BandRun& u : runs[i]) if (!u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
-          check(lsdhip_depth_stage_rows(b->dm[i], 5, 0, 0, 1), "lsdhip_depth_stage_rows");   // validity planes swapped: the pass is queued
-        }
-      } else {
-        for (int i = 0; i < b->nlocal; i++) {
-          const int t0 = runs[i].front().t0, t1 = runs[i].back().t0 + runs[i].back().n;
-          check(lsdhip_depth_stage_rows(b->dm[i], 5, t0, t1 - t0, 1), "lsdhip_depth_stage_rows");
-        }
-      }
-      b->passes_run++;
-      if (p + 1 == passes) break;
-      void* xstream = overlap ? lsdhip_ctx_aux_stream(b->ctx) : stream;
+    // one halo exchange: every window's non-owned rows are refreshed from their owners.  onAux: between lsdhip_ctx_aux_begin / _end
+    // (the transport primitives go to the transport stream, and so do the RCCL calls); otherwise everything on the main stream
+    auto exchange = [&](bool onAux) {
+      void* xstream = onAux ? lsdhip_ctx_aux_stream(b->ctx) : stream;
       // the halo rows a window receives are never rows it owns, and sources are always owned rows: the copies of one
       // exchange cannot overwrite each other's inputs, so one launch serves all of them
       if (!packs.empty()) check(lsdhip_depth_copy_rows_batch(b->ctx, (int)packs.size(), packs.data()), "lsdhip_depth_copy_rows_batch");
@@ -814,6 +809,31 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
         nc(R.GroupEnd(), "ncclGroupEnd");
         check(lsdhip_depth_copy_rows_batch(b->ctx, (int)unpacks.size(), unpacks.data()), "lsdhip_depth_copy_rows_batch");
       }
+    };
+    // A call ends with its last pass, not with an exchange (the caller may only want the owned rows): when passes of an earlier call
+    // have run, the halo rows are one pass old (and tile rows without an owned row are never computed locally), so the refresh that
+    // belongs between that pass and this call's first one is queued here, on the main stream.
+    if (passes > 0 && b->passes_run > 0) exchange(false);
+    for (int p = 0; p < passes; p++) {
+      if (overlap) {
+        // edge parts first (they wait for the previous exchange), the exchange forks behind them, interior parts run beside it
+        check(lsdhip_ctx_aux_join(b->ctx), "lsdhip_ctx_aux_join");
+        for (int i = 0; i < b->nlocal; i++)
+          for (const BandRun& u : runs[i]) if (u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
+        if (p + 1 < passes) check(lsdhip_ctx_aux_begin(b->ctx), "lsdhip_ctx_aux_begin");
+        for (int i = 0; i < b->nlocal; i++) {
+          for (const BandRun& u : runs[i]) if (!u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
+          check(lsdhip_depth_stage_rows(b->dm[i], 5, 0, 0, 1), "lsdhip_depth_stage_rows");   // validity planes swapped: the pass is queued
+        }
+      } else {
+        for (int i = 0; i < b->nlocal; i++) {
+          const int t0 = runs[i].front().t0, t1 = runs[i].back().t0 + runs[i].back().n;
+          check(lsdhip_depth_stage_rows(b->dm[i], 5, t0, t1 - t0, 1), "lsdhip_depth_stage_rows");
+        }
+      }
+      b->passes_run++;
+      if (p + 1 == passes) break;
+      exchange(overlap);
       if (overlap) check(lsdhip_ctx_aux_end(b->ctx), "lsdhip_ctx_aux_end");
     }
     if (overlap) check(lsdhip_ctx_aux_join(b->ctx), "lsdhip_ctx_aux_join");

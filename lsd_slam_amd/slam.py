@@ -231,9 +231,6 @@ class SE3Tracker:
     def set_settings(self, st):
         check(self.L.lsdhip_tracker_set_settings(self.h_, C.byref(st)))
 
-    def set_coarse(self, enable, fold=True):
-        """coarsest pyramid levels in one launch of the cluster kernel (default on) / level-boundary speculation; see include/lsdhip.h"""
-        check(self.L.lsdhip_tracker_set_coarse(self.h_, int(bool(enable)), int(bool(fold))))
 
     def set_speculation(self, trials, finest_level_workgroups=0):
         """LM retries evaluated per launch (1 = one evaluation per launch); see include/lsdhip.h"""

@@ -800,50 +800,6 @@ def test_permaref_batch_matches_single_and_oracle(oracle, hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,fold", [((640, 480), 1), ((640, 480), 0), ((320, 240), 1), ((160, 128), 1), ((1280, 1024), 1)])
-def test_coarse_cluster_kernel_matches_the_chain(oracle, hip, size, fold):
-    """lsdhip_tracker_set_coarse: the coarsest levels of trackFrame in ONE launch of k_track_coarse (a 512-lane workgroup per
-    speculative trial evaluates the whole level from an LDS point list; one granule exchange per step; optional level-boundary
-    speculation) give what the launch-per-step chain gives — same points, same per-point arithmetic, same LM step, another
-    summation order — and the kernel never gives up on a spin.  640x480: levels 4 + 3; 320x240 / 160x128: levels 4, 3, 2; 1280x1024: level 4."""
-    w, h = size
-    n = 6 if w <= 640 else 4
-    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, n)
-    kf = hip.Frame(ctx, 0, frames[0])
-    kf.setDepthFromGroundTruth(depth0)
-    ref = hip.TrackingReference()
-    ref.importFrame(kf)
-    tr_a, tr_b = hip.SE3Tracker(ctx), hip.SE3Tracker(ctx)
-    tr_a.set_maxItsPerLvl(ODOMETRY_ITS)
-    tr_b.set_maxItsPerLvl(ODOMETRY_ITS)
-    tr_a.set_coarse(False)
-    tr_b.set_coarse(True, bool(fold))
-    init = IDENT7.copy()
-    for i in range(1, n):
-        fa, fb = hip.Frame(ctx, i, frames[i]), hip.Frame(ctx, i, frames[i])
-        pa = tr_a.trackFrame(ref, fa, init)
-        pb = tr_b.trackFrame(ref, fb, init)
-        dt, dr = pose_distance(pa, pb, oracle)
-        assert max(dt, dr) < 2e-5, (i, dt, dr)
-        assert (tr_a.diverged, tr_a.trackingWasGood) == (tr_b.diverged, tr_b.trackingWasGood)
-        assert abs(tr_a.last.numEvaluations - tr_b.last.numEvaluations) <= 2
-        assert tr_b.lastResidual == pytest.approx(tr_a.lastResidual, rel=1e-3) and tr_b.pointUsage == pytest.approx(tr_a.pointUsage, rel=1e-5)
-        assert (fa.refPixelWasGoodNoCreate() != fb.refPixelWasGoodNoCreate()).mean() < 1e-3
-        chain_a, steps_a, launches_a, _ = tr_a.step_stats()
-        chain_b, steps_b, launches_b, _ = tr_b.step_stats()
-        assert (steps_a, launches_a) == (0, 0) and launches_b == 1 and steps_b >= 1
-        assert chain_b < chain_a                      # the coarse levels' launches are gone from the chain
-        init = pa
-    jobs, fallbacks, off, levels = tr_b.exec_stats()
-    assert jobs == n - 1 and fallbacks == 0 and not off
-    assert sum(levels) == tr_b.last.numEvaluations and levels[4] == 1
-    # divergence inside the cluster kernel: identity + flags
-    bad = oracle.se3_exp(np.array([5.0, 0, 0, 0, 0, 0]))
-    est = tr_b.trackFrame(ref, hip.Frame(ctx, 9, frames[1]), bad)
-    assert tr_b.diverged and not tr_b.trackingWasGood and np.array_equal(est, IDENT7)
-
-
-@pytest.mark.gpu
 def test_tracker_settings_block_reaches_the_device(oracle, hip):
     """lsdhip_tracker_set_settings: every DenseDepthTrackerSettings field (C/util/settings.h:355-402).  Defaults equal the
     reference's; changed fields change the run the way they change the oracle's."""
@@ -884,16 +840,12 @@ def test_tracker_settings_block_reaches_the_device(oracle, hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("trials,coarse,params", [(2, 1, {}), (5, 1, {}), (6, 1, {}), (6, 1, {"useAffineLightningEstimation": 0}),
-                                                  (2, 0, {}), (5, 0, {}), (6, 0, {})])
-def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip, trials, coarse, params):
+@pytest.mark.parametrize("trials,params", [(2, {}), (5, {}), (6, {}), (6, {"useAffineLightningEstimation": 0})])
+def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip, trials, params):
     """lsdhip_tracker_set_speculation: a step evaluates the next `trials` poses of the LM loop's retry chain side by side and the
     next step consumes them in the reference's order.  With the same workgroups per trial as the one-evaluation-per-step run
     (identical partial-sum tiling) every output is the same BIT FOR BIT — pose, counters, residual, the frame's refPixelWasGood
-    (which must be what the last trial the LM loop executed wrote, not what a later speculative one did) — in fewer dependent steps.
-    coarse = 1: levels 4 + 3 inside the cluster kernel (one workgroup per trial + level-boundary speculation, which is off in the
-    one-trial run), levels 2 + 1 on the k_track_step chain; coarse = 0: every level on the chain.  Without affine lighting the
-    boundary speculation also covers level 4 -> 3 (level 4 runs no iteration: SlamSystem.cpp:80-81)."""
+    (which must be what the last trial the LM loop executed wrote, not what a later speculative one did) — in fewer dependent steps."""
     w, h = 640, 480
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 8, params=params)
     kf = hip.Frame(ctx, 0, frames[0])
@@ -903,8 +855,6 @@ def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip,
     tr_a, tr_b = hip.SE3Tracker(ctx), hip.SE3Tracker(ctx)
     tr_a.set_maxItsPerLvl(ODOMETRY_ITS)
     tr_b.set_maxItsPerLvl(ODOMETRY_ITS)
-    tr_a.set_coarse(bool(coarse))
-    tr_b.set_coarse(bool(coarse))
     tr_a.set_speculation(1)
     tr_b.set_speculation(trials, 304)       # 304 = the single-trial grid at 320x240 (level 1)
     init = IDENT7.copy()
@@ -921,8 +871,8 @@ def test_speculative_retries_give_the_one_evaluation_per_launch_run(oracle, hip,
         assert_bit_equal(fa.refPixelWasGoodNoCreate(), fb.refPixelWasGoodNoCreate(), "refPixelWasGood")
         ca, sa, ka, _ = tr_a.step_stats()
         cb_, sb, kb, cb = tr_b.step_stats()
-        la, lb = ca + sa, cb_ + sb                  # dependent steps: chain launches + steps inside the cluster kernel
-        assert cb == trials and la == tr_a.last.numEvaluations and lb <= la and ka == kb == coarse
+        la, lb = ca + sa, cb_ + sb                  # dependent steps = chain launches
+        assert cb == trials and la == tr_a.last.numEvaluations and lb <= la and ka == kb == 0
         saved += la - lb
         init = pa
     assert saved >= 7 * 3, saved           # the retry chains that end every level collapse into single launches

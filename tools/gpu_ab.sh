@@ -10,8 +10,8 @@ for spec in "$@"; do
 import json
 try:
     d = json.load(open("gpurun_out/ab_${label}_$rep.json"))
-    print("${label} #$rep: %.0f frames/s, %.4f ms/step, launches/frame %.2f, coarse steps/frame %.2f, evals %.2f, ok %s" % (
-        d["value"], d["ms_per_step"], d["track_launches_per_frame"], d.get("coarse_steps_per_frame", 0), d["lm_evaluations_per_frame"], d["validation"]["ok"]))
+    print("${label} #$rep: %.0f frames/s, %.4f ms/step, launches/frame %.2f, evals %.2f, ok %s" % (
+        d["value"], d["ms_per_step"], d["track_launches_per_frame"], d["lm_evaluations_per_frame"], d["validation"]["ok"]))
 except Exception as e:
     print("${label} #$rep: FAILED", e)
     print(open("gpurun_out/ab_${label}_$rep.err").read()[-2000:])
