@@ -140,11 +140,13 @@ def quat_to_rot(q):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def trajectory_rmse(poses, scales, gt_of_frame, first_scored):
+def trajectory_rmse(poses, scales, gt_of_frame, first_scored, lag=0):
     """Camera centres in the frame of image 0 from the loop's outputs — frame->keyframe poses chained through every keyframe change
     with the Sim3 scale createKeyFrame assigned (C/DepthEstimation/DepthMap.cpp:1305) — against the synthetic ground truth.
-    Returns (rmse over frames >= first_scored, number of keyframe changes)."""
+    lag = 1 (pipelined loop): the frame after a keyframe change is still expressed in the OLD keyframe (the tracker adopts the new one
+    a frame later) and is not mapped.  Returns (rmse over frames >= first_scored, number of keyframe changes)."""
     s, R, t = 1.0, np.eye(3), np.zeros(3)
+    pending = None
     since = k = 0
     err = []
     for i, est in enumerate(poses):
@@ -152,12 +154,18 @@ def trajectory_rmse(poses, scales, gt_of_frame, first_scored):
         if i >= first_scored:
             err.append(float(np.sum((c - gt_of_frame(i)[4:7]) ** 2)))
         since += 1
+        if pending is not None:        # this frame was tracked on the replaced keyframe: the tracker adopts the new one now
+            s, R, t = pending
+            pending = None
+            continue
         if since >= KF_EVERY:
             if k >= len(scales):
                 break
-            t = s * (R @ est[4:7]) + t
-            R = R @ quat_to_rot(est[:4])
-            s = s * float(scales[k])
+            new = (s * float(scales[k]), R @ quat_to_rot(est[:4]), s * (R @ est[4:7]) + t)
+            if lag:
+                pending = new
+            else:
+                s, R, t = new
             k += 1
             since = 0
     return (float(np.sqrt(np.mean(err))) if err else None), k
@@ -309,6 +317,10 @@ def main():
     ap.add_argument("--trials", type=int, default=-1, help="LM retries evaluated per k_track_step launch (lsdhip_tracker_set_speculation); -1 = library default")
     ap.add_argument("--trial-cap", type=int, default=0, help="workgroups per trial at the finest level (0 = library default)")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra host-image (PCIe-inclusive) measurement")
+    ap.add_argument("--block-until-mapped", action="store_true",
+                    help="one stream: every frame's mapping iteration runs behind its tracking and the next frame waits for it "
+                         "(SlamSystem's blockUntilMapped, C/SlamSystem.cpp:1026-1040).  Default: pipelined — tracking stream beside "
+                         "mapping stream, the mapper one frame behind (the reference's two threads; lsd_slam_hip::SlamLoop)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work, gloo when there is no GPU): prints the JSON skeleton")
     ap.add_argument("--repeats", type=int, default=0,
@@ -399,6 +411,9 @@ def main():
     from lsd_slam_amd.driver import DriverLoop
     from lsd_slam_amd import capi
     loop = DriverLoop(w, h, K, ptr(0), depth0, kf_every=KF_EVERY, images_on_device=True, device=local_rank)
+    pipelined = not args.block_until_mapped
+    if pipelined:
+        loop.set_pipeline(True)
     if args.trials > 0:
         loop.set_speculation(args.trials, args.trial_cap)
     if args.live_queue > 1:
@@ -498,7 +513,7 @@ def main():
     # ---- self-validation of the run that was just timed (nothing below is inside the timed region) ----------------------------------------
     poses_all = np.concatenate(state["poses"]) if state["poses"] else np.zeros((0, 7))
     kf_scales, kf_points = loop.keyframe_log()
-    rmse, n_kf = trajectory_rmse(poses_all, kf_scales, lambda i: gt[order[(i + 1) % len(order)]], args.warmup)
+    rmse, n_kf = trajectory_rmse(poses_all, kf_scales, lambda i: gt[order[(i + 1) % len(order)]], args.warmup, lag=1 if pipelined else 0)
     import ctypes as C
     ms_, n_, b_ = C.c_double(), C.c_longlong(), C.c_double()
     capi.check(L.lsdhip_prof_read(ctx_h, C.byref(ms_), C.byref(n_), C.byref(b_)))

@@ -105,6 +105,9 @@ class Context {
   void synchronize() { check(lsdhip_ctx_synchronize(h_), "lsdhip_ctx_synchronize"); }
   // mapping calls return after enqueueing; host-side results are picked up lazily (lsdhip.h: lsdhip_ctx_set_async)
   void setAsync(bool on) { check(lsdhip_ctx_set_async(h_, on ? 1 : 0), "lsdhip_ctx_set_async"); }
+  // tracking stream beside mapping stream (lsdhip.h: lsdhip_ctx_set_pipeline): the reference's two threads, blockUntilMapped == false
+  void setPipeline(bool on) { check(lsdhip_ctx_set_pipeline(h_, on ? 1 : 0), "lsdhip_ctx_set_pipeline"); }
+  bool pipeline() const { return lsdhip_ctx_pipeline(h_) == 1; }
 
  private:
   Context(int device, int w, int h, const Mat3f& K) : w_(w), h_px_(h), K_(K) {
@@ -131,6 +134,13 @@ class Frame {
   Frame(int id, int width, int height, const Mat3f& K, double timestamp, DeviceImage image)
       : ctx_(Context::get(width, height, K)), id_(id), timestamp_(timestamp) {
     check(lsdhip_frame_create_from_device(ctx_->handle(), id, image.ptr, &h_), "lsdhip_frame_create_from_device");
+  }
+  // host image whose bytes stay unchanged until the frame has been tracked (or the context synchronised): upload and pyramids are
+  // queued, nothing waits (lsdhip_frame_create_async)
+  struct HostImageAsync { const unsigned char* ptr; };
+  Frame(int id, int width, int height, const Mat3f& K, double timestamp, HostImageAsync image)
+      : ctx_(Context::get(width, height, K)), id_(id), timestamp_(timestamp) {
+    check(lsdhip_frame_create_async(ctx_->handle(), id, image.ptr, &h_), "lsdhip_frame_create_async");
   }
   Frame(const Frame&) = delete;
   Frame& operator=(const Frame&) = delete;
@@ -218,7 +228,14 @@ class TrackingReference {
  public:
   Frame* keyframe = nullptr;
   int frameID = -1;
-  void importFrame(Frame* source) { keyframe = source; frameID = source ? source->id() : -1; }
+  // TrackingReference.cpp:71-87.  The reference's object is a snapshot of the keyframe's depth taken here (lazily, at the next
+  // trackFrame); on a pipelined context this is the moment the mapping side's newest Frame::setDepth result is handed to the tracker
+  // (lsdhip_frame_publish_depth) — until then SE3Tracker jobs keep reading the planes of the previous import.
+  void importFrame(Frame* source) {
+    keyframe = source;
+    frameID = source ? source->id() : -1;
+    if (source) check(lsdhip_frame_publish_depth(source->handle()), "lsdhip_frame_publish_depth");
+  }
   void invalidate() { keyframe = nullptr; frameID = -1; }
   // returns the number of points; any output may be null (TrackingReference.cpp:96-147)
   int makePointCloud(int level, std::vector<float>* posData, std::vector<float>* colorAndVarData,
@@ -468,10 +485,20 @@ class DepthMap {
   lsdhip_depthmap* h_ = nullptr;
 };
 
-// The part of SlamSystem either side of the hot path, with doSlam = false and blockUntilMapped = true
-// (SlamSystem.cpp:890-1040 trackFrame, :739-828 doMappingIteration, :542-614 updateKeyframe, :458-490
-// createNewCurrentKeyframe) and a deterministic keyframe policy (a new keyframe every `kfEvery` frames) in place of the
-// distance / usage score.  Orchestration only: every per-pixel operation is a liblsdhip.so call.
+// The part of SlamSystem either side of the hot path with doSlam = false (SlamSystem.cpp:890-1040 trackFrame, :739-828
+// doMappingIteration, :542-614 updateKeyframe, :458-490 createNewCurrentKeyframe) and a deterministic keyframe policy (a new keyframe
+// every `kfEvery` frames) in place of the distance / usage score.  Orchestration only: every per-pixel operation is a liblsdhip.so call.
+//
+// Two execution models, both the reference's own:
+//   * blockUntilMapped = true (default): track frame t, then its mapping iteration, on one stream; frame t + 1 is tracked against what
+//     map(t) left (SlamSystem.cpp:1026-1040 with the wait);
+//   * pipelined (setPipelined(true); blockUntilMapped = false with the mapper exactly one frame behind): the mapping iteration of frame t
+//     is queued on the context's mapping stream when trackFrame(t) ends and runs BESIDE trackFrame(t + 1), which tracks against the
+//     keyframe and depth version map(t - 1) left — what the reference's tracking thread does when the mapping thread is still busy
+//     (:907-912: it re-imports the tracking reference only when it finds depthHasBeenUpdatedFlag set / the keyframe replaced).  The
+//     frame that follows a keyframe change is therefore still tracked on the old keyframe; the mapper drops it (updateKeyframe pops
+//     frames whose tracking parent is not the current keyframe, :559-566) and the first frame tracked on the new keyframe starts from
+//     se3FromSim3(newKeyframe^-1 * lastTrackedFrame) (:918-920).  The lag is fixed at one frame, so results do not depend on timing.
 class SlamLoop {
  public:
   // gtDepth0 != null: SlamSystem::gtDepthInit (SlamSystem.cpp:831-854); null: SlamSystem::randomInit (:857-881).
@@ -488,16 +515,24 @@ class SlamLoop {
     } else {
       map.initializeRandomly(keyframe.get());
     }
+    trackKF_ = keyframe;
     reference.importFrame(keyframe.get());
     keyframe->clearDepthHasBeenUpdatedFlag();
     tracker.setEnqueueHook([this]() {
       if (!pendingNext_) return;
-      prefetched_ = makeFrame(frameId_ + 1, pendingNext_);
+      prefetched_ = makeFrame(frameId_ + 1, pendingNext_, true);
       prefetchedSrc_ = pendingNext_;
     });
   }
   SlamLoop(const SlamLoop&) = delete;
   SlamLoop& operator=(const SlamLoop&) = delete;
+  // Tracking beside mapping with the mapper one frame behind (see above).  Switch before the first step() call.
+  void setPipelined(bool on) {
+    if (frameId_ != 0) throw Error(LSDHIP_E_STATE, "SlamLoop::setPipelined: switch before the first frame");
+    Context::get(w_, h_, K_)->setPipeline(on);
+    pipelined_ = on;
+  }
+  bool pipelined() const { return pipelined_; }
   // TrackableKeyFrameSearch::getRefFrameScore (GlobalMapping/TrackableKeyFrameSearch.h:75-79) with the default weights
   // KFDistWeight = 4, KFUsageWeight = 3 (util/settings.cpp:77-78)
   static float keyframeScore(float distanceSquared, float usage) {
@@ -505,7 +540,8 @@ class SlamLoop {
   }
   // called with the keyframe that has just been finalised (before the next one replaces it): output hook (PLY, messages)
   std::function<void(Frame&, DepthMap&)> onKeyframeFinished;
-  // track one frame, then one mapping iteration; returns frameToKeyframe.  Throws when tracking diverges.
+  // track one frame, then one mapping iteration; returns frameToKeyframe (of the keyframe the frame was tracked on).  Throws when
+  // tracking diverges.
   SE3 step(const unsigned char* image) { return step(image, [](double) {}); }
   // same, reporting the wall-clock instant (seconds, steady clock) at which tracking ended and mapping began.
   // nextImage (optional): the image of the following step() call, if it is already available — its upload and pyramids
@@ -523,11 +559,12 @@ class SlamLoop {
     else frame = makeFrame(frameId_, image);
     prefetched_.reset();
     pendingNext_ = nextImage;
-    if (keyframe->depthHasBeenUpdatedFlag()) {
+    if (!pipelined_ && keyframe->depthHasBeenUpdatedFlag()) {
       reference.importFrame(keyframe.get());
       keyframe->clearDepthHasBeenUpdatedFlag();
     }
     lsdhip_host_mark(1);
+    const std::shared_ptr<Frame> trackedOn = trackKF_;     // == keyframe unless the mapper is promoting a new one right now (pipelined)
     SE3 est = tracker.trackFrame(&reference, frame.get(), lastFrameToKF_);
     lsdhip_host_mark(8);
     pendingNext_ = nullptr;
@@ -557,7 +594,35 @@ class SlamLoop {
       throw Error(LSDHIP_DIVERGED, std::string("SlamLoop: tracking lost at frame ") + std::to_string(frameId_) +
                                        (tracker.diverged ? " (diverged)" : " (trackingWasGood false)"));
     }
+    if (pipelined_) {
+      // What the tracking thread finds when it comes back for the next frame: the mapping iteration queued one frame ago has finished.
+      if (pendingKF_) {
+        // the mapper promoted pendingKF_ (createNewCurrentKeyframe) while this frame was being tracked on the old keyframe: the next
+        // frame is tracked on the new one, from se3FromSim3(newKeyframe^-1 * thisFrame) (SlamSystem.cpp:907-920)
+        double p[7];
+        check(lsdhip_frame_relative_pose(pendingKF_->handle(), frame->handle(), p), "lsdhip_frame_relative_pose");
+        lastFrameToKF_ = SE3::from7(p);
+        trackKF_ = pendingKF_;
+        pendingKF_.reset();
+        reference.importFrame(trackKF_.get());
+        trackKF_->clearDepthHasBeenUpdatedFlag();
+      } else {
+        lastFrameToKF_ = est;
+        if (trackKF_->depthHasBeenUpdatedFlag()) {
+          reference.importFrame(trackKF_.get());
+          trackKF_->clearDepthHasBeenUpdatedFlag();
+        }
+      }
+    }
+    // ---- this frame's mapping iteration (pipelined: queued on the mapping stream, it runs beside the next frame's tracking) ----------
     ++sinceKF_;
+    newKeyframe = false;
+    if (trackedOn != keyframe) {
+      // tracked on the keyframe the mapper has just replaced: SlamSystem::updateKeyframe pops such frames unmapped (:559-566)
+      frame->clear_refPixelWasGood();
+      numDropped++;
+      return est;
+    }
     bool createNewKeyFrame = kfEvery_ > 0 && sinceKF_ >= kfEvery_;
     // numMappedOnThisTotal of the current keyframe = updateKeyframe calls since it was created: counted here, so that the
     // asynchronous pipeline is not drained every frame by Frame::stats()
@@ -577,9 +642,14 @@ class SlamLoop {
       keyframe = frame;
       if (keepKeyframes) keyframeLog.push_back(frame);
       liveQueue_.clear();
-      reference.importFrame(keyframe.get());
-      keyframe->clearDepthHasBeenUpdatedFlag();
-      lastFrameToKF_ = SE3();
+      if (pipelined_) {
+        pendingKF_ = frame;        // the tracker keeps the old keyframe for one more frame
+      } else {
+        trackKF_ = frame;
+        reference.importFrame(keyframe.get());
+        keyframe->clearDepthHasBeenUpdatedFlag();
+        lastFrameToKF_ = SE3();
+      }
       sinceKF_ = 0;
       newKeyframe = true;
     } else {
@@ -594,9 +664,8 @@ class SlamLoop {
       lsdhip_host_mark(13);
       mappedOnKF_++;
       frame->clear_refPixelWasGood();
-      lastFrameToKF_ = est;
+      if (!pipelined_) lastFrameToKF_ = est;
       numUpdates++;
-      newKeyframe = false;
       lsdhip_host_mark(14);
     }
     return est;
@@ -604,10 +673,11 @@ class SlamLoop {
   SE3Tracker tracker;
   DepthMap map;
   TrackingReference reference;
-  std::shared_ptr<Frame> keyframe;
+  std::shared_ptr<Frame> keyframe;                   // the mapper's current keyframe (DepthMap::activeKeyFrame)
   bool newKeyframe = false;
   bool trackingLost = false;                         // set before step() throws: SlamSystem::trackingIsGood == false
   long evaluations = 0, launches = 0, numTracked = 0, numUpdates = 0, numTrackedGood = 0;
+  long numDropped = 0;                               // frames tracked on a keyframe the mapper had already replaced (pipelined): not mapped
   long levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};
   double lastTrackEnd = 0;
   int liveQueueLength = 1;                           // frames handed to updateKeyframe per mapping iteration
@@ -615,17 +685,23 @@ class SlamLoop {
   std::vector<std::shared_ptr<Frame>> keyframeLog;
 
  private:
-  std::shared_ptr<Frame> makeFrame(int id, const unsigned char* img) {
+  std::shared_ptr<Frame> makeFrame(int id, const unsigned char* img, bool mayDefer = false) {
     if (onDevice_) return std::make_shared<Frame>(id, w_, h_, K_, 0.0, Frame::DeviceImage{img});
+    // a prefetched host image on a pipelined context: the copy is queued on the mapping stream and nothing waits for it (the caller
+    // keeps the bytes unchanged until the frame has been tracked: step()'s nextImage contract)
+    if (mayDefer && pipelined_) return std::make_shared<Frame>(id, w_, h_, K_, 0.0, Frame::HostImageAsync{img});
     return std::make_shared<Frame>(id, w_, h_, K_, 0.0, img);
   }
   int w_, h_;
   Mat3f K_;
   bool onDevice_;
+  bool pipelined_ = false;
   int kfEvery_, sinceKF_ = 0, frameId_ = 0;
   int mappedOnKF_ = 0;            // Frame::numMappedOnThisTotal of the current keyframe
   int numKeyframesFinished_ = 0;  // keyFrameGraph->keyframesAll.size()
   SE3 lastFrameToKF_;
+  std::shared_ptr<Frame> trackKF_;     // the keyframe the tracker's reference points at
+  std::shared_ptr<Frame> pendingKF_;   // pipelined: promoted by the mapping iteration queued last, not yet adopted by the tracker
   std::shared_ptr<Frame> prefetched_;
   const unsigned char* prefetchedSrc_ = nullptr;
   const unsigned char* pendingNext_ = nullptr;

@@ -72,6 +72,18 @@ void* lsdhip_ctx_stream(lsdhip_ctx* ctx);        /* hipStream_t of the context *
  * overflow) are picked up by the first call that asks for them (lsdhip_frame_stats / _get_pose) or by
  * lsdhip_ctx_synchronize.  Default 0: every call is synchronous, like the reference's. */
 int lsdhip_ctx_set_async(lsdhip_ctx* ctx, int on);
+/* The reference's execution model — SE3Tracker::trackFrame on the tracking thread BESIDE DepthMap::updateKeyframe on the mapping thread,
+ * blockUntilMapped == false (C/SlamSystem.h:124-132, C/SlamSystem.cpp:1026-1040) — on one GPU: on != 0 gives the context a second
+ * stream.  Tracker calls keep running on lsdhip_ctx_stream; frame creation (upload + pyramids) and every DepthMap call run on
+ * lsdhip_ctx_map_stream.  The streams are ordered by events only where data crosses: a tracker call waits for the point its frame's
+ * pyramids and its keyframe's PUBLISHED depth planes were complete at; a mapping-stream call waits for the newest finished tracker call
+ * (it consumes that call's pose and refPixelWasGood mask).  Frame::setDepth on the mapping stream writes a second set of depth planes,
+ * so a tracker call running beside it keeps reading an unchanged TrackingReference; lsdhip_frame_publish_depth hands the new planes
+ * over.  Default 0: one stream, every call ordered behind the previous one (blockUntilMapped == true).  Usually combined with
+ * lsdhip_ctx_set_async(ctx, 1); host-synchronous entries (downloads, uploads) drain both streams. */
+int lsdhip_ctx_set_pipeline(lsdhip_ctx* ctx, int on);
+int lsdhip_ctx_pipeline(lsdhip_ctx* ctx);          /* 1 / 0 */
+void* lsdhip_ctx_map_stream(lsdhip_ctx* ctx);      /* hipStream_t of the mapping side (== lsdhip_ctx_stream on a non-pipelined context) */
 int lsdhip_ctx_synchronize(lsdhip_ctx* ctx);
 const char* lsdhip_last_error(void);
 /* per-level intrinsics fx,fy,cx,cy,fxi,fyi,cxi,cyi (C/DataStructures/Frame.cpp:445-459) */
@@ -82,6 +94,11 @@ int lsdhip_ctx_intrinsics(lsdhip_ctx* ctx, int level, float out[8]);
  * builders buildImage/buildGradients/buildMaxGradients (Frame.cpp:491-767), executed eagerly on the device. */
 int lsdhip_frame_create(lsdhip_ctx* ctx, int id, const uint8_t* gray_host, lsdhip_frame** out);
 int lsdhip_frame_create_from_device(lsdhip_ctx* ctx, int id, const uint8_t* gray_dev, lsdhip_frame** out);
+/* lsdhip_frame_create without the final wait: the upload and the pyramid kernels are queued (on a pipelined context: on the mapping
+ * stream, i.e. beside the tracking job in flight — what the reference's image-loader thread does ahead of the tracking thread,
+ * C/LiveSLAMWrapper.cpp:82-118).  gray_host must stay unchanged until a tracker call on the frame has returned or the context has
+ * been synchronised; pinned memory makes the copy a true asynchronous DMA. */
+int lsdhip_frame_create_async(lsdhip_ctx* ctx, int id, const uint8_t* gray_host, lsdhip_frame** out);
 void lsdhip_frame_destroy(lsdhip_frame* f);
 int lsdhip_frame_id(lsdhip_frame* f);
 /* Frame::image/gradients/maxGradients/idepth/idepthVar(level) accessors (Frame.h:357-418), copied to host.
@@ -103,6 +120,14 @@ int lsdhip_frame_clear_wasgood(lsdhip_frame* f); /* Frame::clear_refPixelWasGood
 int lsdhip_frame_set_pose(lsdhip_frame* f, const double thisToParent_sim3[8], lsdhip_frame* trackingParent,
                           float initialTrackedResidual);
 int lsdhip_frame_get_pose(lsdhip_frame* f, double thisToParent_sim3[8]);
+/* se3FromSim3(reference->getCamToWorld().inverse() * frame->getCamToWorld()), the initial estimate SlamSystem::trackFrame forms
+ * (C/SlamSystem.cpp:918-920), for the pose-tree shapes of this path: `frame` tracked on `reference`, or both tracked on the same parent
+ * (the frame tracked on the old keyframe while the mapper was promoting `reference`).  LSDHIP_E_STATE otherwise. */
+int lsdhip_frame_relative_pose(lsdhip_frame* reference, lsdhip_frame* frame, double frameToReference[7]);
+/* TrackingReference::importFrame (C/Tracking/TrackingReference.cpp:71-87) as the hand-over point between the mapping and the tracking
+ * side of a pipelined context: the planes the keyframe's latest Frame::setDepth wrote become what tracker calls read (the reference's
+ * tracking thread does this when it finds depthHasBeenUpdatedFlag set, C/SlamSystem.cpp:907-912).  No-op on other contexts. */
+int lsdhip_frame_publish_depth(lsdhip_frame* f);
 /* out: initialTrackedResidual, meanIdepth, numPoints, numFramesTrackedOnThis, numMappedOnThis,
  *      numMappedOnThisTotal, depthHasBeenUpdatedFlag, reserved */
 int lsdhip_frame_stats(lsdhip_frame* f, float out[8]);

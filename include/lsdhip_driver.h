@@ -20,7 +20,7 @@ typedef struct lsdloop_stats {
   long long tracked_good;    /* frames whose trackFrame ended with trackingWasGood (C/Tracking/SE3Tracker.cpp:472-477) */
   long long level_evaluations[5];   /* residual evaluations per pyramid level 0..4 */
   long long track_launches;  /* k_track_step launches of the tracking jobs that evaluated */
-  long long reserved0;
+  long long dropped;         /* pipelined loops: frames tracked on a keyframe the mapper had already replaced, hence not mapped (C/SlamSystem.cpp:559-566) */
 } lsdloop_stats;
 /* K4 = fx, fy, cx, cy.  first_image / images: uint8 w*h, host memory or (images_on_device != 0) memory of `device`. */
 int lsdloop_create(int device, int w, int h, const float K4[4], const uint8_t* first_image, int images_on_device,
@@ -45,6 +45,9 @@ long long lsdloop_keyframes_exported(lsdloop* l);
  * The read-back resolves deferred results, i.e. synchronises — call it outside timed regions. */
 int lsdloop_keep_keyframes(lsdloop* l, int on);
 int lsdloop_keyframe_log(lsdloop* l, double* scales_out, long long* points_out, int max);
+/* on != 0: tracking beside mapping (the reference's two threads with blockUntilMapped == false, C/SlamSystem.cpp:1026-1040), the mapper
+ * exactly one frame behind the tracker: see lsd_slam_hip::SlamLoop.  Call before the first lsdloop_run.  Default 0 (blockUntilMapped). */
+int lsdloop_set_pipeline(lsdloop* l, int on);
 /* frames handed to DepthMap::updateKeyframe per mapping iteration (1 = blockUntilMapped, the default; K > 1 restates live
  * operation where the mapper finds up to K tracked frames queued, C/SlamSystem.cpp:559-571) */
 int lsdloop_set_live_queue(lsdloop* l, int frames);

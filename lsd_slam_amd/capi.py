@@ -71,6 +71,12 @@ def _signatures():
         "lsdhip_ctx_stream": (vp, [vp]),
         "lsdhip_ctx_synchronize": (i, [vp]),
         "lsdhip_ctx_set_async": (i, [vp, i]),
+        "lsdhip_ctx_set_pipeline": (i, [vp, i]),
+        "lsdhip_ctx_pipeline": (i, [vp]),
+        "lsdhip_ctx_map_stream": (vp, [vp]),
+        "lsdhip_frame_create_async": (i, [vp, i, vp, pvp]),
+        "lsdhip_frame_relative_pose": (i, [vp, vp, vp]),
+        "lsdhip_frame_publish_depth": (i, [vp]),
         "lsdhip_last_error": (C.c_char_p, []),
         "lsdhip_ctx_intrinsics": (i, [vp, i, vp]),
         "lsdhip_frame_create": (i, [vp, i, vp, pvp]),

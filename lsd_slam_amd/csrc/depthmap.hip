@@ -1201,7 +1201,7 @@ static int depth_create_impl(lsdhip_ctx* c, lsdhip_depthmap* dm) {
   HIPCHK(hipMalloc((void**)&dm->d_ovf, n * sizeof(int2)));
   HIPCHK(hipMalloc((void**)&dm->d_cand, n * 16));
   HIPCHK(hipMalloc((void**)&dm->d_flags, 64));
-  HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, c->stream));
+  HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, lsd_map_stream(c)));
   int nb = (int)((n + 255) / 256);
   const int ntiles = ((c->w + 31) / 32) * ((c->h + 7) / 8);   // partials of the fused regulariser: one pair per 32x8 tile
   HIPCHK(hipMalloc((void**)&dm->d_red, (size_t)(2 * (nb > ntiles ? nb : ntiles) + 16) * sizeof(double)));
@@ -1233,7 +1233,7 @@ extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
     for (size_t i = 0; i < v.size(); i++) if (v[i] == dm) { v.erase(v.begin() + i); break; }
   }
   (void)hipSetDevice(dm->ctx->device);
-  (void)hipStreamSynchronize(dm->ctx->stream);
+  (void)hipStreamSynchronize(lsd_map_stream(dm->ctx));
   for (int i = 0; i < 3; i++) (void)hipFree(dm->bases[i]);  // plane pointers get swapped around; free the arenas
   (void)hipFree(dm->d_slotCount);
   (void)hipFree(dm->d_slots);
@@ -1266,8 +1266,8 @@ extern "C" int lsdhip_depth_invalidate(lsdhip_depthmap* dm) { if (!dm) return LS
 extern "C" int lsdhip_depth_reset(lsdhip_depthmap* dm) {
   if (!dm) return LSDHIP_E_ARG;
   size_t n = (size_t)dm->ctx->w * dm->ctx->h;
-  HIPCHK(hipMemsetAsync(dm->cur.valid, 0, n, dm->ctx->stream));
-  HIPCHK(hipMemsetAsync(dm->oth.valid, 0, n, dm->ctx->stream));
+  HIPCHK(hipMemsetAsync(dm->cur.valid, 0, n, lsd_map_stream(dm->ctx)));
+  HIPCHK(hipMemsetAsync(dm->oth.valid, 0, n, lsd_map_stream(dm->ctx)));
   return LSDHIP_OK;
 }
 
@@ -1279,7 +1279,7 @@ static int set_depth(lsdhip_depthmap* dm) {
   lsdhip_frame* kf = dm->activeKeyFrame;
   int n = c->w * c->h;
   int nb = (n + 255) / 256;
-  hipLaunchKernelGGL(k_set_depth, dim3(nb), dim3(256), 0, c->stream, dm->cur, kf->d_idepth[0], kf->d_idepthVar[0], n, dm->d_red + 16);
+  hipLaunchKernelGGL(k_set_depth, dim3(nb), dim3(256), 0, lsd_map_stream(c), dm->cur, lsd_depth_w(kf)[0], lsd_depthvar_w(kf)[0], n, dm->d_red + 16);
   return set_depth_finish(dm, nb);
 }
 // second half of Frame::setDepth: mean inverse depth / point count from the (sum, count) partials, idepth pyramid
@@ -1321,7 +1321,7 @@ static int fill_holes(lsdhip_depthmap* dm) {
   lsdhip_ctx* c = dm->ctx;
   LSD_CTX_LOCK(c);
   RegArgs a = reg_args(dm, 0);
-  hipLaunchKernelGGL(k_fill_holes, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_fill_holes, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, lsd_map_stream(c), a);
   HIPCHK(hipGetLastError());
   swap_valid(dm);
   return LSDHIP_OK;
@@ -1331,8 +1331,8 @@ static int regularize(lsdhip_depthmap* dm, bool removeOcclusions, int validityTH
   LSD_CTX_LOCK(c);
   RegArgs a = reg_args(dm, validityTH);
   dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
-  if (removeOcclusions) hipLaunchKernelGGL((k_reg_fused<false, true, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
-  else hipLaunchKernelGGL((k_reg_fused<false, false, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
+  if (removeOcclusions) hipLaunchKernelGGL((k_reg_fused<false, true, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
+  else hipLaunchKernelGGL((k_reg_fused<false, false, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
   HIPCHK(hipGetLastError());
   swap_valid(dm);
   return LSDHIP_OK;
@@ -1345,9 +1345,9 @@ static int fill_regularize(lsdhip_depthmap* dm, int validityTH, bool setDepth) {
   RegArgs a = reg_args(dm, validityTH);
   dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
   if (setDepth)
-    hipLaunchKernelGGL((k_reg_fused<true, false, true>), grid, dim3(256), 0, c->stream, a, kf->d_idepth[0], kf->d_idepthVar[0], dm->d_red + 16);
+    hipLaunchKernelGGL((k_reg_fused<true, false, true>), grid, dim3(256), 0, lsd_map_stream(c), a, lsd_depth_w(kf)[0], lsd_depthvar_w(kf)[0], dm->d_red + 16);
   else
-    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
   HIPCHK(hipGetLastError());
   swap_valid(dm);
   if (setDepth) return set_depth_finish(dm, (int)(grid.x * grid.y));
@@ -1368,7 +1368,7 @@ static int fill_regularize_rows(lsdhip_depthmap* dm, int validityTH, int tileRow
     RegArgs a = reg_args(dm, validityTH);
     a.tileRow0 = tileRow0;
     dim3 grid((c->w + 31) / 32, nTileRows);
-    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, c->stream, a, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
     HIPCHK(hipGetLastError());
   }
   if (last) swap_valid(dm);
@@ -1448,7 +1448,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
     }
     const size_t refsBytes = (sizeof(StereoRef) * (size_t)n + 255) / 256 * 256;
     const size_t need = refsBytes + sizeof(int) * byIDCount;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
     if (need > dm->stage_bytes) {
       if (dm->h_stage) { (void)hipHostFree(dm->h_stage); dm->h_stage = nullptr; }   // never leave a freed pointer behind
       if (dm->d_stage) { (void)hipFree(dm->d_stage); dm->d_stage = nullptr; }
@@ -1464,7 +1464,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
       prepare_stereo(dm, refs[i], hrefs[i]);
       while ((int)nByID + offset <= refs[i]->id) byID[nByID++] = i;
     }
-    HIPCHK(hipMemcpyAsync(dm->d_stage, dm->h_stage, refsBytes + sizeof(int) * nByID, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dm->d_stage, dm->h_stage, refsBytes + sizeof(int) * nByID, hipMemcpyHostToDevice, lsd_map_stream(c)));
     dm->d_refs = (StereoRef*)dm->d_stage;
     dm->d_refByID = (int*)(dm->d_stage + refsBytes);
     memset(&a.one, 0, sizeof(a.one));
@@ -1493,7 +1493,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   {
     const size_t words = (size_t)((c->w + 31) / 32) * ((c->h + 7) / 8) * 16;
     if (!dm->d_obs_trace) HIPCHK(hipMalloc((void**)&dm->d_obs_trace, words * 8));
-    HIPCHK(hipMemsetAsync(dm->d_obs_trace, 0, words * 8, c->stream));
+    HIPCHK(hipMemsetAsync(dm->d_obs_trace, 0, words * 8, lsd_map_stream(c)));
     a.trace = dm->d_obs_trace;
     dm->obs_trace_words = words;
   }
@@ -1506,14 +1506,14 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
 #endif
     const dim3 grid((c->w + 31) / 32, (c->h + rows - 1) / rows);
     if (rows == 8) {
-      if (n == 1) hipLaunchKernelGGL((k_observe<true, 8>), grid, dim3(256), 0, c->stream, a);
-      else hipLaunchKernelGGL((k_observe<false, 8>), grid, dim3(256), 0, c->stream, a);
+      if (n == 1) hipLaunchKernelGGL((k_observe<true, 8>), grid, dim3(256), 0, lsd_map_stream(c), a);
+      else hipLaunchKernelGGL((k_observe<false, 8>), grid, dim3(256), 0, lsd_map_stream(c), a);
     } else if (rows == 4) {
-      if (n == 1) hipLaunchKernelGGL((k_observe<true, 4>), grid, dim3(128), 0, c->stream, a);
-      else hipLaunchKernelGGL((k_observe<false, 4>), grid, dim3(128), 0, c->stream, a);
+      if (n == 1) hipLaunchKernelGGL((k_observe<true, 4>), grid, dim3(128), 0, lsd_map_stream(c), a);
+      else hipLaunchKernelGGL((k_observe<false, 4>), grid, dim3(128), 0, lsd_map_stream(c), a);
     } else {
-      if (n == 1) hipLaunchKernelGGL((k_observe<true, 2>), grid, dim3(64), 0, c->stream, a);
-      else hipLaunchKernelGGL((k_observe<false, 2>), grid, dim3(64), 0, c->stream, a);
+      if (n == 1) hipLaunchKernelGGL((k_observe<true, 2>), grid, dim3(64), 0, lsd_map_stream(c), a);
+      else hipLaunchKernelGGL((k_observe<false, 2>), grid, dim3(64), 0, lsd_map_stream(c), a);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1556,15 +1556,15 @@ static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNo
   for (int i = 0; i < 9; i++) a.R[i] = (float)Rd[i];
   for (int i = 0; i < 3; i++) a.t[i] = (float)oldToNew.t[i];
 
-  HIPCHK(hipMemsetAsync(dm->d_slotCount, 0, n * 4, c->stream));
-  HIPCHK(hipMemsetAsync(dm->d_ovfHead, 0xFF, n * 4, c->stream));
-  HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, c->stream));
-  hipLaunchKernelGGL(k_prop_candidates, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(k_prop_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+  HIPCHK(hipMemsetAsync(dm->d_slotCount, 0, n * 4, lsd_map_stream(c)));
+  HIPCHK(hipMemsetAsync(dm->d_ovfHead, 0xFF, n * 4, lsd_map_stream(c)));
+  HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, lsd_map_stream(c)));
+  hipLaunchKernelGGL(k_prop_candidates, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, lsd_map_stream(c), a);
+  hipLaunchKernelGGL(k_prop_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lsd_map_stream(c), a);
   if (checkOverflowNow) {
     int flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, dm->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(&flag, dm->d_flags, 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+    HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
     if (flag) {
       lsd_set_error("propagateDepth: overflow chains exhausted (more than w*h sources beyond %d per target)", PROP_SLOT_CAP);
       return LSDHIP_E_CAPACITY;
@@ -1615,12 +1615,12 @@ static int timing_begin(lsdhip_depthmap* dm, int kind) {
   }
   if (!dm->ev[i][0]) { HIPCHK(hipEventCreate(&dm->ev[i][0])); HIPCHK(hipEventCreate(&dm->ev[i][1])); }
   dm->ev_kind[i] = kind;
-  HIPCHK(hipEventRecord(dm->ev[i][0], dm->ctx->stream));
+  HIPCHK(hipEventRecord(dm->ev[i][0], lsd_map_stream(dm->ctx)));
   return i;
 }
 static int timing_end(lsdhip_depthmap* dm, int i) {
   if (i == EV_SKIP) return LSDHIP_OK;
-  HIPCHK(hipEventRecord(dm->ev[i][1], dm->ctx->stream));
+  HIPCHK(hipEventRecord(dm->ev[i][1], lsd_map_stream(dm->ctx)));
   dm->ev_pending[i] = true;
   return LSDHIP_OK;
 }
@@ -1634,8 +1634,11 @@ extern "C" int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = false;
   int n = c->w * c->h;
-  hipLaunchKernelGGL(k_init_gt, dim3((n + 255) / 256), dim3(256), 0, c->stream, dm->cur, kf->d_idepth[0], n);
-  return set_depth(dm);
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  hipLaunchKernelGGL(k_init_gt, dim3((n + 255) / 256), dim3(256), 0, lsd_map_stream(c), dm->cur, kf->d_idepth[0], n);
+  int rc = set_depth(dm);
+  if (rc == LSDHIP_OK && lsd_m_record(c) < 0) rc = LSDHIP_E_HIP;
+  return rc;
 }
 
 extern "C" int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf) {
@@ -1649,9 +1652,10 @@ extern "C" int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   int w = c->w, h = c->h;
   size_t n = (size_t)w * h;
   std::vector<float> mg(n);
-  HIPCHK(hipMemcpyAsync(mg.data(), kf->d_maxgrad, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  HIPCHK(hipMemcpyAsync(mg.data(), kf->d_maxgrad, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
   std::vector<lsdhip_hypothesis> hyp(n);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   int rc = lsdhip_depth_download(dm, hyp.data());
   if (rc) return rc;
   for (int y = 1; y < h - 1; y++)
@@ -1667,7 +1671,9 @@ extern "C" int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf) {
     }
   rc = lsdhip_depth_upload(dm, kf, hyp.data(), 0);
   if (rc) return rc;
-  return set_depth(dm);
+  rc = set_depth(dm);
+  if (rc == LSDHIP_OK && lsd_m_record(c) < 0) rc = LSDHIP_E_HIP;
+  return rc;
 }
 
 extern "C" int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame* kf) {
@@ -1681,11 +1687,12 @@ extern "C" int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame*
   kf->numFramesTrackedOnThis = 0;
   dm->activeKeyFrameIsReactivated = true;
   int n = c->w * c->h;
-  hipLaunchKernelGGL(k_from_react, dim3((n + 255) / 256), dim3(256), 0, c->stream, dm->cur, kf->d_idepth_reAct, kf->d_idepthVar_reAct,
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  hipLaunchKernelGGL(k_from_react, dim3((n + 255) / 256), dim3(256), 0, lsd_map_stream(c), dm->cur, kf->d_idepth_reAct, kf->d_idepthVar_reAct,
                      kf->d_validity_reAct, n);
   int rc = regularize(dm, false, VAL_SUM_MIN_FOR_KEEP);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   return LSDHIP_OK;
 }
 
@@ -1698,6 +1705,7 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
+  if (int rcb = lsd_m_begin(c)) return rcb;
   const int ev = timing_begin(dm, 0);
   if (ev < 0 && ev != EV_SKIP) return ev;
   // while profiling, every 8th call brackets the observe kernel alone with a second event pair (bench.py roofline_depth)
@@ -1716,7 +1724,8 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   lsdhip_host_mark(12);
   rc = timing_end(dm, ev);
   if (rc) return rc;
-  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
+  if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
+  if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);   // host wall time of the call (enqueue time only in async mode)
   kf->numMappedOnThis++;
   kf->numMappedOnThisTotal++;
@@ -1739,6 +1748,7 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   for (int i = 0; i < 3; i++) newToOld.t[i] = nk->thisToParent_raw.t[i];
   lsdm::SE3dH oldToNew = lsdm::se3d_inverse(newToOld);
 
+  if (int rcb = lsd_m_begin(c)) return rcb;
   const int ev = timing_begin(dm, 1);
   if (ev < 0 && ev != EV_SKIP) return ev;
   int rc = propagate(dm, nk, false);
@@ -1757,10 +1767,10 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   int nb = (n + 255) / 256;
   const int slot = lsd_ctx_take_slot(c);
   if (slot < 0) return slot;
-  hipLaunchKernelGGL(k_sum_valid_idepth, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, dm->d_red + 16);
-  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, c->stream, dm->d_red + 16, nb, (double*)&c->h_slots[slot], dm->d_red,
+  hipLaunchKernelGGL(k_sum_valid_idepth, dim3(nb), dim3(256), 0, lsd_map_stream(c), dm->cur, n, dm->d_red + 16);
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, lsd_map_stream(c), dm->d_red + 16, nb, (double*)&c->h_slots[slot], dm->d_red,
                      (const int*)dm->d_flags);
-  hipLaunchKernelGGL(k_rescale, dim3(nb), dim3(256), 0, c->stream, dm->cur, n, dm->d_red);
+  hipLaunchKernelGGL(k_rescale, dim3(nb), dim3(256), 0, lsd_map_stream(c), dm->cur, n, dm->d_red);
   lsdm::SE3dH back = lsdm::se3d_inverse(oldToNew);
   nk->thisToParent_raw.q = back.q;
   lsdm::q_normalize(nk->thisToParent_raw.q);   // sim3FromSE3 -> Sim3::setScale normalises the quaternion (rxso3.hpp:332-335)
@@ -1772,6 +1782,7 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   if (rc) return rc;
   rc = timing_end(dm, ev);
   if (rc) return rc;
+  if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
   if (!c->async || rescale_out) {
     rc = lsd_frame_resolve(nk);
     if (rc) return rc;
@@ -1788,17 +1799,19 @@ extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
+  if (int rcb = lsd_m_begin(c)) return rcb;
   const int ev = timing_begin(dm, 2);
   if (ev < 0 && ev != EV_SKIP) return ev;
   int rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, true);
   if (rc) return rc;
   lsdhip_frame* kf = dm->activeKeyFrame;
   size_t n = (size_t)c->w * c->h;
-  hipLaunchKernelGGL(k_take_react, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dm->cur, kf->d_idepth_reAct,
+  hipLaunchKernelGGL(k_take_react, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lsd_map_stream(c), dm->cur, kf->d_idepth_reAct,
                      kf->d_idepthVar_reAct, kf->d_validity_reAct, (int)n);
   rc = timing_end(dm, ev);
   if (rc) return rc;
-  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
+  if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
+  if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   kf->reActValid = true;
   dm->msFinalize = ema(dm->msFinalize, now_ms() - t0);
   return LSDHIP_OK;
@@ -1808,7 +1821,7 @@ extern "C" int lsdhip_depth_finalize(lsdhip_depthmap* dm) {
 extern "C" int lsdhip_depth_observe_time(lsdhip_depthmap* dm, double* ms_out, long long* calls_out) {
   if (!dm || !ms_out || !calls_out) return LSDHIP_E_ARG;
   HIPCHK(hipSetDevice(dm->ctx->device));
-  HIPCHK(hipStreamSynchronize(dm->ctx->stream));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(dm->ctx)));
   timing_collect(dm, true);
   *ms_out = dm->gpu_ms[3];
   *calls_out = dm->gpu_calls[3];
@@ -1817,7 +1830,7 @@ extern "C" int lsdhip_depth_observe_time(lsdhip_depthmap* dm, double* ms_out, lo
 extern "C" int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]) {
   if (!dm || !ms_out || !calls_out) return LSDHIP_E_ARG;
   HIPCHK(hipSetDevice(dm->ctx->device));
-  HIPCHK(hipStreamSynchronize(dm->ctx->stream));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(dm->ctx)));
   timing_collect(dm, true);
   for (int i = 0; i < 3; i++) { ms_out[i] = dm->gpu_ms[i]; calls_out[i] = dm->gpu_calls[i]; }
   return LSDHIP_OK;
@@ -1832,15 +1845,16 @@ extern "C" int lsdhip_depth_download(lsdhip_depthmap* dm, lsdhip_hypothesis* out
   std::vector<uint8_t> v(n);
   std::vector<int32_t> bl(n), vc(n);
   std::vector<float> nid(n), id(n), var(n), ids(n), vars(n);
-  HIPCHK(hipMemcpyAsync(v.data(), dm->cur.valid, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(bl.data(), dm->cur.blacklisted, n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(vc.data(), dm->cur.validity, n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(nid.data(), dm->cur.nextID, n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(id.data(), dm->cur.idepth, n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(var.data(), dm->cur.var, n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(ids.data(), dm->cur.idepth_s, n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(vars.data(), dm->cur.var_s, n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  HIPCHK(hipMemcpyAsync(v.data(), dm->cur.valid, n, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(bl.data(), dm->cur.blacklisted, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(vc.data(), dm->cur.validity, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(nid.data(), dm->cur.nextID, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(id.data(), dm->cur.idepth, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(var.data(), dm->cur.var, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(ids.data(), dm->cur.idepth_s, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(vars.data(), dm->cur.var_s, n * 4, hipMemcpyDeviceToHost, lsd_map_stream(c)));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   for (size_t i = 0; i < n; i++) {
     lsdhip_hypothesis& h = out[i];
     h.isValid = v[i]; h.pad_[0] = h.pad_[1] = h.pad_[2] = 0;
@@ -1863,15 +1877,16 @@ extern "C" int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const 
     v[i] = h.isValid ? 1 : 0; bl[i] = h.blacklisted; nid[i] = h.nextStereoFrameMinID; vc[i] = h.validity_counter;
     id[i] = h.idepth; var[i] = h.idepth_var; ids[i] = h.idepth_smoothed; vars[i] = h.idepth_var_smoothed;
   }
-  HIPCHK(hipMemcpyAsync(dm->cur.valid, v.data(), n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->cur.blacklisted, bl.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->cur.validity, vc.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->cur.nextID, nid.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->cur.idepth, id.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->cur.var, var.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->cur.idepth_s, ids.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dm->cur.var_s, vars.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  HIPCHK(hipMemcpyAsync(dm->cur.valid, v.data(), n, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(dm->cur.blacklisted, bl.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(dm->cur.validity, vc.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(dm->cur.nextID, nid.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(dm->cur.idepth, id.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(dm->cur.var, var.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(dm->cur.idepth_s, ids.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(dm->cur.var_s, vars.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = reactivated != 0;
   return LSDHIP_OK;
@@ -1884,6 +1899,7 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   int rc = LSDHIP_E_ARG;
+  if (int rcb = lsd_m_begin(c)) return rcb;
   switch (stage) {
     case 0: rc = observe(dm, refs, n); break;
     case 1: rc = fill_holes(dm); break;
@@ -1898,7 +1914,8 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
     default: return LSDHIP_E_ARG;
   }
   if (rc) return rc;
-  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));   // asynchronous contexts: ordered on the stream
+  if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
+  if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));   // asynchronous contexts: ordered on the stream
   return LSDHIP_OK;
 }
 
@@ -1910,19 +1927,22 @@ extern "C" int lsdhip_depth_stage_rows(lsdhip_depthmap* dm, int stage, int tile_
   HIPCHK(hipSetDevice(c->device));
   int rc = fill_regularize_rows(dm, VAL_SUM_MIN_FOR_KEEP, tile_row0, n_tile_rows, last != 0);
   if (rc) return rc;
-  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));
+  if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   return LSDHIP_OK;
 }
 
 extern "C" int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* var_dev) {
   if (!dm || !idepth_dev || !var_dev) return LSDHIP_E_ARG;
-  if (!dm->activeKeyFrame || !dm->activeKeyFrame->hasIDepth) return LSDHIP_E_STATE;
+  if (!dm->activeKeyFrame || !(dm->activeKeyFrame->hasIDepth || dm->activeKeyFrame->depthPending)) return LSDHIP_E_STATE;
   lsdhip_ctx* c = dm->ctx;
   LSD_CTX_LOCK(c);
   size_t n = (size_t)c->w * c->h;
-  HIPCHK(hipMemcpyAsync(idepth_dev, dm->activeKeyFrame->d_idepth[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(var_dev, dm->activeKeyFrame->d_idepthVar[0], n * 4, hipMemcpyDeviceToDevice, c->stream));
-  if (!c->async) HIPCHK(hipStreamSynchronize(c->stream));   // asynchronous contexts: ordered on the stream, see lsdhip_ctx_synchronize
+  // what the last Frame::setDepth of the mapping side left (on a pipelined context possibly not yet published to the tracker)
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  HIPCHK(hipMemcpyAsync(idepth_dev, lsd_depth_latest(dm->activeKeyFrame)[0], n * 4, hipMemcpyDeviceToDevice, lsd_map_stream(c)));
+  HIPCHK(hipMemcpyAsync(var_dev, lsd_depthvar_latest(dm->activeKeyFrame)[0], n * 4, hipMemcpyDeviceToDevice, lsd_map_stream(c)));
+  if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
+  if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));   // asynchronous contexts: ordered on the stream, see lsdhip_ctx_synchronize
   return LSDHIP_OK;
 }
 
@@ -1943,11 +1963,11 @@ extern "C" int lsdhip_depth_copy_rows_dev(lsdhip_depthmap* dm, int row0, int nro
   for (int k = 0; k < 8; k++) {
     char* mp = (char*)planes[k].plane + off * planes[k].elt;
     const size_t bytes = px * planes[k].elt;
-    if (to_map) HIPCHK(hipMemcpyAsync(mp, p, bytes, hipMemcpyDeviceToDevice, c->stream));
-    else HIPCHK(hipMemcpyAsync(p, mp, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (to_map) HIPCHK(hipMemcpyAsync(mp, p, bytes, hipMemcpyDeviceToDevice, lsd_map_stream(c)));
+    else HIPCHK(hipMemcpyAsync(p, mp, bytes, hipMemcpyDeviceToDevice, lsd_map_stream(c)));
     p += bytes;
   }
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   return LSDHIP_OK;
 }
 

@@ -418,6 +418,11 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   host_trace_print();
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->mstream) {
+    (void)hipStreamSynchronize(c->mstream);
+    for (int i = 0; i < LSD_EVR; i++) { if (c->mEv[i]) (void)hipEventDestroy(c->mEv[i]); if (c->tEv[i]) (void)hipEventDestroy(c->tEv[i]); }
+    (void)hipStreamDestroy(c->mstream);
+  }
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipEventDestroy(c->aux_fork); (void)hipEventDestroy(c->aux_done); (void)hipStreamDestroy(c->aux_stream); }
   for (void* a : c->free_arenas) (void)hipFree(a);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -440,7 +445,7 @@ extern "C" int lsdhip_ctx_free_dev(lsdhip_ctx* c, void* p) {
   if (!c) return LSDHIP_E_ARG;
   if (!p) return LSDHIP_OK;
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rc = lsd_sync_all(c)) return rc;
   HIPCHK(hipFree(p));
   return LSDHIP_OK;
 }
@@ -455,8 +460,90 @@ extern "C" int lsdhip_ctx_synchronize(lsdhip_ctx* c) {
   }
   if (!c) return LSDHIP_E_ARG;
   if (c->aux_stream) HIPCHK(hipStreamSynchronize(c->aux_stream));
+  return lsd_sync_all(c);
+}
+// ---- pipelined contexts: tracking stream beside mapping stream ---------------------------------------------------------------------
+extern "C" int lsdhip_ctx_set_pipeline(lsdhip_ctx* c, int on) {
+  if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = lsd_sync_all(c)) return rc;
+  if (on && !c->mstream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking));
+    for (int i = 0; i < LSD_EVR; i++) {
+      HIPCHK(hipEventCreateWithFlags(&c->mEv[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->tEv[i], hipEventDisableTiming));
+    }
+  }
+  if (!on && c->pipeline) {
+    // back to one stream: everything is drained, so every recorded point counts as passed and waited for
+    c->mDoneSeq = c->tWaitedM = c->mSeq;
+    c->mWaitedT = c->tSeq;
+  }
+  c->pipeline = on != 0;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_pipeline(lsdhip_ctx* c) { return c ? (c->pipeline ? 1 : 0) : LSDHIP_E_ARG; }
+extern "C" void* lsdhip_ctx_map_stream(lsdhip_ctx* c) { return c ? (void*)lsd_map_stream(c) : nullptr; }
+int lsd_sync_all(lsdhip_ctx* c) {
+  if (c->mstream) {
+    HIPCHK(hipStreamSynchronize(c->mstream));
+    c->mDoneSeq = c->mSeq;
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
+}
+int lsd_m_begin(lsdhip_ctx* c) {
+  if (!c->pipeline || c->mWaitedT >= c->tSeq) return LSDHIP_OK;
+  HIPCHK(hipStreamWaitEvent(c->mstream, c->tEv[c->tSeq % LSD_EVR], 0));
+  c->mWaitedT = c->tSeq;
+  return LSDHIP_OK;
+}
+long long lsd_m_record(lsdhip_ctx* c) {
+  if (!c->pipeline) return 0;
+  const long long s = c->mSeq + 1;
+  if (hipEventRecord(c->mEv[s % LSD_EVR], c->mstream) != hipSuccess) { lsd_set_error("hipEventRecord on the mapping stream failed"); return LSDHIP_E_HIP; }
+  c->mSeq = s;
+  return s;
+}
+int lsd_t_wait_m(lsdhip_ctx* c, long long seq) {
+  if (!c->pipeline || seq <= c->tWaitedM || seq <= c->mDoneSeq) return LSDHIP_OK;
+  if (seq > c->mSeq) seq = c->mSeq;                 // (cannot happen: a sequence number is handed out by lsd_m_record)
+  // the ring slot holds the event of `seq` or, once the ring has wrapped, of a later point of the in-order stream: either orders us
+  HIPCHK(hipStreamWaitEvent(c->stream, c->mEv[seq % LSD_EVR], 0));
+  c->tWaitedM = seq;
+  return LSDHIP_OK;
+}
+int lsd_t_record(lsdhip_ctx* c) {
+  if (!c->pipeline) return LSDHIP_OK;
+  const long long s = c->tSeq + 1;
+  HIPCHK(hipEventRecord(c->tEv[s % LSD_EVR], c->stream));
+  c->tSeq = s;
+  return LSDHIP_OK;
+}
+bool lsd_m_done(lsdhip_ctx* c, long long seq) {
+  if (seq <= c->mDoneSeq) return true;
+  if (seq > c->mSeq) return false;
+  if (hipEventQuery(c->mEv[seq % LSD_EVR]) != hipSuccess) return false;
+  // (after a wrap the slot's event is a later point: then more than `seq` is done, which is still true of `seq`)
+  if (c->mSeq - seq < LSD_EVR) c->mDoneSeq = seq;
+  return true;
+}
+// TrackingReference::importFrame (C/Tracking/TrackingReference.cpp:71-87) as the tracking side's hand-over point: the newest
+// Frame::setDepth result of the mapping stream becomes what SE3Tracker jobs read.  A no-op on non-pipelined contexts.
+int lsd_frame_publish_depth(lsdhip_frame* f) {
+  if (!f->depthPending) return LSDHIP_OK;
+  for (int l = 0; l < LSD_LEVELS; l++) { std::swap(f->d_idepth[l], f->d_idepthW[l]); std::swap(f->d_idepthVar[l], f->d_idepthVarW[l]); }
+  f->depthPending = false;
+  f->depthSeq = f->depthPendingSeq;
+  f->hasIDepth = true;
+  f->depthVersion++;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_publish_depth(lsdhip_frame* f) {
+  if (!f) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(f->ctx);
+  return lsd_frame_publish_depth(f);
 }
 extern "C" int lsdhip_ctx_copy_dev(lsdhip_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c || !dst || !src) return LSDHIP_E_ARG;
@@ -590,6 +677,7 @@ extern "C" int lsdhip_ctx_read_dev(lsdhip_ctx* c, void* host, const void* dev, s
   if (!c || !host || !dev) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
+  if (c->pipeline) { if (int rc = lsd_sync_all(c)) return rc; }
   HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
@@ -607,6 +695,7 @@ int lsd_ctx_take_slot(lsdhip_ctx* c) {
   if (c->slot_stats_owner[i]) { int rc = lsd_frame_resolve(c->slot_stats_owner[i]); if (rc) return rc; }
   if (c->slot_rescale_owner[i]) { int rc = lsd_frame_resolve(c->slot_rescale_owner[i]); if (rc) return rc; }
   c->slot_epoch[i] = c->enqEpoch;
+  c->slot_mseq[i] = c->mSeq + 1;     // pipelined contexts: the calling DepthMap entry ends with the record point of this number
   return i;
 }
 int lsd_frame_resolve(lsdhip_frame* f) {
@@ -616,12 +705,19 @@ int lsd_frame_resolve(lsdhip_frame* f) {
   HIPCHK(hipSetDevice(c->device));
   // the values are in pinned host memory once the kernels that write them have completed: known without a synchronisation when a
   // tracking job enqueued after them has been seen to finish (the ring of slots wraps onto a retired keyframe's every few keyframes)
-  const bool landed = (f->pendRescale < 0 || c->doneEpoch > c->slot_epoch[f->pendRescale]) &&
-                      (f->pendStats < 0 || c->doneEpoch > c->slot_epoch[f->pendStats]);
-  if (!landed) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->enqEpoch++;
-    c->doneEpoch = c->enqEpoch;
+  bool landed;
+  if (c->pipeline) {
+    // the slots are written on the mapping stream: done once the record point behind their DepthMap call has been passed
+    landed = (f->pendRescale < 0 || lsd_m_done(c, c->slot_mseq[f->pendRescale])) && (f->pendStats < 0 || lsd_m_done(c, c->slot_mseq[f->pendStats]));
+    if (!landed) { HIPCHK(hipStreamSynchronize(c->mstream)); c->mDoneSeq = c->mSeq; }
+  } else {
+    landed = (f->pendRescale < 0 || c->doneEpoch > c->slot_epoch[f->pendRescale]) &&
+             (f->pendStats < 0 || c->doneEpoch > c->slot_epoch[f->pendStats]);
+    if (!landed) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      c->enqEpoch++;
+      c->doneEpoch = c->enqEpoch;
+    }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   int rc = LSDHIP_OK;
@@ -692,6 +788,8 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   take(n0 * 4);   // re-activation data (Frame::takeReActivationData): idepth, idepthVar, validity
   take(n0 * 4);
   take(n0);
+  for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);   // second depth plane set (pipelined contexts)
+  for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
   char* base = nullptr;
   c->arena_bytes = align_up(off, 256);
   if (!c->free_arenas.empty()) {
@@ -713,6 +811,8 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   f->d_idepth_reAct = (float*)(base + offs[k++]);
   f->d_idepthVar_reAct = (float*)(base + offs[k++]);
   f->d_validity_reAct = (uint8_t*)(base + offs[k++]);
+  for (int l = 0; l < LSD_LEVELS; l++) f->d_idepthW[l] = (float*)(base + offs[k++]);
+  for (int l = 0; l < LSD_LEVELS; l++) f->d_idepthVarW[l] = (float*)(base + offs[k++]);
   *out = f;
   return LSDHIP_OK;
 }
@@ -720,7 +820,7 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream) {
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
-  if (!stream) stream = c->stream;
+  if (!stream) stream = lsd_map_stream(c);
   dim3 grid(c->w / 16, c->h / 16);
   lsdhip_host_mark(21);
   hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
@@ -747,14 +847,19 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, int redN, double* redOut) {
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
-  f->depthVersion++;                    // a tracking job that is topped up after this point would read the new planes (tracker.hip)
+  // non-pipelined: a tracking job that is topped up after this point would read the new planes (tracker.hip); pipelined: the job's
+  // planes stay untouched, the version changes when the new ones are published
+  if (!c->pipeline) f->depthVersion++;
   DepthPyrArgs a;
-  for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = f->d_idepth[l]; a.var[l] = f->d_idepthVar[l]; }
+  float** id = lsd_depth_w(f);
+  float** var = lsd_depthvar_w(f);
+  for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = id[l]; a.var[l] = var[l]; }
   a.w0 = c->w;
   a.redPartials = redPartials; a.redN = redN; a.redOut = redOut;
-  hipLaunchKernelGGL(k_idepth_pyramid, dim3(c->w / 16, c->h / 16 + (redPartials ? 1 : 0)), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_idepth_pyramid, dim3(c->w / 16, c->h / 16 + (redPartials ? 1 : 0)), dim3(256), 0, lsd_map_stream(c), a);
   HIPCHK(hipGetLastError());
-  f->hasIDepth = true;
+  if (c->pipeline) { f->depthPending = true; f->depthPendingSeq = c->mSeq + 1; }   // complete at the caller's record point
+  else f->hasIDepth = true;
   return LSDHIP_OK;
 }
 
@@ -775,26 +880,43 @@ extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
   // the pyramid kernel reads the caller's device image directly (stream-ordered; nothing else needs the uint8 plane)
-  rc = lsd_frame_build_pyramids(f, gray_dev, nullptr);
+  rc = lsd_m_begin(c);
+  if (rc == LSDHIP_OK) rc = lsd_frame_build_pyramids(f, gray_dev, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
+  f->readySeq = lsd_m_record(c);
+  if (f->readySeq < 0) { lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
   *out = f;
   return LSDHIP_OK;
 }
-extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_host, lsdhip_frame** out) {
+static int frame_create_host(lsdhip_ctx* c, int id, const uint8_t* gray_host, bool wait, lsdhip_frame** out) {
   if (!c || !gray_host || !out) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   lsdhip_frame* f = nullptr;
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
-  hipError_t e = hipMemcpyAsync(f->d_gray, gray_host, (size_t)c->w * c->h, hipMemcpyHostToDevice, c->stream);
+  const hipStream_t ms = lsd_map_stream(c);
+  rc = lsd_m_begin(c);
+  if (rc) { lsdhip_frame_destroy(f); return rc; }
+  hipError_t e = hipMemcpyAsync(f->d_gray, gray_host, (size_t)c->w * c->h, hipMemcpyHostToDevice, ms);
   if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create: upload failed: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
   rc = lsd_frame_build_pyramids(f, nullptr, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
-  e = hipStreamSynchronize(c->stream);  // the host buffer may be reused by the caller
-  if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
+  f->readySeq = lsd_m_record(c);
+  if (f->readySeq < 0) { lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
+  if (wait) {
+    e = hipStreamSynchronize(ms);  // the host buffer may be reused by the caller
+    if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create: %s", hipGetErrorString(e)); lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
+    if (c->pipeline) c->mDoneSeq = c->mSeq;
+  }
   *out = f;
   return LSDHIP_OK;
+}
+extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_host, lsdhip_frame** out) {
+  return frame_create_host(c, id, gray_host, true, out);
+}
+extern "C" int lsdhip_frame_create_async(lsdhip_ctx* c, int id, const uint8_t* gray_host, lsdhip_frame** out) {
+  return frame_create_host(c, id, gray_host, false, out);
 }
 extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   if (!f) return;
@@ -804,7 +926,7 @@ extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
     c->free_arenas.push_back(f->d_gray);   // arena base; reuse is ordered by the stream itself
   } else {
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)lsd_sync_all(c);
     (void)hipFree(f->d_gray);
   }
   if (f->pendStats >= 0) c->slot_stats_owner[f->pendStats] = nullptr;
@@ -820,12 +942,14 @@ extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float
   LSD_CTX_LOCK(c);
   size_t n = (size_t)c->wl[level] * c->hl[level];
   const void* src = nullptr;
+  if (c->pipeline) { if (int rc = lsd_sync_all(c)) return rc; }
   switch (what) {
     case 0: src = f->d_image[level]; break;
     case 1: src = f->d_grad[level]; n *= 4; break;
     case 2: if (level != 0) return LSDHIP_E_ARG; src = f->d_maxgrad; break;
-    case 3: if (!f->hasIDepth) return LSDHIP_E_STATE; src = f->d_idepth[level]; break;
-    case 4: if (!f->hasIDepth) return LSDHIP_E_STATE; src = f->d_idepthVar[level]; break;
+    // Frame::idepth / idepthVar: what the last Frame::setDepth left (on pipelined contexts possibly not yet published to the tracker)
+    case 3: if (!f->hasIDepth && !f->depthPending) return LSDHIP_E_STATE; src = lsd_depth_latest(f)[level]; break;
+    case 4: if (!f->hasIDepth && !f->depthPending) return LSDHIP_E_STATE; src = lsd_depthvar_latest(f)[level]; break;
     default: return LSDHIP_E_ARG;
   }
   HIPCHK(hipMemcpyAsync(out, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -841,11 +965,14 @@ extern "C" int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_hos
   // staging plane kept by the context (ground-truth depth arrives once per keyframe in the GT-initialised modes)
   if (!c->d_gtStage) HIPCHK(hipMalloc((void**)&c->d_gtStage, (size_t)n0 * 4));
   float* d_depth = c->d_gtStage;
-  HIPCHK(hipMemcpyAsync(d_depth, depth_host, (size_t)n0 * 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_set_depth_gt, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, d_depth, f->d_maxgrad, f->d_idepth[0],
-                     f->d_idepthVar[0], c->w, c->h, cov_scale, c->params.minUseGrad);
+  if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
+  const hipStream_t ms = lsd_map_stream(c);
+  HIPCHK(hipMemcpyAsync(d_depth, depth_host, (size_t)n0 * 4, hipMemcpyHostToDevice, ms));
+  hipLaunchKernelGGL(k_set_depth_gt, dim3((n0 + 255) / 256), dim3(256), 0, ms, d_depth, f->d_maxgrad, lsd_depth_w(f)[0],
+                     lsd_depthvar_w(f)[0], c->w, c->h, cov_scale, c->params.minUseGrad);
   int rc = lsd_frame_build_idepth_pyramid(f);
-  HIPCHK(hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
+  HIPCHK(hipStreamSynchronize(ms));   // the host buffer may be reused by the caller
+  if (rc == LSDHIP_OK && c->pipeline) { f->depthPendingSeq = 0; rc = lsd_frame_publish_depth(f); }   // a synchronous call: visible to the tracker at once
   return rc;
 }
 extern "C" int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* id, const float* var) {
@@ -853,10 +980,13 @@ extern "C" int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* id, c
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
   size_t n0 = (size_t)c->w * c->h;
-  HIPCHK(hipMemcpyAsync(f->d_idepth[0], id, n0 * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(f->d_idepthVar[0], var, n0 * 4, hipMemcpyHostToDevice, c->stream));
+  if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
+  const hipStream_t ms = lsd_map_stream(c);
+  HIPCHK(hipMemcpyAsync(lsd_depth_w(f)[0], id, n0 * 4, hipMemcpyHostToDevice, ms));
+  HIPCHK(hipMemcpyAsync(lsd_depthvar_w(f)[0], var, n0 * 4, hipMemcpyHostToDevice, ms));
   int rc = lsd_frame_build_idepth_pyramid(f);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(ms));
+  if (rc == LSDHIP_OK && c->pipeline) { f->depthPendingSeq = 0; rc = lsd_frame_publish_depth(f); }
   return rc;
 }
 // Test / synthetic-benchmark hook: overwrite the level-0 maxGradients plane (scene S3 of SURVEY.md §8(d) generates
@@ -866,6 +996,7 @@ extern "C" int lsdhip_frame_set_maxgrad(lsdhip_frame* f, const float* maxgrad_ho
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
+  if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
   HIPCHK(hipMemcpyAsync(f->d_maxgrad, maxgrad_host, (size_t)c->w * c->h * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
@@ -875,6 +1006,7 @@ extern "C" int lsdhip_frame_get_wasgood(lsdhip_frame* f, uint8_t* out) {
   if (!f->wasGoodValid) return 0;
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
+  if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
   HIPCHK(hipMemcpyAsync(out, f->d_wasGood, (size_t)c->wl[1] * c->hl[1], hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 1;
@@ -883,6 +1015,7 @@ extern "C" int lsdhip_frame_set_wasgood(lsdhip_frame* f, const uint8_t* in) {
   if (!f || !in) return LSDHIP_E_ARG;
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
+  if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
   HIPCHK(hipMemcpyAsync(f->d_wasGood, in, (size_t)c->wl[1] * c->hl[1], hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   f->wasGoodValid = true;
@@ -912,6 +1045,31 @@ extern "C" int lsdhip_frame_get_pose(lsdhip_frame* f, double s[8]) {
   s[7] = f->thisToParent_raw.s;
   return LSDHIP_OK;
 }
+// se3FromSim3(reference->getCamToWorld().inverse() * frame->getCamToWorld()) for the two pose-tree shapes the hot path produces
+// (C/SlamSystem.cpp:918-920: the initial estimate of SlamSystem::trackFrame): `frame` was tracked on `reference`, or both were tracked
+// on the same parent (the frame that followed a keyframe change: tracked on the old keyframe while the mapper promoted `reference`).
+extern "C" int lsdhip_frame_relative_pose(lsdhip_frame* reference, lsdhip_frame* frame, double frameToReference[7]) {
+  if (!reference || !frame || !frameToReference) return LSDHIP_E_ARG;
+  lsdm::Sim3dH rel;
+  if (frame->trackingParent == reference && frame->trackingParentID == reference->id) {
+    rel = frame->thisToParent_raw;
+  } else if (frame->trackingParent && frame->trackingParent == reference->trackingParent && frame->trackingParentID == reference->trackingParentID) {
+    { int rc = lsd_frame_resolve(reference); if (rc) return rc; }   // the Sim3 scale of a new keyframe is a deferred result
+    const lsdm::Sim3dH inv = lsdm::sim3_inverse(reference->thisToParent_raw);
+    rel.q = lsdm::q_mul(inv.q, frame->thisToParent_raw.q);
+    rel.s = inv.s * frame->thisToParent_raw.s;
+    double rt[3];
+    lsdm::q_rotate<lsdm::Quatd, double>(inv.q, frame->thisToParent_raw.t, rt);
+    for (int i = 0; i < 3; i++) rel.t[i] = inv.s * rt[i] + inv.t[i];
+  } else {
+    lsd_set_error("lsdhip_frame_relative_pose: frame %d and frame %d are neither parent and child nor siblings in the pose tree", reference->id, frame->id);
+    return LSDHIP_E_STATE;
+  }
+  lsdm::q_normalize(rel.q);     // se3FromSim3 -> SO3 constructor (so3.hpp:630-633)
+  frameToReference[0] = rel.q.w; frameToReference[1] = rel.q.x; frameToReference[2] = rel.q.y; frameToReference[3] = rel.q.z;
+  frameToReference[4] = rel.t[0]; frameToReference[5] = rel.t[1]; frameToReference[6] = rel.t[2];
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_frame_depth_updated(lsdhip_frame* f) { return f ? (f->depthHasBeenUpdatedFlag ? 1 : 0) : LSDHIP_E_ARG; }
 extern "C" int lsdhip_frame_clear_depth_updated(lsdhip_frame* f) {
   if (!f) return LSDHIP_E_ARG;
@@ -939,6 +1097,7 @@ extern "C" int lsdhip_ref_pointcloud(lsdhip_frame* kf, int level, float* pos, fl
   LSD_CTX_LOCK(c);
   int w = c->wl[level], h = c->hl[level];
   size_t nmax = (size_t)w * h;
+  if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
   char* scratch = nullptr;
   size_t bytes = (size_t)(w + 1) * 4 + nmax * (12 + 8 + 8 + 4) + 1024;
   HIPCHK(hipMalloc((void**)&scratch, bytes));

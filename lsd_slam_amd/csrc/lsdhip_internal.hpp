@@ -164,6 +164,23 @@ struct lsdhip_ctx {
   float K0[9], K0inv[9];
   lsdhip_params params;
   hipStream_t stream = nullptr;
+  // Pipelined operation (lsdhip_ctx_set_pipeline; the reference's tracking thread beside its mapping thread, C/SlamSystem.h:124-132):
+  // SE3Tracker jobs run on `stream`, frame creation (upload + pyramids) and every DepthMap call on `mstream`.  The two are ordered by
+  // events only where data crosses: a tracking job waits for the M-sequence point its frame's pyramids / its keyframe's PUBLISHED depth
+  // planes were recorded at, and every mstream operation first waits for the newest finished tracking job (it reads that job's pose —
+  // through the host — and its refPixelWasGood mask, and may recycle arenas the job read).  mstream is in-order, so a later point implies
+  // every earlier one; events live in rings indexed by sequence number modulo LSD_EVR.
+#define LSD_EVR 64
+  bool pipeline = false;
+  hipStream_t mstream = nullptr;
+  hipEvent_t mEv[LSD_EVR] = {};
+  long long mSeq = 0;                    // record points on mstream so far
+  long long mDoneSeq = 0;                // newest M-sequence the host knows to be complete
+  long long tWaitedM = 0;                // newest M-sequence `stream` has been ordered behind
+  hipEvent_t tEv[LSD_EVR] = {};
+  long long tSeq = 0;                    // record points on `stream` (one per finished tracking job)
+  long long mWaitedT = 0;                // newest T-sequence mstream has been ordered behind
+  long long slot_mseq[LSD_NUM_SLOTS] = {};   // M-sequence whose completion implies the slot's value has landed (pipelined contexts)
   // Second stream for the transport primitives of the multi-process loops (row copies, flags, device copies, the caller's RCCL
   // calls): between lsdhip_ctx_aux_begin and lsdhip_ctx_aux_end they are queued there, ordered behind what the main stream held at
   // `begin`; lsdhip_ctx_aux_join makes the main stream wait for them.  Created on first use.
@@ -195,9 +212,17 @@ struct lsdhip_frame {
   float4* d_grad[LSD_LEVELS] = {};      // (gx, gy, I, 0)
   float* d_absgrad = nullptr;           // level-0 |grad| (temp of buildMaxGradients)
   float* d_maxgrad = nullptr;           // level-0 maxGradients
-  float* d_idepth[LSD_LEVELS] = {};
+  float* d_idepth[LSD_LEVELS] = {};     // the depth planes the TRACKING side reads (TrackingReference's view of the keyframe)
   float* d_idepthVar[LSD_LEVELS] = {};
   bool hasIDepth = false;
+  // Pipelined contexts: Frame::setDepth on the mapping stream writes the second plane set while a tracking job may still read the
+  // first; lsdhip_frame_publish_depth (= TrackingReference::importFrame) swaps them.  Non-pipelined contexts write d_idepth directly.
+  float* d_idepthW[LSD_LEVELS] = {};
+  float* d_idepthVarW[LSD_LEVELS] = {};
+  bool depthPending = false;            // the W set holds a setDepth result that has not been published yet
+  long long depthPendingSeq = 0;        // ... M-sequence it is complete at
+  long long depthSeq = 0;               // M-sequence the published planes are complete at (0: written synchronously)
+  long long readySeq = 0;               // M-sequence the image pyramids are complete at (0: built on `stream` / synchronously)
   unsigned depthVersion = 0;            // incremented whenever the idepth / idepthVar pyramids are rewritten (setDepth)
   uint8_t* d_wasGood = nullptr;         // level-1 mask (lazily created, 0xFF)
   bool wasGoodValid = false;
@@ -341,8 +366,30 @@ struct lsdhip_depthmap {
 
 // kernels / launchers implemented in the .hip files
 inline hipStream_t lsd_transport_stream(lsdhip_ctx* c) { return c->aux_active ? c->aux_stream : c->stream; }
+// the stream frame creation and the DepthMap calls run on
+inline hipStream_t lsd_map_stream(lsdhip_ctx* c) { return c->pipeline ? c->mstream : c->stream; }
+int lsd_m_begin(lsdhip_ctx* c);                    // an mstream operation starts: order it behind the newest finished tracking job
+long long lsd_m_record(lsdhip_ctx* c);             // record point on mstream -> its M-sequence (0 when the context is not pipelined, < 0: error)
+int lsd_t_wait_m(lsdhip_ctx* c, long long seq);    // order `stream` behind M-sequence `seq`
+int lsd_t_record(lsdhip_ctx* c);                   // a tracking job has finished: record point on `stream`
+bool lsd_m_done(lsdhip_ctx* c, long long seq);     // has mstream passed M-sequence `seq`?  (never blocks)
+int lsd_sync_all(lsdhip_ctx* c);                   // both streams drained
+// depth planes a Frame::setDepth writes / the most recently written ones (== d_idepth on non-pipelined contexts)
+inline float** lsd_depth_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthW : f->d_idepth; }
+inline float** lsd_depthvar_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthVarW : f->d_idepthVar; }
+inline float** lsd_depth_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthW : f->d_idepth; }
+inline float** lsd_depthvar_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthVarW : f->d_idepthVar; }
+int lsd_frame_publish_depth(lsdhip_frame* f);
+// A job on the tracking stream of a pipelined context: entered behind everything the mapping stream holds (entries that need less
+// say so themselves, lsdhip_tracker_track), left with a record point the mapping stream's next operation waits for.
+struct LsdTrackJobScope {
+  lsdhip_ctx* c;
+  int rc = LSDHIP_OK;
+  LsdTrackJobScope(lsdhip_ctx* c_, bool waitAll) : c(c_) { if (c->pipeline && waitAll) rc = lsd_t_wait_m(c, c->mSeq); }
+  ~LsdTrackJobScope() { if (c->pipeline) (void)lsd_t_record(c); }
+};
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream);
-int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);
+int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);   // on lsd_map_stream, into lsd_depth_w
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);
 void lsd_depthmaps_forget_frame(lsdhip_ctx* c, lsdhip_frame* f);   // depthmap.hip: unhook a frame that is being destroyed

@@ -523,6 +523,8 @@ static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsd
 static int sim3_run_batch(lsdhip_sim3tracker* t, Sim3Batch& batch, int nslots) {
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
+  LsdTrackJobScope tjob_(c, true);   // pipelined contexts: behind the mapping stream's products, and a record point for it afterwards
+  if (tjob_.rc) return tjob_.rc;
   const int seq = ++t->seq;
   int grid = 0;
   for (int k = 0; k < S3_MAXB; k++) {

@@ -1356,6 +1356,14 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   t->affineEstimation_a = 1; t->affineEstimation_b = 0;
   t->numEvaluations = 0; t->numWarpUpdates = 0;
   TrackJob job;
+  // pipelined contexts: the job reads the frame's pyramids and the keyframe's image pyramid + published depth planes, all products of
+  // the mapping stream; it does NOT wait for mapping work queued behind those points (DepthMap::updateKeyframe of the previous frame)
+  LsdTrackJobScope tjob_(c, false);
+  if (c->pipeline) {
+    long long need = frame->readySeq > kf->readySeq ? frame->readySeq : kf->readySeq;
+    if (kf->depthSeq > need) need = kf->depthSeq;
+    if (int rcw = lsd_t_wait_m(c, need)) return rcw;
+  }
   int rc = fill_trackframe_job(t, job, kf, frame);
   if (rc) return rc;
   lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(init)));
@@ -1503,6 +1511,8 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
   if (!t || n <= 0 || !keyframes || !frames || !inits || !results) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
+  LsdTrackJobScope tjob_(c, true);
+  if (tjob_.rc) return tjob_.rc;
   HIPCHK(hipSetDevice(c->device));
   for (int j = 0; j < n; j++) {
     if (!keyframes[j] || !frames[j]) return LSDHIP_E_ARG;
@@ -1543,6 +1553,8 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
     return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
+  LsdTrackJobScope tjob_(c, true);
+  if (tjob_.rc) return tjob_.rc;
   HIPCHK(hipSetDevice(c->device));
   int rc = batch_reserve(t, n);
   if (rc) return rc;
@@ -1630,6 +1642,9 @@ extern "C" int lsdhip_tracker_evaluate(lsdhip_tracker* t, lsdhip_frame* kf, lsdh
   if (!t || !kf || !frame || !T7 || !out || level < 0 || level >= LSD_LEVELS) return LSDHIP_E_ARG;
   if (!kf->hasIDepth) { lsd_set_error("lsdhip_tracker_evaluate: keyframe has no depth"); return LSDHIP_E_STATE; }
   HIPCHK(hipSetDevice(t->ctx->device));
+  LSD_CTX_LOCK(t->ctx);
+  LsdTrackJobScope tjob_(t->ctx, true);
+  if (tjob_.rc) return tjob_.rc;
   lsdm::SE3fH T;
   T.q = {T7[0], T7[1], T7[2], T7[3]};
   T.t[0] = T7[4]; T.t[1] = T7[5]; T.t[2] = T7[6];
@@ -1673,6 +1688,8 @@ extern "C" int lsdhip_tracker_track_permaref(lsdhip_tracker* t, const float* pos
   if (!t || !pos || !colvar || n <= 0 || !frame || !refToFrame || !out) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
+  LsdTrackJobScope tjob_(c, true);
+  if (tjob_.rc) return tjob_.rc;
   HIPCHK(hipSetDevice(c->device));
     int rc = upload_points(t, pos, colvar, n);
   if (rc) return rc;
@@ -1716,6 +1733,8 @@ extern "C" int lsdhip_tracker_track_permaref_batch(lsdhip_tracker* t, int n, con
   if (!t || n <= 0 || !pos || !colvar || !counts || !frames || !refToFrame || !results) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
+  LsdTrackJobScope tjob_(c, true);
+  if (tjob_.rc) return tjob_.rc;
   HIPCHK(hipSetDevice(c->device));
   int total = 0;
   for (int j = 0; j < n; j++) { if (counts[j] <= 0 || !frames[j]) return LSDHIP_E_ARG; total += counts[j]; }
@@ -1770,6 +1789,8 @@ extern "C" int lsdhip_tracker_check_overlap(lsdhip_tracker* t, const float* pos,
   if (!t || !pos || n <= 0 || !refToFrame || !usage_out) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
+  LsdTrackJobScope tjob_(c, true);
+  if (tjob_.rc) return tjob_.rc;
   HIPCHK(hipSetDevice(c->device));
   int rc = upload_points(t, pos, nullptr, n);
   if (rc) return rc;

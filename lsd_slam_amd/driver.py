@@ -15,12 +15,12 @@ _lib = None
 class LoopStats(C.Structure):
     _fields_ = [("seconds_track", C.c_double), ("seconds_map", C.c_double), ("seconds_keyframe", C.c_double), ("frames", C.c_longlong),
                 ("updates", C.c_longlong), ("keyframes", C.c_longlong), ("evaluations", C.c_longlong), ("tracked_good", C.c_longlong),
-                ("level_evaluations", C.c_longlong * 5), ("track_launches", C.c_longlong), ("reserved0", C.c_longlong)]
+                ("level_evaluations", C.c_longlong * 5), ("track_launches", C.c_longlong), ("dropped", C.c_longlong)]
 
 
 EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop_get_stats", "lsdloop_reset_stats",
                     "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
-                    "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
+                    "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_pipeline", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
                     "lsdloop_gather_keyframes", "lsdband_create", "lsdband_destroy", "lsdband_window_rows", "lsdband_layout", "lsdband_load",
                     "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_set_overlap", "lsdband_tile_runs", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result"]
 
@@ -55,6 +55,8 @@ def lib():
         L.lsdloop_keyframe_log.argtypes = [vp, vp, vp, i]
         L.lsdloop_set_live_queue.restype = i
         L.lsdloop_set_live_queue.argtypes = [vp, i]
+        L.lsdloop_set_pipeline.restype = i
+        L.lsdloop_set_pipeline.argtypes = [vp, i]
         L.lsdloop_set_speculation.restype = i
         L.lsdloop_set_speculation.argtypes = [vp, i, i]
         L.lsdloop_observe_time.restype = i
@@ -182,6 +184,9 @@ class DriverLoop:
     def set_speculation(self, trials, finest_level_workgroups=0):
         _check(self.L.lsdloop_set_speculation(self.h_, int(trials), int(finest_level_workgroups)))
 
+    def set_pipeline(self, on=True):
+        """tracking beside mapping, the mapper one frame behind (lsdloop_set_pipeline); before the first run()"""
+        _check(self.L.lsdloop_set_pipeline(self.h_, int(bool(on))))
 
     def observe_time(self):
         """(ms, calls) of the observe kernel alone, sampled while profiling is on; synchronises"""

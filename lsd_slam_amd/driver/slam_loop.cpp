@@ -131,6 +131,7 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       const long ev0 = L.evaluations;
       const long la0 = L.launches;
       const long good0 = L.numTrackedGood;
+      const long drop0 = L.numDropped;
       long lev0[5];
       for (int k = 0; k < 5; k++) lev0[k] = L.levelEvaluations[k];
       SE3 est = L.step(images[i], [](double) {}, (prefetch && i + 1 < n) ? images[i + 1] : nullptr);
@@ -139,6 +140,7 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       l->st.evaluations += L.evaluations - ev0;
       l->st.track_launches += L.launches - la0;
       l->st.tracked_good += L.numTrackedGood - good0;
+      l->st.dropped += L.numDropped - drop0;
       for (int k = 0; k < 5; k++) l->st.level_evaluations[k] += L.levelEvaluations[k] - lev0[k];
       if (L.newKeyframe) l->st.keyframes++;
       if (out7) est.to7(out7 + 7 * (size_t)i);
@@ -173,7 +175,9 @@ extern "C" int lsdloop_get_stats(lsdloop* l, lsdloop_stats* out) {
     };
     l->st.seconds_map = scaled(0, l->st.updates);
     l->st.seconds_keyframe = scaled(1, l->st.keyframes) + scaled(2, l->st.keyframes);
-    l->st.seconds_track = l->wall - l->st.seconds_map - l->st.seconds_keyframe;
+    // one stream: tracking = the rest of the wall time; pipelined: the mapping stream runs beside the tracking stream, which is the
+    // critical path, so tracking is the whole wall time
+    l->st.seconds_track = l->loop->pipelined() ? l->wall : l->wall - l->st.seconds_map - l->st.seconds_keyframe;
     *out = l->st;
     return LSDHIP_OK;
   } catch (const Error& e) { g_err = e.what(); return e.status; }
@@ -222,6 +226,11 @@ extern "C" int lsdloop_keyframe_log(lsdloop* l, double* scales_out, long long* p
     }
     return (int)log.size();
   } catch (const Error& e) { g_err = e.what(); return e.status; }
+}
+extern "C" int lsdloop_set_pipeline(lsdloop* l, int on) {
+  if (!l) return LSDHIP_E_ARG;
+  try { l->loop->setPipelined(on != 0); return LSDHIP_OK; }
+  catch (const Error& e) { g_err = e.what(); return e.status; }
 }
 extern "C" int lsdloop_set_live_queue(lsdloop* l, int frames) {
   if (!l || frames < 1) return LSDHIP_E_ARG;

@@ -47,6 +47,14 @@ class Context:
     def synchronize(self):
         check(self.L.lsdhip_ctx_synchronize(self.h_))
 
+    def set_async(self, on=True):
+        """DepthMap calls return once queued (lsdhip_ctx_set_async)"""
+        check(self.L.lsdhip_ctx_set_async(self.h_, int(bool(on))))
+
+    def set_pipeline(self, on=True):
+        """tracking stream beside mapping stream (lsdhip_ctx_set_pipeline): the reference's two threads with blockUntilMapped == false"""
+        check(self.L.lsdhip_ctx_set_pipeline(self.h_, int(bool(on))))
+
     def intrinsics(self, level):
         out = np.zeros(8, np.float32)
         check(self.L.lsdhip_ctx_intrinsics(self.h_, level, out.ctypes.data))
@@ -159,6 +167,19 @@ class Frame:
         check(self.L.lsdhip_frame_get_pose(self.h_, out.ctypes.data))
         return out
 
+    def relativePoseTo(self, reference):
+        """se3FromSim3(reference.camToWorld^-1 * self.camToWorld) (C/SlamSystem.cpp:918-920) for a frame tracked on `reference` or on
+        the same parent as `reference` (lsdhip_frame_relative_pose)"""
+        out = np.zeros(7, np.float64)
+        check(self.L.lsdhip_frame_relative_pose(reference.h_, self.h_, out.ctypes.data))
+        return out
+
+    def depthHasBeenUpdatedFlag(self):
+        return check(self.L.lsdhip_frame_depth_updated(self.h_)) != 0
+
+    def clearDepthHasBeenUpdatedFlag(self):
+        check(self.L.lsdhip_frame_clear_depth_updated(self.h_))
+
     def stats(self):
         out = np.zeros(8, np.float32)
         check(self.L.lsdhip_frame_stats(self.h_, out.ctypes.data))
@@ -185,7 +206,11 @@ class TrackingReference:
         self.keyframe = None
 
     def importFrame(self, kf):
+        """TrackingReference.cpp:71-87; on a pipelined context the hand-over of the mapping side's newest Frame::setDepth result to
+        the tracker (lsdhip_frame_publish_depth)"""
         self.keyframe = kf
+        if kf is not None:
+            check(kf.L.lsdhip_frame_publish_depth(kf.h_))
 
     def invalidate(self):
         self.keyframe = None

@@ -98,11 +98,14 @@ def test_cpp_loop_rccl_gather_single_rank():
 
 
 @pytest.mark.gpu
-def test_cpp_loop_is_deterministic_run_to_run():
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_cpp_loop_is_deterministic_run_to_run(pipelined):
     """The C++ track + map loop (asynchronous mapping behind tracking, next frame's pyramids queued by the enqueue hook, launch budgets
     from the recent jobs, top-ups) gives the same poses, evaluation and launch counts, bit for bit, in every run: no result depends on
     timing.  (An experiment that built the next frame's pyramids on a second stream with a pinned-memory flag instead of an event
-    failed exactly this check once in five runs — profiles/r03_notes.md — and was dropped.)"""
+    failed exactly this check once in five runs — profiles/r03_notes.md — and was dropped.)
+    pipelined: tracking stream beside mapping stream with the mapper one frame behind (lsdloop_set_pipeline) — the hand-overs between
+    the two streams are events, and the one-frame lag is part of the loop's definition, not of its timing."""
     import torch
     from lsd_slam_amd.driver import DriverLoop
     w, h, n = 640, 480, 150
@@ -110,8 +113,10 @@ def test_cpp_loop_is_deterministic_run_to_run():
     dev = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
     ptr = lambda i: dev[i % dev.shape[0]].data_ptr()
     base = None
-    for rep in range(4):
+    for rep in range(5 if pipelined else 4):
         drv = DriverLoop(w, h, K, ptr(0), depth0, kf_every=10, images_on_device=True)
+        if pipelined:
+            drv.set_pipeline(True)
         done, poses = drv.run([ptr(1 + k) for k in range(n)], want_poses=True)
         st = drv.stats()
         sig = (np.asarray(poses).tobytes(), int(st.track_launches), int(st.evaluations), int(st.keyframes))
@@ -122,6 +127,42 @@ def test_cpp_loop_is_deterministic_run_to_run():
         else:
             assert sig[1:] == base[1:], (rep, sig[1:], base[1:])
             assert sig[0] == base[0], "run %d: poses differ from run 0" % rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host_images", [False, True])
+def test_cpp_pipelined_loop_equals_the_python_loop(host_images):
+    """lsd_slam_hip::SlamLoop in pipelined mode (C++, nothing waits between frames: the mapping iteration of frame t really runs beside
+    the tracking of frame t + 1, the next image's upload / pyramids beside both) against tests/seq_loops.py::run_loop with lag = 1 driven
+    from Python over the same library (where the interpreter's pace lets every mapping iteration finish before the next tracking call):
+    identical poses, bit for bit, frame for frame — the overlap changes nothing — and the same frames dropped after keyframe changes.
+    host_images: frames come from host memory, uploaded asynchronously on the mapping stream (lsdhip_frame_create_async)."""
+    import torch
+    import lsd_slam_amd as la
+    import seq_loops as sl
+    from lsd_slam_amd.driver import DriverLoop
+    w, h, n = 640, 480, 60
+    frames, depth0, K, gt = sequence(w, h, 41)
+    frames = np.ascontiguousarray(frames)
+    if host_images:
+        pinned = torch.from_numpy(frames).pin_memory()
+        ptr = lambda i: pinned[i % pinned.shape[0]].data_ptr()
+    else:
+        dev = torch.from_numpy(frames).cuda()
+        ptr = lambda i: dev[i % dev.shape[0]].data_ptr()
+    drv = DriverLoop(w, h, K, ptr(0), depth0, kf_every=10, images_on_device=not host_images)
+    drv.set_pipeline(True)
+    done, poses = drv.run([ptr(1 + k) for k in range(n)], want_poses=True)
+    st = drv.stats()
+    drv.close()
+    assert done == n and int(st.dropped) == 5 and int(st.keyframes) == 6 and int(st.updates) == n - 6 - 5
+    ctx = la.Context(w, h, K)
+    ctx.set_pipeline(True)
+    ctx.set_async(True)
+    g = sl.run_hip(la, ctx, frames, depth0, n, lag=1)
+    assert g.dropped == [11, 21, 31, 41, 51] and g.kf_frames == [10, 20, 30, 40, 50, 60]
+    for i, (a, b) in enumerate(zip(np.asarray(poses), g.frameToKF)):
+        assert np.array_equal(a, b), ("frame %d" % (i + 1), a, b)
 
 
 @pytest.mark.gpu

@@ -16,31 +16,62 @@ N_FRAMES = 50
 ROS_ALL0 = {"useAffineLightningEstimation": 0, "allowNegativeIdepths": 0, "useSubpixelStereo": 0}
 # (parameters, sequence index = seed of the synthetic scene — BASELINE.json configs[3] runs indices 0..7 —, frames handed to
 #  updateKeyframe per mapping iteration: 1 = blockUntilMapped, 4 = the reference's live operation, C/SlamSystem.cpp:559-571)
-CONFIGS = [pytest.param({}, 0, 1, id="defaults"),
-           pytest.param(ROS_ALL0, 0, 1, id="ros-all0"),
-           pytest.param({}, 3, 1, id="defaults-seq3"),
-           pytest.param({}, 7, 1, id="defaults-seq7"),
-           pytest.param({}, 0, 4, id="defaults-livequeue4"),
-           pytest.param(ROS_ALL0, 3, 4, id="ros-all0-seq3-livequeue4")]
+#  lag: 0 = blockUntilMapped; 1 = tracking beside mapping with the mapper one frame behind (lsdhip_ctx_set_pipeline, the reference's two
+#  threads with blockUntilMapped == false: tests/seq_loops.py::run_loop); flag: SlamSystem::trackFrame's import-and-clear of
+#  depthHasBeenUpdatedFlag, i.e. Frame::setDepth in EVERY updateKeyframe — what lsd_slam_hip::SlamLoop and bench.py run)
+CONFIGS = [pytest.param({}, 0, 1, 0, False, id="defaults"),
+           pytest.param(ROS_ALL0, 0, 1, 0, False, id="ros-all0"),
+           pytest.param({}, 3, 1, 0, False, id="defaults-seq3"),
+           pytest.param({}, 7, 1, 0, False, id="defaults-seq7"),
+           pytest.param({}, 0, 4, 0, False, id="defaults-livequeue4"),
+           pytest.param(ROS_ALL0, 3, 4, 0, False, id="ros-all0-seq3-livequeue4"),
+           pytest.param({}, 0, 1, 0, True, id="defaults-setdepth-every-update"),
+           pytest.param({}, 0, 1, 1, True, id="lag1"),
+           pytest.param({}, 3, 1, 1, True, id="lag1-seq3"),
+           pytest.param(ROS_ALL0, 7, 4, 1, True, id="lag1-ros-all0-seq7-livequeue4")]
 
 
-@pytest.mark.parametrize("params,seq_index,live_queue", CONFIGS)
-def test_sequence_50_frames_hip_vs_oracle(oracle, params, seq_index, live_queue):
+@pytest.mark.parametrize("params,seq_index,live_queue,lag,flag", CONFIGS)
+def test_sequence_50_frames_hip_vs_oracle(oracle, params, seq_index, live_queue, lag, flag):
     import lsd_slam_amd as la
     w, h = 640, 480
     frames, depth0, K, gt = sequence(w, h, N_FRAMES, seq_index)
     op = oracle.default_params()
     for k, v in params.items():
         setattr(op, k, v)
-    o_sse = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SSE, params=op, live_queue=live_queue)
-    o_sc = sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=oracle.SCALAR, params=op, live_queue=live_queue)
-    ctx = la.Context(w, h, K, params=params)
-    g = sl.run_hip(la, ctx, frames, depth0, N_FRAMES, live_queue=live_queue)
+    run_o = lambda mode, perturb=None: sl.run_oracle(oracle, frames, depth0, K, N_FRAMES, mode=mode, params=op, live_queue=live_queue, lag=lag,
+                                                     clear_flag=flag, init_perturb=perturb)
+    o_sse = run_o(oracle.SSE)
+    o_sc = run_o(oracle.SCALAR)
+    ensemble = [o_sse]
+    if flag:
+        # With Frame::setDepth in every updateKeyframe the tracker sees the map change every frame, and the loop becomes sensitive to
+        # single decisions: the reference's OWN trajectory moves by ~3e-4 (a keyframe's pose lands on the other side of one LM stopping
+        # test) when the first frame's initial estimate is shifted by 1e-6 or the SSE path is swapped for the scalar one — measured with
+        # exactly this ensemble.  The device arithmetic is a third such variation, so it is compared with the member of the reference's
+        # own ensemble it agrees with best, at the usual tight bound; the yardstick is that member's nearest neighbour.
+        ensemble += [run_o(oracle.SSE, p) for p in ([1e-6, 0, 0], [0, -1e-6, 1e-6], [0, 1e-6, 0], [-1e-6, 0, -1e-6])]
+
+    def hip_run():
+        ctx = la.Context(w, h, K, params=params)
+        if lag:
+            ctx.set_pipeline(True)       # mapping stream beside tracking stream; DepthMap calls only queue their work
+            ctx.set_async(True)
+        return sl.run_hip(la, ctx, frames, depth0, N_FRAMES, live_queue=live_queue, lag=lag, clear_flag=flag)
+
+    g = hip_run()
+    o_ref = min(ensemble, key=lambda m: sl.rmse(g.trajectory(), m.trajectory()))
+    o_alt = min([m for m in ensemble + [o_sc] if m is not o_ref], key=lambda m: sl.rmse(o_ref.trajectory(), m.trajectory()))
+    if flag:
+        print("reference ensemble: trajectory RMSE of each member to the SSE run %s; HIP to each member %s"
+              % (["%.1e" % sl.rmse(o_sse.trajectory(), m.trajectory()) for m in ensemble + [o_sc]],
+                 ["%.1e" % sl.rmse(g.trajectory(), m.trajectory()) for m in ensemble + [o_sc]]))
     try:
-        _compare(g, o_sse, o_sc, gt, affine_on=params.get("useAffineLightningEstimation", 1) != 0)
+        assert g.dropped == o_ref.dropped == ([11, 21, 31, 41] if lag else [])
+        _compare(g, o_ref, o_alt, gt, affine_on=params.get("useAffineLightningEstimation", 1) != 0)
     except AssertionError as e:
         # diagnosis: a second HIP run on a fresh context tells a nondeterministic device path from a real disagreement with the oracle
-        g2 = sl.run_hip(la, la.Context(w, h, K, params=params), frames, depth0, N_FRAMES, live_queue=live_queue)
+        g2 = hip_run()
         same = len(g2.frameToKF) == len(g.frameToKF) and all(np.array_equal(a, b) for a, b in zip(g.frameToKF, g2.frameToKF))
         raise AssertionError("%s | a second HIP run gives %s poses" % (e, "IDENTICAL" if same else "DIFFERENT")) from e
 
