@@ -66,6 +66,17 @@ def build_trace(verbose=False):
     return out
 
 
+def build_variant(name, defines, verbose=False):
+    """Developer build of liblsdhip with extra -D flags (liblsdhip_<name>.so); loaded through LSDHIP_LIB + LD_PRELOAD by the A/B tools."""
+    out = os.path.join(HERE, "liblsdhip_%s.so" % name)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-x", "hip"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    _compile_checked(cmd)
+    return out
+
+
 DRIVER_OUT = os.path.join(HERE, "liblsdhip_driver.so")
 DRIVER_SRC = os.path.join(HERE, "driver", "slam_loop.cpp")
 

@@ -1706,6 +1706,7 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   HIPCHK(hipSetDevice(c->device));
   double t0 = now_ms();
   if (int rcb = lsd_m_begin(c)) return rcb;
+  if (int rcg = lsd_gate_wait(c)) return rcg;
   const int ev = timing_begin(dm, 0);
   if (ev < 0 && ev != EV_SKIP) return ev;
   // while profiling, every 8th call brackets the observe kernel alone with a second event pair (bench.py roofline_depth)
@@ -1724,6 +1725,20 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   lsdhip_host_mark(12);
   rc = timing_end(dm, ev);
   if (rc) return rc;
+  {
+    const size_t npx = (size_t)c->w * c->h;
+    const int fid = refs[n - 1]->id;
+    lsd_trace_sum(c, lsd_map_stream(c), 30, fid, refs[n - 1]->d_wasGood, (size_t)c->wl[1] * c->hl[1]);
+    lsd_trace_sum(c, lsd_map_stream(c), 31, fid, dm->cur.valid, npx);
+    lsd_trace_sum(c, lsd_map_stream(c), 32, fid, dm->cur.idepth, npx * 4);
+    lsd_trace_sum(c, lsd_map_stream(c), 33, fid, dm->cur.var, npx * 4);
+    lsd_trace_sum(c, lsd_map_stream(c), 34, fid, dm->cur.idepth_s, npx * 4);
+    lsd_trace_sum(c, lsd_map_stream(c), 35, fid, dm->cur.validity, npx * 4);
+    lsd_trace_sum(c, lsd_map_stream(c), 36, fid, dm->cur.blacklisted, npx * 4);
+    lsd_trace_sum(c, lsd_map_stream(c), 37, fid, lsd_depth_latest(kf)[0], npx * 4);
+    lsd_trace_sum(c, lsd_map_stream(c), 38, fid, lsd_depth_latest(kf)[1], npx);
+    lsd_trace_sum(c, lsd_map_stream(c), 39, fid, lsd_depthvar_latest(kf)[1], npx);
+  }
   if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
   if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);   // host wall time of the call (enqueue time only in async mode)

@@ -333,6 +333,9 @@ __global__ __launch_bounds__(256) void k_pc_write(const float* __restrict__ id, 
 // ---------------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------------
+#define LSD_FLAG_WGS 16
+static void trace_dump(lsdhip_ctx* c);
+static const int g_pipeDebug = getenv("LSDHIP_PIPE_DEBUG") ? atoi(getenv("LSDHIP_PIPE_DEBUG")) : 0;   // developer bisection switches
 extern "C" void lsdhip_default_params(lsdhip_params* p) {
   p->minUseGrad = 5;
   p->cameraPixelNoise2 = 4 * 4;
@@ -418,9 +421,11 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   host_trace_print();
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->mstream) (void)hipStreamSynchronize(c->mstream);
+  trace_dump(c);
+  if (c->d_sums) (void)hipFree(c->d_sums);
   if (c->mstream) {
-    (void)hipStreamSynchronize(c->mstream);
-    for (int i = 0; i < LSD_EVR; i++) { if (c->mEv[i]) (void)hipEventDestroy(c->mEv[i]); if (c->tEv[i]) (void)hipEventDestroy(c->tEv[i]); }
+    for (int i = 0; i < LSD_EVR; i++) if (c->mEv[i]) (void)hipEventDestroy(c->mEv[i]);
     (void)hipStreamDestroy(c->mstream);
   }
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipEventDestroy(c->aux_fork); (void)hipEventDestroy(c->aux_done); (void)hipStreamDestroy(c->aux_stream); }
@@ -429,6 +434,7 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   if (c->h_slots) (void)hipHostFree(c->h_slots);
   if (c->d_gtStage) (void)hipFree(c->d_gtStage);
   if (c->d_flagArrive) (void)hipFree(c->d_flagArrive);
+  if (c->d_gate) (void)hipFree(c->d_gate);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   (void)hipStreamDestroy(c->stream);
@@ -469,16 +475,25 @@ extern "C" int lsdhip_ctx_set_pipeline(lsdhip_ctx* c, int on) {
   HIPCHK(hipSetDevice(c->device));
   if (int rc = lsd_sync_all(c)) return rc;
   if (on && !c->mstream) {
+    if (const char* e = getenv("LSDHIP_PIPE_CUMASK")) {
+      // developer experiment: the mapping stream on its own compute units (bits i with i % 32 >= 32 - k), the tracking stream on the rest
+      const int k = atoi(e) > 0 && atoi(e) < 32 ? atoi(e) : 4;
+      uint32_t mm[8], tm[8];
+      for (int i = 0; i < 8; i++) { mm[i] = ~0u << (32 - k); tm[i] = ~mm[i]; }
+      HIPCHK(hipExtStreamCreateWithCUMask(&c->mstream, 8, mm));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipStreamDestroy(c->stream));
+      HIPCHK(hipExtStreamCreateWithCUMask(&c->stream, 8, tm));
+    } else
     HIPCHK(hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking));
     for (int i = 0; i < LSD_EVR; i++) {
-      HIPCHK(hipEventCreateWithFlags(&c->mEv[i], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&c->tEv[i], hipEventDisableTiming));
+      const unsigned evflags = (g_pipeDebug & 32) ? hipEventDefault : hipEventDisableTiming;
+      HIPCHK(hipEventCreateWithFlags(&c->mEv[i], evflags));
     }
   }
   if (!on && c->pipeline) {
     // back to one stream: everything is drained, so every recorded point counts as passed and waited for
     c->mDoneSeq = c->tWaitedM = c->mSeq;
-    c->mWaitedT = c->tSeq;
   }
   c->pipeline = on != 0;
   return LSDHIP_OK;
@@ -493,10 +508,83 @@ int lsd_sync_all(lsdhip_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
 }
+// Tracking -> mapping ordering.  A mapping-stream operation that consumes a tracking job's results is queued by the host AFTER it has
+// seen the job's `done` (pinned memory, written behind a system-scope fence by the finishing launch); what the operation reads — the
+// frame's mask, and through the host the pose — was written by launches that had completed before the finishing launch started, and
+// the launches still queued behind it touch only the tracker's own state.  So no event is recorded on the tracking stream: a record
+// behind every job is a barrier packet in the queue the launch chain runs through (the first form of the pipeline had one, plus a
+// hipStreamWaitEvent on the mapping stream; profiles/r04_notes.md).
+static const int g_pipeAcq = getenv("LSDHIP_PIPE_ACQ") ? atoi(getenv("LSDHIP_PIPE_ACQ")) : 0;
+__global__ void k_acquire_all() {
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: this XCD's caches drop what they hold
+}
+int lsd_acquire_all(lsdhip_ctx* c, hipStream_t s) {
+  hipLaunchKernelGGL(k_acquire_all, dim3(LSD_FLAG_WGS), dim3(64), 0, s);
+  return LSDHIP_OK;
+}
 int lsd_m_begin(lsdhip_ctx* c) {
-  if (!c->pipeline || c->mWaitedT >= c->tSeq) return LSDHIP_OK;
-  HIPCHK(hipStreamWaitEvent(c->mstream, c->tEv[c->tSeq % LSD_EVR], 0));
-  c->mWaitedT = c->tSeq;
+  if (c->pipeline && (g_pipeDebug & 2)) HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->pipeline && (g_pipeDebug & 8)) HIPCHK(hipStreamSynchronize(c->mstream));
+  if (c->pipeline && (g_pipeAcq & 2)) return lsd_acquire_all(c, c->mstream);
+  return LSDHIP_OK;
+}
+int lsd_pipe_acq() { return g_pipeAcq; }
+// Experiment: kernels that touch nothing but their own buffer, queued on the mapping stream right when a tracking job starts.
+// kind 1: memory streaming (32 MB read-modify-write), 2: LDS-heavy workgroups (9.6 KB each, like k_reg_fused), 3: ALU spin.
+static const int g_pipeDummy = getenv("LSDHIP_PIPE_DUMMY") ? atoi(getenv("LSDHIP_PIPE_DUMMY")) : 0;
+__global__ __launch_bounds__(256) void k_dummy_stream(float* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = p[i] * 1.0001f + 1.0f;
+}
+__global__ __launch_bounds__(256) void k_dummy_lds(float* p) {
+  __shared__ float s[2400];
+  for (int i = threadIdx.x; i < 2400; i += 256) s[i] = (float)(i + blockIdx.x);
+  __syncthreads();
+  float acc = 0;
+  for (int r = 0; r < 40; r++) for (int i = threadIdx.x; i < 2400; i += 256) acc += s[(i * 7 + r) % 2400];
+  p[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+// kind 4: workgroup barriers, no LDS; kind 5: LDS, no barrier (64-lane workgroups, lane-private slots); kind 6: like 2 with 40 KB
+__global__ __launch_bounds__(256) void k_dummy_barrier(float* p) {
+  float acc = (float)threadIdx.x;
+  for (int r = 0; r < 400; r++) { acc = acc * 1.0001f + 0.5f; __syncthreads(); }
+  p[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(64) void k_dummy_lds_nobar(float* p) {
+  __shared__ float s[2400];
+  float acc = 0;
+  for (int r = 0; r < 60; r++) {
+    for (int i = threadIdx.x; i < 2400; i += 64) s[i] = (float)(i + r);
+    for (int i = threadIdx.x; i < 2400; i += 64) acc += s[i];
+  }
+  p[(size_t)blockIdx.x * 64 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_dummy_lds_big(float* p) {
+  __shared__ float s[10000];
+  for (int i = threadIdx.x; i < 10000; i += 256) s[i] = (float)(i + blockIdx.x);
+  __syncthreads();
+  float acc = 0;
+  for (int r = 0; r < 10; r++) for (int i = threadIdx.x; i < 10000; i += 256) acc += s[(i * 7 + r) % 10000];
+  p[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(64) void k_dummy_spin(float* p, long long spin) {
+  long long t0 = clock64();
+  float a = (float)threadIdx.x;
+  while (clock64() - t0 < spin) a = a * 1.0001f + 0.5f;
+  p[(size_t)blockIdx.x * 64 + threadIdx.x] = a;
+}
+int lsd_pipe_dummy(lsdhip_ctx* c) {
+  if (!g_pipeDummy || !c->pipeline) return LSDHIP_OK;
+  static float* buf = nullptr;
+  const size_t n = 8u << 20;
+  if (!buf) { HIPCHK(hipMalloc((void**)&buf, n * 4)); HIPCHK(hipMemset(buf, 0, n * 4)); }
+  for (int rep = 0; rep < 4; rep++) {
+    if (g_pipeDummy == 1) hipLaunchKernelGGL(k_dummy_stream, dim3(2048), dim3(256), 0, c->mstream, buf, n);
+    else if (g_pipeDummy == 2) hipLaunchKernelGGL(k_dummy_lds, dim3(1200), dim3(256), 0, c->mstream, buf);
+    else if (g_pipeDummy == 4) hipLaunchKernelGGL(k_dummy_barrier, dim3(1200), dim3(256), 0, c->mstream, buf);
+    else if (g_pipeDummy == 5) hipLaunchKernelGGL(k_dummy_lds_nobar, dim3(4800), dim3(64), 0, c->mstream, buf);
+    else if (g_pipeDummy == 6) hipLaunchKernelGGL(k_dummy_lds_big, dim3(1200), dim3(256), 0, c->mstream, buf);
+    else hipLaunchKernelGGL(k_dummy_spin, dim3(4800), dim3(64), 0, c->mstream, buf, 20000LL);
+  }
   return LSDHIP_OK;
 }
 long long lsd_m_record(lsdhip_ctx* c) {
@@ -507,18 +595,14 @@ long long lsd_m_record(lsdhip_ctx* c) {
   return s;
 }
 int lsd_t_wait_m(lsdhip_ctx* c, long long seq) {
+  if (c->pipeline && (g_pipeDebug & 1)) seq = c->mSeq;
+  if (c->pipeline && (g_pipeDebug & 4)) { HIPCHK(hipStreamSynchronize(c->mstream)); c->mDoneSeq = c->mSeq; }
   if (!c->pipeline || seq <= c->tWaitedM || seq <= c->mDoneSeq) return LSDHIP_OK;
+  if (g_pipeDebug & 128) { c->tWaitedM = seq; return LSDHIP_OK; }        // diagnostic (unsafe): no event wait on the tracking stream
   if (seq > c->mSeq) seq = c->mSeq;                 // (cannot happen: a sequence number is handed out by lsd_m_record)
   // the ring slot holds the event of `seq` or, once the ring has wrapped, of a later point of the in-order stream: either orders us
   HIPCHK(hipStreamWaitEvent(c->stream, c->mEv[seq % LSD_EVR], 0));
   c->tWaitedM = seq;
-  return LSDHIP_OK;
-}
-int lsd_t_record(lsdhip_ctx* c) {
-  if (!c->pipeline) return LSDHIP_OK;
-  const long long s = c->tSeq + 1;
-  HIPCHK(hipEventRecord(c->tEv[s % LSD_EVR], c->stream));
-  c->tSeq = s;
   return LSDHIP_OK;
 }
 bool lsd_m_done(lsdhip_ctx* c, long long seq) {
@@ -528,6 +612,73 @@ bool lsd_m_done(lsdhip_ctx* c, long long seq) {
   // (after a wrap the slot's event is a later point: then more than `seq` is done, which is still true of `seq`)
   if (c->mSeq - seq < LSD_EVR) c->mDoneSeq = seq;
   return true;
+}
+static const char* g_traceSums = getenv("LSDHIP_TRACE_SUMS");
+#define LSD_TRACE_SLOTS 65536
+__global__ __launch_bounds__(256) void k_trace_sum(const uint32_t* __restrict__ p, size_t nwords, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256)
+    acc += (unsigned long long)p[i] * (unsigned long long)(i * 2654435761ull + 1ull);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+void lsd_trace_sum(lsdhip_ctx* c, hipStream_t s, int kind, int id, const void* p, size_t bytes) {
+  if (!g_traceSums) return;
+  if (!c->d_sums) { if (hipMalloc((void**)&c->d_sums, LSD_TRACE_SLOTS * 8) != hipSuccess) return; (void)hipMemset(c->d_sums, 0, LSD_TRACE_SLOTS * 8); }
+  const size_t slot = c->sums_meta.size() / 2;
+  if (slot >= LSD_TRACE_SLOTS) return;
+  c->sums_meta.push_back(kind); c->sums_meta.push_back(id);
+  c->sums_host.push_back(0);
+  const size_t nwords = bytes / 4;
+  int grid = (int)((nwords + 255) / 256); if (grid > 64) grid = 64; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_trace_sum, dim3(grid), dim3(256), 0, s, (const uint32_t*)p, nwords, c->d_sums + slot);
+}
+void lsd_trace_val(lsdhip_ctx* c, int kind, int id, unsigned long long v) {
+  if (!g_traceSums) return;
+  if (c->sums_meta.size() / 2 >= LSD_TRACE_SLOTS) return;
+  c->sums_meta.push_back(-kind); c->sums_meta.push_back(id);
+  c->sums_host.push_back(v);
+}
+static void trace_dump(lsdhip_ctx* c) {
+  if (!g_traceSums || c->sums_meta.empty()) return;
+  const size_t n = c->sums_meta.size() / 2;
+  std::vector<unsigned long long> h(n, 0);
+  if (c->d_sums) (void)hipMemcpy(h.data(), c->d_sums, n * 8, hipMemcpyDeviceToHost);
+  if (FILE* f = fopen(g_traceSums, "a")) {
+    for (size_t i = 0; i < n; i++) {
+      const int kind = c->sums_meta[2 * i];
+      fprintf(f, "%d %d %016llx\n", kind < 0 ? -kind : kind, c->sums_meta[2 * i + 1], kind < 0 ? c->sums_host[i] : h[i]);
+    }
+    fclose(f);
+  }
+}
+// Developer hook (LSDHIP_PIPE_GATE=1): forces the overlap the pipelined mode is about, whatever the host's pace — a DepthMap::updateKeyframe
+// queued on the mapping stream holds (a one-lane spin, bounded) until the NEXT tracking job's launches are about to start, so that its
+// kernels run exactly beside that job's first launches even when the caller is a slow Python loop (tools/pipe_overlap_debug.py).
+static const bool g_pipeGate = getenv("LSDHIP_PIPE_GATE") != nullptr;
+__global__ void k_gate_wait(const int* flag, int value) {
+  if (threadIdx.x != 0) return;
+  for (unsigned spins = 0; spins < (1u << 22); spins++) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+__global__ void k_gate_open(int* flag, int value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+int lsd_gate_wait(lsdhip_ctx* c) {
+  if (!g_pipeGate || !c->pipeline) return LSDHIP_OK;
+  if (!c->d_gate) { HIPCHK(hipMalloc((void**)&c->d_gate, 64)); HIPCHK(hipMemset(c->d_gate, 0, 64)); }
+  c->gateWaited = c->gateSeq + 1;
+  hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, c->mstream, c->d_gate, c->gateWaited);
+  return LSDHIP_OK;
+}
+int lsd_gate_open(lsdhip_ctx* c) {
+  if (!g_pipeGate || !c->pipeline) return LSDHIP_OK;
+  if (!c->d_gate) { HIPCHK(hipMalloc((void**)&c->d_gate, 64)); HIPCHK(hipMemset(c->d_gate, 0, 64)); }
+  c->gateSeq++;
+  hipLaunchKernelGGL(k_gate_open, dim3(1), dim3(64), 0, c->stream, c->d_gate, c->gateSeq);
+  return LSDHIP_OK;
 }
 // TrackingReference::importFrame (C/Tracking/TrackingReference.cpp:71-87) as the tracking side's hand-over point: the newest
 // Frame::setDepth result of the mapping stream becomes what SE3Tracker jobs read.  A no-op on non-pipelined contexts.
@@ -597,7 +748,6 @@ extern "C" void* lsdhip_ctx_aux_stream(lsdhip_ctx* c) { return c ? (void*)c->aux
 // any XCD's L2 and the data a wait is followed by may be cached stale in any XCD's L2 — and the other side is another process, whose
 // accesses this runtime's own cache bookkeeping between consecutive launches knows nothing about.  So every XCD runs the
 // system-scope release (set: before the last arriving workgroup raises the flag) or acquire (wait: after it has seen the flag).
-#define LSD_FLAG_WGS 16
 __global__ void k_flag_set(int* flag, int value, unsigned* arrive) {
   if (threadIdx.x != 0) return;
   __threadfence_system();
@@ -880,11 +1030,20 @@ extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
   // the pyramid kernel reads the caller's device image directly (stream-ordered; nothing else needs the uint8 plane)
+  if (c->pipeline && (g_pipeDebug & 16)) {      // bisection: pyramids on the tracking stream
+    rc = lsd_t_wait_m(c, c->mSeq);
+    if (rc == LSDHIP_OK) rc = lsd_frame_build_pyramids(f, gray_dev, c->stream);
+    if (rc) { lsdhip_frame_destroy(f); return rc; }
+    *out = f;
+    return LSDHIP_OK;
+  }
   rc = lsd_m_begin(c);
   if (rc == LSDHIP_OK) rc = lsd_frame_build_pyramids(f, gray_dev, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
+  lsd_trace_sum(c, lsd_map_stream(c), 2, id, f->d_image[0], (size_t)((char*)f->d_idepth[0] - (char*)f->d_image[0]));
   f->readySeq = lsd_m_record(c);
   if (f->readySeq < 0) { lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
+  if (c->pipeline && (g_pipeDebug & 64)) { HIPCHK(hipStreamSynchronize(c->mstream)); c->mDoneSeq = c->mSeq; }
   *out = f;
   return LSDHIP_OK;
 }

@@ -91,6 +91,11 @@ struct TrackSpec {
   uint8_t* wasGoodSide;      // refPixelWasGood planes of trials 1 .. (trial 0 writes the frame's own plane)
   unsigned maskStride;
   int seq;                   // progress tag this launch reports to the host (TrackSummary::seq); 0 = none
+  int copyMask;              // 1: the finishing launch copies the side plane of the last executed trial into the frame's plane; 0 (pipelined
+                             //    contexts): the host queues that merge on the mapping stream instead (the finishing launch must leave nothing
+                             //    behind that a mapping kernel could still be waiting for once the host has seen `done`)
+  unsigned long long dbgCum;         // developer build LSD_ORDER_CHECK: workgroups of all launches queued before this one
+  unsigned long long* dbgCounters;   // ... [0] workgroups finished, [1] workgroups that started before all earlier ones had finished, [2] largest deficit seen
   int last;                  // 1: the last launch of the enqueued budget — if the job is not finished when it ends it says so (TrackSummary::exhausted)
 };
 
@@ -126,8 +131,8 @@ struct TrackSummary {
   double bytes;              // algorithmic bytes of all evaluations of the job
   int levelEvals[LSD_LEVELS];
   int numLaunches;           // k_track_step launches that evaluated (< numEvaluations with reject-chain speculation)
+  int lastCand;              // trial (within the launch that produced the final sums) the LM loop executed last: its mask plane is the frame's
   int seq;                   // (job tag << 12) | ordinal of the latest k_track_step launch of the chain that has started
-  int pad1_;
   int exhausted;             // seq of the budget's last launch, written when that launch ends with the job unfinished: the host tops up
   int pad2_;
 };
@@ -166,10 +171,12 @@ struct lsdhip_ctx {
   hipStream_t stream = nullptr;
   // Pipelined operation (lsdhip_ctx_set_pipeline; the reference's tracking thread beside its mapping thread, C/SlamSystem.h:124-132):
   // SE3Tracker jobs run on `stream`, frame creation (upload + pyramids) and every DepthMap call on `mstream`.  The two are ordered by
-  // events only where data crosses: a tracking job waits for the M-sequence point its frame's pyramids / its keyframe's PUBLISHED depth
-  // planes were recorded at, and every mstream operation first waits for the newest finished tracking job (it reads that job's pose —
-  // through the host — and its refPixelWasGood mask, and may recycle arenas the job read).  mstream is in-order, so a later point implies
-  // every earlier one; events live in rings indexed by sequence number modulo LSD_EVR.
+  // events where mapping products reach the tracker: a tracking job waits for the M-sequence point its frame's pyramids / its
+  // keyframe's PUBLISHED depth planes were recorded at (mstream is in-order, so a later point implies every earlier one; the events live
+  // in a ring indexed by sequence number modulo LSD_EVR).  The other direction needs no device-side ordering: a mapping operation that
+  // consumes a tracking job's results (its pose — through the host — and its refPixelWasGood mask) is queued by the host after it has
+  // SEEN that job finish, and everything the job wrote for others was written by launches that completed before the finishing one
+  // started (the mask of a speculative trial is merged into the frame's plane by a kernel on mstream, see lsdhip_tracker_track).
 #define LSD_EVR 64
   bool pipeline = false;
   hipStream_t mstream = nullptr;
@@ -177,10 +184,12 @@ struct lsdhip_ctx {
   long long mSeq = 0;                    // record points on mstream so far
   long long mDoneSeq = 0;                // newest M-sequence the host knows to be complete
   long long tWaitedM = 0;                // newest M-sequence `stream` has been ordered behind
-  hipEvent_t tEv[LSD_EVR] = {};
-  long long tSeq = 0;                    // record points on `stream` (one per finished tracking job)
-  long long mWaitedT = 0;                // newest T-sequence mstream has been ordered behind
   long long slot_mseq[LSD_NUM_SLOTS] = {};   // M-sequence whose completion implies the slot's value has landed (pipelined contexts)
+  unsigned long long* d_sums = nullptr;  // LSDHIP_TRACE_SUMS: checksum slots
+  std::vector<int> sums_meta;            // (kind, id) per slot; kind < 0: host value stored in sums_host
+  std::vector<unsigned long long> sums_host;
+  int* d_gate = nullptr;                 // developer hook LSDHIP_PIPE_GATE: the next tracking job's first launch releases the mapping work queued before it
+  int gateSeq = 0, gateWaited = 0;
   // Second stream for the transport primitives of the multi-process loops (row copies, flags, device copies, the caller's RCCL
   // calls): between lsdhip_ctx_aux_begin and lsdhip_ctx_aux_end they are queued there, ordered behind what the main stream held at
   // `begin`; lsdhip_ctx_aux_join makes the main stream wait for them.  Created on first use.
@@ -277,9 +286,14 @@ struct lsdhip_tracker {
   int specCaps[LSD_LEVELS] = {0, 0, 0, 0, 0};    // per-level workgroups per trial (LSDHIP_SPEC_CAPS; 0 = automatic)
   int specLevel[LSD_LEVELS] = {0, 0, 0, 0, 0};   // per-level trials (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = automatic / specC)
   int specCap = 80;               // workgroups per trial on levels of 24 K - 88 K pixels when speculating (0 = grid_cap / 2)
-  uint8_t* d_maskSide = nullptr;  // (SPEC_MAX - 1) mask planes of (w >> 1) x (h >> 1) bytes
+  uint8_t* d_maskSide = nullptr;  // 2 sets (alternating by job) of (SPEC_MAX - 1) mask planes of (w >> 1) x (h >> 1) bytes
+  int maskSet = 0;                // set the job being launched writes
+  long long maskMergeSeq[2] = {0, 0};   // pipelined contexts: M-sequence behind which the merge that reads set s has completed
   size_t maskStride = 0;
   int numLaunches = 0;
+  unsigned long long dbgCum = 0;
+  std::vector<unsigned> dumpL0;   // developer dump (LSDHIP_DUMP_L0): what the job's first launch left in the scratch
+  unsigned long long* d_dbg = nullptr;
   TrackSpec spec = {};             // of the job being launched
   const lsdhip_frame* jobKf = nullptr;   // keyframe whose planes the job being run reads (trackFrame jobs), and their version at its start
   unsigned jobKfVersion = 0;
@@ -368,25 +382,36 @@ struct lsdhip_depthmap {
 inline hipStream_t lsd_transport_stream(lsdhip_ctx* c) { return c->aux_active ? c->aux_stream : c->stream; }
 // the stream frame creation and the DepthMap calls run on
 inline hipStream_t lsd_map_stream(lsdhip_ctx* c) { return c->pipeline ? c->mstream : c->stream; }
-int lsd_m_begin(lsdhip_ctx* c);                    // an mstream operation starts: order it behind the newest finished tracking job
+int lsd_m_begin(lsdhip_ctx* c);                    // an mstream operation starts (developer switches only: see the note on tracking -> mapping ordering in frame.hip)
 long long lsd_m_record(lsdhip_ctx* c);             // record point on mstream -> its M-sequence (0 when the context is not pipelined, < 0: error)
 int lsd_t_wait_m(lsdhip_ctx* c, long long seq);    // order `stream` behind M-sequence `seq`
-int lsd_t_record(lsdhip_ctx* c);                   // a tracking job has finished: record point on `stream`
 bool lsd_m_done(lsdhip_ctx* c, long long seq);     // has mstream passed M-sequence `seq`?  (never blocks)
 int lsd_sync_all(lsdhip_ctx* c);                   // both streams drained
+int lsd_gate_wait(lsdhip_ctx* c);                  // developer hook (LSDHIP_PIPE_GATE=1): mapping stream holds until the next tracking job starts
+int lsd_gate_open(lsdhip_ctx* c);
+int lsd_pipe_acq();
+int lsd_pipe_dummy(lsdhip_ctx* c);   // experiment LSDHIP_PIPE_DUMMY=<kind>: unrelated kernels on the mapping stream beside a tracking job
+int lsd_acquire_all(lsdhip_ctx* c, hipStream_t s);   // one system-scope acquire per XCD, stream-ordered (experiment LSDHIP_PIPE_ACQ)
+// developer trace (LSDHIP_TRACE_SUMS=<file>): order-independent checksums of device buffers, queued on a stream at chosen points of the
+// loop and written out when the context is destroyed — two runs of the same loop are compared entry by entry (tools/trace_cmp.py)
+void lsd_trace_sum(lsdhip_ctx* c, hipStream_t s, int kind, int id, const void* p, size_t bytes);
+void lsd_trace_val(lsdhip_ctx* c, int kind, int id, unsigned long long v);
 // depth planes a Frame::setDepth writes / the most recently written ones (== d_idepth on non-pipelined contexts)
 inline float** lsd_depth_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthW : f->d_idepth; }
 inline float** lsd_depthvar_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthVarW : f->d_idepthVar; }
 inline float** lsd_depth_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthW : f->d_idepth; }
 inline float** lsd_depthvar_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthVarW : f->d_idepthVar; }
 int lsd_frame_publish_depth(lsdhip_frame* f);
-// A job on the tracking stream of a pipelined context: entered behind everything the mapping stream holds (entries that need less
-// say so themselves, lsdhip_tracker_track), left with a record point the mapping stream's next operation waits for.
+// A job on the tracking stream of a pipelined context: entered behind everything the mapping stream holds (lsdhip_tracker_track
+// needs less and says so itself); left with the tracking stream DRAINED, because mapping-stream operations are ordered behind tracking
+// work by the host having seen it complete (see frame.hip).  lsdhip_tracker_track, the one hot entry, does not drain: it leaves only
+// launches behind that touch nothing but the tracker's own state.
 struct LsdTrackJobScope {
   lsdhip_ctx* c;
   int rc = LSDHIP_OK;
-  LsdTrackJobScope(lsdhip_ctx* c_, bool waitAll) : c(c_) { if (c->pipeline && waitAll) rc = lsd_t_wait_m(c, c->mSeq); }
-  ~LsdTrackJobScope() { if (c->pipeline) (void)lsd_t_record(c); }
+  bool drain;
+  LsdTrackJobScope(lsdhip_ctx* c_, bool waitAll) : c(c_), drain(waitAll) { if (c->pipeline && waitAll) rc = lsd_t_wait_m(c, c->mSeq); }
+  ~LsdTrackJobScope() { if (c->pipeline && drain) (void)hipStreamSynchronize(c->stream); }
 };
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);   // on lsd_map_stream, into lsd_depth_w

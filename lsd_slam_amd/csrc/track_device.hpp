@@ -373,6 +373,7 @@ __device__ __forceinline__ void write_summary(const TrackState& s, const float* 
   out->bytes = s.bytes;
   for (int l = 0; l < LSD_LEVELS; l++) out->levelEvals[l] = s.levelEvals[l];
   out->numLaunches = s.numLaunches;
+  out->lastCand = s.lastCand;
   __threadfence_system();
   out->done = s.done;
 }

@@ -130,6 +130,21 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   }
 #endif
   PHASE_MARK(0);
+#ifdef LSD_TRACK_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // developer experiment: explicit L2 invalidate at kernel start
+#define LSD_TRACK_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#else
+#define LSD_TRACK_RELEASE() do { } while (0)
+#endif
+#ifdef LSD_LDS_FILL
+  {   // developer build: every LDS array starts from a known pattern (hunting reads of uninitialised LDS)
+    auto fill = [&](void* p, size_t bytes) { unsigned* q = (unsigned*)p; for (size_t i = threadIdx.x; i < bytes / 4; i += BLOCK) q[i] = (unsigned)LSD_LDS_FILL; };
+    fill(&S, sizeof(S)); fill(&sh, sizeof(sh)); fill(&s_par, sizeof(s_par)); fill(s_sum, sizeof(s_sum)); fill(s_red, sizeof(s_red));
+    fill(s_wtop, sizeof(s_wtop)); fill(s_top, sizeof(s_top)); fill(s_sumT, sizeof(s_sumT)); fill(s_subT, sizeof(s_subT));
+    fill(s_nsubT, sizeof(s_nsubT)); fill(s_rec, sizeof(s_rec));
+    __syncthreads();
+  }
+#endif
   if (!BATCH && MODE == TS_FUSED && !first && !leader && st2[parity].done) return;   // launches queued behind the finishing one
   if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.seq != 0) out->seq = spec.seq;   // pinned host memory: fire and forget
   if (first) {
@@ -154,7 +169,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   __syncthreads();
   PHASE_MARK(1);
   if (S.done) {
-    if (MODE != TS_EVAL && leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);   // keep both buffers "done"
+    if (MODE != TS_EVAL && leader) { copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK); LSD_TRACK_RELEASE(); }   // keep both buffers "done"
     return;
   }
   const int lvlPending = S.level;
@@ -449,6 +464,19 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
           if (need > 2) s -= sub2;
         }
         if (tid < RS_NUM) sh.tot[tid] = s;
+#ifdef LSD_ORDER_CHECK
+        if (!BATCH && spec.dbgCounters) {
+          // do all workgroups of this launch finish the previous evaluation with the same totals?
+          unsigned hv = tid < RS_END ? __float_as_uint(s) * (2654435761u * (unsigned)(tid + 1)) : 0u;
+          hv += (unsigned)pc * 97u;
+          for (int off = 32; off > 0; off >>= 1) hv += __shfl_xor(hv, off);
+          if (tid == 0) {
+            const unsigned long long slot = 8 + 2 * ((spec.dbgCum / 400ull) % 8192ull);
+            __hip_atomic_fetch_min(&spec.dbgCounters[slot], (unsigned long long)hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(&spec.dbgCounters[slot + 1], (unsigned long long)hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#endif
         PHASE_MARK(3);
 #ifdef LSD_PHASE_TRACE
         if (blockIdx.x == 0 && tid == 0) { tr_[19] = (unsigned long long)ncandPending; tr_[7] = (unsigned long long)pc; }
@@ -462,7 +490,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     PHASE_MARK(4);
     if (S.done) {
       // the frame's refPixelWasGood must be what the last trial the LM loop executed wrote: trials > 0 wrote side planes
-      if (!BATCH && MODE == TS_FUSED && S.lastCand > 0 && job.lv[level].writeMask && cand == 0 && bx < nb) {
+      if (!BATCH && MODE == TS_FUSED && S.lastCand > 0 && spec.copyMask != 0 && job.lv[level].writeMask && cand == 0 && bx < nb) {
         const uint8_t* side = spec.wasGoodSide + (size_t)(S.lastCand - 1) * spec.maskStride;
         EvalCtx a;
         make_ctx_dev(job, S, level, a);
@@ -474,6 +502,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         }
       }
       if (leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
+      LSD_TRACK_RELEASE();
       return;
     }
     // a workgroup that evaluates trial c > 0 leaves that trial's increment and pose for the launch that finishes it
@@ -488,6 +517,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   }
 
   if (MODE == TS_LM) {
+    __syncthreads();              // (every wave has tested S.pending before it changes: see the note at the residual evaluation below)
     if (tid == 0) S.pending = 1;
     __syncthreads();
     copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
@@ -496,7 +526,11 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 
   // ---- residual evaluation at S.level / S.R, S.t ------------------------------------------------------------------
   const int level = S.level;
-  if (MODE == TS_FUSED && tid == 0) { S.pending = 1; S.numLaunches = S.numLaunches + 1; }
+  // (S.pending = 1 / S.numLaunches++ for the state this launch publishes are set further down, behind the first barrier of the
+  // reduction: in a job's first launch the finishing phase above is skipped, so no barrier separates a wave that is still about to test
+  // `S.pending` from wave 0 arriving here — with the write here, a wave held up by LDS traffic of another stream's workgroups on
+  // the same CU could read 1, enter the finishing phase alone and pair its barriers with the others' reduction barriers: one
+  // tile's sums came out as LDS residue.  Seen only with a second stream active, profiles/r04_notes.md.)
   const int nb = job.lv[level].nblocks;
   if (!BATCH && MODE == TS_FUSED && level != lvlPending) { cand = 0; bx = (int)blockIdx.x; }   // first evaluation of the next level
   if (bx >= nb || cand >= S.ncand) return;   // workgroup 0 always has work: it publishes the state at the end
@@ -677,6 +711,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     for (int k = 0; k < CPP; k++)
       if (hp * CPP + k < RS_END) s_red[k * (BLOCK + 1) + tid] = acc[hp * CPP + k];
     __syncthreads();
+    if (MODE == TS_FUSED && hp == 0 && tid == 0) { S.pending = 1; S.numLaunches = S.numLaunches + 1; }   // every wave is past its reads of S.pending
     {
       const int slice = tid / CPP, k = tid - slice * CPP;
       if (slice < RSLICE) {
@@ -718,6 +753,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   // the budget's last launch ends with the job unfinished: tell the host (pinned memory), which polls this next to `done` and
   // appends launches — the stream order makes them follow; no hipStreamQuery in the wait loop (each one puts a marker packet into
   // the queue the chain runs through: ~3 us per frame)
+  LSD_TRACK_RELEASE();
   if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.last != 0) out->exhausted = spec.seq;
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
@@ -728,7 +764,36 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 template <int BLOCK, bool BATCH, int MODE = TS_FUSED>
 __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
                                                        TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first, TrackSpec spec) {
+#ifdef LSD_ORDER_CHECK
+  // developer build: is every workgroup of every earlier launch of this stream finished when a workgroup of this launch starts?
+  if (!BATCH && spec.dbgCounters && threadIdx.x == 0) {
+    const unsigned long long fin = __hip_atomic_load(&spec.dbgCounters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fin < spec.dbgCum) {
+      __hip_atomic_fetch_add(&spec.dbgCounters[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(&spec.dbgCounters[2], spec.dbgCum - fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#endif
   track_step_impl<BLOCK, BATCH, MODE>(jobv, jobs, st2, sc, out, parity, first, spec);
+#ifdef LSD_ORDER_CHECK
+  __syncthreads();
+  if (!BATCH && spec.dbgCounters && threadIdx.x == 0) __hip_atomic_fetch_add(&spec.dbgCounters[0], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// Pipelined contexts: the frame's refPixelWasGood is what the LAST trial the LM loop executed wrote.  Trial 0 of every launch writes the
+// frame's own plane, trials > 0 write side planes — at the same pixels (the valid reference points do not depend on the pose), so the
+// pixels the job visited are those whose byte in the frame's plane is no longer the 0xFF of frame creation: there the side plane's byte
+// replaces it.  Queued on the mapping stream by lsdhip_tracker_track (one-stream contexts: the finishing launch copies instead).
+__global__ __launch_bounds__(256) void k_mask_merge(uint32_t* __restrict__ plane, const uint32_t* __restrict__ side, int nwords) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nwords) return;
+  const uint32_t a = plane[i], b = side[i];
+  // per byte: visited (a != 0xFF) -> b, else a
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (((a >> (8 * k)) & 0xFFu) != 0xFFu) m |= 0xFFu << (8 * k);
+  plane[i] = (a & ~m) | (b & m);
 }
 
 // checkPermaRefOverlap (SE3Tracker.cpp:121-157): usage only, explicit point list
@@ -796,10 +861,17 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
     for (int l = 0; l < LSD_LEVELS; l++) t->specLevel[l] = v[l] < 0 ? 0 : (v[l] > LSD_SPEC_MAX ? LSD_SPEC_MAX : v[l]);
   }
   t->maskStride = (((size_t)c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) + 255) & ~(size_t)255;
-  HIPCHK(hipMalloc((void**)&t->d_maskSide, t->maskStride * (LSD_SPEC_MAX - 1)));
-  HIPCHK(hipMemsetAsync(t->d_maskSide, 0, t->maskStride * (LSD_SPEC_MAX - 1), c->stream));
+  HIPCHK(hipMalloc((void**)&t->d_maskSide, 2 * t->maskStride * (LSD_SPEC_MAX - 1)));
+  HIPCHK(hipMemsetAsync(t->d_maskSide, 0, 2 * t->maskStride * (LSD_SPEC_MAX - 1), c->stream));
   HIPCHK(hipMalloc((void**)&t->d_partials, scratch_bytes));
   HIPCHK(hipMemsetAsync(t->d_partials, 0, scratch_bytes, c->stream));
+  {
+    const size_t nd = 8 + 2 * 8192;
+    HIPCHK(hipMalloc((void**)&t->d_dbg, nd * 8));
+    std::vector<unsigned long long> init(nd, 0);
+    for (size_t i = 8; i < nd; i += 2) init[i] = ~0ull;     // (min, max) pairs of the per-launch totals hash
+    HIPCHK(hipMemcpy(t->d_dbg, init.data(), nd * 8, hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
   HIPCHK(hipMemsetAsync(t->d_state, 0, 2 * sizeof(TrackState), c->stream));
 #ifdef LSD_PHASE_TRACE
@@ -825,6 +897,23 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
             (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs);
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
+#ifdef LSD_ORDER_CHECK
+  {
+    std::vector<unsigned long long> h(8 + 2 * 8192, 0);
+    (void)hipMemcpy(h.data(), t->d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    int used = 0, split = 0;
+    for (size_t i = 8; i < h.size(); i += 2) if (h[i] != ~0ull) { used++; if (h[i] != h[i + 1]) split++; }
+    if (const char* path = getenv("LSDHIP_ORDER_DUMP")) {
+      if (FILE* f = fopen(path, "w")) {
+        for (size_t i = 8; i < h.size(); i += 2) if (h[i] != ~0ull) fprintf(f, "%zu %llx %llx\n", (i - 8) / 2, h[i], h[i + 1]);
+        fclose(f);
+      }
+    }
+    fprintf(stderr, "ORDERCHECK: %llu workgroups finished (%llu launched), %llu started before every earlier workgroup had finished (largest deficit %llu); "
+                    "%d launch slots hashed, %d in which the workgroups did NOT all see the same totals\n", h[0], t->dbgCum, h[1], h[2], used, split);
+  }
+#endif
+  (void)hipFree(t->d_dbg);
 #ifdef LSD_PHASE_TRACE
   if (const char* path = getenv("LSDHIP_TRACE_FILE")) {
     std::vector<unsigned long long> h(1 + 4096 * 20);
@@ -989,6 +1078,9 @@ static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int pa
   TrackScratch sc = scratch_of(t);
   t->launchOrdinal++;
   t->spec.seq = t->jobTag ? ((t->jobTag << 12) | (t->launchOrdinal & 0xFFF)) : 0;
+  t->spec.dbgCum = t->dbgCum;
+  t->spec.dbgCounters = t->d_dbg;
+  t->dbgCum += (unsigned long long)grid;
   hipLaunchKernelGGL((k_track_step<256, false>), dim3(grid), dim3(256), 0, c->stream, job, (const TrackJob*)nullptr, t->d_state, sc,
                      t->d_summary, parity, first, t->spec);
 }
@@ -1161,8 +1253,18 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
   t->spec.specC = t->specC;
   t->spec.specGrid = 0;
-  t->spec.wasGoodSide = t->d_maskSide;
+  // two sets of side planes, alternating by job: on a pipelined context the merge of job t's final mask runs on the mapping stream
+  // while job t + 1 writes the other set
+  t->maskSet ^= 1;
+  t->spec.wasGoodSide = t->d_maskSide + (size_t)t->maskSet * t->maskStride * (LSD_SPEC_MAX - 1);
   t->spec.maskStride = (unsigned)t->maskStride;
+  t->spec.copyMask = c->pipeline ? 0 : 1;
+  if (c->pipeline && t->maskMergeSeq[t->maskSet] > 0) {
+    // the merge that read this set two jobs ago must have run (in a frame loop the job's own frame was created behind it anyway)
+    if (t->maskMergeSeq[t->maskSet] > c->mSeq && lsd_m_record(c) < 0) return LSDHIP_E_HIP;
+    if (int rcw = lsd_t_wait_m(c, t->maskMergeSeq[t->maskSet])) return rcw;
+    t->maskMergeSeq[t->maskSet] = 0;
+  }
   // Trials per launch and workgroups per trial, per level.  Speculation pays where a level is latency-bound, i.e. small: the
   // automatic policy goes by the level's pixel (or point) count — <= 6 K: 6 trials, <= 24 K: 5, <= 88 K: 5 trials on specCap (80)
   // workgroups each (multi-pass; 4 x 104 measured 1.5 % slower), larger: one evaluation per launch on the full grid (such levels are work-bound: at
@@ -1252,6 +1354,21 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     if (S->done) break;
     t->dbgMisses++;
     HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
+    {
+      static const bool dumpL0 = getenv("LSDHIP_DUMP_L0") != nullptr;
+      if (dumpL0 && guard == 0 && t->budgetFixed == 1) {
+        // the first launch (level `topLevel`, one trial) wrote parity 1, trial 0: rows | keys | tail contributions of its tiles
+        const TrackScratch sc = scratch_of(t);
+        const size_t rows = (size_t)t->max_blocks;
+        const int nb = job.lv[topLevel].nblocks;
+        t->dumpL0.assign((size_t)nb * (RS_COLS + 4 + 96) + sizeof(TrackState) / 4, 0u);
+        unsigned* d = t->dumpL0.data();
+        HIPCHK(hipMemcpy(d, sc.sums + (size_t)(1 * LSD_SPEC_MAX + 0) * RS_COLS * rows, (size_t)nb * RS_COLS * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(d + (size_t)nb * RS_COLS, sc.topkey + (size_t)(1 * LSD_SPEC_MAX + 0) * rows, (size_t)nb * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(d + (size_t)nb * (RS_COLS + 4), sc.topval + (size_t)(1 * LSD_SPEC_MAX + 0) * rows * 96, (size_t)nb * 96 * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(d + (size_t)nb * (RS_COLS + 4 + 96), t->d_state + 1, sizeof(TrackState), hipMemcpyDeviceToHost));
+      }
+    }
     if (S->done) break;
     if (int rc2 = prof_collect(c)) return rc2;
     if (t->jobKf && t->jobKf->depthVersion != t->jobKfVersion && guard < 8) {
@@ -1366,6 +1483,26 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   }
   int rc = fill_trackframe_job(t, job, kf, frame);
   if (rc) return rc;
+  if (int rcg = lsd_gate_open(c)) return rcg;
+  if (c->pipeline && (lsd_pipe_acq() & 1)) lsd_acquire_all(c, c->stream);
+  if (int rcd = lsd_pipe_dummy(c)) return rcd;
+  static const bool traceInputs = getenv("LSDHIP_TRACE_INPUTS") != nullptr;
+  auto trace_inputs = [&](int base) {
+    for (int l = 1; l <= 4; l++) {
+      const size_t nl = (size_t)c->wl[l] * c->hl[l];
+      lsd_trace_sum(c, c->stream, base + 10 + l, frame->id, kf->d_idepth[l], nl * 4);
+      lsd_trace_sum(c, c->stream, base + 14 + l, frame->id, kf->d_idepthVar[l], nl * 4);
+      lsd_trace_sum(c, c->stream, base + 50 + l, frame->id, kf->d_image[l], nl * 4);
+      lsd_trace_sum(c, c->stream, base + 54 + l, frame->id, frame->d_grad[l], nl * 16);
+    }
+  };
+  if (traceInputs) trace_inputs(0);
+  {
+    unsigned long long pv = 0;
+    for (int i = 0; i < 7; i++) { unsigned long long u; memcpy(&u, &init[i], 8); pv = pv * 1000003ull + u; }
+    lsd_trace_val(c, 22, frame->id, pv);
+    lsd_trace_val(c, 23, frame->id, (unsigned long long)kf->id);
+  }
   lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(init)));
 
   if (t->hostLM) {
@@ -1394,10 +1531,60 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   }
   t->jobKf = kf;
   t->jobKfVersion = kf->depthVersion;
+  const lsdm::SE3fH referenceToFrame0 = referenceToFrame;
+  lsd_trace_val(c, 26, frame->id, t->dbgCum / 400ull);
   rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
+  if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) { t->jobKf = nullptr; return rc; }
+  static const bool replay = getenv("LSDHIP_TRACK_REPLAY") != nullptr;
+  if (replay && c->pipeline) {
+    // developer check: the same job once more with the mapping stream drained — identical inputs must give the identical result
+    unsigned long long pv = 0;
+    for (int i = 0; i < 4; i++) { unsigned u; memcpy(&u, &t->h_summary->q[i], 4); pv = pv * 1000003ull + u; }
+    for (int i = 0; i < 3; i++) { unsigned u; memcpy(&u, &t->h_summary->t[i], 4); pv = pv * 1000003ull + u; }
+    lsd_trace_val(c, 24, frame->id, pv);
+    lsd_trace_val(c, 25, frame->id, (unsigned long long)t->h_summary->numEvaluations * 1000 + t->h_summary->lastCand);
+    HIPCHK(hipStreamSynchronize(c->mstream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->mDoneSeq = c->mSeq;
+    const std::vector<unsigned> dump1 = t->dumpL0;
+    if (traceInputs) trace_inputs(100);
+    lsd_trace_val(c, 27, frame->id, t->dbgCum / 400ull);
+    referenceToFrame = referenceToFrame0;
+    rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
+    if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) { t->jobKf = nullptr; return rc; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!dump1.empty() && dump1.size() == t->dumpL0.size()) {
+      const int nb = job.lv[LSD_TRACK_MAX_LEVEL - 1].nblocks;
+      int shown = 0;
+      for (size_t i = 0; i < dump1.size(); i++)
+        if (dump1[i] != t->dumpL0[i] && shown++ < 12) {
+          const size_t a = (size_t)nb * RS_COLS, b = a + (size_t)nb * 4, cst = b + (size_t)nb * 96;
+          float f1, f2; memcpy(&f1, &dump1[i], 4); memcpy(&f2, &t->dumpL0[i], 4);
+          if (i < a) fprintf(stderr, "L0DIFF frame %d: sums tile %zu column %zu: run %.9g (%08x) replay %.9g (%08x)\n", frame->id, i / RS_COLS, i % RS_COLS, f1, dump1[i], f2, t->dumpL0[i]);
+          else if (i < b) fprintf(stderr, "L0DIFF frame %d: topkey tile %zu [%zu]: run %d replay %d\n", frame->id, (i - a) / 4, (i - a) % 4, (int)dump1[i], (int)t->dumpL0[i]);
+          else if (i < cst) fprintf(stderr, "L0DIFF frame %d: topval tile %zu slot %zu entry %zu: run %.9g replay %.9g\n", frame->id, (i - b) / 96, ((i - b) % 96) / 32, (i - b) % 32, f1, f2);
+          else fprintf(stderr, "L0DIFF frame %d: state word %zu: run %08x (%.9g) replay %08x (%.9g)\n", frame->id, i - cst, dump1[i], f1, t->dumpL0[i], f2);
+        }
+      if (shown) fprintf(stderr, "L0DIFF frame %d: %d words differ after the first launch\n", frame->id, shown);
+    }
+  }
   t->jobKf = nullptr;
-  if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) return rc;
   lsdhip_host_mark(6);
+  {
+    unsigned long long pv = 0;
+    for (int i = 0; i < 4; i++) { unsigned u; memcpy(&u, &t->h_summary->q[i], 4); pv = pv * 1000003ull + u; }
+    for (int i = 0; i < 3; i++) { unsigned u; memcpy(&u, &t->h_summary->t[i], 4); pv = pv * 1000003ull + u; }
+    lsd_trace_val(c, 20, frame->id, pv);
+    lsd_trace_val(c, 21, frame->id, (unsigned long long)t->h_summary->numEvaluations * 1000 + t->h_summary->lastCand);
+  }
+  if (c->pipeline && rc == LSDHIP_OK && t->h_summary->lastCand > 0 && t->h_summary->level == LSD_TRACK_MIN_LEVEL) {
+    // the final mask sits in a side plane: merged into the frame's plane on the mapping stream, ahead of whatever reads the mask next
+    const int nwords = (int)((((size_t)c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) + 3) / 4);
+    const uint8_t* side = t->spec.wasGoodSide + (size_t)(t->h_summary->lastCand - 1) * t->maskStride;
+    hipLaunchKernelGGL(k_mask_merge, dim3((nwords + 255) / 256), dim3(256), 0, c->mstream, (uint32_t*)frame->d_wasGood, (const uint32_t*)side, nwords);
+    HIPCHK(hipGetLastError());
+    t->maskMergeSeq[t->maskSet] = c->mSeq + 1;      // complete at the mapping stream's next record point
+  }
   rc = finish_trackframe(t, t->h_summary, kf, frame, out);
   lsdhip_host_mark(7);
   return rc;

@@ -20,7 +20,8 @@ for fi in (30, 31):
             if n_step > 2 and gap < 3.0 and "--all" not in sys.argv:
                 prev = en
                 continue
-        print("%-42s start=%8.1f dur=%6.1f gap=%6.1f" % (name, (st - t0) / 1e3, (en - st) / 1e3, gap))
+        q = r.get("Queue_Id", "?")   # two queues on a pipelined context: tracking stream / mapping stream
+        print("q=%-3s %-42s start=%8.1f end=%8.1f dur=%6.1f gap=%6.1f" % (q, name, (st - t0) / 1e3, (en - t0) / 1e3, (en - st) / 1e3, gap))
         prev = en
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[a:b]) / 1e3
     print("frame total %.1f us, %d track steps, kernels busy %.1f us" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3, n_step, busy))
