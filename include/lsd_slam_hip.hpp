@@ -519,6 +519,8 @@ class SlamLoop {
     reference.importFrame(keyframe.get());
     keyframe->clearDepthHasBeenUpdatedFlag();
     tracker.setEnqueueHook([this]() {
+      // runs once the tracking job's launches are queued: the place for everything the device can do beside it
+      flushDeferredMapping();
       if (!pendingNext_) return;
       prefetched_ = makeFrame(frameId_ + 1, pendingNext_, true);
       prefetchedSrc_ = pendingNext_;
@@ -533,6 +535,15 @@ class SlamLoop {
     pipelined_ = on;
   }
   bool pipelined() const { return pipelined_; }
+  // Pipelined loops queue a frame's updateKeyframe only once the NEXT frame's tracking launches are queued (from the tracker's enqueue
+  // hook: between two tracking jobs the host queues nothing but the next job).  After the last step() of a batch this queues what is
+  // still waiting.
+  void flushDeferredMapping() {
+    if (!deferredMap_) return;
+    std::shared_ptr<Frame> frame = std::move(deferredMap_);
+    deferredMap_.reset();
+    runUpdate(frame);
+  }
   // TrackableKeyFrameSearch::getRefFrameScore (GlobalMapping/TrackableKeyFrameSearch.h:75-79) with the default weights
   // KFDistWeight = 4, KFUsageWeight = 3 (util/settings.cpp:77-78)
   static float keyframeScore(float distanceSquared, float usage) {
@@ -617,6 +628,7 @@ class SlamLoop {
     // ---- this frame's mapping iteration (pipelined: queued on the mapping stream, it runs beside the next frame's tracking) ----------
     ++sinceKF_;
     newKeyframe = false;
+    flushDeferredMapping();      // (normally empty: the tracking job's hook has queued it)
     if (trackedOn != keyframe) {
       // tracked on the keyframe the mapper has just replaced: SlamSystem::updateKeyframe pops such frames unmapped (:559-566)
       frame->clear_refPixelWasGood();
@@ -652,21 +664,11 @@ class SlamLoop {
       }
       sinceKF_ = 0;
       newKeyframe = true;
+    } else if (pipelined_ && deferMapping) {
+      deferredMap_ = frame;       // queued from the next tracking job's enqueue hook (or flushDeferredMapping)
     } else {
-      // blockUntilMapped = true: the unmapped queue holds exactly this frame (SlamSystem.cpp:559-571, :1030-1039).
-      // liveQueueLength > 1 restates live operation, where the mapper finds several tracked frames waiting and passes the
-      // whole deque (oldest first, at most liveQueueLength of them) to updateKeyframe.
-      liveQueue_.push_back(frame);
-      while ((int)liveQueue_.size() > (liveQueueLength > 1 ? liveQueueLength : 1)) liveQueue_.pop_front();
-      std::deque<std::shared_ptr<Frame>> q(liveQueue_.begin(), liveQueue_.end());
-      lsdhip_host_mark(9);
-      map.updateKeyframe(q);
-      lsdhip_host_mark(13);
-      mappedOnKF_++;
-      frame->clear_refPixelWasGood();
+      runUpdate(frame);
       if (!pipelined_) lastFrameToKF_ = est;
-      numUpdates++;
-      lsdhip_host_mark(14);
     }
     return est;
   }
@@ -681,10 +683,28 @@ class SlamLoop {
   long levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};
   double lastTrackEnd = 0;
   int liveQueueLength = 1;                           // frames handed to updateKeyframe per mapping iteration
+  bool deferMapping = true;                          // pipelined loops: see flushDeferredMapping
   bool keepKeyframes = false;                        // keep every keyframe alive in keyframeLog (validation: rescale factors)
   std::vector<std::shared_ptr<Frame>> keyframeLog;
 
  private:
+  // DepthMap::updateKeyframe for one tracked frame (SlamSystem::updateKeyframe, SlamSystem.cpp:542-614)
+  void runUpdate(const std::shared_ptr<Frame>& frame) {
+    // blockUntilMapped = true: the unmapped queue holds exactly this frame (SlamSystem.cpp:559-571, :1030-1039).
+    // liveQueueLength > 1 restates live operation, where the mapper finds several tracked frames waiting and passes the
+    // whole deque (oldest first, at most liveQueueLength of them) to updateKeyframe.
+    liveQueue_.push_back(frame);
+    while ((int)liveQueue_.size() > (liveQueueLength > 1 ? liveQueueLength : 1)) liveQueue_.pop_front();
+    std::deque<std::shared_ptr<Frame>> q(liveQueue_.begin(), liveQueue_.end());
+    lsdhip_host_mark(9);
+    map.updateKeyframe(q);
+    lsdhip_host_mark(13);
+    mappedOnKF_++;
+    frame->clear_refPixelWasGood();
+    numUpdates++;
+    lsdhip_host_mark(14);
+  }
+  std::shared_ptr<Frame> deferredMap_;
   std::shared_ptr<Frame> makeFrame(int id, const unsigned char* img, bool mayDefer = false) {
     if (onDevice_) return std::make_shared<Frame>(id, w_, h_, K_, 0.0, Frame::DeviceImage{img});
     // a prefetched host image on a pipelined context: the copy is queued on the mapping stream and nothing waits for it (the caller

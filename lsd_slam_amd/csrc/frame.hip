@@ -501,6 +501,7 @@ extern "C" int lsdhip_ctx_set_pipeline(lsdhip_ctx* c, int on) {
 extern "C" int lsdhip_ctx_pipeline(lsdhip_ctx* c) { return c ? (c->pipeline ? 1 : 0) : LSDHIP_E_ARG; }
 extern "C" void* lsdhip_ctx_map_stream(lsdhip_ctx* c) { return c ? (void*)lsd_map_stream(c) : nullptr; }
 int lsd_sync_all(lsdhip_ctx* c) {
+  if (c->pipeline && !c->pendingMerges.empty()) { if (int rc = lsd_flush_merges(c)) return rc; }
   if (c->mstream) {
     HIPCHK(hipStreamSynchronize(c->mstream));
     c->mDoneSeq = c->mSeq;
@@ -526,6 +527,7 @@ int lsd_m_begin(lsdhip_ctx* c) {
   if (c->pipeline && (g_pipeDebug & 2)) HIPCHK(hipStreamSynchronize(c->stream));
   if (c->pipeline && (g_pipeDebug & 8)) HIPCHK(hipStreamSynchronize(c->mstream));
   if (c->pipeline && (g_pipeAcq & 2)) return lsd_acquire_all(c, c->mstream);
+  if (!c->pendingMerges.empty()) return lsd_flush_merges(c);
   return LSDHIP_OK;
 }
 int lsd_pipe_acq() { return g_pipeAcq; }
@@ -1090,6 +1092,9 @@ extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   }
   if (f->pendStats >= 0) c->slot_stats_owner[f->pendStats] = nullptr;
   if (f->pendRescale >= 0) c->slot_rescale_owner[f->pendRescale] = nullptr;
+  for (size_t i = 0; i < c->pendingMerges.size();)     // nobody will read this frame's mask any more
+    if (c->pendingMerges[i].plane == f->d_wasGood) { *c->pendingMerges[i].doneSeq = 0; c->pendingMerges.erase(c->pendingMerges.begin() + i); }
+    else i++;
   lsd_depthmaps_forget_frame(c, f);   // a depth map whose active keyframe this is becomes "no active keyframe"
   delete f;
 }

@@ -185,6 +185,11 @@ struct lsdhip_ctx {
   long long mDoneSeq = 0;                // newest M-sequence the host knows to be complete
   long long tWaitedM = 0;                // newest M-sequence `stream` has been ordered behind
   long long slot_mseq[LSD_NUM_SLOTS] = {};   // M-sequence whose completion implies the slot's value has landed (pipelined contexts)
+  // Pipelined contexts: merges of a speculative trial's refPixelWasGood plane into its frame's plane (k_mask_merge) that have not been
+  // queued yet: the tracking call only notes them (nothing may delay the next tracking job's launches), the next mapping-stream
+  // operation queues them first (lsd_m_begin)
+  struct PendingMerge { uint8_t* plane; const uint8_t* side; long long* doneSeq; };
+  std::vector<PendingMerge> pendingMerges;
   unsigned long long* d_sums = nullptr;  // LSDHIP_TRACE_SUMS: checksum slots
   std::vector<int> sums_meta;            // (kind, id) per slot; kind < 0: host value stored in sums_host
   std::vector<unsigned long long> sums_host;
@@ -402,6 +407,7 @@ inline float** lsd_depthvar_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_
 inline float** lsd_depth_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthW : f->d_idepth; }
 inline float** lsd_depthvar_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthVarW : f->d_idepthVar; }
 int lsd_frame_publish_depth(lsdhip_frame* f);
+int lsd_flush_merges(lsdhip_ctx* c);               // tracker.hip: queue the pending mask merges on the mapping stream
 // A job on the tracking stream of a pipelined context: entered behind everything the mapping stream holds (lsdhip_tracker_track
 // needs less and says so itself); left with the tracking stream DRAINED, because mapping-stream operations are ordered behind tracking
 // work by the host having seen it complete (see frame.hip).  lsdhip_tracker_track, the one hot entry, does not drain: it leaves only

@@ -796,6 +796,17 @@ __global__ __launch_bounds__(256) void k_mask_merge(uint32_t* __restrict__ plane
   plane[i] = (a & ~m) | (b & m);
 }
 
+int lsd_flush_merges(lsdhip_ctx* c) {
+  const int nwords = (int)((((size_t)c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) + 3) / 4);
+  for (const lsdhip_ctx::PendingMerge& m : c->pendingMerges) {
+    hipLaunchKernelGGL(k_mask_merge, dim3((nwords + 255) / 256), dim3(256), 0, c->mstream, (uint32_t*)m.plane, (const uint32_t*)m.side, nwords);
+    *m.doneSeq = c->mSeq + 1;      // complete at the mapping stream's next record point
+  }
+  c->pendingMerges.clear();
+  HIPCHK(hipGetLastError());
+  return LSDHIP_OK;
+}
+
 // checkPermaRefOverlap (SE3Tracker.cpp:121-157): usage only, explicit point list
 __global__ __launch_bounds__(256) void k_overlap(const float* __restrict__ pos, int n, EvalCtx a, float* __restrict__ out) {
   __shared__ float s_w[4];
@@ -892,6 +903,13 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
 }
 extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   if (!t) return;
+  {
+    lsdhip_ctx* c = t->ctx;
+    LSD_CTX_LOCK(c);
+    for (size_t i = 0; i < c->pendingMerges.size();)     // merges out of this tracker's side planes die with it
+      if (c->pendingMerges[i].doneSeq == &t->maskMergeSeq[0] || c->pendingMerges[i].doneSeq == &t->maskMergeSeq[1]) c->pendingMerges.erase(c->pendingMerges.begin() + i);
+      else i++;
+  }
   if (getenv("LSDHIP_TRACK_DEBUG") && t->dbgJobs > 0)
     fprintf(stderr, "TRACKDBG jobs %lld launches enqueued %.2f/job, budget misses %lld, host launch %.1f us/job, host wait %.1f us/job\n", t->dbgJobs,
             (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs);
@@ -1259,8 +1277,10 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   t->spec.wasGoodSide = t->d_maskSide + (size_t)t->maskSet * t->maskStride * (LSD_SPEC_MAX - 1);
   t->spec.maskStride = (unsigned)t->maskStride;
   t->spec.copyMask = c->pipeline ? 0 : 1;
-  if (c->pipeline && t->maskMergeSeq[t->maskSet] > 0) {
-    // the merge that read this set two jobs ago must have run (in a frame loop the job's own frame was created behind it anyway)
+  if (c->pipeline && t->maskMergeSeq[t->maskSet] != 0) {
+    // the merge that reads this set (noted two jobs ago) must have run before the set is overwritten (in a frame loop a mapping
+    // operation has queued it long ago and the job's own frame was created behind it)
+    if (t->maskMergeSeq[t->maskSet] < 0) { if (int rcf = lsd_flush_merges(c)) return rcf; }
     if (t->maskMergeSeq[t->maskSet] > c->mSeq && lsd_m_record(c) < 0) return LSDHIP_E_HIP;
     if (int rcw = lsd_t_wait_m(c, t->maskMergeSeq[t->maskSet])) return rcw;
     t->maskMergeSeq[t->maskSet] = 0;
@@ -1578,12 +1598,11 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
     lsd_trace_val(c, 21, frame->id, (unsigned long long)t->h_summary->numEvaluations * 1000 + t->h_summary->lastCand);
   }
   if (c->pipeline && rc == LSDHIP_OK && t->h_summary->lastCand > 0 && t->h_summary->level == LSD_TRACK_MIN_LEVEL) {
-    // the final mask sits in a side plane: merged into the frame's plane on the mapping stream, ahead of whatever reads the mask next
-    const int nwords = (int)((((size_t)c->wl[LSD_TRACK_MIN_LEVEL] * c->hl[LSD_TRACK_MIN_LEVEL]) + 3) / 4);
+    // the final mask sits in a side plane: to be merged into the frame's plane on the mapping stream, ahead of whatever reads the mask
+    // next — noted here, queued by the next mapping-stream operation (nothing is launched between two tracking jobs)
     const uint8_t* side = t->spec.wasGoodSide + (size_t)(t->h_summary->lastCand - 1) * t->maskStride;
-    hipLaunchKernelGGL(k_mask_merge, dim3((nwords + 255) / 256), dim3(256), 0, c->mstream, (uint32_t*)frame->d_wasGood, (const uint32_t*)side, nwords);
-    HIPCHK(hipGetLastError());
-    t->maskMergeSeq[t->maskSet] = c->mSeq + 1;      // complete at the mapping stream's next record point
+    t->maskMergeSeq[t->maskSet] = -1;               // pending
+    c->pendingMerges.push_back({frame->d_wasGood, side, &t->maskMergeSeq[t->maskSet]});
   }
   rc = finish_trackframe(t, t->h_summary, kf, frame, out);
   lsdhip_host_mark(7);

@@ -123,11 +123,11 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
   if (!l || !images || n < 0) return LSDHIP_E_ARG;
   try {
     int done = 0;
+    long updSeen = l->loop->numUpdates;
     static const bool prefetch = !std::getenv("LSDHIP_NO_PREFETCH");   // developer switch for A/B timing
     const double t0 = now_s();
     for (int i = 0; i < n; i++) {
       SlamLoop& L = *l->loop;
-      const long upd0 = L.numUpdates;
       const long ev0 = L.evaluations;
       const long la0 = L.launches;
       const long good0 = L.numTrackedGood;
@@ -136,7 +136,8 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       for (int k = 0; k < 5; k++) lev0[k] = L.levelEvaluations[k];
       SE3 est = L.step(images[i], [](double) {}, (prefetch && i + 1 < n) ? images[i + 1] : nullptr);
       l->st.frames++;
-      l->st.updates += L.numUpdates - upd0;
+      l->st.updates += L.numUpdates - updSeen;     // (a pipelined loop counts a frame's update when it is queued: one step later)
+      updSeen = L.numUpdates;
       l->st.evaluations += L.evaluations - ev0;
       l->st.track_launches += L.launches - la0;
       l->st.tracked_good += L.numTrackedGood - good0;
@@ -146,6 +147,11 @@ extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int 
       if (out7) est.to7(out7 + 7 * (size_t)i);
       done++;
       if (stop_at_keyframe && L.newKeyframe) break;
+    }
+    l->loop->flushDeferredMapping();
+    {
+      const long upd = l->loop->numUpdates - updSeen;
+      l->st.updates += upd;
     }
     l->ctx->synchronize();   // one synchronisation per batch: the enqueued mapping work belongs to this batch's time
     l->wall += now_s() - t0;
