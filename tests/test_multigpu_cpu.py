@@ -88,3 +88,6 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
+    # what an N-rank run adds to the line: one rate per rank (BASELINE.json configs[3]) and the row-band regulariser across the ranks
+    # (configs[4]: lsdband_run's RCCL halo exchange) — bench.py::bands_distributed
+    assert d["per_rank_frames_s"] == [None, None] and "reg_3840x2160_bands" in d["extra_configs"]
