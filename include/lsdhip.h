@@ -99,6 +99,15 @@ int lsdhip_frame_create_from_device(lsdhip_ctx* ctx, int id, const uint8_t* gray
  * C/LiveSLAMWrapper.cpp:82-118).  gray_host must stay unchanged until a tracker call on the frame has returned or the context has
  * been synchronised; pinned memory makes the copy a true asynchronous DMA. */
 int lsdhip_frame_create_async(lsdhip_ctx* ctx, int id, const uint8_t* gray_host, lsdhip_frame** out);
+/* The new frames of n sequences at once: two launches for all of them instead of two per frame; the planes of every frame are
+ * those lsdhip_frame_create_from_device (images_on_device != 0) / lsdhip_frame_create (== 0: returns after the uploads) produce.
+ * gray: n image pointers (all device or all host), out: n handles.  Several sequences sharing one GPU (BASELINE.json configs[3]
+ * with more sequences than GPUs) enter the device through this call; no reference counterpart (one Frame constructor per image). */
+int lsdhip_frame_create_batch(lsdhip_ctx* ctx, int n, const int* ids, const uint8_t* const* gray, int images_on_device, lsdhip_frame** out);
+/* Frame-memory pool (FrameMemory::getBuffer / returnBuffer keep returned buffers for reuse, C/DataStructures/FrameMemory.cpp:67-117):
+ * make sure n frame arenas are allocated and waiting.  A loop that keeps its keyframes alive takes a fresh arena per keyframe; without
+ * the pool that is a hipMalloc of ~20 MB (0.5 ms) every keyframe. */
+int lsdhip_ctx_reserve_frames(lsdhip_ctx* ctx, int n);
 void lsdhip_frame_destroy(lsdhip_frame* f);
 int lsdhip_frame_id(lsdhip_frame* f);
 /* Frame::image/gradients/maxGradients/idepth/idepthVar(level) accessors (Frame.h:357-418), copied to host.
@@ -308,6 +317,11 @@ int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame* kf); /* se
 /* DepthMap::updateKeyframe(std::deque<std::shared_ptr<Frame>> referenceFrames) (DepthMap.cpp:1072-1213).
  * refs[0] is the oldest, refs[n-1] the newest frame of the deque. */
 int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int n);
+/* DepthMap::updateKeyframe for the depth maps of n sequences (one context), one tracked frame each (the blockUntilMapped deque of
+ * SlamSystem.cpp:559-571), in three launches for all of them (blockIdx.z = map): observe, fill holes + regularise + Frame::setDepth,
+ * idepth pyramid.  Every map ends bit-identical to lsdhip_depth_update(maps[j], &refs[j], 1).  Keyframes whose
+ * depthHasBeenUpdatedFlag is still set skip Frame::setDepth, as in the single call. */
+int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_frame** refs);
 /* DepthMap::createKeyFrame(Frame* new_keyframe) (DepthMap.cpp:1222-1327); rescale_out = rescaleFactor (:1294) */
 int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* new_keyframe, float* rescale_out);
 /* DepthMap::finalizeKeyFrame (DepthMap.cpp:1363-1395), incl. Frame::takeReActivationData */

@@ -75,6 +75,8 @@ def _signatures():
         "lsdhip_ctx_pipeline": (i, [vp]),
         "lsdhip_ctx_map_stream": (vp, [vp]),
         "lsdhip_frame_create_async": (i, [vp, i, vp, pvp]),
+        "lsdhip_frame_create_batch": (i, [vp, i, vp, pvp, i, pvp]),
+        "lsdhip_ctx_reserve_frames": (i, [vp, i]),
         "lsdhip_frame_relative_pose": (i, [vp, vp, vp]),
         "lsdhip_frame_publish_depth": (i, [vp]),
         "lsdhip_last_error": (C.c_char_p, []),
@@ -150,6 +152,7 @@ def _signatures():
         "lsdhip_depth_init_random": (i, [vp, vp]),
         "lsdhip_depth_set_from_existing": (i, [vp, vp]),
         "lsdhip_depth_update": (i, [vp, pvp, i]),
+        "lsdhip_depth_update_batch": (i, [i, pvp, pvp]),
         "lsdhip_depth_create_keyframe": (i, [vp, vp, C.POINTER(C.c_float)]),
         "lsdhip_depth_finalize": (i, [vp]),
         "lsdhip_depth_download": (i, [vp, vp]),

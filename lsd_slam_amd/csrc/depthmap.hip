@@ -604,6 +604,16 @@ __global__ __launch_bounds__(32 * ROWS) void k_observe(ObserveArgs a) {
   OBS_MARK(7);
 }
 
+// the same over the maps of several sequences (blockIdx.z = map; lsdhip_depth_update_batch): one reference frame per map, its
+// arguments read from a device array (uniform per workgroup: scalar loads)
+template <int ROWS>
+__global__ __launch_bounds__(32 * ROWS) void k_observe_batch(const ObserveArgs* __restrict__ items) {
+  const ObserveArgs& a = items[blockIdx.z];
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * ROWS + (threadIdx.x >> 5);
+  observe_pixel<true>(a, x, y);
+}
+
 struct RegArgs {
   HypPlanes m;
   const uint8_t* validIn;   // snapshot plane (read)
@@ -710,8 +720,8 @@ __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
 // the per-pixel arithmetic and its order are those of k_fill_holes / k_regularize above (and of the reference).
 //   id0 / var0 / partials: outputs of K8 (SET only): level-0 idepth planes of the keyframe and per-workgroup (sum, count).
 template <bool FILL, bool OCC, bool SET>
-__global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict__ id0, float* __restrict__ var0,
-                                                    double* __restrict__ partials) {
+__device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restrict__ id0, float* __restrict__ var0,
+                                               double* __restrict__ partials) {
   constexpr int HALO = FILL ? 4 : 2;
   constexpr int TW = 32 + 2 * HALO, TH = 8 + 2 * HALO, TN = TW * TH;
   __shared__ uint8_t s_valid[TN];     // snapshot validity
@@ -917,6 +927,29 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
       partials[2 * b] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
       partials[2 * b + 1] = (double)(((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3]);
     }
+  }
+}
+template <bool FILL, bool OCC, bool SET>
+__global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict__ id0, float* __restrict__ var0,
+                                                    double* __restrict__ partials) {
+  reg_fused_tile<FILL, OCC, SET>(a, id0, var0, partials);
+}
+// the update-time pass (fill holes + regularise [+ setDepth]) over the maps of several sequences, blockIdx.z = map
+struct RegBatchItem {
+  RegArgs a;
+  float* id0;          // null: this map's keyframe is not due for Frame::setDepth (depthHasBeenUpdatedFlag still set)
+  float* var0;
+  double* partials;
+};
+template <bool SET>
+__global__ __launch_bounds__(256) void k_reg_fused_batch(const RegBatchItem* __restrict__ items) {
+  const RegBatchItem& it = items[blockIdx.z];
+  if (SET) {
+    if (it.id0 == nullptr) return;
+    reg_fused_tile<true, false, true>(it.a, it.id0, it.var0, it.partials);
+  } else {
+    if (it.id0 != nullptr) return;
+    reg_fused_tile<true, false, false>(it.a, nullptr, nullptr, nullptr);
   }
 }
 
@@ -1415,6 +1448,26 @@ static void prepare_stereo(lsdhip_depthmap* dm, lsdhip_frame* fr, StereoRef& s) 
   s.initialTrackedResidual = fr->initialTrackedResidual;
 }
 
+// the part of k_observe's arguments that does not depend on the reference frames
+static void observe_args_common(lsdhip_depthmap* dm, ObserveArgs& a) {
+  lsdhip_ctx* c = dm->ctx;
+  lsdhip_frame* kf = dm->activeKeyFrame;
+  a.m = dm->cur;
+  a.kfImage = kf->d_image[0];
+  a.kfGrad = kf->d_grad[0];
+  a.kfMaxGrad = kf->d_maxgrad;
+  a.reactivated = dm->activeKeyFrameIsReactivated ? 1 : 0;
+  a.w = c->w; a.h = c->h;
+  const LevelIntr& in = c->intr[0];
+  a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
+  a.minUseGrad = c->params.minUseGrad;
+  a.cameraPixelNoise2 = c->params.cameraPixelNoise2;
+  a.allowNegativeIdepths = c->params.allowNegativeIdepths;
+  a.useSubpixelStereo = c->params.useSubpixelStereo;
+  a.kfNumFramesTrackedOnThis = kf->numFramesTrackedOnThis;
+  a.kfNumMappedOnThis = kf->numMappedOnThis;
+}
+
 static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   lsdhip_ctx* c = dm->ctx;
   LSD_CTX_LOCK(c);
@@ -1470,25 +1523,12 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
     memset(&a.one, 0, sizeof(a.one));
   }
 
-  a.m = dm->cur;
-  a.kfImage = kf->d_image[0];
-  a.kfGrad = kf->d_grad[0];
-  a.kfMaxGrad = kf->d_maxgrad;
   a.refs = dm->d_refs;
   a.refByID = dm->d_refByID;
   a.nByID = (int)nByID;
   a.byIDOffset = offset;
   a.nRefs = n;
-  a.reactivated = dm->activeKeyFrameIsReactivated ? 1 : 0;
-  a.w = c->w; a.h = c->h;
-  const LevelIntr& in = c->intr[0];
-  a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
-  a.minUseGrad = c->params.minUseGrad;
-  a.cameraPixelNoise2 = c->params.cameraPixelNoise2;
-  a.allowNegativeIdepths = c->params.allowNegativeIdepths;
-  a.useSubpixelStereo = c->params.useSubpixelStereo;
-  a.kfNumFramesTrackedOnThis = kf->numFramesTrackedOnThis;
-  a.kfNumMappedOnThis = kf->numMappedOnThis;
+  observe_args_common(dm, a);
 #ifdef LSD_PHASE_TRACE
   {
     const size_t words = (size_t)((c->w + 31) / 32) * ((c->h + 7) / 8) * 16;
@@ -1744,6 +1784,103 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);   // host wall time of the call (enqueue time only in async mode)
   kf->numMappedOnThis++;
   kf->numMappedOnThisTotal++;
+  return LSDHIP_OK;
+}
+
+// DepthMap::updateKeyframe for the maps of n sequences, one tracked frame each (the blockUntilMapped deque), in three launches for
+// all of them: k_observe_batch, k_reg_fused_batch (+ its non-setDepth twin if some keyframe is not due), k_idepth_pyramid_batch.
+// Per map the arithmetic, the launch geometry inside its z-slice and therefore every plane are those of lsdhip_depth_update.
+extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_frame** refs) {
+  if (n <= 0 || !maps || !refs) return LSDHIP_E_ARG;
+  for (int j = 0; j < n; j++) if (!maps[j] || !refs[j]) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = maps[0]->ctx;
+  LSD_CTX_LOCK(c);
+  for (int j = 0; j < n; j++) {
+    lsdhip_depthmap* dm = maps[j];
+    if (dm->ctx != c || refs[j]->ctx != c) { lsd_set_error("updateKeyframe batch: maps and frames of one batch live on one context"); return LSDHIP_E_ARG; }
+    if (!dm->activeKeyFrame) { lsd_set_error("updateKeyframe batch: depth map %d has no active keyframe", j); return LSDHIP_E_STATE; }
+    for (int i = 0; i < j; i++) if (maps[i] == dm) { lsd_set_error("updateKeyframe batch: depth map %d appears twice", j); return LSDHIP_E_ARG; }
+    if (refs[j]->trackingParentID != dm->activeKeyFrame->id) {
+      lsd_set_error("updateKeyframe: frame %d was tracked on keyframe %d, active keyframe is %d (pose-graph path is out of scope)",
+                    refs[j]->id, refs[j]->trackingParentID, dm->activeKeyFrame->id);
+      return LSDHIP_E_STATE;
+    }
+  }
+  HIPCHK(hipSetDevice(c->device));
+  double t0 = now_ms();
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  const hipStream_t ms = lsd_map_stream(c);
+  // ---- observe ---------------------------------------------------------------------------------------------------------------------
+  const size_t obsBytes = (sizeof(ObserveArgs) * (size_t)n + 255) / 256 * 256;
+  std::vector<uint8_t> blob(obsBytes + sizeof(RegBatchItem) * (size_t)n);
+  ObserveArgs* oa = (ObserveArgs*)blob.data();
+  RegBatchItem* ra = (RegBatchItem*)(blob.data() + obsBytes);
+  int nSet = 0;
+  for (int j = 0; j < n; j++) {
+    lsdhip_depthmap* dm = maps[j];
+    lsdhip_frame* kf = dm->activeKeyFrame;
+    ObserveArgs& a = oa[j];
+    memset((void*)&a, 0, sizeof(a));
+    prepare_stereo(dm, refs[j], a.one);
+    a.refs = nullptr; a.refByID = nullptr; a.nByID = 1; a.byIDOffset = refs[j]->id; a.nRefs = 1;
+    observe_args_common(dm, a);
+#ifdef LSD_PHASE_TRACE
+    a.trace = nullptr;
+#endif
+    dm->d_refs = nullptr;
+    dm->d_refByID = nullptr;
+    // the regulariser pass that follows: reads cur.valid, writes the spare plane (swapped below, as fill_regularize does)
+    RegBatchItem& r = ra[j];
+    r.a = reg_args(dm, VAL_SUM_MIN_FOR_KEEP);
+    const bool setDepth = !kf->depthHasBeenUpdatedFlag;
+    r.id0 = setDepth ? lsd_depth_w(kf)[0] : nullptr;
+    r.var0 = setDepth ? lsd_depthvar_w(kf)[0] : nullptr;
+    r.partials = dm->d_red + 16;
+    if (setDepth) nSet++;
+  }
+  void* dev = nullptr;
+  int rc = lsd_args_push(c, blob.data(), blob.size(), ms, &dev);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_observe_batch<2>), dim3((c->w + 31) / 32, (c->h + 1) / 2, n), dim3(64), 0, ms, (const ObserveArgs*)dev);
+  const RegBatchItem* dra = (const RegBatchItem*)((const uint8_t*)dev + obsBytes);
+  const dim3 rgrid((c->w + 31) / 32, (c->h + 7) / 8, n);
+  if (nSet > 0) hipLaunchKernelGGL((k_reg_fused_batch<true>), rgrid, dim3(256), 0, ms, dra);
+  if (nSet < n) hipLaunchKernelGGL((k_reg_fused_batch<false>), rgrid, dim3(256), 0, ms, dra);
+  HIPCHK(hipGetLastError());
+  for (int j = 0; j < n; j++) swap_valid(maps[j]);
+  // ---- Frame::setDepth's second half for the keyframes that were due -------------------------------------------------------------------
+  if (nSet > 0) {
+    std::vector<lsdhip_frame*> kfs;
+    std::vector<const double*> parts;
+    std::vector<double*> outs;
+    for (int j = 0; j < n; j++) {
+      lsdhip_frame* kf = maps[j]->activeKeyFrame;
+      if (kf->depthHasBeenUpdatedFlag) continue;
+      const int slot = lsd_ctx_take_slot(c);
+      if (slot < 0) return slot;
+      if (kf->pendStats >= 0) c->slot_stats_owner[kf->pendStats] = nullptr;
+      kf->pendStats = slot;
+      c->slot_stats_owner[slot] = kf;
+      kfs.push_back(kf);
+      parts.push_back(maps[j]->d_red + 16);
+      outs.push_back((double*)&c->h_slots[slot]);
+    }
+    rc = lsd_frame_build_idepth_pyramid_batch(kfs.data(), (int)kfs.size(), parts.data(), (int)(rgrid.x * rgrid.y), outs.data());
+    if (rc) return rc;
+    for (lsdhip_frame* kf : kfs) kf->depthHasBeenUpdatedFlag = true;
+  }
+  if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
+  if (!c->async) {
+    HIPCHK(hipStreamSynchronize(ms));
+    for (int j = 0; j < n; j++) { rc = lsd_frame_resolve(maps[j]->activeKeyFrame); if (rc) return rc; }
+  }
+  const double dt = now_ms() - t0;
+  for (int j = 0; j < n; j++) {
+    lsdhip_depthmap* dm = maps[j];
+    dm->msUpdate = ema(dm->msUpdate, dt / n);
+    dm->activeKeyFrame->numMappedOnThis++;
+    dm->activeKeyFrame->numMappedOnThisTotal++;
+  }
   return LSDHIP_OK;
 }
 

@@ -24,10 +24,10 @@
 // HBM traffic: 1 B/px read (uint8) + 4 B * (1 + 1/4 + 1/16 + 1/64 + 1/256) written.
 // The same workgroup also writes the level-0 gradient texels (gx, gy, I, 0) and |grad| of its 16x16 pixels, straight from
 // the uint8 source (the float image is its exact conversion), with the reference's linear-index neighbour rule.
-__global__ __launch_bounds__(256) void k_image_pyramid(const uint8_t* __restrict__ gray, float* __restrict__ i0,
-                                                        float* __restrict__ i1, float* __restrict__ i2,
-                                                        float* __restrict__ i3, float* __restrict__ i4, int w, int h,
-                                                        float4* __restrict__ grad0, float* __restrict__ absgrad0) {
+__device__ __forceinline__ void image_pyramid_tile(const uint8_t* __restrict__ gray, float* __restrict__ i0,
+                                                   float* __restrict__ i1, float* __restrict__ i2,
+                                                   float* __restrict__ i3, float* __restrict__ i4, int w, int h,
+                                                   float4* __restrict__ grad0, float* __restrict__ absgrad0) {
   __shared__ float s0[16][17];
   __shared__ float s1[8][9];
   __shared__ float s2[4][5];
@@ -86,6 +86,23 @@ __global__ __launch_bounds__(256) void k_image_pyramid(const uint8_t* __restrict
     i4[by * (w >> 4) + bx] = (c0 + c1) * 0.25f;
   }
 }
+__global__ __launch_bounds__(256) void k_image_pyramid(const uint8_t* __restrict__ gray, float* __restrict__ i0,
+                                                        float* __restrict__ i1, float* __restrict__ i2,
+                                                        float* __restrict__ i3, float* __restrict__ i4, int w, int h,
+                                                        float4* __restrict__ grad0, float* __restrict__ absgrad0) {
+  image_pyramid_tile(gray, i0, i1, i2, i3, i4, w, h, grad0, absgrad0);
+}
+// the same for the new frames of several sequences in one launch (blockIdx.z = frame; lsdhip_frame_create_batch)
+struct ImagePyrItem {
+  const uint8_t* gray;
+  float* img[LSD_LEVELS];
+  float4* grad0;
+  float* absgrad0;
+};
+__global__ __launch_bounds__(256) void k_image_pyramid_batch(const ImagePyrItem* __restrict__ items, int w, int h) {
+  const ImagePyrItem it = items[blockIdx.z];
+  image_pyramid_tile(it.gray, it.img[0], it.img[1], it.img[2], it.img[3], it.img[4], w, h, it.grad0, it.absgrad0);
+}
 
 struct GradArgs {
   const float* img[LSD_LEVELS];
@@ -110,7 +127,7 @@ struct GradMaxArgs {
   uint32_t* wasGoodWords;
   int nMaskWords;
 };
-__global__ __launch_bounds__(256) void k_gradients_max(GradMaxArgs a) {
+__device__ __forceinline__ void gradients_max_block(const GradMaxArgs& a) {
   const int b = blockIdx.x;
   if (b < a.blk0[LSD_LEVELS]) {
     int l = 1;
@@ -157,6 +174,14 @@ __global__ __launch_bounds__(256) void k_gradients_max(GradMaxArgs a) {
   }
   a.maxgrad[i] = out;
 }
+__global__ __launch_bounds__(256) void k_gradients_max(GradMaxArgs a) { gradients_max_block(a); }
+__global__ __launch_bounds__(256) void k_gradients_max_batch(const GradMaxArgs* __restrict__ items) {
+  __shared__ GradMaxArgs s_a;     // (a by-value copy of an indexed record would live in scratch: the level tables are indexed dynamically)
+  const int* src = (const int*)(items + blockIdx.y);
+  for (int i = threadIdx.x; i < (int)(sizeof(GradMaxArgs) / 4); i += 256) ((int*)&s_a)[i] = src[i];
+  __syncthreads();
+  gradients_max_block(s_a);
+}
 
 // inverse-variance pooling of one 2x2 block, children in the order idx, idx+1, idx+sw, idx+sw+1
 __device__ __forceinline__ void pool4(const float id[4], const float var[4], float& oid, float& ovar) {
@@ -193,7 +218,7 @@ struct DepthPyrArgs {
 };
 
 // Levels 1..4 of (idepth, idepthVar) from level 0, one 16x16 level-0 tile per workgroup.
-__global__ __launch_bounds__(256) void k_idepth_pyramid(DepthPyrArgs a) {
+__device__ __forceinline__ void idepth_pyramid_tile(const DepthPyrArgs& a) {
   __shared__ float sid[16][17], svar[16][17];
   __shared__ float tid1[8][9], tvar1[8][9];
   __shared__ float tid2[4][5], tvar2[4][5];
@@ -264,6 +289,11 @@ __global__ __launch_bounds__(256) void k_idepth_pyramid(DepthPyrArgs a) {
     int o = by * (w0 >> 4) + bx;
     a.id[4][o] = oi; a.var[4][o] = ov;
   }
+}
+__global__ __launch_bounds__(256) void k_idepth_pyramid(DepthPyrArgs a) { idepth_pyramid_tile(a); }
+__global__ __launch_bounds__(256) void k_idepth_pyramid_batch(const DepthPyrArgs* __restrict__ items) {
+  const DepthPyrArgs a = items[blockIdx.z];
+  idepth_pyramid_tile(a);
 }
 
 // Frame::setDepthFromGroundTruth
@@ -432,6 +462,9 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   for (void* a : c->free_arenas) (void)hipFree(a);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->h_slots) (void)hipHostFree(c->h_slots);
+  if (c->args.h) (void)hipHostFree(c->args.h);
+  if (c->args.d) (void)hipFree(c->args.d);
+  for (hipEvent_t e : c->args.ev) if (e) (void)hipEventDestroy(e);
   if (c->d_gtStage) (void)hipFree(c->d_gtStage);
   if (c->d_flagArrive) (void)hipFree(c->d_flagArrive);
   if (c->d_gate) (void)hipFree(c->d_gate);
@@ -1015,6 +1048,60 @@ int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, i
   return LSDHIP_OK;
 }
 
+int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out) {
+  LSD_CTX_LOCK(c);
+  lsdhip_ctx::ArgRing& r = c->args;
+  constexpr int NS = 8;
+  if (bytes > r.slotBytes) {
+    // grow: nothing may still read the old block
+    HIPCHK(hipDeviceSynchronize());
+    if (r.h) { (void)hipHostFree(r.h); r.h = nullptr; }
+    if (r.d) { (void)hipFree(r.d); r.d = nullptr; }
+    r.slotBytes = 0;
+    const size_t want = align_up(bytes * 2 > 65536 ? bytes * 2 : 65536, 256);
+    HIPCHK(hipHostMalloc((void**)&r.h, want * NS, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&r.d, want * NS));
+    r.slotBytes = want;
+    for (int i = 0; i < NS; i++) { r.used[i] = false; if (!r.ev[i]) HIPCHK(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming)); }
+  }
+  const int i = r.next;
+  r.next = (r.next + 1) % NS;
+  if (r.used[i]) HIPCHK(hipEventSynchronize(r.ev[i]));   // (seven pushes ago: long finished)
+  memcpy(r.h + (size_t)i * r.slotBytes, src, bytes);
+  HIPCHK(hipMemcpyAsync(r.d + (size_t)i * r.slotBytes, r.h + (size_t)i * r.slotBytes, bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(r.ev[i], s));
+  r.used[i] = true;
+  *dev_out = r.d + (size_t)i * r.slotBytes;
+  return LSDHIP_OK;
+}
+
+int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double* const* redPartials, int redN, double* const* redOut) {
+  if (n <= 0) return LSDHIP_OK;
+  lsdhip_ctx* c = fs[0]->ctx;
+  LSD_CTX_LOCK(c);
+  std::vector<DepthPyrArgs> items((size_t)n);
+  for (int j = 0; j < n; j++) {
+    lsdhip_frame* f = fs[j];
+    if (!c->pipeline) f->depthVersion++;
+    DepthPyrArgs& a = items[j];
+    float** id = lsd_depth_w(f);
+    float** var = lsd_depthvar_w(f);
+    for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = id[l]; a.var[l] = var[l]; }
+    a.w0 = c->w;
+    a.redPartials = redPartials[j]; a.redN = redN; a.redOut = redOut[j];
+  }
+  void* dev = nullptr;
+  int rc = lsd_args_push(c, items.data(), sizeof(DepthPyrArgs) * (size_t)n, lsd_map_stream(c), &dev);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_idepth_pyramid_batch, dim3(c->w / 16, c->h / 16 + 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
+  HIPCHK(hipGetLastError());
+  for (int j = 0; j < n; j++) {
+    if (c->pipeline) { fs[j]->depthPending = true; fs[j]->depthPendingSeq = c->mSeq + 1; }
+    else fs[j]->hasIDepth = true;
+  }
+  return LSDHIP_OK;
+}
+
 int lsd_frame_ensure_wasgood(lsdhip_frame* f) {
   if (!f->wasGoodValid) {
     if (!f->wasGoodPristine) HIPCHK(hipMemsetAsync(f->d_wasGood, 0xFF, (size_t)f->ctx->wl[1] * f->ctx->hl[1], f->ctx->stream));
@@ -1079,11 +1166,89 @@ extern "C" int lsdhip_frame_create(lsdhip_ctx* c, int id, const uint8_t* gray_ho
 extern "C" int lsdhip_frame_create_async(lsdhip_ctx* c, int id, const uint8_t* gray_host, lsdhip_frame** out) {
   return frame_create_host(c, id, gray_host, false, out);
 }
+// Frame-memory pool (the reference's FrameMemory keeps returned buffers for reuse, util/... FrameMemory.cpp): make sure n arenas are
+// allocated and waiting, so that a loop which keeps its keyframes alive does not pay a hipMalloc (0.5 ms for 20 MB) per keyframe.
+extern "C" int lsdhip_ctx_reserve_frames(lsdhip_ctx* c, int n) {
+  if (!c || n < 0) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  if ((size_t)n > c->arena_keep) c->arena_keep = (size_t)n;
+  std::vector<lsdhip_frame*> tmp;
+  int rc = LSDHIP_OK;
+  const size_t have = c->free_arenas.size();
+  for (size_t i = 0; i < (size_t)n && rc == LSDHIP_OK; i++) {   // the first `have` come out of the pool, the rest are new
+    lsdhip_frame* f = nullptr;
+    rc = frame_alloc(c, -1, &f);
+    if (rc == LSDHIP_OK) tmp.push_back(f);
+  }
+  (void)have;
+  for (lsdhip_frame* f : tmp) lsdhip_frame_destroy(f);
+  return rc;
+}
+// Frame creation for the new frames of n sequences at once: two launches for all of them (blockIdx.z / .y = frame) instead of two per
+// frame.  Same planes, bit for bit, as n lsdhip_frame_create_from_device / lsdhip_frame_create calls.
+extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, const uint8_t* const* gray, int images_on_device, lsdhip_frame** out) {
+  if (!c || n <= 0 || !ids || !gray || !out) return LSDHIP_E_ARG;
+  for (int j = 0; j < n; j++) if (!gray[j]) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  if ((size_t)(2 * n + 8) > c->arena_keep) c->arena_keep = (size_t)(2 * n + 8);   // a round of n frames retires n arenas at once
+  for (int j = 0; j < n; j++) out[j] = nullptr;
+  auto fail = [&](int rc) { for (int j = 0; j < n; j++) if (out[j]) { lsdhip_frame_destroy(out[j]); out[j] = nullptr; } return rc; };
+  for (int j = 0; j < n; j++) { int rc = frame_alloc(c, ids[j], &out[j]); if (rc) return fail(rc); }
+  const hipStream_t ms = lsd_map_stream(c);
+  int rc = lsd_m_begin(c);
+  if (rc) return fail(rc);
+  std::vector<ImagePyrItem> pi((size_t)n);
+  std::vector<GradMaxArgs> gi((size_t)n);
+  int nb = 0;
+  for (int j = 0; j < n; j++) {
+    lsdhip_frame* f = out[j];
+    if (!images_on_device) {
+      hipError_t e = hipMemcpyAsync(f->d_gray, gray[j], (size_t)c->w * c->h, hipMemcpyHostToDevice, ms);
+      if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: upload failed: %s", hipGetErrorString(e)); return fail(LSDHIP_E_HIP); }
+    }
+    pi[j].gray = images_on_device ? gray[j] : f->d_gray;
+    for (int l = 0; l < LSD_LEVELS; l++) pi[j].img[l] = f->d_image[l];
+    pi[j].grad0 = f->d_grad[0]; pi[j].absgrad0 = f->d_absgrad;
+    GradMaxArgs& ga = gi[j];
+    nb = 0;
+    for (int l = 0; l < LSD_LEVELS; l++) {
+      ga.img[l] = f->d_image[l]; ga.grad[l] = f->d_grad[l]; ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l];
+      ga.blk0[l] = nb;
+      if (l >= 1) nb += (c->wl[l] * c->hl[l] + 255) / 256;
+    }
+    ga.blk0[LSD_LEVELS] = nb;
+    ga.absg = f->d_absgrad; ga.maxgrad = f->d_maxgrad;
+    ga.wasGoodWords = (uint32_t*)f->d_wasGood; ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
+    f->wasGoodPristine = true;
+  }
+  const size_t piBytes = align_up(sizeof(ImagePyrItem) * (size_t)n, 256);
+  std::vector<uint8_t> blob(piBytes + sizeof(GradMaxArgs) * (size_t)n);
+  memcpy(blob.data(), pi.data(), sizeof(ImagePyrItem) * (size_t)n);
+  memcpy(blob.data() + piBytes, gi.data(), sizeof(GradMaxArgs) * (size_t)n);
+  void* dev = nullptr;
+  rc = lsd_args_push(c, blob.data(), blob.size(), ms, &dev);
+  if (rc) return fail(rc);
+  hipLaunchKernelGGL(k_image_pyramid_batch, dim3(c->w / 16, c->h / 16, n), dim3(256), 0, ms, (const ImagePyrItem*)dev, c->w, c->h);
+  const int n0 = c->w * c->h;
+  hipLaunchKernelGGL(k_gradients_max_batch, dim3(nb + (n0 + 255) / 256, n), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + piBytes));
+  if (hipGetLastError() != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: launch failed"); return fail(LSDHIP_E_HIP); }
+  const long long seq = lsd_m_record(c);
+  if (seq < 0) return fail(LSDHIP_E_HIP);
+  for (int j = 0; j < n; j++) out[j]->readySeq = seq;
+  if (!images_on_device) {
+    hipError_t e = hipStreamSynchronize(ms);   // the host buffers may be reused by the caller
+    if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: %s", hipGetErrorString(e)); return fail(LSDHIP_E_HIP); }
+    if (c->pipeline) c->mDoneSeq = c->mSeq;
+  }
+  return LSDHIP_OK;
+}
 extern "C" void lsdhip_frame_destroy(lsdhip_frame* f) {
   if (!f) return;
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
-  if (c->free_arenas.size() < 16) {
+  if (c->free_arenas.size() < c->arena_keep) {
     c->free_arenas.push_back(f->d_gray);   // arena base; reuse is ordered by the stream itself
   } else {
     (void)hipSetDevice(c->device);

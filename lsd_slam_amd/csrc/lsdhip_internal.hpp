@@ -141,7 +141,7 @@ struct TrackSummary {
 // of a createKeyFrame): written by the device into a pinned slot, read by the host at the first later point that
 // synchronises anyway (or when somebody asks for the value).
 struct DeferredSlot { double sum, count, flag, pad; };
-#define LSD_NUM_SLOTS 32
+#define LSD_NUM_SLOTS 256
 struct lsdhip_frame;
 
 // Host-side state of a context (arena free list, deferred-result slot ring and its owner tables, profiling events, the
@@ -213,7 +213,11 @@ struct lsdhip_ctx {
   // recycled frame arenas (the FrameMemory idea, C/DataStructures/FrameMemory.cpp:67-127, for device buffers);
   // reuse is stream-ordered, so no synchronisation is needed when a frame dies
   std::vector<void*> free_arenas;
+  size_t arena_keep = 16;                // arenas of destroyed frames kept for reuse (grows with the batch width of lsdhip_frame_create_batch)
   float* d_gtStage = nullptr;                        // w x h floats: staging of lsdhip_frame_set_depth_gt
+  // kernel-argument arrays of the batched launches (several sequences per launch): pinned staging slots and their device twins,
+  // reused round-robin; a slot is rewritten only after the copy that last read it has completed (lsd_args_push)
+  struct ArgRing { uint8_t* h = nullptr; uint8_t* d = nullptr; size_t slotBytes = 0; int next = 0; hipEvent_t ev[8] = {}; bool used[8] = {}; } args;
   std::vector<struct lsdhip_depthmap*> depthmaps;   // alive on this context: a destroyed frame is unhooked from them
   size_t arena_bytes = 0;
 };
@@ -420,6 +424,10 @@ struct LsdTrackJobScope {
   ~LsdTrackJobScope() { if (c->pipeline && drain) (void)hipStreamSynchronize(c->stream); }
 };
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream);
+// copies `bytes` of kernel-argument records to the device on `s` (stream-ordered) and returns the device address
+int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out);
+// Frame::setDepth's second half for n keyframes in one launch (lsdhip_depth_update_batch)
+int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** f, int n, const double* const* redPartials, int redN, double* const* redOut);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);   // on lsd_map_stream, into lsd_depth_w
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);

@@ -55,6 +55,10 @@ class Context:
         """tracking stream beside mapping stream (lsdhip_ctx_set_pipeline): the reference's two threads with blockUntilMapped == false"""
         check(self.L.lsdhip_ctx_set_pipeline(self.h_, int(bool(on))))
 
+    def reserve_frames(self, n):
+        """frame-memory pool: n arenas allocated ahead (lsdhip_ctx_reserve_frames)"""
+        check(self.L.lsdhip_ctx_reserve_frames(self.h_, int(n)), False)
+
     def intrinsics(self, level):
         out = np.zeros(8, np.float32)
         check(self.L.lsdhip_ctx_intrinsics(self.h_, level, out.ctypes.data))
@@ -92,6 +96,29 @@ class Frame:
         self.h_ = h_
         self._id = id_
         self._parent = None
+
+    @classmethod
+    def createBatch(cls, ctx, ids, images=None, device_ptrs=None):
+        """the new frames of several sequences in two launches (lsdhip_frame_create_batch) -> list of Frame"""
+        n = len(ids)
+        ida = (C.c_int * n)(*[int(v) for v in ids])
+        out = (C.c_void_p * n)()
+        if device_ptrs is not None:
+            ptrs = (C.c_void_p * n)(*[int(p) for p in device_ptrs])
+            check(ctx.L.lsdhip_frame_create_batch(ctx.h_, n, ida, ptrs, 1, out), False)
+        else:
+            imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+            for im in imgs:
+                if im.shape != (ctx.h, ctx.w):
+                    raise ValueError("image must be %dx%d uint8" % (ctx.w, ctx.h))
+            ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+            check(ctx.L.lsdhip_frame_create_batch(ctx.h_, n, ida, ptrs, 0, out), False)
+        frames = []
+        for j in range(n):
+            f = cls.__new__(cls)
+            f.ctx, f.L, f.h_, f._id, f._parent = ctx, ctx.L, C.c_void_p(out[j]), int(ids[j]), None
+            frames.append(f)
+        return frames
 
     def __del__(self):
         self.close()
@@ -459,6 +486,14 @@ class DepthMap:
     def updateKeyframe(self, referenceFrames):
         frames = list(referenceFrames)
         check(self.L.lsdhip_depth_update(self.h_, self._arr(frames), len(frames)), False)
+
+    @staticmethod
+    def updateKeyframeBatch(maps, frames):
+        """updateKeyframe of several sequences' maps, one tracked frame each, in shared launches (lsdhip_depth_update_batch)"""
+        n = len(maps)
+        ma = (C.c_void_p * n)(*[m.h_ for m in maps])
+        fa = (C.c_void_p * n)(*[f.h_ for f in frames])
+        check(maps[0].L.lsdhip_depth_update_batch(n, ma, fa), False)
 
     def createKeyFrame(self, new_keyframe):
         self._keep.append(new_keyframe)

@@ -1,0 +1,118 @@
+"""Several sequences sharing one GPU (BASELINE.json configs[3] with more sequences than GPUs): the batched entries
+lsdhip_frame_create_batch and lsdhip_depth_update_batch put the work of n sequences into the same launches (blockIdx.z = sequence).
+Per sequence nothing changes — same arithmetic, same launch geometry inside its slice — so every plane must be BIT-identical to what
+the single calls leave, which are the ones checked against the oracle in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from common import ODOMETRY_ITS, assert_bit_equal, sequence
+
+pytestmark = pytest.mark.gpu
+
+IDENT7 = np.array([1.0, 0, 0, 0, 0, 0, 0])
+HYP_FIELDS = ("isValid", "blacklisted", "nextStereoFrameMinID", "validity_counter", "idepth", "idepth_var", "idepth_smoothed", "idepth_var_smoothed")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import lsd_slam_amd as la
+    return la
+
+
+def assert_maps_equal(a, b, what):
+    for k in HYP_FIELDS:
+        if k in ("isValid", "blacklisted", "nextStereoFrameMinID", "validity_counter"):
+            assert np.array_equal(a[k], b[k]), "%s: %s differs at %d pixels" % (what, k, int((a[k] != b[k]).sum()))
+        else:
+            v = a["isValid"] > 0
+            assert_bit_equal(a[k][v], b[k][v], "%s: %s" % (what, k))
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_frame_create_batch_equals_single_creations(hip, on_device):
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 6)
+    ctx = hip.Context(w, h, K)
+    single = [hip.Frame(ctx, 10 + j, frames[j]) for j in range(6)]
+    if on_device:
+        import torch
+        d = torch.from_numpy(np.ascontiguousarray(frames[:6])).cuda()
+        torch.cuda.synchronize()
+        batch = hip.Frame.createBatch(ctx, [10 + j for j in range(6)], device_ptrs=[d[j].data_ptr() for j in range(6)])
+    else:
+        batch = hip.Frame.createBatch(ctx, [10 + j for j in range(6)], images=[frames[j] for j in range(6)])
+    for j in range(6):
+        assert batch[j].id() == 10 + j
+        for lvl in range(5):
+            assert_bit_equal(batch[j].image(lvl), single[j].image(lvl), "frame %d image level %d" % (j, lvl))
+            assert_bit_equal(batch[j].gradients(lvl), single[j].gradients(lvl), "frame %d gradients level %d" % (j, lvl))
+        assert_bit_equal(batch[j].maxGradients(0), single[j].maxGradients(0), "frame %d maxGradients" % j)
+        assert batch[j].refPixelWasGoodNoCreate() is None            # the mask starts "never written", as after a single creation
+
+
+def test_depth_update_batch_equals_single_calls(hip):
+    """S sequences, each with its own keyframe / depth map, twice: set A goes through lsdhip_depth_update one map at a time, set B
+    through lsdhip_depth_update_batch.  Four rounds, with a keyframe whose depthHasBeenUpdatedFlag is still set in some of them (that
+    map skips Frame::setDepth inside the shared launch).  Depth maps and keyframe depth pyramids equal bit for bit after every round."""
+    w, h = 320, 240
+    S = 5
+    seqs = [sequence(w, h, 6, seq_index=s) for s in range(S)]
+    ctx = hip.Context(w, h, seqs[0][2])
+    tr = hip.SE3Tracker(ctx)
+    tr.set_maxItsPerLvl(ODOMETRY_ITS)
+    sets = []
+    for copy in range(2):
+        cur = []
+        for s, (frames, depth0, K, gt) in enumerate(seqs):
+            kf = hip.Frame(ctx, 1000 * s, frames[0])
+            kf.setDepthFromGroundTruth(depth0)
+            dm = hip.DepthMap(ctx)
+            dm.initializeFromGTDepth(kf)
+            ref = hip.TrackingReference()
+            ref.importFrame(kf)
+            kf.clearDepthHasBeenUpdatedFlag()
+            cur.append({"kf": kf, "map": dm, "ref": ref, "pose": IDENT7.copy()})
+        sets.append(cur)
+    for rnd in range(1, 5):
+        tracked = [[], []]
+        for copy in range(2):
+            for s in range(S):
+                st = sets[copy][s]
+                fr = hip.Frame(ctx, 1000 * s + rnd, seqs[s][0][rnd])
+                st["pose"] = tr.trackFrame(st["ref"], fr, st["pose"])
+                tracked[copy].append(fr)
+        for s in range(S):
+            sets[0][s]["map"].updateKeyframe([tracked[0][s]])
+        hip.DepthMap.updateKeyframeBatch([sets[1][s]["map"] for s in range(S)], tracked[1])
+        for s in range(S):
+            a, b = sets[0][s], sets[1][s]
+            assert_maps_equal(a["map"].currentDepthMap(), b["map"].currentDepthMap(), "round %d sequence %d" % (rnd, s))
+            assert a["kf"].depthHasBeenUpdatedFlag() == b["kf"].depthHasBeenUpdatedFlag()
+            for lvl in range(5):
+                assert_bit_equal(a["kf"].idepth(lvl), b["kf"].idepth(lvl), "round %d sequence %d idepth level %d" % (rnd, s, lvl))
+                assert_bit_equal(a["kf"].idepthVar(lvl), b["kf"].idepthVar(lvl), "round %d sequence %d idepthVar level %d" % (rnd, s, lvl))
+            sa, sb = a["kf"].stats(), b["kf"].stats()
+            assert sa["meanIdepth"] == sb["meanIdepth"] and sa["numPoints"] == sb["numPoints"] and sa["numMappedOnThis"] == sb["numMappedOnThis"]
+            # the tracking thread's import: every sequence but the odd ones in round 2 (their keyframes keep the flag: no setDepth next round)
+            if not (rnd == 2 and s % 2 == 1):
+                for st in (a, b):
+                    st["ref"].importFrame(st["kf"])
+                    st["kf"].clearDepthHasBeenUpdatedFlag()
+
+
+def test_depth_update_batch_rejects_what_the_single_call_rejects(hip):
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 3)
+    ctx = hip.Context(w, h, K)
+    kf = hip.Frame(ctx, 0, frames[0])
+    kf.setDepthFromGroundTruth(depth0)
+    dm = hip.DepthMap(ctx)
+    dm.initializeFromGTDepth(kf)
+    fr = hip.Frame(ctx, 1, frames[1])                       # never tracked: no tracking parent
+    with pytest.raises(Exception):
+        hip.DepthMap.updateKeyframeBatch([dm], [fr])
+    empty = hip.DepthMap(ctx)                                # no active keyframe
+    with pytest.raises(Exception):
+        hip.DepthMap.updateKeyframeBatch([empty], [fr])
+    with pytest.raises(Exception):
+        hip.DepthMap.updateKeyframeBatch([dm, dm], [fr, fr])  # the same map twice
