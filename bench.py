@@ -323,6 +323,50 @@ def bands_distributed(torch, dist, rank, world, local_rank, passes=20):
     return rec if rank == 0 else None
 
 
+def multi_seq(torch, w, h, K, d_frames, depth0, device, single_value, sizes=(8, 32), steps=30, warmup=10, regions=3):
+    """BASELINE.json configs[3] with more sequences than GPUs: S independent sequences share this GPU (lsd_slam_hip::SlamLoopBatch — per
+    sequence the blockUntilMapped loop; frame creation, tracking jobs and updateKeyframe calls of all sequences in shared launches).
+    The sequences are four camera motions over the bench scene (the closed camera loop forwards / backwards at one and two frames per
+    step, all starting on frame 0 with its ground-truth depth), each replicated S / 4 times with its own frames, keyframes and maps.
+    Replicas must come out bit-identical (same inputs through different z-slices of the same launches): checked here."""
+    from lsd_slam_amd.driver import DriverLoopBatch
+    from lsd_slam_amd import capi
+    n = d_frames.shape[0]
+    motions = [(1, 1), (-1, 1), (1, 2), (-1, 2)]
+    out = {"workload": "S sequences x 640x480 track+map loop on one GPU (BASELINE.json configs[3], sequences > GPUs), 4 camera motions x S/4 replicas, "
+                       "new keyframe every %d frames, %d timed steps (= frames per sequence)" % (KF_EVERY, steps)}
+    for S in sizes:
+        idx = lambda s, t: (motions[s % 4][0] * motions[s % 4][1] * t) % n
+        ptrs = lambda t: [d_frames[idx(s, t)].data_ptr() for s in range(S)]
+        loop = DriverLoopBatch(w, h, K, ptrs(0), [depth0] * S, kf_every=KF_EVERY, images_on_device=True, device=device)
+        L = capi.lib()
+        ctx_h = loop.ctx_handle()
+        t = 1
+        loop.run([ptrs(t + k) for k in range(warmup)])
+        t += warmup
+        capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+        dts, poses = [], None
+        for _ in range(regions):
+            batch = [ptrs(t + k) for k in range(steps)]
+            t0 = time.perf_counter()
+            done, poses = loop.run(batch, want_poses=True)
+            capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+            dts.append(time.perf_counter() - t0)
+            t += steps
+        st = loop.stats()
+        loop.close()
+        dt = float(np.median(dts))
+        identical = all(np.array_equal(poses[:, s], poses[:, s % 4]) for s in range(S))
+        fps = S * steps / dt
+        out["S%d" % S] = {"sequences": S, "frames_s": fps, "ms_per_step": dt / steps * 1e3, "us_per_frame": dt / steps / S * 1e6,
+                          "vs_one_sequence": (fps / single_value) if single_value else None,
+                          "tracked_good": sum(q["tracked_good"] for q in st), "frames": sum(q["frames"] for q in st),
+                          "updates": sum(q["updates"] for q in st), "keyframes": sum(q["keyframes"] for q in st), "lost": sum(q["lost"] for q in st),
+                          "lm_evaluations_per_frame": sum(q["evaluations"] for q in st) / max(1, sum(q["frames"] for q in st)),
+                          "replicas_bit_identical": bool(identical)}
+    return out
+
+
 def extra_configs(la, torch, device):
     """Two short legs after the timed region (not the bench metric): BASELINE.json configs[2] — the full track+map loop at 1280x1024 on
     the edge-texture scene S2 — and configs[4] — the 3840x2160 depth regularisation (fill holes + regularise fused), full frame and as
@@ -716,6 +760,10 @@ def main():
                 out.setdefault("extra_configs", {}).update(extra_configs(la, torch, local_rank))
             except Exception as e:   # extras: never let them take the bench line down
                 out.setdefault("extra_configs", {})["error"] = str(e)
+            try:
+                out.setdefault("extra_configs", {})["multi_seq"] = multi_seq(torch, w, h, K, d_frames, depth0, local_rank, out["value"])
+            except Exception as e:
+                out.setdefault("extra_configs", {})["multi_seq"] = {"error": str(e)}
         if world == 1 and not args.no_pcie_leg:
             # SURVEY.md §8(d) counts the 8-bit upload inside tracked frames/s: the same loop fed from (pinned) host memory, every frame
             # crossing PCIe inside lsdhip_frame_create.  Reported beside `value`, never as `value`.

@@ -145,6 +145,18 @@ class Frame {
   Frame(const Frame&) = delete;
   Frame& operator=(const Frame&) = delete;
   ~Frame() { lsdhip_frame_destroy(h_); }
+  // the new frames of n sequences (one context) in two launches instead of two per frame (lsdhip_frame_create_batch)
+  static std::vector<std::shared_ptr<Frame>> createBatch(int width, int height, const Mat3f& K, const std::vector<int>& ids,
+                                                         const unsigned char* const* images, bool imagesOnDevice) {
+    std::shared_ptr<Context> ctx = Context::get(width, height, K);
+    const int n = (int)ids.size();
+    std::vector<lsdhip_frame*> hs((size_t)n, nullptr);
+    check(lsdhip_frame_create_batch(ctx->handle(), n, ids.data(), images, imagesOnDevice ? 1 : 0, hs.data()), "lsdhip_frame_create_batch");
+    std::vector<std::shared_ptr<Frame>> out;
+    out.reserve((size_t)n);
+    for (int j = 0; j < n; j++) out.push_back(std::shared_ptr<Frame>(new Frame(ctx, ids[j], hs[j])));
+    return out;
+  }
 
   int id() const { return id_; }
   int width(int level = 0) const { return ctx_->width() >> level; }
@@ -216,6 +228,7 @@ class Frame {
     check(lsdhip_frame_download(h_, what, level, v.data()), "lsdhip_frame_download");
     return v;
   }
+  Frame(std::shared_ptr<Context> ctx, int id, lsdhip_frame* adopted) : ctx_(std::move(ctx)), h_(adopted), id_(id), timestamp_(0.0) {}
   std::shared_ptr<Context> ctx_;
   lsdhip_frame* h_ = nullptr;
   int id_;
@@ -293,6 +306,28 @@ class SE3Tracker {
     publish(r);
     if (hookError_) std::rethrow_exception(hookError_);
     return SE3::from7(r.frameToReference);
+  }
+  // trackFrame for n independent (reference, frame) pairs in the same launches (lsdhip_tracker_track_batch): several sequences sharing
+  // one GPU.  results[j] carries what the members above carry after a single call.  A diverged job does not throw: look at
+  // results[j].diverged.
+  std::vector<SE3> trackFrameBatch(const std::vector<TrackingReference*>& references, const std::vector<Frame*>& frames,
+                                   const std::vector<SE3>& inits, std::vector<lsdhip_track_result>& results) {
+    pushSettings();
+    const int n = (int)frames.size();
+    std::vector<lsdhip_frame*> kfs((size_t)n), frs((size_t)n);
+    std::vector<double> init((size_t)n * 7);
+    for (int j = 0; j < n; j++) {
+      if (!references[j] || !references[j]->keyframe || !frames[j]) throw Error(LSDHIP_E_STATE, "SE3Tracker::trackFrameBatch: a tracking reference holds no keyframe");
+      kfs[j] = references[j]->keyframe->handle();
+      frs[j] = frames[j]->handle();
+      inits[j].to7(&init[(size_t)j * 7]);
+    }
+    results.assign((size_t)n, lsdhip_track_result());
+    const int rc = lsdhip_tracker_track_batch(h_, n, kfs.data(), frs.data(), init.data(), results.data());
+    if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) check(rc, "lsdhip_tracker_track_batch");
+    std::vector<SE3> out((size_t)n);
+    for (int j = 0; j < n; j++) out[j] = SE3::from7(results[j].frameToReference);
+    return out;
   }
   SE3 trackFrameOnPermaref(Frame* reference, Frame* frame, SE3 referenceToFrame) {
     pushSettings();
@@ -450,6 +485,15 @@ class DepthMap {
     for (auto& f : referenceFrames) refs.push_back(f->handle());
     check(lsdhip_depth_update(h_, refs.data(), (int)refs.size()), "lsdhip_depth_update");
     timings();
+  }
+  // updateKeyframe of several sequences' maps (one context), one tracked frame each, in shared launches (lsdhip_depth_update_batch)
+  static void updateKeyframeBatch(const std::vector<DepthMap*>& maps, const std::vector<Frame*>& frames) {
+    if (maps.empty()) return;
+    std::vector<lsdhip_depthmap*> ms;
+    std::vector<lsdhip_frame*> fs;
+    for (DepthMap* m : maps) ms.push_back(m->h_);
+    for (Frame* f : frames) fs.push_back(f->handle());
+    check(lsdhip_depth_update_batch((int)ms.size(), ms.data(), fs.data()), "lsdhip_depth_update_batch");
   }
   void createKeyFrame(Frame* new_keyframe) {
     check(lsdhip_depth_create_keyframe(h_, new_keyframe->handle(), nullptr), "lsdhip_depth_create_keyframe");
@@ -726,6 +770,141 @@ class SlamLoop {
   const unsigned char* prefetchedSrc_ = nullptr;
   const unsigned char* pendingNext_ = nullptr;
   std::deque<std::shared_ptr<Frame>> liveQueue_;
+};
+
+// S independent sequences through ONE GPU, one frame of each per step() (BASELINE.json configs[3] with more sequences than GPUs).
+// Per sequence this is SlamLoop with blockUntilMapped = true: track the frame, then its mapping iteration, the next frame tracked against
+// what that left.  Across sequences every stage shares its launches: the new frames (Frame::createBatch), the tracking jobs
+// (SE3Tracker::trackFrameBatch: throughput mode from 8 jobs on), the updateKeyframe calls (DepthMap::updateKeyframeBatch).  Keyframe
+// changes (finalize + createKeyFrame, once every kfEvery frames per sequence) stay per-sequence calls.  A sequence whose tracking is
+// lost stops taking part (lost(s) == true, SlamLoop's rules); the others go on.
+class SlamLoopBatch {
+ public:
+  struct Sequence {
+    Sequence(int w, int h, const Mat3f& K) : map(w, h, K) {}
+    DepthMap map;
+    TrackingReference reference;
+    std::shared_ptr<Frame> keyframe;
+    SE3 lastFrameToKF;
+    int sinceKF = 0, mappedOnKF = 0, numKeyframesFinished = 0;
+    long numTracked = 0, numTrackedGood = 0, numUpdates = 0, evaluations = 0;
+    bool trackingLost = false, newKeyframe = false;
+    lsdhip_track_result last = lsdhip_track_result();
+  };
+  // firstImages / gtDepth0: S pointers each (gtDepth0 == null or gtDepth0[s] == null: random initialisation of that sequence)
+  SlamLoopBatch(int w, int h, const Mat3f& K, int S, const unsigned char* const* firstImages, bool imagesOnDevice,
+                const float* const* gtDepth0, int kfEvery)
+      : tracker(w, h, K), w_(w), h_(h), K_(K), onDevice_(imagesOnDevice), kfEvery_(kfEvery) {
+    if (S <= 0 || kfEvery <= 0) throw Error(LSDHIP_E_ARG, "SlamLoopBatch: S > 0 sequences, a fixed keyframe interval > 0");
+    const int its[LSDHIP_PYRAMID_LEVELS] = {5, 20, 50, 100, 0};
+    std::memcpy(tracker.settings.maxItsPerLvl, its, sizeof(its));
+    std::vector<int> ids((size_t)S);
+    for (int s = 0; s < S; s++) ids[s] = idOf(s, 0);
+    std::vector<std::shared_ptr<Frame>> first = Frame::createBatch(w, h, K, ids, firstImages, imagesOnDevice);
+    for (int s = 0; s < S; s++) {
+      seqs_.emplace_back(new Sequence(w, h, K));
+      Sequence& q = *seqs_.back();
+      q.keyframe = first[s];
+      if (gtDepth0 && gtDepth0[s]) {
+        q.keyframe->setDepthFromGroundTruth(gtDepth0[s]);
+        q.map.initializeFromGTDepth(q.keyframe.get());
+      } else {
+        q.map.initializeRandomly(q.keyframe.get());
+      }
+      q.reference.importFrame(q.keyframe.get());
+      q.keyframe->clearDepthHasBeenUpdatedFlag();
+    }
+  }
+  SlamLoopBatch(const SlamLoopBatch&) = delete;
+  SlamLoopBatch& operator=(const SlamLoopBatch&) = delete;
+  int size() const { return (int)seqs_.size(); }
+  Sequence& sequence(int s) { return *seqs_[s]; }
+  bool lost(int s) const { return seqs_[s]->trackingLost; }
+  // frame ids count per sequence, as in S separate SlamLoops (an id is only compared with ids of the same sequence: tracking parent,
+  // nextStereoFrameMinID — which is a float, DepthMapPixelHypothesis.h:49: ids beyond 2^24 would round)
+  static int idOf(int /*s*/, int t) { return t; }
+  // one frame of every sequence that is still tracking (images[s] is ignored for lost ones); returns frameToKeyframe per sequence
+  std::vector<SE3> step(const unsigned char* const* images) {
+    frameId_++;
+    const int S = size();
+    std::vector<int> alive, ids;
+    std::vector<const unsigned char*> imgs;
+    for (int s = 0; s < S; s++) if (!seqs_[s]->trackingLost) { alive.push_back(s); ids.push_back(idOf(s, frameId_)); imgs.push_back(images[s]); }
+    std::vector<SE3> out((size_t)S);
+    if (alive.empty()) return out;
+    std::vector<std::shared_ptr<Frame>> frames = Frame::createBatch(w_, h_, K_, ids, imgs.data(), onDevice_);
+    std::vector<TrackingReference*> refs;
+    std::vector<Frame*> frs;
+    std::vector<SE3> inits;
+    for (size_t k = 0; k < alive.size(); k++) {
+      Sequence& q = *seqs_[alive[k]];
+      if (q.keyframe->depthHasBeenUpdatedFlag()) {        // the tracking thread's import (SlamSystem.cpp:907-912)
+        q.reference.importFrame(q.keyframe.get());
+        q.keyframe->clearDepthHasBeenUpdatedFlag();
+      }
+      refs.push_back(&q.reference);
+      frs.push_back(frames[k].get());
+      inits.push_back(q.lastFrameToKF);
+    }
+    std::vector<lsdhip_track_result> res;
+    std::vector<SE3> est = tracker.trackFrameBatch(refs, frs, inits, res);
+    std::vector<DepthMap*> updMaps;
+    std::vector<Frame*> updFrames;
+    std::vector<int> updSeq;
+    for (size_t k = 0; k < alive.size(); k++) {
+      Sequence& q = *seqs_[alive[k]];
+      q.last = res[k];
+      q.numTracked++;
+      q.evaluations += res[k].numEvaluations;
+      if (res[k].trackingWasGood) q.numTrackedGood++;
+      out[alive[k]] = est[k];
+      q.newKeyframe = false;
+      if (res[k].diverged || (q.numKeyframesFinished > 5 /* INITIALIZATION_PHASE_COUNT */ && !res[k].trackingWasGood)) {
+        // SlamSystem::trackFrame's lost branch (:946-966) and doMappingIteration's (:809-817), as in SlamLoop::step
+        q.trackingLost = true;
+        q.reference.invalidate();
+        if (q.map.isValid()) {
+          if (q.mappedOnKF >= 5 /* MIN_NUM_MAPPED */) { q.map.finalizeKeyFrame(); q.numKeyframesFinished++; }
+          q.map.invalidate();
+        }
+        continue;
+      }
+      ++q.sinceKF;
+      if (q.sinceKF >= kfEvery_) {
+        q.map.finalizeKeyFrame();
+        q.numKeyframesFinished++;
+        q.mappedOnKF = 0;
+        q.map.createKeyFrame(frames[k].get());
+        q.keyframe = frames[k];
+        q.reference.importFrame(q.keyframe.get());
+        q.keyframe->clearDepthHasBeenUpdatedFlag();
+        q.lastFrameToKF = SE3();
+        q.sinceKF = 0;
+        q.newKeyframe = true;
+      } else {
+        updMaps.push_back(&q.map);
+        updFrames.push_back(frames[k].get());
+        updSeq.push_back(alive[k]);
+        q.lastFrameToKF = est[k];
+      }
+    }
+    DepthMap::updateKeyframeBatch(updMaps, updFrames);
+    for (size_t k = 0; k < updSeq.size(); k++) {
+      Sequence& q = *seqs_[updSeq[k]];
+      q.mappedOnKF++;
+      q.numUpdates++;
+      updFrames[k]->clear_refPixelWasGood();
+    }
+    return out;
+  }
+  SE3Tracker tracker;
+
+ private:
+  int w_, h_;
+  Mat3f K_;
+  bool onDevice_;
+  int kfEvery_, frameId_ = 0;
+  std::vector<std::unique_ptr<Sequence>> seqs_;
 };
 
 }  // namespace lsd_slam_hip

@@ -81,6 +81,19 @@ int lsdloop_ipc_init(lsdloop* l, int rank, int world, int root, unsigned char ha
 int lsdloop_ipc_connect(lsdloop* l, const unsigned char root_handle64[64]);
 int lsdloop_ipc_result(lsdloop* l, int* counts_out, float** data_out);
 void* lsdloop_ctx(lsdloop* l);   /* the lsdhip_ctx* the loop runs on (prof hooks, stream) */
+/* ---- S sequences sharing one GPU (lsd_slam_hip::SlamLoopBatch; BASELINE.json configs[3] with more sequences than GPUs): per sequence
+ * the blockUntilMapped loop above, across sequences every stage in shared launches (lsdhip_frame_create_batch,
+ * lsdhip_tracker_track_batch, lsdhip_depth_update_batch).  first_images / gt_depth0_host: S pointers.
+ * lsdloopbatch_run: n steps = n frames of every sequence, images[t * S + s]; frameToKeyframe_out: n x S x 7 doubles or NULL; returns
+ * the number of steps run.  lsdloopbatch_get_stats: 6 values per sequence (frames, tracked_good, updates, keyframes, evaluations,
+ * lost 0/1). */
+typedef struct lsdloopbatch lsdloopbatch;
+int lsdloopbatch_create(int device, int w, int h, const float K4[4], int S, const uint8_t* const* first_images, int images_on_device,
+                        const float* const* gt_depth0_host, int kf_every, lsdloopbatch** out);
+void lsdloopbatch_destroy(lsdloopbatch* l);
+int lsdloopbatch_run(lsdloopbatch* l, const uint8_t* const* images, int n, double* frameToKeyframe_out);
+int lsdloopbatch_get_stats(lsdloopbatch* l, long long* out6_per_sequence);
+void* lsdloopbatch_ctx(lsdloopbatch* l);
 const char* lsdloop_last_error(void);
 /* ---- row-band decomposition of the regulariser (BASELINE.json configs[4]) ----------------------------
  * `world` bands over an H-row map; this process holds bands [first_band, first_band + n_local) as windows of

@@ -85,6 +85,16 @@ def lib():
             getattr(L, name).argtypes = args
         L.lsdloop_ctx.restype = vp
         L.lsdloop_ctx.argtypes = [vp]
+        L.lsdloopbatch_create.restype = i
+        L.lsdloopbatch_create.argtypes = [i, i, i, vp, i, vp, i, vp, i, C.POINTER(vp)]
+        L.lsdloopbatch_destroy.restype = None
+        L.lsdloopbatch_destroy.argtypes = [vp]
+        L.lsdloopbatch_run.restype = i
+        L.lsdloopbatch_run.argtypes = [vp, vp, i, vp]
+        L.lsdloopbatch_get_stats.restype = i
+        L.lsdloopbatch_get_stats.argtypes = [vp, vp]
+        L.lsdloopbatch_ctx.restype = vp
+        L.lsdloopbatch_ctx.argtypes = [vp]
         L.lsdloop_last_error.restype = C.c_char_p
         L.lsdloop_last_error.argtypes = []
         _lib = L
@@ -95,6 +105,50 @@ def _check(rc):
     if rc < 0:
         raise capi.LsdHipError("liblsdhip_driver call failed (%d): %s" % (rc, (lib().lsdloop_last_error() or b"").decode()))
     return rc
+
+
+class DriverLoopBatch:
+    """lsd_slam_hip::SlamLoopBatch: S sequences sharing one GPU, one frame of each per step.  Images are raw pointers (device pointers when
+    images_on_device, else host pointers)."""
+
+    def __init__(self, w, h, K, first_image_ptrs, depth0s, kf_every=10, images_on_device=True, device=0):
+        self.L = lib()
+        self.S = len(first_image_ptrs)
+        K4 = np.ascontiguousarray(K, dtype=np.float32)
+        self._d0 = [np.ascontiguousarray(d, dtype=np.float32) for d in depth0s]
+        imgs = (C.c_void_p * self.S)(*first_image_ptrs)
+        d0s = (C.c_void_p * self.S)(*[d.ctypes.data for d in self._d0])
+        h_ = C.c_void_p()
+        _check(self.L.lsdloopbatch_create(device, w, h, K4.ctypes.data, self.S, imgs, int(images_on_device), d0s, kf_every, C.byref(h_)))
+        self.h_ = h_
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.lsdloopbatch_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, image_ptrs, want_poses=False):
+        """image_ptrs: n steps x S pointers (list of lists) -> (steps run, poses n x S x 7 or None)"""
+        n = len(image_ptrs)
+        flat = [p for step in image_ptrs for p in step]
+        assert len(flat) == n * self.S
+        arr = (C.c_void_p * (n * self.S))(*flat)
+        poses = np.zeros((n, self.S, 7), np.float64) if want_poses else None
+        done = _check(self.L.lsdloopbatch_run(self.h_, arr, n, poses.ctypes.data if want_poses else None))
+        return done, poses
+
+    def stats(self):
+        """per sequence: dict(frames, tracked_good, updates, keyframes, evaluations, lost)"""
+        out = np.zeros((self.S, 6), np.int64)
+        _check(self.L.lsdloopbatch_get_stats(self.h_, out.ctypes.data))
+        keys = ("frames", "tracked_good", "updates", "keyframes", "evaluations", "lost")
+        return [dict(zip(keys, (int(v) for v in row))) for row in out]
+
+    def ctx_handle(self):
+        return C.c_void_p(self.L.lsdloopbatch_ctx(self.h_))
 
 
 class DriverLoop:

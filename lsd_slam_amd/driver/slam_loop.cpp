@@ -119,6 +119,70 @@ extern "C" void lsdloop_destroy(lsdloop* l) {
   delete l;
 }
 
+// ---- S sequences sharing one GPU ------------------------------------------------------------------------------------------------------
+struct lsdloopbatch {
+  std::shared_ptr<Context> ctx;
+  std::unique_ptr<lsd_slam_hip::SlamLoopBatch> loop;
+  std::vector<long long> keyframes;
+};
+extern "C" int lsdloopbatch_create(int device, int w, int h, const float K4[4], int S, const uint8_t* const* first_images, int images_on_device,
+                                   const float* const* gt_depth0_host, int kf_every, lsdloopbatch** out) {
+  if (!K4 || !first_images || !out || kf_every < 1 || S < 1) return LSDHIP_E_ARG;
+  try {
+    Context::defaultDevice() = device;
+    Mat3f K = Mat3f::intrinsics(K4[0], K4[1], K4[2], K4[3]);
+    std::unique_ptr<lsdloopbatch> l(new lsdloopbatch());
+    l->ctx = Context::get(w, h, K, device);
+    l->ctx->setPipeline(false);
+    l->loop.reset(new lsd_slam_hip::SlamLoopBatch(w, h, K, S, first_images, images_on_device != 0, gt_depth0_host, kf_every));
+    l->ctx->setAsync(true);
+    l->keyframes.assign((size_t)S, 0);
+    *out = l.release();
+    return LSDHIP_OK;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.status;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return LSDHIP_E_STATE;
+  }
+}
+extern "C" void lsdloopbatch_destroy(lsdloopbatch* l) {
+  if (!l) return;
+  if (l->ctx) (void)lsdhip_ctx_synchronize(l->ctx->handle());
+  delete l;
+}
+extern "C" int lsdloopbatch_run(lsdloopbatch* l, const uint8_t* const* images, int n, double* out7) {
+  if (!l || !images || n < 0) return LSDHIP_E_ARG;
+  try {
+    const int S = l->loop->size();
+    for (int t = 0; t < n; t++) {
+      std::vector<SE3> est = l->loop->step(images + (size_t)t * S);
+      for (int s = 0; s < S; s++) {
+        if (l->loop->sequence(s).newKeyframe) l->keyframes[s]++;
+        if (out7) est[s].to7(out7 + 7 * ((size_t)t * S + s));
+      }
+    }
+    return n;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.status < 0 ? e.status : LSDHIP_E_STATE;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return LSDHIP_E_STATE;
+  }
+}
+extern "C" int lsdloopbatch_get_stats(lsdloopbatch* l, long long* out) {
+  if (!l || !out) return LSDHIP_E_ARG;
+  for (int s = 0; s < l->loop->size(); s++) {
+    const lsd_slam_hip::SlamLoopBatch::Sequence& q = l->loop->sequence(s);
+    long long* o = out + 6 * (size_t)s;
+    o[0] = q.numTracked; o[1] = q.numTrackedGood; o[2] = q.numUpdates; o[3] = l->keyframes[s]; o[4] = q.evaluations; o[5] = q.trackingLost ? 1 : 0;
+  }
+  return LSDHIP_OK;
+}
+extern "C" void* lsdloopbatch_ctx(lsdloopbatch* l) { return l ? (void*)l->ctx->handle() : nullptr; }
+
 extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int stop_at_keyframe, double* out7) {
   if (!l || !images || n < 0) return LSDHIP_E_ARG;
   try {
