@@ -11,8 +11,11 @@
  *   - every call returns an int status: 0 ok, >0 algorithmic condition (1 = tracking diverged), <0 usage /
  *     runtime error (LSDHIP_E_*).  Nothing throws across the boundary.
  *   - a context owns one HIP stream; all calls on objects of one context are serialised on that stream and are
- *     synchronous from the caller's point of view unless documented otherwise.  Different contexts may be
- *     used concurrently from different host threads (C/SlamSystem.h:124-132: tracking and mapping threads).
+ *     synchronous from the caller's point of view unless documented otherwise (lsdhip_ctx_set_async).  A PIPELINED
+ *     context (lsdhip_ctx_set_pipeline) owns two: SE3Tracker jobs run on the tracking stream, frame creation and
+ *     DepthMap calls on the mapping stream, beside each other (C/SlamSystem.h:124-132: tracking and mapping threads).
+ *     Host calls on one context are serialised by a per-context mutex; different contexts may be used concurrently
+ *     from different host threads.
  *   - "host" pointers are ordinary host memory; "dev" pointers are device memory on the context's GPU.
  */
 #ifndef LSDHIP_H

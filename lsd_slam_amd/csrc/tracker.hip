@@ -113,10 +113,11 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   const float* topval_in0 = sc.topval + (size_t)parity * cmax * max_rows * 96;
   float* topval_out = sc.topval + (size_t)outp * cmax * max_rows * 96;
   constexpr int NSLOT = 16;                                  // row slots of the column sums: slot s adds rows s, s + 16, ...
-  __shared__ __attribute__((aligned(16))) float s_sumT[LSD_SPEC_MAX][NSLOT][RS_COLS];    // per pending trial: column sums by row slot
-  __shared__ float s_subT[LSD_SPEC_MAX][3][32];             // ... K2/K3 contributions of its (up to 3) tail points
-  __shared__ int s_nsubT[LSD_SPEC_MAX];
-  __shared__ float s_rec[LSD_SPEC_MAX][32];                 // ... increment [0..5], pose [6..12], R [13..21], t [22..24] (trials > 0)
+  constexpr int TRIALS_MAX = BATCH ? 1 : LSD_SPEC_MAX;      // batches run one trial per step (cmax == 1)
+  __shared__ __attribute__((aligned(16))) float s_sumT[TRIALS_MAX][NSLOT][RS_COLS];    // per pending trial: column sums by row slot
+  __shared__ float s_subT[TRIALS_MAX][3][32];               // ... K2/K3 contributions of its (up to 3) tail points
+  __shared__ int s_nsubT[TRIALS_MAX];
+  __shared__ float s_rec[TRIALS_MAX][32];                   // ... increment [0..5], pose [6..12], R [13..21], t [22..24] (trials > 0)
 #ifdef LSD_PHASE_TRACE
   __shared__ unsigned long long* s_trp;
   unsigned long long* tr_ = sc.trace;
@@ -164,7 +165,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
   } else {
     copy_words<sizeof(TrackState) / 4>(&S, st2 + parity, tid, BLOCK);
-    if (cmax > 1 && tid < 32 * LSD_SPEC_MAX) (&s_rec[0][0])[tid] = sc.recs[(size_t)parity * cmax * 32 + (tid < 32 * cmax ? tid : 0)];
+    if (!BATCH && cmax > 1 && tid < 32 * LSD_SPEC_MAX) (&s_rec[0][0])[tid] = sc.recs[(size_t)parity * cmax * 32 + (tid < 32 * cmax ? tid : 0)];
   }
   __syncthreads();
   PHASE_MARK(1);
