@@ -52,6 +52,17 @@ typedef struct lsdhip_params {
   int useAffineLightningEstimation; /* 1 (ROS cfg default 0, cfg/LSDParams.cfg:27) */
 } lsdhip_params;
 void lsdhip_default_params(lsdhip_params* p);
+/* The execution defaults this header states in prose, as built into the library (no GPU needed): tests/test_abi_cpu.py compares the
+ * two, so that the text cannot drift from the code. */
+typedef struct lsdhip_build_defaults_t {
+  int ctx_async, ctx_pipeline;                          /* lsdhip_ctx_set_async / lsdhip_ctx_set_pipeline without a call */
+  int spec_trials_small, spec_small_pixels;             /* automatic speculation policy of lsdhip_tracker_set_speculation ... */
+  int spec_trials_mid, spec_mid_pixels;
+  int spec_workgroups, spec_workgroups_above_pixels;
+  int spec_trials_max;                                  /* largest `trials` lsdhip_tracker_set_speculation accepts */
+  int batch_throughput_min_jobs, batch_strip_workgroups;  /* lsdhip_tracker_track_batch: throughput mode */
+} lsdhip_build_defaults_t;
+void lsdhip_build_defaults(lsdhip_build_defaults_t* out);
 
 /* DepthMapPixelHypothesis, C/DepthEstimation/DepthMapPixelHypothesis.h:43-60 (32-byte AoS exchange format). */
 typedef struct lsdhip_hypothesis {
@@ -79,8 +90,9 @@ int lsdhip_ctx_set_async(lsdhip_ctx* ctx, int on);
  * blockUntilMapped == false (C/SlamSystem.h:124-132, C/SlamSystem.cpp:1026-1040) — on one GPU: on != 0 gives the context a second
  * stream.  Tracker calls keep running on lsdhip_ctx_stream; frame creation (upload + pyramids) and every DepthMap call run on
  * lsdhip_ctx_map_stream.  The streams are ordered by events only where data crosses: a tracker call waits for the point its frame's
- * pyramids and its keyframe's PUBLISHED depth planes were complete at; a mapping-stream call waits for the newest finished tracker call
- * (it consumes that call's pose and refPixelWasGood mask).  Frame::setDepth on the mapping stream writes a second set of depth planes,
+ * pyramids and its keyframe's PUBLISHED depth planes were complete at.  In the other direction there is no event: a DepthMap call
+ * consumes the pose and refPixelWasGood mask of tracker calls that have RETURNED (the host has seen them finish), which is how
+ * SlamSystem's mapping thread uses them; call it after them.  Frame::setDepth on the mapping stream writes a second set of depth planes,
  * so a tracker call running beside it keeps reading an unchanged TrackingReference; lsdhip_frame_publish_depth hands the new planes
  * over.  Default 0: one stream, every call ordered behind the previous one (blockUntilMapped == true).  Usually combined with
  * lsdhip_ctx_set_async(ctx, 1); host-synchronous entries (downloads, uploads) drain both streams. */
@@ -208,14 +220,6 @@ int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
 /* out[0] = k_track_step launches of the last job that evaluated = its dependent steps, out[1] = out[2] = 0 (reserved), out[3] = most
  * trials per step. */
 int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]);
-/* Execution form of the throughput-mode evaluation (batches of >= 8 jobs; no reference counterpart, same results up to summation
- * order).  on = 0 (default): k_track_step<.., TS_EVAL> — the strip's valid pixels compacted into an LDS list, keyframe planes and the
- * four bilinear taps gathered through L1 / L2 behind a three-stage software pipeline.  on = 1: k_track_eval_tiles — per 1024-pixel
- * chunk the planes are read coalesced, the image rows the chunk's warped points sample are staged into LDS (the "LDS-staged image
- * tile" of BASELINE.json's north_star) and the taps are LDS reads.  Measured on MI355X at 64 jobs x 640x480 level 1: 66 us against
- * 41-45 us per launch for the default (profiles/r03_sizes.md): the per-chunk barriers and the exposed staging latency cost more than
- * the gathers they replace.  Environment at creation: LSDHIP_BATCH_TILES=1. */
-int lsdhip_tracker_set_batch_tiles(lsdhip_tracker* t, int on);
 /* Measurement hook (no reference counterpart): the throughput-mode residual evaluation launch alone — n >= 8 jobs
  * (keyframes[j], frames[j]) at pyramid level `level` and poses refToFrame (n x 7 floats: q w x y z, t), `repeats` identical launches
  * between two HIP events.  Reports the mean launch time and the algorithmic bytes of one launch over all jobs (SURVEY.md 8(d)
@@ -236,8 +240,10 @@ int lsdhip_tracker_set_enqueue_hook(lsdhip_tracker* t, lsdhip_enqueue_hook fn, v
  * initialTrackedResidual, keyframe numFramesTrackedOnThis++.  Returns LSDHIP_DIVERGED when diverged. */
 int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame* frame,
                          const double frameToReference_initialEstimate[7], lsdhip_track_result* out);
-/* trackFrame for n independent (keyframe, frame) pairs in the same kernel launches (one job per blockIdx.y): results are
- * identical to n lsdhip_tracker_track calls; n evaluations share every launch.  This is how several sequences share
+/* trackFrame for n independent (keyframe, frame) pairs in the same kernel launches (one job per blockIdx.y): the decisions and
+ * per-point arithmetic of n lsdhip_tracker_track calls, sums in another order (fewer, fatter workgroups per job); n evaluations share
+ * every launch.  From 8 jobs on the batch runs in throughput mode: a step = one LM launch (one workgroup per job) + one evaluation
+ * launch whose strips x jobs fill the chip's 768 workgroup slots.  This is how several sequences share
  * one GPU (BASELINE configs[3] with fewer GPUs than sequences) and how batches of keyframe candidates are checked
  * (SURVEY.md §8(f) N2).  inits: n x 7 doubles, results: n records.  Returns LSDHIP_DIVERGED if any job diverged. */
 int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,

@@ -13,7 +13,7 @@ OUT = os.path.join(HERE, "liblsdhip.so")
 # kernels allowed to spill a few loop-invariant registers (long, memory-bound batch kernels where occupancy matters more;
 # the latency-critical single-job kernels must stay at zero)
 SCRATCH_OK = ()
-SOURCES = ["host_math.cpp", "frame.hip", "tracker.hip", "tracker_batch.hip", "depthmap.hip", "sim3.hip"]
+SOURCES = ["host_math.cpp", "frame.hip", "tracker.hip", "depthmap.hip", "sim3.hip"]
 # -disable-promote-alloca-to-lds: a private array the optimiser cannot split must show up as scratch (and fail the
 # guard below) instead of silently moving to LDS, where indexing it by thread costs a read of the AQL dispatch packet
 # in host memory (~20 us per launch, measured — profiles/r01_notes.md).
@@ -50,7 +50,7 @@ def needs_build():
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(SRC, s) for s in SOURCES] + [os.path.join(SRC, "lsdhip_internal.hpp"), os.path.join(SRC, "pose_math.hpp"),
-                                                       os.path.join(SRC, "track_device.hpp"), os.path.join(SRC, "tracker_batch.hpp"),
+                                                       os.path.join(SRC, "track_device.hpp"),
                                                        os.path.join(HERE, "..", "include", "lsdhip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

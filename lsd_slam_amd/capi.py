@@ -18,6 +18,12 @@ HYP_DTYPE = np.dtype(
 assert HYP_DTYPE.itemsize == 32
 
 
+class BuildDefaults(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("ctx_async", "ctx_pipeline", "spec_trials_small", "spec_small_pixels", "spec_trials_mid", "spec_mid_pixels",
+                                         "spec_workgroups", "spec_workgroups_above_pixels", "spec_trials_max", "batch_throughput_min_jobs",
+                                         "batch_strip_workgroups")]
+
+
 class Params(C.Structure):
     _fields_ = [("minUseGrad", C.c_float), ("cameraPixelNoise2", C.c_float), ("depthSmoothingFactor", C.c_float),
                 ("allowNegativeIdepths", C.c_int), ("useSubpixelStereo", C.c_int),
@@ -66,6 +72,7 @@ def _signatures():
     pvp = C.POINTER(C.c_void_p)
     return {
         "lsdhip_default_params": (None, [C.POINTER(Params)]),
+        "lsdhip_build_defaults": (None, [C.POINTER(BuildDefaults)]),
         "lsdhip_ctx_create": (i, [i, i, i, vp, C.POINTER(Params), pvp]),
         "lsdhip_ctx_destroy": (None, [vp]),
         "lsdhip_ctx_stream": (vp, [vp]),
@@ -127,7 +134,6 @@ def _signatures():
         "lsdhip_tracker_set_enqueue_hook": (i, [vp, vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),
         "lsdhip_tracker_track_batch": (i, [vp, i, pvp, pvp, vp, C.POINTER(TrackResult)]),
-        "lsdhip_tracker_set_batch_tiles": (i, [vp, i]),
         "lsdhip_tracker_eval_throughput": (i, [vp, i, pvp, pvp, vp, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "lsdhip_tracker_evaluate": (i, [vp, vp, vp, vp, i, f, f, C.POINTER(ResidualRecord)]),
         "lsdhip_tracker_track_permaref": (i, [vp, vp, vp, i, vp, vp, C.POINTER(TrackResult)]),

@@ -142,6 +142,18 @@ struct TrackSummary {
 // synchronises anyway (or when somebody asks for the value).
 struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_NUM_SLOTS 256
+// Defaults that include/lsdhip.h states in prose: single source here, exported by lsdhip_build_defaults, compared with the header's text
+// by tests/test_abi_cpu.py::test_header_prose_states_the_built_defaults.
+#define LSD_DEFAULT_ASYNC 0                 // lsdhip_ctx_set_async
+#define LSD_DEFAULT_PIPELINE 0              // lsdhip_ctx_set_pipeline
+#define LSD_SPEC_TRIALS_SMALL 6             // automatic speculation policy: trials per step on levels of up to LSD_SPEC_SMALL_PX pixels
+#define LSD_SPEC_SMALL_PX 6144
+#define LSD_SPEC_TRIALS_MID 5               // ... up to LSD_SPEC_MID_PX pixels; larger levels: one evaluation per step
+#define LSD_SPEC_MID_PX 90112
+#define LSD_SPEC_CAP_WORKGROUPS 80          // workgroups per trial on speculating levels above LSD_SPEC_CAP_ABOVE_PX pixels
+#define LSD_SPEC_CAP_ABOVE_PX 24576
+#define LSD_BATCH_THROUGHPUT_MIN_JOBS 8     // lsdhip_tracker_track_batch: throughput mode from this many jobs on
+#define LSD_BATCH_STRIP_WORKGROUPS 768      // strips x jobs of a throughput-mode evaluation launch (3 workgroups per CU)
 struct lsdhip_frame;
 
 // Host-side state of a context (arena free list, deferred-result slot ring and its owner tables, profiling events, the
@@ -153,7 +165,7 @@ struct lsdhip_frame;
 struct lsdhip_ctx {
   std::recursive_mutex mtx;
   int device = 0;
-  bool async = false;                    // lsdhip_ctx_set_async: mapping calls return after enqueueing
+  bool async = LSD_DEFAULT_ASYNC != 0;                 // lsdhip_ctx_set_async: mapping calls return after enqueueing
   DeferredSlot* h_slots = nullptr;       // pinned, device-mapped ring
   lsdhip_frame* slot_stats_owner[LSD_NUM_SLOTS] = {};
   lsdhip_frame* slot_rescale_owner[LSD_NUM_SLOTS] = {};
@@ -178,7 +190,7 @@ struct lsdhip_ctx {
   // SEEN that job finish, and everything the job wrote for others was written by launches that completed before the finishing one
   // started (the mask of a speculative trial is merged into the frame's plane by a kernel on mstream, see lsdhip_tracker_track).
 #define LSD_EVR 64
-  bool pipeline = false;
+  bool pipeline = LSD_DEFAULT_PIPELINE != 0;
   hipStream_t mstream = nullptr;
   hipEvent_t mEv[LSD_EVR] = {};
   long long mSeq = 0;                    // record points on mstream so far
@@ -294,7 +306,7 @@ struct lsdhip_tracker {
   bool specAuto = true;           // trials per level from the level's size (see track_device); false after set_speculation
   int specCaps[LSD_LEVELS] = {0, 0, 0, 0, 0};    // per-level workgroups per trial (LSDHIP_SPEC_CAPS; 0 = automatic)
   int specLevel[LSD_LEVELS] = {0, 0, 0, 0, 0};   // per-level trials (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = automatic / specC)
-  int specCap = 80;               // workgroups per trial on levels of 24 K - 88 K pixels when speculating (0 = grid_cap / 2)
+  int specCap = LSD_SPEC_CAP_WORKGROUPS;              // workgroups per trial on levels of 24 K - 88 K pixels when speculating (0 = grid_cap / 2)
   uint8_t* d_maskSide = nullptr;  // 2 sets (alternating by job) of (SPEC_MAX - 1) mask planes of (w >> 1) x (h >> 1) bytes
   int maskSet = 0;                // set the job being launched writes
   long long maskMergeSeq[2] = {0, 0};   // pipelined contexts: M-sequence behind which the merge that reads set s has completed
@@ -314,7 +326,6 @@ struct lsdhip_tracker {
   TrackSummary* d_summary = nullptr;  // device alias of h_summary
   unsigned long long* d_trace = nullptr;  // LSD_PHASE_TRACE developer build only
   // batch tracking (lsdhip_tracker_track_batch): per-job descriptions, states, scratch and summaries
-  bool batchTiles = false;            // throughput mode evaluates with k_track_eval_tiles (LDS-staged image tiles; lsdhip_tracker_set_batch_tiles)
   int batch_capacity = 0;
   TrackJob* d_bjobs = nullptr;
   TrackJob* h_bjobs = nullptr;        // pinned staging

@@ -1,4 +1,4 @@
-// Device code shared by the tracking kernels (k_track_step in tracker.hip, the batch evaluation in tracker_batch.hip): per-point
+// Device code shared by the tracking kernels (k_track_step in tracker.hip): per-point
 // arithmetic of K0-K3 in the reference's operation order, the wave-parallel Levenberg-Marquardt step, small reductions.  gfx950 only.
 //
 // Reference behaviour restated:

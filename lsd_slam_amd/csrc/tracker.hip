@@ -29,7 +29,6 @@
 #include <atomic>
 #include <chrono>
 #include "track_device.hpp"
-#include "tracker_batch.hpp"
 
 
 #ifdef LSD_PHASE_TRACE
@@ -890,7 +889,6 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 20) * 8));
   HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 20) * 8, c->stream));
 #endif
-  if (const char* e = getenv("LSDHIP_BATCH_TILES")) t->batchTiles = e[0] == '1';
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
   memset(t->h_summary, 0, sizeof(TrackSummary));
@@ -1047,9 +1045,9 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   if (L.nblocks < 1) L.nblocks = 1;
   L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
   L.tilePx = 0;
-  if (t->batch_jobs >= 8 && npts < 0 && (L.w & 3) == 0) {
+  if (t->batch_jobs >= LSD_BATCH_THROUGHPUT_MIN_JOBS && npts < 0 && (L.w & 3) == 0) {
     // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
-    static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : 768;   // developer sweep
+    static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : LSD_BATCH_STRIP_WORKGROUPS;   // developer sweep
     // strips x jobs = the chip's 768 workgroup slots (3 per CU) where the level is large enough: one full round of equal strips;
     // a strip is a multiple of 256 pixels (the lanes take 4 consecutive pixels each)
     long long px = (((long long)work * t->batch_jobs + wgTarget - 1) / wgTarget + 255) & ~255LL;
@@ -1299,9 +1297,9 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       int trials, cap = t->specCaps[l];
       if (t->specLevel[l] > 0) trials = t->specLevel[l];
       else if (!t->specAuto) trials = t->specC;
-      else trials = work <= 6144 ? 6 : (work <= 90112 ? 5 : 1);
+      else trials = work <= LSD_SPEC_SMALL_PX ? LSD_SPEC_TRIALS_SMALL : (work <= LSD_SPEC_MID_PX ? LSD_SPEC_TRIALS_MID : 1);
       if (trials > t->specC) trials = t->specC;
-      if (cap <= 0 && trials > 1 && (t->specAuto ? work > 24576 : l == job.lastLevel)) cap = t->specCap > 0 ? t->specCap : ((t->grid_cap / 2 + 7) & ~7);
+      if (cap <= 0 && trials > 1 && (t->specAuto ? work > LSD_SPEC_CAP_ABOVE_PX : l == job.lastLevel)) cap = t->specCap > 0 ? t->specCap : ((t->grid_cap / 2 + 7) & ~7);
       t->spec.trials[l] = trials;
       if (trials > 1 && cap > 0 && L.nblocks > cap && L.tilePx == 0) {
         L.nblocks = cap;
@@ -1611,12 +1609,6 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
 }
 
 // ---- batches: n independent jobs in the same launches (job = blockIdx.y) -------------------------------------------
-extern "C" int lsdhip_tracker_set_batch_tiles(lsdhip_tracker* t, int on) {
-  if (!t) return LSDHIP_E_ARG;
-  LSD_CTX_LOCK(t->ctx);
-  t->batchTiles = on != 0;
-  return LSDHIP_OK;
-}
 static int batch_reserve(lsdhip_tracker* t, int n) {
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
@@ -1683,8 +1675,6 @@ static int batch_run(lsdhip_tracker* t, int n) {
         // throughput mode: one LM workgroup per job, then a pure evaluation launch over all jobs' strips
         hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
-        if (t->batchTiles) { if (int rct = lsd_track_eval_tiles_launch(t, grid, n, sc, 1 - parity)) return rct; }
-        else
         hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, 1 - parity, 0, TrackSpec{});
       } else {
@@ -1713,6 +1703,16 @@ static int batch_run(lsdhip_tracker* t, int n) {
 // of lsdhip_tracker_track (same kernel; a batch tiles a level into fewer workgroups, which only changes summation
 // order); the point is throughput — n evaluations share one launch and its latency chain.  inits: n x 7, results: n.
 // Returns LSDHIP_OK, or LSDHIP_DIVERGED if any job diverged (see results[j].diverged).
+extern "C" void lsdhip_build_defaults(lsdhip_build_defaults_t* out) {
+  if (!out) return;
+  out->ctx_async = LSD_DEFAULT_ASYNC; out->ctx_pipeline = LSD_DEFAULT_PIPELINE;
+  out->spec_trials_small = LSD_SPEC_TRIALS_SMALL; out->spec_small_pixels = LSD_SPEC_SMALL_PX;
+  out->spec_trials_mid = LSD_SPEC_TRIALS_MID; out->spec_mid_pixels = LSD_SPEC_MID_PX;
+  out->spec_workgroups = LSD_SPEC_CAP_WORKGROUPS; out->spec_workgroups_above_pixels = LSD_SPEC_CAP_ABOVE_PX;
+  out->spec_trials_max = LSD_SPEC_MAX;
+  out->batch_throughput_min_jobs = LSD_BATCH_THROUGHPUT_MIN_JOBS; out->batch_strip_workgroups = LSD_BATCH_STRIP_WORKGROUPS;
+}
+
 extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
                                           const double* inits, lsdhip_track_result* results) {
   if (!t || n <= 0 || !keyframes || !frames || !inits || !results) return LSDHIP_E_ARG;
@@ -1818,7 +1818,6 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
   hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
                      d_sum, 0, 1, TrackSpec{});
   auto eval_launch = [&]() -> int {
-    if (t->batchTiles) return lsd_track_eval_tiles_launch(t, grid, n, sc, 1);
     hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
                        d_sum, 1, 0, TrackSpec{});
     return LSDHIP_OK;

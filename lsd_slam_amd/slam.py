@@ -342,10 +342,6 @@ class SE3Tracker:
                 f._parent = ref.keyframe
         return np.array([list(r.frameToReference) for r in res]), list(res)
 
-    def set_batch_tiles(self, on):
-        """throughput mode: evaluate with LDS-staged image tiles (k_track_eval_tiles) instead of the pipelined gather; include/lsdhip.h"""
-        check(self.L.lsdhip_tracker_set_batch_tiles(self.h_, int(bool(on))))
-
     def evalThroughput(self, references, frames, referenceToFrames, level, repeats=20):
         """measurement hook: the throughput-mode evaluation launch at `level` for n >= 8 jobs; returns (ms per launch, algorithmic
         bytes per launch)"""

@@ -161,3 +161,31 @@ int main() {
                            str(src), refsrc + "/util/settings.cpp", refsrc + "/util/SophusUtil.cpp", "-o", str(exe), "-L" + os.path.join(ROOT, "lsd_slam_amd"), "-llsdhip",
                            "-Wl,-rpath," + os.path.join(ROOT, "lsd_slam_amd")])
     subprocess.check_call([str(exe)])
+
+
+def test_header_prose_states_the_built_defaults(built_lib):
+    """include/lsdhip.h describes execution defaults in prose (speculation policy, stream model, throughput mode).  The library exports
+    the values it was built with (lsdhip_build_defaults, no GPU needed): the numbers in the text must be those."""
+    from lsd_slam_amd import capi
+    L = capi.lib()
+    d = capi.BuildDefaults()
+    L.lsdhip_build_defaults(ctypes.byref(d))
+    src = open(os.path.join(ROOT, "include", "lsdhip.h")).read()
+
+    def comment_before(decl):
+        i = src.index(decl)
+        return re.sub(r"\s+\*?\s*", " ", src[src.rindex("/*", 0, i):i])
+
+    assert "Default %d: every call is synchronous" % d.ctx_async in comment_before("int lsdhip_ctx_set_async(")
+    assert "Default %d: one stream" % d.ctx_pipeline in comment_before("int lsdhip_ctx_set_pipeline(")
+    spec = comment_before("int lsdhip_tracker_set_speculation(")
+    m = re.search(r"(\d+) trials on levels of up to (\d+) K pixels, (\d+) up to (\d+) K \(on (\d+) workgroups per trial above (\d+) K\)", spec)
+    assert m, spec
+    got = [int(x) for x in m.groups()]
+    assert got == [d.spec_trials_small, d.spec_small_pixels // 1024, d.spec_trials_mid, d.spec_mid_pixels // 1024, d.spec_workgroups,
+                   d.spec_workgroups_above_pixels // 1024], got
+    assert "`trials` (1..%d)" % d.spec_trials_max in spec and "(default %d)" % d.spec_workgroups in spec
+    batch = comment_before("int lsdhip_tracker_track_batch(")
+    assert "From %d jobs on" % d.batch_throughput_min_jobs in batch and "%d workgroup slots" % d.batch_strip_workgroups in batch
+    # and the defaults the wrappers document
+    assert d.ctx_async == 0 and d.ctx_pipeline == 0

@@ -718,17 +718,14 @@ def test_track_batch_equals_single_calls(oracle, hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiles", [0, 1])
-def test_track_batch_throughput_mode_matches_single_calls(oracle, hip, tiles):
+def test_track_batch_throughput_mode_matches_single_calls(oracle, hip):
     """>= 8 jobs switch the batch to its throughput mode (strips of the keyframe level compacted to their valid pixels in
-    LDS, tail points re-evaluated): same points, same per-point arithmetic, another summation order.  tiles = 1: the evaluation
-    with LDS-staged image tiles (k_track_eval_tiles) instead of the pipelined gather."""
+    LDS, tail points re-evaluated): same points, same per-point arithmetic, another summation order."""
     w, h = 320, 240
     seqs = [sequence(w, h, 4, seq_index=s) for s in range(3)]
     ctx = hip.Context(w, h, seqs[0][2])
     tr = hip.SE3Tracker(ctx)
     tr.set_maxItsPerLvl(ODOMETRY_ITS)
-    tr.set_batch_tiles(tiles)
     refs, frs, want = [], [], []
     for s, (frames, depth0, K, gt) in enumerate(seqs):
         for k in (1, 2, 3):

@@ -15,7 +15,6 @@ ap.add_argument("--jobs", type=int, default=64)
 ap.add_argument("--size", type=str, default="640x480")
 ap.add_argument("--repeats", type=int, default=20)
 ap.add_argument("--levels", type=str, default="3,2,1")
-ap.add_argument("--tiles", type=int, default=0, help="1: k_track_eval_tiles (LDS-staged image tiles) instead of the pipelined gather")
 args = ap.parse_args()
 w, h = (int(v) for v in args.size.split("x"))
 frames, depth0, K, gt = synth.make_sequence(w, h, 6)
@@ -31,7 +30,6 @@ for j in range(args.jobs):
     keep.append(kf)
 frs = [la.Frame(ctx, 2000 + j, device_ptr=d_frames[1 + j % 5].data_ptr()) for j in range(args.jobs)]
 tr = la.SE3Tracker(ctx)
-tr.set_batch_tiles(args.tiles)
 # poses: the ground-truth relative poses (reference -> frame), i.e. where the LM loop ends up
 T = np.zeros((args.jobs, 7), np.float32)
 for j in range(args.jobs):

@@ -17,7 +17,6 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OU
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/eval_trace -- python $GRAFT_REPO_ROOT/tools/bench_eval.py --levels 1 --repeats 20 > $OUT/eval_l1.json 2> $OUT/eval_trace.err; echo "eval trace rc=$?"
 cd $GRAFT_REPO_ROOT
 timeout 300 python tools/bench_eval.py > $OUT/eval_levels.json 2> /dev/null
-timeout 300 python tools/bench_eval.py --tiles 1 > $OUT/eval_levels_tiles.json 2> /dev/null
 find $OUT -name "*.csv" | head -20
 # keep the merged payload small: the per-dispatch traces are summarised here, only the summaries travel back
 python tools/profile_summary.py $OUT $TAG

@@ -57,7 +57,7 @@ if et:
                         (mb, mb * 1e6 / (sorted(d)[len(d) // 2] * 1e-6) / 1e9, mb * 1e6 / (sorted(d)[len(d) // 2] * 1e-6) / 8e12 * 100))
         if info:
             f.write("HIP-event figure of the same run (profiled): %s\n" % json.dumps(info))
-for fn in ("eval_levels.json", "eval_levels_tiles.json"):
+for fn in ("eval_levels.json",):
     pth = os.path.join(out, fn)
     if os.path.exists(pth):
         shutil.copy(pth, os.path.join(dst, tag + "_" + fn))
