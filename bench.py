@@ -334,11 +334,12 @@ def multi_seq(torch, w, h, K, d_frames, depth0, device, single_value, sizes=(8, 
     n = d_frames.shape[0]
     motions = [(1, 1), (-1, 1), (1, 2), (-1, 2)]
     out = {"workload": "S sequences x 640x480 track+map loop on one GPU (BASELINE.json configs[3], sequences > GPUs), 4 camera motions x S/4 replicas, "
-                       "new keyframe every %d frames, %d timed steps (= frames per sequence)" % (KF_EVERY, steps)}
+                       "new keyframe every %d frames (phases 0 / 2 / 5 / 7 by camera motion), %d timed steps (= frames per sequence)" % (KF_EVERY, steps)}
     for S in sizes:
         idx = lambda s, t: (motions[s % 4][0] * motions[s % 4][1] * t) % n
         ptrs = lambda t: [d_frames[idx(s, t)].data_ptr() for s in range(S)]
         loop = DriverLoopBatch(w, h, K, ptrs(0), [depth0] * S, kf_every=KF_EVERY, images_on_device=True, device=device)
+        loop.set_keyframe_phases([((s % 4) * KF_EVERY) // 4 for s in range(S)])   # independent cameras do not change keyframe in the same step
         L = capi.lib()
         ctx_h = loop.ctx_handle()
         t = 1
@@ -676,6 +677,7 @@ def main():
 
     st = loop.stats()
     obs_ms, obs_calls = loop.observe_time()
+    obs_counted, obs_searched, obs_steps = loop.observe_work()
     # ---- self-validation of the run that was just timed (nothing below is inside the timed region) ----------------------------------------
     poses_all = np.concatenate(state["poses"]) if state["poses"] else np.zeros((0, 7))
     kf_scales, kf_points = loop.keyframe_log()
@@ -750,6 +752,19 @@ def main():
                                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_us": obs_us,
                                      "launches": int(obs_calls), "algorithmic_bytes_per_launch": 78.0 * w * h,
                                      "note": "upper-bound bytes (every pixel assumed to carry a hypothesis); HIP events around every 8th launch"}
+            if obs_counted > 0:
+                # the same launches with the bytes of the pixels that were actually searched (counted in-kernel: searches = doLineStereo
+                # calls, steps = sum of their loopCounter): every pixel 13 B (isValid, maxGradients, blacklisted, nextStereoFrameMinID: the
+                # cheap rejections); a searched pixel + 16 B (rest of its hypothesis) + <= 29 B written + 4 B keyframe image + 8 B keyframe
+                # gradients + 4 B reference image per sample (steps + 4 per search)
+                srch, stp = obs_searched / obs_counted, obs_steps / obs_counted
+                act_bytes = 13.0 * w * h + 57.0 * srch + 4.0 * (stp + 4.0 * srch)
+                ach_a = act_bytes / (obs_us * 1e-6) / 1e9
+                out["roofline_depth"]["active"] = {"algorithmic_bytes_per_launch": act_bytes, "achieved": ach_a, "frac": ach_a / HBM_PEAK_GBS,
+                                                   "searched_pixels_per_launch": srch, "searched_fraction": srch / (w * h),
+                                                   "walk_steps_per_launch": stp, "walk_steps_per_search": stp / max(1.0, srch),
+                                                   "launches_counted": int(obs_counted)}
+                out["stereo_steps_per_s"] = stp / (obs_us * 1e-6)
         if world == 1 and (w, h) == (640, 480) and not args.no_throughput_mode:
             try:
                 out["roofline_throughput_mode"] = throughput_mode(la, w, h, K, d_frames, depth0, local_rank)

@@ -107,6 +107,10 @@ class Context {
   void setAsync(bool on) { check(lsdhip_ctx_set_async(h_, on ? 1 : 0), "lsdhip_ctx_set_async"); }
   // tracking stream beside mapping stream (lsdhip.h: lsdhip_ctx_set_pipeline): the reference's two threads, blockUntilMapped == false
   void setPipeline(bool on) { check(lsdhip_ctx_set_pipeline(h_, on ? 1 : 0), "lsdhip_ctx_set_pipeline"); }
+  // lanes: DepthMap call chains of different maps side by side (lsdhip.h: lsdhip_ctx_lanes_begin)
+  void lanesBegin(int n) { check(lsdhip_ctx_lanes_begin(h_, n), "lsdhip_ctx_lanes_begin"); }
+  void laneSelect(int lane) { check(lsdhip_ctx_lane_select(h_, lane), "lsdhip_ctx_lane_select"); }
+  void lanesEnd() { check(lsdhip_ctx_lanes_end(h_), "lsdhip_ctx_lanes_end"); }
   bool pipeline() const { return lsdhip_ctx_pipeline(h_) == 1; }
 
  private:
@@ -815,6 +819,13 @@ class SlamLoopBatch {
       q.keyframe->clearDepthHasBeenUpdatedFlag();
     }
   }
+  // Sequences started together change keyframe in the same step; real cameras do not.  phase[s] in [0, kfEvery): sequence s behaves as
+  // if its current keyframe were already phase[s] frames old (its first keyframe change comes kfEvery - phase[s] frames in).  Call before
+  // the first step().
+  void setKeyframePhases(const std::vector<int>& phase) {
+    if (frameId_ != 0 || (int)phase.size() != size()) throw Error(LSDHIP_E_STATE, "SlamLoopBatch::setKeyframePhases: one phase per sequence, before the first step");
+    for (int s = 0; s < size(); s++) seqs_[s]->sinceKF = phase[s] < 0 ? 0 : phase[s] % kfEvery_;
+  }
   SlamLoopBatch(const SlamLoopBatch&) = delete;
   SlamLoopBatch& operator=(const SlamLoopBatch&) = delete;
   int size() const { return (int)seqs_.size(); }
@@ -851,6 +862,7 @@ class SlamLoopBatch {
     std::vector<DepthMap*> updMaps;
     std::vector<Frame*> updFrames;
     std::vector<int> updSeq;
+    std::vector<size_t> kfChange;
     for (size_t k = 0; k < alive.size(); k++) {
       Sequence& q = *seqs_[alive[k]];
       q.last = res[k];
@@ -871,6 +883,26 @@ class SlamLoopBatch {
       }
       ++q.sinceKF;
       if (q.sinceKF >= kfEvery_) {
+        kfChange.push_back(k);
+      } else {
+        updMaps.push_back(&q.map);
+        updFrames.push_back(frames[k].get());
+        updSeq.push_back(alive[k]);
+        q.lastFrameToKF = est[k];
+      }
+    }
+    // keyframe changes: per-sequence call chains (finalizeKeyFrame + createKeyFrame, ~18 small dependent launches each), independent of
+    // each other and of the other sequences' updateKeyframe — dealt to `keyframeLanes` streams so that they run side by side, and queued
+    // AFTER the shared updateKeyframe launches (which go to the context's stream) so that the host's ~0.5 ms of enqueueing lies under them
+    std::shared_ptr<Context> ctx = Context::get(w_, h_, K_);
+    const int lanes = keyframeLanes > 1 && !kfChange.empty() ? (keyframeLanes < (int)kfChange.size() ? keyframeLanes : (int)kfChange.size()) : 0;
+    if (lanes) ctx->lanesBegin(lanes);
+    DepthMap::updateKeyframeBatch(updMaps, updFrames);
+    {
+      for (size_t i = 0; i < kfChange.size(); i++) {
+        const size_t k = kfChange[i];
+        Sequence& q = *seqs_[alive[k]];
+        if (lanes) ctx->laneSelect((int)(i % (size_t)lanes));
         q.map.finalizeKeyFrame();
         q.numKeyframesFinished++;
         q.mappedOnKF = 0;
@@ -881,14 +913,9 @@ class SlamLoopBatch {
         q.lastFrameToKF = SE3();
         q.sinceKF = 0;
         q.newKeyframe = true;
-      } else {
-        updMaps.push_back(&q.map);
-        updFrames.push_back(frames[k].get());
-        updSeq.push_back(alive[k]);
-        q.lastFrameToKF = est[k];
       }
+      if (lanes) ctx->lanesEnd();
     }
-    DepthMap::updateKeyframeBatch(updMaps, updFrames);
     for (size_t k = 0; k < updSeq.size(); k++) {
       Sequence& q = *seqs_[updSeq[k]];
       q.mappedOnKF++;
@@ -898,6 +925,7 @@ class SlamLoopBatch {
     return out;
   }
   SE3Tracker tracker;
+  int keyframeLanes = 8;      // streams the keyframe changes of one step are dealt to (1: all on the context's stream)
 
  private:
   int w_, h_;

@@ -100,6 +100,15 @@ int lsdhip_ctx_set_pipeline(lsdhip_ctx* ctx, int on);
 int lsdhip_ctx_pipeline(lsdhip_ctx* ctx);          /* 1 / 0 */
 void* lsdhip_ctx_map_stream(lsdhip_ctx* ctx);      /* hipStream_t of the mapping side (== lsdhip_ctx_stream on a non-pipelined context) */
 int lsdhip_ctx_synchronize(lsdhip_ctx* ctx);
+/* Lanes (one-stream contexts; no reference counterpart — S SlamSystems would each have their own mapping thread): the DepthMap call
+ * chains of DIFFERENT depth maps are independent, so between lanes_begin(n) and lanes_end the caller may route each map's calls to
+ * one of n extra streams (lane_select(lane), -1 = back to the context's stream) and the chains run side by side: finalizeKeyFrame +
+ * createKeyFrame is ~18 small dependent launches per sequence, S sequences changing keyframe take S times that on one stream.  Work
+ * queued before lanes_begin is visible on every lane; lanes_end orders the context's stream behind all lanes.  All calls on ONE map
+ * between begin and end must use the same lane.  n <= 16. */
+int lsdhip_ctx_lanes_begin(lsdhip_ctx* ctx, int n);
+int lsdhip_ctx_lane_select(lsdhip_ctx* ctx, int lane);
+int lsdhip_ctx_lanes_end(lsdhip_ctx* ctx);
 const char* lsdhip_last_error(void);
 /* per-level intrinsics fx,fy,cx,cy,fxi,fyi,cxi,cyi (C/DataStructures/Frame.cpp:445-459) */
 int lsdhip_ctx_intrinsics(lsdhip_ctx* ctx, int level, float out[8]);
@@ -401,6 +410,10 @@ int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);
 int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]);
 /* GPU time (ms, summed) and count of the observe kernel alone (DepthMap::observeDepth, C/DepthEstimation/DepthMap.cpp:147-150),
  * sampled on every 8th updateKeyframe while lsdhip_prof_enable is on; synchronises the stream. */
+/* Work of the k_observe launches sampled while profiling (every 8th updateKeyframe): out[0] = launches counted, out[1] = pixels that
+ * entered the epipolar search (DepthMap::doLineStereo calls), out[2] = steps of the search loops (sum of loopCounter,
+ * DepthMap.cpp:1622-1744).  bench.py: stereo_steps_per_s, roofline_depth on the bytes of searched pixels.  Synchronises. */
+int lsdhip_depth_observe_work(lsdhip_depthmap* dm, double out[3]);
 int lsdhip_depth_observe_time(lsdhip_depthmap* dm, double* ms_out, long long* calls_out);
 
 /* ---- measurement hooks ---------------------------------------------------------------------------- */

@@ -55,6 +55,8 @@ int lsdloop_set_live_queue(lsdloop* l, int frames);
 int lsdloop_set_speculation(lsdloop* l, int trials, int finest_level_workgroups);
 /* lsdhip_depth_observe_time of the loop's depth map */
 int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out);
+/* lsdhip_depth_observe_work of the loop's depth map: launches counted, searched pixels, walk steps */
+int lsdloop_observe_work(lsdloop* l, double out3[3]);
 /* ---- RCCL over xGMI, issued from the C++ loop on its own stream (BASELINE.json configs[3]: independent sequences, one per GPU,
  * results collected on rank 0).  The library binds the ncclXxx entry points of the RCCL already loaded into the process (the one
  * torch.distributed uses) or of librccl.so, by name.  Rendezvous: rank 0 calls lsdloop_comm_unique_id and hands the 128 bytes to
@@ -94,6 +96,9 @@ void lsdloopbatch_destroy(lsdloopbatch* l);
 int lsdloopbatch_run(lsdloopbatch* l, const uint8_t* const* images, int n, double* frameToKeyframe_out);
 int lsdloopbatch_get_stats(lsdloopbatch* l, long long* out6_per_sequence);
 void* lsdloopbatch_ctx(lsdloopbatch* l);
+/* phase[s] in [0, kf_every): sequence s changes keyframe as if its current keyframe were already phase[s] frames old (sequences that
+ * start together otherwise all change keyframe in the same step, which independent cameras do not).  Before the first run. */
+int lsdloopbatch_set_keyframe_phases(lsdloopbatch* l, const int* phase);
 const char* lsdloop_last_error(void);
 /* ---- row-band decomposition of the regulariser (BASELINE.json configs[4]) ----------------------------
  * `world` bands over an H-row map; this process holds bands [first_band, first_band + n_local) as windows of

@@ -78,6 +78,9 @@ def _signatures():
         "lsdhip_ctx_stream": (vp, [vp]),
         "lsdhip_ctx_synchronize": (i, [vp]),
         "lsdhip_ctx_set_async": (i, [vp, i]),
+        "lsdhip_ctx_lanes_begin": (i, [vp, i]),
+        "lsdhip_ctx_lane_select": (i, [vp, i]),
+        "lsdhip_ctx_lanes_end": (i, [vp]),
         "lsdhip_ctx_set_pipeline": (i, [vp, i]),
         "lsdhip_ctx_pipeline": (i, [vp]),
         "lsdhip_ctx_map_stream": (vp, [vp]),
@@ -158,6 +161,7 @@ def _signatures():
         "lsdhip_depth_init_random": (i, [vp, vp]),
         "lsdhip_depth_set_from_existing": (i, [vp, vp]),
         "lsdhip_depth_update": (i, [vp, pvp, i]),
+        "lsdhip_depth_observe_work": (i, [vp, vp]),
         "lsdhip_depth_update_batch": (i, [i, pvp, pvp]),
         "lsdhip_depth_create_keyframe": (i, [vp, vp, C.POINTER(C.c_float)]),
         "lsdhip_depth_finalize": (i, [vp]),

@@ -100,6 +100,7 @@ struct ObserveArgs {
 #ifdef LSD_PHASE_TRACE
   unsigned long long* trace;   // developer build: per-stage timestamps of one traced pixel per workgroup
 #endif
+  unsigned long long* counters;   // null, or (sampled launches while profiling) two words per wave: pixels that entered the search, walk steps
   StereoRef one;   // nRefs == 1 (the blockUntilMapped case): the reference travels in the kernel arguments, no staging copy
 };
 
@@ -411,12 +412,14 @@ LSD_HD float stereo_finish(const ObserveArgs& a, const StereoRef& rf, const floa
 
 LSD_HD_NOINLINE float do_line_stereo(const ObserveArgs& a, const StereoRef& rf, const float u, const float v, const float epxn,
                                 const float epyn, const float min_idepth, const float prior_idepth, float max_idepth,
-                                float& result_idepth, float& result_var, float& result_eplLength) {
+                                float& result_idepth, float& result_var, float& result_eplLength, int& steps) {
   StereoSetup S;
+  steps = 0;
   const float st = stereo_setup(a, rf, u, v, epxn, epyn, min_idepth, prior_idepth, max_idepth, S);
   if (st < 0) return st;
   WalkResult W;
   stereo_walk_serial(rf.image, a.w, S, W);
+  steps = W.loopCounter;
   return stereo_finish(a, rf, u, v, epxn, epyn, S, W, result_idepth, result_var, result_eplLength);
 }
 
@@ -572,21 +575,50 @@ LSD_HD void observe_back_store(const ObserveArgs& a, const StereoRef& rf, const 
   }
 }
 template <bool ONE>
-LSD_HD_NOINLINE void observe_back(const ObserveArgs& a, const int idx, const int refIdx, const float epx, const float epy) {
+LSD_HD_NOINLINE int observe_back(const ObserveArgs& a, const int idx, const int refIdx, const float epx, const float epy) {
   const int x = idx % a.w, y = idx / a.w;
   const StereoRef& rf = ONE ? a.one : a.refs[refIdx];
   ObsPixel P;
   observe_back_load(a, idx, P);
   float result_idepth = 0, result_var = 0, result_eplLength = 0;   // uninitialised in the reference (:344)
-  const float error = do_line_stereo(a, rf, x, y, epx, epy, P.min_idepth, P.prior_idepth, P.max_idepth, result_idepth, result_var, result_eplLength);
+  int steps;
+  const float error = do_line_stereo(a, rf, x, y, epx, epy, P.min_idepth, P.prior_idepth, P.max_idepth, result_idepth, result_var, result_eplLength, steps);
   observe_back_store(a, rf, idx, P, error, result_idepth, result_var, result_eplLength);
+  return steps;
 }
 
+// returns -1 for a pixel the cheap tests reject, else the number of walk steps of its epipolar search
 template <bool ONE>
-LSD_HD void observe_pixel(const ObserveArgs& a, const int x, const int y) {
+LSD_HD int observe_pixel(const ObserveArgs& a, const int x, const int y) {
   int refIdx = 0;
   float epx = 0, epy = 0;
-  if (observe_front<ONE>(a, x, y, refIdx, epx, epy)) observe_back<ONE>(a, x + y * a.w, refIdx, epx, epy);
+  if (observe_front<ONE>(a, x, y, refIdx, epx, epy)) return observe_back<ONE>(a, x + y * a.w, refIdx, epx, epy);
+  return -1;
+}
+// measurement (sampled launches): the wave's number of searches and walk steps -> its slot of a.counters
+__device__ __forceinline__ void observe_count(const ObserveArgs& a, const int steps) {
+  if (a.counters == nullptr) return;
+  const unsigned long long act = __popcll(__ballot(steps >= 0));
+  int s = steps > 0 ? steps : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) {
+    const size_t wv = ((size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    a.counters[2 * wv] = act;
+    a.counters[2 * wv + 1] = (unsigned long long)s;
+  }
+}
+__global__ __launch_bounds__(256) void k_obs_count_sum(const unsigned long long* __restrict__ counters, int nwaves, unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s_a[256], s_b[256];
+  unsigned long long a0 = 0, b0 = 0;
+  for (int i = threadIdx.x; i < nwaves; i += 256) { a0 += counters[2 * i]; b0 += counters[2 * i + 1]; }
+  s_a[threadIdx.x] = a0; s_b[threadIdx.x] = b0;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { acc[0] += s_a[0]; acc[1] += s_b[0]; acc[2] += 1; }
 }
 
 // K4: observeDepthRow over the whole map, one pixel per lane.
@@ -600,7 +632,8 @@ __global__ __launch_bounds__(32 * ROWS) void k_observe(ObserveArgs a) {
   const int x = blockIdx.x * 32 + (threadIdx.x & 31);
   const int y = blockIdx.y * ROWS + (threadIdx.x >> 5);
   OBS_MARK(0);
-  observe_pixel<ONE>(a, x, y);
+  const int steps = observe_pixel<ONE>(a, x, y);
+  observe_count(a, steps);
   OBS_MARK(7);
 }
 
@@ -611,7 +644,7 @@ __global__ __launch_bounds__(32 * ROWS) void k_observe_batch(const ObserveArgs* 
   const ObserveArgs& a = items[blockIdx.z];
   const int x = blockIdx.x * 32 + (threadIdx.x & 31);
   const int y = blockIdx.y * ROWS + (threadIdx.x >> 5);
-  observe_pixel<true>(a, x, y);
+  (void)observe_pixel<true>(a, x, y);
 }
 
 struct RegArgs {
@@ -1292,6 +1325,7 @@ extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
   for (int i = 0; i < 8; i++) if (dm->ev[i][0]) { (void)hipEventDestroy(dm->ev[i][0]); (void)hipEventDestroy(dm->ev[i][1]); }
   if (dm->d_stage) (void)hipFree(dm->d_stage);
   if (dm->h_stage) (void)hipHostFree(dm->h_stage);
+  if (dm->d_obsCounters) (void)hipFree(dm->d_obsCounters);
   delete dm;
 }
 extern "C" int lsdhip_depth_is_valid(lsdhip_depthmap* dm) { return dm && dm->activeKeyFrame != nullptr; }
@@ -1466,6 +1500,7 @@ static void observe_args_common(lsdhip_depthmap* dm, ObserveArgs& a) {
   a.useSubpixelStereo = c->params.useSubpixelStereo;
   a.kfNumFramesTrackedOnThis = kf->numFramesTrackedOnThis;
   a.kfNumMappedOnThis = kf->numMappedOnThis;
+  a.counters = nullptr;
 }
 
 static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
@@ -1545,6 +1580,18 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
     static const int rows = [] { const char* e = getenv("LSDHIP_OBS_ROWS"); int r = e ? atoi(e) : 2; return (r == 8 || r == 4) ? r : 2; }();   // 64-thread workgroups measured best (+2.5 % Mpixel/s over 256)
 #endif
     const dim3 grid((c->w + 31) / 32, (c->h + rows - 1) / rows);
+    const int nwaves = (int)(grid.x * grid.y) * (rows * 32 / 64);
+    if (dm->countNext) {
+      // sampled launch while profiling: searches and walk steps, per wave, summed behind the launch (bench.py: stereo_steps_per_s,
+      // roofline_depth on the bytes of the pixels that were actually searched)
+      if (!dm->d_obsCounters) {
+        HIPCHK(hipMalloc((void**)&dm->d_obsCounters, (size_t)nwaves * 16 + 32));
+        dm->d_obsAcc = dm->d_obsCounters + (size_t)nwaves * 2;
+        HIPCHK(hipMemsetAsync(dm->d_obsAcc, 0, 32, lsd_map_stream(c)));
+        dm->obsCounterWaves = nwaves;
+      }
+      if (dm->obsCounterWaves == nwaves) a.counters = dm->d_obsCounters;
+    }
     if (rows == 8) {
       if (n == 1) hipLaunchKernelGGL((k_observe<true, 8>), grid, dim3(256), 0, lsd_map_stream(c), a);
       else hipLaunchKernelGGL((k_observe<false, 8>), grid, dim3(256), 0, lsd_map_stream(c), a);
@@ -1556,6 +1603,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
       else hipLaunchKernelGGL((k_observe<false, 2>), grid, dim3(64), 0, lsd_map_stream(c), a);
     }
   }
+  if (a.counters) hipLaunchKernelGGL(k_obs_count_sum, dim3(1), dim3(256), 0, lsd_map_stream(c), (const unsigned long long*)dm->d_obsCounters, dm->obsCounterWaves, dm->d_obsAcc);
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }
@@ -1754,7 +1802,9 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   int evo = -1;
   if (sampleObs) { evo = timing_begin(dm, 3); if (evo < 0) return evo; }
   lsdhip_host_mark(10);
+  dm->countNext = sampleObs;
   int rc = observe(dm, refs, n);
+  dm->countNext = false;
   if (rc) return rc;
   lsdhip_host_mark(11);
   if (sampleObs) { rc = timing_end(dm, evo); if (rc) return rc; }
@@ -1977,6 +2027,19 @@ extern "C" int lsdhip_depth_observe_time(lsdhip_depthmap* dm, double* ms_out, lo
   timing_collect(dm, true);
   *ms_out = dm->gpu_ms[3];
   *calls_out = dm->gpu_calls[3];
+  return LSDHIP_OK;
+}
+// the sampled k_observe launches' work: out[0] = launches counted, out[1] = pixels that entered the epipolar search, out[2] = walk steps
+// (sum of doLineStereo's loopCounter); synchronises
+extern "C" int lsdhip_depth_observe_work(lsdhip_depthmap* dm, double out[3]) {
+  if (!dm || !out) return LSDHIP_E_ARG;
+  out[0] = out[1] = out[2] = 0;
+  if (!dm->d_obsAcc) return LSDHIP_OK;
+  HIPCHK(hipSetDevice(dm->ctx->device));
+  HIPCHK(hipStreamSynchronize(lsd_map_stream(dm->ctx)));
+  unsigned long long acc[3];
+  HIPCHK(hipMemcpy(acc, dm->d_obsAcc, sizeof(acc), hipMemcpyDeviceToHost));
+  out[0] = (double)acc[2]; out[1] = (double)acc[0]; out[2] = (double)acc[1];
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]) {

@@ -458,6 +458,8 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
     for (int i = 0; i < LSD_EVR; i++) if (c->mEv[i]) (void)hipEventDestroy(c->mEv[i]);
     (void)hipStreamDestroy(c->mstream);
   }
+  for (int i = 0; i < lsdhip_ctx::MAX_LANES; i++) if (c->lanes[i]) { (void)hipStreamSynchronize(c->lanes[i]); (void)hipEventDestroy(c->lane_done[i]); (void)hipStreamDestroy(c->lanes[i]); }
+  if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipEventDestroy(c->aux_fork); (void)hipEventDestroy(c->aux_done); (void)hipStreamDestroy(c->aux_stream); }
   for (void* a : c->free_arenas) (void)hipFree(a);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -738,6 +740,55 @@ extern "C" int lsdhip_ctx_copy_dev(lsdhip_ctx* c, void* dst, const void* src, si
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, lsd_transport_stream(c)));
   return LSDHIP_OK;
 }
+// ---- lanes: the DepthMap call chains of DIFFERENT depth maps are independent of each other; between lanes_begin and lanes_end the
+// caller routes each map's calls to one of n extra streams (lane_select), so that the chains of several sequences (finalizeKeyFrame +
+// createKeyFrame: ~18 small dependent launches each) run side by side instead of one after the other.  Everything queued on the
+// context's stream before lanes_begin is visible to every lane; lanes_end orders the context's stream behind all lanes.
+extern "C" int lsdhip_ctx_lanes_begin(lsdhip_ctx* c, int n) {
+  if (!c || n < 1 || n > lsdhip_ctx::MAX_LANES) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  if (c->pipeline) { lsd_set_error("lsdhip_ctx_lanes_begin: one-stream contexts only"); return LSDHIP_E_STATE; }
+  if (c->lanes_open) { lsd_set_error("lsdhip_ctx_lanes_begin: already open"); return LSDHIP_E_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->lane_fork) HIPCHK(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+  for (int i = 0; i < n; i++) {
+    if (!c->lanes[i]) {
+      HIPCHK(hipStreamCreateWithFlags(&c->lanes[i], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->lane_done[i], hipEventDisableTiming));
+    }
+    c->lane_used[i] = false;
+  }
+  HIPCHK(hipEventRecord(c->lane_fork, c->stream));
+  c->lanes_open = n;
+  c->lane_cur = -1;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_lane_select(lsdhip_ctx* c, int lane) {
+  if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  if (!c->lanes_open || lane < -1 || lane >= c->lanes_open) { lsd_set_error("lsdhip_ctx_lane_select: lane %d of %d", lane, c->lanes_open); return LSDHIP_E_ARG; }
+  if (lane >= 0 && !c->lane_used[lane]) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamWaitEvent(c->lanes[lane], c->lane_fork, 0));
+    c->lane_used[lane] = true;
+  }
+  c->lane_cur = lane;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_ctx_lanes_end(lsdhip_ctx* c) {
+  if (!c) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  if (!c->lanes_open) return LSDHIP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  c->lane_cur = -1;
+  for (int i = 0; i < c->lanes_open; i++) {
+    if (!c->lane_used[i]) continue;
+    HIPCHK(hipEventRecord(c->lane_done[i], c->lanes[i]));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->lane_done[i], 0));
+  }
+  c->lanes_open = 0;
+  return LSDHIP_OK;
+}
 // ---- transport stream: exchange under compute (halo rows of the row-band loop travel while the interior rows are computed) -------
 extern "C" int lsdhip_ctx_aux_begin(lsdhip_ctx* c) {
   if (!c) return LSDHIP_E_ARG;
@@ -899,6 +950,7 @@ int lsd_frame_resolve(lsdhip_frame* f) {
     landed = (f->pendRescale < 0 || c->doneEpoch > c->slot_epoch[f->pendRescale]) &&
              (f->pendStats < 0 || c->doneEpoch > c->slot_epoch[f->pendStats]);
     if (!landed) {
+      for (int i = 0; i < c->lanes_open; i++) if (c->lane_used[i]) HIPCHK(hipStreamSynchronize(c->lanes[i]));   // (a slot written on a lane)
       HIPCHK(hipStreamSynchronize(c->stream));
       c->enqEpoch++;
       c->doneEpoch = c->enqEpoch;

@@ -210,6 +210,14 @@ struct lsdhip_ctx {
   // Second stream for the transport primitives of the multi-process loops (row copies, flags, device copies, the caller's RCCL
   // calls): between lsdhip_ctx_aux_begin and lsdhip_ctx_aux_end they are queued there, ordered behind what the main stream held at
   // `begin`; lsdhip_ctx_aux_join makes the main stream wait for them.  Created on first use.
+  // lanes: independent DepthMap call chains of different maps side by side (lsdhip_ctx_lanes_begin / _lane_select / _lanes_end)
+  static constexpr int MAX_LANES = 16;
+  hipStream_t lanes[MAX_LANES] = {};
+  hipEvent_t lane_done[MAX_LANES] = {};
+  hipEvent_t lane_fork = nullptr;
+  int lanes_open = 0;      // > 0 between lanes_begin and lanes_end: number of lanes
+  int lane_cur = -1;       // lane the mapping calls currently go to (-1: the context's own stream)
+  bool lane_used[MAX_LANES] = {};
   hipStream_t aux_stream = nullptr;
   unsigned* d_flagArrive = nullptr;      // arrival counter of k_flag_set's workgroups
   hipEvent_t aux_fork = nullptr, aux_done = nullptr;
@@ -393,6 +401,10 @@ struct lsdhip_depthmap {
   double gpu_ms[4] = {0, 0, 0, 0};    // update, createKeyFrame, finalizeKeyFrame, k_observe alone (sampled while profiling)
   long long gpu_calls[4] = {0, 0, 0, 0};
   unsigned obs_tick = 0;
+  bool countNext = false;                        // the next k_observe launch counts its searches / walk steps (sampled while profiling)
+  unsigned long long* d_obsCounters = nullptr;   // per wave (searches, steps) of the last counted launch | d_obsAcc: totals (searches, steps, launches)
+  unsigned long long* d_obsAcc = nullptr;
+  int obsCounterWaves = 0;
   unsigned ev_tick[3] = {0, 0, 0};   // calls per kind: every 8th updateKeyframe / 2nd createKeyFrame, finalizeKeyFrame is timed
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
         msSetDepth = 0;
@@ -401,7 +413,7 @@ struct lsdhip_depthmap {
 // kernels / launchers implemented in the .hip files
 inline hipStream_t lsd_transport_stream(lsdhip_ctx* c) { return c->aux_active ? c->aux_stream : c->stream; }
 // the stream frame creation and the DepthMap calls run on
-inline hipStream_t lsd_map_stream(lsdhip_ctx* c) { return c->pipeline ? c->mstream : c->stream; }
+inline hipStream_t lsd_map_stream(lsdhip_ctx* c) { return c->lane_cur >= 0 ? c->lanes[c->lane_cur] : (c->pipeline ? c->mstream : c->stream); }
 int lsd_m_begin(lsdhip_ctx* c);                    // an mstream operation starts (developer switches only: see the note on tracking -> mapping ordering in frame.hip)
 long long lsd_m_record(lsdhip_ctx* c);             // record point on mstream -> its M-sequence (0 when the context is not pipelined, < 0: error)
 int lsd_t_wait_m(lsdhip_ctx* c, long long seq);    // order `stream` behind M-sequence `seq`

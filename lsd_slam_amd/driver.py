@@ -22,7 +22,8 @@ EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop
                     "lsdloop_copy_keyframe_planes", "lsdloop_set_keyframe_ring", "lsdloop_keyframes_exported", "lsdloop_ctx",
                     "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_pipeline", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
                     "lsdloop_gather_keyframes", "lsdband_create", "lsdband_destroy", "lsdband_window_rows", "lsdband_layout", "lsdband_load",
-                    "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_set_overlap", "lsdband_tile_runs", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result"]
+                    "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_set_overlap", "lsdband_tile_runs", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result", "lsdloop_observe_work",
+                    "lsdloopbatch_create", "lsdloopbatch_destroy", "lsdloopbatch_run", "lsdloopbatch_get_stats", "lsdloopbatch_ctx", "lsdloopbatch_set_keyframe_phases"]
 
 
 def lib():
@@ -61,6 +62,8 @@ def lib():
         L.lsdloop_set_speculation.argtypes = [vp, i, i]
         L.lsdloop_observe_time.restype = i
         L.lsdloop_observe_time.argtypes = [vp, vp, vp]
+        L.lsdloop_observe_work.restype = i
+        L.lsdloop_observe_work.argtypes = [vp, vp]
         L.lsdloop_comm_unique_id.restype = i
         L.lsdloop_comm_unique_id.argtypes = [vp]
         for name, args in (("lsdband_create", [i, i, i, i, i, i, C.POINTER(vp)]), ("lsdband_window_rows", [vp]), ("lsdband_layout", [vp, i, vp]),
@@ -95,6 +98,8 @@ def lib():
         L.lsdloopbatch_get_stats.argtypes = [vp, vp]
         L.lsdloopbatch_ctx.restype = vp
         L.lsdloopbatch_ctx.argtypes = [vp]
+        L.lsdloopbatch_set_keyframe_phases.restype = i
+        L.lsdloopbatch_set_keyframe_phases.argtypes = [vp, vp]
         L.lsdloop_last_error.restype = C.c_char_p
         L.lsdloop_last_error.argtypes = []
         _lib = L
@@ -149,6 +154,11 @@ class DriverLoopBatch:
 
     def ctx_handle(self):
         return C.c_void_p(self.L.lsdloopbatch_ctx(self.h_))
+
+    def set_keyframe_phases(self, phases):
+        """phase[s] in [0, kf_every): how old sequence s's first keyframe already is (unsynchronised keyframe changes)"""
+        a = (C.c_int * self.S)(*[int(p) for p in phases])
+        _check(self.L.lsdloopbatch_set_keyframe_phases(self.h_, a))
 
 
 class DriverLoop:
@@ -247,6 +257,12 @@ class DriverLoop:
         ms, n = C.c_double(), C.c_longlong()
         _check(self.L.lsdloop_observe_time(self.h_, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def observe_work(self):
+        """(launches counted, searched pixels, walk steps) of the sampled k_observe launches; synchronises"""
+        out = np.zeros(3, np.float64)
+        _check(self.L.lsdloop_observe_work(self.h_, out.ctypes.data))
+        return float(out[0]), float(out[1]), float(out[2])
 
     @staticmethod
     def comm_unique_id():

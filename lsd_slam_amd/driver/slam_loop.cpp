@@ -135,6 +135,7 @@ extern "C" int lsdloopbatch_create(int device, int w, int h, const float K4[4], 
     l->ctx = Context::get(w, h, K, device);
     l->ctx->setPipeline(false);
     l->loop.reset(new lsd_slam_hip::SlamLoopBatch(w, h, K, S, first_images, images_on_device != 0, gt_depth0_host, kf_every));
+    if (const char* e = std::getenv("LSDHIP_KF_LANES")) l->loop->keyframeLanes = std::atoi(e);   // developer A/B (1: keyframe changes on one stream)
     l->ctx->setAsync(true);
     l->keyframes.assign((size_t)S, 0);
     *out = l.release();
@@ -182,6 +183,16 @@ extern "C" int lsdloopbatch_get_stats(lsdloopbatch* l, long long* out) {
   return LSDHIP_OK;
 }
 extern "C" void* lsdloopbatch_ctx(lsdloopbatch* l) { return l ? (void*)l->ctx->handle() : nullptr; }
+extern "C" int lsdloopbatch_set_keyframe_phases(lsdloopbatch* l, const int* phase) {
+  if (!l || !phase) return LSDHIP_E_ARG;
+  try {
+    l->loop->setKeyframePhases(std::vector<int>(phase, phase + l->loop->size()));
+    return LSDHIP_OK;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.status < 0 ? e.status : LSDHIP_E_STATE;
+  }
+}
 
 extern "C" int lsdloop_run(lsdloop* l, const uint8_t* const* images, int n, int stop_at_keyframe, double* out7) {
   if (!l || !images || n < 0) return LSDHIP_E_ARG;
@@ -315,6 +326,10 @@ extern "C" int lsdloop_set_speculation(lsdloop* l, int trials, int finest_level_
 extern "C" int lsdloop_observe_time(lsdloop* l, double* ms_out, long long* calls_out) {
   if (!l) return LSDHIP_E_ARG;
   return lsdhip_depth_observe_time(l->loop->map.handle(), ms_out, calls_out);
+}
+extern "C" int lsdloop_observe_work(lsdloop* l, double out3[3]) {
+  if (!l) return LSDHIP_E_ARG;
+  return lsdhip_depth_observe_work(l->loop->map.handle(), out3);
 }
 extern "C" int lsdloop_comm_unique_id(unsigned char out128[128]) {
   Rccl& R = rccl();

@@ -78,7 +78,7 @@ def test_driver_library_exports_header_symbols(built_lib):
     from lsd_slam_amd import driver
     src = open(os.path.join(ROOT, "include", "lsdhip_driver.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(lsd(?:loop|band)_[a-z0-9_]+)\s*\(", src)))
+    declared = sorted(set(re.findall(r"\b(lsd(?:loopbatch|loop|band)_[a-z0-9_]+)\s*\(", src)))
     assert declared == sorted(driver.EXPORTED_SYMBOLS)
     L = driver.lib()
     for name in declared:
