@@ -771,14 +771,15 @@ def main():
             except Exception as e:   # an extra: never let it take the bench line down
                 out["roofline_throughput_mode"] = {"error": str(e)}
         if world == 1 and (w, h) == (640, 480) and not args.no_extra_configs:
-            try:
-                out.setdefault("extra_configs", {}).update(extra_configs(la, torch, local_rank))
-            except Exception as e:   # extras: never let them take the bench line down
-                out.setdefault("extra_configs", {})["error"] = str(e)
+            # (before the dense 4K leg: a burst like that leaves a box in its slow state for seconds, profiles/r03_notes.md section 1)
             try:
                 out.setdefault("extra_configs", {})["multi_seq"] = multi_seq(torch, w, h, K, d_frames, depth0, local_rank, out["value"])
             except Exception as e:
                 out.setdefault("extra_configs", {})["multi_seq"] = {"error": str(e)}
+            try:
+                out.setdefault("extra_configs", {}).update(extra_configs(la, torch, local_rank))
+            except Exception as e:   # extras: never let them take the bench line down
+                out.setdefault("extra_configs", {})["error"] = str(e)
         if world == 1 and not args.no_pcie_leg:
             # SURVEY.md §8(d) counts the 8-bit upload inside tracked frames/s: the same loop fed from (pinned) host memory, every frame
             # crossing PCIe inside lsdhip_frame_create.  Reported beside `value`, never as `value`.

@@ -365,7 +365,6 @@ __global__ __launch_bounds__(256) void k_pc_write(const float* __restrict__ id, 
 // ---------------------------------------------------------------------------------------------------------
 #define LSD_FLAG_WGS 16
 static void trace_dump(lsdhip_ctx* c);
-static const int g_pipeDebug = getenv("LSDHIP_PIPE_DEBUG") ? atoi(getenv("LSDHIP_PIPE_DEBUG")) : 0;   // developer bisection switches
 extern "C" void lsdhip_default_params(lsdhip_params* p) {
   p->minUseGrad = 5;
   p->cameraPixelNoise2 = 4 * 4;
@@ -510,20 +509,9 @@ extern "C" int lsdhip_ctx_set_pipeline(lsdhip_ctx* c, int on) {
   HIPCHK(hipSetDevice(c->device));
   if (int rc = lsd_sync_all(c)) return rc;
   if (on && !c->mstream) {
-    if (const char* e = getenv("LSDHIP_PIPE_CUMASK")) {
-      // developer experiment: the mapping stream on its own compute units (bits i with i % 32 >= 32 - k), the tracking stream on the rest
-      const int k = atoi(e) > 0 && atoi(e) < 32 ? atoi(e) : 4;
-      uint32_t mm[8], tm[8];
-      for (int i = 0; i < 8; i++) { mm[i] = ~0u << (32 - k); tm[i] = ~mm[i]; }
-      HIPCHK(hipExtStreamCreateWithCUMask(&c->mstream, 8, mm));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      HIPCHK(hipStreamDestroy(c->stream));
-      HIPCHK(hipExtStreamCreateWithCUMask(&c->stream, 8, tm));
-    } else
     HIPCHK(hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking));
     for (int i = 0; i < LSD_EVR; i++) {
-      const unsigned evflags = (g_pipeDebug & 32) ? hipEventDefault : hipEventDisableTiming;
-      HIPCHK(hipEventCreateWithFlags(&c->mEv[i], evflags));
+      HIPCHK(hipEventCreateWithFlags(&c->mEv[i], hipEventDisableTiming));
     }
   }
   if (!on && c->pipeline) {
@@ -550,22 +538,10 @@ int lsd_sync_all(lsdhip_ctx* c) {
 // the launches still queued behind it touch only the tracker's own state.  So no event is recorded on the tracking stream: a record
 // behind every job is a barrier packet in the queue the launch chain runs through (the first form of the pipeline had one, plus a
 // hipStreamWaitEvent on the mapping stream; profiles/r04_notes.md).
-static const int g_pipeAcq = getenv("LSDHIP_PIPE_ACQ") ? atoi(getenv("LSDHIP_PIPE_ACQ")) : 0;
-__global__ void k_acquire_all() {
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: this XCD's caches drop what they hold
-}
-int lsd_acquire_all(lsdhip_ctx* c, hipStream_t s) {
-  hipLaunchKernelGGL(k_acquire_all, dim3(LSD_FLAG_WGS), dim3(64), 0, s);
-  return LSDHIP_OK;
-}
 int lsd_m_begin(lsdhip_ctx* c) {
-  if (c->pipeline && (g_pipeDebug & 2)) HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->pipeline && (g_pipeDebug & 8)) HIPCHK(hipStreamSynchronize(c->mstream));
-  if (c->pipeline && (g_pipeAcq & 2)) return lsd_acquire_all(c, c->mstream);
   if (!c->pendingMerges.empty()) return lsd_flush_merges(c);
   return LSDHIP_OK;
 }
-int lsd_pipe_acq() { return g_pipeAcq; }
 // Experiment: kernels that touch nothing but their own buffer, queued on the mapping stream right when a tracking job starts.
 // kind 1: memory streaming (32 MB read-modify-write), 2: LDS-heavy workgroups (9.6 KB each, like k_reg_fused), 3: ALU spin.
 static const int g_pipeDummy = getenv("LSDHIP_PIPE_DUMMY") ? atoi(getenv("LSDHIP_PIPE_DUMMY")) : 0;
@@ -632,10 +608,7 @@ long long lsd_m_record(lsdhip_ctx* c) {
   return s;
 }
 int lsd_t_wait_m(lsdhip_ctx* c, long long seq) {
-  if (c->pipeline && (g_pipeDebug & 1)) seq = c->mSeq;
-  if (c->pipeline && (g_pipeDebug & 4)) { HIPCHK(hipStreamSynchronize(c->mstream)); c->mDoneSeq = c->mSeq; }
   if (!c->pipeline || seq <= c->tWaitedM || seq <= c->mDoneSeq) return LSDHIP_OK;
-  if (g_pipeDebug & 128) { c->tWaitedM = seq; return LSDHIP_OK; }        // diagnostic (unsafe): no event wait on the tracking stream
   if (seq > c->mSeq) seq = c->mSeq;                 // (cannot happen: a sequence number is handed out by lsd_m_record)
   // the ring slot holds the event of `seq` or, once the ring has wrapped, of a later point of the in-order stream: either orders us
   HIPCHK(hipStreamWaitEvent(c->stream, c->mEv[seq % LSD_EVR], 0));
@@ -1171,20 +1144,12 @@ extern "C" int lsdhip_frame_create_from_device(lsdhip_ctx* c, int id, const uint
   int rc = frame_alloc(c, id, &f);
   if (rc) return rc;
   // the pyramid kernel reads the caller's device image directly (stream-ordered; nothing else needs the uint8 plane)
-  if (c->pipeline && (g_pipeDebug & 16)) {      // bisection: pyramids on the tracking stream
-    rc = lsd_t_wait_m(c, c->mSeq);
-    if (rc == LSDHIP_OK) rc = lsd_frame_build_pyramids(f, gray_dev, c->stream);
-    if (rc) { lsdhip_frame_destroy(f); return rc; }
-    *out = f;
-    return LSDHIP_OK;
-  }
   rc = lsd_m_begin(c);
   if (rc == LSDHIP_OK) rc = lsd_frame_build_pyramids(f, gray_dev, nullptr);
   if (rc) { lsdhip_frame_destroy(f); return rc; }
   lsd_trace_sum(c, lsd_map_stream(c), 2, id, f->d_image[0], (size_t)((char*)f->d_idepth[0] - (char*)f->d_image[0]));
   f->readySeq = lsd_m_record(c);
   if (f->readySeq < 0) { lsdhip_frame_destroy(f); return LSDHIP_E_HIP; }
-  if (c->pipeline && (g_pipeDebug & 64)) { HIPCHK(hipStreamSynchronize(c->mstream)); c->mDoneSeq = c->mSeq; }
   *out = f;
   return LSDHIP_OK;
 }

@@ -421,9 +421,7 @@ bool lsd_m_done(lsdhip_ctx* c, long long seq);     // has mstream passed M-seque
 int lsd_sync_all(lsdhip_ctx* c);                   // both streams drained
 int lsd_gate_wait(lsdhip_ctx* c);                  // developer hook (LSDHIP_PIPE_GATE=1): mapping stream holds until the next tracking job starts
 int lsd_gate_open(lsdhip_ctx* c);
-int lsd_pipe_acq();
 int lsd_pipe_dummy(lsdhip_ctx* c);   // experiment LSDHIP_PIPE_DUMMY=<kind>: unrelated kernels on the mapping stream beside a tracking job
-int lsd_acquire_all(lsdhip_ctx* c, hipStream_t s);   // one system-scope acquire per XCD, stream-ordered (experiment LSDHIP_PIPE_ACQ)
 // developer trace (LSDHIP_TRACE_SUMS=<file>): order-independent checksums of device buffers, queued on a stream at chosen points of the
 // loop and written out when the context is destroyed — two runs of the same loop are compared entry by entry (tools/trace_cmp.py)
 void lsd_trace_sum(lsdhip_ctx* c, hipStream_t s, int kind, int id, const void* p, size_t bytes);

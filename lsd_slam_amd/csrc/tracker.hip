@@ -1503,7 +1503,6 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   int rc = fill_trackframe_job(t, job, kf, frame);
   if (rc) return rc;
   if (int rcg = lsd_gate_open(c)) return rcg;
-  if (c->pipeline && (lsd_pipe_acq() & 1)) lsd_acquire_all(c, c->stream);
   if (int rcd = lsd_pipe_dummy(c)) return rcd;
   static const bool traceInputs = getenv("LSDHIP_TRACE_INPUTS") != nullptr;
   auto trace_inputs = [&](int base) {

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """Developer tool: run-to-run determinism of the pipelined C++ loop (poses of `n` frames, `reps` runs); prints the first differing frame.
-Bisection switches: LSDHIP_PIPE_DEBUG bit 1 = every tracking job waits for all queued mapping work (events), 2 = every mapping-stream
-operation first drains the tracking stream (host), 4 = every tracking job first drains the mapping stream (host), 8 = every mapping
-operation first drains the mapping stream; LSDHIP_NO_PREFETCH=1 = no next-frame prefetch in the enqueue hook."""
+LSDHIP_NO_PREFETCH=1 = no next-frame prefetch in the enqueue hook.  (The LSDHIP_PIPE_DEBUG bisection switches of the round-4 bug hunt —
+profiles/r04_notes.md section 1a — have left the library with the bug.)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,4 +30,4 @@ for rep in range(reps):
     else:
         d = np.where(np.any(poses != base, axis=1))[0]
         firsts.append(int(d[0]) + 1 if len(d) else 0)
-print("PIPE_DEBUG=%s NO_PREFETCH=%s pipe=%d: first differing frame per run (0 = identical): %s" % (os.environ.get("LSDHIP_PIPE_DEBUG", "0"), os.environ.get("LSDHIP_NO_PREFETCH", "0"), pipe, firsts))
+print("NO_PREFETCH=%s pipe=%d: first differing frame per run (0 = identical): %s" % (os.environ.get("LSDHIP_NO_PREFETCH", "0"), pipe, firsts))

@@ -4,7 +4,7 @@ A lag-1 loop without keyframe changes is driven from Python on a pipelined conte
 hypothesis map after its mapping iteration and the keyframe planes Frame::setDepth wrote are recorded (everything is drained before
 the read-backs, between the tracking job and the next mapping iteration).  Run twice and compare:
     LSDHIP_PIPE_GATE=1 python tools/pipe_overlap_debug.py run /tmp/a.npz     # forced overlap (the mapping kernels wait for the next tracking job's start)
-    LSDHIP_PIPE_DEBUG=1 python tools/pipe_overlap_debug.py run /tmp/b.npz    # serialised: every tracking job waits for all queued mapping work
+    python tools/pipe_overlap_debug.py run /tmp/b.npz                        # the Python loop's own pace: every mapping iteration has finished before the next job
     python tools/pipe_overlap_debug.py cmp /tmp/a.npz /tmp/b.npz"""
 import os, sys
 import numpy as np
