@@ -655,11 +655,14 @@ def main():
             dist.barrier()
         e = clock() - t0
         own_all.append(e)
-        if distributed:
-            t = torch.tensor([e], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e = float(t.item())
-        elapsed_all.append(e)
+    if distributed:
+        # every region is bracketed by barriers on all ranks; its time is the MAX over ranks — reduced once, after the last region, so
+        # that a region of K = 20 frames (3.5 ms) is not stretched by a second collective and a host read-back
+        t = torch.tensor(own_all, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_all = [float(x) for x in t.tolist()]
+    else:
+        elapsed_all = list(own_all)
     capi.check(L.lsdhip_prof_enable(ctx_h, 0))
     elapsed = float(np.median(elapsed_all))
     # configs[3]: every rank's own rate (its own median region, not the max over ranks that `value` is made of)
