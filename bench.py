@@ -754,7 +754,7 @@ def main():
             out["roofline_depth"] = {"bound": "hbm", "kernel": "k_observe (makeAndCheckEPL + doLineStereo + observeDepthCreate/Update, one launch per updateKeyframe)",
                                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_us": obs_us,
                                      "launches": int(obs_calls), "algorithmic_bytes_per_launch": 78.0 * w * h,
-                                     "note": "upper-bound bytes (every pixel assumed to carry a hypothesis); HIP events around every 8th launch"}
+                                     "note": "upper-bound bytes (every pixel assumed to carry a hypothesis); HIP events around every 7th launch"}
             if obs_counted > 0:
                 # the same launches with the bytes of the pixels that were actually searched (counted in-kernel: searches = doLineStereo
                 # calls, steps = sum of their loopCounter): every pixel 13 B (isValid, maxGradients, blacklisted, nextStereoFrameMinID: the

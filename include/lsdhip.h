@@ -405,12 +405,12 @@ int lsdhip_depth_copy_rows_batch(lsdhip_ctx* c, int n, const lsdhip_row_copy* it
  * msPropagate, msFillHoles, msSetDepth (exponential moving averages, ms) */
 int lsdhip_depth_timings(lsdhip_depthmap* dm, float out[8]);
 /* GPU time (HIP events on the context's stream, ms, summed since creation) of the TIMED calls of updateKeyframe [0],
- * createKeyFrame [1], finalizeKeyFrame [2] and how many calls were timed: every 8th updateKeyframe and every 2nd createKeyFrame /
+ * createKeyFrame [1], finalizeKeyFrame [2] and how many calls were timed: every 7th updateKeyframe and every 2nd createKeyFrame /
  * finalizeKeyFrame is bracketed (an event record delays the kernel behind it by ~10 us); mean = ms / calls; synchronises the stream */
 int lsdhip_depth_gpu_times(lsdhip_depthmap* dm, double ms_out[3], long long calls_out[3]);
 /* GPU time (ms, summed) and count of the observe kernel alone (DepthMap::observeDepth, C/DepthEstimation/DepthMap.cpp:147-150),
- * sampled on every 8th updateKeyframe while lsdhip_prof_enable is on; synchronises the stream. */
-/* Work of the k_observe launches sampled while profiling (every 8th updateKeyframe): out[0] = launches counted, out[1] = pixels that
+ * sampled on every 7th updateKeyframe while lsdhip_prof_enable is on; synchronises the stream. */
+/* Work of the k_observe launches sampled while profiling (every 7th updateKeyframe): out[0] = launches counted, out[1] = pixels that
  * entered the epipolar search (DepthMap::doLineStereo calls), out[2] = steps of the search loops (sum of loopCounter,
  * DepthMap.cpp:1622-1744).  bench.py: stereo_steps_per_s, roofline_depth on the bytes of searched pixels.  Synchronises. */
 int lsdhip_depth_observe_work(lsdhip_depthmap* dm, double out[3]);

@@ -1686,13 +1686,15 @@ static void timing_collect(lsdhip_depthmap* dm, bool all) {
 }
 // GPU time of the DepthMap calls, SAMPLED: an event record is a barrier packet with a completion signal, and the kernel behind it
 // starts ~10 us late (rocprofv3 timeline, profiles/r03_notes.md §2b) — two of them around every updateKeyframe cost 9 % of the
-// track + map loop.  Every 8th updateKeyframe and every 2nd createKeyFrame / finalizeKeyFrame is bracketed (kind 3, k_observe
+// track + map loop.  Every 7th updateKeyframe and every 2nd createKeyFrame / finalizeKeyFrame is bracketed (kind 3, k_observe
 // alone, is sampled by its caller); gpu_ms / gpu_calls describe the bracketed calls only.  Returns EV_SKIP when the call is not sampled.
+// (7, not 8: a loop with a keyframe every 10 frames runs exactly 8 (pipelined) or 9 updateKeyframe calls per keyframe, and the first
+// update on a new keyframe searches 30x more pixels than the eighth — a period of 8 sampled one phase of that cycle only.)
 constexpr int EV_SKIP = -1000;
 static int timing_begin(lsdhip_depthmap* dm, int kind) {
   if (kind < 3) {
     static const bool every = getenv("LSDHIP_DEPTH_EVENTS_ALL") != nullptr;   // developer switch: A/B of the sampling itself
-    const unsigned period = every ? 1u : (kind == 0 ? 8u : 2u);
+    const unsigned period = every ? 1u : (kind == 0 ? 7u : 2u);
     if ((dm->ev_tick[kind]++ % period) != 0) return EV_SKIP;
   }
   const int i = dm->ev_next;
@@ -1797,8 +1799,8 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   if (int rcg = lsd_gate_wait(c)) return rcg;
   const int ev = timing_begin(dm, 0);
   if (ev < 0 && ev != EV_SKIP) return ev;
-  // while profiling, every 8th call brackets the observe kernel alone with a second event pair (bench.py roofline_depth)
-  const bool sampleObs = c->prof_on && ((dm->obs_tick++ & 7) == 0);
+  // while profiling, every 7th call brackets the observe kernel alone with a second event pair (bench.py roofline_depth)
+  const bool sampleObs = c->prof_on && ((dm->obs_tick++ % 7) == 0);
   int evo = -1;
   if (sampleObs) { evo = timing_begin(dm, 3); if (evo < 0) return evo; }
   lsdhip_host_mark(10);

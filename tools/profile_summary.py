@@ -27,7 +27,7 @@ if ks:
 kt = find("trace", "*kernel_trace.csv")
 if kt:
     rows = list(csv.DictReader(open(kt)))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if r["Kernel_Name"].startswith("void k_track_step")]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if r["Kernel_Name"].startswith("void k_track_step<256, false, 0>")]   # the single-sequence chain (the bench's extra legs run batch forms too)
     d.sort()
     work = [x for x in d if x > 5.5]   # launches queued behind the finishing one leave in 4-5 us (416 workgroups, one scalar load each)
     with open(os.path.join(dst, tag + "_track_step_durations.txt"), "w") as f:
