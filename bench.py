@@ -324,8 +324,10 @@ def bands_distributed(torch, dist, rank, world, local_rank, passes=20):
 
 
 def multi_seq(torch, w, h, K, d_frames, depth0, device, single_value, sizes=(8, 32), steps=30, warmup=10, regions=3):
-    """BASELINE.json configs[3] with more sequences than GPUs: S independent sequences share this GPU (lsd_slam_hip::SlamLoopBatch — per
-    sequence the blockUntilMapped loop; frame creation, tracking jobs and updateKeyframe calls of all sequences in shared launches).
+    """BASELINE.json configs[3] with more sequences than GPUs: S independent sequences share this GPU (lsd_slam_hip::SlamLoopBatch — frame
+    creation, tracking jobs and updateKeyframe calls of all sequences in shared launches, keyframe changes as per-sequence call chains on
+    side streams).  Two execution models per S, as for the single sequence: pipelined (`frames_s`: the tracking batch of step t + 1
+    beside the mapping work of step t, per sequence the mapper one frame behind) and blockUntilMapped (`frames_s_block_until_mapped`).
     The sequences are four camera motions over the bench scene (the closed camera loop forwards / backwards at one and two frames per
     step, all starting on frame 0 with its ground-truth depth), each replicated S / 4 times with its own frames, keyframes and maps.
     Replicas must come out bit-identical (same inputs through different z-slices of the same launches): checked here."""
@@ -335,36 +337,46 @@ def multi_seq(torch, w, h, K, d_frames, depth0, device, single_value, sizes=(8, 
     motions = [(1, 1), (-1, 1), (1, 2), (-1, 2)]
     out = {"workload": "S sequences x 640x480 track+map loop on one GPU (BASELINE.json configs[3], sequences > GPUs), 4 camera motions x S/4 replicas, "
                        "new keyframe every %d frames (phases 0 / 2 / 5 / 7 by camera motion), %d timed steps (= frames per sequence)" % (KF_EVERY, steps)}
+    L = capi.lib()
     for S in sizes:
         idx = lambda s, t: (motions[s % 4][0] * motions[s % 4][1] * t) % n
         ptrs = lambda t: [d_frames[idx(s, t)].data_ptr() for s in range(S)]
-        loop = DriverLoopBatch(w, h, K, ptrs(0), [depth0] * S, kf_every=KF_EVERY, images_on_device=True, device=device)
-        loop.set_keyframe_phases([((s % 4) * KF_EVERY) // 4 for s in range(S)])   # independent cameras do not change keyframe in the same step
-        L = capi.lib()
-        ctx_h = loop.ctx_handle()
-        t = 1
-        loop.run([ptrs(t + k) for k in range(warmup)])
-        t += warmup
-        capi.check(L.lsdhip_ctx_synchronize(ctx_h))
-        dts, poses = [], None
-        for _ in range(regions):
-            batch = [ptrs(t + k) for k in range(steps)]
-            t0 = time.perf_counter()
-            done, poses = loop.run(batch, want_poses=True)
+        rec = {"sequences": S}
+        for pipelined in (True, False):
+            loop = DriverLoopBatch(w, h, K, ptrs(0), [depth0] * S, kf_every=KF_EVERY, images_on_device=True, device=device)
+            loop.set_keyframe_phases([((s % 4) * KF_EVERY) // 4 for s in range(S)])   # independent cameras do not change keyframe in the same step
+            loop.set_pipeline(pipelined)
+            ctx_h = loop.ctx_handle()
+            t = 1
+            loop.run([ptrs(t + k) for k in range(warmup)])
+            t += warmup
             capi.check(L.lsdhip_ctx_synchronize(ctx_h))
-            dts.append(time.perf_counter() - t0)
-            t += steps
-        st = loop.stats()
-        loop.close()
-        dt = float(np.median(dts))
-        identical = all(np.array_equal(poses[:, s], poses[:, s % 4]) for s in range(S))
-        fps = S * steps / dt
-        out["S%d" % S] = {"sequences": S, "frames_s": fps, "ms_per_step": dt / steps * 1e3, "us_per_frame": dt / steps / S * 1e6,
-                          "vs_one_sequence": (fps / single_value) if single_value else None,
-                          "tracked_good": sum(q["tracked_good"] for q in st), "frames": sum(q["frames"] for q in st),
-                          "updates": sum(q["updates"] for q in st), "keyframes": sum(q["keyframes"] for q in st), "lost": sum(q["lost"] for q in st),
-                          "lm_evaluations_per_frame": sum(q["evaluations"] for q in st) / max(1, sum(q["frames"] for q in st)),
-                          "replicas_bit_identical": bool(identical)}
+            dts, poses = [], None
+            for _ in range(regions):
+                batch = [ptrs(t + k) for k in range(steps)]
+                t0 = time.perf_counter()
+                done, poses = loop.run(batch, want_poses=True)
+                capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+                dts.append(time.perf_counter() - t0)
+                t += steps
+            st = loop.stats()
+            dropped = sum(loop.dropped())
+            loop.close()
+            dt = float(np.median(dts))
+            fps = S * steps / dt
+            if not pipelined:
+                rec["frames_s_block_until_mapped"] = fps
+                rec["ms_per_step_block_until_mapped"] = dt / steps * 1e3
+                continue
+            identical = all(np.array_equal(poses[:, s], poses[:, s % 4]) for s in range(S))
+            rec.update({"frames_s": fps, "ms_per_step": dt / steps * 1e3, "us_per_frame": dt / steps / S * 1e6,
+                        "vs_one_sequence": (fps / single_value) if single_value else None,
+                        "tracked_good": sum(q["tracked_good"] for q in st), "frames": sum(q["frames"] for q in st),
+                        "updates": sum(q["updates"] for q in st), "keyframes": sum(q["keyframes"] for q in st), "dropped": dropped,
+                        "lost": sum(q["lost"] for q in st),
+                        "lm_evaluations_per_frame": sum(q["evaluations"] for q in st) / max(1, sum(q["frames"] for q in st)),
+                        "replicas_bit_identical": bool(identical)})
+        out["S%d" % S] = rec
     return out
 
 

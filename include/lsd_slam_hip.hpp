@@ -43,6 +43,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "lsdhip.h"
@@ -327,8 +328,10 @@ class SE3Tracker {
       inits[j].to7(&init[(size_t)j * 7]);
     }
     results.assign((size_t)n, lsdhip_track_result());
+    hookError_ = nullptr;
     const int rc = lsdhip_tracker_track_batch(h_, n, kfs.data(), frs.data(), init.data(), results.data());
     if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) check(rc, "lsdhip_tracker_track_batch");
+    if (hookError_) std::rethrow_exception(hookError_);
     std::vector<SE3> out((size_t)n);
     for (int j = 0; j < n; j++) out[j] = SE3::from7(results[j].frameToReference);
     return out;
@@ -788,10 +791,12 @@ class SlamLoopBatch {
     Sequence(int w, int h, const Mat3f& K) : map(w, h, K) {}
     DepthMap map;
     TrackingReference reference;
-    std::shared_ptr<Frame> keyframe;
+    std::shared_ptr<Frame> keyframe;       // the mapper's current keyframe
+    std::shared_ptr<Frame> trackKF;        // the keyframe the tracking reference points at (== keyframe unless a promotion is pending)
+    std::shared_ptr<Frame> pendingKF;      // pipelined: promoted by the mapping iteration queued last, not yet adopted by the tracker
     SE3 lastFrameToKF;
     int sinceKF = 0, mappedOnKF = 0, numKeyframesFinished = 0;
-    long numTracked = 0, numTrackedGood = 0, numUpdates = 0, evaluations = 0;
+    long numTracked = 0, numTrackedGood = 0, numUpdates = 0, evaluations = 0, numDropped = 0;
     bool trackingLost = false, newKeyframe = false;
     lsdhip_track_result last = lsdhip_track_result();
   };
@@ -817,6 +822,7 @@ class SlamLoopBatch {
       }
       q.reference.importFrame(q.keyframe.get());
       q.keyframe->clearDepthHasBeenUpdatedFlag();
+      q.trackKF = q.keyframe;
     }
   }
   // Sequences started together change keyframe in the same step; real cameras do not.  phase[s] in [0, kfEvery): sequence s behaves as
@@ -835,15 +841,146 @@ class SlamLoopBatch {
   // nextStereoFrameMinID — which is a float, DepthMapPixelHypothesis.h:49: ids beyond 2^24 would round)
   static int idOf(int /*s*/, int t) { return t; }
   // one frame of every sequence that is still tracking (images[s] is ignored for lost ones); returns frameToKeyframe per sequence
-  std::vector<SE3> step(const unsigned char* const* images) {
+  // Tracking beside mapping for ALL sequences (the context becomes a pipelined one): per sequence exactly SlamLoop::setPipelined — the
+  // mapper one frame behind the tracker, frames tracked on a keyframe the mapper has meanwhile replaced are dropped
+  // (SlamSystem.cpp:559-566), the first frame on a new keyframe starts from se3FromSim3(newKeyframe^-1 * lastTrackedFrame) (:913-920).
+  // The tracking batch of step t + 1 — a chain of small latency-bound launches — runs beside the shared updateKeyframe launches and the
+  // keyframe changes of step t.  Call before the first step().
+  void setPipelined(bool on) {
+    if (frameId_ != 0) throw Error(LSDHIP_E_STATE, "SlamLoopBatch::setPipelined: switch before the first step");
+    Context::get(w_, h_, K_)->setPipeline(on);
+    pipelined_ = on;
+    for (auto& q : seqs_) { q->trackKF = q->keyframe; q->pendingKF.reset(); }
+    if (on) tracker.setEnqueueHook([this]() {
+      // the tracking batch's launches are queued: now the mapping work of the previous step, then the next step's frames
+      flush();
+      if (!pendingNext_) return;
+      std::vector<int> all;
+      for (int s = 0; s < size(); s++) all.push_back(s);
+      prefetched_ = makeFrames(all, pendingNext_, frameId_ + 1);
+      prefetchedId_ = frameId_ + 1;
+    });
+    else tracker.setEnqueueHook(nullptr);
+  }
+  bool pipelined() const { return pipelined_; }
+  // nextImages (optional, pipelined loops): the images of the following step() call — their upload / pyramids are queued on the mapping
+  // stream AHEAD of this step's mapping work, so that the next tracking batch does not wait behind it
+  std::vector<SE3> step(const unsigned char* const* images, const unsigned char* const* nextImages = nullptr) {
     frameId_++;
     const int S = size();
-    std::vector<int> alive, ids;
-    std::vector<const unsigned char*> imgs;
-    for (int s = 0; s < S; s++) if (!seqs_[s]->trackingLost) { alive.push_back(s); ids.push_back(idOf(s, frameId_)); imgs.push_back(images[s]); }
     std::vector<SE3> out((size_t)S);
-    if (alive.empty()) return out;
-    std::vector<std::shared_ptr<Frame>> frames = Frame::createBatch(w_, h_, K_, ids, imgs.data(), onDevice_);
+    std::vector<int> all;
+    for (int s = 0; s < S; s++) all.push_back(s);
+    std::vector<std::shared_ptr<Frame>> groupFrames;
+    if (prefetchedId_ == frameId_ && (int)prefetched_.size() == S) groupFrames = std::move(prefetched_);
+    else groupFrames = makeFrames(all, images, frameId_);
+    prefetched_.clear();
+    prefetchedId_ = -1;
+    if (!pipelined_) {
+      MapWork w = trackGroup(all, groupFrames, out);
+      mapGroup(w);
+      return out;
+    }
+    // ---- pipelined: track, adopt what the mapper did one step ago, then queue [next frames, this step's mapping] ----------------------
+    std::vector<int> alive;
+    std::vector<std::shared_ptr<Frame>> frames, trackedOn;
+    std::vector<TrackingReference*> refs;
+    std::vector<Frame*> frs;
+    std::vector<SE3> inits;
+    for (int s = 0; s < S; s++) {
+      Sequence& q = *seqs_[s];
+      if (q.trackingLost || !groupFrames[s]) continue;
+      alive.push_back(s); frames.push_back(groupFrames[s]); trackedOn.push_back(q.trackKF);
+      refs.push_back(&q.reference); frs.push_back(groupFrames[s].get()); inits.push_back(q.lastFrameToKF);
+    }
+    MapWork work;
+    pendingNext_ = nextImages;
+    if (alive.empty()) { flush(); pendingNext_ = nullptr; }
+    if (!alive.empty()) {
+      std::vector<lsdhip_track_result> res;
+      std::vector<SE3> est = tracker.trackFrameBatch(refs, frs, inits, res);    // (the enqueue hook queues the previous step's mapping and the next frames)
+      pendingNext_ = nullptr;
+      for (size_t k = 0; k < alive.size(); k++) {
+        Sequence& q = *seqs_[alive[k]];
+        q.last = res[k];
+        q.numTracked++;
+        q.evaluations += res[k].numEvaluations;
+        if (res[k].trackingWasGood) q.numTrackedGood++;
+        out[alive[k]] = est[k];
+        q.newKeyframe = false;
+        if (res[k].diverged || (q.numKeyframesFinished > 5 /* INITIALIZATION_PHASE_COUNT */ && !res[k].trackingWasGood)) {
+          q.trackingLost = true;
+          q.reference.invalidate();
+          if (q.map.isValid()) {
+            if (q.mappedOnKF >= 5 /* MIN_NUM_MAPPED */) { q.map.finalizeKeyFrame(); q.numKeyframesFinished++; }
+            q.map.invalidate();
+          }
+          continue;
+        }
+        if (q.pendingKF) {
+          // the mapper promoted pendingKF while this frame was being tracked on the old keyframe (SlamSystem.cpp:907-920)
+          double p[7];
+          check(lsdhip_frame_relative_pose(q.pendingKF->handle(), frames[k]->handle(), p), "lsdhip_frame_relative_pose");
+          q.lastFrameToKF = SE3::from7(p);
+          q.trackKF = q.pendingKF;
+          q.pendingKF.reset();
+          q.reference.importFrame(q.trackKF.get());
+          q.trackKF->clearDepthHasBeenUpdatedFlag();
+        } else {
+          q.lastFrameToKF = est[k];
+          if (q.trackKF->depthHasBeenUpdatedFlag()) {
+            q.reference.importFrame(q.trackKF.get());
+            q.trackKF->clearDepthHasBeenUpdatedFlag();
+          }
+        }
+        ++q.sinceKF;
+        if (trackedOn[k] != q.keyframe) {        // tracked on the keyframe the mapper has just replaced: popped unmapped (:559-566)
+          frames[k]->clear_refPixelWasGood();
+          q.numDropped++;
+          continue;
+        }
+        if (q.sinceKF >= kfEvery_) { work.kfChange.emplace_back(alive[k], frames[k]); q.newKeyframe = true; }
+        else { work.updMaps.push_back(&q.map); work.updFrames.push_back(frames[k]); work.updSeq.push_back(alive[k]); }
+      }
+    }
+    // queued from the NEXT tracking batch's enqueue hook (or flush()): the host's enqueueing of ~10^2 launches then lies under that
+    // batch, and so does the device work
+    deferred_ = std::move(work);
+    return out;
+  }
+  // queues the mapping work the last step left (a pipelined loop keeps it back for the next tracking batch's enqueue hook); call after the
+  // last step() before reading maps or statistics
+  void flush() { MapWork w = std::move(deferred_); deferred_ = MapWork(); mapGroup(w); }
+  SE3Tracker tracker;
+  int keyframeLanes = 8;      // streams the keyframe changes of one step are dealt to (1: all on the context's stream)
+
+ private:
+  struct MapWork {            // what a tracking batch leaves for the mapping side
+    std::vector<DepthMap*> updMaps;
+    std::vector<std::shared_ptr<Frame>> updFrames;
+    std::vector<int> updSeq;
+    std::vector<std::pair<int, std::shared_ptr<Frame>>> kfChange;   // (sequence, its new keyframe)
+  };
+  // new frames of the sequences in `group` that are still tracking (null entries for lost ones)
+  std::vector<std::shared_ptr<Frame>> makeFrames(const std::vector<int>& group, const unsigned char* const* images, int frameId) {
+    std::vector<int> ids;
+    std::vector<const unsigned char*> imgs;
+    for (int s : group) if (!seqs_[s]->trackingLost) { ids.push_back(idOf(s, frameId)); imgs.push_back(images[s]); }
+    std::vector<std::shared_ptr<Frame>> out(group.size());
+    if (ids.empty()) return out;
+    std::vector<std::shared_ptr<Frame>> made = Frame::createBatch(w_, h_, K_, ids, imgs.data(), onDevice_);
+    size_t k = 0;
+    for (size_t i = 0; i < group.size(); i++) if (!seqs_[group[i]]->trackingLost) out[i] = made[k++];
+    return out;
+  }
+  // SlamSystem::trackFrame for every sequence of the group in shared launches + the decisions of doMappingIteration; the device work
+  // of the mapping iterations is returned, not queued
+  MapWork trackGroup(const std::vector<int>& group, const std::vector<std::shared_ptr<Frame>>& groupFrames, std::vector<SE3>& out) {
+    MapWork work;
+    std::vector<int> alive;
+    std::vector<std::shared_ptr<Frame>> frames;
+    for (size_t i = 0; i < group.size(); i++) if (!seqs_[group[i]]->trackingLost && groupFrames[i]) { alive.push_back(group[i]); frames.push_back(groupFrames[i]); }
+    if (alive.empty()) return work;
     std::vector<TrackingReference*> refs;
     std::vector<Frame*> frs;
     std::vector<SE3> inits;
@@ -859,10 +996,6 @@ class SlamLoopBatch {
     }
     std::vector<lsdhip_track_result> res;
     std::vector<SE3> est = tracker.trackFrameBatch(refs, frs, inits, res);
-    std::vector<DepthMap*> updMaps;
-    std::vector<Frame*> updFrames;
-    std::vector<int> updSeq;
-    std::vector<size_t> kfChange;
     for (size_t k = 0; k < alive.size(); k++) {
       Sequence& q = *seqs_[alive[k]];
       q.last = res[k];
@@ -883,51 +1016,61 @@ class SlamLoopBatch {
       }
       ++q.sinceKF;
       if (q.sinceKF >= kfEvery_) {
-        kfChange.push_back(k);
+        work.kfChange.emplace_back(alive[k], frames[k]);
+        q.newKeyframe = true;
       } else {
-        updMaps.push_back(&q.map);
-        updFrames.push_back(frames[k].get());
-        updSeq.push_back(alive[k]);
+        work.updMaps.push_back(&q.map);
+        work.updFrames.push_back(frames[k]);
+        work.updSeq.push_back(alive[k]);
         q.lastFrameToKF = est[k];
       }
     }
-    // keyframe changes: per-sequence call chains (finalizeKeyFrame + createKeyFrame, ~18 small dependent launches each), independent of
-    // each other and of the other sequences' updateKeyframe — dealt to `keyframeLanes` streams so that they run side by side, and queued
-    // AFTER the shared updateKeyframe launches (which go to the context's stream) so that the host's ~0.5 ms of enqueueing lies under them
+    return work;
+  }
+  // the mapping iterations a tracking batch left: updateKeyframe of all its sequences in shared launches, then the keyframe changes —
+  // per-sequence call chains (finalizeKeyFrame + createKeyFrame, ~18 small dependent launches each), independent of each other: on a
+  // one-stream context dealt to `keyframeLanes` streams, and queued AFTER the shared launches so that the host's enqueueing lies under them
+  void mapGroup(MapWork& work) {
+    if (work.updMaps.empty() && work.kfChange.empty()) return;
     std::shared_ptr<Context> ctx = Context::get(w_, h_, K_);
-    const int lanes = keyframeLanes > 1 && !kfChange.empty() ? (keyframeLanes < (int)kfChange.size() ? keyframeLanes : (int)kfChange.size()) : 0;
+    const int nkf = (int)work.kfChange.size();
+    const int lanes = keyframeLanes > 1 && nkf > 0 ? (keyframeLanes < nkf ? keyframeLanes : nkf) : 0;
     if (lanes) ctx->lanesBegin(lanes);
-    DepthMap::updateKeyframeBatch(updMaps, updFrames);
-    {
-      for (size_t i = 0; i < kfChange.size(); i++) {
-        const size_t k = kfChange[i];
-        Sequence& q = *seqs_[alive[k]];
-        if (lanes) ctx->laneSelect((int)(i % (size_t)lanes));
-        q.map.finalizeKeyFrame();
-        q.numKeyframesFinished++;
-        q.mappedOnKF = 0;
-        q.map.createKeyFrame(frames[k].get());
-        q.keyframe = frames[k];
+    std::vector<Frame*> updFrames;
+    for (auto& f : work.updFrames) updFrames.push_back(f.get());
+    DepthMap::updateKeyframeBatch(work.updMaps, updFrames);
+    for (int i = 0; i < nkf; i++) {
+      Sequence& q = *seqs_[work.kfChange[i].first];
+      const std::shared_ptr<Frame>& frame = work.kfChange[i].second;
+      if (lanes) ctx->laneSelect(i % lanes);
+      q.map.finalizeKeyFrame();
+      q.numKeyframesFinished++;
+      q.mappedOnKF = 0;
+      q.map.createKeyFrame(frame.get());
+      q.keyframe = frame;
+      q.sinceKF = 0;
+      if (pipelined_) {
+        q.pendingKF = frame;          // the tracker keeps the old keyframe for one more frame
+      } else {
+        q.trackKF = frame;
         q.reference.importFrame(q.keyframe.get());
         q.keyframe->clearDepthHasBeenUpdatedFlag();
         q.lastFrameToKF = SE3();
-        q.sinceKF = 0;
-        q.newKeyframe = true;
       }
-      if (lanes) ctx->lanesEnd();
     }
-    for (size_t k = 0; k < updSeq.size(); k++) {
-      Sequence& q = *seqs_[updSeq[k]];
+    if (lanes) ctx->lanesEnd();
+    for (size_t k = 0; k < work.updSeq.size(); k++) {
+      Sequence& q = *seqs_[work.updSeq[k]];
       q.mappedOnKF++;
       q.numUpdates++;
-      updFrames[k]->clear_refPixelWasGood();
+      work.updFrames[k]->clear_refPixelWasGood();
     }
-    return out;
   }
-  SE3Tracker tracker;
-  int keyframeLanes = 8;      // streams the keyframe changes of one step are dealt to (1: all on the context's stream)
-
- private:
+  bool pipelined_ = false;
+  std::vector<std::shared_ptr<Frame>> prefetched_;
+  int prefetchedId_ = -1;
+  const unsigned char* const* pendingNext_ = nullptr;
+  MapWork deferred_;
   int w_, h_;
   Mat3f K_;
   bool onDevice_;

@@ -100,7 +100,7 @@ int lsdhip_ctx_set_pipeline(lsdhip_ctx* ctx, int on);
 int lsdhip_ctx_pipeline(lsdhip_ctx* ctx);          /* 1 / 0 */
 void* lsdhip_ctx_map_stream(lsdhip_ctx* ctx);      /* hipStream_t of the mapping side (== lsdhip_ctx_stream on a non-pipelined context) */
 int lsdhip_ctx_synchronize(lsdhip_ctx* ctx);
-/* Lanes (one-stream contexts; no reference counterpart — S SlamSystems would each have their own mapping thread): the DepthMap call
+/* Lanes (no reference counterpart — S SlamSystems would each have their own mapping thread): the DepthMap call
  * chains of DIFFERENT depth maps are independent, so between lanes_begin(n) and lanes_end the caller may route each map's calls to
  * one of n extra streams (lane_select(lane), -1 = back to the context's stream) and the chains run side by side: finalizeKeyFrame +
  * createKeyFrame is ~18 small dependent launches per sequence, S sequences changing keyframe take S times that on one stream.  Work
@@ -240,7 +240,8 @@ int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_frame** keyf
 /* Host-side pipelining: `fn(user)` is called on the calling thread by lsdhip_tracker_track once the job's launches are
  * queued and before the host waits for the result — the place to queue independent work on the same context (the next
  * image's upload and pyramids, what the reference's image-loader thread does ahead of the tracking thread,
- * C/LiveSLAMWrapper.cpp:82-118).  fn = NULL removes the hook.  The hook must not call into this tracker. */
+ * C/LiveSLAMWrapper.cpp:82-118).  fn = NULL removes the hook.  The hook must not call into this tracker.  lsdhip_tracker_track_batch
+ * calls it too, once the batch's first budget of launches is queued. */
 typedef void (*lsdhip_enqueue_hook)(void* user);
 int lsdhip_tracker_set_enqueue_hook(lsdhip_tracker* t, lsdhip_enqueue_hook fn, void* user);
 /* SE3Tracker::trackFrame(TrackingReference*, Frame*, const SE3& frameToReference_initialEstimate)

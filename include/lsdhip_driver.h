@@ -99,6 +99,11 @@ void* lsdloopbatch_ctx(lsdloopbatch* l);
 /* phase[s] in [0, kf_every): sequence s changes keyframe as if its current keyframe were already phase[s] frames old (sequences that
  * start together otherwise all change keyframe in the same step, which independent cameras do not).  Before the first run. */
 int lsdloopbatch_set_keyframe_phases(lsdloopbatch* l, const int* phase);
+/* on != 0: tracking beside mapping for all sequences (lsd_slam_hip::SlamLoopBatch::setPipelined; per sequence the schedule of
+ * lsdloop_set_pipeline: mapper one frame behind, frames tracked on a replaced keyframe dropped).  Before the first run.
+ * lsdloopbatch_dropped counts the dropped frames of a sequence. */
+int lsdloopbatch_set_pipeline(lsdloopbatch* l, int on);
+long long lsdloopbatch_dropped(lsdloopbatch* l, int sequence);   /* frames of a sequence tracked on a replaced keyframe (pipelined): not mapped */
 const char* lsdloop_last_error(void);
 /* ---- row-band decomposition of the regulariser (BASELINE.json configs[4]) ----------------------------
  * `world` bands over an H-row map; this process holds bands [first_band, first_band + n_local) as windows of

@@ -602,6 +602,7 @@ int lsd_pipe_dummy(lsdhip_ctx* c) {
 }
 long long lsd_m_record(lsdhip_ctx* c) {
   if (!c->pipeline) return 0;
+  if (c->lanes_open) { c->lane_record_pending = true; return c->mSeq + 1; }   // recorded once, where the lanes join (lsdhip_ctx_lanes_end)
   const long long s = c->mSeq + 1;
   if (hipEventRecord(c->mEv[s % LSD_EVR], c->mstream) != hipSuccess) { lsd_set_error("hipEventRecord on the mapping stream failed"); return LSDHIP_E_HIP; }
   c->mSeq = s;
@@ -720,8 +721,8 @@ extern "C" int lsdhip_ctx_copy_dev(lsdhip_ctx* c, void* dst, const void* src, si
 extern "C" int lsdhip_ctx_lanes_begin(lsdhip_ctx* c, int n) {
   if (!c || n < 1 || n > lsdhip_ctx::MAX_LANES) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
-  if (c->pipeline) { lsd_set_error("lsdhip_ctx_lanes_begin: one-stream contexts only"); return LSDHIP_E_STATE; }
   if (c->lanes_open) { lsd_set_error("lsdhip_ctx_lanes_begin: already open"); return LSDHIP_E_STATE; }
+  const hipStream_t base = c->pipeline ? c->mstream : c->stream;     // lanes branch off the stream the DepthMap calls run on
   HIPCHK(hipSetDevice(c->device));
   if (!c->lane_fork) HIPCHK(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
   for (int i = 0; i < n; i++) {
@@ -731,9 +732,10 @@ extern "C" int lsdhip_ctx_lanes_begin(lsdhip_ctx* c, int n) {
     }
     c->lane_used[i] = false;
   }
-  HIPCHK(hipEventRecord(c->lane_fork, c->stream));
+  HIPCHK(hipEventRecord(c->lane_fork, base));
   c->lanes_open = n;
   c->lane_cur = -1;
+  c->lane_record_pending = false;
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_ctx_lane_select(lsdhip_ctx* c, int lane) {
@@ -754,12 +756,16 @@ extern "C" int lsdhip_ctx_lanes_end(lsdhip_ctx* c) {
   if (!c->lanes_open) return LSDHIP_OK;
   HIPCHK(hipSetDevice(c->device));
   c->lane_cur = -1;
+  const hipStream_t base = c->pipeline ? c->mstream : c->stream;
   for (int i = 0; i < c->lanes_open; i++) {
     if (!c->lane_used[i]) continue;
     HIPCHK(hipEventRecord(c->lane_done[i], c->lanes[i]));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->lane_done[i], 0));
+    HIPCHK(hipStreamWaitEvent(base, c->lane_done[i], 0));
   }
   c->lanes_open = 0;
+  // pipelined contexts: the calls inside the region were all given the mapping-stream sequence number of THIS point (lsd_m_record), the
+  // first one at which the mapping stream is behind every lane
+  if (c->lane_record_pending) { c->lane_record_pending = false; if (lsd_m_record(c) < 0) return LSDHIP_E_HIP; }
   return LSDHIP_OK;
 }
 // ---- transport stream: exchange under compute (halo rows of the row-band loop travel while the interior rows are computed) -------

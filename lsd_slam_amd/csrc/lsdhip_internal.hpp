@@ -218,6 +218,7 @@ struct lsdhip_ctx {
   int lanes_open = 0;      // > 0 between lanes_begin and lanes_end: number of lanes
   int lane_cur = -1;       // lane the mapping calls currently go to (-1: the context's own stream)
   bool lane_used[MAX_LANES] = {};
+  bool lane_record_pending = false;   // pipelined: a DepthMap call inside the open region asked for a record point
   hipStream_t aux_stream = nullptr;
   unsigned* d_flagArrive = nullptr;      // arrival counter of k_flag_set's workgroups
   hipEvent_t aux_fork = nullptr, aux_done = nullptr;

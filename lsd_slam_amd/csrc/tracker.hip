@@ -1634,7 +1634,7 @@ static void batch_begin(lsdhip_tracker* t, int n) {
   if (n == 1) t->cap_override = 0;
 }
 // runs the n jobs described in t->h_bjobs[0..n) to completion; summaries in t->h_bsummary
-static int batch_run(lsdhip_tracker* t, int n) {
+static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
   t->cap_override = 0;
@@ -1685,6 +1685,8 @@ static int batch_run(lsdhip_tracker* t, int n) {
     }
     HIPCHK(hipGetLastError());
     if (c->prof_on) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
+    // the batch's launches are queued: the place for everything the device can do beside them (lsdhip_tracker_set_enqueue_hook)
+    if (callHook && guard == 0 && t->enqueueHook) t->enqueueHook(t->enqueueHookUser);
     HIPCHK(hipStreamSynchronize(c->stream));
     bool all = true;
     for (int j = 0; j < n; j++) all = all && t->h_bsummary[j].done;
@@ -1717,12 +1719,20 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
   if (!t || n <= 0 || !keyframes || !frames || !inits || !results) return LSDHIP_E_ARG;
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
-  LsdTrackJobScope tjob_(c, true);
-  if (tjob_.rc) return tjob_.rc;
   HIPCHK(hipSetDevice(c->device));
   for (int j = 0; j < n; j++) {
     if (!keyframes[j] || !frames[j]) return LSDHIP_E_ARG;
     if (!keyframes[j]->hasIDepth) { lsd_set_error("lsdhip_tracker_track_batch: keyframe %d has no depth", keyframes[j]->id); return LSDHIP_E_STATE; }
+  }
+  if (c->pipeline) {
+    // as lsdhip_tracker_track: the tracking stream waits for the mapping-stream points its inputs were complete at (the frames'
+    // pyramids, the keyframes' PUBLISHED depth) and for nothing queued behind them — the mapping iterations of OTHER sequences run
+    // beside this batch (SlamLoopBatch::setOverlapped).  batch_run leaves the tracking stream drained.
+    long long need = 0;
+    for (int j = 0; j < n; j++) {
+      need = std::max(need, std::max(frames[j]->readySeq, std::max(keyframes[j]->readySeq, keyframes[j]->depthSeq)));
+    }
+    if (int rcw = lsd_t_wait_m(c, need)) return rcw;
   }
   int rc = batch_reserve(t, n);
   if (rc) return rc;
@@ -1736,7 +1746,7 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
     job.T0 = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(inits + 7 * (size_t)j)));
     job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
   }
-  rc = batch_run(t, n);
+  rc = batch_run(t, n, true);
   if (rc) return rc;
   int rcAll = LSDHIP_OK;
   for (int j = 0; j < n; j++) {

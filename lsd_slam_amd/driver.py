@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop
                     "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_pipeline", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
                     "lsdloop_gather_keyframes", "lsdband_create", "lsdband_destroy", "lsdband_window_rows", "lsdband_layout", "lsdband_load",
                     "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_set_overlap", "lsdband_tile_runs", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result", "lsdloop_observe_work",
-                    "lsdloopbatch_create", "lsdloopbatch_destroy", "lsdloopbatch_run", "lsdloopbatch_get_stats", "lsdloopbatch_ctx", "lsdloopbatch_set_keyframe_phases"]
+                    "lsdloopbatch_create", "lsdloopbatch_destroy", "lsdloopbatch_run", "lsdloopbatch_get_stats", "lsdloopbatch_ctx", "lsdloopbatch_set_keyframe_phases", "lsdloopbatch_set_pipeline", "lsdloopbatch_dropped"]
 
 
 def lib():
@@ -100,6 +100,10 @@ def lib():
         L.lsdloopbatch_ctx.argtypes = [vp]
         L.lsdloopbatch_set_keyframe_phases.restype = i
         L.lsdloopbatch_set_keyframe_phases.argtypes = [vp, vp]
+        L.lsdloopbatch_set_pipeline.restype = i
+        L.lsdloopbatch_set_pipeline.argtypes = [vp, i]
+        L.lsdloopbatch_dropped.restype = C.c_longlong
+        L.lsdloopbatch_dropped.argtypes = [vp, i]
         L.lsdloop_last_error.restype = C.c_char_p
         L.lsdloop_last_error.argtypes = []
         _lib = L
@@ -154,6 +158,14 @@ class DriverLoopBatch:
 
     def ctx_handle(self):
         return C.c_void_p(self.L.lsdloopbatch_ctx(self.h_))
+
+    def set_pipeline(self, on=True):
+        """tracking beside mapping for all sequences, the mapper one frame behind (before the first run)"""
+        _check(self.L.lsdloopbatch_set_pipeline(self.h_, int(bool(on))))
+
+    def dropped(self):
+        """per sequence: frames tracked on a keyframe the mapper had already replaced (pipelined loops)"""
+        return [int(self.L.lsdloopbatch_dropped(self.h_, s)) for s in range(self.S)]
 
     def set_keyframe_phases(self, phases):
         """phase[s] in [0, kf_every): how old sequence s's first keyframe already is (unsynchronised keyframe changes)"""

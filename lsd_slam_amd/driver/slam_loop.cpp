@@ -151,19 +151,22 @@ extern "C" int lsdloopbatch_create(int device, int w, int h, const float K4[4], 
 extern "C" void lsdloopbatch_destroy(lsdloopbatch* l) {
   if (!l) return;
   if (l->ctx) (void)lsdhip_ctx_synchronize(l->ctx->handle());
+  std::shared_ptr<Context> ctx = l->ctx;
   delete l;
+  if (ctx) { try { ctx->setPipeline(false); } catch (...) {} }   // the context is shared by (w, h, K): leave it as a one-stream context
 }
 extern "C" int lsdloopbatch_run(lsdloopbatch* l, const uint8_t* const* images, int n, double* out7) {
   if (!l || !images || n < 0) return LSDHIP_E_ARG;
   try {
     const int S = l->loop->size();
     for (int t = 0; t < n; t++) {
-      std::vector<SE3> est = l->loop->step(images + (size_t)t * S);
+      std::vector<SE3> est = l->loop->step(images + (size_t)t * S, t + 1 < n ? images + (size_t)(t + 1) * S : nullptr);
       for (int s = 0; s < S; s++) {
         if (l->loop->sequence(s).newKeyframe) l->keyframes[s]++;
         if (out7) est[s].to7(out7 + 7 * ((size_t)t * S + s));
       }
     }
+    l->loop->flush();     // (a pipelined loop keeps the last step's mapping work back for the next tracking batch)
     return n;
   } catch (const Error& e) {
     g_err = e.what();
@@ -183,6 +186,20 @@ extern "C" int lsdloopbatch_get_stats(lsdloopbatch* l, long long* out) {
   return LSDHIP_OK;
 }
 extern "C" void* lsdloopbatch_ctx(lsdloopbatch* l) { return l ? (void*)l->ctx->handle() : nullptr; }
+extern "C" int lsdloopbatch_set_pipeline(lsdloopbatch* l, int on) {
+  if (!l) return LSDHIP_E_ARG;
+  try {
+    l->loop->setPipelined(on != 0);
+    return LSDHIP_OK;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.status < 0 ? e.status : LSDHIP_E_STATE;
+  }
+}
+extern "C" long long lsdloopbatch_dropped(lsdloopbatch* l, int s) {
+  if (!l || s < 0 || s >= l->loop->size()) return -1;
+  return l->loop->sequence(s).numDropped;
+}
 extern "C" int lsdloopbatch_set_keyframe_phases(lsdloopbatch* l, const int* phase) {
   if (!l || !phase) return LSDHIP_E_ARG;
   try {

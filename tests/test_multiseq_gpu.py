@@ -118,12 +118,13 @@ def test_depth_update_batch_rejects_what_the_single_call_rejects(hip):
         hip.DepthMap.updateKeyframeBatch([dm, dm], [fr, fr])  # the same map twice
 
 
-@pytest.mark.parametrize("S", [3, 9])
-def test_batch_loop_follows_the_single_sequence_loops(hip, S):
-    """lsd_slam_hip::SlamLoopBatch against S separate lsd_slam_hip::SlamLoop runs (blockUntilMapped) over the same images: same keyframes,
-    every frame tracked, the poses within the tolerance a different summation order of the tracker's batch form allows (S = 3: the
-    chain form with fewer, fatter workgroups per job; S = 9: throughput mode) — and a sequence replicated inside the batch comes out
-    bit-identical to its twin (same inputs through different slices of the same launches)."""
+@pytest.mark.parametrize("S,pipelined", [(3, False), (9, False), (3, True), (9, True)])
+def test_batch_loop_follows_the_single_sequence_loops(hip, S, pipelined):
+    """lsd_slam_hip::SlamLoopBatch against S separate lsd_slam_hip::SlamLoop runs over the same images, in both execution models
+    (blockUntilMapped; pipelined = tracking beside mapping, mapper one frame behind): same keyframes, same dropped frames, every frame
+    tracked, the poses within the tolerance a different summation order of the tracker's batch form allows (S = 3: the chain form with
+    fewer, fatter workgroups per job; S = 9: throughput mode) — and a sequence replicated inside the batch comes out bit-identical to
+    its twin (same inputs through different slices of the same launches)."""
     from lsd_slam_amd.driver import DriverLoop, DriverLoopBatch
     import oracle.pyoracle as po
     from common import pose_distance
@@ -134,18 +135,23 @@ def test_batch_loop_follows_the_single_sequence_loops(hip, S):
     single = []
     for s in range(2):
         drv = DriverLoop(w, h, K, imgs[s][0].ctypes.data, seqs[s][1], kf_every=10, images_on_device=False)
+        drv.set_pipeline(pipelined)
         done, poses = drv.run([imgs[s][t].ctypes.data for t in range(1, n + 1)], want_poses=True)
         st = drv.stats()
         drv.close()
-        assert done == n and int(st.tracked_good) == n and int(st.keyframes) == 2
+        assert done == n and int(st.tracked_good) == n and int(st.keyframes) == 2 and int(st.dropped) == (2 if pipelined else 0)
         single.append(np.asarray(poses))
     bl = DriverLoopBatch(w, h, K, [imgs[s][0].ctypes.data for s in range(S)], [seqs[s][1] for s in range(S)], kf_every=10, images_on_device=False)
+    bl.set_pipeline(pipelined)
     done, poses = bl.run([[imgs[s][t].ctypes.data for s in range(S)] for t in range(1, n + 1)], want_poses=True)
     st = bl.stats()
+    dropped = bl.dropped()
     bl.close()
     assert done == n
     for s in range(S):
-        assert st[s]["frames"] == n and st[s]["tracked_good"] == n and st[s]["keyframes"] == 2 and st[s]["updates"] == n - 2 and st[s]["lost"] == 0
+        nd = 2 if pipelined else 0
+        assert st[s]["frames"] == n and st[s]["tracked_good"] == n and st[s]["keyframes"] == 2 and st[s]["updates"] == n - 2 - nd and st[s]["lost"] == 0
+        assert dropped[s] == nd
         if s >= 2:
             assert np.array_equal(poses[:, s], poses[:, s - 2]), "sequence %d differs from its twin %d" % (s, s - 2)
         worst = max(max(pose_distance(poses[t, s], single[s % 2][t], po)) for t in range(n))
