@@ -525,6 +525,7 @@ extern "C" int lsdhip_ctx_pipeline(lsdhip_ctx* c) { return c ? (c->pipeline ? 1 
 extern "C" void* lsdhip_ctx_map_stream(lsdhip_ctx* c) { return c ? (void*)lsd_map_stream(c) : nullptr; }
 int lsd_sync_all(lsdhip_ctx* c) {
   if (c->pipeline && !c->pendingMerges.empty()) { if (int rc = lsd_flush_merges(c)) return rc; }
+  for (int i = 0; i < c->lanes_open; i++) if (c->lane_used[i]) HIPCHK(hipStreamSynchronize(c->lanes[i]));   // (inside an open lane region)
   if (c->mstream) {
     HIPCHK(hipStreamSynchronize(c->mstream));
     c->mDoneSeq = c->mSeq;
