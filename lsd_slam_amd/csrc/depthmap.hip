@@ -757,12 +757,13 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
                                                double* __restrict__ partials) {
   constexpr int HALO = FILL ? 4 : 2;
   constexpr int TW = 32 + 2 * HALO, TH = 8 + 2 * HALO, TN = TW * TH;
-  __shared__ uint8_t s_valid[TN];     // snapshot validity
-  __shared__ uint8_t s_validP[TN];    // validity after K5
+  // Per tile entry two words instead of four arrays: pk = validity_counter of a valid pixel (never negative), -1 for an invalid one
+  // (s_pk0: the snapshot K5 reads, s_pk: after K5, what K6 reads), and (idepth, idepth_var) as one 8-byte word — a neighbour costs K6
+  // two LDS reads instead of four, K5 one or two instead of two or three.
+  __shared__ int s_pk0[TN];
+  __shared__ int s_pk[TN];
   __shared__ uint8_t s_created[TN];
-  __shared__ int s_validity[TN];
-  __shared__ float s_id[TN];
-  __shared__ float s_var[TN];
+  __shared__ float2 s_iv[TN];
   __shared__ double s_sum[4];
   __shared__ int s_cnt[4];
   const int tid = threadIdx.x;
@@ -788,13 +789,11 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
       const int vc = a.m.validity[g];
       const float id = a.m.idepth[g];
       const float var = a.m.var[g];
-      const uint8_t vv = inb ? v : (uint8_t)0;
-      s_valid[e] = vv;
-      s_validP[e] = vv;
+      const int pk = (inb && v) ? vc : -1;
+      s_pk0[e] = pk;
+      s_pk[e] = pk;
       s_created[e] = 0;
-      s_validity[e] = vc;
-      s_id[e] = id;
-      s_var[e] = var;
+      s_iv[e] = make_float2(id, var);
     }
   }
   // K5's gradient test reads the keyframe's maxGradients at the pixels of its region: issued with the tile loads (one memory round
@@ -822,7 +821,7 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
         const int lx = 2 + f % FW, ly = 2 + f / FW;
         const int e = lx + ly * TW;
         const int x = x0 + lx, y = y0 + ly;
-        if (x >= 3 && x < w - 2 && y >= 3 && y < h - 2 && !s_valid[e]) {
+        if (x >= 3 && x < w - 2 && y >= 3 && y < h - 2 && s_pk0[e] < 0) {
           const int idx = x + y * w;
           if (!(mg[it] < a.minUseGrad)) {
             int val = 0;
@@ -831,7 +830,8 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
 #pragma unroll
               for (int dx = -2; dx <= 2; dx++) {
                 const int j = e + dx + dy * TW;
-                val += s_valid[j] ? s_validity[j] : 0;
+                const int pk0 = s_pk0[j];
+                val += pk0 > 0 ? pk0 : 0;
               }
             if (val > VAL_SUM_MIN_FOR_UNBLACKLIST || (val > VAL_SUM_MIN_FOR_CREATE && a.m.blacklisted[idx] >= MIN_BLACKLIST)) {
               float sumIdepthObs = 0, sumIVarObs = 0;
@@ -840,20 +840,19 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
 #pragma unroll
                 for (int dx = -2; dx <= 2; dx++) {
                   const int j = e + dx + dy * TW;
-                  if (s_valid[j]) {
-                    const float sv = s_var[j];
-                    sumIdepthObs += s_id[j] / sv;
+                  if (s_pk0[j] >= 0) {
+                    const float2 iv = s_iv[j];
+                    const float sv = iv.y;
+                    sumIdepthObs += iv.x / sv;
                     sumIVarObs += 1.0f / sv;
                   }
                 }
               float idepthObs = sumIdepthObs / sumIVarObs;
               idepthObs = unzero(idepthObs);
               s_created[e] = 1;
-              s_validP[e] = 1;
               // nobody reads these entries during K5 (their snapshot validity is 0)
-              s_validity[e] = 0;
-              s_id[e] = idepthObs;
-              s_var[e] = VAR_RANDOM_INIT_INITIAL;
+              s_pk[e] = 0;
+              s_iv[e] = make_float2(idepthObs, VAR_RANDOM_INIT_INITIAL);
             }
           }
         }
@@ -869,13 +868,14 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   const bool inImage = x < w && y < h;
   const int idx = inImage ? x + y * w : 0;
   const bool created = FILL && s_created[e] != 0;
-  const uint8_t wasValid = s_validP[e];
+  const uint8_t wasValid = s_pk[e] >= 0 ? 1 : 0;
   uint8_t nowValid = wasValid;
   bool smoothed = false, blacklistDec = false;
   float out_ids = 0.f, out_vars = 0.f;
   if (inImage && x >= 2 && x < w - 2 && y >= 2 && y < h - 2 && wasValid) {
-    const float c_id = s_id[e];
-    const float c_var = s_var[e];
+    const float2 c_iv = s_iv[e];
+    const float c_id = c_iv.x;
+    const float c_var = c_iv.y;
     float sum = 0, val_sum = 0, sumIvar = 0;
     int numOccluding = 0, numNotOccluding = 0;
 #pragma unroll
@@ -883,11 +883,11 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
 #pragma unroll
       for (int dy = -2; dy <= 2; dy++) {
         const int j = e + dx + dy * TW;
-        const bool nv = s_validP[j] != 0;
-        const float s_idj = s_id[j];
-        const float s_varj = s_var[j];
-        const int vcj = s_validity[j];
-        if (!nv) continue;
+        const int vcj = s_pk[j];
+        const float2 ivj = s_iv[j];
+        const float s_idj = ivj.x;
+        const float s_varj = ivj.y;
+        if (vcj < 0) continue;
         const float diff = s_idj - c_id;
         if (DIFF_FAC_SMOOTHING * diff * diff > s_varj + c_var) {
           if (OCC) { if (s_idj > c_id) numOccluding++; }
@@ -917,8 +917,8 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     if (created) {
       a.m.nextID[idx] = 0;
       a.m.validity[idx] = 0;
-      a.m.idepth[idx] = s_id[e];
-      a.m.var[idx] = s_var[e];
+      a.m.idepth[idx] = s_iv[e].x;
+      a.m.var[idx] = s_iv[e].y;
       a.m.blacklisted[idx] = blacklistDec ? -1 : 0;
       if (!smoothed) { a.m.idepth_s[idx] = -1; a.m.var_s[idx] = -1; }
     } else if (blacklistDec) {
