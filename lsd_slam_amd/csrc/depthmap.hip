@@ -101,6 +101,8 @@ struct ObserveArgs {
   unsigned long long* trace;   // developer build: per-stage timestamps of one traced pixel per workgroup
 #endif
   unsigned long long* counters;   // null, or (sampled launches while profiling) two words per wave: pixels that entered the search, walk steps
+  float4* queue;                  // batches, two-launch form: this map's search queue (pixel index bits, epx, epy, -) and its fill count
+  int* qcount;
   StereoRef one;   // nRefs == 1 (the blockUntilMapped case): the reference travels in the kernel arguments, no staging copy
 };
 
@@ -645,6 +647,80 @@ __global__ __launch_bounds__(32 * ROWS) void k_observe_batch(const ObserveArgs* 
   const int x = blockIdx.x * 32 + (threadIdx.x & 31);
   const int y = blockIdx.y * ROWS + (threadIdx.x >> 5);
   (void)observe_pixel<true>(a, x, y);
+}
+
+// The same for many maps in TWO launches (lsdhip_depth_update_batch from LSD_OBS_SPLIT_MIN_MAPS maps on).  In k_observe_batch a wave
+// that holds a single searching pixel walks the whole dependent chain of doLineStereo at 126 registers per lane with one lane busy, and
+// three waves in four hold one (2-7 % of the pixels search).  With enough maps in a launch to fill the chip that is what bounds it, not
+// the planes it reads.  So: k_observe_select_batch runs observe_front — the cheap rejections, a streaming pass at few registers — over
+// every pixel and appends the survivors of a 64x16 tile, compacted, to their map's queue (one atomic per tile); k_observe_walk_batch
+// runs observe_back over the queues with every lane busy: chunks of 64 consecutive entries (neighbouring tiles: shared lines), dealt to a
+// fixed number of one-wave workgroups.  A pixel's update reads and writes nothing but its own hypothesis and constant planes, so the
+// order of the queue does not matter: every plane is bit-identical to the one-launch form (tests/test_multiseq_gpu.py).
+// (For ONE map the split was measured in round 2 and lost — two latency-bound launches instead of one; it stays one launch there.)
+#define LSD_OBS_WALK_MAX_MAPS 256
+__global__ __launch_bounds__(1024) void k_observe_select_batch(const ObserveArgs* __restrict__ items) {
+  const ObserveArgs& a = items[blockIdx.z];
+  __shared__ int s_wcount[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int x = blockIdx.x * 64 + (tid & 63);
+  const int y = blockIdx.y * 16 + wave;
+  int refIdx = 0;
+  float epx = 0, epy = 0;
+  const bool hit = observe_front<true>(a, x, y, refIdx, epx, epy);
+  const unsigned long long bal = __ballot(hit);
+  const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+  if ((tid & 63) == 0) s_wcount[wave] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) tot += s_wcount[k];
+    s_base = tot > 0 ? atomicAdd(a.qcount, tot) : 0;
+  }
+  __syncthreads();
+  if (hit) {
+    int off = s_base + rank;
+#pragma unroll
+    for (int k = 0; k < 16; k++) off += k < wave ? s_wcount[k] : 0;
+    a.queue[off] = make_float4(__int_as_float(x + y * a.w), epx, epy, 0.f);
+  }
+}
+#ifdef LSD_WALK_OCC4
+#define LSD_WALK_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))     // A/B of round 5: 128 registers + 32 bytes of scratch per lane against 144 registers
+#else
+#define LSD_WALK_ATTR
+#endif
+__global__ __launch_bounds__(64) LSD_WALK_ATTR void k_observe_walk_batch(const ObserveArgs* __restrict__ items, const int* __restrict__ counts, int n) {
+  __shared__ int s_incl[LSD_OBS_WALK_MAX_MAPS];     // chunks of 64 entries of maps 0 .. m (inclusive)
+  __shared__ int s_cnt[LSD_OBS_WALK_MAX_MAPS];
+  const int lane = threadIdx.x;
+  int TC = 0;
+#pragma unroll
+  for (int c = 0; c < LSD_OBS_WALK_MAX_MAPS / 64; c++) {
+    const int m = c * 64 + lane;
+    const int cnt = m < n ? counts[m < n ? m : 0] : 0;
+    int v = (cnt + 63) >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off); if (lane >= off) v += u; }
+    s_incl[m] = TC + v;
+    s_cnt[m] = cnt;
+    TC += __builtin_amdgcn_readlane(v, 63);
+  }
+  __syncthreads();
+  for (int ck = (int)blockIdx.x; ck < TC; ck += (int)gridDim.x) {
+    int m = 0;
+#pragma unroll
+    for (int c = 0; c < LSD_OBS_WALK_MAX_MAPS / 64; c++) m += __popcll(__ballot(s_incl[c * 64 + lane] <= ck));
+    m = __builtin_amdgcn_readfirstlane(m);
+    const int e = ((ck - (m > 0 ? s_incl[m - 1] : 0)) << 6) + lane;
+    if (e < s_cnt[m]) {
+      const ObserveArgs& a = items[m];
+      const float4 q = a.queue[e];
+      [[clang::always_inline]] (void)observe_back<true>(a, __float_as_int(q.x), 0, q.y, q.z);   // (as a call the function is compiled without the kernel's register budget)
+    }
+  }
 }
 
 struct RegArgs {
@@ -1326,6 +1402,7 @@ extern "C" void lsdhip_depth_destroy(lsdhip_depthmap* dm) {
   if (dm->d_stage) (void)hipFree(dm->d_stage);
   if (dm->h_stage) (void)hipHostFree(dm->h_stage);
   if (dm->d_obsCounters) (void)hipFree(dm->d_obsCounters);
+  if (dm->d_obsQueue) (void)hipFree(dm->d_obsQueue);
   delete dm;
 }
 extern "C" int lsdhip_depth_is_valid(lsdhip_depthmap* dm) { return dm && dm->activeKeyFrame != nullptr; }
@@ -1501,6 +1578,8 @@ static void observe_args_common(lsdhip_depthmap* dm, ObserveArgs& a) {
   a.kfNumFramesTrackedOnThis = kf->numFramesTrackedOnThis;
   a.kfNumMappedOnThis = kf->numMappedOnThis;
   a.counters = nullptr;
+  a.queue = nullptr;
+  a.qcount = nullptr;
 }
 
 static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
@@ -1864,9 +1943,20 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
   const hipStream_t ms = lsd_map_stream(c);
   // ---- observe ---------------------------------------------------------------------------------------------------------------------
   const size_t obsBytes = (sizeof(ObserveArgs) * (size_t)n + 255) / 256 * 256;
-  std::vector<uint8_t> blob(obsBytes + sizeof(RegBatchItem) * (size_t)n);
-  ObserveArgs* oa = (ObserveArgs*)blob.data();
-  RegBatchItem* ra = (RegBatchItem*)(blob.data() + obsBytes);
+  const size_t regBytes = (sizeof(RegBatchItem) * (size_t)n + 255) / 256 * 256;
+  static const bool splitOff = getenv("LSDHIP_OBS_SPLIT") && getenv("LSDHIP_OBS_SPLIT")[0] == '0';   // A/B of round 5
+  const bool split = !splitOff && n >= LSD_OBS_SPLIT_MIN_MAPS && n <= LSD_OBS_WALK_MAX_MAPS;
+  if (split)
+    for (int j = 0; j < n; j++)
+      if (!maps[j]->d_obsQueue) HIPCHK(hipMalloc((void**)&maps[j]->d_obsQueue, (size_t)c->w * c->h * sizeof(float4)));
+  void* hostBlob = nullptr;
+  void* dev = nullptr;
+  int rc = lsd_args_begin(c, obsBytes + regBytes + sizeof(int) * (size_t)n, &hostBlob, &dev);
+  if (rc) return rc;
+  ObserveArgs* oa = (ObserveArgs*)hostBlob;
+  RegBatchItem* ra = (RegBatchItem*)((uint8_t*)hostBlob + obsBytes);
+  int* qcountHost = (int*)((uint8_t*)hostBlob + obsBytes + regBytes);       // the queues' fill counts start from the zeros copied here
+  int* qcountDev = (int*)((uint8_t*)dev + obsBytes + regBytes);
   int nSet = 0;
   for (int j = 0; j < n; j++) {
     lsdhip_depthmap* dm = maps[j];
@@ -1879,6 +1969,9 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
 #ifdef LSD_PHASE_TRACE
     a.trace = nullptr;
 #endif
+    a.queue = split ? dm->d_obsQueue : nullptr;
+    a.qcount = qcountDev + j;
+    qcountHost[j] = 0;
     dm->d_refs = nullptr;
     dm->d_refByID = nullptr;
     // the regulariser pass that follows: reads cur.valid, writes the spare plane (swapped below, as fill_regularize does)
@@ -1890,15 +1983,22 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
     r.partials = dm->d_red + 16;
     if (setDepth) nSet++;
   }
-  void* dev = nullptr;
-  int rc = lsd_args_push(c, blob.data(), blob.size(), ms, &dev);
+  rc = lsd_args_commit(c, ms);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_observe_batch<2>), dim3((c->w + 31) / 32, (c->h + 1) / 2, n), dim3(64), 0, ms, (const ObserveArgs*)dev);
+  if (split) {
+    static const int walkWaves = getenv("LSDHIP_OBS_WALK_WAVES") ? atoi(getenv("LSDHIP_OBS_WALK_WAVES")) : LSD_OBS_WALK_WAVES;   // developer sweep
+    hipLaunchKernelGGL(k_observe_select_batch, dim3((c->w + 63) / 64, (c->h + 15) / 16, n), dim3(1024), 0, ms, (const ObserveArgs*)dev);
+    hipLaunchKernelGGL(k_observe_walk_batch, dim3(walkWaves), dim3(64), 0, ms, (const ObserveArgs*)dev, (const int*)qcountDev, n);
+  } else {
+    hipLaunchKernelGGL((k_observe_batch<2>), dim3((c->w + 31) / 32, (c->h + 1) / 2, n), dim3(64), 0, ms, (const ObserveArgs*)dev);
+  }
   const RegBatchItem* dra = (const RegBatchItem*)((const uint8_t*)dev + obsBytes);
   const dim3 rgrid((c->w + 31) / 32, (c->h + 7) / 8, n);
   if (nSet > 0) hipLaunchKernelGGL((k_reg_fused_batch<true>), rgrid, dim3(256), 0, ms, dra);
   if (nSet < n) hipLaunchKernelGGL((k_reg_fused_batch<false>), rgrid, dim3(256), 0, ms, dra);
   HIPCHK(hipGetLastError());
+  rc = lsd_args_release(c, ms);
+  if (rc) return rc;
   for (int j = 0; j < n; j++) swap_valid(maps[j]);
   // ---- Frame::setDepth's second half for the keyframes that were due -------------------------------------------------------------------
   if (nSet > 0) {
@@ -2091,6 +2191,8 @@ extern "C" int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const 
   std::vector<float> nid(n), id(n), var(n), ids(n), vars(n);
   for (size_t i = 0; i < n; i++) {
     const lsdhip_hypothesis& h = in[i];
+    // (the fused regulariser packs "invalid" as a negative counter in its LDS tile; the reference never produces a negative one)
+    if (h.isValid && h.validity_counter < 0) { lsd_set_error("lsdhip_depth_upload: pixel %zu is valid with validity_counter %d < 0", i, h.validity_counter); return LSDHIP_E_ARG; }
     v[i] = h.isValid ? 1 : 0; bl[i] = h.blacklisted; nid[i] = h.nextStereoFrameMinID; vc[i] = h.validity_counter;
     id[i] = h.idepth; var[i] = h.idepth_var; ids[i] = h.idepth_smoothed; vars[i] = h.idepth_var_smoothed;
   }

@@ -611,7 +611,12 @@ long long lsd_m_record(lsdhip_ctx* c) {
 }
 int lsd_t_wait_m(lsdhip_ctx* c, long long seq) {
   if (!c->pipeline || seq <= c->tWaitedM || seq <= c->mDoneSeq) return LSDHIP_OK;
-  if (seq > c->mSeq) seq = c->mSeq;                 // (cannot happen: a sequence number is handed out by lsd_m_record)
+  if (seq > c->mSeq) {
+    // a sequence number beyond the last record point: handed out inside an open lane region (recorded where the lanes join) — there is
+    // no event to wait for yet
+    if (c->lanes_open) { lsd_set_error("tracking job depends on mapping work of an open lane region (call lsdhip_ctx_lanes_end first)"); return LSDHIP_E_STATE; }
+    seq = c->mSeq;
+  }
   // the ring slot holds the event of `seq` or, once the ring has wrapped, of a later point of the in-order stream: either orders us
   HIPCHK(hipStreamWaitEvent(c->stream, c->mEv[seq % LSD_EVR], 0));
   c->tWaitedM = seq;
@@ -733,6 +738,9 @@ extern "C" int lsdhip_ctx_lanes_begin(lsdhip_ctx* c, int n) {
     }
     c->lane_used[i] = false;
   }
+  // a lane waits for the fork point only: whatever the lanes' calls read must be queued before it — also the merges of speculative
+  // trials' refPixelWasGood planes that the tracking calls have noted but not queued yet (createKeyFrame reads the new keyframe's mask)
+  if (c->pipeline && !c->pendingMerges.empty()) { if (int rcf = lsd_flush_merges(c)) return rcf; }
   HIPCHK(hipEventRecord(c->lane_fork, base));
   c->lanes_open = n;
   c->lane_cur = -1;
@@ -925,7 +933,13 @@ int lsd_frame_resolve(lsdhip_frame* f) {
   if (c->pipeline) {
     // the slots are written on the mapping stream: done once the record point behind their DepthMap call has been passed
     landed = (f->pendRescale < 0 || lsd_m_done(c, c->slot_mseq[f->pendRescale])) && (f->pendStats < 0 || lsd_m_done(c, c->slot_mseq[f->pendStats]));
-    if (!landed) { HIPCHK(hipStreamSynchronize(c->mstream)); c->mDoneSeq = c->mSeq; }
+    if (!landed) {
+      // (inside an open lane region the slot's record point does not exist yet — it is recorded where the lanes join — and the kernels
+      // that write the slot were queued on a lane: drain the lanes in use as well)
+      for (int i = 0; i < c->lanes_open; i++) if (c->lane_used[i]) HIPCHK(hipStreamSynchronize(c->lanes[i]));
+      HIPCHK(hipStreamSynchronize(c->mstream));
+      c->mDoneSeq = c->mSeq;
+    }
   } else {
     landed = (f->pendRescale < 0 || c->doneEpoch > c->slot_epoch[f->pendRescale]) &&
              (f->pendStats < 0 || c->doneEpoch > c->slot_epoch[f->pendStats]);
@@ -1080,10 +1094,13 @@ int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, i
   return LSDHIP_OK;
 }
 
-int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out) {
+// Kernel-argument records of the batched launches: a ring of pinned slots with device twins.  A slot is handed out again only once the
+// event recorded behind its last use has completed: lsd_args_commit records it behind the copy, lsd_args_release — called after the
+// launches that read the device twin — moves it behind them (whatever stream they were queued on).
+int lsd_args_begin(lsdhip_ctx* c, size_t bytes, void** host_out, void** dev_out) {
   LSD_CTX_LOCK(c);
   lsdhip_ctx::ArgRing& r = c->args;
-  constexpr int NS = 8;
+  constexpr int NS = lsdhip_ctx::ArgRing::NS;
   if (bytes > r.slotBytes) {
     // grow: nothing may still read the old block
     HIPCHK(hipDeviceSynchronize());
@@ -1098,13 +1115,35 @@ int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, v
   }
   const int i = r.next;
   r.next = (r.next + 1) % NS;
-  if (r.used[i]) HIPCHK(hipEventSynchronize(r.ev[i]));   // (seven pushes ago: long finished)
-  memcpy(r.h + (size_t)i * r.slotBytes, src, bytes);
-  HIPCHK(hipMemcpyAsync(r.d + (size_t)i * r.slotBytes, r.h + (size_t)i * r.slotBytes, bytes, hipMemcpyHostToDevice, s));
-  HIPCHK(hipEventRecord(r.ev[i], s));
-  r.used[i] = true;
+  if (r.used[i]) HIPCHK(hipEventSynchronize(r.ev[i]));   // (NS - 1 uses ago: long finished)
+  r.cur = i;
+  r.curBytes = bytes;
+  *host_out = r.h + (size_t)i * r.slotBytes;
   *dev_out = r.d + (size_t)i * r.slotBytes;
   return LSDHIP_OK;
+}
+int lsd_args_commit(lsdhip_ctx* c, hipStream_t s) {
+  LSD_CTX_LOCK(c);
+  lsdhip_ctx::ArgRing& r = c->args;
+  const int i = r.cur;
+  HIPCHK(hipMemcpyAsync(r.d + (size_t)i * r.slotBytes, r.h + (size_t)i * r.slotBytes, r.curBytes, hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(r.ev[i], s));
+  r.used[i] = true;
+  return LSDHIP_OK;
+}
+int lsd_args_release(lsdhip_ctx* c, hipStream_t s) {
+  LSD_CTX_LOCK(c);
+  lsdhip_ctx::ArgRing& r = c->args;
+  if (r.cur < 0 || !r.used[r.cur]) return LSDHIP_OK;
+  HIPCHK(hipEventRecord(r.ev[r.cur], s));
+  return LSDHIP_OK;
+}
+int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out) {
+  LSD_CTX_LOCK(c);
+  void* h = nullptr;
+  if (int rc = lsd_args_begin(c, bytes, &h, dev_out)) return rc;
+  memcpy(h, src, bytes);
+  return lsd_args_commit(c, s);
 }
 
 int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double* const* redPartials, int redN, double* const* redOut) {
@@ -1127,6 +1166,8 @@ int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double*
   if (rc) return rc;
   hipLaunchKernelGGL(k_idepth_pyramid_batch, dim3(c->w / 16, c->h / 16 + 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
   HIPCHK(hipGetLastError());
+  rc = lsd_args_release(c, lsd_map_stream(c));
+  if (rc) return rc;
   for (int j = 0; j < n; j++) {
     if (c->pipeline) { fs[j]->depthPending = true; fs[j]->depthPendingSeq = c->mSeq + 1; }
     else fs[j]->hasIDepth = true;
@@ -1258,6 +1299,8 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
   const int n0 = c->w * c->h;
   hipLaunchKernelGGL(k_gradients_max_batch, dim3(nb + (n0 + 255) / 256, n), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + piBytes));
   if (hipGetLastError() != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: launch failed"); return fail(LSDHIP_E_HIP); }
+  rc = lsd_args_release(c, ms);
+  if (rc) return fail(rc);
   const long long seq = lsd_m_record(c);
   if (seq < 0) return fail(LSDHIP_E_HIP);
   for (int j = 0; j < n; j++) out[j]->readySeq = seq;

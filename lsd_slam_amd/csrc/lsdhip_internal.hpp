@@ -59,7 +59,8 @@ struct TrackLevel {
   int w, h;
   int nblocks;               // workgroups (tiles) that have work at this level
   int singlePass;            // nblocks * workgroup size >= points: every lane evaluates at most one point
-  int tilePx;                // > 0: batch throughput mode, one strip of tilePx pixels per workgroup (compacted in LDS)
+  int tilePx;                // > 0: batch throughput mode, strip form: one strip of tilePx pixels per workgroup (compacted in LDS)
+  int granPx;                // > 0: batch throughput mode, granule form: nblocks granules of granPx pixels, one wave each (k_track_eval_gran)
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
   float lambdaInitial, stepSizeMin, convergenceEps;
   int maxIts;
@@ -152,8 +153,12 @@ struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_SPEC_MID_PX 90112
 #define LSD_SPEC_CAP_WORKGROUPS 80          // workgroups per trial on speculating levels above LSD_SPEC_CAP_ABOVE_PX pixels
 #define LSD_SPEC_CAP_ABOVE_PX 24576
+#define LSD_OBS_SPLIT_MIN_MAPS 4             // lsdhip_depth_update_batch: select + walk launches from this many maps on
+#define LSD_OBS_WALK_WAVES 4096             // one-wave workgroups of the walk launch
 #define LSD_BATCH_THROUGHPUT_MIN_JOBS 8     // lsdhip_tracker_track_batch: throughput mode from this many jobs on
-#define LSD_BATCH_STRIP_WORKGROUPS 768      // strips x jobs of a throughput-mode evaluation launch (3 workgroups per CU)
+#define LSD_BATCH_STRIP_WORKGROUPS 768      // (strip form of rounds 2-4, kept for the A/B of this round: LSDHIP_BATCH_GRAN=0)
+#define LSD_BATCH_GRANULE_PX 1024           // pixels per granule of a throughput-mode evaluation launch (larger levels: the multiple of it that keeps a job's rows within the scratch)
+#define LSD_BATCH_EVAL_WAVES 4096          // one-wave workgroups of a throughput-mode evaluation launch (256 CUs x 4 SIMDs x 4)
 struct lsdhip_frame;
 
 // Host-side state of a context (arena free list, deferred-result slot ring and its owner tables, profiling events, the
@@ -237,8 +242,12 @@ struct lsdhip_ctx {
   size_t arena_keep = 16;                // arenas of destroyed frames kept for reuse (grows with the batch width of lsdhip_frame_create_batch)
   float* d_gtStage = nullptr;                        // w x h floats: staging of lsdhip_frame_set_depth_gt
   // kernel-argument arrays of the batched launches (several sequences per launch): pinned staging slots and their device twins,
-  // reused round-robin; a slot is rewritten only after the copy that last read it has completed (lsd_args_push)
-  struct ArgRing { uint8_t* h = nullptr; uint8_t* d = nullptr; size_t slotBytes = 0; int next = 0; hipEvent_t ev[8] = {}; bool used[8] = {}; } args;
+  // reused round-robin; a slot is rewritten only after the launches that read it have completed (lsd_args_push / lsd_args_release)
+  struct ArgRing {
+    static constexpr int NS = 32;
+    uint8_t* h = nullptr; uint8_t* d = nullptr; size_t slotBytes = 0; int next = 0; hipEvent_t ev[NS] = {}; bool used[NS] = {};
+    int cur = -1; size_t curBytes = 0;   // the slot being filled / last committed
+  } args;
   std::vector<struct lsdhip_depthmap*> depthmaps;   // alive on this context: a destroyed frame is unhooked from them
   size_t arena_bytes = 0;
 };
@@ -341,6 +350,8 @@ struct lsdhip_tracker {
   TrackState* d_bstate = nullptr;     // [capacity][2]
   float* d_bscratch = nullptr;        // TrackScratch arena x capacity (sums | topkey | topval, each [job][...])
   TrackSummary* h_bsummary = nullptr; // pinned, device-mapped
+  int* d_bsched = nullptr;            // [2][capacity] level of each job's published state (throughput mode; -1: finished)
+  unsigned* d_btickets = nullptr;     // [8] granule tickets of the evaluation launch (per XCD)
   float* d_pts = nullptr;         // permaref point upload
   int pts_capacity = 0;
 };
@@ -406,6 +417,7 @@ struct lsdhip_depthmap {
   unsigned long long* d_obsCounters = nullptr;   // per wave (searches, steps) of the last counted launch | d_obsAcc: totals (searches, steps, launches)
   unsigned long long* d_obsAcc = nullptr;
   int obsCounterWaves = 0;
+  float4* d_obsQueue = nullptr;                  // w x h entries: search queue of the two-launch observe of batches (created on first use)
   unsigned ev_tick[3] = {0, 0, 0};   // calls per kind: every 8th updateKeyframe / 2nd createKeyFrame, finalizeKeyFrame is timed
   float msUpdate = 0, msCreate = 0, msFinalize = 0, msObserve = 0, msRegularize = 0, msPropagate = 0, msFillHoles = 0,
         msSetDepth = 0;
@@ -446,8 +458,12 @@ struct LsdTrackJobScope {
   ~LsdTrackJobScope() { if (c->pipeline && drain) (void)hipStreamSynchronize(c->stream); }
 };
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream);
-// copies `bytes` of kernel-argument records to the device on `s` (stream-ordered) and returns the device address
+// copies `bytes` of kernel-argument records to the device on `s` (stream-ordered) and returns the device address; lsd_args_release after
+// the launches that read them (frame.hip).  begin / commit: the same in two steps, for records that hold their own device address
 int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out);
+int lsd_args_begin(lsdhip_ctx* c, size_t bytes, void** host_out, void** dev_out);
+int lsd_args_commit(lsdhip_ctx* c, hipStream_t s);
+int lsd_args_release(lsdhip_ctx* c, hipStream_t s);
 // Frame::setDepth's second half for n keyframes in one launch (lsdhip_depth_update_batch)
 int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** f, int n, const double* const* redPartials, int redN, double* const* redOut);
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);   // on lsd_map_stream, into lsd_depth_w

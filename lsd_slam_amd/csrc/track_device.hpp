@@ -632,6 +632,11 @@ struct TrackScratch {
   int max_rows;    // multiple of 4
   int cmax;        // trial slots per parity (reject-chain speculation): sums [2][cmax][RS_COLS][max_rows], topkey / topval likewise
   float* recs;     // [2][cmax][32]  increment / pose of the trials > 0 of a launch (null when cmax == 1)
+  // batches in throughput mode (TS_LM + k_track_eval_gran): the level each job's published state is at (-1: finished), one int per
+  // job and parity, and the granule tickets of the evaluation launch that follows (zeroed by the LM launch); null otherwise
+  int* sched;      // [2][schedJobs]
+  unsigned* tickets;
+  int schedJobs;
 #ifdef LSD_PHASE_TRACE
   unsigned long long* trace;   // [0] = launch counter, then 20 words per launch (developer build only, tools/phase_trace.py)
 #endif
