@@ -506,6 +506,17 @@ class DepthMap {
     check(lsdhip_depth_create_keyframe(h_, new_keyframe->handle(), nullptr), "lsdhip_depth_create_keyframe");
     timings();
   }
+  // finalizeKeyFrame() + createKeyFrame(newKeyframes[j]) of several sequences' maps (one context) in six shared launches
+  // (lsdhip_depth_change_keyframe_batch); one map: the same six launches instead of the two calls' fifteen
+  static void changeKeyframeBatch(const std::vector<DepthMap*>& maps, const std::vector<Frame*>& newKeyframes) {
+    if (maps.empty()) return;
+    std::vector<lsdhip_depthmap*> ms;
+    std::vector<lsdhip_frame*> fs;
+    for (DepthMap* m : maps) ms.push_back(m->h_);
+    for (Frame* f : newKeyframes) fs.push_back(f->handle());
+    check(lsdhip_depth_change_keyframe_batch((int)ms.size(), ms.data(), fs.data(), nullptr), "lsdhip_depth_change_keyframe_batch");
+  }
+  void changeKeyframe(Frame* new_keyframe) { changeKeyframeBatch({this}, {new_keyframe}); timings(); }
   // GPU time (ms, summed) and call counts of updateKeyframe [0] / createKeyFrame [1] / finalizeKeyFrame [2]; synchronises
   void gpuTimes(double ms[3], long long calls[3]) { check(lsdhip_depth_gpu_times(h_, ms, calls), "lsdhip_depth_gpu_times"); }
   void finalizeKeyFrame() { check(lsdhip_depth_finalize(h_), "lsdhip_depth_finalize"); timings(); }
@@ -697,11 +708,16 @@ class SlamLoop {
       createNewKeyFrame = keyframeScore(d0 * d0 + d1 * d1 + d2 * d2, tracker.pointUsage) > 0.2f * 0.7f;
     }
     if (createNewKeyFrame) {
-      map.finalizeKeyFrame();
       numKeyframesFinished_++;
       mappedOnKF_ = 0;
-      if (onKeyframeFinished) onKeyframeFinished(*keyframe, map);
-      map.createKeyFrame(frame.get());
+      if (onKeyframeFinished || !sharedKeyframeChange) {
+        // an output hook reads the finalised map (PLY, keyframe messages, the multi-GPU gather): the two calls, the hook between them
+        map.finalizeKeyFrame();
+        if (onKeyframeFinished) onKeyframeFinished(*keyframe, map);
+        map.createKeyFrame(frame.get());
+      } else {
+        map.changeKeyframe(frame.get());
+      }
       keyframe = frame;
       if (keepKeyframes) keyframeLog.push_back(frame);
       liveQueue_.clear();
@@ -735,6 +751,7 @@ class SlamLoop {
   double lastTrackEnd = 0;
   int liveQueueLength = 1;                           // frames handed to updateKeyframe per mapping iteration
   bool deferMapping = true;                          // pipelined loops: see flushDeferredMapping
+  bool sharedKeyframeChange = true;                  // finalizeKeyFrame + createKeyFrame as DepthMap::changeKeyframe (six launches); false: the two calls
   bool keepKeyframes = false;                        // keep every keyframe alive in keyframeLog (validation: rescale factors)
   std::vector<std::shared_ptr<Frame>> keyframeLog;
 
@@ -952,7 +969,9 @@ class SlamLoopBatch {
   // last step() before reading maps or statistics
   void flush() { MapWork w = std::move(deferred_); deferred_ = MapWork(); mapGroup(w); }
   SE3Tracker tracker;
-  int keyframeLanes = 8;      // streams the keyframe changes of one step are dealt to (1: all on the context's stream)
+  bool sharedKeyframeChange = true;   // the keyframe changes of a step in shared launches (DepthMap::changeKeyframeBatch); false: per-sequence
+                                      // finalizeKeyFrame + createKeyFrame call chains, dealt to keyframeLanes streams (rounds 2-4)
+  int keyframeLanes = 8;      // (per-sequence chains) streams the keyframe changes of one step are dealt to (1: all on the context's stream)
 
  private:
   struct MapWork {            // what a tracking batch leaves for the mapping side
@@ -1034,19 +1053,26 @@ class SlamLoopBatch {
     if (work.updMaps.empty() && work.kfChange.empty()) return;
     std::shared_ptr<Context> ctx = Context::get(w_, h_, K_);
     const int nkf = (int)work.kfChange.size();
-    const int lanes = keyframeLanes > 1 && nkf > 0 ? (keyframeLanes < nkf ? keyframeLanes : nkf) : 0;
+    const int lanes = !sharedKeyframeChange && keyframeLanes > 1 && nkf > 0 ? (keyframeLanes < nkf ? keyframeLanes : nkf) : 0;
     if (lanes) ctx->lanesBegin(lanes);
     std::vector<Frame*> updFrames;
     for (auto& f : work.updFrames) updFrames.push_back(f.get());
     DepthMap::updateKeyframeBatch(work.updMaps, updFrames);
+    if (sharedKeyframeChange && nkf > 0) {
+      // all keyframe changes of the step in six launches
+      std::vector<DepthMap*> kfMaps;
+      std::vector<Frame*> kfFrames;
+      for (int i = 0; i < nkf; i++) { kfMaps.push_back(&seqs_[work.kfChange[i].first]->map); kfFrames.push_back(work.kfChange[i].second.get()); }
+      DepthMap::changeKeyframeBatch(kfMaps, kfFrames);
+    }
     for (int i = 0; i < nkf; i++) {
       Sequence& q = *seqs_[work.kfChange[i].first];
       const std::shared_ptr<Frame>& frame = work.kfChange[i].second;
       if (lanes) ctx->laneSelect(i % lanes);
-      q.map.finalizeKeyFrame();
+      if (!sharedKeyframeChange) q.map.finalizeKeyFrame();
       q.numKeyframesFinished++;
       q.mappedOnKF = 0;
-      q.map.createKeyFrame(frame.get());
+      if (!sharedKeyframeChange) q.map.createKeyFrame(frame.get());
       q.keyframe = frame;
       q.sinceKF = 0;
       if (pipelined_) {

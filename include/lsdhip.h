@@ -253,7 +253,7 @@ int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame
 /* trackFrame for n independent (keyframe, frame) pairs in the same kernel launches (one job per blockIdx.y): the decisions and
  * per-point arithmetic of n lsdhip_tracker_track calls, sums in another order (fewer, fatter workgroups per job); n evaluations share
  * every launch.  From 8 jobs on the batch runs in throughput mode: a step = one LM launch (one workgroup per job) + one evaluation
- * launch whose strips x jobs fill the chip's 768 workgroup slots.  This is how several sequences share
+ * launch whose strips x jobs fill the chip's 1024 workgroup slots.  This is how several sequences share
  * one GPU (BASELINE configs[3] with fewer GPUs than sequences) and how batches of keyframe candidates are checked
  * (SURVEY.md §8(f) N2).  inits: n x 7 doubles, results: n records.  Returns LSDHIP_DIVERGED if any job diverged. */
 int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,
@@ -345,6 +345,13 @@ int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_frame** refs
 int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* new_keyframe, float* rescale_out);
 /* DepthMap::finalizeKeyFrame (DepthMap.cpp:1363-1395), incl. Frame::takeReActivationData */
 int lsdhip_depth_finalize(lsdhip_depthmap* dm);
+/* DepthMap::finalizeKeyFrame() followed by DepthMap::createKeyFrame(new_keyframes[j]) (DepthMap.cpp:1363-1395, :1222-1327, propagateDepth
+ * :475-653) for the depth maps of n sequences (one context; n = 1: one sequence) in six launches shared by all of them (blockIdx.z =
+ * map): [finalize pass + Frame::setDepth + takeReActivationData + propagation candidates] -> [propagation merge] -> regularizeDepthMap(true)
+ * -> [fill holes + regularizeDepthMap(false) + rescale sums] -> [rescale + Frame::setDepth] -> both keyframes' idepth pyramids.  Planes,
+ * re-activation data, pyramids and deferred results as lsdhip_depth_finalize + lsdhip_depth_create_keyframe leave them.
+ * rescale_out: NULL or n floats (asking for them waits for the device). */
+int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps, lsdhip_frame** new_keyframes, float* rescale_out);
 /* currentDepthMap <-> host in the reference's 32-byte AoS layout (debug / parity / drop-in users that read it) */
 int lsdhip_depth_download(lsdhip_depthmap* dm, lsdhip_hypothesis* out_host);
 int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const lsdhip_hypothesis* in_host, int reactivated);

@@ -164,6 +164,7 @@ def _signatures():
         "lsdhip_depth_observe_work": (i, [vp, vp]),
         "lsdhip_depth_update_batch": (i, [i, pvp, pvp]),
         "lsdhip_depth_create_keyframe": (i, [vp, vp, C.POINTER(C.c_float)]),
+        "lsdhip_depth_change_keyframe_batch": (i, [i, pvp, pvp, C.POINTER(C.c_float)]),
         "lsdhip_depth_finalize": (i, [vp]),
         "lsdhip_depth_download": (i, [vp, vp]),
         "lsdhip_depth_upload": (i, [vp, vp, vp, i]),

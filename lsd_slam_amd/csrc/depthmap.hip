@@ -649,6 +649,65 @@ __global__ __launch_bounds__(32 * ROWS) void k_observe_batch(const ObserveArgs* 
   (void)observe_pixel<true>(a, x, y);
 }
 
+// ---- K7: propagateDepth (DepthMap.cpp:475-653) ---------------------------------------------------------------------
+struct PropArgs {
+  HypPlanes src;   // currentDepthMap (old keyframe)
+  HypPlanes dst;   // otherDepthMap (new keyframe)
+  const float* oldKFImage;
+  const float* newKFImage;
+  const float* newKFMaxGrad;
+  const uint8_t* trackingWasGood;  // level-1 mask of the new keyframe or nullptr
+  float4* cand;
+  int* slotCount;
+  int* slots;
+  int* flags;      // [0] error (chain storage exhausted), [1] chain entries handed out
+  int* ovfHead;    // per target: newest chain entry or -1
+  int2* ovf;       // (source index, next entry)
+  int ovfCap;
+  int w, h;
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+  float R[9], t[3];
+  float minUseGrad;
+};
+// phase A for one valid source hypothesis (its smoothed inverse depth, variance and validity counter): target pixel and candidate,
+// registered in the target's slot list.  The slot lists, chain heads and flags are clean at rest: k_prop_resolve leaves slotCount = 0 /
+// ovfHead = -1 behind, the kernel that reads the flags zeroes them.
+__device__ __forceinline__ void prop_candidate(const PropArgs& a, const int x, const int y, const int idx, const float ids, const float srcVar,
+                                               const int srcValidity) {
+  float r0 = x * a.fxi + a.cxi, r1 = y * a.fyi + a.cyi, r2 = 1.0f;
+  float Rr0 = (a.R[0] * r0 + a.R[1] * r1) + a.R[2] * r2;
+  float Rr1 = (a.R[3] * r0 + a.R[4] * r1) + a.R[5] * r2;
+  float Rr2 = (a.R[6] * r0 + a.R[7] * r1) + a.R[8] * r2;
+  float pn0 = Rr0 / ids + a.t[0], pn1 = Rr1 / ids + a.t[1], pn2 = Rr2 / ids + a.t[2];
+  float new_idepth = 1.0f / pn2;
+  float u_new = pn0 * new_idepth * a.fx + a.cx;
+  float v_new = pn1 * new_idepth * a.fy + a.cy;
+  if (!(u_new > 2.1f && v_new > 2.1f && u_new < a.w - 3.1f && v_new < a.h - 3.1f)) return;
+  int newIDX = (int)(u_new + 0.5f) + ((int)(v_new + 0.5f)) * a.w;
+  float destAbsGrad = a.newKFMaxGrad[newIDX];
+  if (a.trackingWasGood != nullptr) {
+    if (!a.trackingWasGood[(x >> 1) + (a.w >> 1) * (y >> 1)] || destAbsGrad < a.minUseGrad) return;
+  } else {
+    float sourceColor = a.oldKFImage[idx];
+    float destColor = interp1(a.newKFImage, u_new, v_new, a.w);
+    float residual = destColor - sourceColor;
+    if (residual * residual / (MAX_DIFF_CONSTANT + MAX_DIFF_GRAD_MULT * destAbsGrad * destAbsGrad) > 1.0f || destAbsGrad < a.minUseGrad) return;
+  }
+  float idepth_ratio_4 = new_idepth / ids;
+  idepth_ratio_4 *= idepth_ratio_4;
+  idepth_ratio_4 *= idepth_ratio_4;
+  float new_var = idepth_ratio_4 * srcVar;
+  a.cand[idx] = make_float4(new_idepth, new_var, __int_as_float(srcValidity), 0.f);
+  int pos = atomicAdd(&a.slotCount[newIDX], 1);
+  if (pos < PROP_SLOT_CAP) a.slots[(size_t)newIDX * PROP_SLOT_CAP + pos] = idx;
+  else {
+    // more sources than slots for this target (zoom-out / backward motion): the rest go on a per-target chain
+    const int o = atomicAdd(&a.flags[1], 1);
+    if (o < a.ovfCap) a.ovf[o] = make_int2(idx, atomicExch(&a.ovfHead[newIDX], o));
+    else atomicExch(&a.flags[0], 1);
+  }
+}
+
 // The same for many maps in TWO launches (lsdhip_depth_update_batch from LSD_OBS_SPLIT_MIN_MAPS maps on).  In k_observe_batch a wave
 // that holds a single searching pixel walks the whole dependent chain of doLineStereo at 126 registers per lane with one lane busy, and
 // three waves in four hold one (2-7 % of the pixels search).  With enough maps in a launch to fill the chip that is what bounds it, not
@@ -828,9 +887,19 @@ __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
 // them) and only the owner writes them to HBM.  Every neighbour access is an LDS read issued in a fully unrolled batch;
 // the per-pixel arithmetic and its order are those of k_fill_holes / k_regularize above (and of the reference).
 //   id0 / var0 / partials: outputs of K8 (SET only): level-0 idepth planes of the keyframe and per-workgroup (sum, count).
-template <bool FILL, bool OCC, bool SET>
+// KF (keyframe change, lsdhip_depth_change_keyframe_batch): the pass is finalizeKeyFrame's, and the owner of a pixel goes on with what
+//   the reference does next with that pixel's finalised hypothesis — Frame::takeReActivationData (kx->react*) and phase A of
+//   propagateDepth into the new keyframe (prop_candidate on kx->prop) — while the values are in its registers.
+// SUMV: per-workgroup (sum of idepth_smoothed, count) over the valid pixels after the pass -> partials (createKeyFrame's rescale sums).
+struct KfExtra {
+  float* reactId;        // old keyframe's re-activation planes
+  float* reactVar;
+  uint8_t* reactVal;
+  PropArgs prop;         // (src unused)
+};
+template <bool FILL, bool OCC, bool SET, bool KF = false, bool SUMV = false>
 __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restrict__ id0, float* __restrict__ var0,
-                                               double* __restrict__ partials) {
+                                               double* __restrict__ partials, const KfExtra* __restrict__ kx = nullptr) {
   constexpr int HALO = FILL ? 4 : 2;
   constexpr int TW = 32 + 2 * HALO, TH = 8 + 2 * HALO, TN = TW * TH;
   // Per tile entry two words instead of four arrays: pk = validity_counter of a valid pixel (never negative), -1 for an invalid one
@@ -988,6 +1057,8 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
       smoothed = true;
     }
   }
+  int blFinal = 0;           // the pixel's blacklisted counter after the pass, where this lane came to know it
+  bool blKnown = false;
   if (inImage) {
     a.validOut[idx] = nowValid;
     if (created) {
@@ -996,11 +1067,51 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
       a.m.idepth[idx] = s_iv[e].x;
       a.m.var[idx] = s_iv[e].y;
       a.m.blacklisted[idx] = blacklistDec ? -1 : 0;
+      blFinal = blacklistDec ? -1 : 0; blKnown = true;
       if (!smoothed) { a.m.idepth_s[idx] = -1; a.m.var_s[idx] = -1; }
     } else if (blacklistDec) {
-      a.m.blacklisted[idx] = a.m.blacklisted[idx] - 1;
+      const int b0 = a.m.blacklisted[idx];
+      a.m.blacklisted[idx] = b0 - 1;
+      blFinal = b0 - 1; blKnown = true;
     }
     if (smoothed) { a.m.idepth_s[idx] = out_ids; a.m.var_s[idx] = out_vars; }
+  }
+  // the pixel's smoothed pair after the pass (SET / SUMV / KF)
+  float ids = -1.f, vars = -1.f;
+  if ((SET || SUMV || KF) && inImage) {
+    if (smoothed) { ids = out_ids; vars = out_vars; }
+    else if (created || !nowValid) { ids = -1.f; vars = -1.f; }    // (not valid: the value is not looked at)
+    else { ids = a.m.idepth_s[idx]; vars = a.m.var_s[idx]; }      // valid, not smoothed: the 2-pixel border only
+  }
+  if (KF && inImage) {
+    // Frame::takeReActivationData (Frame.cpp:107-145) of the keyframe being finalised, then this hypothesis' step into the new keyframe
+    if (nowValid) {
+      kx->reactId[idx] = s_iv[e].x;
+      kx->reactVar[idx] = s_iv[e].y;
+      kx->reactVal[idx] = (uint8_t)s_pk[e];
+      prop_candidate(kx->prop, x, y, idx, ids, s_iv[e].y, s_pk[e]);
+    } else {
+      const int bl = blKnown ? blFinal : a.m.blacklisted[idx];
+      kx->reactVar[idx] = bl < MIN_BLACKLIST ? -2.f : -1.f;
+    }
+  }
+  if (SUMV) {
+    // createKeyFrame's rescale sums (DepthMap.cpp:1286-1294): idepth_smoothed over the valid pixels
+    double s = 0;
+    int c = 0;
+    if (inImage && nowValid) { s = ids; c = 1; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off);
+      c += __shfl_xor(c, off);
+    }
+    if ((tid & 63) == 0) { s_sum[tid >> 6] = s; s_cnt[tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) {
+      const int b = tIdx;
+      partials[2 * b] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+      partials[2 * b + 1] = (double)(((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3]);
+    }
   }
 
   if (SET) {
@@ -1008,10 +1119,6 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     double s = 0;
     int c = 0;
     if (inImage) {
-      float ids, vars;
-      if (smoothed) { ids = out_ids; vars = out_vars; }
-      else if (created || !nowValid) { ids = -1.f; vars = -1.f; }    // (not valid: the value is not looked at)
-      else { ids = a.m.idepth_s[idx]; vars = a.m.var_s[idx]; }      // valid, not smoothed: the 2-pixel border only
       if (nowValid && (double)ids >= -0.05) {
         id0[idx] = ids;
         var0[idx] = vars;
@@ -1060,6 +1167,101 @@ __global__ __launch_bounds__(256) void k_reg_fused_batch(const RegBatchItem* __r
     if (it.id0 != nullptr) return;
     reg_fused_tile<true, false, false>(it.a, nullptr, nullptr, nullptr);
   }
+}
+
+// ---- keyframe change of n maps in shared launches (lsdhip_depth_change_keyframe_batch), blockIdx.z = map -------------------------------
+//   k_kf_finalize_prop     finalizeKeyFrame's pass (fill holes + regularise + Frame::setDepth of the old keyframe) + takeReActivationData
+//                          + phase A of propagateDepth, per owner pixel
+//   k_prop_resolve_batch   phase B into the new map
+//   k_kf_reg<false, true>  regularizeDepthMap(true, ...)        (createKeyFrame, DepthMap.cpp:1271)
+//   k_kf_reg<true, false>  fill holes + regularizeDepthMap(false, ...) + the rescale sums per tile   (:1278-1294)
+//   k_kf_rescale_setdepth  mean inverse depth to one (:1296-1304) + Frame::setDepth of the new keyframe
+//   k_idepth_pyramid_batch both keyframes' pyramids and their (sum, count) records
+struct KfItem {
+  RegArgs a;
+  float* id0;
+  float* var0;
+  double* partials;
+  KfExtra x;
+};
+__global__ __launch_bounds__(256) void k_kf_finalize_prop(const KfItem* __restrict__ items) {
+  const KfItem& it = items[blockIdx.z];
+  reg_fused_tile<true, false, true, true, false>(it.a, it.id0, it.var0, it.partials, &it.x);
+}
+template <bool FILL, bool OCC>
+__global__ __launch_bounds__(256) void k_kf_reg(const RegBatchItem* __restrict__ items) {
+  const RegBatchItem& it = items[blockIdx.z];
+  reg_fused_tile<FILL, OCC, false, false, FILL>(it.a, nullptr, nullptr, it.partials, nullptr);   // (the rescale sums ride on the second pass)
+}
+struct RescaleItem {
+  HypPlanes m;
+  const double* sumPartials;   // per-tile (sum, count) of the pass before
+  int nSumPartials;
+  int* flags;                  // propagation flags: [0] -> slot, then both zeroed
+  double* slot;                // pinned DeferredSlot of the rescale factor: (sum, count, flag)
+  float* id0;                  // new keyframe's level-0 planes
+  float* var0;
+  double* statPartials;        // (sum, count) per workgroup of this launch
+  int n;
+};
+#define LSD_RESCALE_PX 2048    // pixels per workgroup of k_kf_rescale_setdepth
+__global__ __launch_bounds__(256) void k_kf_rescale_setdepth(const RescaleItem* __restrict__ items) {
+  const RescaleItem& it = items[blockIdx.y];
+  __shared__ double s_a[256], s_b[256];
+  const int tid = threadIdx.x;
+  // every workgroup adds the tiles' partials in the same fixed order: the same factor everywhere, no second launch, no atomics
+  double sa = 0, sb = 0;
+  for (int i = tid; i < it.nSumPartials; i += 256) { sa += it.sumPartials[2 * i]; sb += it.sumPartials[2 * i + 1]; }
+  s_a[tid] = sa; s_b[tid] = sb;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { s_a[tid] += s_a[tid + off]; s_b[tid] += s_b[tid + off]; }
+    __syncthreads();
+  }
+  const double sumD = s_a[0], cntD = s_b[0];
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) {
+    it.slot[0] = sumD; it.slot[1] = cntD; it.slot[2] = (double)it.flags[0];
+    it.flags[0] = 0; it.flags[1] = 0;
+  }
+  // rescaleFactor = numIdepth / sumIdepth with both cast to float first (DepthMap.cpp:1286-1294)
+  const float rescaleFactor = (float)cntD / (float)sumD;
+  const float rescaleFactor2 = rescaleFactor * rescaleFactor;
+  double s = 0;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < LSD_RESCALE_PX / 256; k++) {
+    const int i = blockIdx.x * LSD_RESCALE_PX + k * 256 + tid;
+    if (i < it.n) {
+      float ids = -1.f, vars = -1.f;
+      const bool valid = it.m.valid[i] != 0;
+      if (valid) {
+        it.m.idepth[i] *= rescaleFactor;
+        ids = it.m.idepth_s[i] * rescaleFactor;
+        it.m.idepth_s[i] = ids;
+        it.m.var[i] *= rescaleFactor2;
+        vars = it.m.var_s[i] * rescaleFactor2;
+        it.m.var_s[i] = vars;
+      }
+      // Frame::setDepth (Frame.cpp:199-243)
+      if (valid && (double)ids >= -0.05) {
+        it.id0[i] = ids;
+        it.var0[i] = vars;
+        s += ids;
+        c += 1;
+      } else {
+        it.id0[i] = -1.f;
+        it.var0[i] = -1.f;
+      }
+    }
+  }
+  s_a[tid] = s; s_b[tid] = (double)c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { s_a[tid] += s_a[tid + off]; s_b[tid] += s_b[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) { it.statPartials[2 * blockIdx.x] = s_a[0]; it.statPartials[2 * blockIdx.x + 1] = s_b[0]; }
 }
 
 // K8: Frame::setDepth (Frame.cpp:199-243) + per-workgroup (sum, count) partials for meanIdepth / numPoints
@@ -1139,26 +1341,6 @@ __global__ __launch_bounds__(256) void k_rescale(HypPlanes m, int n, const doubl
   m.var_s[i] *= rescaleFactor2;
 }
 
-// ---- K7: propagateDepth (DepthMap.cpp:475-653) ---------------------------------------------------------------------
-struct PropArgs {
-  HypPlanes src;   // currentDepthMap (old keyframe)
-  HypPlanes dst;   // otherDepthMap (new keyframe)
-  const float* oldKFImage;
-  const float* newKFImage;
-  const float* newKFMaxGrad;
-  const uint8_t* trackingWasGood;  // level-1 mask of the new keyframe or nullptr
-  float4* cand;
-  int* slotCount;
-  int* slots;
-  int* flags;      // [0] error (chain storage exhausted), [1] chain entries handed out
-  int* ovfHead;    // per target: newest chain entry or -1
-  int2* ovf;       // (source index, next entry)
-  int ovfCap;
-  int w, h;
-  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
-  float R[9], t[3];
-  float minUseGrad;
-};
 // phase A: every valid source hypothesis computes its target pixel and candidate, and registers in the target's slot list
 __global__ __launch_bounds__(256) void k_prop_candidates(PropArgs a) {
   const int x = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -1166,39 +1348,7 @@ __global__ __launch_bounds__(256) void k_prop_candidates(PropArgs a) {
   if (x >= a.w || y >= a.h) return;
   const int idx = x + y * a.w;
   if (!a.src.valid[idx]) return;
-  const float ids = a.src.idepth_s[idx];
-  float r0 = x * a.fxi + a.cxi, r1 = y * a.fyi + a.cyi, r2 = 1.0f;
-  float Rr0 = (a.R[0] * r0 + a.R[1] * r1) + a.R[2] * r2;
-  float Rr1 = (a.R[3] * r0 + a.R[4] * r1) + a.R[5] * r2;
-  float Rr2 = (a.R[6] * r0 + a.R[7] * r1) + a.R[8] * r2;
-  float pn0 = Rr0 / ids + a.t[0], pn1 = Rr1 / ids + a.t[1], pn2 = Rr2 / ids + a.t[2];
-  float new_idepth = 1.0f / pn2;
-  float u_new = pn0 * new_idepth * a.fx + a.cx;
-  float v_new = pn1 * new_idepth * a.fy + a.cy;
-  if (!(u_new > 2.1f && v_new > 2.1f && u_new < a.w - 3.1f && v_new < a.h - 3.1f)) return;
-  int newIDX = (int)(u_new + 0.5f) + ((int)(v_new + 0.5f)) * a.w;
-  float destAbsGrad = a.newKFMaxGrad[newIDX];
-  if (a.trackingWasGood != nullptr) {
-    if (!a.trackingWasGood[(x >> 1) + (a.w >> 1) * (y >> 1)] || destAbsGrad < a.minUseGrad) return;
-  } else {
-    float sourceColor = a.oldKFImage[idx];
-    float destColor = interp1(a.newKFImage, u_new, v_new, a.w);
-    float residual = destColor - sourceColor;
-    if (residual * residual / (MAX_DIFF_CONSTANT + MAX_DIFF_GRAD_MULT * destAbsGrad * destAbsGrad) > 1.0f || destAbsGrad < a.minUseGrad) return;
-  }
-  float idepth_ratio_4 = new_idepth / ids;
-  idepth_ratio_4 *= idepth_ratio_4;
-  idepth_ratio_4 *= idepth_ratio_4;
-  float new_var = idepth_ratio_4 * a.src.var[idx];
-  a.cand[idx] = make_float4(new_idepth, new_var, __int_as_float(a.src.validity[idx]), 0.f);
-  int pos = atomicAdd(&a.slotCount[newIDX], 1);
-  if (pos < PROP_SLOT_CAP) a.slots[(size_t)newIDX * PROP_SLOT_CAP + pos] = idx;
-  else {
-    // more sources than slots for this target (zoom-out / backward motion): the rest go on a per-target chain
-    const int o = atomicAdd(&a.flags[1], 1);
-    if (o < a.ovfCap) a.ovf[o] = make_int2(idx, atomicExch(&a.ovfHead[newIDX], o));
-    else atomicExch(&a.flags[0], 1);
-  }
+  prop_candidate(a, x, y, idx, a.src.idepth_s[idx], a.src.var[idx], a.src.validity[idx]);
 }
 // one step of the reference's per-target merge (DepthMap.cpp:587-640), sources replayed in the order its double loop visits them
 __device__ __forceinline__ void prop_merge(const float4 c, bool& tValid, float& t_idepth, float& t_var, int& t_validity) {
@@ -1225,10 +1375,9 @@ __device__ __forceinline__ void prop_merge(const float4 c, bool& tValid, float& 
   }
 }
 // phase B: per target, replay its candidates in source order (row-major, as the reference's double loop visits them)
-__global__ __launch_bounds__(256) void k_prop_resolve(PropArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.w * a.h) return;
-  int n = a.slotCount[i];
+__device__ __forceinline__ void prop_resolve_pixel(const PropArgs& a, const int i) {
+  const int cnt = a.slotCount[i];
+  int n = cnt;
   if (n > PROP_SLOT_CAP) n = PROP_SLOT_CAP;
   int srcs[PROP_SLOT_CAP];
   for (int k = 0; k < PROP_SLOT_CAP; k++) srcs[k] = (k < n) ? a.slots[(size_t)i * PROP_SLOT_CAP + k] : 0x7fffffff;
@@ -1241,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_prop_resolve(PropArgs a) {
   bool tValid = false;
   float t_idepth = 0, t_var = 0;
   int t_validity = 0;
-  if (a.slotCount[i] <= PROP_SLOT_CAP) {
+  if (cnt <= PROP_SLOT_CAP) {
     for (int k = 0; k < n; k++) prop_merge(a.cand[srcs[k]], tValid, t_idepth, t_var, t_validity);
   } else {
     // rare: slots + chain, replayed in ascending source order by repeated selection (no per-thread list needed)
@@ -1269,6 +1418,20 @@ __global__ __launch_bounds__(256) void k_prop_resolve(PropArgs a) {
     a.dst.idepth_s[i] = -1;
     a.dst.var_s[i] = -1;
   }
+  // clean at rest: the next propagation into this scratch starts without clears
+  if (cnt != 0) a.slotCount[i] = 0;
+  if (cnt > PROP_SLOT_CAP) a.ovfHead[i] = -1;      // (a chain exists only where the slots overflowed)
+}
+__global__ __launch_bounds__(256) void k_prop_resolve(PropArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  prop_resolve_pixel(a, i);
+}
+__global__ __launch_bounds__(256) void k_prop_resolve_batch(const KfItem* __restrict__ items) {
+  const PropArgs& a = items[blockIdx.y].x.prop;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  prop_resolve_pixel(a, i);
 }
 
 // ---- initialisation / re-activation kernels ------------------------------------------------------------------------
@@ -1346,7 +1509,14 @@ static int depth_create_impl(lsdhip_ctx* c, lsdhip_depthmap* dm) {
   HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, lsd_map_stream(c)));
   int nb = (int)((n + 255) / 256);
   const int ntiles = ((c->w + 31) / 32) * ((c->h + 7) / 8);   // partials of the fused regulariser: one pair per 32x8 tile
-  HIPCHK(hipMalloc((void**)&dm->d_red, (size_t)(2 * (nb > ntiles ? nb : ntiles) + 16) * sizeof(double)));
+  // (sum, count) partials: [16, ...) the setDepth / rescale passes of the single calls; the keyframe change in shared launches keeps
+  // three sets alive at once (old keyframe's setDepth | rescale sums | new keyframe's setDepth)
+  dm->redStride = (size_t)2 * (nb > ntiles ? nb : ntiles);
+  HIPCHK(hipMalloc((void**)&dm->d_red, (3 * dm->redStride + 16) * sizeof(double)));
+  // K7 scratch is clean at rest (k_prop_resolve / the reader of the flags leave it so)
+  HIPCHK(hipMemsetAsync(dm->d_slotCount, 0, n * 4, lsd_map_stream(c)));
+  HIPCHK(hipMemsetAsync(dm->d_ovfHead, 0xFF, n * 4, lsd_map_stream(c)));
+  dm->propClean = true;
   HIPCHK(hipHostMalloc((void**)&dm->h_red, 16 * sizeof(double), hipHostMallocMapped));
   return LSDHIP_OK;
 }
@@ -1687,12 +1857,11 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
   return LSDHIP_OK;
 }
 
-static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNow) {
+// propagateDepth's arguments for the map's current keyframe -> nk (source = currentDepthMap, target = otherDepthMap)
+static void prop_args(lsdhip_depthmap* dm, lsdhip_frame* nk, PropArgs& a) {
   lsdhip_ctx* c = dm->ctx;
-  LSD_CTX_LOCK(c);
   lsdhip_frame* old = dm->activeKeyFrame;
   size_t n = (size_t)c->w * c->h;
-  PropArgs a;
   a.src = dm->cur;
   a.dst = dm->oth;
   a.oldKFImage = old->d_image[0];
@@ -1722,10 +1891,18 @@ static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNo
   lsdm::quatd_to_rot(oldToNew.q, Rd);
   for (int i = 0; i < 9; i++) a.R[i] = (float)Rd[i];
   for (int i = 0; i < 3; i++) a.t[i] = (float)oldToNew.t[i];
+}
+static int propagate(lsdhip_depthmap* dm, lsdhip_frame* nk, bool checkOverflowNow) {
+  lsdhip_ctx* c = dm->ctx;
+  LSD_CTX_LOCK(c);
+  size_t n = (size_t)c->w * c->h;
+  PropArgs a;
+  prop_args(dm, nk, a);
 
   HIPCHK(hipMemsetAsync(dm->d_slotCount, 0, n * 4, lsd_map_stream(c)));
   HIPCHK(hipMemsetAsync(dm->d_ovfHead, 0xFF, n * 4, lsd_map_stream(c)));
   HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, lsd_map_stream(c)));
+  dm->propClean = false;      // (the flags stay set until somebody has read them: lsdhip_depth_change_keyframe_batch then clears first)
   hipLaunchKernelGGL(k_prop_candidates, dim3((c->w + 31) / 32, (c->h + 7) / 8), dim3(256), 0, lsd_map_stream(c), a);
   hipLaunchKernelGGL(k_prop_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lsd_map_stream(c), a);
   if (checkOverflowNow) {
@@ -2093,6 +2270,167 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
     if (rescale_out) *rescale_out = (float)nk->thisToParent_raw.s;
   }
   dm->msCreate = ema(dm->msCreate, now_ms() - t0);
+  return LSDHIP_OK;
+}
+
+// DepthMap::finalizeKeyFrame (DepthMap.cpp:1363-1395) on the current keyframes of n maps followed by DepthMap::createKeyFrame(new_keyframes[j])
+// (:1222-1327), in six launches shared by all maps (kernels above).  Per map every plane, the re-activation data, both keyframes' idepth
+// pyramids and the deferred results (mean inverse depth / point counts, rescale factor, overflow flag) are those of
+// lsdhip_depth_finalize + lsdhip_depth_create_keyframe (tests/test_multiseq_gpu.py).
+extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps, lsdhip_frame** new_keyframes, float* rescale_out) {
+  if (n <= 0 || !maps || !new_keyframes) return LSDHIP_E_ARG;
+  for (int j = 0; j < n; j++) if (!maps[j] || !new_keyframes[j]) return LSDHIP_E_ARG;
+  lsdhip_ctx* c = maps[0]->ctx;
+  LSD_CTX_LOCK(c);
+  for (int j = 0; j < n; j++) {
+    lsdhip_depthmap* dm = maps[j];
+    if (dm->ctx != c || new_keyframes[j]->ctx != c) { lsd_set_error("keyframe change batch: maps and frames of one batch live on one context"); return LSDHIP_E_ARG; }
+    if (!dm->activeKeyFrame) { lsd_set_error("keyframe change batch: depth map %d has no active keyframe", j); return LSDHIP_E_STATE; }
+    if (!new_keyframes[j]->trackingParent) { lsd_set_error("createKeyFrame: new keyframe has no tracking parent"); return LSDHIP_E_STATE; }
+    if (new_keyframes[j] == dm->activeKeyFrame) { lsd_set_error("keyframe change batch: map %d: the new keyframe is the current one", j); return LSDHIP_E_ARG; }
+    for (int i = 0; i < j; i++)
+      if (maps[i] == dm || new_keyframes[i] == new_keyframes[j]) { lsd_set_error("keyframe change batch: entry %d appears twice", j); return LSDHIP_E_ARG; }
+  }
+  HIPCHK(hipSetDevice(c->device));
+  const double t0 = now_ms();
+  if (int rcb = lsd_m_begin(c)) return rcb;
+  const hipStream_t ms = lsd_map_stream(c);
+  const int npx = c->w * c->h;
+  const dim3 tgrid((c->w + 31) / 32, (c->h + 7) / 8, n);
+  const int ntiles = (int)(tgrid.x * tgrid.y);
+  const int nwg5 = (npx + LSD_RESCALE_PX - 1) / LSD_RESCALE_PX;
+  for (int j = 0; j < n; j++) {
+    lsdhip_depthmap* dm = maps[j];
+    if (!dm->propClean) {     // (a single-call propagation, or a failed call, left the K7 scratch in use)
+      HIPCHK(hipMemsetAsync(dm->d_slotCount, 0, (size_t)npx * 4, ms));
+      HIPCHK(hipMemsetAsync(dm->d_ovfHead, 0xFF, (size_t)npx * 4, ms));
+      HIPCHK(hipMemsetAsync(dm->d_flags, 0, 64, ms));
+    }
+    dm->propClean = false;
+  }
+  const int ev = timing_begin(maps[0], 1);
+  if (ev < 0 && ev != EV_SKIP) return ev;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t kfBytes = up(sizeof(KfItem) * (size_t)n), regBytes = up(sizeof(RegBatchItem) * (size_t)n), resBytes = up(sizeof(RescaleItem) * (size_t)n);
+  void* hostBlob = nullptr;
+  void* dev = nullptr;
+  int rc = lsd_args_begin(c, kfBytes + 2 * regBytes + resBytes, &hostBlob, &dev);
+  if (rc) return rc;
+  KfItem* kf = (KfItem*)hostBlob;
+  RegBatchItem* regOcc = (RegBatchItem*)((uint8_t*)hostBlob + kfBytes);
+  RegBatchItem* regFill = (RegBatchItem*)((uint8_t*)hostBlob + kfBytes + regBytes);
+  RescaleItem* res = (RescaleItem*)((uint8_t*)hostBlob + kfBytes + 2 * regBytes);
+  std::vector<lsdhip_frame*> pyrFrames((size_t)2 * n);
+  std::vector<const double*> pyrParts((size_t)2 * n);
+  std::vector<double*> pyrOuts((size_t)2 * n);
+  std::vector<int> pyrN((size_t)2 * n);
+  for (int j = 0; j < n; j++) {
+    lsdhip_depthmap* dm = maps[j];
+    lsdhip_frame* old = dm->activeKeyFrame;
+    lsdhip_frame* nk = new_keyframes[j];
+    double* setA = dm->d_red + 16;
+    double* setB = setA + dm->redStride;
+    double* setC = setB + dm->redStride;
+    // finalizeKeyFrame: the pass on the old keyframe's map, its Frame::setDepth (level 0 + partials), re-activation data; phase A of
+    // propagateDepth into otherDepthMap
+    KfItem& k = kf[j];
+    memset((void*)&k, 0, sizeof(k));
+    k.a = reg_args(dm, VAL_SUM_MIN_FOR_KEEP);
+    k.id0 = lsd_depth_w(old)[0]; k.var0 = lsd_depthvar_w(old)[0]; k.partials = setA;
+    k.x.reactId = old->d_idepth_reAct; k.x.reactVar = old->d_idepthVar_reAct; k.x.reactVal = old->d_validity_reAct;
+    prop_args(dm, nk, k.x.prop);
+    swap_valid(dm);
+    {
+      const int slot = lsd_ctx_take_slot(c);
+      if (slot < 0) return slot;
+      if (old->pendStats >= 0) c->slot_stats_owner[old->pendStats] = nullptr;
+      old->pendStats = slot;
+      c->slot_stats_owner[slot] = old;
+      pyrFrames[j] = old; pyrParts[j] = setA; pyrN[j] = ntiles; pyrOuts[j] = (double*)&c->h_slots[slot];
+    }
+    // createKeyFrame: the new keyframe's map becomes the current one
+    std::swap(dm->cur, dm->oth);
+    dm->activeKeyFrame = nk;
+    dm->activeKeyFrameIsReactivated = false;
+    memset((void*)&regOcc[j], 0, sizeof(RegBatchItem));
+    regOcc[j].a = reg_args(dm, VAL_SUM_MIN_FOR_KEEP);
+    swap_valid(dm);
+    memset((void*)&regFill[j], 0, sizeof(RegBatchItem));
+    regFill[j].a = reg_args(dm, VAL_SUM_MIN_FOR_KEEP);
+    regFill[j].partials = setB;
+    swap_valid(dm);
+    RescaleItem& r = res[j];
+    memset((void*)&r, 0, sizeof(r));
+    r.m = dm->cur;
+    r.sumPartials = setB; r.nSumPartials = ntiles;
+    r.flags = dm->d_flags;
+    {
+      const int slot = lsd_ctx_take_slot(c);
+      if (slot < 0) return slot;
+      if (nk->pendRescale >= 0) c->slot_rescale_owner[nk->pendRescale] = nullptr;
+      nk->pendRescale = slot;
+      c->slot_rescale_owner[slot] = nk;
+      r.slot = (double*)&c->h_slots[slot];
+    }
+    r.id0 = lsd_depth_w(nk)[0]; r.var0 = lsd_depthvar_w(nk)[0];
+    r.statPartials = setC;
+    r.n = npx;
+    {
+      const int slot = lsd_ctx_take_slot(c);
+      if (slot < 0) return slot;
+      if (nk->pendStats >= 0) c->slot_stats_owner[nk->pendStats] = nullptr;
+      nk->pendStats = slot;
+      c->slot_stats_owner[slot] = nk;
+      pyrFrames[n + j] = nk; pyrParts[n + j] = setC; pyrN[n + j] = nwg5; pyrOuts[n + j] = (double*)&c->h_slots[slot];
+    }
+    // the new keyframe's pose: sim3FromSE3(se3FromSim3(thisToParent_raw)) — the scale follows with the rescale factor (DepthMap.cpp:1305)
+    {
+      lsdm::SE3dH newToOld;
+      newToOld.q = nk->thisToParent_raw.q;
+      { const double s_ = nk->thisToParent_raw.s; newToOld.q.w *= s_; newToOld.q.x *= s_; newToOld.q.y *= s_; newToOld.q.z *= s_; }
+      lsdm::q_normalize(newToOld.q);
+      for (int i = 0; i < 3; i++) newToOld.t[i] = nk->thisToParent_raw.t[i];
+      const lsdm::SE3dH back = lsdm::se3d_inverse(lsdm::se3d_inverse(newToOld));
+      nk->thisToParent_raw.q = back.q;
+      lsdm::q_normalize(nk->thisToParent_raw.q);
+      for (int i = 0; i < 3; i++) nk->thisToParent_raw.t[i] = back.t[i];
+    }
+  }
+  rc = lsd_args_commit(c, ms);
+  if (rc) return rc;
+  const KfItem* dkf = (const KfItem*)dev;
+  const RegBatchItem* dOcc = (const RegBatchItem*)((const uint8_t*)dev + kfBytes);
+  const RegBatchItem* dFill = (const RegBatchItem*)((const uint8_t*)dev + kfBytes + regBytes);
+  const RescaleItem* dRes = (const RescaleItem*)((const uint8_t*)dev + kfBytes + 2 * regBytes);
+  hipLaunchKernelGGL(k_kf_finalize_prop, tgrid, dim3(256), 0, ms, dkf);
+  hipLaunchKernelGGL(k_prop_resolve_batch, dim3((unsigned)((npx + 255) / 256), n), dim3(256), 0, ms, dkf);
+  hipLaunchKernelGGL((k_kf_reg<false, true>), tgrid, dim3(256), 0, ms, dOcc);
+  hipLaunchKernelGGL((k_kf_reg<true, false>), tgrid, dim3(256), 0, ms, dFill);
+  hipLaunchKernelGGL(k_kf_rescale_setdepth, dim3(nwg5, n), dim3(256), 0, ms, dRes);
+  HIPCHK(hipGetLastError());
+  rc = lsd_args_release(c, ms);
+  if (rc) return rc;
+  rc = lsd_frame_build_idepth_pyramid_batch(pyrFrames.data(), 2 * n, pyrParts.data(), 0, pyrOuts.data(), pyrN.data());
+  if (rc) return rc;
+  for (int j = 0; j < n; j++) {
+    maps[j]->propClean = true;
+    pyrFrames[j]->depthHasBeenUpdatedFlag = true;
+    pyrFrames[j]->reActValid = true;
+    pyrFrames[n + j]->depthHasBeenUpdatedFlag = true;
+  }
+  rc = timing_end(maps[0], ev);
+  if (rc) return rc;
+  if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
+  if (!c->async || rescale_out) {
+    for (int j = 0; j < n; j++) {
+      if (!c->async) { rc = lsd_frame_resolve(pyrFrames[j]); if (rc) return rc; }
+      rc = lsd_frame_resolve(pyrFrames[n + j]);
+      if (rc) return rc;
+      if (rescale_out) rescale_out[j] = (float)pyrFrames[n + j]->thisToParent_raw.s;
+    }
+  }
+  const double dt = now_ms() - t0;
+  for (int j = 0; j < n; j++) maps[j]->msCreate = ema(maps[j]->msCreate, dt / n);
   return LSDHIP_OK;
 }
 

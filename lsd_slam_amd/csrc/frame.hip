@@ -1146,7 +1146,7 @@ int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, v
   return lsd_args_commit(c, s);
 }
 
-int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double* const* redPartials, int redN, double* const* redOut) {
+int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double* const* redPartials, int redN, double* const* redOut, const int* redNs) {
   if (n <= 0) return LSDHIP_OK;
   lsdhip_ctx* c = fs[0]->ctx;
   LSD_CTX_LOCK(c);
@@ -1159,7 +1159,7 @@ int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double*
     float** var = lsd_depthvar_w(f);
     for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = id[l]; a.var[l] = var[l]; }
     a.w0 = c->w;
-    a.redPartials = redPartials[j]; a.redN = redN; a.redOut = redOut[j];
+    a.redPartials = redPartials[j]; a.redN = redNs ? redNs[j] : redN; a.redOut = redOut[j];
   }
   void* dev = nullptr;
   int rc = lsd_args_push(c, items.data(), sizeof(DepthPyrArgs) * (size_t)n, lsd_map_stream(c), &dev);

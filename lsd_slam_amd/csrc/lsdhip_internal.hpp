@@ -59,8 +59,7 @@ struct TrackLevel {
   int w, h;
   int nblocks;               // workgroups (tiles) that have work at this level
   int singlePass;            // nblocks * workgroup size >= points: every lane evaluates at most one point
-  int tilePx;                // > 0: batch throughput mode, strip form: one strip of tilePx pixels per workgroup (compacted in LDS)
-  int granPx;                // > 0: batch throughput mode, granule form: nblocks granules of granPx pixels, one wave each (k_track_eval_gran)
+  int tilePx;                // > 0: batch throughput mode, one strip of tilePx pixels per workgroup (compacted in LDS)
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
   float lambdaInitial, stepSizeMin, convergenceEps;
   int maxIts;
@@ -156,9 +155,7 @@ struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_OBS_SPLIT_MIN_MAPS 4             // lsdhip_depth_update_batch: select + walk launches from this many maps on
 #define LSD_OBS_WALK_WAVES 4096             // one-wave workgroups of the walk launch
 #define LSD_BATCH_THROUGHPUT_MIN_JOBS 8     // lsdhip_tracker_track_batch: throughput mode from this many jobs on
-#define LSD_BATCH_STRIP_WORKGROUPS 768      // (strip form of rounds 2-4, kept for the A/B of this round: LSDHIP_BATCH_GRAN=0)
-#define LSD_BATCH_GRANULE_PX 1024           // pixels per granule of a throughput-mode evaluation launch (larger levels: the multiple of it that keeps a job's rows within the scratch)
-#define LSD_BATCH_EVAL_WAVES 4096          // one-wave workgroups of a throughput-mode evaluation launch (256 CUs x 4 SIMDs x 4)
+#define LSD_BATCH_STRIP_WORKGROUPS 1024     // strips x jobs of a throughput-mode evaluation launch (4 workgroups per CU)
 struct lsdhip_frame;
 
 // Host-side state of a context (arena free list, deferred-result slot ring and its owner tables, profiling events, the
@@ -350,8 +347,6 @@ struct lsdhip_tracker {
   TrackState* d_bstate = nullptr;     // [capacity][2]
   float* d_bscratch = nullptr;        // TrackScratch arena x capacity (sums | topkey | topval, each [job][...])
   TrackSummary* h_bsummary = nullptr; // pinned, device-mapped
-  int* d_bsched = nullptr;            // [2][capacity] level of each job's published state (throughput mode; -1: finished)
-  unsigned* d_btickets = nullptr;     // [8] granule tickets of the evaluation launch (per XCD)
   float* d_pts = nullptr;         // permaref point upload
   int pts_capacity = 0;
 };
@@ -402,6 +397,8 @@ struct lsdhip_depthmap {
   float4* d_cand = nullptr;        // per source candidate (new_idepth, new_var, validity as float bits, target)
   int* d_flags = nullptr;          // overflow flag etc.
   double* d_red = nullptr;         // reduction scratch (sum, count)
+  size_t redStride = 0;            // doubles per set of partials (three sets behind the first 16 doubles)
+  bool propClean = false;          // slot counts / chain heads / flags of the K7 scratch are in their rest state
   double* h_red = nullptr;         // pinned
   // GPU-side timing of the mapping calls (events on the context's stream; read back lazily)
   hipEvent_t ev[8][2] = {};
@@ -465,7 +462,8 @@ int lsd_args_begin(lsdhip_ctx* c, size_t bytes, void** host_out, void** dev_out)
 int lsd_args_commit(lsdhip_ctx* c, hipStream_t s);
 int lsd_args_release(lsdhip_ctx* c, hipStream_t s);
 // Frame::setDepth's second half for n keyframes in one launch (lsdhip_depth_update_batch)
-int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** f, int n, const double* const* redPartials, int redN, double* const* redOut);
+int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** f, int n, const double* const* redPartials, int redN, double* const* redOut,
+                                         const int* redNs = nullptr);   // redNs: partial counts per frame (else redN for all)
 int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials = nullptr, int redN = 0, double* redOut = nullptr);   // on lsd_map_stream, into lsd_depth_w
 int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);

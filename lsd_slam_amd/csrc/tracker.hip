@@ -81,12 +81,6 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     sc.topkey += j * 2 * rows;
     sc.topval += j * 2 * rows * 96;
   }
-  // throughput mode: this launch (one workgroup per job) is followed by k_track_eval_gran over the granules of all jobs — it zeroes that
-  // launch's granule tickets and leaves each job's level (or -1: finished) where the evaluation waves build their schedule from
-  if (BATCH && MODE == TS_LM && sc.tickets != nullptr && blockIdx.y == 0 && threadIdx.x < 8) sc.tickets[threadIdx.x] = 0u;
-  auto publish_sched = [&](const int lvl) {
-    if (BATCH && MODE == TS_LM && sc.sched != nullptr && threadIdx.x == 0) sc.sched[(size_t)(1 - parity) * sc.schedJobs + blockIdx.y] = lvl;
-  };
   constexpr int WAVES = BLOCK / 64;
   constexpr int SUMW = WAVES - 1;                    // waves that sum partials (the last one does the tail work)
   constexpr int NSLICE = (SUMW * 64) / RS_END;       // row slices per column
@@ -94,7 +88,15 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   __shared__ TrackState S;
   __shared__ LmShared sh;
   __shared__ LmPar s_par;
-  constexpr int NPASS = 1;   // the workgroup reduction handles the columns in NPASS batches (2 halves the LDS; measured slower)
+  // the workgroup reduction handles the columns in NPASS batches: 2 halves its LDS (measured slower for the latency-bound single jobs);
+  // the throughput-mode evaluation takes 2: 22 instead of 44 KB, so that four workgroups fit a CU beside four waves per SIMD
+#ifdef LSD_EVAL_R04      // A/B build of round 5: the evaluation launch as rounds 2-4 had it (44 KB, 150 registers: three workgroups per CU)
+  constexpr int NPASS = 1;
+  constexpr bool EVAL_UNI = false;
+#else
+  constexpr int NPASS = (BATCH && MODE == TS_EVAL) ? 2 : 1;
+  constexpr bool EVAL_UNI = BATCH && MODE == TS_EVAL;
+#endif
   constexpr int CPP = (RS_END + NPASS - 1) / NPASS;      // columns per batch
   constexpr int RSLICE_ = BLOCK / CPP;
   __shared__ float s_sum[(NSLICE > RSLICE_ ? NSLICE : RSLICE_)][64];
@@ -176,7 +178,6 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   PHASE_MARK(1);
   if (S.done) {
     if (MODE != TS_EVAL && leader) { copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK); LSD_TRACK_RELEASE(); }   // keep both buffers "done"
-    publish_sched(-1);
     return;
   }
   const int lvlPending = S.level;
@@ -510,7 +511,6 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       }
       if (leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
       LSD_TRACK_RELEASE();
-      publish_sched(-1);
       return;
     }
     // a workgroup that evaluates trial c > 0 leaves that trial's increment and pose for the launch that finishes it
@@ -529,7 +529,6 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     if (tid == 0) S.pending = 1;
     __syncthreads();
     copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
-    publish_sched(S.level);
     return;
   }
 
@@ -548,7 +547,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   topval_out += (size_t)cand * max_rows * 96;
   const int tile = xcd_tile(bx, nb);
   EvalCtx a;
-  make_ctx_dev(job, S, level, a);
+  make_ctx_dev<EVAL_UNI>(job, S, level, a);
   gbyte* wasGood = (gbyte*)(job.lv[level].writeMask ? (cand == 0 ? job.wasGood : spec.wasGoodSide + (size_t)(cand - 1) * spec.maskStride) : nullptr);
   const int work = a.npts >= 0 ? a.npts : a.w * a.h;
   float acc[RS_END];
@@ -569,7 +568,11 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     unsigned vmask = 0;      // 4 validity bits per chunk
     int wcount = 0;          // valid pixels of this wave (uniform)
     // all validity loads of the strip are issued together (one memory round trip instead of one per 1024-pixel chunk)
-    constexpr int CHMAX = 8;                       // tilePx <= 8192 (fill_level)
+#ifdef LSD_EVAL_R04
+    constexpr int CHMAX = 8;
+#else
+    constexpr int CHMAX = 6;                       // tilePx <= 5376 (fill_level)
+#endif
     v4f v4s[CHMAX], d4s[CHMAX];
 #pragma unroll
     for (int c = 0; c < CHMAX; c++) {
@@ -790,234 +793,6 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 #endif
 }
 
-// ---- throughput mode of batches: the residual evaluation over GRANULES, one wave each ------------------------------------------------
-// A step of a batch in throughput mode = k_track_step<TS_LM> (one workgroup per job: finishes the pending evaluation, publishes state and
-// level) + this launch.  A granule is a fixed run of gpx[level] consecutive pixels of a keyframe level; its partial row of sums, its
-// order keys and its mask bytes are produced by ONE wave in a fixed internal order, and the LM launch adds a job's rows in granule order —
-// so a job's totals do not depend on which wave evaluated which granule, nor on what the other jobs of the batch are doing (replicas of
-// a job stay bit-identical wherever they sit in the batch).  That freedom is what the schedule uses: every wave reads the jobs' current
-// levels (the LM launch left them in sc.sched), builds the same list of all live granules of the launch — job-major, a job at level l
-// contributing ng[l] of them — and takes its share of it.  A launch in which ten of 64 jobs are still at level 1 therefore spreads those
-// jobs' 750 granules over the whole chip instead of running 120 long strips on 120 workgroups while the rest idles
-// (profiles/r04_notes.md §4: the fixed 12 strips per job of rounds 2-4).
-// One-wave workgroups: no barriers, 8 KB of LDS (the granule's compacted pixel list), the 41 sums reduced with DPP adds.
-struct GranSched {
-  int n;                   // jobs (<= GRAN_MAX_JOBS)
-  int ng[LSD_LEVELS];      // granules per job at each level (0: level not used)
-  int gpx[LSD_LEVELS];     // pixels per granule (multiple of 1024, <= GRAN_MAX_PX)
-};
-#define GRAN_MAX_PX 4096
-#define GRAN_MAX_JOBS 256
-typedef const __attribute__((address_space(4))) unsigned cuint4;      // constant address space: uniform reads become scalar loads
-__device__ __forceinline__ float cfl(const void* base, size_t byteOff) { return __uint_as_float(*(cuint4*)((const char*)base + byteOff)); }
-__device__ __forceinline__ int cin(const void* base, size_t byteOff) { return (int)*(cuint4*)((const char*)base + byteOff); }
-__device__ __forceinline__ const void* cptr(const void* base, size_t byteOff) {
-  typedef const __attribute__((address_space(4))) unsigned long long cu64;
-  return (const void*)*(cu64*)((const char*)base + byteOff);
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_track_eval_gran(const TrackJob* __restrict__ jobs, const TrackState* __restrict__ st2, TrackScratch sc,
-                                                        GranSched gs, int parity) {
-  __shared__ unsigned short s_list[GRAN_MAX_PX];
-  __shared__ int s_incl[GRAN_MAX_JOBS];      // granules of jobs 0 .. j (inclusive)
-  __shared__ int s_lvl[GRAN_MAX_JOBS];
-  const int lane = threadIdx.x;
-  auto ng_of = [&](const int lv) { return lv == 1 ? gs.ng[1] : (lv == 2 ? gs.ng[2] : (lv == 3 ? gs.ng[3] : (lv == 4 ? gs.ng[4] : (lv == 0 ? gs.ng[0] : 0)))); };
-  auto gpx_of = [&](const int lv) { return lv == 1 ? gs.gpx[1] : (lv == 2 ? gs.gpx[2] : (lv == 3 ? gs.gpx[3] : (lv == 4 ? gs.gpx[4] : gs.gpx[0]))); };
-  // ---- the schedule: inclusive prefix of the jobs' granule counts (every wave computes the same one) ----
-  int T = 0;
-  {
-    const int* sched = sc.sched + (size_t)parity * sc.schedJobs;
-#pragma unroll
-    for (int c = 0; c < GRAN_MAX_JOBS / 64; c++) {
-      const int j = c * 64 + lane;
-      const int lv = j < gs.n ? sched[j < gs.n ? j : 0] : -1;
-      int v = ng_of(lv);
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off); if (lane >= off) v += u; }
-      s_incl[j] = T + v;
-      s_lvl[j] = lv;
-      T += __builtin_amdgcn_readlane(v, 63);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (T == 0) return;
-  const size_t rows = (size_t)sc.max_rows;
-  // Which granules this wave evaluates.  The first min(T, waves) granules are dealt statically — wave b sits on XCD b mod 8 (workgroups are
-  // dealt round-robin) and takes the (b / 8)-th granule of that XCD's contiguous eighth of them, so neighbouring granules of a job (they
-  // share texel lines) stay in one L2 — without an atomic in front of the work: most launches of a batch hold fewer granules than the
-  // chip has wave slots.  What is left beyond that (large batches, large frames) is drawn from one ticket counter, the next ticket
-  // travelling while a granule is evaluated.
-  const int NS = T < (int)gridDim.x ? T : (int)gridDim.x;
-  const int per = (NS + 7) >> 3;
-  int g = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-  bool have = (int)(blockIdx.x >> 3) < per && g < NS;
-  const bool dyn = T > NS;
-  auto draw = [&]() { unsigned t = 0u; if (lane == 0) t = atomicAdd(&sc.tickets[0], 1u); return t; };
-  unsigned tk = 0u;
-  if (dyn) tk = draw();
-  while (true) {
-    if (!have) {
-      if (!dyn) break;
-      g = NS + (int)__builtin_amdgcn_readfirstlane(tk);
-      if (g >= T) break;
-      tk = draw();
-    }
-    have = false;
-    // ---- which job, which granule of it ----
-    int jb = 0;
-#pragma unroll
-    for (int c = 0; c < GRAN_MAX_JOBS / 64; c++) jb += __popcll(__ballot(s_incl[c * 64 + lane] <= g));   // jobs that end at or before g
-    jb = __builtin_amdgcn_readfirstlane(jb);
-    const int level = __builtin_amdgcn_readfirstlane(s_lvl[jb]);
-    const int gi = g - (jb > 0 ? __builtin_amdgcn_readfirstlane(s_incl[jb - 1]) : 0);
-    // ---- the job's level and the pose under evaluation, through the scalar cache ----
-    const TrackJob* job = jobs + jb;
-    const size_t lOff = offsetof(TrackJob, lv) + (size_t)level * sizeof(TrackLevel);
-    const TrackState* S = st2 + 2 * (size_t)jb + parity;
-    EvalCtx a;
-    a.kf_idepth = (gfloat*)cptr(job, lOff + offsetof(TrackLevel, kf_idepth));
-    a.kf_idepthVar = (gfloat*)cptr(job, lOff + offsetof(TrackLevel, kf_idepthVar));
-    a.kf_image = (gfloat*)cptr(job, lOff + offsetof(TrackLevel, kf_image));
-    a.fr_grad = (gfloat*)cptr(job, lOff + offsetof(TrackLevel, fr_grad));
-    a.pts_pos = nullptr; a.pts_colvar = nullptr; a.npts = -1;
-    a.w = cin(job, lOff + offsetof(TrackLevel, w)); a.h = cin(job, lOff + offsetof(TrackLevel, h));
-    a.fx = cfl(job, lOff + offsetof(TrackLevel, fx)); a.fy = cfl(job, lOff + offsetof(TrackLevel, fy));
-    a.cx = cfl(job, lOff + offsetof(TrackLevel, cx)); a.cy = cfl(job, lOff + offsetof(TrackLevel, cy));
-    a.fxi = cfl(job, lOff + offsetof(TrackLevel, fxi)); a.fyi = cfl(job, lOff + offsetof(TrackLevel, fyi));
-    a.cxi = cfl(job, lOff + offsetof(TrackLevel, cxi)); a.cyi = cfl(job, lOff + offsetof(TrackLevel, cyi));
-#pragma unroll
-    for (int i = 0; i < 9; i++) a.R[i] = cfl(S, offsetof(TrackState, R) + 4 * i);
-#pragma unroll
-    for (int i = 0; i < 3; i++) a.t[i] = cfl(S, offsetof(TrackState, t) + 4 * i);
-    a.aff_a = cfl(S, offsetof(TrackState, aff_a)); a.aff_b = cfl(S, offsetof(TrackState, aff_b));
-    a.cameraPixelNoise2 = cfl(job, offsetof(TrackJob, cameraPixelNoise2)); a.var_weight = cfl(job, offsetof(TrackJob, var_weight));
-    a.huber_half = cfl(job, offsetof(TrackJob, huber_half));
-    gbyte* wasGood = cin(job, lOff + offsetof(TrackLevel, writeMask)) ? (gbyte*)cptr(job, offsetof(TrackJob, wasGood)) : nullptr;
-    const int G = gpx_of(level);
-    const int work = a.w * a.h;
-    const int base = gi * G;
-    const float inv_w = 1.0f / (float)a.w;
-    auto xy_of = [&](const int i, int& x, int& y) {
-      y = (int)((float)i * inv_w);
-      x = i - y * a.w;
-      if (x < 0) { y--; x += a.w; }
-      if (x >= a.w) { y++; x -= a.w; }
-    };
-    // ---- compaction of the granule's valid reference pixels into the list (order: 1024-pixel block, 256-pixel chunk, pixel slot, lane) ----
-    int total = 0;
-    for (int sb = 0; sb < G; sb += 1024) {
-      v4f v4s[4], d4s[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int i0 = base + sb + (c << 8) + (lane << 2);
-        const bool in = i0 < work;
-        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
-        v4s[c] = in ? *(gv4f*)(a.kf_idepthVar + i0) : zero4;   // (the planes are padded to 256 bytes: a vector that straddles the end is readable)
-        d4s[c] = in ? *(gv4f*)(a.kf_idepth + i0) : zero4;
-      }
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int o0 = sb + (c << 8) + (lane << 2);
-        const int i0 = base + o0;
-        int x, y;
-        xy_of(i0, x, y);
-        const float vv[4] = {v4s[c].x, v4s[c].y, v4s[c].z, v4s[c].w}, dd[4] = {d4s[c].x, d4s[c].y, d4s[c].z, d4s[c].w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool ok = i0 + k < work && !(x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) && !(vv[k] <= 0 || dd[k] == 0);
-          const unsigned long long bal = __ballot(ok);
-          if (ok) s_list[total + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)(o0 + k);
-          total += __popcll(bal);
-          if (++x >= a.w) { x = 0; y++; }
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- evaluation: entries lane, lane + 64, ... in a three-stage software pipeline (as the strips of rounds 2-4 did) ----
-    float acc[RS_END];
-#pragma unroll
-    for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
-    int key0 = -1, key1 = -1, key2 = -1;
-    if (total > 0) {
-      struct StA { int i; float var, id, img; bool live; };
-      struct StB { int i; float pz, I_ref, var; PointWarp q; PointTexels t; bool live; };
-      auto stageA = [&](const int p, StA& A) {
-        A.live = p < total;
-        A.i = base + (int)s_list[A.live ? p : 0];
-        A.var = a.kf_idepthVar[A.i];
-        A.id = a.kf_idepth[A.i];
-        A.img = a.kf_image[A.i];
-      };
-      auto stageB = [&](const StA& A, StB& B) {
-        B.live = A.live;
-        B.i = A.i;
-        int bx_, by_;
-        xy_of(A.i, bx_, by_);
-        const float inv = 1.0f / A.id;
-        const float px = inv * (a.fxi * bx_ + a.cxi), py = inv * (a.fyi * by_ + a.cyi);
-        B.pz = inv * 1.0f;
-        B.I_ref = A.img; B.var = A.var;
-        eval_warp(a, px, py, B.pz, B.q);
-        eval_fetch(a, B.q, B.live && B.q.in_image, B.t);
-      };
-      auto stageC = [&](const StB& B) {
-        if (B.live) {
-          acc[RS_NREF] += 1.f;
-          if (!B.q.in_image) {
-            if (wasGood) wasGood[B.i] = 0;
-          } else {
-            PointOut o;
-            eval_finish(a, B.q, B.t, B.pz, B.I_ref, B.var, o);
-            if (wasGood) wasGood[B.i] = o.good ? 1 : 0;
-            int x_, y_;
-            xy_of(B.i, x_, y_);
-            top3_insert(__mul24(x_, a.h) + y_, key0, key1, key2);
-            accumulate_point(o, acc);
-          }
-        }
-      };
-      const int rounds = (total + 63) >> 6;
-      StA A1, A2;
-      StB B0, B1;
-      stageA(lane, A1);
-      stageB(A1, B0);
-      stageA(lane + 64, A1);
-      for (int r = 0; r < rounds; r += 2) {
-        stageB(A1, B1);
-        stageA(lane + (r + 2) * 64, A2);
-        stageC(B0);
-        stageB(A2, B0);
-        stageA(lane + (r + 3) * 64, A1);
-        stageC(B1);
-      }
-    }
-    // ---- the granule's row: 41 wave sums (DPP), column k delivered by lane k; its three largest order keys ----
-    float rowv = 0.f;
-#pragma unroll
-    for (int k = 0; k < RS_END; k++) {
-      const float s = rl(wave_sum_to_lane63(acc[k]), 63);
-      rowv = lane == k ? s : rowv;
-    }
-    float* sums_out = sc.sums + ((size_t)jb * 2 + parity) * RS_COLS * rows + (size_t)gi * RS_COLS;
-    if (lane < RS_COLS) sums_out[lane] = rowv;
-    int t0k, t1k, t2k;
-    {
-      int c0 = key0, c1 = key1, c2 = key2;
-      t0k = __builtin_amdgcn_readlane(wave_max_to_lane63(c0), 63);
-      if (c0 == t0k && t0k >= 0) { c0 = c1; c1 = c2; c2 = -1; }
-      t1k = __builtin_amdgcn_readlane(wave_max_to_lane63(c0), 63);
-      if (c0 == t1k && t1k >= 0) { c0 = c1; c1 = c2; c2 = -1; }
-      t2k = __builtin_amdgcn_readlane(wave_max_to_lane63(c0), 63);
-    }
-    if (lane == 0) sc.topkey[((size_t)jb * 2 + parity) * rows + gi] = make_int4(t0k, t1k, t2k, -1);
-    __builtin_amdgcn_wave_barrier();     // (the next granule's compaction rewrites the list)
-  }
-}
-
 // Pipelined contexts: the frame's refPixelWasGood is what the LAST trial the LM loop executed wrote.  Trial 0 of every launch writes the
 // frame's own plane, trials > 0 write side planes — at the same pixels (the valid reference points do not depend on the pose), so the
 // pixels the job visited are those whose byte in the frame's plane is no longer the 0xFF of frame creation: there the side plane's byte
@@ -1184,7 +959,7 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   }
   (void)hipFree(t->d_trace);
 #endif
-  if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); (void)hipFree(t->d_bsched); }
+  if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   (void)hipFree(t->d_partials);
   (void)hipFree(t->d_maskSide);
   (void)hipFree(t->d_state);
@@ -1282,31 +1057,23 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   if (L.nblocks < 1) L.nblocks = 1;
   L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
   L.tilePx = 0;
-  L.granPx = 0;
-  static const bool granForm = !(getenv("LSDHIP_BATCH_GRAN") && getenv("LSDHIP_BATCH_GRAN")[0] == '0');   // A/B of round 5
-  if (granForm && t->batch_jobs >= LSD_BATCH_THROUGHPUT_MIN_JOBS && t->batch_jobs <= GRAN_MAX_JOBS && npts < 0) {
-    // throughput mode, granule form: fixed granules of LSD_BATCH_GRANULE_PX pixels (larger levels: the multiple of it that keeps a job's
-    // rows within the scratch), one partial row per granule
-    const int rowsMax = t->max_blocks < 256 ? t->max_blocks : 256;
-    int g = LSD_BATCH_GRANULE_PX;
-    while ((work + g - 1) / g > rowsMax) g += LSD_BATCH_GRANULE_PX;
-    if (g <= GRAN_MAX_PX) {
-      L.granPx = g;
-      L.nblocks = (work + g - 1) / g;
-      L.singlePass = 0;
-    }
-  } else if (!granForm && t->batch_jobs >= LSD_BATCH_THROUGHPUT_MIN_JOBS && npts < 0 && (L.w & 3) == 0) {
+  if (t->batch_jobs >= LSD_BATCH_THROUGHPUT_MIN_JOBS && npts < 0 && (L.w & 3) == 0) {
     // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
     static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : LSD_BATCH_STRIP_WORKGROUPS;   // developer sweep
-    // strips x jobs = the chip's 768 workgroup slots (3 per CU) where the level is large enough: one full round of equal strips;
+    // strips x jobs = the chip's 1024 workgroup slots (4 per CU) where the level is large enough: one full round of equal strips;
     // a strip is a multiple of 256 pixels (the lanes take 4 consecutive pixels each)
     long long px = (((long long)work * t->batch_jobs + wgTarget - 1) / wgTarget + 255) & ~255LL;
     if (px < 1024) px = 1024;
-    if (px > 8192) px = 8192;                                  // the strip's list lives in the reduction's LDS (10545 words)
-    while ((work + px - 1) / px > t->max_blocks) px += 256;    // cannot happen below 2.6 Mpixel levels
-    L.tilePx = (int)px;
-    L.nblocks = (int)((work + px - 1) / px);
-    L.singlePass = 0;
+#ifdef LSD_EVAL_R04
+    if (px > 8192) px = 8192;
+#else
+    if (px > 5376) px = 5376;                                  // the strip's list lives in the reduction's LDS (two column passes: 5405 words)
+#endif
+    if ((work + px - 1) / px <= t->max_blocks) {               // (levels beyond 1.6 Mpixel keep the grid-stride form)
+      L.tilePx = (int)px;
+      L.nblocks = (int)((work + px - 1) / px);
+      L.singlePass = 0;
+    }
   }
   L.lambdaInitial = t->lambdaInitial[level]; L.stepSizeMin = t->stepSizeMin[level]; L.convergenceEps = t->convergenceEps[level];
   L.maxIts = t->maxItsPerLvl[level];
@@ -1334,7 +1101,6 @@ static TrackScratch scratch_of(lsdhip_tracker* t) {
   sc.recs = t->d_partials + C * 2 * RS_COLS * rows + C * 2 * 4 * rows + C * 2 * 96 * rows;
   sc.max_rows = t->max_blocks;
   sc.cmax = LSD_SPEC_MAX;
-  sc.sched = nullptr; sc.tickets = nullptr; sc.schedJobs = 0;
 #ifdef LSD_PHASE_TRACE
   sc.trace = t->d_trace;
 #endif
@@ -1864,7 +1630,7 @@ static int batch_reserve(lsdhip_tracker* t, int n) {
   LSD_CTX_LOCK(c);
   if (n <= t->batch_capacity) return LSDHIP_OK;
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); (void)hipFree(t->d_bsched); }
+  if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   t->batch_capacity = n < 8 ? 8 : n;
   const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
   const size_t per_job = 2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4;
@@ -1874,46 +1640,8 @@ static int batch_reserve(lsdhip_tracker* t, int n) {
   HIPCHK(hipMemsetAsync(t->d_bscratch, 0, B * per_job, c->stream));
   HIPCHK(hipHostMalloc((void**)&t->h_bjobs, B * sizeof(TrackJob), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&t->h_bsummary, B * sizeof(TrackSummary), hipHostMallocMapped));
-  HIPCHK(hipMalloc((void**)&t->d_bsched, (2 * B + 16) * sizeof(int)));       // [2][B] levels | 8 granule tickets
-  HIPCHK(hipMemsetAsync(t->d_bsched, 0xFF, (2 * B + 16) * sizeof(int), c->stream));
-  t->d_btickets = (unsigned*)(t->d_bsched + 2 * B);
   return LSDHIP_OK;
 }
-// scratch views of a batch (arrays over jobs) and, for the granule form, what the evaluation waves need to build their schedule
-static TrackScratch batch_scratch(lsdhip_tracker* t, bool gran) {
-  TrackScratch sc;
-  const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
-  sc.sums = t->d_bscratch;
-  sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
-  sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
-  sc.max_rows = t->max_blocks;
-  sc.cmax = 1;
-  sc.recs = nullptr;
-  sc.sched = gran ? t->d_bsched : nullptr;
-  sc.tickets = gran ? t->d_btickets : nullptr;
-  sc.schedJobs = t->batch_capacity;
-#ifdef LSD_PHASE_TRACE
-  sc.trace = nullptr;
-#endif
-  return sc;
-}
-// granule form possible?  Every level the jobs can visit must have been described as granules (fill_level), the same way in every job
-static bool batch_gran_sched(const lsdhip_tracker* t, int n, GranSched* gs) {
-  memset(gs, 0, sizeof(*gs));
-  gs->n = n;
-  if (n > GRAN_MAX_JOBS) return false;
-  for (int j = 0; j < n; j++) {
-    const TrackJob& job = t->h_bjobs[j];
-    for (int l = job.lastLevel; l <= job.topLevel; l++) {
-      const TrackLevel& L = job.lv[l];
-      if (L.granPx <= 0) return false;
-      if (gs->gpx[l] == 0) { gs->gpx[l] = L.granPx; gs->ng[l] = L.nblocks; }
-      else if (gs->gpx[l] != L.granPx || gs->ng[l] != L.nblocks) return false;
-    }
-  }
-  return true;
-}
-static const int g_evalWaves = getenv("LSDHIP_BATCH_EVAL_WAVES") ? atoi(getenv("LSDHIP_BATCH_EVAL_WAVES")) : LSD_BATCH_EVAL_WAVES;   // developer sweep
 // With many jobs in flight the other jobs hide a job's latency, so each job gets fewer, fatter workgroups: the
 // per-workgroup LM replay (the price of the launch needing no inter-workgroup communication) shrinks accordingly.
 static void batch_begin(lsdhip_tracker* t, int n) {
@@ -1939,9 +1667,19 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
     t->h_bsummary[j].done = 0;
   }
   HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
-  GranSched gs;
-  const bool gran = batch_gran_sched(t, n, &gs);
-  const TrackScratch sc = batch_scratch(t, gran);
+  TrackScratch sc;
+  {
+    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
+    sc.sums = t->d_bscratch;
+    sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
+    sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
+    sc.max_rows = t->max_blocks;
+    sc.cmax = 1;
+    sc.recs = nullptr;
+#ifdef LSD_PHASE_TRACE
+    sc.trace = nullptr;
+#endif
+  }
   TrackSummary* d_sum = nullptr;
   HIPCHK(hipHostGetDevicePointer((void**)&d_sum, t->h_bsummary, 0));
   if (int rcp = prof_collect(c)) return rcp;
@@ -1949,13 +1687,7 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     for (int i = 0; i < budget; i++) {
-      if (gran) {
-        // throughput mode: one LM workgroup per job, then the evaluation of all live granules of all jobs, one wave each
-        hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
-                           t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
-        hipLaunchKernelGGL(k_track_eval_gran, dim3(g_evalWaves), dim3(64), 0, c->stream, (const TrackJob*)t->d_bjobs, (const TrackState*)t->d_bstate, sc, gs,
-                           1 - parity);
-      } else if (split) {
+      if (split) {
         // throughput mode: one LM workgroup per job, then a pure evaluation launch over all jobs' strips
         hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
@@ -2081,15 +1813,25 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
     job.T0.t[0] = T7[4]; job.T0.t[1] = T7[5]; job.T0.t[2] = T7[6];
     job.aff_a0 = 1.0f; job.aff_b0 = 0.0f;
     if (job.lv[level].nblocks > grid) grid = job.lv[level].nblocks;
-    if (job.lv[level].tilePx == 0 && job.lv[level].granPx == 0) { t->cap_override = 0; t->batch_jobs = 0; lsd_set_error("lsdhip_tracker_eval_throughput: level %d is not in throughput mode", level); return LSDHIP_E_STATE; }
+    if (job.lv[level].tilePx == 0) { t->cap_override = 0; t->batch_jobs = 0; lsd_set_error("lsdhip_tracker_eval_throughput: level %d is not in throughput mode", level); return LSDHIP_E_STATE; }
     t->h_bsummary[j].done = 0;
   }
   t->cap_override = 0;
   t->batch_jobs = 0;
   HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
-  GranSched gs;
-  const bool gran = batch_gran_sched(t, n, &gs);
-  const TrackScratch sc = batch_scratch(t, gran);
+  TrackScratch sc;
+  {
+    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
+    sc.sums = t->d_bscratch;
+    sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
+    sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
+    sc.max_rows = t->max_blocks;
+    sc.cmax = 1;
+    sc.recs = nullptr;
+#ifdef LSD_PHASE_TRACE
+    sc.trace = nullptr;
+#endif
+  }
   TrackSummary* d_sum = nullptr;
   HIPCHK(hipHostGetDevicePointer((void**)&d_sum, t->h_bsummary, 0));
   struct EventPair {      // destroyed on every exit path
@@ -2102,14 +1844,8 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
   hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
                      d_sum, 0, 1, TrackSpec{});
   auto eval_launch = [&]() -> int {
-    if (gran) {
-      // (an evaluation launch draws the tickets the LM launch before it zeroed: a repeat needs them zeroed again)
-      HIPCHK(hipMemsetAsync(t->d_btickets, 0, 8 * sizeof(unsigned), c->stream));
-      hipLaunchKernelGGL(k_track_eval_gran, dim3(g_evalWaves), dim3(64), 0, c->stream, (const TrackJob*)t->d_bjobs, (const TrackState*)t->d_bstate, sc, gs, 1);
-    } else {
-      hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
-                         d_sum, 1, 0, TrackSpec{});
-    }
+    hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs, t->d_bstate, sc,
+                       d_sum, 1, 0, TrackSpec{});
     return LSDHIP_OK;
   };
   if (int rcw = eval_launch()) return rcw;     // warm-up

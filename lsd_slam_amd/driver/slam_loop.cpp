@@ -95,6 +95,7 @@ extern "C" int lsdloop_create(int device, int w, int h, const float K4[4], const
     std::unique_ptr<lsdloop> l(new lsdloop());
     l->ctx = Context::get(w, h, K, device);
     l->loop.reset(new SlamLoop(w, h, K, first_image, images_on_device != 0, gt_depth0_host, kf_every));
+    if (const char* e = std::getenv("LSDHIP_KF_SHARED")) l->loop->sharedKeyframeChange = e[0] != '0';   // developer A/B of round 5
     l->ctx->setAsync(true);   // mapping kernels are enqueued behind the tracker's; the host never waits for them
     *out = l.release();
     return LSDHIP_OK;
@@ -136,6 +137,7 @@ extern "C" int lsdloopbatch_create(int device, int w, int h, const float K4[4], 
     l->ctx->setPipeline(false);
     l->loop.reset(new lsd_slam_hip::SlamLoopBatch(w, h, K, S, first_images, images_on_device != 0, gt_depth0_host, kf_every));
     if (const char* e = std::getenv("LSDHIP_KF_LANES")) l->loop->keyframeLanes = std::atoi(e);   // developer A/B (1: keyframe changes on one stream)
+    if (const char* e = std::getenv("LSDHIP_KF_SHARED")) l->loop->sharedKeyframeChange = e[0] != '0';   // developer A/B of round 5
     l->ctx->setAsync(true);
     l->keyframes.assign((size_t)S, 0);
     *out = l.release();

@@ -500,6 +500,19 @@ class DepthMap:
     def finalizeKeyFrame(self):
         check(self.L.lsdhip_depth_finalize(self.h_), False)
 
+    @staticmethod
+    def changeKeyframeBatch(maps, new_keyframes):
+        """finalizeKeyFrame() + createKeyFrame(new_keyframes[j]) of several sequences' maps in shared launches
+        (lsdhip_depth_change_keyframe_batch); returns the rescale factors"""
+        n = len(maps)
+        for m, f in zip(maps, new_keyframes):
+            m._keep.append(f)
+        ma = (C.c_void_p * n)(*[m.h_ for m in maps])
+        fa = (C.c_void_p * n)(*[f.h_ for f in new_keyframes])
+        s = (C.c_float * n)()
+        check(maps[0].L.lsdhip_depth_change_keyframe_batch(n, ma, fa, s), False)
+        return [float(v) for v in s]
+
     def currentDepthMap(self):
         out = np.zeros((self.ctx.h, self.ctx.w), dtype=HYP_DTYPE)
         check(self.L.lsdhip_depth_download(self.h_, out.ctypes.data), False)

@@ -156,3 +156,110 @@ def test_batch_loop_follows_the_single_sequence_loops(hip, S, pipelined):
             assert np.array_equal(poses[:, s], poses[:, s - 2]), "sequence %d differs from its twin %d" % (s, s - 2)
         worst = max(max(pose_distance(poses[t, s], single[s % 2][t], po)) for t in range(n))
         assert worst < 1e-3, (s, worst)
+
+
+def test_change_keyframe_batch_equals_finalize_plus_create(hip):
+    """finalizeKeyFrame + createKeyFrame of S maps through lsdhip_depth_change_keyframe_batch (six shared launches: the finalize pass
+    with takeReActivationData and the propagation candidates fused in, propagation merge, the two regulariser passes, rescale +
+    Frame::setDepth, both keyframes' pyramids) against the two single calls per map: the new maps, both keyframes' depth pyramids and
+    statistics, the rescale factors, the new keyframes' poses and the old keyframes' re-activation data, bit for bit — twice in a row
+    (the second change starts from the propagation scratch the first one left), with updates in between."""
+    w, h = 320, 240
+    S = 4
+    seqs = [sequence(w, h, 9, seq_index=s) for s in range(S)]
+    ctx = hip.Context(w, h, seqs[0][2])
+    tr = hip.SE3Tracker(ctx)
+    tr.set_maxItsPerLvl(ODOMETRY_ITS)
+    sets = []
+    for copy in range(2):
+        cur = []
+        for s, (frames, depth0, K, gt) in enumerate(seqs):
+            kf = hip.Frame(ctx, 1000 * s, frames[0])
+            kf.setDepthFromGroundTruth(depth0)
+            dm = hip.DepthMap(ctx)
+            dm.initializeFromGTDepth(kf)
+            ref = hip.TrackingReference()
+            ref.importFrame(kf)
+            kf.clearDepthHasBeenUpdatedFlag()
+            cur.append({"kf": kf, "map": dm, "ref": ref, "pose": IDENT7.copy(), "old": []})
+        sets.append(cur)
+
+    def track_all(t):
+        out = [[], []]
+        for copy in range(2):
+            for s in range(S):
+                st = sets[copy][s]
+                fr = hip.Frame(ctx, 1000 * s + t, seqs[s][0][t])
+                st["pose"] = tr.trackFrame(st["ref"], fr, st["pose"])
+                out[copy].append(fr)
+        return out
+
+    def update_all(frames):
+        for copy in range(2):
+            for s in range(S):
+                st = sets[copy][s]
+                st["map"].updateKeyframe([frames[copy][s]])
+                st["ref"].importFrame(st["kf"])
+                st["kf"].clearDepthHasBeenUpdatedFlag()
+
+    def compare(tag):
+        for s in range(S):
+            a, b = sets[0][s], sets[1][s]
+            assert_maps_equal(a["map"].currentDepthMap(), b["map"].currentDepthMap(), "%s sequence %d" % (tag, s))
+            for fa, fb, name in [(a["kf"], b["kf"], "keyframe")] + [(x, y, "old keyframe %d" % i) for i, (x, y) in enumerate(zip(a["old"], b["old"]))]:
+                for lvl in range(5):
+                    assert_bit_equal(fa.idepth(lvl), fb.idepth(lvl), "%s sequence %d %s idepth level %d" % (tag, s, name, lvl))
+                    assert_bit_equal(fa.idepthVar(lvl), fb.idepthVar(lvl), "%s sequence %d %s idepthVar level %d" % (tag, s, name, lvl))
+                sa, sb = fa.stats(), fb.stats()
+                assert sa["meanIdepth"] == sb["meanIdepth"] and sa["numPoints"] == sb["numPoints"], (tag, s, name, sa, sb)
+                assert fa.depthHasBeenUpdatedFlag() == fb.depthHasBeenUpdatedFlag()
+                assert np.array_equal(np.asarray(fa.thisToParent_raw()), np.asarray(fb.thisToParent_raw())), (tag, s, name)
+
+    t = 1
+    for change in range(2):
+        for _ in range(2):
+            update_all(track_all(t))
+            t += 1
+        frames = track_all(t)
+        t += 1
+        scalesA = []
+        for s in range(S):
+            st = sets[0][s]
+            st["map"].finalizeKeyFrame()
+            scalesA.append(st["map"].createKeyFrame(frames[0][s]))
+        scalesB = hip.DepthMap.changeKeyframeBatch([sets[1][s]["map"] for s in range(S)], frames[1])
+        assert [np.float32(v) for v in scalesA] == [np.float32(v) for v in scalesB], (scalesA, scalesB)
+        for copy in range(2):
+            for s in range(S):
+                st = sets[copy][s]
+                st["old"].append(st["kf"])
+                st["kf"] = frames[copy][s]
+                st["ref"].importFrame(st["kf"])
+                st["kf"].clearDepthHasBeenUpdatedFlag()
+                st["pose"] = IDENT7.copy()
+        compare("change %d" % change)
+        # Frame::takeReActivationData of the finalised keyframes: what setFromExistingKF rebuilds from it
+        for s in range(S):
+            ma, mb = hip.DepthMap(ctx), hip.DepthMap(ctx)
+            ma.setFromExistingKF(sets[0][s]["old"][-1])
+            mb.setFromExistingKF(sets[1][s]["old"][-1])
+            assert_maps_equal(ma.currentDepthMap(), mb.currentDepthMap(), "change %d sequence %d re-activation" % (change, s))
+    update_all(track_all(t))
+    compare("after the second change")
+
+
+def test_change_keyframe_batch_rejects_bad_arguments(hip):
+    w, h = 320, 240
+    frames, depth0, K, gt = sequence(w, h, 3)
+    ctx = hip.Context(w, h, K)
+    kf = hip.Frame(ctx, 0, frames[0])
+    kf.setDepthFromGroundTruth(depth0)
+    dm = hip.DepthMap(ctx)
+    dm.initializeFromGTDepth(kf)
+    fr = hip.Frame(ctx, 1, frames[1])                       # never tracked: no tracking parent
+    with pytest.raises(Exception):
+        hip.DepthMap.changeKeyframeBatch([dm], [fr])
+    with pytest.raises(Exception):
+        hip.DepthMap.changeKeyframeBatch([hip.DepthMap(ctx)], [fr])   # no active keyframe
+    with pytest.raises(Exception):
+        hip.DepthMap.changeKeyframeBatch([dm], [kf])                   # the new keyframe is the current one
