@@ -253,7 +253,7 @@ int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame
 /* trackFrame for n independent (keyframe, frame) pairs in the same kernel launches (one job per blockIdx.y): the decisions and
  * per-point arithmetic of n lsdhip_tracker_track calls, sums in another order (fewer, fatter workgroups per job); n evaluations share
  * every launch.  From 8 jobs on the batch runs in throughput mode: a step = one LM launch (one workgroup per job) + one evaluation
- * launch whose strips x jobs fill the chip's 1024 workgroup slots.  This is how several sequences share
+ * launch whose strips x jobs fill the chip's 768 workgroup slots.  This is how several sequences share
  * one GPU (BASELINE configs[3] with fewer GPUs than sequences) and how batches of keyframe candidates are checked
  * (SURVEY.md §8(f) N2).  inits: n x 7 doubles, results: n records.  Returns LSDHIP_DIVERGED if any job diverged. */
 int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,

@@ -12,7 +12,7 @@ SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblsdhip.so")
 # kernels allowed to spill a few loop-invariant registers (long, memory-bound batch kernels where occupancy matters more;
 # the latency-critical single-job kernels must stay at zero)
-SCRATCH_OK = ("k_observe_walk_batch",)   # (only its LSD_WALK_OCC4 variant build spills: 32 bytes per lane)
+SCRATCH_OK = ()
 SOURCES = ["host_math.cpp", "frame.hip", "tracker.hip", "depthmap.hip", "sim3.hip"]
 # -disable-promote-alloca-to-lds: a private array the optimiser cannot split must show up as scratch (and fail the
 # guard below) instead of silently moving to LDS, where indexing it by thread costs a read of the AQL dispatch packet

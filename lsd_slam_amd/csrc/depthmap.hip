@@ -746,12 +746,9 @@ __global__ __launch_bounds__(1024) void k_observe_select_batch(const ObserveArgs
     a.queue[off] = make_float4(__int_as_float(x + y * a.w), epx, epy, 0.f);
   }
 }
-#ifdef LSD_WALK_OCC4
-#define LSD_WALK_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))     // A/B of round 5: 128 registers + 32 bytes of scratch per lane against 144 registers
-#else
-#define LSD_WALK_ATTR
-#endif
-__global__ __launch_bounds__(64) LSD_WALK_ATTR void k_observe_walk_batch(const ObserveArgs* __restrict__ items, const int* __restrict__ counts, int n) {
+// (144 registers, three waves per SIMD; capped at 128 — four waves, 32 bytes of scratch per lane — the 32-sequence loop ran the same:
+// profiles/r05_notes.md)
+__global__ __launch_bounds__(64) void k_observe_walk_batch(const ObserveArgs* __restrict__ items, const int* __restrict__ counts, int n) {
   __shared__ int s_incl[LSD_OBS_WALK_MAX_MAPS];     // chunks of 64 entries of maps 0 .. m (inclusive)
   __shared__ int s_cnt[LSD_OBS_WALK_MAX_MAPS];
   const int lane = threadIdx.x;

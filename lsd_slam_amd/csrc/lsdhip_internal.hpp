@@ -155,7 +155,9 @@ struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_OBS_SPLIT_MIN_MAPS 4             // lsdhip_depth_update_batch: select + walk launches from this many maps on
 #define LSD_OBS_WALK_WAVES 4096             // one-wave workgroups of the walk launch
 #define LSD_BATCH_THROUGHPUT_MIN_JOBS 8     // lsdhip_tracker_track_batch: throughput mode from this many jobs on
-#define LSD_BATCH_STRIP_WORKGROUPS 1024     // strips x jobs of a throughput-mode evaluation launch (4 workgroups per CU)
+#define LSD_BATCH_SPEC_MAX 4                // reject-chain speculation of batches in throughput mode: most trials per step (levels without a mask)
+#define LSD_BATCH_SPEC_PIXELS 2560000       // ... trials per step at a level = what keeps jobs x trials x pixels of the level within this
+#define LSD_BATCH_STRIP_WORKGROUPS 768      // strips x jobs of a throughput-mode evaluation launch (3 workgroups per CU)
 struct lsdhip_frame;
 
 // Host-side state of a context (arena free list, deferred-result slot ring and its owner tables, profiling events, the
@@ -345,7 +347,8 @@ struct lsdhip_tracker {
   TrackJob* d_bjobs = nullptr;
   TrackJob* h_bjobs = nullptr;        // pinned staging
   TrackState* d_bstate = nullptr;     // [capacity][2]
-  float* d_bscratch = nullptr;        // TrackScratch arena x capacity (sums | topkey | topval, each [job][...])
+  float* d_bscratch = nullptr;        // TrackScratch arena x capacity (sums | topkey | topval | recs, each [job][parity][trial][...])
+  int batchRecent[4] = {0, 0, 0, 0};  // rounds the last batches needed: size the launch budget of the next one
   TrackSummary* h_bsummary = nullptr; // pinned, device-mapped
   float* d_pts = nullptr;         // permaref point upload
   int pts_capacity = 0;

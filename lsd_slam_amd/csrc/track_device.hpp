@@ -597,34 +597,7 @@ __device__ __forceinline__ void accumulate_point(const PointOut& o, float (&acc)
   acc[RS_ERR] = __builtin_fmaf(resw, o.res, acc[RS_ERR]);
 }
 
-// UNI: every value is the same in all lanes (one job, one level, one pose per workgroup): say so (v_readfirstlane), so that the ~40
-// of them live in scalar registers instead of one vector register each — the throughput-mode evaluation is register-bound
-// (150 -> 128 vector registers: four waves per SIMD instead of three).
-__device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ gfloat* uni_p(gfloat* p) {
-  const unsigned long long u = (unsigned long long)p;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-  return (gfloat*)(((unsigned long long)hi << 32) | lo);
-}
-template <bool UNI = false>
 __device__ __forceinline__ void make_ctx_dev(const TrackJob& jobr, const TrackState& S, int level, EvalCtx& a) {
-  if (UNI) {
-    const TrackJob* job = &jobr;
-    const TrackLevel& L = job->lv[level];
-    a.kf_idepth = uni_p((gfloat*)L.kf_idepth); a.kf_idepthVar = uni_p((gfloat*)L.kf_idepthVar); a.kf_image = uni_p((gfloat*)L.kf_image);
-    a.fr_grad = uni_p((gfloat*)L.fr_grad);
-    a.pts_pos = uni_p((gfloat*)L.pts_pos); a.pts_colvar = uni_p((gfloat*)L.pts_colvar); a.npts = uni_i(L.npts); a.w = uni_i(L.w); a.h = uni_i(L.h);
-    a.fx = uni_f(L.fx); a.fy = uni_f(L.fy); a.cx = uni_f(L.cx); a.cy = uni_f(L.cy);
-    a.fxi = uni_f(L.fxi); a.fyi = uni_f(L.fyi); a.cxi = uni_f(L.cxi); a.cyi = uni_f(L.cyi);
-#pragma unroll
-    for (int i = 0; i < 9; i++) a.R[i] = uni_f(S.R[i]);
-#pragma unroll
-    for (int i = 0; i < 3; i++) a.t[i] = uni_f(S.t[i]);
-    a.aff_a = uni_f(S.aff_a); a.aff_b = uni_f(S.aff_b);
-    a.cameraPixelNoise2 = uni_f(job->cameraPixelNoise2); a.var_weight = uni_f(job->var_weight); a.huber_half = uni_f(job->huber_half);
-    return;
-  }
   const TrackJob* job = &jobr;
   const TrackLevel& L = job->lv[level];
   a.kf_idepth = (gfloat*)L.kf_idepth; a.kf_idepthVar = (gfloat*)L.kf_idepthVar; a.kf_image = (gfloat*)L.kf_image; a.fr_grad = (gfloat*)L.fr_grad;

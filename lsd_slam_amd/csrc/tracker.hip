@@ -74,12 +74,13 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     asm volatile("" ::"s"(warm));   // the loads complete here, in the shadow of the prologue's own argument loads
   }
   if (BATCH) {
-    const size_t j = blockIdx.y, rows = (size_t)sc.max_rows;
+    const size_t j = blockIdx.y, rows = (size_t)sc.max_rows, cm = (size_t)sc.cmax;
     st2 += 2 * j;
     out += j;
-    sc.sums += j * 2 * RS_COLS * rows;
-    sc.topkey += j * 2 * rows;
-    sc.topval += j * 2 * rows * 96;
+    sc.sums += j * 2 * cm * RS_COLS * rows;
+    sc.topkey += j * 2 * cm * rows;
+    sc.topval += j * 2 * cm * rows * 96;
+    if (sc.recs) sc.recs += j * 2 * cm * 32;
   }
   constexpr int WAVES = BLOCK / 64;
   constexpr int SUMW = WAVES - 1;                    // waves that sum partials (the last one does the tail work)
@@ -88,15 +89,9 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   __shared__ TrackState S;
   __shared__ LmShared sh;
   __shared__ LmPar s_par;
-  // the workgroup reduction handles the columns in NPASS batches: 2 halves its LDS (measured slower for the latency-bound single jobs);
-  // the throughput-mode evaluation takes 2: 22 instead of 44 KB, so that four workgroups fit a CU beside four waves per SIMD
-#ifdef LSD_EVAL_R04      // A/B build of round 5: the evaluation launch as rounds 2-4 had it (44 KB, 150 registers: three workgroups per CU)
+  // the workgroup reduction handles the columns in NPASS batches (2 halves the LDS; measured slower — also for the throughput-mode
+  // evaluation, where it would let four workgroups share a CU: profiles/r05_notes.md)
   constexpr int NPASS = 1;
-  constexpr bool EVAL_UNI = false;
-#else
-  constexpr int NPASS = (BATCH && MODE == TS_EVAL) ? 2 : 1;
-  constexpr bool EVAL_UNI = BATCH && MODE == TS_EVAL;
-#endif
   constexpr int CPP = (RS_END + NPASS - 1) / NPASS;      // columns per batch
   constexpr int RSLICE_ = BLOCK / CPP;
   __shared__ float s_sum[(NSLICE > RSLICE_ ? NSLICE : RSLICE_)][64];
@@ -120,7 +115,10 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   const float* topval_in0 = sc.topval + (size_t)parity * cmax * max_rows * 96;
   float* topval_out = sc.topval + (size_t)outp * cmax * max_rows * 96;
   constexpr int NSLOT = 16;                                  // row slots of the column sums: slot s adds rows s, s + 16, ...
-  constexpr int TRIALS_MAX = BATCH ? 1 : LSD_SPEC_MAX;      // batches run one trial per step (cmax == 1)
+  // trials a launch can finish: single jobs up to LSD_SPEC_MAX; batches in throughput mode up to LSD_BATCH_SPEC_MAX (the LM launch has one
+  // workgroup per (trial, job): each proposes its own retry, as the trial groups of a single job's launch do); small batches one
+  constexpr int TRIALS_MAX = BATCH ? (MODE == TS_LM ? LSD_BATCH_SPEC_MAX : 1) : LSD_SPEC_MAX;
+  constexpr bool SPEC_LM = (!BATCH && MODE == TS_FUSED) || (BATCH && MODE == TS_LM);
   __shared__ __attribute__((aligned(16))) float s_sumT[TRIALS_MAX][NSLOT][RS_COLS];    // per pending trial: column sums by row slot
   __shared__ float s_subT[TRIALS_MAX][3][32];               // ... K2/K3 contributions of its (up to 3) tail points
   __shared__ int s_nsubT[TRIALS_MAX];
@@ -172,7 +170,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
   } else {
     copy_words<sizeof(TrackState) / 4>(&S, st2 + parity, tid, BLOCK);
-    if (!BATCH && cmax > 1 && tid < 32 * LSD_SPEC_MAX) (&s_rec[0][0])[tid] = sc.recs[(size_t)parity * cmax * 32 + (tid < 32 * cmax ? tid : 0)];
+    if (SPEC_LM && cmax > 1 && tid < 32 * TRIALS_MAX) (&s_rec[0][0])[tid] = sc.recs[(size_t)parity * cmax * 32 + (tid < 32 * cmax ? tid : 0)];
   }
   __syncthreads();
   PHASE_MARK(1);
@@ -195,12 +193,26 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     if (!leader && !needTrial && !needNext) return;
   }
 
+  if (BATCH && MODE == TS_LM) {
+    // one workgroup per (trial, job): workgroup `cand` proposes the cand-th retry down the reject chain; those without a trial leave
+    cand = (int)blockIdx.x;
+    bx = 0;
+    const int tr = (spec.specC > 1 && spec.trials[lvlPending] > 1) ? spec.trials[lvlPending] : 1;
+    if (!leader && !(S.pending && cand < tr)) return;
+  }
+  if (BATCH && MODE == TS_EVAL) {
+    // workgroup = (trial, strip) of the job's level
+    const int nbl = job.lv[lvlPending].nblocks;
+    cand = (int)blockIdx.x / nbl;
+    bx = (int)blockIdx.x - cand * nbl;
+  }
+
   if (MODE != TS_EVAL && S.pending) {
     // Finish the trials of the previous launch, in the order the LM loop would have run them.  All their partial sums, order
     // keys and tail contributions are fetched TOGETHER (one memory round trip, whatever the number of trials), then wave 0 walks
     // through them without further barriers: totals -> LM decision -> (rejected, retry waiting) next trial, whose increment
     // and pose come from the record the workgroups that evaluated it left behind.
-    const int ncandPending = S.ncand < 1 ? 1 : (S.ncand > LSD_SPEC_MAX ? LSD_SPEC_MAX : S.ncand);
+    const int ncandPending = S.ncand < 1 ? 1 : (S.ncand > TRIALS_MAX ? TRIALS_MAX : S.ncand);
     const int level = S.level;
     const int nb = job.lv[level].nblocks;
     const size_t trialStrideF4 = (size_t)RS_COLS * max_rows / 4;
@@ -373,7 +385,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         };
         typedef std::integral_constant<int, 1> I1;
         typedef std::integral_constant<int, 3> I3;
-        typedef std::integral_constant<int, LSD_SPEC_MAX> IM;
+        typedef std::integral_constant<int, TRIALS_MAX> IM;
         if (ncandPending == 1) {
           if (K <= 2) colsum(std::integral_constant<int, 2>(), I1(), 0);
           else if (K <= 5) colsum(std::integral_constant<int, 5>(), I1(), 0);
@@ -488,9 +500,9 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         PHASE_MARK(3);
 #ifdef LSD_PHASE_TRACE
         if (blockIdx.x == 0 && tid == 0) { tr_[19] = (unsigned long long)ncandPending; tr_[7] = (unsigned long long)pc; }
-        lm_wave<!BATCH && MODE == TS_FUSED>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, leader ? tr_ : nullptr, pc, cand);
+        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, leader ? tr_ : nullptr, pc, cand);
 #else
-        lm_wave<!BATCH && MODE == TS_FUSED>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, nullptr, pc, cand);
+        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, nullptr, pc, cand);
 #endif
       }
     }
@@ -526,9 +538,9 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 
   if (MODE == TS_LM) {
     __syncthreads();              // (every wave has tested S.pending before it changes: see the note at the residual evaluation below)
-    if (tid == 0) S.pending = 1;
+    if (tid == 0) { S.pending = 1; S.numLaunches = S.numLaunches + 1; }   // (numLaunches of a batch job: its rounds)
     __syncthreads();
-    copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
+    if (leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
     return;
   }
 
@@ -547,7 +559,15 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   topval_out += (size_t)cand * max_rows * 96;
   const int tile = xcd_tile(bx, nb);
   EvalCtx a;
-  make_ctx_dev<EVAL_UNI>(job, S, level, a);
+  make_ctx_dev(job, S, level, a);
+  if (BATCH && MODE == TS_EVAL && cand > 0) {
+    // a retry further down the reject chain: its pose is in the record the LM workgroup that proposed it left
+    const float* rec = sc.recs + ((size_t)parity * cmax + cand) * 32;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.R[i] = rec[13 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) a.t[i] = rec[22 + i];
+  }
   gbyte* wasGood = (gbyte*)(job.lv[level].writeMask ? (cand == 0 ? job.wasGood : spec.wasGoodSide + (size_t)(cand - 1) * spec.maskStride) : nullptr);
   const int work = a.npts >= 0 ? a.npts : a.w * a.h;
   float acc[RS_END];
@@ -568,11 +588,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     unsigned vmask = 0;      // 4 validity bits per chunk
     int wcount = 0;          // valid pixels of this wave (uniform)
     // all validity loads of the strip are issued together (one memory round trip instead of one per 1024-pixel chunk)
-#ifdef LSD_EVAL_R04
-    constexpr int CHMAX = 8;
-#else
-    constexpr int CHMAX = 6;                       // tilePx <= 5376 (fill_level)
-#endif
+    constexpr int CHMAX = 8;                       // tilePx <= 8192 (fill_level)
     v4f v4s[CHMAX], d4s[CHMAX];
 #pragma unroll
     for (int c = 0; c < CHMAX; c++) {
@@ -1060,16 +1076,12 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   if (t->batch_jobs >= LSD_BATCH_THROUGHPUT_MIN_JOBS && npts < 0 && (L.w & 3) == 0) {
     // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
     static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : LSD_BATCH_STRIP_WORKGROUPS;   // developer sweep
-    // strips x jobs = the chip's 1024 workgroup slots (4 per CU) where the level is large enough: one full round of equal strips;
+    // strips x jobs = the chip's 768 workgroup slots (3 per CU) where the level is large enough: one full round of equal strips;
     // a strip is a multiple of 256 pixels (the lanes take 4 consecutive pixels each)
     long long px = (((long long)work * t->batch_jobs + wgTarget - 1) / wgTarget + 255) & ~255LL;
     if (px < 1024) px = 1024;
-#ifdef LSD_EVAL_R04
-    if (px > 8192) px = 8192;
-#else
-    if (px > 5376) px = 5376;                                  // the strip's list lives in the reduction's LDS (two column passes: 5405 words)
-#endif
-    if ((work + px - 1) / px <= t->max_blocks) {               // (levels beyond 1.6 Mpixel keep the grid-stride form)
+    if (px > 8192) px = 8192;                                  // the strip's list lives in the reduction's LDS (10545 words)
+    if ((work + px - 1) / px <= t->max_blocks) {               // (levels beyond 2.4 Mpixel keep the grid-stride form)
       L.tilePx = (int)px;
       L.nblocks = (int)((work + px - 1) / px);
       L.singlePass = 0;
@@ -1633,7 +1645,7 @@ static int batch_reserve(lsdhip_tracker* t, int n) {
   if (t->d_bjobs) { (void)hipFree(t->d_bjobs); (void)hipFree(t->d_bstate); (void)hipFree(t->d_bscratch); (void)hipHostFree(t->h_bjobs); (void)hipHostFree(t->h_bsummary); }
   t->batch_capacity = n < 8 ? 8 : n;
   const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
-  const size_t per_job = 2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4;
+  const size_t per_job = (size_t)LSD_BATCH_SPEC_MAX * (2 * RS_COLS * rows * 4 + 2 * rows * 16 + 2 * rows * 96 * 4 + 2 * 32 * 4);
   HIPCHK(hipMalloc((void**)&t->d_bjobs, B * sizeof(TrackJob)));
   HIPCHK(hipMalloc((void**)&t->d_bstate, B * 2 * sizeof(TrackState)));
   HIPCHK(hipMalloc((void**)&t->d_bscratch, B * per_job));
@@ -1641,6 +1653,21 @@ static int batch_reserve(lsdhip_tracker* t, int n) {
   HIPCHK(hipHostMalloc((void**)&t->h_bjobs, B * sizeof(TrackJob), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&t->h_bsummary, B * sizeof(TrackSummary), hipHostMallocMapped));
   return LSDHIP_OK;
+}
+// scratch of a batch: arrays over [job][parity][trial]; cmax = trial slots per parity (1: no speculation)
+static TrackScratch batch_scratch(lsdhip_tracker* t, int cmax) {
+  TrackScratch sc;
+  const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks, C = (size_t)LSD_BATCH_SPEC_MAX;
+  sc.sums = t->d_bscratch;
+  sc.topkey = (int4*)(t->d_bscratch + B * C * 2 * RS_COLS * rows);
+  sc.topval = t->d_bscratch + B * C * 2 * RS_COLS * rows + B * C * 2 * 4 * rows;
+  sc.recs = cmax > 1 ? t->d_bscratch + B * C * 2 * RS_COLS * rows + B * C * 2 * 4 * rows + B * C * 2 * 96 * rows : nullptr;
+  sc.max_rows = t->max_blocks;
+  sc.cmax = cmax;
+#ifdef LSD_PHASE_TRACE
+  sc.trace = nullptr;
+#endif
+  return sc;
 }
 // With many jobs in flight the other jobs hide a job's latency, so each job gets fewer, fatter workgroups: the
 // per-workgroup LM replay (the price of the launch needing no inter-workgroup communication) shrinks accordingly.
@@ -1667,32 +1694,57 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
     t->h_bsummary[j].done = 0;
   }
   HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
-  TrackScratch sc;
-  {
-    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
-    sc.sums = t->d_bscratch;
-    sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
-    sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
-    sc.max_rows = t->max_blocks;
-    sc.cmax = 1;
-    sc.recs = nullptr;
-#ifdef LSD_PHASE_TRACE
-    sc.trace = nullptr;
-#endif
+  // Reject-chain speculation in throughput mode (as single jobs have it, SE3Tracker.cpp:341-447): a step evaluates the next `trials`
+  // retries of the LM loop side by side, the next step consumes them in the reference's order — same decisions, same evaluation
+  // counts, fewer dependent rounds.  Per level as many trials as keep jobs x trials x pixels of the level within LSD_BATCH_SPEC_PIXELS
+  // (a round must not cost more than the rounds it saves); one at the level that writes refPixelWasGood (no side planes in batches).
+  TrackSpec spec = TrackSpec{};
+  int lmGrid = 1;
+  static const int specMaxEnv = getenv("LSDHIP_BATCH_SPEC") ? atoi(getenv("LSDHIP_BATCH_SPEC")) : LSD_BATCH_SPEC_MAX;   // developer A/B (1: off)
+  int specMax = specMaxEnv < 1 ? 1 : (specMaxEnv > LSD_BATCH_SPEC_MAX ? LSD_BATCH_SPEC_MAX : specMaxEnv);
+  if (t->specC < specMax) specMax = t->specC;        // lsdhip_tracker_set_speculation(t, 1, 0): one evaluation per step, batches too
+  if (split && specMax > 1) {
+    for (int l = 0; l < LSD_LEVELS; l++) spec.trials[l] = 1;
+    const TrackJob& j0 = t->h_bjobs[0];
+    for (int l = j0.lastLevel; l <= j0.topLevel; l++) {
+      bool ok = true;
+      for (int j = 0; j < n; j++) ok = ok && t->h_bjobs[j].lv[l].tilePx > 0 && !t->h_bjobs[j].lv[l].writeMask && t->h_bjobs[j].lastLevel <= l && t->h_bjobs[j].topLevel >= l;
+      if (!ok) continue;
+      long long tr = (long long)LSD_BATCH_SPEC_PIXELS / ((long long)j0.lv[l].w * j0.lv[l].h * n);
+      if (tr > specMax) tr = specMax;
+      if (tr < 1) tr = 1;
+      spec.trials[l] = (int)tr;
+      if (tr > lmGrid) lmGrid = (int)tr;
+    }
+    spec.specC = lmGrid;
+    // the evaluation launch holds (trial, strip) workgroups of the level with the most of them
+    for (int j = 0; j < n; j++) {
+      const TrackJob& job = t->h_bjobs[j];
+      for (int l = job.lastLevel; l <= job.topLevel; l++) if (job.lv[l].nblocks * spec.trials[l] > grid) grid = job.lv[l].nblocks * spec.trials[l];
+    }
   }
+  const TrackScratch sc = batch_scratch(t, split && lmGrid > 1 ? LSD_BATCH_SPEC_MAX : 1);
   TrackSummary* d_sum = nullptr;
   HIPCHK(hipHostGetDevicePointer((void**)&d_sum, t->h_bsummary, 0));
   if (int rcp = prof_collect(c)) return rcp;
-  int budget = 26, parity = 0, first = 1, guard = 0;
+  // budget of rounds: what the recent batches needed (+ the finishing step and a margin); launches behind the last job's finishing step
+  // cost ~3 us each
+  int budget = 26;
+  if (split && t->batchRecent[0] > 0) {
+    budget = 0;
+    for (int i = 0; i < 4; i++) if (t->batchRecent[i] > budget) budget = t->batchRecent[i];
+    budget += 3;
+  }
+  int parity = 0, first = 1, guard = 0;
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     for (int i = 0; i < budget; i++) {
       if (split) {
-        // throughput mode: one LM workgroup per job, then a pure evaluation launch over all jobs' strips
-        hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(1, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
-                           t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
+        // throughput mode: one LM workgroup per (trial, job), then a pure evaluation launch over all jobs' (trial, strip) pairs
+        hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(lmGrid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
+                           t->d_bstate, sc, d_sum, parity, first, spec);
         hipLaunchKernelGGL((k_track_step<256, true, TS_EVAL>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
-                           t->d_bstate, sc, d_sum, 1 - parity, 0, TrackSpec{});
+                           t->d_bstate, sc, d_sum, 1 - parity, 0, spec);
       } else {
         hipLaunchKernelGGL((k_track_step<256, true>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, parity, first, TrackSpec{});
@@ -1714,6 +1766,12 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   }
   if (c->prof_on)
     for (int j = 0; j < n; j++) { c->prof_bytes += t->h_bsummary[j].bytes; c->prof_launches += t->h_bsummary[j].numEvaluations; }
+  if (split) {
+    int rounds = 0;
+    for (int j = 0; j < n; j++) if (t->h_bsummary[j].numLaunches > rounds) rounds = t->h_bsummary[j].numLaunches;
+    t->batchRecent[3] = t->batchRecent[2]; t->batchRecent[2] = t->batchRecent[1]; t->batchRecent[1] = t->batchRecent[0]; t->batchRecent[0] = rounds;
+    t->numLaunches = rounds;
+  }
   return LSDHIP_OK;
 }
 
@@ -1819,19 +1877,7 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
   t->cap_override = 0;
   t->batch_jobs = 0;
   HIPCHK(hipMemcpyAsync(t->d_bjobs, t->h_bjobs, (size_t)n * sizeof(TrackJob), hipMemcpyHostToDevice, c->stream));
-  TrackScratch sc;
-  {
-    const size_t B = (size_t)t->batch_capacity, rows = (size_t)t->max_blocks;
-    sc.sums = t->d_bscratch;
-    sc.topkey = (int4*)(t->d_bscratch + B * 2 * RS_COLS * rows);
-    sc.topval = t->d_bscratch + B * 2 * RS_COLS * rows + B * 2 * 4 * rows;
-    sc.max_rows = t->max_blocks;
-    sc.cmax = 1;
-    sc.recs = nullptr;
-#ifdef LSD_PHASE_TRACE
-    sc.trace = nullptr;
-#endif
-  }
+  const TrackScratch sc = batch_scratch(t, 1);
   TrackSummary* d_sum = nullptr;
   HIPCHK(hipHostGetDevicePointer((void**)&d_sum, t->h_bsummary, 0));
   struct EventPair {      // destroyed on every exit path

@@ -949,3 +949,41 @@ def test_speculation_default_matches_oracle_sequence(oracle, hip):
         assert (fo.wasgood() != fg.refPixelWasGoodNoCreate()).mean() < 2e-3
         assert trg.launch_stats()[0] < trg.last.numEvaluations
         init = np.array(r.frameToRef)
+
+
+@pytest.mark.gpu
+def test_track_batch_speculation_is_bit_identical_to_one_trial_per_step(oracle, hip):
+    """Throughput-mode batches evaluate the next retries of a job's reject chain side by side (levels without a mask) and consume them
+    in the reference's order: same decisions, same evaluation counts, the same poses and masks bit for bit as one evaluation per step
+    (lsdhip_tracker_set_speculation(t, 1, 0)) — in fewer rounds."""
+    w, h = 320, 240
+    seqs = [sequence(w, h, 5, seq_index=s) for s in range(4)]
+    ctx = hip.Context(w, h, seqs[0][2])
+    results = []
+    for trials in (1, 0):
+        tr = hip.SE3Tracker(ctx)
+        tr.set_maxItsPerLvl(ODOMETRY_ITS)
+        if trials == 1:
+            tr.set_speculation(1)
+        refs, frs = [], []
+        for s, (frames, depth0, K, gt) in enumerate(seqs):
+            for k in (1, 2, 3, 4):
+                kf = hip.Frame(ctx, 100 * s + 10 * k, frames[0])
+                depth = depth0.copy()
+                if k == 3:
+                    depth[::2, 1::3] = 0
+                kf.setDepthFromGroundTruth(depth)
+                ref = hip.TrackingReference()
+                ref.importFrame(kf)
+                refs.append(ref)
+                frs.append(hip.Frame(ctx, 100 * s + 10 * k + 1, frames[k]))
+        poses, recs = tr.trackFrameBatch(refs, frs, np.tile(IDENT7, (16, 1)))
+        rounds = tr.launch_stats()[0]
+        results.append((np.asarray(poses).copy(), [r.numEvaluations for r in recs], [r.lastResidual for r in recs],
+                        [f.refPixelWasGoodNoCreate().copy() for f in frs], rounds))
+    (p1, e1, r1, m1, n1), (p0, e0, r0, m0, n0) = results
+    assert np.array_equal(p1, p0), np.abs(p1 - p0).max()
+    assert e1 == e0 and r1 == r0
+    for a, b in zip(m1, m0):
+        assert np.array_equal(a, b)
+    assert n0 < n1, (n0, n1)          # the reject chains collapsed: fewer rounds for the same evaluations
