@@ -364,6 +364,10 @@ int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame** refs, int 
  * last != 0 on the final part of the pass (it swaps the validity planes).  Rows no part covers must be refreshed by the caller before
  * the next pass reads them (row-band decomposition: they are another band's rows and arrive with the halo exchange). */
 int lsdhip_depth_stage_rows(lsdhip_depthmap* dm, int stage, int tile_row0, int n_tile_rows, int last);
+/* n such parts (stage 5), of the same or of different maps of one context, in ONE launch (blockIdx.z = part): the windows of a process in
+ * the row-band decomposition (BASELINE.json configs[4]).  No validity planes are swapped: lsdhip_depth_stage_rows(dm, 5, 0, 0, 1) per map
+ * once its parts are queued. */
+int lsdhip_depth_stage_rows_batch(lsdhip_ctx* c, int n, lsdhip_depthmap** maps, const int* tile_row0, const int* n_tile_rows);
 /* smoothed idepth / variance planes of the active keyframe (what setDepth produced), device to device —
  * the payload the multi-GPU gather collects per keyframe. */
 int lsdhip_depth_copy_planes_dev(lsdhip_depthmap* dm, float* idepth_dev, float* idepthVar_dev);

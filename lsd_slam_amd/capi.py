@@ -130,6 +130,7 @@ def _signatures():
         "lsdhip_ctx_aux_join": (i, [vp]),
         "lsdhip_ctx_aux_stream": (vp, [vp]),
         "lsdhip_depth_stage_rows": (i, [vp, i, i, i, i]),
+        "lsdhip_depth_stage_rows_batch": (i, [vp, i, pvp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
         "lsdhip_tracker_launch_stats": (i, [vp, vp]),

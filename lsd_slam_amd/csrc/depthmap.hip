@@ -788,6 +788,7 @@ struct RegArgs {
   float minUseGrad, regDistVar;
   int validityTH;
   int tileRow0;             // k_reg_fused on a range of tile rows (8 rows each): first tile row of the launch (0: whole map)
+  int tileRows;             // > 0: the launch's grid may hold more tile rows than this part has (several parts per launch): the rest leave
 };
 
 // K5: regularizeDepthMapFillHolesRow (DepthMap.cpp:656-703); 5x5 validity sum replaces the integral image.
@@ -915,6 +916,7 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   const int nt = gridDim.x * gridDim.y;
   const int lin = blockIdx.x + blockIdx.y * gridDim.x;
   const int tIdx = (nt & 7) == 0 ? (lin & 7) * (nt >> 3) + (lin >> 3) : lin;
+  if (a.tileRows > 0 && tIdx / (int)gridDim.x >= a.tileRows) return;
   const int tbx = tIdx % gridDim.x, tby = tIdx / gridDim.x + a.tileRow0;
   const int x0 = tbx * 32 - HALO, y0 = tby * 8 - HALO;
   const int w = a.w, h = a.h;
@@ -1259,6 +1261,13 @@ __global__ __launch_bounds__(256) void k_kf_rescale_setdepth(const RescaleItem* 
     __syncthreads();
   }
   if (tid == 0) { it.statPartials[2 * blockIdx.x] = s_a[0]; it.statPartials[2 * blockIdx.x + 1] = s_b[0]; }
+}
+
+// parts of the fused fill-holes + regularise pass of several maps in one launch (row-band decomposition: the windows of one process),
+// blockIdx.z = part
+__global__ __launch_bounds__(256) void k_reg_rows_batch(const RegBatchItem* __restrict__ items) {
+  const RegBatchItem& it = items[blockIdx.z];
+  reg_fused_tile<true, false, false>(it.a, nullptr, nullptr, nullptr);
 }
 
 // K8: Frame::setDepth (Frame.cpp:199-243) + per-workgroup (sum, count) partials for meanIdepth / numPoints
@@ -1624,6 +1633,7 @@ static RegArgs reg_args(lsdhip_depthmap* dm, int validityTH) {
   a.regDistVar = 0.075f * 0.075f * c->params.depthSmoothingFactor * c->params.depthSmoothingFactor;  // REG_DIST_VAR
   a.validityTH = validityTH;
   a.tileRow0 = 0;
+  a.tileRows = 0;
   return a;
 }
 static void swap_valid(lsdhip_depthmap* dm) { std::swap(dm->cur.valid, dm->d_validSnap); }
@@ -2070,6 +2080,7 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
   lsdhip_host_mark(12);
   rc = timing_end(dm, ev);
   if (rc) return rc;
+#ifdef LSD_DEVTOOLS
   {
     const size_t npx = (size_t)c->w * c->h;
     const int fid = refs[n - 1]->id;
@@ -2084,6 +2095,7 @@ extern "C" int lsdhip_depth_update(lsdhip_depthmap* dm, lsdhip_frame** refs, int
     lsd_trace_sum(c, lsd_map_stream(c), 38, fid, lsd_depth_latest(kf)[1], npx);
     lsd_trace_sum(c, lsd_map_stream(c), 39, fid, lsd_depthvar_latest(kf)[1], npx);
   }
+#endif
   if (lsd_m_record(c) < 0) return LSDHIP_E_HIP;
   if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   dm->msUpdate = ema(dm->msUpdate, now_ms() - t0);   // host wall time of the call (enqueue time only in async mode)
@@ -2582,6 +2594,41 @@ extern "C" int lsdhip_depth_stage_rows(lsdhip_depthmap* dm, int stage, int tile_
   int rc = fill_regularize_rows(dm, VAL_SUM_MIN_FOR_KEEP, tile_row0, n_tile_rows, last != 0);
   if (rc) return rc;
   if (!c->async) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
+  return LSDHIP_OK;
+}
+
+extern "C" int lsdhip_depth_stage_rows_batch(lsdhip_ctx* c, int n, lsdhip_depthmap** maps, const int* tile_row0, const int* n_tile_rows) {
+  if (!c || n < 0 || (n > 0 && (!maps || !tile_row0 || !n_tile_rows))) return LSDHIP_E_ARG;
+  if (n == 0) return LSDHIP_OK;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  const int T = (c->h + 7) / 8;
+  int maxRows = 0;
+  for (int k = 0; k < n; k++) {
+    if (!maps[k] || maps[k]->ctx != c) return LSDHIP_E_ARG;
+    if (!maps[k]->activeKeyFrame) { lsd_set_error("depth stage: no active keyframe"); return LSDHIP_E_STATE; }
+    if (tile_row0[k] < 0 || n_tile_rows[k] <= 0 || tile_row0[k] + n_tile_rows[k] > T) { lsd_set_error("depth stage rows: tile rows [%d, %d) outside [0, %d)", tile_row0[k], tile_row0[k] + n_tile_rows[k], T); return LSDHIP_E_ARG; }
+    if (n_tile_rows[k] > maxRows) maxRows = n_tile_rows[k];
+  }
+  void* host = nullptr;
+  void* dev = nullptr;
+  int rc = lsd_args_begin(c, sizeof(RegBatchItem) * (size_t)n, &host, &dev);
+  if (rc) return rc;
+  RegBatchItem* items = (RegBatchItem*)host;
+  for (int k = 0; k < n; k++) {
+    memset((void*)&items[k], 0, sizeof(RegBatchItem));
+    items[k].a = reg_args(maps[k], VAL_SUM_MIN_FOR_KEEP);
+    items[k].a.tileRow0 = tile_row0[k];
+    items[k].a.tileRows = n_tile_rows[k];
+  }
+  const hipStream_t ms = lsd_map_stream(c);
+  rc = lsd_args_commit(c, ms);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_reg_rows_batch, dim3((c->w + 31) / 32, maxRows, n), dim3(256), 0, ms, (const RegBatchItem*)dev);
+  HIPCHK(hipGetLastError());
+  rc = lsd_args_release(c, ms);
+  if (rc) return rc;
+  if (!c->async) HIPCHK(hipStreamSynchronize(ms));
   return LSDHIP_OK;
 }
 

@@ -364,7 +364,9 @@ __global__ __launch_bounds__(256) void k_pc_write(const float* __restrict__ id, 
 // host
 // ---------------------------------------------------------------------------------------------------------
 #define LSD_FLAG_WGS 16
+#ifdef LSD_DEVTOOLS
 static void trace_dump(lsdhip_ctx* c);
+#endif
 extern "C" void lsdhip_default_params(lsdhip_params* p) {
   p->minUseGrad = 5;
   p->cameraPixelNoise2 = 4 * 4;
@@ -420,6 +422,7 @@ extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], con
 }
 // Developer instrumentation (LSDHIP_HOST_TRACE=1): host-side time between consecutive marks of the calling thread, summed per mark
 // id and printed when a context is destroyed.  Costs one steady_clock read per mark when on, one branch when off.
+#ifdef LSD_DEVTOOLS
 static const bool g_hostTraceOn = getenv("LSDHIP_HOST_TRACE") != nullptr;
 static long long g_htNs[32], g_htN[32], g_htHist[32][9];
 static thread_local long long g_htLast = 0;
@@ -445,13 +448,19 @@ static void host_trace_print() {
       fprintf(stderr, "\n");
     }
 }
+#else
+extern "C" void lsdhip_host_mark(int) {}      // (the C++ loop of include/lsd_slam_hip.hpp marks its phases: a no-op in the default library)
+static void host_trace_print() {}
+#endif
 extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   if (!c) return;
   host_trace_print();
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->mstream) (void)hipStreamSynchronize(c->mstream);
+#ifdef LSD_DEVTOOLS
   trace_dump(c);
+#endif
   if (c->d_sums) (void)hipFree(c->d_sums);
   if (c->mstream) {
     for (int i = 0; i < LSD_EVR; i++) if (c->mEv[i]) (void)hipEventDestroy(c->mEv[i]);
@@ -543,6 +552,7 @@ int lsd_m_begin(lsdhip_ctx* c) {
   if (!c->pendingMerges.empty()) return lsd_flush_merges(c);
   return LSDHIP_OK;
 }
+#ifdef LSD_DEVTOOLS
 // Experiment: kernels that touch nothing but their own buffer, queued on the mapping stream right when a tracking job starts.
 // kind 1: memory streaming (32 MB read-modify-write), 2: LDS-heavy workgroups (9.6 KB each, like k_reg_fused), 3: ALU spin.
 static const int g_pipeDummy = getenv("LSDHIP_PIPE_DUMMY") ? atoi(getenv("LSDHIP_PIPE_DUMMY")) : 0;
@@ -601,6 +611,7 @@ int lsd_pipe_dummy(lsdhip_ctx* c) {
   }
   return LSDHIP_OK;
 }
+#endif   // LSD_DEVTOOLS
 long long lsd_m_record(lsdhip_ctx* c) {
   if (!c->pipeline) return 0;
   if (c->lanes_open) { c->lane_record_pending = true; return c->mSeq + 1; }   // recorded once, where the lanes join (lsdhip_ctx_lanes_end)
@@ -630,6 +641,7 @@ bool lsd_m_done(lsdhip_ctx* c, long long seq) {
   if (c->mSeq - seq < LSD_EVR) c->mDoneSeq = seq;
   return true;
 }
+#ifdef LSD_DEVTOOLS
 static const char* g_traceSums = getenv("LSDHIP_TRACE_SUMS");
 #define LSD_TRACE_SLOTS 65536
 __global__ __launch_bounds__(256) void k_trace_sum(const uint32_t* __restrict__ p, size_t nwords, unsigned long long* out) {
@@ -697,6 +709,7 @@ int lsd_gate_open(lsdhip_ctx* c) {
   hipLaunchKernelGGL(k_gate_open, dim3(1), dim3(64), 0, c->stream, c->d_gate, c->gateSeq);
   return LSDHIP_OK;
 }
+#endif   // LSD_DEVTOOLS
 // TrackingReference::importFrame (C/Tracking/TrackingReference.cpp:71-87) as the tracking side's hand-over point: the newest
 // Frame::setDepth result of the mapping stream becomes what SE3Tracker jobs read.  A no-op on non-pipelined contexts.
 int lsd_frame_publish_depth(lsdhip_frame* f) {

@@ -156,7 +156,7 @@ struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_OBS_WALK_WAVES 4096             // one-wave workgroups of the walk launch
 #define LSD_BATCH_THROUGHPUT_MIN_JOBS 8     // lsdhip_tracker_track_batch: throughput mode from this many jobs on
 #define LSD_BATCH_SPEC_MAX 4                // reject-chain speculation of batches in throughput mode: most trials per step (levels without a mask)
-#define LSD_BATCH_SPEC_PIXELS 2560000       // ... trials per step at a level = what keeps jobs x trials x pixels of the level within this
+#define LSD_BATCH_SPEC_PIXELS 1000000       // ... trials per step at a level = what keeps jobs x trials x pixels of the level within this
 #define LSD_BATCH_STRIP_WORKGROUPS 768      // strips x jobs of a throughput-mode evaluation launch (3 workgroups per CU)
 struct lsdhip_frame;
 
@@ -432,13 +432,26 @@ long long lsd_m_record(lsdhip_ctx* c);             // record point on mstream ->
 int lsd_t_wait_m(lsdhip_ctx* c, long long seq);    // order `stream` behind M-sequence `seq`
 bool lsd_m_done(lsdhip_ctx* c, long long seq);     // has mstream passed M-sequence `seq`?  (never blocks)
 int lsd_sync_all(lsdhip_ctx* c);                   // both streams drained
-int lsd_gate_wait(lsdhip_ctx* c);                  // developer hook (LSDHIP_PIPE_GATE=1): mapping stream holds until the next tracking job starts
+// Developer instrumentation of the pipeline bug hunt of round 4 (profiles/r04_notes.md §1a) — compiled only into the LSD_DEVTOOLS build
+// (lsd_slam_amd/build.py build_variant("devtools", ["LSD_DEVTOOLS"]), loaded through LSDHIP_LIB); the default library carries none of it:
+//   LSDHIP_PIPE_GATE=1      mapping stream holds until the next tracking job starts (lsd_gate_wait / lsd_gate_open)
+//   LSDHIP_PIPE_DUMMY=<k>   unrelated kernels on the mapping stream beside a tracking job (lsd_pipe_dummy)
+//   LSDHIP_TRACE_SUMS=<f>   order-independent checksums of device buffers, queued on a stream at chosen points of the loop and written
+//                           out when the context is destroyed — two runs of the same loop are compared entry by entry (tools/trace_cmp.py)
+//   LSDHIP_TRACK_REPLAY / LSDHIP_DUMP_L0 / LSDHIP_TRACE_INPUTS / LSDHIP_TRACK_DEBUG / LSDHIP_HOST_TRACE   (tracker.hip, frame.hip)
+#ifdef LSD_DEVTOOLS
+int lsd_gate_wait(lsdhip_ctx* c);
 int lsd_gate_open(lsdhip_ctx* c);
-int lsd_pipe_dummy(lsdhip_ctx* c);   // experiment LSDHIP_PIPE_DUMMY=<kind>: unrelated kernels on the mapping stream beside a tracking job
-// developer trace (LSDHIP_TRACE_SUMS=<file>): order-independent checksums of device buffers, queued on a stream at chosen points of the
-// loop and written out when the context is destroyed — two runs of the same loop are compared entry by entry (tools/trace_cmp.py)
+int lsd_pipe_dummy(lsdhip_ctx* c);
 void lsd_trace_sum(lsdhip_ctx* c, hipStream_t s, int kind, int id, const void* p, size_t bytes);
 void lsd_trace_val(lsdhip_ctx* c, int kind, int id, unsigned long long v);
+#else
+inline int lsd_gate_wait(lsdhip_ctx*) { return LSDHIP_OK; }
+inline int lsd_gate_open(lsdhip_ctx*) { return LSDHIP_OK; }
+inline int lsd_pipe_dummy(lsdhip_ctx*) { return LSDHIP_OK; }
+inline void lsd_trace_sum(lsdhip_ctx*, hipStream_t, int, int, const void*, size_t) {}
+inline void lsd_trace_val(lsdhip_ctx*, int, int, unsigned long long) {}
+#endif
 // depth planes a Frame::setDepth writes / the most recently written ones (== d_idepth on non-pipelined contexts)
 inline float** lsd_depth_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthW : f->d_idepth; }
 inline float** lsd_depthvar_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthVarW : f->d_idepthVar; }

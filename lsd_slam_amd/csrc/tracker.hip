@@ -136,21 +136,6 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   }
 #endif
   PHASE_MARK(0);
-#ifdef LSD_TRACK_FENCE
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // developer experiment: explicit L2 invalidate at kernel start
-#define LSD_TRACK_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
-#else
-#define LSD_TRACK_RELEASE() do { } while (0)
-#endif
-#ifdef LSD_LDS_FILL
-  {   // developer build: every LDS array starts from a known pattern (hunting reads of uninitialised LDS)
-    auto fill = [&](void* p, size_t bytes) { unsigned* q = (unsigned*)p; for (size_t i = threadIdx.x; i < bytes / 4; i += BLOCK) q[i] = (unsigned)LSD_LDS_FILL; };
-    fill(&S, sizeof(S)); fill(&sh, sizeof(sh)); fill(&s_par, sizeof(s_par)); fill(s_sum, sizeof(s_sum)); fill(s_red, sizeof(s_red));
-    fill(s_wtop, sizeof(s_wtop)); fill(s_top, sizeof(s_top)); fill(s_sumT, sizeof(s_sumT)); fill(s_subT, sizeof(s_subT));
-    fill(s_nsubT, sizeof(s_nsubT)); fill(s_rec, sizeof(s_rec));
-    __syncthreads();
-  }
-#endif
   if (!BATCH && MODE == TS_FUSED && !first && !leader && st2[parity].done) return;   // launches queued behind the finishing one
   if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.seq != 0) out->seq = spec.seq;   // pinned host memory: fire and forget
   if (first) {
@@ -175,7 +160,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   __syncthreads();
   PHASE_MARK(1);
   if (S.done) {
-    if (MODE != TS_EVAL && leader) { copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK); LSD_TRACK_RELEASE(); }   // keep both buffers "done"
+    if (MODE != TS_EVAL && leader) { copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK); }   // keep both buffers "done"
     return;
   }
   const int lvlPending = S.level;
@@ -522,7 +507,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         }
       }
       if (leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
-      LSD_TRACK_RELEASE();
+     
       return;
     }
     // a workgroup that evaluates trial c > 0 leaves that trial's increment and pose for the launch that finishes it
@@ -781,7 +766,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   // the budget's last launch ends with the job unfinished: tell the host (pinned memory), which polls this next to `done` and
   // appends launches — the stream order makes them follow; no hipStreamQuery in the wait loop (each one puts a marker packet into
   // the queue the chain runs through: ~3 us per frame)
-  LSD_TRACK_RELEASE();
+ 
   if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.last != 0) out->exhausted = spec.seq;
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
@@ -904,6 +889,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   HIPCHK(hipMemsetAsync(t->d_maskSide, 0, 2 * t->maskStride * (LSD_SPEC_MAX - 1), c->stream));
   HIPCHK(hipMalloc((void**)&t->d_partials, scratch_bytes));
   HIPCHK(hipMemsetAsync(t->d_partials, 0, scratch_bytes, c->stream));
+#ifdef LSD_ORDER_CHECK
   {
     const size_t nd = 8 + 2 * 8192;
     HIPCHK(hipMalloc((void**)&t->d_dbg, nd * 8));
@@ -911,6 +897,7 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
     for (size_t i = 8; i < nd; i += 2) init[i] = ~0ull;     // (min, max) pairs of the per-launch totals hash
     HIPCHK(hipMemcpy(t->d_dbg, init.data(), nd * 8, hipMemcpyHostToDevice));
   }
+#endif
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
   HIPCHK(hipMemsetAsync(t->d_state, 0, 2 * sizeof(TrackState), c->stream));
 #ifdef LSD_PHASE_TRACE
@@ -937,9 +924,11 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
       if (c->pendingMerges[i].doneSeq == &t->maskMergeSeq[0] || c->pendingMerges[i].doneSeq == &t->maskMergeSeq[1]) c->pendingMerges.erase(c->pendingMerges.begin() + i);
       else i++;
   }
+#ifdef LSD_DEVTOOLS
   if (getenv("LSDHIP_TRACK_DEBUG") && t->dbgJobs > 0)
     fprintf(stderr, "TRACKDBG jobs %lld launches enqueued %.2f/job, budget misses %lld, host launch %.1f us/job, host wait %.1f us/job\n", t->dbgJobs,
             (double)t->dbgEnqueued / t->dbgJobs, t->dbgMisses, t->dbgLaunchNs / 1e3 / t->dbgJobs, t->dbgWaitNs / 1e3 / t->dbgJobs);
+#endif
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
 #ifdef LSD_ORDER_CHECK
@@ -958,7 +947,7 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
                     "%d launch slots hashed, %d in which the workgroups did NOT all see the same totals\n", h[0], t->dbgCum, h[1], h[2], used, split);
   }
 #endif
-  (void)hipFree(t->d_dbg);
+  if (t->d_dbg) (void)hipFree(t->d_dbg);
 #ifdef LSD_PHASE_TRACE
   if (const char* path = getenv("LSDHIP_TRACE_FILE")) {
     std::vector<unsigned long long> h(1 + 4096 * 20);
@@ -1124,9 +1113,11 @@ static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int pa
   TrackScratch sc = scratch_of(t);
   t->launchOrdinal++;
   t->spec.seq = t->jobTag ? ((t->jobTag << 12) | (t->launchOrdinal & 0xFFF)) : 0;
+#ifdef LSD_ORDER_CHECK
   t->spec.dbgCum = t->dbgCum;
   t->spec.dbgCounters = t->d_dbg;
   t->dbgCum += (unsigned long long)grid;
+#endif
   hipLaunchKernelGGL((k_track_step<256, false>), dim3(grid), dim3(256), 0, c->stream, job, (const TrackJob*)nullptr, t->d_state, sc,
                      t->d_summary, parity, first, t->spec);
 }
@@ -1143,7 +1134,9 @@ static int launch_steps(lsdhip_tracker* t, TrackJob& job, int steps, int* parity
     }
     t->spec.specGrid = grid;
   }
+#ifdef LSD_DEVTOOLS
   const auto tl0 = std::chrono::steady_clock::now();
+#endif
   for (int i = 0; i < steps; i++) {
     t->spec.last = (i + 1 == steps) ? 1 : 0;
     launch_step(t, job, grid, *parity, *first);
@@ -1151,8 +1144,10 @@ static int launch_steps(lsdhip_tracker* t, TrackJob& job, int steps, int* parity
     *first = 0;
     *parity ^= 1;
   }
+#ifdef LSD_DEVTOOLS
   t->dbgEnqueued += steps;
   t->dbgLaunchNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tl0).count();
+#endif
   HIPCHK(hipGetLastError());
   return LSDHIP_OK;
 }
@@ -1350,7 +1345,9 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
   if (t->budgetFixed > 0) budget = t->budgetFixed;
   // timing events on every 8th job only: two event packets and a host-side event query per job cost ~5 % of a frame
   const bool sample = c->prof_on && ((c->prof_tick++ & 7) == 0);
+#ifdef LSD_DEVTOOLS
   t->dbgJobs++;
+#endif
   t->jobTag = (t->jobTag % 0x7FFFF) + 1;
   t->launchOrdinal = 0;
   t->h_summary->seq = 0;
@@ -1371,8 +1368,10 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     // The finishing step writes the summary to pinned host memory and raises `done` last (system-scope fence in
     // between): poll it instead of sleeping in hipStreamSynchronize, whose wake-up costs more than two evaluations.
     // Steps of the budget still queued behind the finishing one exit immediately; later work is stream-ordered.
+#ifdef LSD_DEVTOOLS
     const auto tw0 = std::chrono::steady_clock::now();
     struct WaitClock { lsdhip_tracker* t; std::chrono::steady_clock::time_point t0; ~WaitClock() { t->dbgWaitNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } waitClock_{t, tw0};
+#endif
     c->mtx.unlock();    // nothing below touches context state until the result is in: let the mapping thread enqueue
     struct Relock { std::recursive_mutex& m; ~Relock() { m.lock(); } };
     {
@@ -1400,8 +1399,11 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     }
     lsdhip_host_mark(5);
     if (S->done) break;
+#ifdef LSD_DEVTOOLS
     t->dbgMisses++;
+#endif
     HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
+#ifdef LSD_DEVTOOLS
     {
       static const bool dumpL0 = getenv("LSDHIP_DUMP_L0") != nullptr;
       if (dumpL0 && guard == 0 && t->budgetFixed == 1) {
@@ -1417,6 +1419,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
         HIPCHK(hipMemcpy(d + (size_t)nb * (RS_COLS + 4 + 96), t->d_state + 1, sizeof(TrackState), hipMemcpyDeviceToHost));
       }
     }
+#endif
     if (S->done) break;
     if (int rc2 = prof_collect(c)) return rc2;
     if (t->jobKf && t->jobKf->depthVersion != t->jobKfVersion && guard < 8) {
@@ -1533,6 +1536,7 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   if (rc) return rc;
   if (int rcg = lsd_gate_open(c)) return rcg;
   if (int rcd = lsd_pipe_dummy(c)) return rcd;
+#ifdef LSD_DEVTOOLS
   static const bool traceInputs = getenv("LSDHIP_TRACE_INPUTS") != nullptr;
   auto trace_inputs = [&](int base) {
     for (int l = 1; l <= 4; l++) {
@@ -1550,6 +1554,7 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
     lsd_trace_val(c, 22, frame->id, pv);
     lsd_trace_val(c, 23, frame->id, (unsigned long long)kf->id);
   }
+#endif
   lsdm::SE3fH referenceToFrame = lsdm::se3f_from_d(lsdm::se3d_inverse(lsdm::se3d_from7(init)));
 
   if (t->hostLM) {
@@ -1578,10 +1583,13 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
   }
   t->jobKf = kf;
   t->jobKfVersion = kf->depthVersion;
+#ifdef LSD_DEVTOOLS
   const lsdm::SE3fH referenceToFrame0 = referenceToFrame;
   lsd_trace_val(c, 26, frame->id, t->dbgCum / 400ull);
+#endif
   rc = track_device(t, job, LSD_TRACK_MAX_LEVEL - 1, referenceToFrame, &referenceToFrame);
   if (rc != LSDHIP_OK && rc != LSDHIP_DIVERGED) { t->jobKf = nullptr; return rc; }
+#ifdef LSD_DEVTOOLS
   static const bool replay = getenv("LSDHIP_TRACK_REPLAY") != nullptr;
   if (replay && c->pipeline) {
     // developer check: the same job once more with the mapping stream drained — identical inputs must give the identical result
@@ -1615,8 +1623,10 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
       if (shown) fprintf(stderr, "L0DIFF frame %d: %d words differ after the first launch\n", frame->id, shown);
     }
   }
+#endif
   t->jobKf = nullptr;
   lsdhip_host_mark(6);
+#ifdef LSD_DEVTOOLS
   {
     unsigned long long pv = 0;
     for (int i = 0; i < 4; i++) { unsigned u; memcpy(&u, &t->h_summary->q[i], 4); pv = pv * 1000003ull + u; }
@@ -1624,6 +1634,7 @@ extern "C" int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* kf, lsdhip_
     lsd_trace_val(c, 20, frame->id, pv);
     lsd_trace_val(c, 21, frame->id, (unsigned long long)t->h_summary->numEvaluations * 1000 + t->h_summary->lastCand);
   }
+#endif
   if (c->pipeline && rc == LSDHIP_OK && t->h_summary->lastCand > 0 && t->h_summary->level == LSD_TRACK_MIN_LEVEL) {
     // the final mask sits in a side plane: to be merged into the frame's plane on the mapping stream, ahead of whatever reads the mask
     // next — noted here, queued by the next mapping-stream operation (nothing is launched between two tracking jobs)

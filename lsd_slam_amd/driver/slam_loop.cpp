@@ -927,23 +927,34 @@ extern "C" int lsdband_run(lsdband* b, int passes) {
     // have run, the halo rows are one pass old (and tile rows without an owned row are never computed locally), so the refresh that
     // belongs between that pass and this call's first one is queued here, on the main stream.
     if (passes > 0 && b->passes_run > 0) exchange(false);
+    // the parts of a pass — (window, run of tile rows) pairs — share launches (blockIdx.z = part): all edge parts of this process's
+    // windows in one, all interior parts in one; without an exchange to hide, every window's whole range in one
+    std::vector<lsdhip_depthmap*> edgeMaps, innerMaps, allMaps;
+    std::vector<int> edgeT0, edgeN, innerT0, innerN, allT0, allN;
+    for (int i = 0; i < b->nlocal; i++) {
+      for (const BandRun& u : runs[i]) {
+        (u.edge ? edgeMaps : innerMaps).push_back(b->dm[i]);
+        (u.edge ? edgeT0 : innerT0).push_back(u.t0);
+        (u.edge ? edgeN : innerN).push_back(u.n);
+      }
+      allMaps.push_back(b->dm[i]);
+      allT0.push_back(runs[i].front().t0);
+      allN.push_back(runs[i].back().t0 + runs[i].back().n - runs[i].front().t0);
+    }
+    auto parts = [&](std::vector<lsdhip_depthmap*>& m, std::vector<int>& t0, std::vector<int>& n) {
+      check(lsdhip_depth_stage_rows_batch(b->ctx, (int)m.size(), m.data(), t0.data(), n.data()), "lsdhip_depth_stage_rows_batch");
+    };
     for (int p = 0; p < passes; p++) {
       if (overlap) {
         // edge parts first (they wait for the previous exchange), the exchange forks behind them, interior parts run beside it
         check(lsdhip_ctx_aux_join(b->ctx), "lsdhip_ctx_aux_join");
-        for (int i = 0; i < b->nlocal; i++)
-          for (const BandRun& u : runs[i]) if (u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
+        parts(edgeMaps, edgeT0, edgeN);
         if (p + 1 < passes) check(lsdhip_ctx_aux_begin(b->ctx), "lsdhip_ctx_aux_begin");
-        for (int i = 0; i < b->nlocal; i++) {
-          for (const BandRun& u : runs[i]) if (!u.edge) check(lsdhip_depth_stage_rows(b->dm[i], 5, u.t0, u.n, 0), "lsdhip_depth_stage_rows");
-          check(lsdhip_depth_stage_rows(b->dm[i], 5, 0, 0, 1), "lsdhip_depth_stage_rows");   // validity planes swapped: the pass is queued
-        }
+        parts(innerMaps, innerT0, innerN);
       } else {
-        for (int i = 0; i < b->nlocal; i++) {
-          const int t0 = runs[i].front().t0, t1 = runs[i].back().t0 + runs[i].back().n;
-          check(lsdhip_depth_stage_rows(b->dm[i], 5, t0, t1 - t0, 1), "lsdhip_depth_stage_rows");
-        }
+        parts(allMaps, allT0, allN);
       }
+      for (int i = 0; i < b->nlocal; i++) check(lsdhip_depth_stage_rows(b->dm[i], 5, 0, 0, 1), "lsdhip_depth_stage_rows");   // validity planes swapped: the pass is queued
       b->passes_run++;
       if (p + 1 == passes) break;
       exchange(overlap);

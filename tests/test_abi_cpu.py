@@ -189,3 +189,14 @@ def test_header_prose_states_the_built_defaults(built_lib):
     assert "From %d jobs on" % d.batch_throughput_min_jobs in batch and "%d workgroup slots" % d.batch_strip_workgroups in batch
     # and the defaults the wrappers document
     assert d.ctx_async == 0 and d.ctx_pipeline == 0
+
+
+def test_default_library_carries_no_developer_scaffolding():
+    """The bisection tools of the round-4 pipeline bug hunt (dummy co-runner kernels, the gate kernels, checksum traces, job replay, the
+    first-launch dump) are compiled only into the LSD_DEVTOOLS build (lsd_slam_amd/build.py: build_variant("devtools", ["LSD_DEVTOOLS"])):
+    the default liblsdhip.so holds neither their kernels nor the names of the environment variables that switched them on."""
+    from lsd_slam_amd import capi
+    blob = open(capi.LIB_PATH, "rb").read()
+    for needle in (b"k_dummy", b"k_gate_wait", b"k_gate_open", b"k_trace_sum", b"LSDHIP_TRACK_REPLAY", b"LSDHIP_PIPE_DUMMY", b"LSDHIP_PIPE_GATE",
+                   b"LSDHIP_TRACE_SUMS", b"LSDHIP_DUMP_L0", b"LSDHIP_TRACE_INPUTS", b"LSDHIP_TRACK_DEBUG", b"LSDHIP_HOST_TRACE"):
+        assert needle not in blob, needle

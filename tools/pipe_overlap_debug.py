@@ -5,7 +5,8 @@ hypothesis map after its mapping iteration and the keyframe planes Frame::setDep
 the read-backs, between the tracking job and the next mapping iteration).  Run twice and compare:
     LSDHIP_PIPE_GATE=1 python tools/pipe_overlap_debug.py run /tmp/a.npz     # forced overlap (the mapping kernels wait for the next tracking job's start)
     python tools/pipe_overlap_debug.py run /tmp/b.npz                        # the Python loop's own pace: every mapping iteration has finished before the next job
-    python tools/pipe_overlap_debug.py cmp /tmp/a.npz /tmp/b.npz"""
+    python tools/pipe_overlap_debug.py cmp /tmp/a.npz /tmp/b.npz
+(These switches live in the developer build only: python -c "from lsd_slam_amd import build; build.build_variant('devtools', ['LSD_DEVTOOLS'])", then LSDHIP_LIB=lsd_slam_amd/liblsdhip_devtools.so LD_PRELOAD=$LSDHIP_LIB.)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,7 +2,8 @@
 """Compare two LSDHIP_TRACE_SUMS files (developer tool): entries are (kind, frame id, checksum); the streams interleave differently from
 run to run, so entries are matched by (kind, id, occurrence).  Prints the earliest frames at which each kind differs.
 kinds: 2 frame pyramid arena | 10-15 tracking inputs at job start (kf idepth L1, var L1, image L1, frame grad L1, kf idepth L3, frame grad L3)
-| 20 pose, 21 evaluations*1000 + lastCand | 30 frame mask as the depth update saw it, 31-36 hypothesis planes after the update, 37-39 keyframe depth planes written"""
+| 20 pose, 21 evaluations*1000 + lastCand | 30 frame mask as the depth update saw it, 31-36 hypothesis planes after the update, 37-39 keyframe depth planes written
+(These switches live in the developer build only: python -c "from lsd_slam_amd import build; build.build_variant('devtools', ['LSD_DEVTOOLS'])", then LSDHIP_LIB=lsd_slam_amd/liblsdhip_devtools.so LD_PRELOAD=$LSDHIP_LIB.)"""
 import sys
 from collections import defaultdict
 def load(p):

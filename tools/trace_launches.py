@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """For the frames whose job differed from its replay (tools/trace_replay.py): which launch of the job was the first to finish the previous
-evaluation with other totals?  Needs the LSD_ORDER_CHECK build: LSDHIP_ORDER_DUMP=<hashes> next to LSDHIP_TRACE_SUMS=<trace>."""
+evaluation with other totals?  Needs the LSD_ORDER_CHECK build: LSDHIP_ORDER_DUMP=<hashes> next to LSDHIP_TRACE_SUMS=<trace>.
+(These switches live in the developer build only: python -c "from lsd_slam_amd import build; build.build_variant('devtools', ['LSD_DEVTOOLS'])", then LSDHIP_LIB=lsd_slam_amd/liblsdhip_devtools.so LD_PRELOAD=$LSDHIP_LIB.)"""
 import sys
 from collections import defaultdict
 rows = defaultdict(dict)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """LSDHIP_TRACK_REPLAY=1 LSDHIP_TRACE_SUMS=<file>: per frame, did the job that ran beside the mapping stream (kinds 24 / 25) give what
 its replay on a quiet GPU gave (kinds 20 / 21)?  With LSDHIP_TRACE_INPUTS=1 also: were the job's inputs the same at both starts
-(kinds 11-18, 51-58 vs 111-118, 151-158)?"""
+(kinds 11-18, 51-58 vs 111-118, 151-158)?
+(These switches live in the developer build only: python -c "from lsd_slam_amd import build; build.build_variant('devtools', ['LSD_DEVTOOLS'])", then LSDHIP_LIB=lsd_slam_amd/liblsdhip_devtools.so LD_PRELOAD=$LSDHIP_LIB.)"""
 import sys
 from collections import defaultdict
 rows = defaultdict(dict)
