@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 HBM_ACHIEVABLE_GBS = 6290.0  # what a copy kernel achieves on this part (same table): every roofline object also carries frac_of_achievable
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the residual kernel from the committed PMC passes (profiles/rNN_pmc_traffic.json, made by
+def pmc_traffic(kernel="k_track_step"):
+    """HBM bytes per launch of a kernel (default: the residual kernel) from the committed PMC passes (profiles/rNN_pmc_traffic.json, made by
     tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, KiB units,
     FETCH_SIZE doubled on gfx950).  Counters cannot be collected from inside an un-profiled run, so the latest committed
     summary is reported; None if there is none."""
@@ -48,7 +48,7 @@ def pmc_traffic():
     try:
         d = json.load(open(files[-1]))
         for name, t in d["kernels"].items():
-            if "k_track_step" in name and t.get("hbm_bytes_per_launch") is not None:
+            if kernel in name and "batch" not in name and t.get("hbm_bytes_per_launch") is not None:
                 return float(t["hbm_bytes_per_launch"]), os.path.basename(files[-1])
     except Exception:
         pass
@@ -119,7 +119,102 @@ def _cpu_loop(po, L, frames, depth0, K, n_frames, w, h, mode):
         t_map += time.perf_counter() - t1
     total = time.perf_counter() - t_all
     return {"value": n_frames / total, "unit": "frames/s", "track_fps": n_frames / t_track,
-            "depth_mpix_per_s": (w * h * n_upd) / t_map / 1e6 if t_map > 0 else None, "seconds": total, "tracked_good": good}
+            "depth_mpix_per_s": (w * h * n_upd) / t_map / 1e6 if t_map > 0 else None, "seconds": total, "tracked_good": good,
+            "updates_per_frame": n_upd / n_frames, "execution": "blockUntilMapped: track, then map, one thread at a time (+ the mapping pool's 4 workers)"}
+
+
+def _quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx])
+
+
+def _relative_pose(kfToParent8, frameToParent7):
+    """se3FromSim3(newKeyframe.camToWorld^-1 * frame.camToWorld) for two frames tracked on the same parent (C/SlamSystem.cpp:918-920)"""
+    qk, tk, sk = np.asarray(kfToParent8[:4]), np.asarray(kfToParent8[4:7]), float(kfToParent8[7])
+    qf, tf = np.asarray(frameToParent7[:4]), np.asarray(frameToParent7[4:7])
+    qi = qk * np.array([1.0, -1, -1, -1])
+    q = _quat_mul(qi, qf)
+    q = q / np.linalg.norm(q)
+    return np.concatenate([q, quat_to_rot(qi) @ (tf - tk) / sk])
+
+
+def _cpu_loop_pipelined(po, L, frames, depth0, K, n_frames, w, h, mode):
+    """The reference's two-thread model on the CPU library (C/SlamSystem.cpp:1026-1040 with blockUntilMapped == false, :542-614, :907-920), in
+    the deterministic form the GPU loop's pipelined mode has: the mapper exactly one frame behind the tracker.  Step t: the tracking
+    thread imports the keyframe the mapper left one step ago and builds its point clouds (TrackingReference::makePointCloud, which reads
+    the keyframe's depth planes), then trackFrame(t) runs on this thread WHILE the mapping iteration of frame t - 1 (updateKeyframe, or
+    finalizeKeyFrame + createKeyFrame) runs on a second thread (its IndexThreadReduce pool of 4 workers beside it); a frame tracked on a
+    keyframe the mapper has meanwhile replaced is dropped unmapped (:559-566)."""
+    import threading
+    kf = po.Frame(0, frames[0], K, L=L)
+    kf.set_depth_gt(depth0)
+    dm = po.DepthMap(w, h, K, L=L, threads=4)
+    dm.init_gt(kf)
+    ref = po.TrackingReference(L=L)
+    tr = po.SE3Tracker(w, h, K, mode=mode, L=L)
+    tr.set_max_its([5, 20, 50, 100, 0])
+    track_kf, pending_kf = kf, None
+    last = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    deferred = None                 # mapping work of the previous step: ("upd", frame) | ("kf", frame)
+    since = n_upd = n_kf = n_drop = good = 0
+    t_all = time.perf_counter()
+
+    def map_work(work):
+        kind, fr = work
+        if kind == "upd":
+            dm.update([fr])
+            fr.clear_wasgood()
+        else:
+            dm.finalize()
+            dm.create_keyframe(fr)
+
+    for i in range(1, n_frames + 1):
+        f = po.Frame(i, frames[i % len(frames)], K, L=L)
+        ref.import_frame(track_kf)
+        for lvl in (4, 3, 2, 1):
+            L.orc_ref_pointcloud(ref.h_, lvl, None, None, None, None)      # makePointCloud(lvl): nothing is copied out
+        th = None
+        if deferred is not None:
+            th = threading.Thread(target=map_work, args=(deferred,))
+            th.start()
+        tracked_on = track_kf
+        r = tr.track(ref, f, last)
+        good += int(r.trackingWasGood)
+        if th is not None:
+            th.join()
+        if deferred is not None and deferred[0] == "kf":
+            n_kf += 1
+        elif deferred is not None:
+            n_upd += 1
+        deferred = None
+        if pending_kf is not None:
+            # the mapper promoted pending_kf while this frame was tracked on the old keyframe
+            last = _relative_pose(pending_kf.pose(), np.array(r.frameToRef))
+            track_kf, pending_kf = pending_kf, None
+        else:
+            last = np.array(r.frameToRef)
+        since += 1
+        if tracked_on is not kf:
+            f.clear_wasgood()
+            n_drop += 1
+            continue
+        if since >= KF_EVERY:
+            deferred = ("kf", f)
+            kf = f
+            pending_kf = f
+            since = 0
+        else:
+            deferred = ("upd", f)
+    if deferred is not None:
+        map_work(deferred)
+        n_kf += deferred[0] == "kf"
+        n_upd += deferred[0] == "upd"
+    total = time.perf_counter() - t_all
+    return {"value": n_frames / total, "unit": "frames/s", "seconds": total, "tracked_good": good, "frames": n_frames,
+            "updates_per_frame": n_upd / n_frames, "keyframes_per_frame": n_kf / n_frames, "dropped_frames_per_frame": n_drop / n_frames,
+            "cores": 5, "threads": "tracking thread (incl. frame creation and makePointCloud) beside a mapping thread with the reference's pool of 4 workers"}
 
 
 def cpu_baseline(frames, depth0, K, n_frames, w, h):
@@ -150,6 +245,11 @@ def cpu_baseline(frames, depth0, K, n_frames, w, h):
                  "sample": "%d frames of the same %dx%d track+map loop through the reference's own SE3Tracker / DepthMap / Frame code "
                            "(tracking 1 thread, mapping: IndexThreadReduce pool of 4 workers)" % (n_frames, w, h)})
     refb.update(info)
+    # the same library in the reference's two-thread model, mapper one frame behind (what `value` of a pipelined run is measured in)
+    try:
+        refb["pipelined"] = _cpu_loop_pipelined(po, po.lib(ref=key), frames, depth0, K, max(60, (n_frames * 3) // 5), w, h, po.SSE)
+    except Exception as e:
+        refb["pipelined"] = {"error": str(e)}
     # the reference's scalar path ("both scalar-path and SSE-path numbers"): the same sources and timing flags without
     # -DENABLE_SSE, a shorter sample
     skey = key.replace("sse_", "scalar_")
@@ -361,6 +461,12 @@ def multi_seq(torch, w, h, K, d_frames, depth0, device, single_value, sizes=(8, 
                 t += steps
             st = loop.stats()
             dropped = sum(loop.dropped())
+            roof = None
+            if pipelined:
+                try:
+                    roof = multi_seq_roofline(loop, L, ctx_h, ptrs, t, S, w, h, steps)
+                except Exception as e:
+                    roof = {"error": str(e)}
             loop.close()
             dt = float(np.median(dts))
             fps = S * steps / dt
@@ -375,8 +481,64 @@ def multi_seq(torch, w, h, K, d_frames, depth0, device, single_value, sizes=(8, 
                         "updates": sum(q["updates"] for q in st), "keyframes": sum(q["keyframes"] for q in st), "dropped": dropped,
                         "lost": sum(q["lost"] for q in st),
                         "lm_evaluations_per_frame": sum(q["evaluations"] for q in st) / max(1, sum(q["frames"] for q in st)),
-                        "replicas_bit_identical": bool(identical)})
+                        "replicas_bit_identical": bool(identical), "roofline": roof})
         out["S%d" % S] = rec
+    return out
+
+
+# algorithmic bytes per map pixel of the shared launches of the S-sequence loop (unique bytes read + written):
+#   frame pyramids : k_image_pyramid_batch (1 B in, five image levels 4 x 1.332 B, level-0 texels 16 B, |grad| 4 B) + k_gradients_max_batch
+#                    (image levels 1-4 in 1.33 B, texels of levels 1-4 out 5.31 B, |grad| in 4 B, maxGradients out 4 B)         = 41.0 B
+#   regularise     : K5 ~34 + K6 30 (+ K8 17 when the pass carries Frame::setDepth; counted without)                           = 64.0 B
+#   idepth pyramids: level-0 (idepth, var) in 8 B, levels 1-4 out 2.66 B                                                         = 10.7 B
+#   keyframe change: finalize pass 64 + setDepth 17 + re-activation data 9 + candidates 16 | merge 20 + 29 | regularise(occ) 30 | fill +
+#                    regularise 64 | rescale + setDepth 41 | two idepth pyramids 21.3                                            = 311 B
+#   observe        : 13 B per map pixel (the cheap rejections) + 57 B per searched pixel + 4 B per reference-image sample (steps + 4)
+MS_BYTES_PER_PX = {"frame_pyramids": 41.0, "regularise": 64.0, "idepth_pyramids": 10.7, "keyframe_change": 311.0}
+
+
+def multi_seq_roofline(loop, L, ctx_h, ptrs, t0, S, w, h, steps):
+    """Where the shared launches of the S-sequence loop sit against the HBM roofline: a profiled leg after the timed regions (HIP events
+    around every third call of each batched entry and around the tracking batches' launch budgets; the events cost time, so this leg is
+    not what frames_s is measured on).  Algorithmic bytes per launch / event time per launch, per kind."""
+    import ctypes as C
+    from lsd_slam_amd import capi
+    capi.check(L.lsdhip_prof_reset(ctx_h))
+    capi.check(L.lsdhip_prof_enable(ctx_h, 1))
+    loop.run([ptrs(t0 + k) for k in range(steps)])
+    capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+    capi.check(L.lsdhip_prof_enable(ctx_h, 0))
+    ms_, n_, b_ = C.c_double(), C.c_longlong(), C.c_double()
+    capi.check(L.lsdhip_prof_read(ctx_h, C.byref(ms_), C.byref(n_), C.byref(b_)))
+    ms = (C.c_double * 5)()
+    calls = (C.c_longlong * 5)()
+    units = (C.c_double * 5)()
+    obs = (C.c_double * 3)()
+    capi.check(L.lsdhip_ctx_batch_prof_read(ctx_h, ms, calls, units, obs))
+
+    def rec(kernel, ms_tot, n, bytes_tot, **kw):
+        if n <= 0 or ms_tot <= 0:
+            return None
+        ach = bytes_tot / (ms_tot * 1e-3) / 1e9
+        d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "avg_launch_us": ms_tot / n * 1e3, "algorithmic_bytes_per_launch": bytes_tot / n, "launches_sampled": int(n)}
+        d.update(kw)
+        return d
+
+    out = {"note": "profiled leg of %d steps after the timed regions; bytes are algorithmic (SURVEY.md 8(d)), times HIP events on the launches' stream" % steps}
+    out["track_batch"] = rec("k_track_step<TS_LM> + k_track_step<TS_EVAL>: all rounds of a tracking batch (one bracket per batch)", ms_.value,
+                             max(1, steps), b_.value, evaluations=int(n_.value), note="per batch of %d jobs, not per launch" % S)
+    names = [("frame_pyramids", 0, "k_image_pyramid_batch + k_gradients_max_batch"), ("regularise", 2, "k_reg_fused_batch (fill holes + regularise [+ setDepth])"),
+             ("idepth_pyramids", 3, "k_idepth_pyramid_batch"), ("keyframe_change", 4, "the six launches of lsdhip_depth_change_keyframe_batch")]
+    for key, k, kern in names:
+        out[key] = rec(kern, ms[k], calls[k], MS_BYTES_PER_PX[key] * units[k], maps_per_launch=(units[k] / calls[k] / (w * h)) if calls[k] else None)
+    if calls[1] > 0 and obs[0] > 0:
+        srch, stp = obs[1] / obs[0], obs[2] / obs[0]
+        px = units[1] / calls[1]
+        act = 13.0 * px + 57.0 * srch + 4.0 * (stp + 4.0 * srch)
+        out["observe"] = rec("k_observe_select_batch + k_observe_walk_batch", ms[1], calls[1], act * calls[1], maps_per_launch=px / (w * h),
+                             searched_pixels_per_launch=srch, searched_fraction=srch / px, walk_steps_per_launch=stp,
+                             upper_bound_bytes_per_launch=78.0 * px, stereo_steps_per_s=stp / (ms[1] / calls[1] * 1e-3))
     return out
 
 
@@ -538,7 +700,11 @@ def main():
                              # what a real N-rank run adds to the line: every rank's own frames/s (configs[3]: a straggler shows) and the
                              # row-band regulariser over the ranks (configs[4], RCCL halo exchange inside the C++ loop)
                              "per_rank_frames_s": [None] * world if distributed else None,
-                             "extra_configs": {"reg_3840x2160_bands": None} if distributed else None}))
+                             "extra_configs": {"reg_3840x2160_bands": None} if distributed else
+                                              {"multi_seq": {"S32": {"frames_s": None, "roofline": {k: None for k in ("track_batch", "frame_pyramids", "observe", "regularise", "idepth_pyramids", "keyframe_change")}}}},
+                             # like-for-like CPU comparison (one-GPU runs): the reference's sources in both execution models
+                             "cpu_baseline": None if distributed else {"value": None, "updates_per_frame": None, "pipelined": {"value": None, "updates_per_frame": None}},
+                             "speedup_vs_cpu_baseline": None if distributed else {"block_until_mapped": None, "pipelined": None, "updates_per_frame": {"gpu": None, "cpu": None}}}))
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -767,6 +933,7 @@ def main():
                                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_us": obs_us,
                                      "launches": int(obs_calls), "algorithmic_bytes_per_launch": 78.0 * w * h,
                                      "note": "upper-bound bytes (every pixel assumed to carry a hypothesis); HIP events around every 7th launch"}
+            obs_traffic, obs_traffic_src = pmc_traffic("k_observe") if ((w, h) == (640, 480) and args.scene == "S1") else (None, None)
             if obs_counted > 0:
                 # the same launches with the bytes of the pixels that were actually searched (counted in-kernel: searches = doLineStereo
                 # calls, steps = sum of their loopCounter): every pixel 13 B (isValid, maxGradients, blacklisted, nextStereoFrameMinID: the
@@ -780,6 +947,14 @@ def main():
                                                    "walk_steps_per_launch": stp, "walk_steps_per_search": stp / max(1.0, srch),
                                                    "launches_counted": int(obs_counted)}
                 out["stereo_steps_per_s"] = stp / (obs_us * 1e-6)
+                # the object's own achieved / frac are those of the ACTIVE bytes (what the searched pixels need); the every-pixel-carries-a-
+                # hypothesis bound moves under `upper_bound`; `traffic` = HBM bytes per launch of the committed PMC passes, beside its ratio
+                rd = out["roofline_depth"]
+                rd["upper_bound"] = {"algorithmic_bytes_per_launch": rd["algorithmic_bytes_per_launch"], "achieved": rd["achieved"], "frac": rd["frac"], "unit": "GB/s",
+                                     "note": rd.pop("note")}
+                rd.update({"achieved": ach_a, "frac": ach_a / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": act_bytes, "traffic": obs_traffic,
+                           "traffic_source": obs_traffic_src, "traffic_vs_algorithmic": (obs_traffic / act_bytes) if obs_traffic else None,
+                           "note": "algorithmic bytes of the pixels that were actually searched (counted in-kernel on the sampled launches); HIP events around every 7th launch"})
         if world == 1 and (w, h) == (640, 480) and not args.no_throughput_mode:
             try:
                 out["roofline_throughput_mode"] = throughput_mode(la, w, h, K, d_frames, depth0, local_rank)
@@ -828,7 +1003,22 @@ def main():
             out["cpu_baseline"], other = cpu_baseline(frames, depth0, K, args.cpu_frames, w, h)
             if other is not None:
                 out["cpu_baseline_other"] = other
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            # like for like: pipelined / pipelined and blockUntilMapped / blockUntilMapped, the mapping iterations per frame of both sides beside it
+            cb = out["cpu_baseline"]
+            pip = out["value"] if pipelined else (out.get("value_pipelined") or {}).get("value")
+            blk = (out.get("value_block_until_mapped") or {}).get("value") if pipelined else out["value"]
+            gpu_upd = {"pipelined": out["execution"]["updates_per_frame"] if pipelined else None,
+                       "block_until_mapped": None if pipelined else out["execution"]["updates_per_frame"]}
+            for k, rec in (("pipelined", out.get("value_pipelined")), ("block_until_mapped", out.get("value_block_until_mapped"))):
+                if isinstance(rec, dict) and rec.get("frames"):
+                    gpu_upd[k] = rec["updates"] / rec["frames"]
+            cpu_pip = (cb.get("pipelined") or {}).get("value")
+            out["speedup_vs_cpu_baseline"] = {
+                "block_until_mapped": (blk / cb["value"]) if blk else None,
+                "pipelined": (pip / cpu_pip) if (pip and cpu_pip) else None,
+                "updates_per_frame": {"gpu": gpu_upd, "cpu": {"block_until_mapped": cb.get("updates_per_frame"),
+                                                              "pipelined": (cb.get("pipelined") or {}).get("updates_per_frame")}},
+                "note": "same execution model on both sides (cpu_baseline.value: sequential track-then-map; cpu_baseline.pipelined: tracking thread beside mapping thread, mapper one frame behind)"}
         else:
             out["cpu_baseline"] = None
         add_achievable(out)

@@ -433,6 +433,12 @@ int lsdhip_depth_observe_time(lsdhip_depthmap* dm, double* ms_out, long long* ca
  * reset, plus the algorithmic bytes those launches moved; bench.py's roofline leg. */
 int lsdhip_prof_enable(lsdhip_ctx* ctx, int on);
 int lsdhip_prof_read(lsdhip_ctx* ctx, double* residual_ms, long long* residual_launches, double* residual_bytes);
+/* While profiling is on, every third call of the batched entries brackets its shared launches with HIP events.  ms / calls / units: 5
+ * entries each — [0] lsdhip_frame_create_batch (image pyramids + gradients), [1] the observe launch(es), [2] fill holes + regularise
+ * (+ setDepth) and [3] the idepth pyramids of lsdhip_depth_update_batch, [4] the launches of lsdhip_depth_change_keyframe_batch;
+ * units = map pixels the bracketed launches processed.  obs (may be NULL): [0] walk launches counted, [1] their searches (doLineStereo
+ * calls), [2] their walk steps.  Waits for the brackets still in flight; lsdhip_prof_reset clears. */
+int lsdhip_ctx_batch_prof_read(lsdhip_ctx* ctx, double* ms, long long* calls, double* units, double obs[3]);
 int lsdhip_prof_reset(lsdhip_ctx* ctx);
 
 #ifdef __cplusplus

@@ -178,6 +178,7 @@ def _signatures():
         "lsdhip_depth_observe_time": (i, [vp, vp, vp]),
         "lsdhip_prof_enable": (i, [vp, i]),
         "lsdhip_prof_read": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+        "lsdhip_ctx_batch_prof_read": (i, [vp, vp, vp, vp, vp]),
         "lsdhip_prof_reset": (i, [vp]),
     }
 

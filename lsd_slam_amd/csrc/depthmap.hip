@@ -748,15 +748,17 @@ __global__ __launch_bounds__(1024) void k_observe_select_batch(const ObserveArgs
 }
 // (144 registers, three waves per SIMD; capped at 128 — four waves, 32 bytes of scratch per lane — the 32-sequence loop ran the same:
 // profiles/r05_notes.md)
-__global__ __launch_bounds__(64) void k_observe_walk_batch(const ObserveArgs* __restrict__ items, const int* __restrict__ counts, int n) {
+__global__ __launch_bounds__(64) void k_observe_walk_batch(const ObserveArgs* __restrict__ items, const int* __restrict__ counts, int n,
+                                                           unsigned long long* __restrict__ acc) {
   __shared__ int s_incl[LSD_OBS_WALK_MAX_MAPS];     // chunks of 64 entries of maps 0 .. m (inclusive)
   __shared__ int s_cnt[LSD_OBS_WALK_MAX_MAPS];
   const int lane = threadIdx.x;
-  int TC = 0;
+  int TC = 0, total = 0;
 #pragma unroll
   for (int c = 0; c < LSD_OBS_WALK_MAX_MAPS / 64; c++) {
     const int m = c * 64 + lane;
     const int cnt = m < n ? counts[m < n ? m : 0] : 0;
+    total += cnt;
     int v = (cnt + 63) >> 6;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off); if (lane >= off) v += u; }
@@ -765,16 +767,27 @@ __global__ __launch_bounds__(64) void k_observe_walk_batch(const ObserveArgs* __
     TC += __builtin_amdgcn_readlane(v, 63);
   }
   __syncthreads();
+  if (acc != nullptr && blockIdx.x == 0) {     // sampled launch (profiling): its searches
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (lane == 0) { atomicAdd(&acc[0], (unsigned long long)total); atomicAdd(&acc[65], 1ull); }
+  }
   for (int ck = (int)blockIdx.x; ck < TC; ck += (int)gridDim.x) {
     int m = 0;
 #pragma unroll
     for (int c = 0; c < LSD_OBS_WALK_MAX_MAPS / 64; c++) m += __popcll(__ballot(s_incl[c * 64 + lane] <= ck));
     m = __builtin_amdgcn_readfirstlane(m);
     const int e = ((ck - (m > 0 ? s_incl[m - 1] : 0)) << 6) + lane;
+    int steps = 0;
     if (e < s_cnt[m]) {
       const ObserveArgs& a = items[m];
       const float4 q = a.queue[e];
-      [[clang::always_inline]] (void)observe_back<true>(a, __float_as_int(q.x), 0, q.y, q.z);   // (as a call the function is compiled without the kernel's register budget)
+      [[clang::always_inline]] steps = observe_back<true>(a, __float_as_int(q.x), 0, q.y, q.z);   // (as a call the function is compiled without the kernel's register budget)
+    }
+    if (acc != nullptr) {                         // ... and walk steps
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) steps += __shfl_xor(steps, off);
+      if (lane == 0) atomicAdd(&acc[1 + (ck & 63)], (unsigned long long)steps);
     }
   }
 }
@@ -2171,17 +2184,31 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
   }
   rc = lsd_args_commit(c, ms);
   if (rc) return rc;
+  const double mapPixels = (double)n * c->w * c->h;
+  int bp = lsd_bprof_begin(c, 1, ms);
+  if (bp < -1) return bp;
   if (split) {
     static const int walkWaves = getenv("LSDHIP_OBS_WALK_WAVES") ? atoi(getenv("LSDHIP_OBS_WALK_WAVES")) : LSD_OBS_WALK_WAVES;   // developer sweep
+    unsigned long long* acc = nullptr;
+    if (bp >= 0) {     // a sampled call also counts its searches and walk steps
+      if (!c->d_obsBatchAcc) { HIPCHK(hipMalloc((void**)&c->d_obsBatchAcc, 66 * 8)); HIPCHK(hipMemsetAsync(c->d_obsBatchAcc, 0, 66 * 8, ms)); }
+      acc = c->d_obsBatchAcc;
+    }
     hipLaunchKernelGGL(k_observe_select_batch, dim3((c->w + 63) / 64, (c->h + 15) / 16, n), dim3(1024), 0, ms, (const ObserveArgs*)dev);
-    hipLaunchKernelGGL(k_observe_walk_batch, dim3(walkWaves), dim3(64), 0, ms, (const ObserveArgs*)dev, (const int*)qcountDev, n);
+    hipLaunchKernelGGL(k_observe_walk_batch, dim3(walkWaves), dim3(64), 0, ms, (const ObserveArgs*)dev, (const int*)qcountDev, n, acc);
   } else {
     hipLaunchKernelGGL((k_observe_batch<2>), dim3((c->w + 31) / 32, (c->h + 1) / 2, n), dim3(64), 0, ms, (const ObserveArgs*)dev);
   }
+  rc = lsd_bprof_end(c, bp, ms, mapPixels);
+  if (rc) return rc;
   const RegBatchItem* dra = (const RegBatchItem*)((const uint8_t*)dev + obsBytes);
   const dim3 rgrid((c->w + 31) / 32, (c->h + 7) / 8, n);
+  bp = lsd_bprof_begin(c, 2, ms);
+  if (bp < -1) return bp;
   if (nSet > 0) hipLaunchKernelGGL((k_reg_fused_batch<true>), rgrid, dim3(256), 0, ms, dra);
   if (nSet < n) hipLaunchKernelGGL((k_reg_fused_batch<false>), rgrid, dim3(256), 0, ms, dra);
+  rc = lsd_bprof_end(c, bp, ms, mapPixels);
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   rc = lsd_args_release(c, ms);
   if (rc) return rc;
@@ -2203,7 +2230,11 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
       parts.push_back(maps[j]->d_red + 16);
       outs.push_back((double*)&c->h_slots[slot]);
     }
+    bp = lsd_bprof_begin(c, 3, ms);
+    if (bp < -1) return bp;
     rc = lsd_frame_build_idepth_pyramid_batch(kfs.data(), (int)kfs.size(), parts.data(), (int)(rgrid.x * rgrid.y), outs.data());
+    if (rc) return rc;
+    rc = lsd_bprof_end(c, bp, ms, (double)kfs.size() * c->w * c->h);
     if (rc) return rc;
     for (lsdhip_frame* kf : kfs) kf->depthHasBeenUpdatedFlag = true;
   }
@@ -2407,6 +2438,8 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   }
   rc = lsd_args_commit(c, ms);
   if (rc) return rc;
+  const int bp = lsd_bprof_begin(c, 4, ms);
+  if (bp < -1) return bp;
   const KfItem* dkf = (const KfItem*)dev;
   const RegBatchItem* dOcc = (const RegBatchItem*)((const uint8_t*)dev + kfBytes);
   const RegBatchItem* dFill = (const RegBatchItem*)((const uint8_t*)dev + kfBytes + regBytes);
@@ -2420,6 +2453,8 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   rc = lsd_args_release(c, ms);
   if (rc) return rc;
   rc = lsd_frame_build_idepth_pyramid_batch(pyrFrames.data(), 2 * n, pyrParts.data(), 0, pyrOuts.data(), pyrN.data());
+  if (rc) return rc;
+  rc = lsd_bprof_end(c, bp, ms, (double)n * npx);
   if (rc) return rc;
   for (int j = 0; j < n; j++) {
     maps[j]->propClean = true;

@@ -475,6 +475,8 @@ extern "C" void lsdhip_ctx_destroy(lsdhip_ctx* c) {
   if (c->args.h) (void)hipHostFree(c->args.h);
   if (c->args.d) (void)hipFree(c->args.d);
   for (hipEvent_t e : c->args.ev) if (e) (void)hipEventDestroy(e);
+  for (int i = 0; i < LSD_BPROF_SLOTS; i++) if (c->bprof[i].a) { (void)hipEventDestroy(c->bprof[i].a); (void)hipEventDestroy(c->bprof[i].b); }
+  if (c->d_obsBatchAcc) (void)hipFree(c->d_obsBatchAcc);
   if (c->d_gtStage) (void)hipFree(c->d_gtStage);
   if (c->d_flagArrive) (void)hipFree(c->d_flagArrive);
   if (c->d_gate) (void)hipFree(c->d_gate);
@@ -991,10 +993,64 @@ extern "C" int lsdhip_ctx_intrinsics(lsdhip_ctx* c, int level, float out[8]) {
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_prof_enable(lsdhip_ctx* c, int on) { if (!c) return LSDHIP_E_ARG; c->prof_on = on != 0; return LSDHIP_OK; }
+static void bprof_collect(lsdhip_ctx* c, bool wait) {
+  for (int i = 0; i < LSD_BPROF_SLOTS; i++) {
+    lsdhip_ctx::BProfSlot& p = c->bprof[i];
+    if (!p.pending) continue;
+    if (wait) (void)hipEventSynchronize(p.b);
+    else if (hipEventQuery(p.b) != hipSuccess) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->bprof_ms[p.kind] += ms; c->bprof_units[p.kind] += p.units; c->bprof_calls[p.kind]++; }
+    p.pending = false;
+  }
+}
+int lsd_bprof_begin(lsdhip_ctx* c, int kind, hipStream_t s) {
+  if (!c->prof_on || kind < 0 || kind >= LSD_BPROF_KINDS) return -1;
+  if ((c->bprof_tick[kind]++ % LSD_BPROF_PERIOD) != 0) return -1;
+  const int i = c->bprof_next;
+  c->bprof_next = (c->bprof_next + 1) % LSD_BPROF_SLOTS;
+  lsdhip_ctx::BProfSlot& p = c->bprof[i];
+  if (p.pending) { bprof_collect(c, false); if (p.pending) { if (hipEventSynchronize(p.b) != hipSuccess) return LSDHIP_E_HIP; bprof_collect(c, false); } }
+  if (!p.a) { if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return LSDHIP_E_HIP; }
+  p.kind = kind;
+  if (hipEventRecord(p.a, s) != hipSuccess) return LSDHIP_E_HIP;
+  return i;
+}
+int lsd_bprof_end(lsdhip_ctx* c, int slot, hipStream_t s, double units) {
+  if (slot < 0) return slot == -1 ? LSDHIP_OK : slot;
+  lsdhip_ctx::BProfSlot& p = c->bprof[slot];
+  if (hipEventRecord(p.b, s) != hipSuccess) return LSDHIP_E_HIP;
+  p.units = units;
+  p.pending = true;
+  return LSDHIP_OK;
+}
+// ms / calls / units per kind (LSD_BPROF_KINDS of each) of the sampled shared launches since the last reset, and the sampled walk launches'
+// work: obs[0] = launches counted, obs[1] = searches, obs[2] = walk steps.  Waits for the brackets still in flight.
+extern "C" int lsdhip_ctx_batch_prof_read(lsdhip_ctx* c, double* ms, long long* calls, double* units, double obs[3]) {
+  if (!c || !ms || !calls || !units) return LSDHIP_E_ARG;
+  LSD_CTX_LOCK(c);
+  HIPCHK(hipSetDevice(c->device));
+  bprof_collect(c, true);
+  for (int k = 0; k < LSD_BPROF_KINDS; k++) { ms[k] = c->bprof_ms[k]; calls[k] = c->bprof_calls[k]; units[k] = c->bprof_units[k]; }
+  if (obs) {
+    obs[0] = obs[1] = obs[2] = 0;
+    if (c->d_obsBatchAcc) {
+      unsigned long long h[66];
+      if (int rc = lsd_sync_all(c)) return rc;
+      HIPCHK(hipMemcpy(h, c->d_obsBatchAcc, sizeof(h), hipMemcpyDeviceToHost));
+      obs[0] = (double)h[65]; obs[1] = (double)h[0];
+      for (int i = 1; i <= 64; i++) obs[2] += (double)h[i];
+    }
+  }
+  return LSDHIP_OK;
+}
 extern "C" int lsdhip_prof_reset(lsdhip_ctx* c) {
   if (!c) return LSDHIP_E_ARG;
   LSD_CTX_LOCK(c);
   c->prof_ms = 0; c->prof_bytes = 0; c->prof_launches = 0;
+  bprof_collect(c, true);
+  for (int k = 0; k < LSD_BPROF_KINDS; k++) { c->bprof_ms[k] = 0; c->bprof_units[k] = 0; c->bprof_calls[k] = 0; }
+  if (c->d_obsBatchAcc) HIPCHK(hipMemsetAsync(c->d_obsBatchAcc, 0, 66 * 8, lsd_map_stream(c)));
   return LSDHIP_OK;
 }
 extern "C" int lsdhip_prof_read(lsdhip_ctx* c, double* ms, long long* launches, double* bytes) {
@@ -1308,9 +1364,13 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
   void* dev = nullptr;
   rc = lsd_args_push(c, blob.data(), blob.size(), ms, &dev);
   if (rc) return fail(rc);
+  const int bp = lsd_bprof_begin(c, 0, ms);
+  if (bp < -1) return fail(bp);
   hipLaunchKernelGGL(k_image_pyramid_batch, dim3(c->w / 16, c->h / 16, n), dim3(256), 0, ms, (const ImagePyrItem*)dev, c->w, c->h);
   const int n0 = c->w * c->h;
   hipLaunchKernelGGL(k_gradients_max_batch, dim3(nb + (n0 + 255) / 256, n), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + piBytes));
+  rc = lsd_bprof_end(c, bp, ms, (double)n * n0);
+  if (rc) return fail(rc);
   if (hipGetLastError() != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: launch failed"); return fail(LSDHIP_E_HIP); }
   rc = lsd_args_release(c, ms);
   if (rc) return fail(rc);

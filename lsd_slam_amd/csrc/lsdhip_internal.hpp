@@ -235,6 +235,18 @@ struct lsdhip_ctx {
   double prof_ms = 0, prof_bytes = 0;
   long long prof_launches = 0;
   std::vector<hipEvent_t> prof_events;   // per-launch event pairs for the device-resident LM loop
+  // sampled event brackets around the shared launches of the batched entries (bench.py: extra_configs.multi_seq.*.roofline), while
+  // prof_on: every LSD_BPROF_PERIOD-th call of a kind.  kinds: 0 frame pyramids (lsdhip_frame_create_batch), 1 observe, 2 fill holes +
+  // regularise (+ setDepth), 3 idepth pyramids of lsdhip_depth_update_batch, 4 the keyframe change chain; units = map pixels processed
+#define LSD_BPROF_KINDS 5
+#define LSD_BPROF_SLOTS 16
+#define LSD_BPROF_PERIOD 3
+  struct BProfSlot { hipEvent_t a = nullptr, b = nullptr; int kind = -1; double units = 0; bool pending = false; } bprof[LSD_BPROF_SLOTS];
+  int bprof_next = 0;
+  unsigned bprof_tick[LSD_BPROF_KINDS] = {};
+  double bprof_ms[LSD_BPROF_KINDS] = {}, bprof_units[LSD_BPROF_KINDS] = {};
+  long long bprof_calls[LSD_BPROF_KINDS] = {};
+  unsigned long long* d_obsBatchAcc = nullptr;   // [0] searches, [1 .. 64] walk steps (by wave), [65] counted launches — of the sampled walk launches
   // recycled frame arenas (the FrameMemory idea, C/DataStructures/FrameMemory.cpp:67-127, for device buffers);
   // reuse is stream-ordered, so no synchronisation is needed when a frame dies
   std::vector<void*> free_arenas;
@@ -485,5 +497,7 @@ int lsd_frame_ensure_depth_planes(lsdhip_frame* f);
 int lsd_frame_ensure_wasgood(lsdhip_frame* f);
 void lsd_depthmaps_forget_frame(lsdhip_ctx* c, lsdhip_frame* f);   // depthmap.hip: unhook a frame that is being destroyed
 int lsd_prof_collect(lsdhip_ctx* c);
+int lsd_bprof_begin(lsdhip_ctx* c, int kind, hipStream_t s);               // slot (>= 0) when this call is sampled, -1 otherwise, < -1: error
+int lsd_bprof_end(lsdhip_ctx* c, int slot, hipStream_t s, double units);
 int lsd_frame_resolve(lsdhip_frame* f);        // reads the frame's deferred results (synchronises the stream if any)
 int lsd_ctx_take_slot(lsdhip_ctx* c);          // next slot of the ring (resolving whoever still waits on it)

@@ -91,3 +91,40 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     # what an N-rank run adds to the line: one rate per rank (BASELINE.json configs[3]) and the row-band regulariser across the ranks
     # (configs[4]: lsdband_run's RCCL halo exchange) — bench.py::bands_distributed
     assert d["per_rank_frames_s"] == [None, None] and "reg_3840x2160_bands" in d["extra_configs"]
+
+
+def test_bench_line_skeleton_of_a_one_gpu_run():
+    """What a one-GPU bench line carries beside `value` (printed by --dry-run without a GPU): the CPU baseline in BOTH execution models with
+    the like-for-like speed-ups and the mapping iterations per frame of both sides, and the roofline objects of the S-sequence leg."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert set(d["speedup_vs_cpu_baseline"]) == {"block_until_mapped", "pipelined", "updates_per_frame"}
+    assert "pipelined" in d["cpu_baseline"] and "updates_per_frame" in d["cpu_baseline"]["pipelined"]
+    assert set(d["extra_configs"]["multi_seq"]["S32"]["roofline"]) >= {"track_batch", "frame_pyramids", "observe", "regularise", "idepth_pyramids", "keyframe_change"}
+
+
+def test_cpu_baseline_two_thread_model():
+    """bench.py's cpu_baseline.pipelined: the reference's two-thread model on the CPU library with the mapper one frame behind — every frame
+    tracked well, the frame after a keyframe change dropped unmapped, the rest mapped (the GPU loop's pipelined mode, frame for frame)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import pyoracle as po
+    from lsd_slam_amd import synth
+    w, h, n = 160, 128, 45
+    frames, depth0, K, gt = synth.make_sequence(w, h, 30)
+    po.build()
+    rec = bench._cpu_loop_pipelined(po, po.lib(fast=True), frames, depth0, K, n, w, h, po.SSE)
+    assert rec["tracked_good"] == n and rec["frames"] == n
+    # keyframes every 10 mapped-or-dropped frames; each change is followed by exactly one dropped frame
+    assert abs(rec["keyframes_per_frame"] - rec["dropped_frames_per_frame"]) <= 1.0 / n
+    assert abs(rec["updates_per_frame"] + rec["keyframes_per_frame"] + rec["dropped_frames_per_frame"] - 1.0) < 1e-9
+    seq = bench._cpu_loop(po, po.lib(fast=True), frames, depth0, K, n, w, h, po.SSE)
+    assert seq["tracked_good"] == n and seq["updates_per_frame"] > rec["updates_per_frame"]
