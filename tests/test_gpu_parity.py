@@ -196,6 +196,70 @@ def test_residual_kernel_fixed_pose(oracle, hip, w, h, params):
             assert np.allclose(np.array(r_g.A), np.array(r_o.A), rtol=2e-4, atol=1e-4 * np.abs(np.array(r_o.A)).max()), tag
 
 
+def _affine_truth64(tro, fo, lvl):
+    """(a, b) of the affine-lighting estimate (SE3Tracker.cpp:956-961, :1016-1024) from the per-point terms of the oracle's LAST
+    evaluation, accumulated in float64: c2 = frame intensity at the warped position (bilinear), c1 = c2 + residual, Huber(5) weights."""
+    x, y, z, r = [tro.buffer(k).astype(np.float64) for k in ("x", "y", "z", "residual")]
+    fx, fy, cx, cy = [float(v) for v in fo.intrinsics(lvl)[:4]]
+    img = fo.plane("image", lvl).astype(np.float64)
+    u, v = x / z * fx + cx, y / z * fy + cy
+    ix, iy = u.astype(np.int64), v.astype(np.int64)
+    dx, dy = u - ix, v - iy
+    c2 = dx * dy * img[iy + 1, ix + 1] + (dy - dx * dy) * img[iy + 1, ix] + (dx - dx * dy) * img[iy, ix + 1] + (1 - dx - dy + dx * dy) * img[iy, ix]
+    c1 = c2 + r
+    wgt = np.where(np.abs(r) < 5.0, 1.0, 5.0 / np.maximum(np.abs(r), 1e-30))
+    sxx, syy, sx, sy, sw = (c1 * c1 * wgt).sum(), (c2 * c2 * wgt).sum(), (c1 * wgt).sum(), (c2 * wgt).sum(), wgt.sum()
+    a = np.sqrt((syy - sy * sy / sw) / (sxx - sx * sx / sw))
+    return a, (sy - a * sx) / sw
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+def test_affine_lighting_estimate_against_float64_truth(oracle, hip, w, h):
+    """The affine-lighting estimate is a difference of float32 sums of ~1e4 products of magnitude 1e4: the reference adds them one by
+    one, the device as a tree.  Evidence instead of prose (profiles/r04_notes.md section 4c): (a, b) accumulated in float64 from the
+    oracle's own per-point terms is the truth both are measured against — the device must be within max(10 x the reference's own distance,
+    a small floor) of it — and the weighted residual of a second evaluation at each side's own (a, b) (what lastResidual is made of)
+    within max(10 x the reference's distance, 2e-3) of the one at the true (a, b).  The reference's distances are printed."""
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 4, params={})
+    kfo = oracle.Frame(0, frames[0], K)
+    kfg = hip.Frame(ctx, 0, frames[0])
+    kfo.set_depth_gt(depth0)
+    kfg.setDepthFromGroundTruth(depth0)
+    ro = oracle.TrackingReference()
+    ro.import_frame(kfo)
+    rg = hip.TrackingReference()
+    rg.importFrame(kfg)
+    tro = oracle.SE3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP)
+    trg = hip.SE3Tracker(ctx)
+    poses = [IDENT7.astype(np.float32), oracle.se3_inv(gt[3]).astype(np.float32),
+             oracle.se3_exp(np.array([0.05, -0.03, 0.02, 0.01, -0.02, 0.03])).astype(np.float32)]
+    worst = {"a_ref": 0.0, "a_hip": 0.0, "b_ref": 0.0, "b_hip": 0.0, "res_ref": 0.0, "res_hip": 0.0}
+    for pi, T in enumerate(poses):
+        for lvl in (2, 1):
+            for a0, b0 in ((1.0, 0.0), (1.03, -2.5)):
+                tag = "pose %d level %d (a, b) = (%g, %g)" % (pi, lvl, a0, b0)
+                fo = oracle.Frame(3, frames[3], K)
+                fg = hip.Frame(ctx, 3, frames[3])
+                r_o = tro.evaluate(ro, fo, T, lvl, a0, b0)
+                a64, b64 = _affine_truth64(tro, fo, lvl)
+                r_g = trg.evaluate(rg, fg, T, lvl, a0, b0)
+                da_o, da_g = abs(r_o.affine_a_lastIt - a64) / a64, abs(r_g.affine_a_lastIt - a64) / a64
+                db_o, db_g = abs(r_o.affine_b_lastIt - b64), abs(r_g.affine_b_lastIt - b64)
+                assert da_g <= max(10 * da_o, 2e-5), (tag, da_g, da_o)
+                assert db_g <= max(10 * db_o, 5e-3), (tag, db_g, db_o)
+                # the next evaluation's weighted residual at each side's own estimate against the one at the true estimate
+                e_t = tro.evaluate(ro, fo, T, lvl, np.float32(a64), np.float32(b64)).weightedError
+                e_o = tro.evaluate(ro, fo, T, lvl, r_o.affine_a_lastIt, r_o.affine_b_lastIt).weightedError
+                e_g = trg.evaluate(rg, fg, T, lvl, r_g.affine_a_lastIt, r_g.affine_b_lastIt).weightedError
+                de_o, de_g = abs(e_o - e_t) / e_t, abs(e_g - e_t) / e_t
+                assert de_g <= max(10 * de_o, 2e-3), (tag, de_g, de_o)
+                for k, val in (("a_ref", da_o), ("a_hip", da_g), ("b_ref", db_o), ("b_hip", db_g), ("res_ref", de_o), ("res_hip", de_g)):
+                    worst[k] = max(worst[k], val)
+    print("affine lighting vs float64 truth, worst case: a relative — reference %.2e, device %.2e; b absolute — reference %.2e, device %.2e; "
+          "weighted residual of the next evaluation relative — reference %.2e, device %.2e"
+          % (worst["a_ref"], worst["a_hip"], worst["b_ref"], worst["b_hip"], worst["res_ref"], worst["res_hip"]))
+
+
 @pytest.mark.parametrize("params", AFFINE)
 @pytest.mark.parametrize("w,h", [(176, 144), (640, 480)])
 def test_trackframe_parity(oracle, hip, w, h, params):
