@@ -209,7 +209,7 @@ __device__ __forceinline__ void pool4(const float id[4], const float var[4], flo
 struct DepthPyrArgs {
   float* id[LSD_LEVELS];
   float* var[LSD_LEVELS];
-  int w0;
+  int w0, h0;
   // optional passenger: one extra workgroup (blockIdx.y == gridDim.y - 1, blockIdx.x == 0 of an extra grid row) folds the
   // (sum, count) partials of the setDepth that produced level 0 into a pinned record (Frame::setDepth's meanIdepth / numPoints)
   const double* redPartials;
@@ -217,16 +217,17 @@ struct DepthPyrArgs {
   double* redOut;
 };
 
-// Levels 1..4 of (idepth, idepthVar) from level 0, one 16x16 level-0 tile per workgroup.
+// Levels 1..4 of (idepth, idepthVar) from level 0, one 32x32 level-0 tile per workgroup: every lane pools one 2x2 block of level 0
+// straight from HBM (two 8-byte loads per plane) into its level-1 pixel, the coarser levels follow through LDS (16x16 -> 8x8 -> 4x4 ->
+// 2x2).  (Rounds 1-4: 16x16 tiles, one level-0 pixel per lane — a quarter of the bytes per workgroup and four barriers for them: 41 %
+// of the HBM peak with 32 maps per launch.)  Image sizes are multiples of 16, so a tile may hang over the right / lower edge by half.
 __device__ __forceinline__ void idepth_pyramid_tile(const DepthPyrArgs& a) {
-  __shared__ float sid[16][17], svar[16][17];
-  __shared__ float tid1[8][9], tvar1[8][9];
-  __shared__ float tid2[4][5], tvar2[4][5];
-  __shared__ float tid3[2][3], tvar3[2][3];
+  __shared__ float tid1[16][17], tvar1[16][17];
+  __shared__ float tid2[8][9], tvar2[8][9];
+  __shared__ float tid3[4][5], tvar3[4][5];
   const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
   const int bx = blockIdx.x, by = blockIdx.y;
-  const int w0 = a.w0;
+  const int w0 = a.w0, h0 = a.h0;
   if (a.redPartials && by == (int)gridDim.y - 1) {
     if (bx != 0) return;
     __shared__ double s_a[256], s_b[256];
@@ -243,51 +244,57 @@ __device__ __forceinline__ void idepth_pyramid_tile(const DepthPyrArgs& a) {
     return;
   }
   {
-    int x = bx * 16 + tx, y = by * 16 + ty;
-    sid[ty][tx] = a.id[0][y * w0 + x];
-    svar[ty][tx] = a.var[0][y * w0 + x];
+    const int ax = tid & 15, ay = tid >> 4;
+    const int x = bx * 32 + 2 * ax, y = by * 32 + 2 * ay;         // the block's upper left level-0 pixel
+    float oi = -1.f, ov = -1.f;
+    if (x < w0 && y < h0) {
+      const float2 i0 = *(const float2*)(a.id[0] + (size_t)y * w0 + x), i1 = *(const float2*)(a.id[0] + (size_t)(y + 1) * w0 + x);
+      const float2 v0 = *(const float2*)(a.var[0] + (size_t)y * w0 + x), v1 = *(const float2*)(a.var[0] + (size_t)(y + 1) * w0 + x);
+      const float i4[4] = {i0.x, i0.y, i1.x, i1.y};
+      const float v4[4] = {v0.x, v0.y, v1.x, v1.y};
+      pool4(i4, v4, oi, ov);
+      const int o = (by * 16 + ay) * (w0 >> 1) + bx * 16 + ax;
+      a.id[1][o] = oi; a.var[1][o] = ov;
+    }
+    tid1[ay][ax] = oi; tvar1[ay][ax] = ov;
   }
   __syncthreads();
   if (tid < 64) {
-    int ax = tid & 7, ay = tid >> 3;
-    float i4[4] = {sid[2 * ay][2 * ax], sid[2 * ay][2 * ax + 1], sid[2 * ay + 1][2 * ax], sid[2 * ay + 1][2 * ax + 1]};
-    float v4[4] = {svar[2 * ay][2 * ax], svar[2 * ay][2 * ax + 1], svar[2 * ay + 1][2 * ax], svar[2 * ay + 1][2 * ax + 1]};
-    float oi, ov;
-    pool4(i4, v4, oi, ov);
-    tid1[ay][ax] = oi; tvar1[ay][ax] = ov;
-    int o = (by * 8 + ay) * (w0 >> 1) + bx * 8 + ax;
-    a.id[1][o] = oi; a.var[1][o] = ov;
-  }
-  __syncthreads();
-  if (tid < 16) {
-    int ax = tid & 3, ay = tid >> 2;
+    const int ax = tid & 7, ay = tid >> 3;
     float i4[4] = {tid1[2 * ay][2 * ax], tid1[2 * ay][2 * ax + 1], tid1[2 * ay + 1][2 * ax], tid1[2 * ay + 1][2 * ax + 1]};
     float v4[4] = {tvar1[2 * ay][2 * ax], tvar1[2 * ay][2 * ax + 1], tvar1[2 * ay + 1][2 * ax], tvar1[2 * ay + 1][2 * ax + 1]};
     float oi, ov;
     pool4(i4, v4, oi, ov);
     tid2[ay][ax] = oi; tvar2[ay][ax] = ov;
-    int o = (by * 4 + ay) * (w0 >> 2) + bx * 4 + ax;
-    a.id[2][o] = oi; a.var[2][o] = ov;
+    if (bx * 8 + ax < (w0 >> 2) && by * 8 + ay < (h0 >> 2)) {
+      const int o = (by * 8 + ay) * (w0 >> 2) + bx * 8 + ax;
+      a.id[2][o] = oi; a.var[2][o] = ov;
+    }
   }
   __syncthreads();
-  if (tid < 4) {
-    int ax = tid & 1, ay = tid >> 1;
+  if (tid < 16) {
+    const int ax = tid & 3, ay = tid >> 2;
     float i4[4] = {tid2[2 * ay][2 * ax], tid2[2 * ay][2 * ax + 1], tid2[2 * ay + 1][2 * ax], tid2[2 * ay + 1][2 * ax + 1]};
     float v4[4] = {tvar2[2 * ay][2 * ax], tvar2[2 * ay][2 * ax + 1], tvar2[2 * ay + 1][2 * ax], tvar2[2 * ay + 1][2 * ax + 1]};
     float oi, ov;
     pool4(i4, v4, oi, ov);
     tid3[ay][ax] = oi; tvar3[ay][ax] = ov;
-    int o = (by * 2 + ay) * (w0 >> 3) + bx * 2 + ax;
-    a.id[3][o] = oi; a.var[3][o] = ov;
+    if (bx * 4 + ax < (w0 >> 3) && by * 4 + ay < (h0 >> 3)) {
+      const int o = (by * 4 + ay) * (w0 >> 3) + bx * 4 + ax;
+      a.id[3][o] = oi; a.var[3][o] = ov;
+    }
   }
   __syncthreads();
-  if (tid == 0) {
-    float i4[4] = {tid3[0][0], tid3[0][1], tid3[1][0], tid3[1][1]};
-    float v4[4] = {tvar3[0][0], tvar3[0][1], tvar3[1][0], tvar3[1][1]};
+  if (tid < 4) {
+    const int ax = tid & 1, ay = tid >> 1;
+    float i4[4] = {tid3[2 * ay][2 * ax], tid3[2 * ay][2 * ax + 1], tid3[2 * ay + 1][2 * ax], tid3[2 * ay + 1][2 * ax + 1]};
+    float v4[4] = {tvar3[2 * ay][2 * ax], tvar3[2 * ay][2 * ax + 1], tvar3[2 * ay + 1][2 * ax], tvar3[2 * ay + 1][2 * ax + 1]};
     float oi, ov;
     pool4(i4, v4, oi, ov);
-    int o = by * (w0 >> 4) + bx;
-    a.id[4][o] = oi; a.var[4][o] = ov;
+    if (bx * 2 + ax < (w0 >> 4) && by * 2 + ay < (h0 >> 4)) {
+      const int o = (by * 2 + ay) * (w0 >> 4) + bx * 2 + ax;
+      a.id[4][o] = oi; a.var[4][o] = ov;
+    }
   }
 }
 __global__ __launch_bounds__(256) void k_idepth_pyramid(DepthPyrArgs a) { idepth_pyramid_tile(a); }
@@ -1154,9 +1161,9 @@ int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, i
   float** id = lsd_depth_w(f);
   float** var = lsd_depthvar_w(f);
   for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = id[l]; a.var[l] = var[l]; }
-  a.w0 = c->w;
+  a.w0 = c->w; a.h0 = c->h;
   a.redPartials = redPartials; a.redN = redN; a.redOut = redOut;
-  hipLaunchKernelGGL(k_idepth_pyramid, dim3(c->w / 16, c->h / 16 + (redPartials ? 1 : 0)), dim3(256), 0, lsd_map_stream(c), a);
+  hipLaunchKernelGGL(k_idepth_pyramid, dim3((c->w + 31) / 32, (c->h + 31) / 32 + (redPartials ? 1 : 0)), dim3(256), 0, lsd_map_stream(c), a);
   HIPCHK(hipGetLastError());
   if (c->pipeline) { f->depthPending = true; f->depthPendingSeq = c->mSeq + 1; }   // complete at the caller's record point
   else f->hasIDepth = true;
@@ -1227,13 +1234,13 @@ int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double*
     float** id = lsd_depth_w(f);
     float** var = lsd_depthvar_w(f);
     for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = id[l]; a.var[l] = var[l]; }
-    a.w0 = c->w;
+    a.w0 = c->w; a.h0 = c->h;
     a.redPartials = redPartials[j]; a.redN = redNs ? redNs[j] : redN; a.redOut = redOut[j];
   }
   void* dev = nullptr;
   int rc = lsd_args_push(c, items.data(), sizeof(DepthPyrArgs) * (size_t)n, lsd_map_stream(c), &dev);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_idepth_pyramid_batch, dim3(c->w / 16, c->h / 16 + 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
+  hipLaunchKernelGGL(k_idepth_pyramid_batch, dim3((c->w + 31) / 32, (c->h + 31) / 32 + 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
   HIPCHK(hipGetLastError());
   rc = lsd_args_release(c, lsd_map_stream(c));
   if (rc) return rc;

@@ -301,7 +301,18 @@ def test_trackframe_parity(oracle, hip, w, h, params):
         res_floor = 2e-2 if affine_on else 2e-3
         res_spread = abs(r_sc.lastResidual - r_sse.lastResidual) / abs(r_sse.lastResidual)
         res_diff = abs(trg.lastResidual - r_sse.lastResidual) / abs(r_sse.lastResidual)
-        print("frame %d lastResidual: HIP vs oracle-SSE %.2e, oracle scalar vs SSE %.2e (bound %.2e)" % (i, res_diff, res_spread, max(10 * res_spread, res_floor)))
+        sens = 0.0
+        if affine_on:
+            # where the 2e-2 comes from, measured instead of argued: at the reference's final pose, the distance of ITS estimate of b from the
+            # float64 accumulation of its own per-point terms, times the residual's sensitivity to b (d/db of sum w r^2 over sum w r^2)
+            Tf = oracle.se3_inv(np.array(r_sse.frameToRef)).astype(np.float32)
+            fe = oracle.Frame(100 + i, frames[i], K)
+            ev = tr_sse.evaluate(ro, fe, Tf, 1, r_sse.affine_a, r_sse.affine_b)
+            a64, b64 = _affine_truth64(tr_sse, fe, 1)
+            rbuf, wbuf = tr_sse.buffer("residual").astype(np.float64), tr_sse.buffer("weight_p").astype(np.float64)
+            sens = 2.0 * abs(ev.affine_b_lastIt - b64) * float((wbuf * np.abs(rbuf)).sum() / (wbuf * rbuf * rbuf).sum())
+        print("frame %d lastResidual: HIP vs oracle-SSE %.2e, oracle scalar vs SSE %.2e (bound %.2e); the reference's own b error moves its residual by up to %.2e"
+              % (i, res_diff, res_spread, max(10 * res_spread, res_floor), sens))
         assert res_diff <= max(10 * res_spread, res_floor), (i, trg.lastResidual, r_sse.lastResidual, r_sc.lastResidual)
         assert trg.pointUsage == pytest.approx(r_sse.pointUsage, rel=1e-3)
         if params.get("useAffineLightningEstimation", 1) == 0:
