@@ -712,39 +712,95 @@ __device__ __forceinline__ void prop_candidate(const PropArgs& a, const int x, c
 // that holds a single searching pixel walks the whole dependent chain of doLineStereo at 126 registers per lane with one lane busy, and
 // three waves in four hold one (2-7 % of the pixels search).  With enough maps in a launch to fill the chip that is what bounds it, not
 // the planes it reads.  So: k_observe_select_batch runs observe_front — the cheap rejections, a streaming pass at few registers — over
-// every pixel and appends the survivors of a 64x16 tile, compacted, to their map's queue (one atomic per tile); k_observe_walk_batch
+// every pixel (four per lane, their loads in flight together) and appends the survivors of a 64x16 tile, compacted, to their map's queue
+// (one atomic per tile); k_observe_walk_batch
 // runs observe_back over the queues with every lane busy: chunks of 64 consecutive entries (neighbouring tiles: shared lines), dealt to a
 // fixed number of one-wave workgroups.  A pixel's update reads and writes nothing but its own hypothesis and constant planes, so the
 // order of the queue does not matter: every plane is bit-identical to the one-launch form (tests/test_multiseq_gpu.py).
 // (For ONE map the split was measured in round 2 and lost — two latency-bound launches instead of one; it stays one launch there.)
 #define LSD_OBS_WALK_MAX_MAPS 256
-__global__ __launch_bounds__(1024) void k_observe_select_batch(const ObserveArgs* __restrict__ items) {
+// observe_front<true> for the four pixels (x, y0 + 4 k) of a lane, staged: the 13 bytes every pixel pays for the cheap rejections of all
+// four are requested before the first is looked at, likewise the second batch (mask byte, four keyframe-image taps) of the survivors —
+// the pass is a chain of two dependent memory round trips per pixel, and a lane that keeps eight of them in flight needs a quarter of
+// the residency rounds (the one-pixel form ran at 1.7 TB/s: 0.84 of its wave cycles waiting, profiles/r05_notes.md).
+// Same tests in the same order as observe_front (incl. its one store: a hypothesis on a pixel below the gradient threshold is dropped).
+__device__ __forceinline__ void observe_front4(const ObserveArgs& a, const int x, const int y0, bool (&hit)[4], float (&epx)[4], float (&epy)[4]) {
+  const StereoRef& rf = a.one;
+  const bool useMask = rf.parentIsKF && rf.wasGood != nullptr;
+  bool in[4], hyp[4];
+  int idx[4], bl[4];
+  float mg[4], nid[4];
+  uint8_t val[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int y = y0 + 4 * k;
+    in[k] = !(x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3);
+    idx[k] = in[k] ? x + y * a.w : 0;
+    val[k] = a.m.valid[idx[k]];
+    mg[k] = a.kfMaxGrad[idx[k]];
+    bl[k] = a.m.blacklisted[idx[k]];
+    nid[k] = a.m.nextID[idx[k]];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    hyp[k] = val[k] != 0;
+    bool pass = in[k];
+    if (pass && hyp[k] && mg[k] < a.minUseGrad) { a.m.valid[idx[k]] = 0; pass = false; }
+    if (pass && (mg[k] < a.minUseGrad || bl[k] < MIN_BLACKLIST)) pass = false;
+    if (pass && hyp[k] && !a.reactivated) {
+      const int rel = (int)nid[k] - a.byIDOffset;
+      if (rel >= a.nByID) pass = false;
+    }
+    hit[k] = pass;
+  }
+  uint8_t good[4];
+  float kR[4], kL[4], kD[4], kU[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int y = y0 + 4 * k;
+    const int j = hit[k] ? idx[k] : a.w + 1;                          // (a pixel with all four neighbours inside the plane)
+    good[k] = (useMask && hit[k]) ? rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)] : (uint8_t)1;
+    kR[k] = a.kfImage[j + 1]; kL[k] = a.kfImage[j - 1]; kD[k] = a.kfImage[j + a.w]; kU[k] = a.kfImage[j - a.w];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    epx[k] = 0; epy[k] = 0;
+    if (hit[k]) {
+      if (!good[k]) hit[k] = false;
+      else hit[k] = make_and_check_epl(a, rf, x, y0 + 4 * k, kR[k], kL[k], kD[k], kU[k], &epx[k], &epy[k]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_observe_select_batch(const ObserveArgs* __restrict__ items) {
   const ObserveArgs& a = items[blockIdx.z];
-  __shared__ int s_wcount[16];
+  __shared__ int s_wcount[4];
   __shared__ int s_base;
-  const int tid = threadIdx.x, wave = tid >> 6;
-  const int x = blockIdx.x * 64 + (tid & 63);
-  const int y = blockIdx.y * 16 + wave;
-  int refIdx = 0;
-  float epx = 0, epy = 0;
-  const bool hit = observe_front<true>(a, x, y, refIdx, epx, epy);
-  const unsigned long long bal = __ballot(hit);
-  const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-  if ((tid & 63) == 0) s_wcount[wave] = __popcll(bal);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int x = blockIdx.x * 64 + lane;
+  const int y0 = blockIdx.y * 16 + wave;                              // the lane's pixels: rows y0, y0 + 4, y0 + 8, y0 + 12 of the 64x16 tile
+  bool hit[4];
+  float epx[4], epy[4];
+  observe_front4(a, x, y0, hit, epx, epy);
+  int rank[4], wc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned long long bal = __ballot(hit[k]);
+    rank[k] = wc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    wc += __popcll(bal);
+  }
+  if (lane == 0) s_wcount[wave] = wc;
   __syncthreads();
   if (tid == 0) {
-    int tot = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) tot += s_wcount[k];
+    const int tot = (s_wcount[0] + s_wcount[1]) + (s_wcount[2] + s_wcount[3]);
     s_base = tot > 0 ? atomicAdd(a.qcount, tot) : 0;
   }
   __syncthreads();
-  if (hit) {
-    int off = s_base + rank;
+  int off = s_base;
 #pragma unroll
-    for (int k = 0; k < 16; k++) off += k < wave ? s_wcount[k] : 0;
-    a.queue[off] = make_float4(__int_as_float(x + y * a.w), epx, epy, 0.f);
-  }
+  for (int k = 0; k < 4; k++) off += k < wave ? s_wcount[k] : 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (hit[k]) a.queue[off + rank[k]] = make_float4(__int_as_float(x + (y0 + 4 * k) * a.w), epx[k], epy[k], 0.f);
 }
 // (144 registers, three waves per SIMD; capped at 128 — four waves, 32 bytes of scratch per lane — the 32-sequence loop ran the same:
 // profiles/r05_notes.md)
@@ -2267,7 +2323,7 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
       if (!c->d_obsBatchAcc) { HIPCHK(hipMalloc((void**)&c->d_obsBatchAcc, 66 * 8)); HIPCHK(hipMemsetAsync(c->d_obsBatchAcc, 0, 66 * 8, ms)); }
       acc = c->d_obsBatchAcc;
     }
-    hipLaunchKernelGGL(k_observe_select_batch, dim3((c->w + 63) / 64, (c->h + 15) / 16, n), dim3(1024), 0, ms, (const ObserveArgs*)dev);
+    hipLaunchKernelGGL(k_observe_select_batch, dim3((c->w + 63) / 64, (c->h + 15) / 16, n), dim3(256), 0, ms, (const ObserveArgs*)dev);
     hipLaunchKernelGGL(k_observe_walk_batch, dim3(walkWaves), dim3(64), 0, ms, (const ObserveArgs*)dev, (const int*)qcountDev, n, acc);
   } else {
     hipLaunchKernelGGL((k_observe_batch<2>), dim3((c->w + 31) / 32, (c->h + 1) / 2, n), dim3(64), 0, ms, (const ObserveArgs*)dev);
