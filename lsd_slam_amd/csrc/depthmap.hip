@@ -1085,78 +1085,9 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   uint8_t nowValid = wasValid;
   bool smoothed = false, blacklistDec = false;
   float out_ids = 0.f, out_vars = 0.f;
+  // (the 25-neighbour loop on compacted centres — ballots, a list in LDS, the outcome handed back to the pixel's owner — measured the
+  // same as this form at 30 % and at 50 % valid pixels: profiles/r05_notes.md section 5)
   const bool doK6 = inImage && x >= 2 && x < w - 2 && y >= 2 && y < h - 2 && wasValid;
-#ifndef LSD_REG_NO_COMPACT
-  // A semi-dense map holds a hypothesis at about a quarter of the pixels, and the 25-neighbour loop below is what the pass spends its
-  // issue slots on (25 IEEE divisions per centre): run it on DENSE lanes.  The owned pixels that need it are compacted into a list
-  // (wave ballots + the four waves' counts), lane t of the workgroup takes the t-th of them and leaves the outcome in LDS for the
-  // pixel's owner, who does the stores as before — the arithmetic per pixel, and therefore every plane, is unchanged.
-  __shared__ uint8_t s_k6list[256];
-  __shared__ int s_k6wc[4];
-  __shared__ float2 s_k6out[256];        // (idepth_smoothed, idepth_var_smoothed) of a smoothed pixel
-  __shared__ uint8_t s_k6flag[256];      // 1: smoothed, 2: invalidated + blacklist decrement, 4: invalidated (occluded)
-  {
-    const unsigned long long bal = __ballot(doK6);
-    if ((tid & 63) == 0) s_k6wc[tid >> 6] = __popcll(bal);
-    __syncthreads();
-    int off = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-#pragma unroll
-    for (int k = 0; k < 4; k++) off += k < (tid >> 6) ? s_k6wc[k] : 0;
-    if (doK6) s_k6list[off] = (uint8_t)tid;
-    __syncthreads();
-  }
-  const int nK6 = s_k6wc[0] + s_k6wc[1] + s_k6wc[2] + s_k6wc[3];
-  if (tid < nK6) {
-    const int p = s_k6list[tid];
-    const int e = HALO + (p & 31) + (HALO + (p >> 5)) * TW;       // (shadows the owner's own entry: this lane works for pixel p)
-    uint8_t flag;
-    float2 res = make_float2(0.f, 0.f);
-    const float2 c_iv = s_iv[e];
-    const float c_id = c_iv.x;
-    const float c_var = c_iv.y;
-    float sum = 0, val_sum = 0, sumIvar = 0;
-    int numOccluding = 0, numNotOccluding = 0;
-#pragma unroll
-    for (int dx = -2; dx <= 2; dx++)
-#pragma unroll
-      for (int dy = -2; dy <= 2; dy++) {
-        const int j = e + dx + dy * TW;
-        const int vcj = s_pk[j];
-        const float2 ivj = s_iv[j];
-        const float s_idj = ivj.x;
-        const float s_varj = ivj.y;
-        if (vcj < 0) continue;
-        const float diff = s_idj - c_id;
-        if (DIFF_FAC_SMOOTHING * diff * diff > s_varj + c_var) {
-          if (OCC) { if (s_idj > c_id) numOccluding++; }
-          continue;
-        }
-        val_sum += vcj;
-        if (OCC) numNotOccluding++;
-        const float distFac = (float)(dx * dx + dy * dy) * a.regDistVar;
-        const float ivar = 1.0f / (s_varj + distFac);
-        sum += s_idj * ivar;
-        sumIvar += ivar;
-      }
-    if (val_sum < a.validityTH) {
-      flag = 2;
-    } else if (OCC && numOccluding > numNotOccluding) {
-      flag = 4;
-    } else {
-      sum = sum / sumIvar;
-      res = make_float2(unzero(sum), 1.0f / sumIvar);
-      flag = 1;
-    }
-    s_k6flag[p] = flag;
-    s_k6out[p] = res;
-  }
-  __syncthreads();
-  if (doK6) {
-    const uint8_t flag = s_k6flag[tid];
-    if (flag == 1) { const float2 res = s_k6out[tid]; out_ids = res.x; out_vars = res.y; smoothed = true; }
-    else { nowValid = 0; blacklistDec = flag == 2; }
-  }
-#else
   if (doK6) {
     const float2 c_iv = s_iv[e];
     const float c_id = c_iv.x;
@@ -1197,7 +1128,6 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
       smoothed = true;
     }
   }
-#endif
   int blFinal = 0;           // the pixel's blacklisted counter after the pass, where this lane came to know it
   bool blKnown = false;
   if (inImage) {

@@ -419,7 +419,13 @@ extern "C" int lsdhip_ctx_create(int device, int w, int h, const float K[4], con
     c->intr[l] = {fx[l], fy[l], cx[l], cy[l], Ki[0], Ki[4], Ki[2], Ki[5]};
     if (l == 0) { memcpy(c->K0, Kl, sizeof(Kl)); memcpy(c->K0inv, Ki, sizeof(Ki)); }
   }
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (getenv("LSDHIP_TRACK_PRIO")) {     // round-5 experiment: the tracking stream at the highest queue priority
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  }
   HIPCHK(hipEventCreate(&c->ev_a));
   HIPCHK(hipEventCreate(&c->ev_b));
   HIPCHK(hipHostMalloc((void**)&c->h_slots, LSD_NUM_SLOTS * sizeof(DeferredSlot), hipHostMallocMapped));

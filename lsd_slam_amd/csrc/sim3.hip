@@ -52,9 +52,7 @@ struct Sim3Job {
 struct Sim3Batch { Sim3Job j[S3_MAXB]; };
 static_assert(sizeof(Sim3Batch) <= 4096, "kernel-argument limit");
 
-__global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Batch batch) {
-  const Sim3Job& a = batch.j[blockIdx.y];
-  if ((int)blockIdx.x >= a.nblocks) return;
+__device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
   __shared__ float s_red[S3_END * (S3_BLOCK + 1) + 8];
   __shared__ float s_sum[4][64];
   __shared__ int s_max;
@@ -215,13 +213,15 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Batch batch) {
     for (int k = 0; k < S3_NTAIL; k++) dst[k] = acc[S3_TAIL0 + k];
   }
 }
-
-// fixed-order sum of the tile rows, global top-3 keys, SSE tail drop; result to the pinned record
-__global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Batch batch) {
+__global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Batch batch) {
   const Sim3Job& a = batch.j[blockIdx.y];
-  if (a.nblocks <= 0) return;
+  if ((int)blockIdx.x >= a.nblocks) return;
+  sim3_eval_tile(a);
+}
+
+// fixed-order sum of the tile rows, global top-3 keys, SSE tail drop: the evaluation's totals (tail-corrected) in s_tot[0 .. S3_END)
+__device__ __forceinline__ void sim3_totals(const Sim3Job& a, float* s_tot) {
   __shared__ float s_part[4][64];
-  __shared__ float s_tot[64];
   __shared__ int s_keys[3], s_src[3];
   __shared__ int s_max;
   const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Batch batch) {
     s_tot[tid] = s;
   }
   __syncthreads();
+  float corrected = 0.f;
   if (tid < 64) {
     float s = s_tot[tid];
     const int M = (int)s_tot[S3_M];
@@ -280,8 +281,20 @@ __global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Batch batch) {
     if (tid >= S3_TAIL0 && tid < S3_END)
       for (int k = 0; k < need; k++)
         if (s_keys[k] >= 0) s -= a.topval[(size_t)s_src[k] * 48 + (tid - S3_TAIL0)];
-    if (tid < 63) a.record[tid] = tid < S3_END ? s : 0.f;
+    corrected = tid < S3_END ? s : 0.f;
   }
+  __syncthreads();
+  if (tid < 64) s_tot[tid] = corrected;
+  __syncthreads();
+}
+// ... to the pinned record of a host-driven evaluation (lsdhip_sim3tracker_evaluate)
+__global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Batch batch) {
+  const Sim3Job& a = batch.j[blockIdx.y];
+  if (a.nblocks <= 0) return;
+  __shared__ float s_tot[64];
+  const int tid = threadIdx.x;
+  sim3_totals(a, s_tot);
+  if (tid < 63) a.record[tid] = s_tot[tid];
   // the host polls word 63 instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the evaluation)
   __threadfence_system();
   __syncthreads();
