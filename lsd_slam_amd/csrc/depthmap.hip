@@ -679,7 +679,7 @@ __device__ __forceinline__ void prop_candidate(const PropArgs& a, const int x, c
   float Rr1 = (a.R[3] * r0 + a.R[4] * r1) + a.R[5] * r2;
   float Rr2 = (a.R[6] * r0 + a.R[7] * r1) + a.R[8] * r2;
   float pn0 = Rr0 / ids + a.t[0], pn1 = Rr1 / ids + a.t[1], pn2 = Rr2 / ids + a.t[2];
-  float new_idepth = 1.0f / pn2;
+  float new_idepth = lsd_rcp_exact(pn2);
   float u_new = pn0 * new_idepth * a.fx + a.cx;
   float v_new = pn1 * new_idepth * a.fy + a.cy;
   if (!(u_new > 2.1f && v_new > 2.1f && u_new < a.w - 3.1f && v_new < a.h - 3.1f)) return;
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
         val_sum += a.m.validity[j];
         if (removeOcclusions) numNotOccluding++;
         float distFac = (float)(dx * dx + dy * dy) * a.regDistVar;
-        float ivar = 1.0f / (s_var + distFac);
+        float ivar = lsd_rcp_exact(s_var + distFac);
         sum += s_id * ivar;
         sumIvar += ivar;
       }
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
       sum = sum / sumIvar;
       sum = unzero(sum);
       a.m.idepth_s[idx] = sum;
-      a.m.var_s[idx] = 1.0f / sumIvar;
+      a.m.var_s[idx] = lsd_rcp_exact(sumIvar);
     }
   }
   a.validOut[idx] = nowValid;
@@ -969,13 +969,14 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
                                                double* __restrict__ partials, const KfExtra* __restrict__ kx = nullptr) {
   constexpr int HALO = FILL ? 4 : 2;
   constexpr int TW = 32 + 2 * HALO, TH = 8 + 2 * HALO, TN = TW * TH;
-  // Per tile entry two words instead of four arrays: pk = validity_counter of a valid pixel (never negative), -1 for an invalid one
-  // (s_pk0: the snapshot K5 reads, s_pk: after K5, what K6 reads), and (idepth, idepth_var) as one 8-byte word — a neighbour costs K6
-  // two LDS reads instead of four, K5 one or two instead of two or three.
+  // Per tile entry ONE 16-byte word (idepth, idepth_var, pk) with pk = validity_counter of a valid pixel (never negative), -1 for an
+  // invalid one: a neighbour costs K6 one LDS round trip (round 4: two dependent ones — the validity word, then, behind the branch on
+  // it, the hypothesis; rounds 1-3: four arrays).  s_pk0 is the pre-K5 snapshot of pk that K5 reads.
   __shared__ int s_pk0[TN];
-  __shared__ int s_pk[TN];
   __shared__ uint8_t s_created[TN];
-  __shared__ float2 s_iv[TN];
+  typedef float rege __attribute__((ext_vector_type(4)));
+  typedef float rege3 __attribute__((ext_vector_type(3)));   // (what K6 reads of an entry: a 12-byte load leaves no dead register behind)
+  __shared__ rege s_e[TN];
   __shared__ double s_sum[4];
   __shared__ int s_cnt[4];
   const int tid = threadIdx.x;
@@ -1004,9 +1005,8 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
       const float var = a.m.var[g];
       const int pk = (inb && v) ? vc : -1;
       s_pk0[e] = pk;
-      s_pk[e] = pk;
       s_created[e] = 0;
-      s_iv[e] = make_float2(id, var);
+      s_e[e] = rege{id, var, __int_as_float(pk), 0.f};
     }
   }
   // K5's gradient test reads the keyframe's maxGradients at the pixels of its region: issued with the tile loads (one memory round
@@ -1054,18 +1054,17 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
                 for (int dx = -2; dx <= 2; dx++) {
                   const int j = e + dx + dy * TW;
                   if (s_pk0[j] >= 0) {
-                    const float2 iv = s_iv[j];
+                    const rege iv = s_e[j];
                     const float sv = iv.y;
                     sumIdepthObs += iv.x / sv;
-                    sumIVarObs += 1.0f / sv;
+                    sumIVarObs += lsd_rcp_exact(sv);
                   }
                 }
               float idepthObs = sumIdepthObs / sumIVarObs;
               idepthObs = unzero(idepthObs);
               s_created[e] = 1;
               // nobody reads these entries during K5 (their snapshot validity is 0)
-              s_pk[e] = 0;
-              s_iv[e] = make_float2(idepthObs, VAR_RANDOM_INIT_INITIAL);
+              s_e[e] = rege{idepthObs, VAR_RANDOM_INIT_INITIAL, __int_as_float(0), 0.f};
             }
           }
         }
@@ -1081,7 +1080,9 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   const bool inImage = x < w && y < h;
   const int idx = inImage ? x + y * w : 0;
   const bool created = FILL && s_created[e] != 0;
-  const uint8_t wasValid = s_pk[e] >= 0 ? 1 : 0;
+  const rege c_e = s_e[e];
+  const int c_pk = __float_as_int(c_e.z);
+  const uint8_t wasValid = c_pk >= 0 ? 1 : 0;
   uint8_t nowValid = wasValid;
   bool smoothed = false, blacklistDec = false;
   float out_ids = 0.f, out_vars = 0.f;
@@ -1089,33 +1090,37 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   // same as this form at 30 % and at 50 % valid pixels: profiles/r05_notes.md section 5)
   const bool doK6 = inImage && x >= 2 && x < w - 2 && y >= 2 && y < h - 2 && wasValid;
   if (doK6) {
-    const float2 c_iv = s_iv[e];
-    const float c_id = c_iv.x;
-    const float c_var = c_iv.y;
+    const float c_id = c_e.x;
+    const float c_var = c_e.y;
     float sum = 0, val_sum = 0, sumIvar = 0;
     int numOccluding = 0, numNotOccluding = 0;
+    // (the branches stay: on semi-dense maps whole waves skip most neighbours — the predicated form of this loop, every neighbour's
+    // arithmetic for every valid centre, ran the 32-map pass in 214 us against 166, profiles/r05_notes.md section 5.)
+    // The next neighbour's entry is requested before the current one is worked on (volatile: the read stays where it is written instead
+    // of sinking below the branches to its first use), so an LDS round trip overlaps the arithmetic instead of preceding it.
+    auto entry = [&](int k) { const int dx = k / 5 - 2, dy = k % 5 - 2; return *(const volatile __attribute__((address_space(3))) rege3*)&s_e[e + dx + dy * TW]; };
+    rege3 ej = entry(0);
 #pragma unroll
-    for (int dx = -2; dx <= 2; dx++)
-#pragma unroll
-      for (int dy = -2; dy <= 2; dy++) {
-        const int j = e + dx + dy * TW;
-        const int vcj = s_pk[j];
-        const float2 ivj = s_iv[j];
-        const float s_idj = ivj.x;
-        const float s_varj = ivj.y;
-        if (vcj < 0) continue;
-        const float diff = s_idj - c_id;
-        if (DIFF_FAC_SMOOTHING * diff * diff > s_varj + c_var) {
-          if (OCC) { if (s_idj > c_id) numOccluding++; }
-          continue;
-        }
-        val_sum += vcj;
-        if (OCC) numNotOccluding++;
-        const float distFac = (float)(dx * dx + dy * dy) * a.regDistVar;
-        const float ivar = 1.0f / (s_varj + distFac);
-        sum += s_idj * ivar;
-        sumIvar += ivar;
+    for (int k = 0; k < 25; k++) {
+      const int dx = k / 5 - 2, dy = k % 5 - 2;     // dx outer, dy inner: the reference's order of the sums
+      const rege3 en = entry(k < 24 ? k + 1 : 24);
+      const int vcj = __float_as_int(ej.z);
+      const float s_idj = ej.x;
+      const float s_varj = ej.y;
+      ej = en;
+      if (vcj < 0) continue;
+      const float diff = s_idj - c_id;
+      if (DIFF_FAC_SMOOTHING * diff * diff > s_varj + c_var) {
+        if (OCC) { if (s_idj > c_id) numOccluding++; }
+        continue;
       }
+      val_sum += vcj;
+      if (OCC) numNotOccluding++;
+      const float distFac = (float)(dx * dx + dy * dy) * a.regDistVar;
+      const float ivar = lsd_rcp_exact(s_varj + distFac);
+      sum += s_idj * ivar;
+      sumIvar += ivar;
+    }
     if (val_sum < a.validityTH) {
       nowValid = 0;
       blacklistDec = true;
@@ -1124,7 +1129,7 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     } else {
       sum = sum / sumIvar;
       out_ids = unzero(sum);
-      out_vars = 1.0f / sumIvar;
+      out_vars = lsd_rcp_exact(sumIvar);
       smoothed = true;
     }
   }
@@ -1135,8 +1140,8 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     if (created) {
       a.m.nextID[idx] = 0;
       a.m.validity[idx] = 0;
-      a.m.idepth[idx] = s_iv[e].x;
-      a.m.var[idx] = s_iv[e].y;
+      a.m.idepth[idx] = c_e.x;
+      a.m.var[idx] = c_e.y;
       a.m.blacklisted[idx] = blacklistDec ? -1 : 0;
       blFinal = blacklistDec ? -1 : 0; blKnown = true;
       if (!smoothed) { a.m.idepth_s[idx] = -1; a.m.var_s[idx] = -1; }
@@ -1157,10 +1162,10 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   if (KF && inImage) {
     // Frame::takeReActivationData (Frame.cpp:107-145) of the keyframe being finalised, then this hypothesis' step into the new keyframe
     if (nowValid) {
-      kx->reactId[idx] = s_iv[e].x;
-      kx->reactVar[idx] = s_iv[e].y;
-      kx->reactVal[idx] = (uint8_t)s_pk[e];
-      prop_candidate(kx->prop, x, y, idx, ids, s_iv[e].y, s_pk[e]);
+      kx->reactId[idx] = c_e.x;
+      kx->reactVar[idx] = c_e.y;
+      kx->reactVal[idx] = (uint8_t)c_pk;
+      prop_candidate(kx->prop, x, y, idx, ids, c_e.y, c_pk);
     } else {
       const int bl = blKnown ? blFinal : a.m.blacklisted[idx];
       kx->reactVar[idx] = bl < MIN_BLACKLIST ? -2.f : -1.f;

@@ -6,11 +6,14 @@
 //   Sim3Tracker::calcSim3LGSSSE                  :858-983 + LGS4 / LGS6 / LGS7  C/Tracking/LGSX.h:45-176, :184-402, :411-443
 //   Sim3Tracker::trackFrameSim3                  :149-378
 //
-// One evaluation = k_sim3_eval (buffers + weights + both least-squares systems fused, one reference pixel per lane,
-// 54 sums reduced lane -> LDS -> one row per tile) + k_sim3_finalize (fixed-order row sums, SSE tail drop) -> pinned host
-// record.  The Levenberg-Marquardt loop itself runs on the host in the reference's precision (7x7 float LDL^T, Sim3 exp /
-// composition in double): this tracker serves the constraint search, where a ~30 us round trip per evaluation does not
-// matter; the pose-critical SE3 tracker (tracker.hip) keeps its loop on the device.
+// One evaluation = buffers + weights + both least-squares systems fused (sim3_eval_tile: one reference pixel per lane, 54 sums
+// reduced lane -> LDS -> one row per tile) + fixed-order row sums with the SSE tail drop (sim3_totals).
+// trackFrameSim3 runs on the device, one launch per evaluation (k_sim3_fused, built like k_track_step of the SE3 tracker): every
+// workgroup first totals the previous launch's rows, takes the Levenberg-Marquardt decision (the loop of Sim3Tracker.cpp:149-378 as
+// a state machine; 7x7 system solved by one wave, Sim3 exp / composition in double as the reference) and then evaluates its tile of
+// the next request.  The host queues a budget of launches and waits for one pinned word per job.  Rounds 2-4 drove the loop from
+// the host: one round trip per evaluation, 28 us per evaluation of which 21 were kernels.
+// lsdhip_sim3tracker_evaluate (a single evaluation for the tests) keeps the two-kernel form: k_sim3_eval + k_sim3_finalize -> pinned record.
 //
 // Quirks kept: the SSE loops ignore the last size % 4 in-image points (x-outer / y-inner order) for the residual sums and
 // both systems; LGS6::updateSSE counts 6 and LGS4::updateSSE 4 constraints per group of four points.
@@ -69,7 +72,7 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
     const float id = a.kf_idepth[i];
     if (!(var <= 0 || id == 0)) {
       // TrackingReference::makePointCloud (TrackingReference.cpp:128-138)
-      const float inv = 1.0f / id;
+      const float inv = lsd_rcp_exact(id);
       const float px = inv * (a.fxi * x + a.cxi), py = inv * (a.fyi * y + a.cyi), pz = inv * 1.0f;
       const float I_ref = a.kf_image[i];
       const float4 gref = a.kf_grad[i];
@@ -103,29 +106,29 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
         acc[S3_SXX] = c1 * c1 * hwgt; acc[S3_SYY] = c2 * c2 * hwgt; acc[S3_SX] = c1 * hwgt; acc[S3_SY] = c2 * hwgt; acc[S3_SW] = hwgt;
         const int idx_rounded = (int)(u_new + 0.5f) + a.w * (int)(v_new + 0.5f);
         const float var_frameDepth = a.fr_idepthVar[idx_rounded];
-        const float ref_idepth = 1.0f / Wz;
-        const float d = 1.0f / pz;
+        const float ref_idepth = lsd_rcp_exact(Wz);
+        const float d = lsd_rcp_exact(pz);
         float rd = -1, sv = -1;
         if (var_frameDepth > 0) { rd = ref_idepth - a.fr_idepth[idx_rounded]; sv = var_frameDepth; }
         const float depthChange = pz / Wz;
         acc[S3_USAGE] = depthChange < 1 ? depthChange : 1;
 
         // calcSim3WeightsAndResidualSSE, operation order of the SSE path
-        const float pz2d = 1.0f / ((Wz * Wz) * d);
+        const float pz2d = lsd_rcp_exact((Wz * Wz) * d);
         const float g0 = (Wz * a.t[0] - Wx * a.t[2]) * pz2d;
         const float g1 = (Wz * a.t[1] - Wy * a.t[2]) * pz2d;
         const float g2 = (Wz - a.t[2]) * pz2d;
         const float drpdd = g0 * gx + g1 * gy;
         const float s_ = a.var_weight * var;
-        const float w_p = 1.0f / (a.cameraPixelNoise2 + drpdd * (drpdd * s_));
-        const float w_d = 1.0f / (sv + g2 * (g2 * s_));
+        const float w_p = lsd_rcp_exact(a.cameraPixelNoise2 + drpdd * (drpdd * s_));
+        const float w_d = lsd_rcp_exact(sv + g2 * (g2 * s_));
         float wrp = rp * sqrtf(w_p);
         wrp = fmaxf(wrp, 0.0f - wrp);
         float wrd = rd * sqrtf(w_d);
         wrd = fmaxf(wrd, 0.0f - wrd);
         const bool depthValid = 0.0f < sv;
         const float wabs = (depthValid ? wrd : 0.0f) + wrp;
-        const float wh = (wabs < a.huber_d) ? 1.0f : a.huber_d * (1.0f / wabs);
+        const float wh = (wabs < a.huber_d) ? 1.0f : a.huber_d * lsd_rcp_exact(wabs);
         acc[S3_NUMD] = depthValid ? 1.f : 0.f;
         acc[S3_SUMRESD] = depthValid ? wh * (wrd * wrd) : 0.f;
         acc[S3_SUMRESP] = wh * (wrp * wrp);
@@ -133,7 +136,7 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
         const float wd = depthValid ? wh * w_d : 0.f;
 
         // calcSim3LGSSSE
-        const float z = 1.0f / Wz;
+        const float z = lsd_rcp_exact(Wz);
         float J6[6], J4[4];
         J4[3] = z;
         J6[0] = z * gx;
@@ -305,17 +308,18 @@ __global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Batch batch) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// host: Sim3 algebra (double, Sophus semantics), 7x7 LDL^T, the LM loop
+// Sim3 algebra (double, Sophus semantics) and 7x7 LDL^T — host + device
 // ---------------------------------------------------------------------------------------------------------------
+#define S3_HD __host__ __device__ inline
 namespace {
 struct Sim3H { lsdm::Quatd q; double t[3]; double s; };
 
-Sim3H sim3_identity() { Sim3H r; r.q = {1, 0, 0, 0}; r.t[0] = r.t[1] = r.t[2] = 0; r.s = 1; return r; }
-void qd_normalize(lsdm::Quatd& q) {
+S3_HD Sim3H sim3_identity() { Sim3H r; r.q = {1, 0, 0, 0}; r.t[0] = r.t[1] = r.t[2] = 0; r.s = 1; return r; }
+S3_HD void qd_normalize(lsdm::Quatd& q) {
   double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
   q.w /= n; q.x /= n; q.y /= n; q.z /= n;
 }
-Sim3H sim3_inverse(const Sim3H& S) {   // sim3.hpp:169-173
+S3_HD Sim3H sim3_inverse(const Sim3H& S) {   // sim3.hpp:169-173
   Sim3H r;
   r.q = lsdm::q_conj(S.q);
   r.s = 1.0 / S.s;
@@ -324,7 +328,7 @@ Sim3H sim3_inverse(const Sim3H& S) {   // sim3.hpp:169-173
   for (int i = 0; i < 3; i++) r.t[i] = -(rt[i] * r.s);
   return r;
 }
-Sim3H sim3_mul(const Sim3H& a, const Sim3H& b) {   // sim3.hpp:160-163
+S3_HD Sim3H sim3_mul(const Sim3H& a, const Sim3H& b) {   // sim3.hpp:160-163
   Sim3H r;
   double rt[3];
   lsdm::q_rotate<lsdm::Quatd, double>(a.q, b.t, rt);
@@ -334,7 +338,7 @@ Sim3H sim3_mul(const Sim3H& a, const Sim3H& b) {   // sim3.hpp:160-163
   r.s = a.s * b.s;
   return r;
 }
-Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-425, calcW sim3.hpp:608-650
+S3_HD Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-425, calcW sim3.hpp:608-650
   const double eps = 1e-10;
   const double ox = a[3], oy = a[4], oz = a[5], sigma = a[6];
   const double scale = std::exp(sigma);
@@ -391,10 +395,13 @@ Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-425, ca
   return r;
 }
 // 7x7 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics), as lsdm::ldlt6_solve
-void ldlt7_solve(const float Ain[49], const float bin[7], float x[7]) {
+// (the factorisation indexes its matrix with run-time indices: the caller provides the storage — the stack on the host, LDS on the device,
+// where a private array of that kind would live in scratch memory)
+struct Ldlt7Scratch { float M[7][7]; int p[7]; float y[7]; };
+S3_HD void ldlt7_solve(const float Ain[49], const float bin[7], float x[7], Ldlt7Scratch& W) {
   const int n = 7;
-  float M[7][7];
-  int p[7];
+  float (&M)[7][7] = W.M;
+  int (&p)[7] = W.p;
   for (int i = 0; i < n; i++) { p[i] = i; for (int j = 0; j < n; j++) M[i][j] = Ain[i * n + j]; }
   for (int k = 0; k < n; k++) {
     int piv = k;
@@ -414,7 +421,7 @@ void ldlt7_solve(const float Ain[49], const float bin[7], float x[7]) {
       M[i][k] = d != 0.0f ? v / d : 0.0f;
     }
   }
-  float y[7];
+  float (&y)[7] = W.y;
   for (int i = 0; i < n; i++) y[i] = bin[p[i]];
   for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) y[i] -= M[i][j] * y[j];
   for (int i = 0; i < n; i++) y[i] = M[i][i] != 0.0f ? y[i] / M[i][i] : 0.0f;
@@ -430,20 +437,64 @@ struct Eval {
   float A[49], b[7];
   size_t num_constraints;
 };
+// the evaluation's outcome in the reference's terms, from its (tail-corrected) totals
+S3_HD void sim3_eval_from_totals(const float* r, Eval* ev) {
+  ev->M = (int)r[S3_M];
+  ev->pointUsage = r[S3_USAGE] / r[S3_NREF];
+  {
+    const float sxx = r[S3_SXX], syy = r[S3_SYY], sx = r[S3_SX], sy = r[S3_SY], sw = r[S3_SW];
+    ev->aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
+    ev->aff_b_lastIt = (sy - ev->aff_a_lastIt * sx) / sw;
+  }
+  Sim3Res& s = ev->res;
+  s.sumResP = r[S3_SUMRESP];
+  s.numTermsP = (ev->M >> 2) << 2;
+  s.sumResD = r[S3_SUMRESD];
+  s.numTermsD = (int)r[S3_NUMD];
+  s.mean = (s.sumResD + s.sumResP) / (s.numTermsD + s.numTermsP);
+  s.meanD = s.sumResD / s.numTermsD;
+  s.meanP = s.sumResP / s.numTermsP;
+  // LGS6 / LGS4 finishNoDivide + LGS7::initializeFrom (LGSX.h:424-442)
+  for (int i = 0; i < 49; i++) ev->A[i] = 0.f;
+  for (int i = 0; i < 7; i++) ev->b[i] = 0.f;
+  int k = S3_A6;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++, k++) { const float v = 0.0f + r[k]; ev->A[i * 7 + j] = v; ev->A[j * 7 + i] = v; }
+  for (int i = 0; i < 6; i++) ev->b[i] = 0.0f - r[S3_A6 + 21 + i];
+  // (the 4x4 depth system lands on rows / columns 2, 3, 4, 6 of the 7x7 one)
+  k = S3_A4;
+  for (int i = 0; i < 4; i++)
+    for (int j = i; j < 4; j++, k++) {
+      const int ri = i < 3 ? 2 + i : 6, rj = j < 3 ? 2 + j : 6;
+      const float v = 0.0f + r[k];
+      ev->A[ri * 7 + rj] += v;
+      if (i != j) ev->A[rj * 7 + ri] += v;
+    }
+  for (int i = 0; i < 4; i++) ev->b[i < 3 ? 2 + i : 6] += 0.0f - r[S3_A4 + 10 + i];
+  ev->num_constraints = (size_t)6 * (size_t)(ev->M >> 2) + (size_t)4 * (size_t)(ev->M >> 2);
+}
 }  // namespace
 
+struct Sim3Set;
+namespace { struct Sim3Track; }
 struct lsdhip_sim3tracker {
   lsdhip_ctx* ctx = nullptr;
   int maxItsPerLvl[LSD_LEVELS] = {5, 20, 50, 100, 100};
   float lambdaSuccessFac = 0.5f, lambdaFailFac = 2.0f, lambdaInitial = 0, stepSizeMin = 1e-8f, convergenceEps = 0.999f;
   float huber_d = 3, var_weight = 1.0f;
-  float* d_rows = nullptr;     // [S3_MAXB][max_blocks][64]
-  int4* d_topkey = nullptr;    // [S3_MAXB][max_blocks]
-  float* d_topval = nullptr;   // [S3_MAXB][max_blocks][3][48]
+  float* d_rows = nullptr;     // [2][S3_MAXB][max_blocks][64]
+  int4* d_topkey = nullptr;    // [2][S3_MAXB][max_blocks]
+  float* d_topval = nullptr;   // [2][S3_MAXB][max_blocks][3][48]
   float* h_record = nullptr;   // [S3_MAXB][64] pinned, device-mapped
   float* d_record = nullptr;   // device alias of h_record
   int seq = 0;                 // launch counter, echoed by k_sim3_finalize in word 63 of every active slot's record
   int max_blocks = 0;
+  // trackFrameSim3 on the device (k_sim3_eval_dev / k_sim3_step): per batch slot the job's level descriptions and LM state
+  Sim3Set* h_sets = nullptr;  Sim3Set* d_sets = nullptr;              // [S3_MAXB]; h_*: pinned staging
+  Sim3Track* h_states = nullptr;  Sim3Track* d_states = nullptr;      // [S3_MAXB]
+  lsdhip_sim3_result* h_results = nullptr;  lsdhip_sim3_result* d_results = nullptr;   // [S3_MAXB] pinned, device-mapped
+  int* h_done = nullptr;  int* d_done = nullptr;                              // [S3_MAXB] pinned, device-mapped
+  int recentRounds = 0;        // evaluations the longest job of the last call needed: the next call's launch budget
 };
 
 extern "C" int lsdhip_sim3tracker_create(lsdhip_ctx* c, lsdhip_sim3tracker** out) {
@@ -452,7 +503,7 @@ extern "C" int lsdhip_sim3tracker_create(lsdhip_ctx* c, lsdhip_sim3tracker** out
   lsdhip_sim3tracker* t = new lsdhip_sim3tracker();
   t->ctx = c;
   t->max_blocks = (c->w * c->h + S3_BLOCK - 1) / S3_BLOCK;
-  const size_t mb = (size_t)t->max_blocks * S3_MAXB;
+  const size_t mb = (size_t)t->max_blocks * S3_MAXB * 2;   // two launch parities (k_sim3_fused)
   HIPCHK(hipMalloc((void**)&t->d_rows, mb * 64 * 4));
   HIPCHK(hipMalloc((void**)&t->d_topkey, mb * 16));
   HIPCHK(hipMalloc((void**)&t->d_topval, mb * 3 * 48 * 4));
@@ -468,6 +519,8 @@ extern "C" void lsdhip_sim3tracker_destroy(lsdhip_sim3tracker* t) {
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
   (void)hipFree(t->d_rows); (void)hipFree(t->d_topkey); (void)hipFree(t->d_topval); (void)hipHostFree(t->h_record);
+  (void)hipFree(t->d_sets); (void)hipFree(t->d_states);
+  (void)hipHostFree(t->h_sets); (void)hipHostFree(t->h_states); (void)hipHostFree(t->h_results); (void)hipHostFree(t->h_done);
   delete t;
 }
 extern "C" int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int its[LSD_LEVELS]) {
@@ -567,43 +620,7 @@ static int sim3_run_batch(lsdhip_sim3tracker* t, Sim3Batch& batch, int nslots) {
   }
   return LSDHIP_OK;
 }
-// the evaluation's outcome in the reference's terms, from slot `slot`'s record
-static void sim3_read_eval(lsdhip_sim3tracker* t, int slot, Eval* ev) {
-  const float* r = t->h_record + (size_t)slot * 64;
-  ev->M = (int)r[S3_M];
-  ev->pointUsage = r[S3_USAGE] / r[S3_NREF];
-  {
-    const float sxx = r[S3_SXX], syy = r[S3_SYY], sx = r[S3_SX], sy = r[S3_SY], sw = r[S3_SW];
-    ev->aff_a_lastIt = sqrtf((syy - sy * sy / sw) / (sxx - sx * sx / sw));
-    ev->aff_b_lastIt = (sy - ev->aff_a_lastIt * sx) / sw;
-  }
-  Sim3Res& s = ev->res;
-  s.sumResP = r[S3_SUMRESP];
-  s.numTermsP = (ev->M >> 2) << 2;
-  s.sumResD = r[S3_SUMRESD];
-  s.numTermsD = (int)r[S3_NUMD];
-  s.mean = (s.sumResD + s.sumResP) / (s.numTermsD + s.numTermsP);
-  s.meanD = s.sumResD / s.numTermsD;
-  s.meanP = s.sumResP / s.numTermsP;
-  // LGS6 / LGS4 finishNoDivide + LGS7::initializeFrom (LGSX.h:424-442)
-  memset(ev->A, 0, sizeof(ev->A));
-  memset(ev->b, 0, sizeof(ev->b));
-  int k = S3_A6;
-  for (int i = 0; i < 6; i++)
-    for (int j = i; j < 6; j++, k++) { const float v = 0.0f + r[k]; ev->A[i * 7 + j] = v; ev->A[j * 7 + i] = v; }
-  for (int i = 0; i < 6; i++) ev->b[i] = 0.0f - r[S3_A6 + 21 + i];
-  float A4[16], b4[4];
-  k = S3_A4;
-  for (int i = 0; i < 4; i++)
-    for (int j = i; j < 4; j++, k++) { const float v = 0.0f + r[k]; A4[i * 4 + j] = v; A4[j * 4 + i] = v; }
-  for (int i = 0; i < 4; i++) b4[i] = 0.0f - r[S3_A4 + 10 + i];
-  const int remap[4] = {2, 3, 4, 6};
-  for (int i = 0; i < 4; i++) {
-    ev->b[remap[i]] += b4[i];
-    for (int j = 0; j < 4; j++) ev->A[remap[i] * 7 + remap[j]] += A4[i * 4 + j];
-  }
-  ev->num_constraints = (size_t)6 * (size_t)(ev->M >> 2) + (size_t)4 * (size_t)(ev->M >> 2);
-}
+static void sim3_read_eval(lsdhip_sim3tracker* t, int slot, Eval* ev) { sim3_eval_from_totals(t->h_record + (size_t)slot * 64, ev); }
 
 static Sim3H sim3_in(const double p[8]) { Sim3H T; T.q = {p[0], p[1], p[2], p[3]}; T.t[0] = p[4]; T.t[1] = p[5]; T.t[2] = p[6]; T.s = p[7]; return T; }
 static void sim3_out(const Sim3H& T, double p[8]) { p[0] = T.q.w; p[1] = T.q.x; p[2] = T.q.y; p[3] = T.q.z; p[4] = T.t[0]; p[5] = T.t[1]; p[6] = T.t[2]; p[7] = T.s; }
@@ -616,7 +633,8 @@ extern "C" int lsdhip_host_sim3_step(const double increment[7], const double ref
 }
 extern "C" int lsdhip_host_ldlt7(const float A[49], const float b[7], float x[7]) {
   if (!A || !b || !x) return LSDHIP_E_ARG;
-  ldlt7_solve(A, b, x);
+  Ldlt7Scratch W;
+  ldlt7_solve(A, b, x, W);
   return LSDHIP_OK;
 }
 
@@ -641,31 +659,77 @@ extern "C" int lsdhip_sim3tracker_evaluate(lsdhip_sim3tracker* t, lsdhip_frame* 
   return LSDHIP_OK;
 }
 
-// Sim3Tracker::trackFrameSim3 (Sim3Tracker.cpp:149-378) as a resumable state machine: the control flow of the reference
-// between two evaluations is `advance`, which either asks for the next evaluation (pose + level) or finishes the job.
-// Several jobs advance in lock step and share the launches of their evaluations (lsdhip_sim3tracker_track_batch).
+// ---- the Levenberg-Marquardt loop of trackFrameSim3 (Sim3Tracker.cpp:149-378) as a state machine between two evaluations --------------
+// `advance` takes the evaluation that was asked for and either asks for the next one (transformation + level) or finishes the job.
+// It runs on the device (lane 0 of every workgroup of k_sim3_fused, the state staged in LDS); the host only starts a job with it
+// (sim3_init_job).  7x7 float system, Sim3 exp / composition in double, as the reference.  Several jobs advance in lock step and share
+// their launches (lsdhip_sim3tracker_track_batch: blockIdx.y = job).
 namespace {
-struct Sim3Track {
-  lsdhip_frame* kf = nullptr;
-  lsdhip_frame* frame = nullptr;
-  lsdhip_sim3_result* out = nullptr;
-  enum Phase { LEVEL_FIRST, TRY, FINAL, DONE } phase = DONE;
-  int rc = LSDHIP_OK;
+struct Sim3LM {                    // the tracker's settings as the state machine needs them
+  int maxIts[LSD_LEVELS];
+  float lambdaSuccessFac, lambdaFailFac, lambdaInitial, stepSizeMin, convergenceEps;
+  int useAffine, w, h;
+};
+struct Sim3Track {                  // plain data: lives in HBM between the launches, in LDS while k_sim3_step works on it
+  lsdhip_sim3_result res;          // the result record as far as it is known (workgroup 0 copies it to the pinned record at the end)
+  lsdhip_sim3_result* hostOut;     // the caller's record
+  enum Phase { LEVEL_FIRST, TRY, FINAL, DONE };
+  int phase;
+  int rc;
   Sim3H referenceToFrame, candidate;
-  float aff_a = 1, aff_b = 0;
-  int lvl = 0, finalLevel = 0, iteration = 0, incTry = 0, numEvaluations = 0;
-  float LM_lambda = 0, absInc = 0;
-  bool warp_update_up_to_date = false;
+  float aff_a, aff_b;
+  int lvl, finalLevel, iteration, incTry, numEvaluations;
+  float LM_lambda, absInc;
+  int warp_update_up_to_date;
   Eval cur;
   Sim3Res lastErr, finalResidual;
   // the evaluation this job waits for
   Sim3H reqPose;
-  int reqLevel = 0;
+  int reqLevel;
+  // ... as k_sim3_eval_dev reads it (sim3_request)
+  float reqR[9], reqT[3], reqRoll[4];
+  int pendingEval;                 // the previous launch evaluated the request: its rows wait in the scratch of this launch's parity
 };
+static_assert(sizeof(Sim3Track) % 4 == 0, "copied by words");
+struct Sim3Scratch { float A[49], b[7], inc[7]; int solve; float m[7][8]; };
 
-void sim3_finish(lsdhip_sim3tracker* t, Sim3Track& J) {
-  lsdhip_sim3_result* out = J.out;
-  memcpy(out->lastSim3Hessian, J.cur.A, sizeof(J.cur.A));
+// the requested transformation as the evaluation kernel wants it: rxso3().matrix() and translation in float, the in-plane roll of the
+// reference gradients (ESM, Sim3Tracker.cpp:455-464)
+S3_HD void sim3_request(Sim3Track& J) {
+  const Sim3H& T = J.reqPose;
+  double Rd[9];
+  lsdm::quatd_to_rot(T.q, Rd);
+  float Ru[9];
+  for (int i = 0; i < 9; i++) { J.reqR[i] = (float)(T.s * Rd[i]); Ru[i] = (float)Rd[i]; }
+  for (int i = 0; i < 3; i++) J.reqT[i] = (float)T.t[i];
+  // Quaternionf::setFromTwoVectors(R * (0,0,-1), (0,0,-1)).toRotationMatrix() * R
+  const float rf[3] = {Ru[0] * 0.f + Ru[1] * 0.f + Ru[2] * -1.f, Ru[3] * 0.f + Ru[4] * 0.f + Ru[5] * -1.f, Ru[6] * 0.f + Ru[7] * 0.f + Ru[8] * -1.f};
+  const float n0 = sqrtf(rf[0] * rf[0] + (rf[1] * rf[1] + rf[2] * rf[2]));
+  const float v0[3] = {rf[0] / n0, rf[1] / n0, rf[2] / n0};
+  const float v1[3] = {0, 0, -1};
+  const float cdot = v1[0] * v0[0] + (v1[1] * v0[1] + v1[2] * v0[2]);
+  lsdm::Quatf q;
+  if (cdot < -1.0f + 1e-5f) {
+    q = {0, 1, 0, 0};
+  } else {
+    const float ax = v0[1] * v1[2] - v0[2] * v1[1], ay = v0[2] * v1[0] - v0[0] * v1[2], az = v0[0] * v1[1] - v0[1] * v1[0];
+    const float sq = sqrtf((1.0f + cdot) * 2.0f);
+    const float invs = 1.0f / sq;
+    q = {sq * 0.5f, ax * invs, ay * invs, az * invs};
+  }
+  float Q[9];
+  lsdm::quatf_to_rot(q, Q);
+  // rows 0 and 1, columns 0 and 1 of Q * R
+  J.reqRoll[0] = (Q[0] * Ru[0] + Q[1] * Ru[3]) + Q[2] * Ru[6];
+  J.reqRoll[1] = (Q[0] * Ru[1] + Q[1] * Ru[4]) + Q[2] * Ru[7];
+  J.reqRoll[2] = (Q[3] * Ru[0] + Q[4] * Ru[3]) + Q[5] * Ru[6];
+  J.reqRoll[3] = (Q[3] * Ru[1] + Q[4] * Ru[4]) + Q[5] * Ru[7];
+}
+
+S3_HD void sim3_out8(const Sim3H& T, double p[8]) { p[0] = T.q.w; p[1] = T.q.x; p[2] = T.q.y; p[3] = T.q.z; p[4] = T.t[0]; p[5] = T.t[1]; p[6] = T.t[2]; p[7] = T.s; }
+S3_HD void sim3_finish(Sim3Track& J) {
+  lsdhip_sim3_result* out = &J.res;
+  for (int i = 0; i < 49; i++) out->lastSim3Hessian[i] = J.cur.A[i];
   out->numEvaluations = J.numEvaluations;
   out->pointUsage = J.cur.pointUsage;
   out->affineEstimation_a = J.aff_a; out->affineEstimation_b = J.aff_b;
@@ -674,19 +738,19 @@ void sim3_finish(lsdhip_sim3tracker* t, Sim3Track& J) {
   out->lastResidual = J.finalResidual.mean;
   out->lastDepthResidual = J.finalResidual.meanD;
   out->lastPhotometricResidual = J.finalResidual.meanP;
-  sim3_out(sim3_inverse(J.referenceToFrame), out->frameToReference);
+  sim3_out8(sim3_inverse(J.referenceToFrame), out->frameToReference);
   J.rc = LSDHIP_OK;
 }
-void sim3_diverge(Sim3Track& J, bool setFlag) {
+S3_HD void sim3_diverge(Sim3Track& J, bool setFlag) {
   // Sim3() is already in the result; `diverged` is only raised where the reference raises it (too few points, scale <= 0)
-  if (setFlag) J.out->diverged = 1;
-  J.out->numEvaluations = J.numEvaluations;
+  if (setFlag) J.res.diverged = 1;
+  J.res.numEvaluations = J.numEvaluations;
   J.phase = Sim3Track::DONE;
   J.rc = LSDHIP_DIVERGED;
 }
 // enter the next level that has iterations (or the final re-evaluation / the end)
-void sim3_next_level(lsdhip_sim3tracker* t, Sim3Track& J) {
-  while (J.lvl >= J.finalLevel && t->maxItsPerLvl[J.lvl] == 0) J.lvl--;
+S3_HD void sim3_next_level(const Sim3LM& P, Sim3Track& J) {
+  while (J.lvl >= J.finalLevel && P.maxIts[J.lvl] == 0) J.lvl--;
   if (J.lvl >= J.finalLevel) {
     J.phase = Sim3Track::LEVEL_FIRST;
     J.reqPose = J.referenceToFrame; J.reqLevel = J.lvl;
@@ -699,111 +763,316 @@ void sim3_next_level(lsdhip_sim3tracker* t, Sim3Track& J) {
     J.reqPose = J.referenceToFrame; J.reqLevel = J.finalLevel;
     return;
   }
-  sim3_finish(t, J);
+  sim3_finish(J);
 }
-// solve the damped system of the last accepted evaluation and ask for the evaluation of the candidate
-void sim3_propose(lsdhip_sim3tracker* t, Sim3Track& J) {
-  float b[7], A[49], inc[7];
+// The damped system of the last accepted evaluation (A / n, b / n with the constraint count n, diagonal * (1 + lambda)); its solution is
+// the next increment.  The device solves it with the lanes of a wave between the two halves (gj7_solve_wave); `solve` is raised for that.
+S3_HD void sim3_propose(const Sim3LM& P, Sim3Track& J, Sim3Scratch& W) {
   const float nc = (float)J.cur.num_constraints;
-  for (int i = 0; i < 7; i++) b[i] = -J.cur.b[i] / nc;
-  for (int i = 0; i < 49; i++) A[i] = J.cur.A[i] / nc;
-  for (int i = 0; i < 7; i++) A[i * 7 + i] *= 1 + J.LM_lambda;
-  ldlt7_solve(A, b, inc);
+  for (int i = 0; i < 7; i++) W.b[i] = -J.cur.b[i] / nc;
+  for (int i = 0; i < 49; i++) W.A[i] = J.cur.A[i] / nc;
+  for (int i = 0; i < 7; i++) W.A[i * 7 + i] *= 1 + J.LM_lambda;
+  W.solve = 1;
+}
+// ... and, with the increment, the candidate transformation whose evaluation is asked for
+S3_HD void sim3_propose_finish(const Sim3LM& P, Sim3Track& J, Sim3Scratch& W) {
   J.incTry++;
   float absInc = 0;
-  for (int i = 0; i < 7; i++) absInc += inc[i] * inc[i];
+  for (int i = 0; i < 7; i++) absInc += W.inc[i] * W.inc[i];
   J.absInc = absInc;
   if (!(absInc >= 0 && absInc < 1)) { sim3_diverge(J, false); return; }   // returns Sim3(), Hessian zero
-  double incd[7];
-  for (int i = 0; i < 7; i++) incd[i] = (double)inc[i];
+  const double incd[7] = {(double)W.inc[0], (double)W.inc[1], (double)W.inc[2], (double)W.inc[3], (double)W.inc[4], (double)W.inc[5], (double)W.inc[6]};
   J.candidate = sim3_mul(sim3_exp(incd), J.referenceToFrame);
   J.phase = Sim3Track::TRY;
   J.reqPose = J.candidate; J.reqLevel = J.lvl;
 }
 // start of an iteration of the level's loop (`for iteration < maxIts`), or leave the level
-void sim3_iteration(lsdhip_sim3tracker* t, Sim3Track& J) {
-  if (J.iteration >= t->maxItsPerLvl[J.lvl]) { J.lvl--; sim3_next_level(t, J); return; }
-  J.warp_update_up_to_date = true;   // the system of the last accepted evaluation is what calcSim3LGS would build here
+S3_HD void sim3_iteration(const Sim3LM& P, Sim3Track& J, Sim3Scratch& W) {
+  if (J.iteration >= P.maxIts[J.lvl]) { J.lvl--; sim3_next_level(P, J); return; }
+  J.warp_update_up_to_date = 1;   // the system of the last accepted evaluation is what calcSim3LGS would build here
   J.incTry = 0;
-  sim3_propose(t, J);
+  sim3_propose(P, J, W);
 }
 // the requested evaluation has arrived
-void sim3_advance(lsdhip_sim3tracker* t, Sim3Track& J, const Eval& ev) {
-  lsdhip_ctx* c = t->ctx;
-  LSD_CTX_LOCK(c);
-  const bool useAffine = c->params.useAffineLightningEstimation != 0;
+S3_HD void sim3_advance(const Sim3LM& P, Sim3Track& J, const Eval& ev, Sim3Scratch& W) {
+  const bool useAffine = P.useAffine != 0;
   J.numEvaluations++;
   if (J.phase == Sim3Track::FINAL) {
     J.cur = ev;
     J.finalResidual = ev.res;
-    sim3_finish(t, J);
+    sim3_finish(J);
     return;
   }
-  if (ev.M < 0.5 * 0.01 * (c->w >> J.lvl) * (c->h >> J.lvl) || ev.M < 10) { sim3_diverge(J, true); return; }
+  if (ev.M < 0.5 * 0.01 * (P.w >> J.lvl) * (P.h >> J.lvl) || ev.M < 10) { sim3_diverge(J, true); return; }
   if (J.phase == Sim3Track::LEVEL_FIRST) {
     J.cur = ev;
     J.lastErr = ev.res;
     if (useAffine) { J.aff_a = ev.aff_a_lastIt; J.aff_b = ev.aff_b_lastIt; }
-    J.LM_lambda = t->lambdaInitial;
-    J.warp_update_up_to_date = false;
+    J.LM_lambda = P.lambdaInitial;
+    J.warp_update_up_to_date = 0;
     J.iteration = 0;
-    sim3_iteration(t, J);
+    sim3_iteration(P, J, W);
     return;
   }
   // TRY
   if (ev.res.mean < J.lastErr.mean) {
     J.referenceToFrame = J.candidate;
     J.cur = ev;
-    J.warp_update_up_to_date = false;
+    J.warp_update_up_to_date = 0;
     if (useAffine) { J.aff_a = ev.aff_a_lastIt; J.aff_b = ev.aff_b_lastIt; }
-    if (ev.res.mean / J.lastErr.mean > t->convergenceEps) J.iteration = t->maxItsPerLvl[J.lvl];
+    if (ev.res.mean / J.lastErr.mean > P.convergenceEps) J.iteration = P.maxIts[J.lvl];
     J.finalResidual = J.lastErr = ev.res;
     if (J.LM_lambda <= 0.2) J.LM_lambda = 0;
-    else J.LM_lambda *= t->lambdaSuccessFac;
+    else J.LM_lambda *= P.lambdaSuccessFac;
     J.iteration++;
-    sim3_iteration(t, J);
+    sim3_iteration(P, J, W);
   } else {
-    if (!(J.absInc > t->stepSizeMin)) {
-      J.iteration = t->maxItsPerLvl[J.lvl];
+    if (!(J.absInc > P.stepSizeMin)) {
+      J.iteration = P.maxIts[J.lvl];
       J.iteration++;
-      sim3_iteration(t, J);
+      sim3_iteration(P, J, W);
       return;
     }
     if (J.LM_lambda == 0) J.LM_lambda = 0.2;
-    else J.LM_lambda *= std::pow(t->lambdaFailFac, J.incTry);
-    sim3_propose(t, J);
+    else J.LM_lambda *= pow((double)P.lambdaFailFac, (double)J.incTry);
+    sim3_propose(P, J, W);
   }
 }
 }  // namespace
 
-// n independent trackFrameSim3 jobs in lock step: every round evaluates the pending transformation of each unfinished job
-// in one pair of launches (at most S3_MAXB jobs per launch)
-static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs) {
+// ---- the job on the device ---------------------------------------------------------------------------------------------------------
+struct Sim3Lvl {                  // what does not change during a job, per pyramid level
+  const float* kf_idepth; const float* kf_idepthVar; const float* kf_image; const float4* kf_grad;
+  const float4* fr_grad; const float* fr_idepth; const float* fr_idepthVar;
+  int w, h, nblocks;
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+};
+struct Sim3Set {
+  Sim3Lvl lv[LSD_LEVELS];
+  float cameraPixelNoise2, var_weight, huber_d;
+  float* rows[2]; int4* topkey[2]; float* topval[2];   // per launch parity
+  lsdhip_sim3_result* result;     // pinned: the job's result record
+  int* done;                      // pinned: seq * 256 + 255 (254: diverged) once the job has finished; seq * 256 + b when the b-th launch budget of the call
+  int seq;                        // ends with the job unfinished (the host then queues another budget)
+};
+__device__ __forceinline__ void sim3_job_view(const Sim3Set& set, const Sim3Track& J, const int parity, Sim3Job& a) {
+  const Sim3Lvl& L = set.lv[J.reqLevel];
+  a.kf_idepth = L.kf_idepth; a.kf_idepthVar = L.kf_idepthVar; a.kf_image = L.kf_image; a.kf_grad = L.kf_grad;
+  a.fr_grad = L.fr_grad; a.fr_idepth = L.fr_idepth; a.fr_idepthVar = L.fr_idepthVar;
+  a.w = L.w; a.h = L.h; a.nblocks = L.nblocks;
+  a.fx = L.fx; a.fy = L.fy; a.cx = L.cx; a.cy = L.cy; a.fxi = L.fxi; a.fyi = L.fyi; a.cxi = L.cxi; a.cyi = L.cyi;
+#pragma unroll
+  for (int i = 0; i < 9; i++) a.R[i] = J.reqR[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) a.t[i] = J.reqT[i];
+  a.xRoll0 = J.reqRoll[0]; a.xRoll1 = J.reqRoll[1]; a.yRoll0 = J.reqRoll[2]; a.yRoll1 = J.reqRoll[3];
+  a.aff_a = J.aff_a; a.aff_b = J.aff_b;
+  a.cameraPixelNoise2 = set.cameraPixelNoise2; a.var_weight = set.var_weight; a.huber_d = set.huber_d;
+  a.rows = set.rows[parity]; a.topkey = set.topkey[parity]; a.topval = set.topval[parity];
+  a.record = nullptr; a.seq = 0;
+}
+// 7x7 solve of the LM step with one element of the augmented 7x8 system per lane (lane = 8 i + j), pivot row / column read back through
+// LDS — gj6_solve_wave of the SE3 tracker (track_device.hpp) with one more row.  No pivoting: J^T W J (+ damping) is symmetric positive
+// definite; same solution as the reference's A.ldlt().solve(b) up to rounding (ldlt7_solve above stays as the CPU-checked form,
+// tests/test_host_math_cpu.py), which is what the trackFrameSim3 tests hold the poses to.
+__device__ __forceinline__ void gj7_solve_wave(Sim3Scratch& W, const int lane) {
+  const int i = lane >> 3, j = lane & 7;
+  const bool act = i < 7;
+  const int ii = act ? i : 0, jj = j < 7 ? j : 0;
+  float m = (j == 7) ? W.b[ii] : W.A[ii * 7 + jj];
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    if (act) W.m[i][j] = m;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float d = W.m[k][k], rk = W.m[k][j], ck = W.m[ii][k];
+    const float f = ck * lsd_rcp_exact(d);
+    const float upd = m - f * rk;
+    m = (i == k) ? m : upd;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (act) W.m[i][j] = m;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 7) W.inc[lane] = W.m[lane][7] * lsd_rcp_exact(W.m[lane][lane]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// One launch per evaluation, as k_track_step does for the SE3 tracker: every workgroup of a job first brings the job's state up to date
+// — the totals of the evaluation the previous launch left in the rows of this launch's parity, then the LM decision and the next
+// request, computed redundantly (same inputs, same instructions, same result in every workgroup; workgroup 0 writes it to the state of
+// the other parity) —, then evaluates its tile of the request into the rows of the other parity.  A finished job's launches leave at once.
+__global__ __launch_bounds__(S3_BLOCK) void k_sim3_fused(const Sim3Set* __restrict__ sets, Sim3Track* __restrict__ st, const Sim3LM P, const int parity,
+                                                          const int budgetEnd) {
+  __shared__ Sim3Track s_J;
+  __shared__ Eval s_ev;
+  __shared__ Sim3Scratch s_W;
+  __shared__ float s_tot[64];
+  const int tid = threadIdx.x, job = blockIdx.y;
+  const Sim3Set& set = sets[job];
+  const Sim3Track* src = st + parity * S3_MAXB + job;
+  Sim3Track* dst = st + (parity ^ 1) * S3_MAXB + job;
+  for (int i = tid; i < (int)(sizeof(Sim3Track) / 4); i += S3_BLOCK) ((unsigned*)&s_J)[i] = ((const unsigned*)src)[i];
+  __syncthreads();
+  const bool wasDone = s_J.phase == Sim3Track::DONE;
+  if (!wasDone && s_J.pendingEval) {
+    if ((int)blockIdx.x >= set.lv[s_J.finalLevel].nblocks) return;   // no tile on any level to come (the final level is the finest)
+    Sim3Job a;
+    sim3_job_view(set, s_J, parity, a);
+    sim3_totals(a, s_tot);
+    if (tid == 0) {
+      s_W.solve = 0;
+      sim3_eval_from_totals(s_tot, &s_ev);
+      sim3_advance(P, s_J, s_ev, s_W);
+    }
+    __syncthreads();
+    if (s_W.solve) {
+      if (tid < 64) gj7_solve_wave(s_W, tid);
+      __syncthreads();
+      if (tid == 0) sim3_propose_finish(P, s_J, s_W);
+    }
+    if (tid == 0 && s_J.phase != Sim3Track::DONE) sim3_request(s_J);
+    __syncthreads();
+  }
+  const bool done = s_J.phase == Sim3Track::DONE;
+  if (blockIdx.x == 0) {
+    if (tid == 0) s_J.pendingEval = done ? 0 : 1;
+    __syncthreads();
+    for (int i = tid; i < (int)(sizeof(Sim3Track) / 4); i += S3_BLOCK) ((unsigned*)dst)[i] = ((const unsigned*)&s_J)[i];
+    if (done && !wasDone)
+      for (int i = tid; i < (int)(sizeof(lsdhip_sim3_result) / 4); i += S3_BLOCK) ((unsigned*)set.result)[i] = ((const unsigned*)&s_J.res)[i];
+    __threadfence_system();                   // the result record (pinned) before the flag
+    __syncthreads();
+    if (tid == 0 && ((done && !wasDone) || (!done && budgetEnd >= 0))) {
+      *(volatile int*)set.done = set.seq * 256 + (done ? (s_J.rc == LSDHIP_OK ? 255 : 254) : budgetEnd);
+      __threadfence_system();
+    }
+  }
+  if (done) return;
+  Sim3Job a;
+  sim3_job_view(set, s_J, parity ^ 1, a);
+  if ((int)blockIdx.x >= a.nblocks) return;
+  sim3_eval_tile(a);
+}
+
+// the device-side job storage of a tracker (first trackFrameSim3 call)
+static int sim3_device_storage(lsdhip_sim3tracker* t) {
+  if (t->d_states) return LSDHIP_OK;
+  HIPCHK(hipMalloc((void**)&t->d_sets, sizeof(Sim3Set) * S3_MAXB));
+  HIPCHK(hipHostMalloc((void**)&t->h_sets, sizeof(Sim3Set) * S3_MAXB, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&t->h_states, sizeof(Sim3Track) * S3_MAXB, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&t->h_results, sizeof(lsdhip_sim3_result) * S3_MAXB, hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&t->d_results, t->h_results, 0));
+  HIPCHK(hipHostMalloc((void**)&t->h_done, sizeof(int) * S3_MAXB, hipHostMallocMapped));
+  memset(t->h_done, 0, sizeof(int) * S3_MAXB);
+  HIPCHK(hipHostGetDevicePointer((void**)&t->d_done, t->h_done, 0));
+  HIPCHK(hipMalloc((void**)&t->d_states, sizeof(Sim3Track) * S3_MAXB * 2));
+  return LSDHIP_OK;
+}
+static Sim3LM sim3_lm_params(const lsdhip_sim3tracker* t) {
+  Sim3LM P;
+  for (int l = 0; l < LSD_LEVELS; l++) P.maxIts[l] = t->maxItsPerLvl[l];
+  P.lambdaSuccessFac = t->lambdaSuccessFac; P.lambdaFailFac = t->lambdaFailFac; P.lambdaInitial = t->lambdaInitial;
+  P.stepSizeMin = t->stepSizeMin; P.convergenceEps = t->convergenceEps;
+  P.useAffine = t->ctx->params.useAffineLightningEstimation; P.w = t->ctx->w; P.h = t->ctx->h;
+  return P;
+}
+// n independent trackFrameSim3 jobs: their states and level descriptions go to the device, a budget of (evaluation, step) launch pairs is
+// queued — every pair advances all unfinished jobs by one evaluation (at most S3_MAXB jobs per launch) —, the host waits for the jobs'
+// `done` words (pinned) and tops the budget up if some job needs more
+static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs, const std::vector<std::pair<lsdhip_frame*, lsdhip_frame*>>& frames) {
+  lsdhip_ctx* c = t->ctx;
+  LSD_CTX_LOCK(c);
   const int n = (int)jobs.size();
+  const Sim3LM P = sim3_lm_params(t);
+  LsdTrackJobScope tjob_(c, true);   // pipelined contexts: behind the mapping stream's products, and a record point for it afterwards
+  if (tjob_.rc) return tjob_.rc;
+  { int rc = sim3_device_storage(t); if (rc) return rc; }
   for (int base = 0; base < n; base += S3_MAXB) {
     const int m = std::min(S3_MAXB, n - base);
-    while (true) {
-      Sim3Batch batch;
-      memset(&batch, 0, sizeof(batch));
-      int active = 0;
-      for (int k = 0; k < m; k++) {
-        Sim3Track& J = jobs[base + k];
-        if (J.phase == Sim3Track::DONE) continue;
-        int rc = sim3_build_job(t, k, J.kf, J.frame, J.reqPose, J.reqLevel, J.aff_a, J.aff_b, &batch.j[k]);
-        if (rc) return rc;
-        active++;
+    const int seq = t->seq = (t->seq % 0x3FFFFF) + 1;
+    int grid = 0, pending = 0;
+    for (int k = 0; k < m; k++) {
+      Sim3Track& J = jobs[base + k];
+      Sim3Set& S = t->h_sets[k];
+      for (int l = 0; l < LSD_LEVELS; l++) {
+        Sim3Lvl& L = S.lv[l];
+        lsdhip_frame* kf = frames[base + k].first;
+        lsdhip_frame* fr = frames[base + k].second;
+        L.kf_idepth = kf->d_idepth[l]; L.kf_idepthVar = kf->d_idepthVar[l]; L.kf_image = kf->d_image[l]; L.kf_grad = kf->d_grad[l];
+        L.fr_grad = fr->d_grad[l]; L.fr_idepth = fr->d_idepth[l]; L.fr_idepthVar = fr->d_idepthVar[l];
+        L.w = c->wl[l]; L.h = c->hl[l];
+        L.nblocks = (L.w * L.h + S3_BLOCK - 1) / S3_BLOCK;
+        const LevelIntr& in = c->intr[l];
+        L.fx = in.fx; L.fy = in.fy; L.cx = in.cx; L.cy = in.cy; L.fxi = in.fxi; L.fyi = in.fyi; L.cxi = in.cxi; L.cyi = in.cyi;
+        if (l == J.finalLevel && J.phase != Sim3Track::DONE && L.nblocks > grid) grid = L.nblocks;
       }
-      if (!active) break;
-      int rc = sim3_run_batch(t, batch, m);
-      if (rc) return rc;
-      for (int k = 0; k < m; k++) {
-        Sim3Track& J = jobs[base + k];
-        if (J.phase == Sim3Track::DONE) continue;
-        Eval ev;
-        sim3_read_eval(t, k, &ev);
-        sim3_advance(t, J, ev);
+      S.cameraPixelNoise2 = c->params.cameraPixelNoise2; S.var_weight = t->var_weight; S.huber_d = t->huber_d;
+      for (int par = 0; par < 2; par++) {
+        const size_t slot = (size_t)par * S3_MAXB + k;
+        S.rows[par] = t->d_rows + slot * t->max_blocks * 64;
+        S.topkey[par] = t->d_topkey + slot * t->max_blocks;
+        S.topval[par] = t->d_topval + slot * t->max_blocks * 3 * 48;
       }
+      S.result = t->d_results + k;     // pinned, written by the device when the job ends
+      S.done = t->d_done + k;
+      S.seq = seq;
+      if (J.phase != Sim3Track::DONE) { sim3_request(J); pending++; }
+      J.pendingEval = 0;
+      t->h_states[k] = J;
     }
+    if (!pending) continue;
+    HIPCHK(hipMemcpyAsync(t->d_sets, t->h_sets, sizeof(Sim3Set) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(t->d_states, t->h_states, sizeof(Sim3Track) * (size_t)m, hipMemcpyHostToDevice, c->stream));   // parity 0
+    int budget = t->recentRounds > 0 ? t->recentRounds + 3 : 24, parity = 0;   // evaluations + 1 launches end a job
+    for (int b = 0;; b++) {
+      if (b >= 250) { lsd_set_error("Sim3 tracking did not terminate"); return LSDHIP_E_STATE; }
+      for (int i = 0; i < budget; i++, parity ^= 1)
+        hipLaunchKernelGGL(k_sim3_fused, dim3(grid, m), dim3(S3_BLOCK), 0, c->stream, (const Sim3Set*)t->d_sets, t->d_states, P, parity, i == budget - 1 ? b : -1);
+      HIPCHK(hipGetLastError());
+      // every pending job raises its word when it finishes or when the budget's last step leaves it unfinished; no stream query in
+      // the wait (each one puts a marker packet into the queue the chain runs through) but as a safety net
+      const auto tStart = std::chrono::steady_clock::now();
+      bool unfinished = false;
+      for (int k = 0; k < m; k++) {
+        if (jobs[base + k].phase == Sim3Track::DONE) continue;
+        volatile const int* flag = (volatile const int*)t->h_done + k;
+        unsigned spins = 0;
+        int v;
+        auto settled = [&](int x) { return x == seq * 256 + 255 || x == seq * 256 + 254 || x == seq * 256 + b; };
+        while (!settled(v = *flag)) {
+          if ((++spins & 0xFFFFFu) == 0) {
+            hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) { lsd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return LSDHIP_E_HIP; }
+            if (std::chrono::steady_clock::now() - tStart > std::chrono::seconds(10)) {
+              HIPCHK(hipStreamSynchronize(c->stream));
+              if (!settled(v = *flag)) { lsd_set_error("Sim3 tracking did not complete"); return LSDHIP_E_STATE; }
+              break;
+            }
+          }
+          __builtin_ia32_pause();
+        }
+        if (v == seq * 256 + b) unfinished = true;
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (!unfinished) break;
+      budget = 8;
+    }
+    // results: the pinned records the device wrote before it raised the words (launches of the budget still queued behind a job's end
+    // leave at once; the stream orders them before whatever comes next)
+    int rounds = 0;
+    for (int k = 0; k < m; k++) {
+      Sim3Track& J = jobs[base + k];
+      if (J.phase == Sim3Track::DONE) continue;             // finished before any evaluation (no level with iterations)
+      *J.hostOut = t->h_results[k];
+      J.rc = ((volatile int*)t->h_done)[k] == seq * 256 + 255 ? LSDHIP_OK : LSDHIP_DIVERGED;
+      J.phase = Sim3Track::DONE;
+      if (J.hostOut->numEvaluations > rounds) rounds = J.hostOut->numEvaluations;
+    }
+    t->recentRounds = rounds;
   }
   return LSDHIP_OK;
 }
@@ -813,17 +1082,20 @@ static int sim3_init_job(lsdhip_sim3tracker* t, Sim3Track& J, lsdhip_frame* kf, 
   if (!kf->hasIDepth || !frame->hasIDepth) { lsd_set_error("Sim3 tracking needs inverse depth on both frames"); return LSDHIP_E_STATE; }
   memset(out, 0, sizeof(*out));
   out->frameToReference[0] = 1; out->frameToReference[7] = 1;   // Sim3() on failure
-  J.kf = kf; J.frame = frame; J.out = out;
+  memset(&J, 0, sizeof(J));
+  J.res = *out; J.hostOut = out;
+  J.phase = Sim3Track::DONE;
   J.aff_a = 1; J.aff_b = 0;
   J.referenceToFrame = sim3_inverse(sim3_in(init));
   memset(&J.cur, 0, sizeof(J.cur));
   memset(&J.finalResidual, 0, sizeof(J.finalResidual));
   memset(&J.lastErr, 0, sizeof(J.lastErr));
-  J.warp_update_up_to_date = false;
+  J.warp_update_up_to_date = 0;
   J.numEvaluations = 0;
   J.lvl = startLevel; J.finalLevel = finalLevel;
   J.rc = LSDHIP_OK;
-  sim3_next_level(t, J);
+  sim3_next_level(sim3_lm_params(t), J);
+  if (J.phase == Sim3Track::DONE) *out = J.res;   // no level with iterations
   return LSDHIP_OK;
 }
 
@@ -834,7 +1106,7 @@ extern "C" int lsdhip_sim3tracker_track(lsdhip_sim3tracker* t, lsdhip_frame* kf,
   std::vector<Sim3Track> jobs(1);
   int rc = sim3_init_job(t, jobs[0], kf, frame, init, startLevel, finalLevel, out);
   if (rc) return rc;
-  rc = sim3_track_jobs(t, jobs);
+  rc = sim3_track_jobs(t, jobs, {{kf, frame}});
   if (rc) return rc;
   return jobs[0].rc;
 }
@@ -845,11 +1117,13 @@ extern "C" int lsdhip_sim3tracker_track_batch(lsdhip_sim3tracker* t, int n, lsdh
     return LSDHIP_E_ARG;
   HIPCHK(hipSetDevice(t->ctx->device));
   std::vector<Sim3Track> jobs((size_t)n);
+  std::vector<std::pair<lsdhip_frame*, lsdhip_frame*>> pairs((size_t)n);
   for (int j = 0; j < n; j++) {
     int rc = sim3_init_job(t, jobs[j], keyframes[j], frames[j], inits + 8 * (size_t)j, startLevel, finalLevel, &results[j]);
     if (rc) return rc;
+    pairs[j] = {keyframes[j], frames[j]};
   }
-  int rc = sim3_track_jobs(t, jobs);
+  int rc = sim3_track_jobs(t, jobs, pairs);
   if (rc) return rc;
   int rcAll = LSDHIP_OK;
   for (int j = 0; j < n; j++) if (jobs[j].rc == LSDHIP_DIVERGED) rcAll = LSDHIP_DIVERGED;

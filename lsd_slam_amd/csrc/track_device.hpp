@@ -223,7 +223,7 @@ __device__ __forceinline__ bool fetch_point(const EvalCtx& a, int i, float& px, 
   var = a.kf_idepthVar[i];
   float id = a.kf_idepth[i];
   if (var <= 0 || id == 0) return false;
-  float inv = 1.0f / id;
+  float inv = lsd_rcp_exact(id);
   px = inv * (a.fxi * x + a.cxi);
   py = inv * (a.fyi * y + a.cyi);
   pz = inv * 1.0f;

@@ -649,7 +649,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         B.live = A.live;
         B.xy = A.xy;
         const int bx_ = (int)(A.xy & 0xffffu), by_ = (int)(A.xy >> 16);
-        const float inv = 1.0f / A.id;
+        const float inv = lsd_rcp_exact(A.id);
         const float px = inv * (a.fxi * bx_ + a.cxi), py = inv * (a.fyi * by_ + a.cyi);
         B.pz = inv * 1.0f;
         B.I_ref = A.img; B.var = A.var;

@@ -1,6 +1,8 @@
-// Is v_rcp_f32 (1 ulp) + Newton-Raphson corrections with fused multiply-adds the correctly rounded 1/x for every positive normal float?
-// Exhaustive on the device itself: all 2^31 positive bit patterns against the IEEE division sequence hipcc emits for 1.0f / x.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/rcp_exhaustive.hip -o /tmp/rcp_exhaustive && /tmp/rcp_exhaustive
+// Is v_rcp_f32 (1 ulp) + one Newton-Raphson correction with fused multiply-adds the correctly rounded 1/x?
+// Exhaustive on the device itself: all 2^32 bit patterns against the IEEE division sequence hipcc emits for 1.0f / x, by class of input.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/rcp_exhaustive.hip -o tools/rcp_exhaustive.bin && tools/rcp_exhaustive.bin
+// Variants: nr1 = the bare correction (claim: inputs whose reciprocal is a normal number); exact = lsd_rcp_exact of
+// lsd_slam_amd/csrc/lsdhip_internal.hpp (claim: every input, NaNs compared as a class).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __device__ __forceinline__ float rcp_nr1(float x) {
@@ -8,32 +10,47 @@ __device__ __forceinline__ float rcp_nr1(float x) {
   const float e = __builtin_fmaf(-x, r0, 1.0f);
   return __builtin_fmaf(r0, e, r0);
 }
-__device__ __forceinline__ float rcp_nr2(float x) {
-  const float r1 = rcp_nr1(x);
-  const float e = __builtin_fmaf(-x, r1, 1.0f);
-  return __builtin_fmaf(r1, e, r1);
+__device__ __forceinline__ float rcp_exact(float x) {
+  const float r0 = __builtin_amdgcn_rcpf(x);
+  if (__builtin_expect(!__builtin_amdgcn_classf(r0, 0x108), 0)) return 1.0f / x;   // estimate not +-normal: the division itself
+  const float e = __builtin_fmaf(-x, r0, 1.0f);
+  return __builtin_fmaf(r0, e, r0);
 }
-__global__ void k_check(unsigned long long* out, unsigned lo, unsigned hi) {
-  unsigned long long bad1 = 0, bad2 = 0, n = 0;
-  for (unsigned long long b = lo + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; b < hi; b += (unsigned long long)gridDim.x * blockDim.x) {
+// classes: 0 zero, 1 denormal, 2 normal with normal reciprocal, 3 normal with denormal reciprocal, 4 normal with infinite reciprocal, 5 inf, 6 nan
+__global__ void k_check(unsigned long long* out) {
+  unsigned long long n[7] = {0}, bad1[7] = {0}, badx[7] = {0}, bad0[7] = {0};
+  for (unsigned long long b = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; b < (1ull << 32); b += (unsigned long long)gridDim.x * blockDim.x) {
     const float x = __uint_as_float((unsigned)b);
     const float ref = 1.0f / x;
-    // results that are denormal / zero / inf are outside the claim
-    const unsigned rb = __float_as_uint(ref) & 0x7f800000u;
-    if (rb == 0u || rb == 0x7f800000u) continue;
-    n++;
-    if (__float_as_uint(rcp_nr1(x)) != __float_as_uint(ref)) bad1++;
-    if (__float_as_uint(rcp_nr2(x)) != __float_as_uint(ref)) bad2++;
+    const unsigned xe = ((unsigned)b >> 23) & 0xff, xm = (unsigned)b & 0x7fffff;
+    const unsigned re = (__float_as_uint(ref) >> 23) & 0xff;
+    int cls;
+    if (xe == 0) cls = xm ? 1 : 0;
+    else if (xe == 255) cls = xm ? 6 : 5;
+    else cls = re == 0 ? 3 : (re == 255 ? 4 : 2);
+    const float a = rcp_nr1(x), c = rcp_exact(x), r0 = __builtin_amdgcn_rcpf(x);
+    const bool refnan = ref != ref;
+    auto differs = [&](float v) { return refnan ? !(v != v) : __float_as_uint(v) != __float_as_uint(ref); };
+    n[cls]++;
+    if (differs(a)) bad1[cls]++;
+    if (differs(c)) badx[cls]++;
+    if (differs(r0)) bad0[cls]++;
   }
-  atomicAdd(&out[0], n); atomicAdd(&out[1], bad1); atomicAdd(&out[2], bad2);
+  for (int k = 0; k < 7; k++) { atomicAdd(&out[k], n[k]); atomicAdd(&out[7 + k], bad1[k]); atomicAdd(&out[14 + k], badx[k]); atomicAdd(&out[21 + k], bad0[k]); }
 }
 int main() {
   unsigned long long* d;
-  hipMalloc(&d, 24); hipMemset(d, 0, 24);
-  // positive normal inputs: exponent field 1 .. 254
-  hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, 0, d, 0x00800000u, 0x7f800000u);
-  unsigned long long h[3];
-  hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
-  printf("{\"inputs_checked\": %llu, \"mismatch_rcp_plus_one_correction\": %llu, \"mismatch_rcp_plus_two_corrections\": %llu}\n", h[0], h[1], h[2]);
+  hipMalloc(&d, 28 * 8); hipMemset(d, 0, 28 * 8);
+  hipLaunchKernelGGL(k_check, dim3(8192), dim3(256), 0, 0, d);
+  unsigned long long h[28];
+  hipMemcpy(h, d, 28 * 8, hipMemcpyDeviceToHost);
+  const char* names[7] = {"zero", "denormal", "normal_recip_normal", "normal_recip_denormal", "normal_recip_inf", "inf", "nan"};
+  printf("{");
+  unsigned long long tot = 0, totx = 0;
+  for (int k = 0; k < 7; k++) {
+    printf("\"%s\": {\"inputs\": %llu, \"mismatch_rcp_hw\": %llu, \"mismatch_rcp_plus_one_correction\": %llu, \"mismatch_lsd_rcp_exact\": %llu}, ", names[k], h[k], h[21 + k], h[7 + k], h[14 + k]);
+    tot += h[k]; totx += h[14 + k];
+  }
+  printf("\"inputs_checked\": %llu, \"mismatch_lsd_rcp_exact\": %llu}\n", tot, totx);
   return 0;
 }
