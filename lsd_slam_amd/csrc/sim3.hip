@@ -18,6 +18,7 @@
 // Quirks kept: the SSE loops ignore the last size % 4 in-image points (x-outer / y-inner order) for the residual sums and
 // both systems; LGS6::updateSSE counts 6 and LGS4::updateSSE 4 constraints per group of four points.
 #include "lsdhip_internal.hpp"
+#include "track_device.hpp"   // wave / workgroup reductions (block_top3, top3_insert), global address-space pointer types
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -38,45 +39,51 @@ static_assert(S3_END == 54 && S3_NTAIL == 46, "layout");
 struct Sim3Job {
   const float* kf_idepth; const float* kf_idepthVar; const float* kf_image; const float4* kf_grad;
   const float4* fr_grad; const float* fr_idepth; const float* fr_idepthVar;
-  int w, h, nblocks;
+  int w, h, nblocks, ppl;                   // nblocks strips of ppl * 256 pixels (ppl: pixels per lane)
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
   float R[9], t[3];                         // rxso3().matrix() (scale * rotation) and translation, cast to float
   float xRoll0, xRoll1, yRoll0, yRoll1;     // in-plane rotation of the reference gradients (ESM, Sim3Tracker.cpp:455-464)
   float aff_a, aff_b, cameraPixelNoise2, var_weight, huber_d;
   float* rows;                              // [nblocks][64] partial sums
   int4* topkey;                             // [nblocks] three largest order keys of in-image points
-  float* topval;                            // [nblocks][3][48] their tail contributions
   float* record;                            // pinned host: S3_END totals (tail-corrected); word 63 = seq, raised last
   int seq;
 };
 
 // Up to S3_MAXB independent evaluations per launch (blockIdx.y = slot); the job descriptions travel in the kernel arguments.
 #define S3_MAXB 12
+// Strips per level: at most S3_NBMAX workgroups, each lane ceil(pixels / (256 S3_NBMAX)) pixels — few rows for the totals that every
+// workgroup of the next launch adds up, enough workgroups to spread a level's memory latency
+#define S3_NBMAX 128
 struct Sim3Batch { Sim3Job j[S3_MAXB]; };
 static_assert(sizeof(Sim3Batch) <= 4096, "kernel-argument limit");
 
-__device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
-  __shared__ float s_red[S3_END * (S3_BLOCK + 1) + 8];
-  __shared__ float s_sum[4][64];
-  __shared__ int s_max;
-  __shared__ int s_top[3];
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * S3_BLOCK + tid;
-  float acc[S3_END];
-#pragma unroll
-  for (int k = 0; k < S3_END; k++) acc[k] = 0.f;
+// One reference pixel: its contributions to the S3_END sums, added to (ADD) or stored in `acc`; returns the pixel's order key
+// x * h + y when its point lands inside the image, -1 otherwise
+template <bool ADD>
+__device__ __forceinline__ int sim3_eval_pixel(const Sim3Job& a, const int i, float (&acc)[S3_END]) {
+  auto put = [&](const int k, const float v) { acc[k] = ADD ? acc[k] + v : v; };
+  // (a job description read from memory hands over generic pointers, and loads through those are FLAT instructions that count against
+  // the LDS counter too — track_device.hpp)
+  typedef gv4f gfloat4;
+  gfloat* kf_idepthVar = (gfloat*)a.kf_idepthVar; gfloat* kf_idepth = (gfloat*)a.kf_idepth; gfloat* kf_image = (gfloat*)a.kf_image;
+  gfloat4* kf_grad = (gfloat4*)a.kf_grad; gfloat4* fr_grad = (gfloat4*)a.fr_grad;
+  gfloat* fr_idepthVar = (gfloat*)a.fr_idepthVar; gfloat* fr_idepth = (gfloat*)a.fr_idepth;
   int key = -1;
   const int x = i % a.w, y = i / a.w;
   if (i < a.w * a.h && x >= 1 && x < a.w - 1 && y >= 1 && y < a.h - 1) {
-    const float var = a.kf_idepthVar[i];
-    const float id = a.kf_idepth[i];
+    // (the pixel's four keyframe planes in one memory round trip, whether it holds a hypothesis or not; then the four texels and the
+    // target pixel's depth pair in a second one: the evaluation is bound by these dependent round trips, not by their bytes)
+    const float var = kf_idepthVar[i];
+    const float id = kf_idepth[i];
+    float I_ref = kf_image[i];
+    v4f gref = kf_grad[i];
+    asm volatile("" : "+v"(I_ref), "+v"(gref.x), "+v"(gref.y));   // (keeps the two loads here instead of behind the branch on var / id)
     if (!(var <= 0 || id == 0)) {
       // TrackingReference::makePointCloud (TrackingReference.cpp:128-138)
       const float inv = lsd_rcp_exact(id);
       const float px = inv * (a.fxi * x + a.cxi), py = inv * (a.fyi * y + a.cyi), pz = inv * 1.0f;
-      const float I_ref = a.kf_image[i];
-      const float4 gref = a.kf_grad[i];
-      acc[S3_NREF] = 1.f;
+      put(S3_NREF, 1.f);
       const float Wx = ((a.R[0] * px + a.R[1] * py) + a.R[2] * pz) + a.t[0];
       const float Wy = ((a.R[3] * px + a.R[4] * py) + a.R[5] * pz) + a.t[1];
       const float Wz = ((a.R[6] * px + a.R[7] * py) + a.R[8] * pz) + a.t[2];
@@ -87,8 +94,12 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
         // getInterpolatedElement43
         const int ix = (int)u_new, iy = (int)v_new;
         const float dx = u_new - ix, dy = v_new - iy, dxdy = dx * dy;
-        const float4* bp = a.fr_grad + ix + iy * a.w;
-        const float4 t00 = bp[0], t10 = bp[1], t01 = bp[a.w], t11 = bp[1 + a.w];
+        gfloat4* bp = fr_grad + ix + iy * a.w;
+        const v4f t00 = bp[0], t10 = bp[1], t01 = bp[a.w], t11 = bp[1 + a.w];
+        const int idx_rounded = (int)(u_new + 0.5f) + a.w * (int)(v_new + 0.5f);
+        const float var_frameDepth = fr_idepthVar[idx_rounded];
+        float id_frameDepth = fr_idepth[idx_rounded];
+        asm volatile("" : "+v"(id_frameDepth));                    // (... and this one beside the texels instead of behind var > 0)
         const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
         const float rx = w11 * t11.x + w01 * t01.x + w10 * t10.x + w00 * t00.x;
         const float ry = w11 * t11.y + w01 * t01.y + w10 * t10.y + w00 * t00.y;
@@ -102,16 +113,14 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
         const float c2 = rz;
         const float rp = c1 - c2;
         const float hwgt = fabsf(rp) < 2.0f ? 1 : 2.0f / fabsf(rp);
-        acc[S3_M] = 1.f;
-        acc[S3_SXX] = c1 * c1 * hwgt; acc[S3_SYY] = c2 * c2 * hwgt; acc[S3_SX] = c1 * hwgt; acc[S3_SY] = c2 * hwgt; acc[S3_SW] = hwgt;
-        const int idx_rounded = (int)(u_new + 0.5f) + a.w * (int)(v_new + 0.5f);
-        const float var_frameDepth = a.fr_idepthVar[idx_rounded];
+        put(S3_M, 1.f);
+        put(S3_SXX, c1 * c1 * hwgt); put(S3_SYY, c2 * c2 * hwgt); put(S3_SX, c1 * hwgt); put(S3_SY, c2 * hwgt); put(S3_SW, hwgt);
         const float ref_idepth = lsd_rcp_exact(Wz);
         const float d = lsd_rcp_exact(pz);
         float rd = -1, sv = -1;
-        if (var_frameDepth > 0) { rd = ref_idepth - a.fr_idepth[idx_rounded]; sv = var_frameDepth; }
+        if (var_frameDepth > 0) { rd = ref_idepth - id_frameDepth; sv = var_frameDepth; }
         const float depthChange = pz / Wz;
-        acc[S3_USAGE] = depthChange < 1 ? depthChange : 1;
+        put(S3_USAGE, depthChange < 1 ? depthChange : 1);
 
         // calcSim3WeightsAndResidualSSE, operation order of the SSE path
         const float pz2d = lsd_rcp_exact((Wz * Wz) * d);
@@ -129,9 +138,9 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
         const bool depthValid = 0.0f < sv;
         const float wabs = (depthValid ? wrd : 0.0f) + wrp;
         const float wh = (wabs < a.huber_d) ? 1.0f : a.huber_d * lsd_rcp_exact(wabs);
-        acc[S3_NUMD] = depthValid ? 1.f : 0.f;
-        acc[S3_SUMRESD] = depthValid ? wh * (wrd * wrd) : 0.f;
-        acc[S3_SUMRESP] = wh * (wrp * wrp);
+        put(S3_NUMD, depthValid ? 1.f : 0.f);
+        put(S3_SUMRESD, depthValid ? wh * (wrd * wrd) : 0.f);
+        put(S3_SUMRESP, wh * (wrp * wrp));
         const float wp = wh * w_p;
         const float wd = depthValid ? wh * w_d : 0.f;
 
@@ -154,30 +163,48 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
         for (int r = 0; r < 6; r++) {
           const float Jw = J6[r] * wp;
 #pragma unroll
-          for (int c = r; c < 6; c++) acc[S3_A6 + (r * 6 - (r * (r - 1)) / 2 + (c - r))] = Jw * J6[c];
+          for (int c = r; c < 6; c++) put(S3_A6 + (r * 6 - (r * (r - 1)) / 2 + (c - r)), Jw * J6[c]);
         }
         const float resw6 = rp * wp;
 #pragma unroll
-        for (int r = 0; r < 6; r++) acc[S3_A6 + 21 + r] = resw6 * J6[r];
-        acc[S3_A6 + 27] = resw6 * rp;
+        for (int r = 0; r < 6; r++) put(S3_A6 + 21 + r, resw6 * J6[r]);
+        put(S3_A6 + 27, resw6 * rp);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const float Jw = J4[r] * wd;
 #pragma unroll
-          for (int c = r; c < 4; c++) acc[S3_A4 + (r * 4 - (r * (r - 1)) / 2 + (c - r))] = Jw * J4[c];
+          for (int c = r; c < 4; c++) put(S3_A4 + (r * 4 - (r * (r - 1)) / 2 + (c - r)), Jw * J4[c]);
         }
         const float resw4 = rd * wd;
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[S3_A4 + 10 + r] = resw4 * J4[r];
-        acc[S3_A4 + 14] = resw4 * rd;
+        for (int r = 0; r < 4; r++) put(S3_A4 + 10 + r, resw4 * J4[r]);
+        put(S3_A4 + 14, resw4 * rd);
       }
     }
   }
+  return key;
+}
+// The strip of workgroup blockIdx.x: a.ppl pixels per lane (consecutive 256-pixel runs, coalesced), their sums reduced lane -> LDS ->
+// one row; the strip's three largest order keys beside it (sim3_totals drops the last M % 4 points in column order, as the SSE loops do)
+__device__ __forceinline__ void sim3_eval_strip(const Sim3Job& a) {
+  __shared__ float s_red[S3_END * (S3_BLOCK + 1) + 8];
+  __shared__ float s_sum[4][64];
+  __shared__ int s_wtop[S3_BLOCK / 64][3];
+  __shared__ int s_top[3];
+  const int tid = threadIdx.x;
+  const int npix = a.w * a.h;
+  float acc[S3_END];
+#pragma unroll
+  for (int k = 0; k < S3_END; k++) acc[k] = 0.f;
+  int k0 = -1, k1 = -1, k2 = -1;       // this lane's in-image keys, descending
+  for (int p = 0; p < a.ppl; p++) {
+    const int i = (blockIdx.x * a.ppl + p) * S3_BLOCK + tid;
+    if (i < npix) top3_insert(sim3_eval_pixel<true>(a, i, acc), k0, k1, k2);
+  }
   // workgroup reduction through LDS (same scheme as k_track_step)
-  constexpr int RSLICE = 4, RRUN = 64;
+  constexpr int RRUN = 64;
 #pragma unroll
   for (int k = 0; k < S3_END; k++) s_red[k * (S3_BLOCK + 1) + tid] = acc[k];
-  if (tid == 0) s_max = -1;
   __syncthreads();
   {
     const int slice = tid >> 6, k = tid & 63;
@@ -192,102 +219,81 @@ __device__ __forceinline__ void sim3_eval_tile(const Sim3Job& a) {
       s_sum[slice][k] = s;
     }
   }
-  // top-3 order keys of the tile (one candidate per lane): three rounds of an LDS max
-  int rank = -1;
-  for (int r = 0; r < 3; r++) {
-    if (rank < 0 && key >= 0) atomicMax(&s_max, key);
-    __syncthreads();
-    const int m = s_max;
-    if (rank < 0 && key >= 0 && key == m) rank = r;
-    if (tid == 0) s_top[r] = m;
-    __syncthreads();
-    if (tid == 0) s_max = -1;
-    __syncthreads();
-  }
+  block_top3(k0, k1, k2, s_wtop, s_top);      // (its barriers also publish s_sum)
   if (tid < 64) {
     float s = 0.f;
     if (tid < S3_END) s = ((s_sum[0][tid] + s_sum[1][tid]) + s_sum[2][tid]) + s_sum[3][tid];
-    a.rows[(size_t)blockIdx.x * 64 + tid] = s;
+    ((__attribute__((address_space(1))) float*)a.rows)[(size_t)blockIdx.x * 64 + tid] = s;
   }
   if (tid == 0) a.topkey[blockIdx.x] = make_int4(s_top[0], s_top[1], s_top[2], -1);
-  if (rank >= 0) {
-    float* dst = a.topval + ((size_t)blockIdx.x * 3 + rank) * 48;
-#pragma unroll
-    for (int k = 0; k < S3_NTAIL; k++) dst[k] = acc[S3_TAIL0 + k];
-  }
 }
 __global__ __launch_bounds__(S3_BLOCK) void k_sim3_eval(Sim3Batch batch) {
   const Sim3Job& a = batch.j[blockIdx.y];
   if ((int)blockIdx.x >= a.nblocks) return;
-  sim3_eval_tile(a);
+  sim3_eval_strip(a);
 }
 
-// fixed-order sum of the tile rows, global top-3 keys, SSE tail drop: the evaluation's totals (tail-corrected) in s_tot[0 .. S3_END)
+// fixed-order sum of the strips' rows, the evaluation's three largest order keys, SSE tail drop: the evaluation's totals (tail-corrected)
+// in s_tot[0 .. S3_END).  `a` is the evaluation's own description: the points of the three largest keys are evaluated once more, one
+// lane each, for what they added to the sums; the last M % 4 of them in column order are what the SSE loops never visit.
+// Everything a workgroup of the next launch waits for before its own strip, so ordered by memory round trips: the strips' keys and
+// all rows are requested at once, the keys are merged while the rows arrive, and three lanes re-evaluate while the others add up.
+static_assert(S3_NBMAX <= 256 && S3_NBMAX % 16 == 0, "one strip's keys per thread; 16 slices of at most S3_NBMAX / 16 rows");
 __device__ __forceinline__ void sim3_totals(const Sim3Job& a, float* s_tot) {
-  __shared__ float s_part[4][64];
-  __shared__ int s_keys[3], s_src[3];
-  __shared__ int s_max;
-  const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
+  __shared__ float s_part[16][64];
+  __shared__ float s_tail[3][S3_NTAIL + 2];
+  __shared__ int s_keys[3];
+  __shared__ int s_wtop[4][3];
+  typedef int iv4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) iv4 giv4;
+  const int tid = threadIdx.x;
+  const iv4 none = {-1, -1, -1, -1};
+  const iv4 kv = tid < a.nblocks ? ((giv4*)a.topkey)[tid] : none;      // (a strip's three keys are stored in descending order)
+  // thread (slice, quad): rows [slice R, slice R + R) of columns 4 quad .. 4 quad + 3, one 16-byte load per row
+  constexpr int RMAX = S3_NBMAX / 16;
+  const int quad = tid & 15, sl = tid >> 4;
+  const int R = (a.nblocks + 15) / 16;
+  const int r0 = sl * R, r1 = min((sl + 1) * R, a.nblocks);
+  v4f v[RMAX];
   {
-    // slice s sums rows [s R, s R + R) of column `col`: four interleaved accumulators (rows = 0..3 mod 4) so that the loads
-    // overlap, combined in a fixed order
-    const int R = (a.nblocks + 3) / 4;
-    const int r0 = slice * R, r1 = min((slice + 1) * R, a.nblocks);
-    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-    int r = r0;
-    for (; r + 4 <= r1; r += 4) {
-      const float v0 = a.rows[(size_t)r * 64 + col], v1 = a.rows[(size_t)(r + 1) * 64 + col];
-      const float v2 = a.rows[(size_t)(r + 2) * 64 + col], v3 = a.rows[(size_t)(r + 3) * 64 + col];
-      acc4[0] += v0; acc4[1] += v1; acc4[2] += v2; acc4[3] += v3;
-    }
-    float tailsum = 0.f;
-    for (; r < r1; r++) tailsum += a.rows[(size_t)r * 64 + col];
-    s_part[slice][col] = ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + tailsum;
-  }
-  // global top-3 of the tiles' top-3 lists: per-thread top-3 over tiles tid, tid + 256, ..., then three rounds of an LDS max
-  int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
-  for (int r = tid; r < a.nblocks; r += 256) {
-    const int4 kv = a.topkey[r];
-    const int ks[3] = {kv.x, kv.y, kv.z};
+    gv4f* rows4 = (gv4f*)a.rows + quad;
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int k = ks[q], e = r * 3 + q;
-      const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
-      k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? e : e2);
-      k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? e : e1);
-      k0 = g0 ? k : k0; e0 = g0 ? e : e0;
+    for (int j = 0; j < RMAX; j++) v[j] = r0 + j < r1 ? rows4[(size_t)(r0 + j) * 16] : zero4;
+  }
+  block_top3(kv.x, kv.y, kv.z, s_wtop, s_keys);     // the three largest of the strips' keys
+  if (tid < 3 && s_keys[tid] >= 0) {
+    const int key = s_keys[tid];
+    float c[S3_END];
+#pragma unroll
+    for (int k = 0; k < S3_END; k++) c[k] = 0.f;
+    sim3_eval_pixel<false>(a, (key / a.h) + (key % a.h) * a.w, c);
+#pragma unroll
+    for (int k = 0; k < S3_NTAIL; k++) s_tail[tid][k] = c[S3_TAIL0 + k];
+  }
+  {
+    // two interleaved accumulators over the slice's rows, in row order (rows past the slice's end are zero: x + 0 == x)
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f), o = e;
+#pragma unroll
+    for (int j = 0; j < RMAX; j += 2) {
+      e.x += v[j].x; e.y += v[j].y; e.z += v[j].z; e.w += v[j].w;
+      if (j + 1 < RMAX) { o.x += v[j + 1].x; o.y += v[j + 1].y; o.z += v[j + 1].z; o.w += v[j + 1].w; }
     }
-  }
-  if (tid == 0) s_max = -1;
-  __syncthreads();
-  for (int rr = 0; rr < 3; rr++) {
-    if (k0 >= 0) atomicMax(&s_max, k0);
-    __syncthreads();
-    const int m = s_max;
-    if (tid == 0) s_keys[rr] = m;
-    if (m >= 0 && k0 == m) { s_src[rr] = e0; k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }   // keys are unique: one owner
-    __syncthreads();
-    if (tid == 0) s_max = -1;
-    __syncthreads();
+    float* dst = &s_part[sl][quad * 4];
+    dst[0] = e.x + o.x; dst[1] = e.y + o.y; dst[2] = e.z + o.z; dst[3] = e.w + o.w;
   }
   __syncthreads();
   if (tid < 64) {
-    float s = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
-    s_tot[tid] = s;
-  }
-  __syncthreads();
-  float corrected = 0.f;
-  if (tid < 64) {
-    float s = s_tot[tid];
-    const int M = (int)s_tot[S3_M];
-    int need = M & 3;
+    // (each of the 64 threads adds up the point count itself — same terms, same order, same value — instead of waiting for thread S3_M's)
+    float s = s_part[0][tid], cnt = s_part[0][S3_M];
+#pragma unroll
+    for (int sl2 = 1; sl2 < 16; sl2++) { s += s_part[sl2][tid]; cnt += s_part[sl2][S3_M]; }
+    const int need = ((int)cnt) & 3;
     if (tid >= S3_TAIL0 && tid < S3_END)
       for (int k = 0; k < need; k++)
-        if (s_keys[k] >= 0) s -= a.topval[(size_t)s_src[k] * 48 + (tid - S3_TAIL0)];
-    corrected = tid < S3_END ? s : 0.f;
+        if (s_keys[k] >= 0) s -= s_tail[k][tid - S3_TAIL0];
+    s_tot[tid] = tid < S3_END ? s : 0.f;
   }
-  __syncthreads();
-  if (tid < 64) s_tot[tid] = corrected;
   __syncthreads();
 }
 // ... to the pinned record of a host-driven evaluation (lsdhip_sim3tracker_evaluate)
@@ -437,8 +443,24 @@ struct Eval {
   float A[49], b[7];
   size_t num_constraints;
 };
-// the evaluation's outcome in the reference's terms, from its (tail-corrected) totals
-S3_HD void sim3_eval_from_totals(const float* r, Eval* ev) {
+// LGS6 / LGS4 finishNoDivide + LGS7::initializeFrom (LGSX.h:424-442) entry by entry, from an evaluation's (tail-corrected) totals: the 6x6
+// photometric system on rows / columns 0..5, the 4x4 depth system added on rows / columns 2, 3, 4, 6
+S3_HD float sim3_system_A(const float* r, const int i, const int j) {
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  float v = 0.f;
+  if (hi < 6) v = 0.0f + r[S3_A6 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+  const int l4 = lo == 6 ? 3 : lo - 2, h4 = hi == 6 ? 3 : hi - 2;     // 2, 3, 4, 6 -> 0, 1, 2, 3
+  if (lo >= 2 && lo != 5 && hi != 5) v += 0.0f + r[S3_A4 + l4 * 4 - (l4 * (l4 - 1)) / 2 + (h4 - l4)];
+  return v;
+}
+S3_HD float sim3_system_b(const float* r, const int i) {
+  float v = 0.f;
+  if (i < 6) v = 0.0f - r[S3_A6 + 21 + i];
+  if (i >= 2 && i != 5) v += 0.0f - r[S3_A4 + 10 + (i == 6 ? 3 : i - 2)];
+  return v;
+}
+// the evaluation's outcome in the reference's terms but for the system (`part` of `parts` callers share its 56 entries)
+S3_HD void sim3_eval_scalars(const float* r, Eval* ev) {
   ev->M = (int)r[S3_M];
   ev->pointUsage = r[S3_USAGE] / r[S3_NREF];
   {
@@ -454,24 +476,14 @@ S3_HD void sim3_eval_from_totals(const float* r, Eval* ev) {
   s.mean = (s.sumResD + s.sumResP) / (s.numTermsD + s.numTermsP);
   s.meanD = s.sumResD / s.numTermsD;
   s.meanP = s.sumResP / s.numTermsP;
-  // LGS6 / LGS4 finishNoDivide + LGS7::initializeFrom (LGSX.h:424-442)
-  for (int i = 0; i < 49; i++) ev->A[i] = 0.f;
-  for (int i = 0; i < 7; i++) ev->b[i] = 0.f;
-  int k = S3_A6;
-  for (int i = 0; i < 6; i++)
-    for (int j = i; j < 6; j++, k++) { const float v = 0.0f + r[k]; ev->A[i * 7 + j] = v; ev->A[j * 7 + i] = v; }
-  for (int i = 0; i < 6; i++) ev->b[i] = 0.0f - r[S3_A6 + 21 + i];
-  // (the 4x4 depth system lands on rows / columns 2, 3, 4, 6 of the 7x7 one)
-  k = S3_A4;
-  for (int i = 0; i < 4; i++)
-    for (int j = i; j < 4; j++, k++) {
-      const int ri = i < 3 ? 2 + i : 6, rj = j < 3 ? 2 + j : 6;
-      const float v = 0.0f + r[k];
-      ev->A[ri * 7 + rj] += v;
-      if (i != j) ev->A[rj * 7 + ri] += v;
-    }
-  for (int i = 0; i < 4; i++) ev->b[i < 3 ? 2 + i : 6] += 0.0f - r[S3_A4 + 10 + i];
   ev->num_constraints = (size_t)6 * (size_t)(ev->M >> 2) + (size_t)4 * (size_t)(ev->M >> 2);
+}
+S3_HD void sim3_eval_from_totals(const float* r, Eval* ev) {
+  sim3_eval_scalars(r, ev);
+  for (int i = 0; i < 7; i++) {
+    for (int j = 0; j < 7; j++) ev->A[i * 7 + j] = sim3_system_A(r, i, j);
+    ev->b[i] = sim3_system_b(r, i);
+  }
 }
 }  // namespace
 
@@ -482,16 +494,14 @@ struct lsdhip_sim3tracker {
   int maxItsPerLvl[LSD_LEVELS] = {5, 20, 50, 100, 100};
   float lambdaSuccessFac = 0.5f, lambdaFailFac = 2.0f, lambdaInitial = 0, stepSizeMin = 1e-8f, convergenceEps = 0.999f;
   float huber_d = 3, var_weight = 1.0f;
-  float* d_rows = nullptr;     // [2][S3_MAXB][max_blocks][64]
-  int4* d_topkey = nullptr;    // [2][S3_MAXB][max_blocks]
-  float* d_topval = nullptr;   // [2][S3_MAXB][max_blocks][3][48]
+  float* d_rows = nullptr;     // [2][S3_MAXB][S3_NBMAX][64]  (two launch parities: k_sim3_fused)
+  int4* d_topkey = nullptr;    // [2][S3_MAXB][S3_NBMAX]
   float* h_record = nullptr;   // [S3_MAXB][64] pinned, device-mapped
   float* d_record = nullptr;   // device alias of h_record
   int seq = 0;                 // launch counter, echoed by k_sim3_finalize in word 63 of every active slot's record
-  int max_blocks = 0;
   // trackFrameSim3 on the device (k_sim3_eval_dev / k_sim3_step): per batch slot the job's level descriptions and LM state
   Sim3Set* h_sets = nullptr;  Sim3Set* d_sets = nullptr;              // [S3_MAXB]; h_*: pinned staging
-  Sim3Track* h_states = nullptr;  Sim3Track* d_states = nullptr;      // [S3_MAXB]
+  Sim3Track* h_states = nullptr;  Sim3Track* d_states = nullptr;      // [S3_MAXB] ([2][S3_MAXB] on the device: launch parities)
   lsdhip_sim3_result* h_results = nullptr;  lsdhip_sim3_result* d_results = nullptr;   // [S3_MAXB] pinned, device-mapped
   int* h_done = nullptr;  int* d_done = nullptr;                              // [S3_MAXB] pinned, device-mapped
   int recentRounds = 0;        // evaluations the longest job of the last call needed: the next call's launch budget
@@ -502,12 +512,9 @@ extern "C" int lsdhip_sim3tracker_create(lsdhip_ctx* c, lsdhip_sim3tracker** out
   HIPCHK(hipSetDevice(c->device));
   lsdhip_sim3tracker* t = new lsdhip_sim3tracker();
   t->ctx = c;
-  t->max_blocks = (c->w * c->h + S3_BLOCK - 1) / S3_BLOCK;
-  const size_t mb = (size_t)t->max_blocks * S3_MAXB * 2;   // two launch parities (k_sim3_fused)
+  const size_t mb = (size_t)S3_NBMAX * S3_MAXB * 2;
   HIPCHK(hipMalloc((void**)&t->d_rows, mb * 64 * 4));
   HIPCHK(hipMalloc((void**)&t->d_topkey, mb * 16));
-  HIPCHK(hipMalloc((void**)&t->d_topval, mb * 3 * 48 * 4));
-  HIPCHK(hipMemsetAsync(t->d_topval, 0, mb * 3 * 48 * 4, c->stream));
   HIPCHK(hipHostMalloc((void**)&t->h_record, S3_MAXB * 64 * 4, hipHostMallocMapped));
   memset(t->h_record, 0, S3_MAXB * 64 * 4);
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_record, t->h_record, 0));
@@ -518,7 +525,7 @@ extern "C" void lsdhip_sim3tracker_destroy(lsdhip_sim3tracker* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
-  (void)hipFree(t->d_rows); (void)hipFree(t->d_topkey); (void)hipFree(t->d_topval); (void)hipHostFree(t->h_record);
+  (void)hipFree(t->d_rows); (void)hipFree(t->d_topkey); (void)hipHostFree(t->h_record);
   (void)hipFree(t->d_sets); (void)hipFree(t->d_states);
   (void)hipHostFree(t->h_sets); (void)hipHostFree(t->h_states); (void)hipHostFree(t->h_results); (void)hipHostFree(t->h_done);
   delete t;
@@ -529,6 +536,10 @@ extern "C" int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int i
   return LSDHIP_OK;
 }
 
+static void sim3_strips(int npix, int* nblocks, int* ppl) {
+  *ppl = (npix + S3_BLOCK * S3_NBMAX - 1) / (S3_BLOCK * S3_NBMAX);
+  *nblocks = (npix + S3_BLOCK * *ppl - 1) / (S3_BLOCK * *ppl);
+}
 // one evaluation = calcSim3Buffers + calcSim3WeightsAndResidualSSE + calcSim3LGSSSE at one transformation.
 // Description of the evaluation for batch slot `slot`:
 static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsdhip_frame* frame, const Sim3H& referenceToFrame, int level,
@@ -539,7 +550,7 @@ static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsd
   a.kf_idepth = kf->d_idepth[level]; a.kf_idepthVar = kf->d_idepthVar[level]; a.kf_image = kf->d_image[level]; a.kf_grad = kf->d_grad[level];
   a.fr_grad = frame->d_grad[level]; a.fr_idepth = frame->d_idepth[level]; a.fr_idepthVar = frame->d_idepthVar[level];
   a.w = c->wl[level]; a.h = c->hl[level];
-  a.nblocks = (a.w * a.h + S3_BLOCK - 1) / S3_BLOCK;
+  sim3_strips(a.w * a.h, &a.nblocks, &a.ppl);
   const LevelIntr& in = c->intr[level];
   a.fx = in.fx; a.fy = in.fy; a.cx = in.cx; a.cy = in.cy; a.fxi = in.fxi; a.fyi = in.fyi; a.cxi = in.cxi; a.cyi = in.cyi;
   double Rd[9];
@@ -577,9 +588,8 @@ static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsd
   }
   a.aff_a = aff_a; a.aff_b = aff_b;
   a.cameraPixelNoise2 = c->params.cameraPixelNoise2; a.var_weight = t->var_weight; a.huber_d = t->huber_d;
-  a.rows = t->d_rows + (size_t)slot * t->max_blocks * 64;
-  a.topkey = t->d_topkey + (size_t)slot * t->max_blocks;
-  a.topval = t->d_topval + (size_t)slot * t->max_blocks * 3 * 48;
+  a.rows = t->d_rows + (size_t)slot * S3_NBMAX * 64;
+  a.topkey = t->d_topkey + (size_t)slot * S3_NBMAX;
   a.record = t->d_record + (size_t)slot * 64;
   a.seq = 0;
   *out = a;
@@ -691,7 +701,7 @@ struct Sim3Track {                  // plain data: lives in HBM between the laun
   int pendingEval;                 // the previous launch evaluated the request: its rows wait in the scratch of this launch's parity
 };
 static_assert(sizeof(Sim3Track) % 4 == 0, "copied by words");
-struct Sim3Scratch { float A[49], b[7], inc[7]; int solve; float m[7][8]; };
+struct Sim3Scratch { float inc[7]; int solve; float m[7][8]; };
 
 // the requested transformation as the evaluation kernel wants it: rxso3().matrix() and translation in float, the in-plane roll of the
 // reference gradients (ESM, Sim3Tracker.cpp:455-464)
@@ -765,15 +775,16 @@ S3_HD void sim3_next_level(const Sim3LM& P, Sim3Track& J) {
   }
   sim3_finish(J);
 }
-// The damped system of the last accepted evaluation (A / n, b / n with the constraint count n, diagonal * (1 + lambda)); its solution is
-// the next increment.  The device solves it with the lanes of a wave between the two halves (gj7_solve_wave); `solve` is raised for that.
-S3_HD void sim3_propose(const Sim3LM& P, Sim3Track& J, Sim3Scratch& W) {
+// The next increment solves the damped system of the last accepted evaluation (A / n, b / n with the constraint count n, diagonal
+// * (1 + lambda)): entry (i, j) of the augmented 7x8 system, j = 7 the right-hand side
+S3_HD float sim3_damped_entry(const Sim3Track& J, const int i, const int j) {
   const float nc = (float)J.cur.num_constraints;
-  for (int i = 0; i < 7; i++) W.b[i] = -J.cur.b[i] / nc;
-  for (int i = 0; i < 49; i++) W.A[i] = J.cur.A[i] / nc;
-  for (int i = 0; i < 7; i++) W.A[i * 7 + i] *= 1 + J.LM_lambda;
-  W.solve = 1;
+  if (j == 7) return -J.cur.b[i] / nc;
+  float v = J.cur.A[i * 7 + j] / nc;
+  if (i == j) v *= 1 + J.LM_lambda;
+  return v;
 }
+S3_HD void sim3_propose(const Sim3LM& P, Sim3Track& J, Sim3Scratch& W) { W.solve = 1; }   // (the device solves it with the lanes of a wave)
 // ... and, with the increment, the candidate transformation whose evaluation is asked for
 S3_HD void sim3_propose_finish(const Sim3LM& P, Sim3Track& J, Sim3Scratch& W) {
   J.incTry++;
@@ -844,13 +855,13 @@ S3_HD void sim3_advance(const Sim3LM& P, Sim3Track& J, const Eval& ev, Sim3Scrat
 struct Sim3Lvl {                  // what does not change during a job, per pyramid level
   const float* kf_idepth; const float* kf_idepthVar; const float* kf_image; const float4* kf_grad;
   const float4* fr_grad; const float* fr_idepth; const float* fr_idepthVar;
-  int w, h, nblocks;
+  int w, h, nblocks, ppl;
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
 };
 struct Sim3Set {
   Sim3Lvl lv[LSD_LEVELS];
   float cameraPixelNoise2, var_weight, huber_d;
-  float* rows[2]; int4* topkey[2]; float* topval[2];   // per launch parity
+  float* rows[2]; int4* topkey[2];   // per launch parity
   lsdhip_sim3_result* result;     // pinned: the job's result record
   int* done;                      // pinned: seq * 256 + 255 (254: diverged) once the job has finished; seq * 256 + b when the b-th launch budget of the call
   int seq;                        // ends with the job unfinished (the host then queues another budget)
@@ -859,7 +870,7 @@ __device__ __forceinline__ void sim3_job_view(const Sim3Set& set, const Sim3Trac
   const Sim3Lvl& L = set.lv[J.reqLevel];
   a.kf_idepth = L.kf_idepth; a.kf_idepthVar = L.kf_idepthVar; a.kf_image = L.kf_image; a.kf_grad = L.kf_grad;
   a.fr_grad = L.fr_grad; a.fr_idepth = L.fr_idepth; a.fr_idepthVar = L.fr_idepthVar;
-  a.w = L.w; a.h = L.h; a.nblocks = L.nblocks;
+  a.w = L.w; a.h = L.h; a.nblocks = L.nblocks; a.ppl = L.ppl;
   a.fx = L.fx; a.fy = L.fy; a.cx = L.cx; a.cy = L.cy; a.fxi = L.fxi; a.fyi = L.fyi; a.cxi = L.cxi; a.cyi = L.cyi;
 #pragma unroll
   for (int i = 0; i < 9; i++) a.R[i] = J.reqR[i];
@@ -868,18 +879,18 @@ __device__ __forceinline__ void sim3_job_view(const Sim3Set& set, const Sim3Trac
   a.xRoll0 = J.reqRoll[0]; a.xRoll1 = J.reqRoll[1]; a.yRoll0 = J.reqRoll[2]; a.yRoll1 = J.reqRoll[3];
   a.aff_a = J.aff_a; a.aff_b = J.aff_b;
   a.cameraPixelNoise2 = set.cameraPixelNoise2; a.var_weight = set.var_weight; a.huber_d = set.huber_d;
-  a.rows = set.rows[parity]; a.topkey = set.topkey[parity]; a.topval = set.topval[parity];
+  a.rows = set.rows[parity]; a.topkey = set.topkey[parity];
   a.record = nullptr; a.seq = 0;
 }
 // 7x7 solve of the LM step with one element of the augmented 7x8 system per lane (lane = 8 i + j), pivot row / column read back through
 // LDS — gj6_solve_wave of the SE3 tracker (track_device.hpp) with one more row.  No pivoting: J^T W J (+ damping) is symmetric positive
 // definite; same solution as the reference's A.ldlt().solve(b) up to rounding (ldlt7_solve above stays as the CPU-checked form,
 // tests/test_host_math_cpu.py), which is what the trackFrameSim3 tests hold the poses to.
-__device__ __forceinline__ void gj7_solve_wave(Sim3Scratch& W, const int lane) {
+__device__ __forceinline__ void gj7_solve_wave(const Sim3Track& J, Sim3Scratch& W, const int lane) {
   const int i = lane >> 3, j = lane & 7;
   const bool act = i < 7;
-  const int ii = act ? i : 0, jj = j < 7 ? j : 0;
-  float m = (j == 7) ? W.b[ii] : W.A[ii * 7 + jj];
+  const int ii = act ? i : 0;
+  float m = sim3_damped_entry(J, ii, j);
 #pragma unroll
   for (int k = 0; k < 7; k++) {
     if (act) W.m[i][j] = m;
@@ -901,12 +912,24 @@ __device__ __forceinline__ void gj7_solve_wave(Sim3Scratch& W, const int lane) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// One launch per evaluation, as k_track_step does for the SE3 tracker: every workgroup of a job first brings the job's state up to date
-// — the totals of the evaluation the previous launch left in the rows of this launch's parity, then the LM decision and the next
-// request, computed redundantly (same inputs, same instructions, same result in every workgroup; workgroup 0 writes it to the state of
-// the other parity) —, then evaluates its tile of the request into the rows of the other parity.  A finished job's launches leave at once.
+// One launch per evaluation, as k_track_step does it for the SE3 tracker: every workgroup of a job first brings the job's state up to
+// date — the totals of the evaluation the previous launch left in the rows of this launch's parity, the Levenberg-Marquardt decision
+// and the next request, computed redundantly (same inputs, same instructions, same result in every workgroup; workgroup 0 writes it
+// to the state of the other parity) — and then evaluates its strip of the request into the rows of the other parity.  A level is at
+// most S3_NBMAX strips, so the redundant part reads little.  A finished job's launches leave at once.
+// Measured and dropped on the way (profiles/r05_notes.md): 256-pixel tiles (300 workgroups on level 1 of a 640x480 keyframe, each
+// adding up 300 rows before 4 us of tile work: no faster than the host-driven loop, 2.3x slower for eight jobs per launch), and a ticket
+// per job with only the last workgroup adding up and deciding (the release fence and ticket of every workgroup and the cold reads behind
+// the acquire cost more than the redundancy: 32 us per launch).
+#ifdef LSD_DEVTOOLS
+// phase stamps of workgroup 0 of job 0, per launch of a budget (LSDHIP_S3_TRACE=1 prints them: where a launch's time goes)
+__device__ unsigned long long g_s3trace[64][8];
+#define S3_MARK(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && traceSlot >= 0 && traceSlot < 64) g_s3trace[traceSlot][k] = wall_clock64(); } while (0)
+#else
+#define S3_MARK(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(S3_BLOCK) void k_sim3_fused(const Sim3Set* __restrict__ sets, Sim3Track* __restrict__ st, const Sim3LM P, const int parity,
-                                                          const int budgetEnd) {
+                                                          const int budgetEnd, const int traceSlot) {
   __shared__ Sim3Track s_J;
   __shared__ Eval s_ev;
   __shared__ Sim3Scratch s_W;
@@ -915,47 +938,62 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_fused(const Sim3Set* __restri
   const Sim3Set& set = sets[job];
   const Sim3Track* src = st + parity * S3_MAXB + job;
   Sim3Track* dst = st + (parity ^ 1) * S3_MAXB + job;
+  S3_MARK(0);
   for (int i = tid; i < (int)(sizeof(Sim3Track) / 4); i += S3_BLOCK) ((unsigned*)&s_J)[i] = ((const unsigned*)src)[i];
   __syncthreads();
   const bool wasDone = s_J.phase == Sim3Track::DONE;
+  if ((int)blockIdx.x >= set.lv[s_J.finalLevel].nblocks) return;   // no strip on any level to come (the final level is the finest)
+  S3_MARK(1);
   if (!wasDone && s_J.pendingEval) {
-    if ((int)blockIdx.x >= set.lv[s_J.finalLevel].nblocks) return;   // no tile on any level to come (the final level is the finest)
     Sim3Job a;
     sim3_job_view(set, s_J, parity, a);
     sim3_totals(a, s_tot);
+    S3_MARK(2);
+    if (tid < 49) s_ev.A[tid] = sim3_system_A(s_tot, tid / 7, tid % 7);
+    else if (tid < 56) s_ev.b[tid - 49] = sim3_system_b(s_tot, tid - 49);
+    else if (tid == 64) sim3_eval_scalars(s_tot, &s_ev);
+    __syncthreads();
     if (tid == 0) {
       s_W.solve = 0;
-      sim3_eval_from_totals(s_tot, &s_ev);
       sim3_advance(P, s_J, s_ev, s_W);
     }
     __syncthreads();
+    S3_MARK(3);
     if (s_W.solve) {
-      if (tid < 64) gj7_solve_wave(s_W, tid);
+      if (tid < 64) gj7_solve_wave(s_J, s_W, tid);
       __syncthreads();
+      S3_MARK(4);
       if (tid == 0) sim3_propose_finish(P, s_J, s_W);
+    } else {
+      S3_MARK(4);
     }
     if (tid == 0 && s_J.phase != Sim3Track::DONE) sim3_request(s_J);
     __syncthreads();
   }
+  S3_MARK(5);
   const bool done = s_J.phase == Sim3Track::DONE;
   if (blockIdx.x == 0) {
     if (tid == 0) s_J.pendingEval = done ? 0 : 1;
     __syncthreads();
     for (int i = tid; i < (int)(sizeof(Sim3Track) / 4); i += S3_BLOCK) ((unsigned*)dst)[i] = ((const unsigned*)&s_J)[i];
-    if (done && !wasDone)
-      for (int i = tid; i < (int)(sizeof(lsdhip_sim3_result) / 4); i += S3_BLOCK) ((unsigned*)set.result)[i] = ((const unsigned*)&s_J.res)[i];
-    __threadfence_system();                   // the result record (pinned) before the flag
-    __syncthreads();
-    if (tid == 0 && ((done && !wasDone) || (!done && budgetEnd >= 0))) {
-      *(volatile int*)set.done = set.seq * 256 + (done ? (s_J.rc == LSDHIP_OK ? 255 : 254) : budgetEnd);
-      __threadfence_system();
+    if ((done && !wasDone) || (!done && budgetEnd >= 0)) {
+      if (done)
+        for (int i = tid; i < (int)(sizeof(lsdhip_sim3_result) / 4); i += S3_BLOCK) ((unsigned*)set.result)[i] = ((const unsigned*)&s_J.res)[i];
+      __threadfence_system();                   // the result record (pinned) before the flag
+      __syncthreads();
+      if (tid == 0) {
+        *(volatile int*)set.done = set.seq * 256 + (done ? (s_J.rc == LSDHIP_OK ? 255 : 254) : budgetEnd);
+        __threadfence_system();
+      }
     }
   }
+  S3_MARK(6);
   if (done) return;
   Sim3Job a;
   sim3_job_view(set, s_J, parity ^ 1, a);
   if ((int)blockIdx.x >= a.nblocks) return;
-  sim3_eval_tile(a);
+  sim3_eval_strip(a);
+  S3_MARK(7);
 }
 
 // the device-side job storage of a tracker (first trackFrameSim3 call)
@@ -1005,17 +1043,15 @@ static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs, 
         L.kf_idepth = kf->d_idepth[l]; L.kf_idepthVar = kf->d_idepthVar[l]; L.kf_image = kf->d_image[l]; L.kf_grad = kf->d_grad[l];
         L.fr_grad = fr->d_grad[l]; L.fr_idepth = fr->d_idepth[l]; L.fr_idepthVar = fr->d_idepthVar[l];
         L.w = c->wl[l]; L.h = c->hl[l];
-        L.nblocks = (L.w * L.h + S3_BLOCK - 1) / S3_BLOCK;
+        sim3_strips(L.w * L.h, &L.nblocks, &L.ppl);
         const LevelIntr& in = c->intr[l];
         L.fx = in.fx; L.fy = in.fy; L.cx = in.cx; L.cy = in.cy; L.fxi = in.fxi; L.fyi = in.fyi; L.cxi = in.cxi; L.cyi = in.cyi;
         if (l == J.finalLevel && J.phase != Sim3Track::DONE && L.nblocks > grid) grid = L.nblocks;
       }
       S.cameraPixelNoise2 = c->params.cameraPixelNoise2; S.var_weight = t->var_weight; S.huber_d = t->huber_d;
       for (int par = 0; par < 2; par++) {
-        const size_t slot = (size_t)par * S3_MAXB + k;
-        S.rows[par] = t->d_rows + slot * t->max_blocks * 64;
-        S.topkey[par] = t->d_topkey + slot * t->max_blocks;
-        S.topval[par] = t->d_topval + slot * t->max_blocks * 3 * 48;
+        S.rows[par] = t->d_rows + ((size_t)par * S3_MAXB + k) * S3_NBMAX * 64;
+        S.topkey[par] = t->d_topkey + ((size_t)par * S3_MAXB + k) * S3_NBMAX;
       }
       S.result = t->d_results + k;     // pinned, written by the device when the job ends
       S.done = t->d_done + k;
@@ -1026,12 +1062,13 @@ static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs, 
     }
     if (!pending) continue;
     HIPCHK(hipMemcpyAsync(t->d_sets, t->h_sets, sizeof(Sim3Set) * (size_t)m, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(t->d_states, t->h_states, sizeof(Sim3Track) * (size_t)m, hipMemcpyHostToDevice, c->stream));   // parity 0
+    HIPCHK(hipMemcpyAsync(t->d_states, t->h_states, sizeof(Sim3Track) * (size_t)m, hipMemcpyHostToDevice, c->stream));
     int budget = t->recentRounds > 0 ? t->recentRounds + 3 : 24, parity = 0;   // evaluations + 1 launches end a job
     for (int b = 0;; b++) {
       if (b >= 250) { lsd_set_error("Sim3 tracking did not terminate"); return LSDHIP_E_STATE; }
       for (int i = 0; i < budget; i++, parity ^= 1)
-        hipLaunchKernelGGL(k_sim3_fused, dim3(grid, m), dim3(S3_BLOCK), 0, c->stream, (const Sim3Set*)t->d_sets, t->d_states, P, parity, i == budget - 1 ? b : -1);
+        hipLaunchKernelGGL(k_sim3_fused, dim3(grid, m), dim3(S3_BLOCK), 0, c->stream, (const Sim3Set*)t->d_sets, t->d_states, P, parity,
+                           i == budget - 1 ? b : -1, b == 0 ? i : -1);
       HIPCHK(hipGetLastError());
       // every pending job raises its word when it finishes or when the budget's last step leaves it unfinished; no stream query in
       // the wait (each one puts a marker packet into the queue the chain runs through) but as a safety net
@@ -1073,6 +1110,25 @@ static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs, 
       if (J.hostOut->numEvaluations > rounds) rounds = J.hostOut->numEvaluations;
     }
     t->recentRounds = rounds;
+#ifdef LSD_DEVTOOLS
+    if (getenv("LSDHIP_S3_TRACE")) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      static unsigned long long h[64][8];
+      HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_s3trace), sizeof(h)));
+      const char* names[7] = {"state", "totals", "system+advance", "solve", "finish+request", "publish", "strip"};
+      double sum[8] = {0}; int cnt = 0; double span = 0;
+      for (int i = 1; i + 1 < rounds && i < 63; i++) {     // launches with a pending evaluation and a strip of their own
+        for (int k = 0; k < 7; k++) sum[k] += (double)(h[i][k + 1] - h[i][k]) * 0.01;
+        span += (double)(h[i + 1][0] - h[i][0]) * 0.01;
+        cnt++;
+      }
+      if (cnt) {
+        fprintf(stderr, "[s3trace] %d launches, start-to-start %.2f us:", cnt, span / cnt);
+        for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.2f", names[k], sum[k] / cnt);
+        fprintf(stderr, " (us, workgroup 0 of job 0)\n");
+      }
+    }
+#endif
   }
   return LSDHIP_OK;
 }

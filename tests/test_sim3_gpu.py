@@ -167,3 +167,35 @@ def test_sim3_batch_equals_single_calls(hip):
         assert np.array_equal(np.array(recs[j].lastSim3Hessian), want[j][4])
     assert recs[3].diverged == 1 and recs[0].diverged == 0 and recs[1].numEvaluations > 5
     assert poses[1][7] == pytest.approx(1.25, rel=2e-2)
+
+
+def test_sim3_launch_budget_top_up_changes_nothing(hip):
+    """The device runs the LM loop inside a budget of launches sized by the previous call (evaluations + 3; 24 for a tracker's first
+    call); a job that needs more gets further budgets of 8.  A long job behind a short one (budget far too small, several top-ups)
+    returns bit for bit what it returns from a fresh tracker, and so does a short one behind a long one (idle launches behind its end)."""
+    from lsd_slam_amd import synth
+    w, h = 320, 240
+    sc = synth.Scene(0)
+    K = synth.intrinsics(w, h)
+    imgA, depthA = sc.render(0, w, h)
+    imgB, depthB = sc.render(3, w, h)
+    ctx = hip.Context(w, h, K)
+    a, b = hip.Frame(ctx, 0, imgA), hip.Frame(ctx, 3, imgB)
+    a.setDepthFromGroundTruth(depthA)
+    b.setDepthFromGroundTruth((depthB / 1.25).astype(np.float32))
+    R, t = sc.frame_to_ref(3, 0)
+    init = np.concatenate([synth.rot_to_quat(R), t, [1.0]])
+    short_its, long_its = [0, 0, 0, 2, 0], [5, 20, 50, 100, 100]
+
+    def run(tr, its, levels):
+        tr.setMaxItsPerLvl(its)
+        T, r = tr.trackFrameSim3(a, b, init, *levels)
+        return np.array(T), r.numEvaluations, r.lastResidual, np.array(r.lastSim3Hessian)
+
+    fresh_long = run(hip.Sim3Tracker(ctx), long_its, (3, 1))
+    fresh_short = run(hip.Sim3Tracker(ctx), short_its, (3, 3))
+    assert fresh_long[1] > fresh_short[1] + 11, (fresh_long[1], fresh_short[1])    # at least one top-up below
+    tr = hip.Sim3Tracker(ctx)
+    seq = [run(tr, short_its, (3, 3)), run(tr, long_its, (3, 1)), run(tr, short_its, (3, 3)), run(tr, long_its, (3, 1))]
+    for got, want in zip(seq, (fresh_short, fresh_long, fresh_short, fresh_long)):
+        assert np.array_equal(got[0], want[0]) and got[1] == want[1] and got[2] == want[2] and np.array_equal(got[3], want[3])
