@@ -85,11 +85,11 @@ LSD_HD float interp1(const float* __restrict__ mat, float x, float y, int width)
 
 struct ObserveArgs {
   HypPlanes m;
-  const float* kfImage;
-  const float4* kfGrad;
-  const float* kfMaxGrad;
-  const StereoRef* refs;
-  const int* refByID;
+  LSD_G const float* kfImage;
+  LSD_G const float4* kfGrad;
+  LSD_G const float* kfMaxGrad;
+  LSD_G const StereoRef* refs;
+  LSD_G const int* refByID;
   int nByID, byIDOffset, nRefs;
   int reactivated;
   int w, h;
@@ -98,11 +98,11 @@ struct ObserveArgs {
   int allowNegativeIdepths, useSubpixelStereo;
   int kfNumFramesTrackedOnThis, kfNumMappedOnThis;
 #ifdef LSD_PHASE_TRACE
-  unsigned long long* trace;   // developer build: per-stage timestamps of one traced pixel per workgroup
+  LSD_G unsigned long long* trace;   // developer build: per-stage timestamps of one traced pixel per workgroup
 #endif
-  unsigned long long* counters;   // null, or (sampled launches while profiling) two words per wave: pixels that entered the search, walk steps
-  float4* queue;                  // batches, two-launch form: this map's search queue (pixel index bits, epx, epy, -) and its fill count
-  int* qcount;
+  LSD_G unsigned long long* counters;   // null, or (sampled launches while profiling) two words per wave: pixels that entered the search, walk steps
+  LSD_G float4* queue;                  // batches, two-launch form: this map's search queue (pixel index bits, epx, epy, -) and its fill count
+  LSD_G int* qcount;
   StereoRef one;   // nRefs == 1 (the blockUntilMapped case): the reference travels in the kernel arguments, no staging copy
 };
 
@@ -653,16 +653,16 @@ __global__ __launch_bounds__(32 * ROWS) void k_observe_batch(const ObserveArgs* 
 struct PropArgs {
   HypPlanes src;   // currentDepthMap (old keyframe)
   HypPlanes dst;   // otherDepthMap (new keyframe)
-  const float* oldKFImage;
-  const float* newKFImage;
-  const float* newKFMaxGrad;
-  const uint8_t* trackingWasGood;  // level-1 mask of the new keyframe or nullptr
-  float4* cand;
-  int* slotCount;
-  int* slots;
-  int* flags;      // [0] error (chain storage exhausted), [1] chain entries handed out
-  int* ovfHead;    // per target: newest chain entry or -1
-  int2* ovf;       // (source index, next entry)
+  LSD_G const float* oldKFImage;
+  LSD_G const float* newKFImage;
+  LSD_G const float* newKFMaxGrad;
+  LSD_G const uint8_t* trackingWasGood;  // level-1 mask of the new keyframe or nullptr
+  LSD_G float4* cand;
+  LSD_G int* slotCount;
+  LSD_G int* slots;
+  LSD_G int* flags;      // [0] error (chain storage exhausted), [1] chain entries handed out
+  LSD_G int* ovfHead;    // per target: newest chain entry or -1
+  LSD_G int2* ovf;       // (source index, next entry)
   int ovfCap;
   int w, h;
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
@@ -850,9 +850,9 @@ __global__ __launch_bounds__(64) void k_observe_walk_batch(const ObserveArgs* __
 
 struct RegArgs {
   HypPlanes m;
-  const uint8_t* validIn;   // snapshot plane (read)
-  uint8_t* validOut;        // new validity plane (written for every pixel)
-  const float* kfMaxGrad;
+  LSD_G const uint8_t* validIn;   // snapshot plane (read)
+  LSD_G uint8_t* validOut;        // new validity plane (written for every pixel)
+  LSD_G const float* kfMaxGrad;
   int w, h;
   float minUseGrad, regDistVar;
   int validityTH;
@@ -959,9 +959,9 @@ __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
 //   propagateDepth into the new keyframe (prop_candidate on kx->prop) — while the values are in its registers.
 // SUMV: per-workgroup (sum of idepth_smoothed, count) over the valid pixels after the pass -> partials (createKeyFrame's rescale sums).
 struct KfExtra {
-  float* reactId;        // old keyframe's re-activation planes
-  float* reactVar;
-  uint8_t* reactVal;
+  LSD_G float* reactId;        // old keyframe's re-activation planes
+  LSD_G float* reactVar;
+  LSD_G uint8_t* reactVal;
   PropArgs prop;         // (src unused)
 };
 template <bool FILL, bool OCC, bool SET, bool KF = false, bool SUMV = false>
@@ -1229,9 +1229,9 @@ __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict_
 // the update-time pass (fill holes + regularise [+ setDepth]) over the maps of several sequences, blockIdx.z = map
 struct RegBatchItem {
   RegArgs a;
-  float* id0;          // null: this map's keyframe is not due for Frame::setDepth (depthHasBeenUpdatedFlag still set)
-  float* var0;
-  double* partials;
+  LSD_G float* id0;          // null: this map's keyframe is not due for Frame::setDepth (depthHasBeenUpdatedFlag still set)
+  LSD_G float* var0;
+  LSD_G double* partials;
 };
 template <bool SET>
 __global__ __launch_bounds__(256) void k_reg_fused_batch(const RegBatchItem* __restrict__ items) {
@@ -1255,9 +1255,9 @@ __global__ __launch_bounds__(256) void k_reg_fused_batch(const RegBatchItem* __r
 //   k_idepth_pyramid_batch both keyframes' pyramids and their (sum, count) records
 struct KfItem {
   RegArgs a;
-  float* id0;
-  float* var0;
-  double* partials;
+  LSD_G float* id0;
+  LSD_G float* var0;
+  LSD_G double* partials;
   KfExtra x;
 };
 __global__ __launch_bounds__(256) void k_kf_finalize_prop(const KfItem* __restrict__ items) {
@@ -1271,13 +1271,13 @@ __global__ __launch_bounds__(256) void k_kf_reg(const RegBatchItem* __restrict__
 }
 struct RescaleItem {
   HypPlanes m;
-  const double* sumPartials;   // per-tile (sum, count) of the pass before
+  LSD_G const double* sumPartials;   // per-tile (sum, count) of the pass before
   int nSumPartials;
-  int* flags;                  // propagation flags: [0] -> slot, then both zeroed
-  double* slot;                // pinned DeferredSlot of the rescale factor: (sum, count, flag)
-  float* id0;                  // new keyframe's level-0 planes
-  float* var0;
-  double* statPartials;        // (sum, count) per workgroup of this launch
+  LSD_G int* flags;                  // propagation flags: [0] -> slot, then both zeroed
+  LSD_G double* slot;                // pinned DeferredSlot of the rescale factor: (sum, count, flag)
+  LSD_G float* id0;                  // new keyframe's level-0 planes
+  LSD_G float* var0;
+  LSD_G double* statPartials;        // (sum, count) per workgroup of this launch
   int n;
 };
 #define LSD_RESCALE_PX 2048    // pixels per workgroup of k_kf_rescale_setdepth
@@ -1562,14 +1562,14 @@ static int alloc_planes(HypPlanes& p, size_t n, void** base_out) {
   HIPCHK(hipMemset(base, 0, bytes));
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   size_t off = 0;
-  p.blacklisted = (int32_t*)(base + off); off = up(off + n * 4);
-  p.nextID = (float*)(base + off); off = up(off + n * 4);
-  p.validity = (int32_t*)(base + off); off = up(off + n * 4);
-  p.idepth = (float*)(base + off); off = up(off + n * 4);
-  p.var = (float*)(base + off); off = up(off + n * 4);
-  p.idepth_s = (float*)(base + off); off = up(off + n * 4);
-  p.var_s = (float*)(base + off); off = up(off + n * 4);
-  p.valid = (uint8_t*)(base + off);
+  p.blacklisted = lsd_g((int32_t*)(base + off)); off = up(off + n * 4);
+  p.nextID = lsd_g((float*)(base + off)); off = up(off + n * 4);
+  p.validity = lsd_g((int32_t*)(base + off)); off = up(off + n * 4);
+  p.idepth = lsd_g((float*)(base + off)); off = up(off + n * 4);
+  p.var = lsd_g((float*)(base + off)); off = up(off + n * 4);
+  p.idepth_s = lsd_g((float*)(base + off)); off = up(off + n * 4);
+  p.var_s = lsd_g((float*)(base + off)); off = up(off + n * 4);
+  p.valid = lsd_g((uint8_t*)(base + off));
   *base_out = base;
   return LSDHIP_OK;
 }
@@ -1703,8 +1703,8 @@ static RegArgs reg_args(lsdhip_depthmap* dm, int validityTH) {
   RegArgs a;
   a.m = dm->cur;
   a.validIn = dm->cur.valid;
-  a.validOut = dm->d_validSnap;
-  a.kfMaxGrad = dm->activeKeyFrame->d_maxgrad;
+  a.validOut = lsd_g(dm->d_validSnap);
+  a.kfMaxGrad = lsd_g(dm->activeKeyFrame->d_maxgrad);
   a.w = c->w; a.h = c->h;
   a.minUseGrad = c->params.minUseGrad;
   a.regDistVar = 0.075f * 0.075f * c->params.depthSmoothingFactor * c->params.depthSmoothingFactor;  // REG_DIST_VAR
@@ -1713,7 +1713,7 @@ static RegArgs reg_args(lsdhip_depthmap* dm, int validityTH) {
   a.tileRows = 0;
   return a;
 }
-static void swap_valid(lsdhip_depthmap* dm) { std::swap(dm->cur.valid, dm->d_validSnap); }
+static void swap_valid(lsdhip_depthmap* dm) { uint8_t* v = (uint8_t*)dm->cur.valid; dm->cur.valid = lsd_g(dm->d_validSnap); dm->d_validSnap = v; }
 
 static int fill_holes(lsdhip_depthmap* dm) {
   lsdhip_ctx* c = dm->ctx;
@@ -1805,10 +1805,10 @@ static void prepare_stereo(lsdhip_depthmap* dm, lsdhip_frame* fr, StereoRef& s) 
   float R2f[9];
   for (int i = 0; i < 9; i++) R2f[i] = (float)R2[i] * (float)thisToOther.s;
   for (int i = 0; i < 3; i++) { s.row0[i] = R2f[i * 3 + 0]; s.row1[i] = R2f[i * 3 + 1]; s.row2[i] = R2f[i * 3 + 2]; }
-  s.image = fr->d_image[0];
+  s.image = lsd_g(fr->d_image[0]);
   // (pointer AND id: a destroyed frame's heap address can be handed out again)
   s.parentIsKF = (fr->trackingParent == dm->activeKeyFrame && fr->trackingParentID == dm->activeKeyFrame->id) ? 1 : 0;
-  s.wasGood = fr->wasGoodValid ? fr->d_wasGood : nullptr;
+  s.wasGood = lsd_g(fr->wasGoodValid ? fr->d_wasGood : nullptr);
   s.id = fr->id;
   s.initialTrackedResidual = fr->initialTrackedResidual;
 }
@@ -1818,9 +1818,9 @@ static void observe_args_common(lsdhip_depthmap* dm, ObserveArgs& a) {
   lsdhip_ctx* c = dm->ctx;
   lsdhip_frame* kf = dm->activeKeyFrame;
   a.m = dm->cur;
-  a.kfImage = kf->d_image[0];
-  a.kfGrad = kf->d_grad[0];
-  a.kfMaxGrad = kf->d_maxgrad;
+  a.kfImage = lsd_g(kf->d_image[0]);
+  a.kfGrad = lsd_g(kf->d_grad[0]);
+  a.kfMaxGrad = lsd_g(kf->d_maxgrad);
   a.reactivated = dm->activeKeyFrameIsReactivated ? 1 : 0;
   a.w = c->w; a.h = c->h;
   const LevelIntr& in = c->intr[0];
@@ -1891,8 +1891,8 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
     memset(&a.one, 0, sizeof(a.one));
   }
 
-  a.refs = dm->d_refs;
-  a.refByID = dm->d_refByID;
+  a.refs = lsd_g(dm->d_refs);
+  a.refByID = lsd_g(dm->d_refByID);
   a.nByID = (int)nByID;
   a.byIDOffset = offset;
   a.nRefs = n;
@@ -1923,7 +1923,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
         HIPCHK(hipMemsetAsync(dm->d_obsAcc, 0, 32, lsd_map_stream(c)));
         dm->obsCounterWaves = nwaves;
       }
-      if (dm->obsCounterWaves == nwaves) a.counters = dm->d_obsCounters;
+      if (dm->obsCounterWaves == nwaves) a.counters = lsd_g(dm->d_obsCounters);
     }
     if (rows == 8) {
       if (n == 1) hipLaunchKernelGGL((k_observe<true, 8>), grid, dim3(256), 0, lsd_map_stream(c), a);
@@ -1948,16 +1948,16 @@ static void prop_args(lsdhip_depthmap* dm, lsdhip_frame* nk, PropArgs& a) {
   size_t n = (size_t)c->w * c->h;
   a.src = dm->cur;
   a.dst = dm->oth;
-  a.oldKFImage = old->d_image[0];
-  a.newKFImage = nk->d_image[0];
-  a.newKFMaxGrad = nk->d_maxgrad;
-  a.trackingWasGood = (nk->trackingParent == old && nk->trackingParentID == old->id && nk->wasGoodValid) ? nk->d_wasGood : nullptr;
-  a.cand = dm->d_cand;
-  a.slotCount = dm->d_slotCount;
-  a.slots = dm->d_slots;
-  a.flags = dm->d_flags;
-  a.ovfHead = dm->d_ovfHead;
-  a.ovf = dm->d_ovf;
+  a.oldKFImage = lsd_g(old->d_image[0]);
+  a.newKFImage = lsd_g(nk->d_image[0]);
+  a.newKFMaxGrad = lsd_g(nk->d_maxgrad);
+  a.trackingWasGood = lsd_g((nk->trackingParent == old && nk->trackingParentID == old->id && nk->wasGoodValid) ? nk->d_wasGood : nullptr);
+  a.cand = lsd_g(dm->d_cand);
+  a.slotCount = lsd_g(dm->d_slotCount);
+  a.slots = lsd_g(dm->d_slots);
+  a.flags = lsd_g(dm->d_flags);
+  a.ovfHead = lsd_g(dm->d_ovfHead);
+  a.ovf = lsd_g(dm->d_ovf);
   a.ovfCap = (int)n;
   a.w = c->w; a.h = c->h;
   const LevelIntr& in = c->intr[0];
@@ -2232,8 +2232,8 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
 #ifdef LSD_PHASE_TRACE
     a.trace = nullptr;
 #endif
-    a.queue = split ? dm->d_obsQueue : nullptr;
-    a.qcount = qcountDev + j;
+    a.queue = lsd_g(split ? dm->d_obsQueue : nullptr);
+    a.qcount = lsd_g(qcountDev + j);
     qcountHost[j] = 0;
     dm->d_refs = nullptr;
     dm->d_refByID = nullptr;
@@ -2241,9 +2241,9 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
     RegBatchItem& r = ra[j];
     r.a = reg_args(dm, VAL_SUM_MIN_FOR_KEEP);
     const bool setDepth = !kf->depthHasBeenUpdatedFlag;
-    r.id0 = setDepth ? lsd_depth_w(kf)[0] : nullptr;
-    r.var0 = setDepth ? lsd_depthvar_w(kf)[0] : nullptr;
-    r.partials = dm->d_red + 16;
+    r.id0 = lsd_g(setDepth ? lsd_depth_w(kf)[0] : nullptr);
+    r.var0 = lsd_g(setDepth ? lsd_depthvar_w(kf)[0] : nullptr);
+    r.partials = lsd_g(dm->d_red + 16);
     if (setDepth) nSet++;
   }
   rc = lsd_args_commit(c, ms);
@@ -2440,8 +2440,8 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
     KfItem& k = kf[j];
     memset((void*)&k, 0, sizeof(k));
     k.a = reg_args(dm, VAL_SUM_MIN_FOR_KEEP);
-    k.id0 = lsd_depth_w(old)[0]; k.var0 = lsd_depthvar_w(old)[0]; k.partials = setA;
-    k.x.reactId = old->d_idepth_reAct; k.x.reactVar = old->d_idepthVar_reAct; k.x.reactVal = old->d_validity_reAct;
+    k.id0 = lsd_g(lsd_depth_w(old)[0]); k.var0 = lsd_g(lsd_depthvar_w(old)[0]); k.partials = lsd_g(setA);
+    k.x.reactId = lsd_g(old->d_idepth_reAct); k.x.reactVar = lsd_g(old->d_idepthVar_reAct); k.x.reactVal = lsd_g(old->d_validity_reAct);
     prop_args(dm, nk, k.x.prop);
     swap_valid(dm);
     {
@@ -2461,23 +2461,23 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
     swap_valid(dm);
     memset((void*)&regFill[j], 0, sizeof(RegBatchItem));
     regFill[j].a = reg_args(dm, VAL_SUM_MIN_FOR_KEEP);
-    regFill[j].partials = setB;
+    regFill[j].partials = lsd_g(setB);
     swap_valid(dm);
     RescaleItem& r = res[j];
     memset((void*)&r, 0, sizeof(r));
     r.m = dm->cur;
-    r.sumPartials = setB; r.nSumPartials = ntiles;
-    r.flags = dm->d_flags;
+    r.sumPartials = lsd_g(setB); r.nSumPartials = ntiles;
+    r.flags = lsd_g(dm->d_flags);
     {
       const int slot = lsd_ctx_take_slot(c);
       if (slot < 0) return slot;
       if (nk->pendRescale >= 0) c->slot_rescale_owner[nk->pendRescale] = nullptr;
       nk->pendRescale = slot;
       c->slot_rescale_owner[slot] = nk;
-      r.slot = (double*)&c->h_slots[slot];
+      r.slot = lsd_g((double*)&c->h_slots[slot]);
     }
-    r.id0 = lsd_depth_w(nk)[0]; r.var0 = lsd_depthvar_w(nk)[0];
-    r.statPartials = setC;
+    r.id0 = lsd_g(lsd_depth_w(nk)[0]); r.var0 = lsd_g(lsd_depthvar_w(nk)[0]);
+    r.statPartials = lsd_g(setC);
     r.n = npx;
     {
       const int slot = lsd_ctx_take_slot(c);

@@ -94,10 +94,10 @@ __global__ __launch_bounds__(256) void k_image_pyramid(const uint8_t* __restrict
 }
 // the same for the new frames of several sequences in one launch (blockIdx.z = frame; lsdhip_frame_create_batch)
 struct ImagePyrItem {
-  const uint8_t* gray;
-  float* img[LSD_LEVELS];
-  float4* grad0;
-  float* absgrad0;
+  LSD_G const uint8_t* gray;
+  LSD_G float* img[LSD_LEVELS];
+  LSD_G float4* grad0;
+  LSD_G float* absgrad0;
 };
 __global__ __launch_bounds__(256) void k_image_pyramid_batch(const ImagePyrItem* __restrict__ items, int w, int h) {
   const ImagePyrItem it = items[blockIdx.z];
@@ -118,13 +118,13 @@ struct GradArgs {
 // leaves the frame's level-1 refPixelWasGood mask in its "never written" state (0xFF), so that the tracker needs no separate
 // fill before its first use.
 struct GradMaxArgs {
-  const float* img[LSD_LEVELS];
-  float4* grad[LSD_LEVELS];
+  LSD_G const float* img[LSD_LEVELS];
+  LSD_G float4* grad[LSD_LEVELS];
   int w[LSD_LEVELS], h[LSD_LEVELS];
   int blk0[LSD_LEVELS + 1];     // first block of level l's gradient range (levels 1..4); blk0[LSD_LEVELS] = gradBlocks
-  const float* absg;
-  float* maxgrad;
-  uint32_t* wasGoodWords;
+  LSD_G const float* absg;
+  LSD_G float* maxgrad;
+  LSD_G uint32_t* wasGoodWords;
   int nMaskWords;
 };
 __device__ __forceinline__ void gradients_max_block(const GradMaxArgs& a) {
@@ -207,14 +207,14 @@ __device__ __forceinline__ void pool4(const float id[4], const float var[4], flo
 }
 
 struct DepthPyrArgs {
-  float* id[LSD_LEVELS];
-  float* var[LSD_LEVELS];
+  LSD_G float* id[LSD_LEVELS];
+  LSD_G float* var[LSD_LEVELS];
   int w0, h0;
   // optional passenger: one extra workgroup (blockIdx.y == gridDim.y - 1, blockIdx.x == 0 of an extra grid row) folds the
   // (sum, count) partials of the setDepth that produced level 0 into a pinned record (Frame::setDepth's meanIdepth / numPoints)
-  const double* redPartials;
+  LSD_G const double* redPartials;
   int redN;
-  double* redOut;
+  LSD_G double* redOut;
 };
 
 // Levels 1..4 of (idepth, idepthVar) from level 0, one 32x32 level-0 tile per workgroup: every lane pools one 2x2 block of level 0
@@ -1136,13 +1136,13 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
   GradMaxArgs ga;
   int nb = 0;
   for (int l = 0; l < LSD_LEVELS; l++) {
-    ga.img[l] = f->d_image[l]; ga.grad[l] = f->d_grad[l]; ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l];
+    ga.img[l] = lsd_g(f->d_image[l]); ga.grad[l] = lsd_g(f->d_grad[l]); ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l];
     ga.blk0[l] = nb;
     if (l >= 1) nb += (c->wl[l] * c->hl[l] + 255) / 256;
   }
   ga.blk0[LSD_LEVELS] = nb;
-  ga.absg = f->d_absgrad; ga.maxgrad = f->d_maxgrad;
-  ga.wasGoodWords = (uint32_t*)f->d_wasGood; ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
+  ga.absg = lsd_g(f->d_absgrad); ga.maxgrad = lsd_g(f->d_maxgrad);
+  ga.wasGoodWords = lsd_g((uint32_t*)f->d_wasGood); ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
   int n0 = c->w * c->h;
   lsdhip_host_mark(22);
   hipLaunchKernelGGL(k_gradients_max, dim3(nb + (n0 + 255) / 256), dim3(256), 0, stream, ga);
@@ -1161,9 +1161,9 @@ int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, i
   DepthPyrArgs a;
   float** id = lsd_depth_w(f);
   float** var = lsd_depthvar_w(f);
-  for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = id[l]; a.var[l] = var[l]; }
+  for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = lsd_g(id[l]); a.var[l] = lsd_g(var[l]); }
   a.w0 = c->w; a.h0 = c->h;
-  a.redPartials = redPartials; a.redN = redN; a.redOut = redOut;
+  a.redPartials = lsd_g(redPartials); a.redN = redN; a.redOut = lsd_g(redOut);
   hipLaunchKernelGGL(k_idepth_pyramid, dim3((c->w + 31) / 32, (c->h + 31) / 32 + (redPartials ? 1 : 0)), dim3(256), 0, lsd_map_stream(c), a);
   HIPCHK(hipGetLastError());
   if (c->pipeline) { f->depthPending = true; f->depthPendingSeq = c->mSeq + 1; }   // complete at the caller's record point
@@ -1234,9 +1234,9 @@ int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double*
     DepthPyrArgs& a = items[j];
     float** id = lsd_depth_w(f);
     float** var = lsd_depthvar_w(f);
-    for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = id[l]; a.var[l] = var[l]; }
+    for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = lsd_g(id[l]); a.var[l] = lsd_g(var[l]); }
     a.w0 = c->w; a.h0 = c->h;
-    a.redPartials = redPartials[j]; a.redN = redNs ? redNs[j] : redN; a.redOut = redOut[j];
+    a.redPartials = lsd_g(redPartials[j]); a.redN = redNs ? redNs[j] : redN; a.redOut = lsd_g(redOut[j]);
   }
   void* dev = nullptr;
   int rc = lsd_args_push(c, items.data(), sizeof(DepthPyrArgs) * (size_t)n, lsd_map_stream(c), &dev);
@@ -1350,19 +1350,19 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
       hipError_t e = hipMemcpyAsync(f->d_gray, gray[j], (size_t)c->w * c->h, hipMemcpyHostToDevice, ms);
       if (e != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: upload failed: %s", hipGetErrorString(e)); return fail(LSDHIP_E_HIP); }
     }
-    pi[j].gray = images_on_device ? gray[j] : f->d_gray;
-    for (int l = 0; l < LSD_LEVELS; l++) pi[j].img[l] = f->d_image[l];
-    pi[j].grad0 = f->d_grad[0]; pi[j].absgrad0 = f->d_absgrad;
+    pi[j].gray = lsd_g(images_on_device ? gray[j] : f->d_gray);
+    for (int l = 0; l < LSD_LEVELS; l++) pi[j].img[l] = lsd_g(f->d_image[l]);
+    pi[j].grad0 = lsd_g(f->d_grad[0]); pi[j].absgrad0 = lsd_g(f->d_absgrad);
     GradMaxArgs& ga = gi[j];
     nb = 0;
     for (int l = 0; l < LSD_LEVELS; l++) {
-      ga.img[l] = f->d_image[l]; ga.grad[l] = f->d_grad[l]; ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l];
+      ga.img[l] = lsd_g(f->d_image[l]); ga.grad[l] = lsd_g(f->d_grad[l]); ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l];
       ga.blk0[l] = nb;
       if (l >= 1) nb += (c->wl[l] * c->hl[l] + 255) / 256;
     }
     ga.blk0[LSD_LEVELS] = nb;
-    ga.absg = f->d_absgrad; ga.maxgrad = f->d_maxgrad;
-    ga.wasGoodWords = (uint32_t*)f->d_wasGood; ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
+    ga.absg = lsd_g(f->d_absgrad); ga.maxgrad = lsd_g(f->d_maxgrad);
+    ga.wasGoodWords = lsd_g((uint32_t*)f->d_wasGood); ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
     f->wasGoodPristine = true;
   }
   const size_t piBytes = align_up(sizeof(ImagePyrItem) * (size_t)n, 256);

@@ -385,20 +385,32 @@ struct lsdhip_tracker {
 };
 
 // SoA hypothesis planes in HBM (29 B/px + one spare validity plane for snapshot semantics)
+// A pointer read from a job description in device memory is a generic pointer to the compiler, and accesses through it are FLAT
+// instructions: 64-bit vector addresses only, and counted against the LDS counter as well as the memory counter, so every wait for an
+// LDS read also drains the loads in flight.  The pointer fields of the descriptions that kernels read from memory (batches) are
+// therefore typed as global-address-space pointers in device code (LSD_G; same layout on the host, where it is empty): whatever is
+// reached through them is a global_load / global_store (also through the plain-pointer parameters of inlined functions: the compiler
+// still knows where the pointer came from).
+#ifdef __HIP_DEVICE_COMPILE__
+#define LSD_G __attribute__((address_space(1)))
+#else
+#define LSD_G
+#endif
+template <typename T> __host__ __device__ inline LSD_G T* lsd_g(T* p) { return (LSD_G T*)p; }    // what the host code fills such a field with
 struct HypPlanes {
-  uint8_t* valid;       // isValid
-  int32_t* blacklisted;
-  float* nextID;        // nextStereoFrameMinID
-  int32_t* validity;    // validity_counter
-  float* idepth;
-  float* var;
-  float* idepth_s;
-  float* var_s;
+  LSD_G uint8_t* valid;       // isValid
+  LSD_G int32_t* blacklisted;
+  LSD_G float* nextID;        // nextStereoFrameMinID
+  LSD_G int32_t* validity;    // validity_counter
+  LSD_G float* idepth;
+  LSD_G float* var;
+  LSD_G float* idepth_s;
+  LSD_G float* var_s;
 };
 
 struct StereoRef {      // one reference (tracked) frame as K4 sees it
-  const float* image;   // level-0 image plane
-  const uint8_t* wasGood;  // level-1 mask or nullptr (only consulted when parentIsKF)
+  LSD_G const float* image;   // level-0 image plane
+  LSD_G const uint8_t* wasGood;  // level-1 mask or nullptr (only consulted when parentIsKF)
   int parentIsKF;
   int id;
   float initialTrackedResidual;
