@@ -344,21 +344,23 @@ S3_HD Sim3H sim3_mul(const Sim3H& a, const Sim3H& b) {   // sim3.hpp:160-163
   r.s = a.s * b.s;
   return r;
 }
-S3_HD Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-425, calcW sim3.hpp:608-650
+// the five transcendental values of an increment's exponential (the device computes them in different lanes: k_sim3_fused)
+struct Sim3Trig { double sin_theta, cos_theta, sin_half, cos_half, exp_sigma; };
+S3_HD double sim3_theta(const double a[7]) { return std::sqrt(a[3] * a[3] + (a[4] * a[4] + a[5] * a[5])); }
+S3_HD Sim3H sim3_exp(const double a[7], const Sim3Trig& tr) {   // sim3.hpp:417-428, rxso3.hpp:416-425, calcW sim3.hpp:608-650
   const double eps = 1e-10;
   const double ox = a[3], oy = a[4], oz = a[5], sigma = a[6];
-  const double scale = std::exp(sigma);
+  const double scale = tr.exp_sigma;
   const double theta_sq = ox * ox + (oy * oy + oz * oz);
   const double theta = std::sqrt(theta_sq);
-  const double half_theta = 0.5 * theta;
   double imag, real;
   if (theta < eps) {
     const double theta_po4 = theta_sq * theta_sq;
     imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
     real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
   } else {
-    imag = std::sin(half_theta) / theta;
-    real = std::cos(half_theta);
+    imag = tr.sin_half / theta;
+    real = tr.cos_half;
   }
   Sim3H r;
   r.q = {real, imag * ox, imag * oy, imag * oz};
@@ -377,7 +379,7 @@ S3_HD Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-4
   if (std::abs(sigma) < eps) {
     C = 1.0;
     if (std::abs(theta) < eps) { A = 0.5; B = 1.0 / 6.0; }
-    else { A = (1.0 - std::cos(theta)) / theta_sq; B = (theta - std::sin(theta)) / (theta_sq * theta); }
+    else { A = (1.0 - tr.cos_theta) / theta_sq; B = (theta - tr.sin_theta) / (theta_sq * theta); }
   } else {
     C = (scale - 1.0) / sigma;
     if (std::abs(theta) < eps) {
@@ -385,7 +387,7 @@ S3_HD Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-4
       A = ((sigma - 1.0) * scale + 1.0) / sigma_sq;
       B = ((0.5 * sigma * sigma - sigma + 1.0) * scale) / (sigma_sq * sigma);
     } else {
-      const double sa = scale * std::sin(theta), sb = scale * std::cos(theta), c = theta_sq + sigma * sigma;
+      const double sa = scale * tr.sin_theta, sb = scale * tr.cos_theta, c = theta_sq + sigma * sigma;
       A = (sa * sigma + (1.0 - sb) * theta) / (theta * c);
       B = (C - ((sb - 1.0) * sigma + sa * theta) / c) * 1.0 / theta_sq;
     }
@@ -399,6 +401,14 @@ S3_HD Sim3H sim3_exp(const double a[7]) {   // sim3.hpp:417-428, rxso3.hpp:416-4
     r.t[i] = acc;
   }
   return r;
+}
+S3_HD Sim3H sim3_exp(const double a[7]) {
+  const double theta = sim3_theta(a);
+  Sim3Trig tr;
+  tr.sin_theta = std::sin(theta); tr.cos_theta = std::cos(theta);
+  tr.sin_half = std::sin(0.5 * theta); tr.cos_half = std::cos(0.5 * theta);
+  tr.exp_sigma = std::exp(a[6]);
+  return sim3_exp(a, tr);
 }
 // 7x7 LDL^T with diagonal pivoting (Eigen A.ldlt().solve(b) semantics), as lsdm::ldlt6_solve
 // (the factorisation indexes its matrix with run-time indices: the caller provides the storage — the stack on the host, LDS on the device,
@@ -526,8 +536,8 @@ extern "C" void lsdhip_sim3tracker_destroy(lsdhip_sim3tracker* t) {
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
   (void)hipFree(t->d_rows); (void)hipFree(t->d_topkey); (void)hipHostFree(t->h_record);
-  (void)hipFree(t->d_sets); (void)hipFree(t->d_states);
-  (void)hipHostFree(t->h_sets); (void)hipHostFree(t->h_states); (void)hipHostFree(t->h_results); (void)hipHostFree(t->h_done);
+  (void)hipFree(t->d_sets);      // (one block: level descriptions + states, as they are uploaded)
+  (void)hipHostFree(t->h_sets); (void)hipHostFree(t->h_results); (void)hipHostFree(t->h_done);
   delete t;
 }
 extern "C" int lsdhip_sim3tracker_set_max_its(lsdhip_sim3tracker* t, const int its[LSD_LEVELS]) {
@@ -701,7 +711,7 @@ struct Sim3Track {                  // plain data: lives in HBM between the laun
   int pendingEval;                 // the previous launch evaluated the request: its rows wait in the scratch of this launch's parity
 };
 static_assert(sizeof(Sim3Track) % 4 == 0, "copied by words");
-struct Sim3Scratch { float inc[7]; int solve; float m[7][8]; };
+struct Sim3Scratch { float inc[7]; int solve; float m[7][8]; Sim3Trig trig; };
 
 // the requested transformation as the evaluation kernel wants it: rxso3().matrix() and translation in float, the in-plane roll of the
 // reference gradients (ESM, Sim3Tracker.cpp:455-464)
@@ -793,7 +803,7 @@ S3_HD void sim3_propose_finish(const Sim3LM& P, Sim3Track& J, Sim3Scratch& W) {
   J.absInc = absInc;
   if (!(absInc >= 0 && absInc < 1)) { sim3_diverge(J, false); return; }   // returns Sim3(), Hessian zero
   const double incd[7] = {(double)W.inc[0], (double)W.inc[1], (double)W.inc[2], (double)W.inc[3], (double)W.inc[4], (double)W.inc[5], (double)W.inc[6]};
-  J.candidate = sim3_mul(sim3_exp(incd), J.referenceToFrame);
+  J.candidate = sim3_mul(sim3_exp(incd, W.trig), J.referenceToFrame);
   J.phase = Sim3Track::TRY;
   J.reqPose = J.candidate; J.reqLevel = J.lvl;
 }
@@ -960,7 +970,22 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_fused(const Sim3Set* __restri
     __syncthreads();
     S3_MARK(3);
     if (s_W.solve) {
-      if (tid < 64) gj7_solve_wave(s_J, s_W, tid);
+      if (tid < 64) {
+        gj7_solve_wave(s_J, s_W, tid);
+        // the exponential's transcendental values side by side: sin / cos of theta and of theta / 2 in two lanes, exp(sigma) in a third
+        if (tid < 3) {
+          const double incd[7] = {0, 0, 0, (double)s_W.inc[3], (double)s_W.inc[4], (double)s_W.inc[5], (double)s_W.inc[6]};
+          const double theta = sim3_theta(incd);
+          if (tid < 2) {
+            double sn, cs;
+            sincos(tid == 0 ? theta : 0.5 * theta, &sn, &cs);
+            if (tid == 0) { s_W.trig.sin_theta = sn; s_W.trig.cos_theta = cs; }
+            else { s_W.trig.sin_half = sn; s_W.trig.cos_half = cs; }
+          } else {
+            s_W.trig.exp_sigma = exp(incd[6]);
+          }
+        }
+      }
       __syncthreads();
       S3_MARK(4);
       if (tid == 0) sim3_propose_finish(P, s_J, s_W);
@@ -998,16 +1023,19 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_fused(const Sim3Set* __restri
 
 // the device-side job storage of a tracker (first trackFrameSim3 call)
 static int sim3_device_storage(lsdhip_sim3tracker* t) {
-  if (t->d_states) return LSDHIP_OK;
-  HIPCHK(hipMalloc((void**)&t->d_sets, sizeof(Sim3Set) * S3_MAXB));
-  HIPCHK(hipHostMalloc((void**)&t->h_sets, sizeof(Sim3Set) * S3_MAXB, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&t->h_states, sizeof(Sim3Track) * S3_MAXB, hipHostMallocDefault));
+  if (t->d_sets) return LSDHIP_OK;
+  // one block on each side — [S3_MAXB] level descriptions, then the states ([2][S3_MAXB] on the device) — so that a call uploads both in one copy
+  static_assert(sizeof(Sim3Set) % 16 == 0 || (sizeof(Sim3Set) * S3_MAXB) % 8 == 0, "states behind the sets stay 8-byte aligned");
+  uint8_t *dblk = nullptr, *hblk = nullptr;
+  HIPCHK(hipMalloc((void**)&dblk, sizeof(Sim3Set) * S3_MAXB + sizeof(Sim3Track) * S3_MAXB * 2));
+  HIPCHK(hipHostMalloc((void**)&hblk, sizeof(Sim3Set) * S3_MAXB + sizeof(Sim3Track) * S3_MAXB, hipHostMallocDefault));
+  t->d_sets = (Sim3Set*)dblk; t->d_states = (Sim3Track*)(dblk + sizeof(Sim3Set) * S3_MAXB);
+  t->h_sets = (Sim3Set*)hblk; t->h_states = (Sim3Track*)(hblk + sizeof(Sim3Set) * S3_MAXB);
   HIPCHK(hipHostMalloc((void**)&t->h_results, sizeof(lsdhip_sim3_result) * S3_MAXB, hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_results, t->h_results, 0));
   HIPCHK(hipHostMalloc((void**)&t->h_done, sizeof(int) * S3_MAXB, hipHostMallocMapped));
   memset(t->h_done, 0, sizeof(int) * S3_MAXB);
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_done, t->h_done, 0));
-  HIPCHK(hipMalloc((void**)&t->d_states, sizeof(Sim3Track) * S3_MAXB * 2));
   return LSDHIP_OK;
 }
 static Sim3LM sim3_lm_params(const lsdhip_sim3tracker* t) {
@@ -1061,8 +1089,7 @@ static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs, 
       t->h_states[k] = J;
     }
     if (!pending) continue;
-    HIPCHK(hipMemcpyAsync(t->d_sets, t->h_sets, sizeof(Sim3Set) * (size_t)m, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(t->d_states, t->h_states, sizeof(Sim3Track) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(t->d_sets, t->h_sets, sizeof(Sim3Set) * S3_MAXB + sizeof(Sim3Track) * (size_t)m, hipMemcpyHostToDevice, c->stream));
     int budget = t->recentRounds > 0 ? t->recentRounds + 3 : 24, parity = 0;   // evaluations + 1 launches end a job
     for (int b = 0;; b++) {
       if (b >= 250) { lsd_set_error("Sim3 tracking did not terminate"); return LSDHIP_E_STATE; }
