@@ -1054,7 +1054,13 @@ class SlamLoopBatch {
     std::shared_ptr<Context> ctx = Context::get(w_, h_, K_);
     const int nkf = (int)work.kfChange.size();
     const int lanes = !sharedKeyframeChange && keyframeLanes > 1 && nkf > 0 ? (keyframeLanes < nkf ? keyframeLanes : nkf) : 0;
-    if (lanes) ctx->lanesBegin(lanes);
+    // (closed by the destructor too: an exception from one of the calls below must not leave the context inside a lane region)
+    struct LaneRegion {
+      Context* c; bool open;
+      LaneRegion(Context* c_, int n) : c(c_), open(n > 0) { if (open) c->lanesBegin(n); }
+      void end() { if (open) { open = false; c->lanesEnd(); } }
+      ~LaneRegion() { if (open) { try { c->lanesEnd(); } catch (...) {} } }
+    } region(ctx.get(), lanes);
     std::vector<Frame*> updFrames;
     for (auto& f : work.updFrames) updFrames.push_back(f.get());
     DepthMap::updateKeyframeBatch(work.updMaps, updFrames);
@@ -1084,7 +1090,7 @@ class SlamLoopBatch {
         q.lastFrameToKF = SE3();
       }
     }
-    if (lanes) ctx->lanesEnd();
+    region.end();
     for (size_t k = 0; k < work.updSeq.size(); k++) {
       Sequence& q = *seqs_[work.updSeq[k]];
       q.mappedOnKF++;

@@ -50,7 +50,7 @@ def needs_build():
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(SRC, s) for s in SOURCES] + [os.path.join(SRC, "lsdhip_internal.hpp"), os.path.join(SRC, "pose_math.hpp"),
-                                                       os.path.join(SRC, "track_device.hpp"),
+                                                       os.path.join(SRC, "track_device.hpp"), os.path.join(SRC, "rcp_exact.hpp"),
                                                        os.path.join(HERE, "..", "include", "lsdhip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -103,7 +103,26 @@ def build_driver(force=False, verbose=False):
     return DRIVER_OUT
 
 
+RCP_CHECK_SRC = os.path.join(HERE, "..", "tools", "rcp_exhaustive.hip")
+RCP_CHECK_OUT = os.path.join(HERE, "rcp_exhaustive.bin")
+
+
+def build_rcp_check(force=False, verbose=False):
+    """The exhaustive check of lsd_rcp_exact (csrc/rcp_exact.hpp) against `1.0f / x` over all 2^32 inputs: a small device program run by
+    tests/test_rcp_gpu.py.  Built with the library so that it travels to the GPU box with it."""
+    deps = [RCP_CHECK_SRC, os.path.join(SRC, "rcp_exact.hpp")]
+    if not force and os.path.exists(RCP_CHECK_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(RCP_CHECK_OUT) for d in deps):
+        return RCP_CHECK_OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-Wno-unused-value", RCP_CHECK_SRC, "-o", RCP_CHECK_OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return RCP_CHECK_OUT
+
+
 def build(force=False, verbose=False):
+    build_rcp_check(force, verbose)
     if not force and not needs_build():
         build_driver(False, verbose)
         return OUT

@@ -55,6 +55,16 @@ class Context:
         """tracking stream beside mapping stream (lsdhip_ctx_set_pipeline): the reference's two threads with blockUntilMapped == false"""
         check(self.L.lsdhip_ctx_set_pipeline(self.h_, int(bool(on))))
 
+    def lanes_begin(self, n):
+        """open a lane region: independent call chains (per-sequence keyframe changes) go to n side streams (lsdhip_ctx_lanes_begin)"""
+        check(self.L.lsdhip_ctx_lanes_begin(self.h_, int(n)))
+
+    def lane_select(self, lane):
+        check(self.L.lsdhip_ctx_lane_select(self.h_, int(lane)))
+
+    def lanes_end(self):
+        check(self.L.lsdhip_ctx_lanes_end(self.h_))
+
     def reserve_frames(self, n):
         """frame-memory pool: n arenas allocated ahead (lsdhip_ctx_reserve_frames)"""
         check(self.L.lsdhip_ctx_reserve_frames(self.h_, int(n)), False)

@@ -248,6 +248,79 @@ def test_change_keyframe_batch_equals_finalize_plus_create(hip):
     compare("after the second change")
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_keyframe_chains_in_a_lane_region_of_a_synchronous_context(hip, pipelined):
+    """finalizeKeyFrame + createKeyFrame of several maps dealt to the side streams of a lane region, on a context that is NOT asynchronous
+    (the Context default): every call resolves its deferred results — Frame::setDepth's meanIdepth / numPoints, the rescale factor —
+    before it returns, i.e. while the region is open and the kernels that write them sit on a lane, not on the mapping stream.  Same
+    maps, pyramids, statistics, rescale factors and poses as the same calls without lanes, on one-stream and on pipelined contexts
+    (the pipelined branch of the resolve used to wait for the mapping stream only: advisor, round 4)."""
+    w, h = 320, 240
+    S = 3
+    seqs = [sequence(w, h, 6, seq_index=s) for s in range(S)]
+    results = []
+    for lanes in (0, 2):
+        ctx = hip.Context(w, h, seqs[0][2])
+        ctx.set_pipeline(pipelined)
+        tr = hip.SE3Tracker(ctx)
+        tr.set_maxItsPerLvl(ODOMETRY_ITS)
+        cur = []
+        for s, (frames, depth0, K, gt) in enumerate(seqs):
+            kf = hip.Frame(ctx, 1000 * s, frames[0])
+            kf.setDepthFromGroundTruth(depth0)
+            dm = hip.DepthMap(ctx)
+            dm.initializeFromGTDepth(kf)
+            ref = hip.TrackingReference()
+            ref.importFrame(kf)
+            kf.clearDepthHasBeenUpdatedFlag()
+            cur.append({"kf": kf, "map": dm, "ref": ref, "pose": IDENT7.copy()})
+        out = []
+        for t in range(1, 5):
+            frs = []
+            for s in range(S):
+                st = cur[s]
+                fr = hip.Frame(ctx, 1000 * s + t, seqs[s][0][t])
+                st["pose"] = tr.trackFrame(st["ref"], fr, st["pose"])
+                frs.append(fr)
+            if t % 2 == 1:
+                for s in range(S):
+                    cur[s]["map"].updateKeyframe([frs[s]])
+                    cur[s]["ref"].importFrame(cur[s]["kf"])
+                    cur[s]["kf"].clearDepthHasBeenUpdatedFlag()
+                continue
+            if lanes:
+                ctx.lanes_begin(lanes)
+            scales, olds = [], []
+            for s in range(S):
+                if lanes:
+                    ctx.lane_select(s % lanes)
+                cur[s]["map"].finalizeKeyFrame()
+                olds.append(cur[s]["kf"].stats())                     # resolved inside the region
+                scales.append(cur[s]["map"].createKeyFrame(frs[s]))
+            if lanes:
+                ctx.lanes_end()
+            for s in range(S):
+                st = cur[s]
+                old = st["kf"]
+                st["kf"] = frs[s]
+                st["ref"].importFrame(st["kf"])
+                st["kf"].clearDepthHasBeenUpdatedFlag()
+                st["pose"] = IDENT7.copy()
+                out.append((np.float32(scales[s]), olds[s]["meanIdepth"], olds[s]["numPoints"], st["kf"].stats()["meanIdepth"], st["kf"].stats()["numPoints"],
+                            np.asarray(st["kf"].thisToParent_raw()).copy(), st["map"].currentDepthMap(), [st["kf"].idepth(l).copy() for l in range(5)],
+                            [old.idepth(l).copy() for l in range(5)]))
+        results.append(out)
+    assert len(results[0]) == len(results[1]) == 2 * S
+    for k, (a, b) in enumerate(zip(*results)):
+        assert a[0] == b[0] and a[1:5] == b[1:5], (k, a[:5], b[:5])
+        assert np.isfinite(a[0]) and a[4] > 100
+        assert np.array_equal(a[5], b[5]), k
+        assert_maps_equal(a[6], b[6], "change %d" % k)
+        for l in range(5):
+            assert_bit_equal(a[7][l], b[7][l], "change %d new keyframe idepth level %d" % (k, l))
+            assert_bit_equal(a[8][l], b[8][l], "change %d old keyframe idepth level %d" % (k, l))
+
+
 def test_change_keyframe_batch_rejects_bad_arguments(hip):
     w, h = 320, 240
     frames, depth0, K, gt = sequence(w, h, 3)

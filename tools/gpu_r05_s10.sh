@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/r05_s10
 mkdir -p $O
-timeout 200 tools/rcp_exhaustive.bin | tee $O/rcp_exhaustive.json | cut -c1-400
+timeout 200 lsd_slam_amd/rcp_exhaustive.bin | tee $O/rcp_exhaustive.json | cut -c1-400
 timeout 300 python -m pytest tests/test_sim3_gpu.py -m gpu -q -x > $O/pytest_sim3.log 2>&1; echo "pytest sim3 rc=$?"; tail -15 $O/pytest_sim3.log
 H=$R/lsd_slam_amd/liblsdhip_head.so
 I=$R/lsd_slam_amd/liblsdhip_ieee.so

@@ -2,20 +2,16 @@
 // Exhaustive on the device itself: all 2^32 bit patterns against the IEEE division sequence hipcc emits for 1.0f / x, by class of input.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/rcp_exhaustive.hip -o tools/rcp_exhaustive.bin && tools/rcp_exhaustive.bin
 // Variants: nr1 = the bare correction (claim: inputs whose reciprocal is a normal number); exact = lsd_rcp_exact of
-// lsd_slam_amd/csrc/lsdhip_internal.hpp (claim: every input, NaNs compared as a class).
+// lsd_slam_amd/csrc/rcp_exact.hpp, included here (claim: every input, NaNs compared as a class).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include "../lsd_slam_amd/csrc/rcp_exact.hpp"
 __device__ __forceinline__ float rcp_nr1(float x) {
   const float r0 = __builtin_amdgcn_rcpf(x);
   const float e = __builtin_fmaf(-x, r0, 1.0f);
   return __builtin_fmaf(r0, e, r0);
 }
-__device__ __forceinline__ float rcp_exact(float x) {
-  const float r0 = __builtin_amdgcn_rcpf(x);
-  if (__builtin_expect(!__builtin_amdgcn_classf(r0, 0x108), 0)) return 1.0f / x;   // estimate not +-normal: the division itself
-  const float e = __builtin_fmaf(-x, r0, 1.0f);
-  return __builtin_fmaf(r0, e, r0);
-}
+__device__ __forceinline__ float rcp_exact(float x) { return lsd_rcp_exact(x); }   // the product's function (lsd_slam_amd/csrc/rcp_exact.hpp)
 // classes: 0 zero, 1 denormal, 2 normal with normal reciprocal, 3 normal with denormal reciprocal, 4 normal with infinite reciprocal, 5 inf, 6 nan
 __global__ void k_check(unsigned long long* out) {
   unsigned long long n[7] = {0}, bad1[7] = {0}, badx[7] = {0}, bad0[7] = {0};
