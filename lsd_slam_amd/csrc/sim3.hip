@@ -6,11 +6,11 @@
 //   Sim3Tracker::calcSim3LGSSSE                  :858-983 + LGS4 / LGS6 / LGS7  C/Tracking/LGSX.h:45-176, :184-402, :411-443
 //   Sim3Tracker::trackFrameSim3                  :149-378
 //
-// One evaluation = buffers + weights + both least-squares systems fused (sim3_eval_tile: one reference pixel per lane, 54 sums
-// reduced lane -> LDS -> one row per tile) + fixed-order row sums with the SSE tail drop (sim3_totals).
+// One evaluation = buffers + weights + both least-squares systems fused (sim3_eval_strip: 1-10 reference pixels per lane, 54 sums
+// reduced lane -> LDS -> one row per strip) + fixed-order row sums with the SSE tail drop (sim3_totals).
 // trackFrameSim3 runs on the device, one launch per evaluation (k_sim3_fused, built like k_track_step of the SE3 tracker): every
 // workgroup first totals the previous launch's rows, takes the Levenberg-Marquardt decision (the loop of Sim3Tracker.cpp:149-378 as
-// a state machine; 7x7 system solved by one wave, Sim3 exp / composition in double as the reference) and then evaluates its tile of
+// a state machine; 7x7 system solved by one wave, Sim3 exp / composition in double as the reference) and then evaluates its strip of
 // the next request.  The host queues a budget of launches and waits for one pinned word per job.  Rounds 2-4 drove the loop from
 // the host: one round trip per evaluation, 28 us per evaluation of which 21 were kernels.
 // lsdhip_sim3tracker_evaluate (a single evaluation for the tests) keeps the two-kernel form: k_sim3_eval + k_sim3_finalize -> pinned record.
@@ -509,7 +509,7 @@ struct lsdhip_sim3tracker {
   float* h_record = nullptr;   // [S3_MAXB][64] pinned, device-mapped
   float* d_record = nullptr;   // device alias of h_record
   int seq = 0;                 // launch counter, echoed by k_sim3_finalize in word 63 of every active slot's record
-  // trackFrameSim3 on the device (k_sim3_eval_dev / k_sim3_step): per batch slot the job's level descriptions and LM state
+  // trackFrameSim3 on the device (k_sim3_fused): per batch slot the job's level descriptions and LM state
   Sim3Set* h_sets = nullptr;  Sim3Set* d_sets = nullptr;              // [S3_MAXB]; h_*: pinned staging
   Sim3Track* h_states = nullptr;  Sim3Track* d_states = nullptr;      // [S3_MAXB] ([2][S3_MAXB] on the device: launch parities)
   lsdhip_sim3_result* h_results = nullptr;  lsdhip_sim3_result* d_results = nullptr;   // [S3_MAXB] pinned, device-mapped
@@ -690,7 +690,7 @@ struct Sim3LM {                    // the tracker's settings as the state machin
   float lambdaSuccessFac, lambdaFailFac, lambdaInitial, stepSizeMin, convergenceEps;
   int useAffine, w, h;
 };
-struct Sim3Track {                  // plain data: lives in HBM between the launches, in LDS while k_sim3_step works on it
+struct Sim3Track {                  // plain data: lives in HBM between the launches, in LDS while a launch works on it
   lsdhip_sim3_result res;          // the result record as far as it is known (workgroup 0 copies it to the pinned record at the end)
   lsdhip_sim3_result* hostOut;     // the caller's record
   enum Phase { LEVEL_FIRST, TRY, FINAL, DONE };
@@ -706,7 +706,7 @@ struct Sim3Track {                  // plain data: lives in HBM between the laun
   // the evaluation this job waits for
   Sim3H reqPose;
   int reqLevel;
-  // ... as k_sim3_eval_dev reads it (sim3_request)
+  // ... as the strips read it (sim3_request)
   float reqR[9], reqT[3], reqRoll[4];
   int pendingEval;                 // the previous launch evaluated the request: its rows wait in the scratch of this launch's parity
 };
