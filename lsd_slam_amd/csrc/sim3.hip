@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_fused(const Sim3Set* __restri
 static int sim3_device_storage(lsdhip_sim3tracker* t) {
   if (t->d_sets) return LSDHIP_OK;
   // one block on each side — [S3_MAXB] level descriptions, then the states ([2][S3_MAXB] on the device) — so that a call uploads both in one copy
-  static_assert(sizeof(Sim3Set) % 16 == 0 || (sizeof(Sim3Set) * S3_MAXB) % 8 == 0, "states behind the sets stay 8-byte aligned");
+  static_assert((sizeof(Sim3Set) * S3_MAXB) % alignof(Sim3Track) == 0, "the states behind the level descriptions keep their alignment");
   uint8_t *dblk = nullptr, *hblk = nullptr;
   HIPCHK(hipMalloc((void**)&dblk, sizeof(Sim3Set) * S3_MAXB + sizeof(Sim3Track) * S3_MAXB * 2));
   HIPCHK(hipHostMalloc((void**)&hblk, sizeof(Sim3Set) * S3_MAXB + sizeof(Sim3Track) * S3_MAXB, hipHostMallocDefault));
