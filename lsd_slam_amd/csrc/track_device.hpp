@@ -171,19 +171,21 @@ __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q
   float depthChange = pz * z;
   o.usage = depthChange < 1 ? depthChange : 1;
 
-  // K2, SSE operation order
+  // K2 / K3: the reference's formulas (SSE operation order) with the multiply-adds fused.  Like the 1-ulp reciprocals above, these
+  // quantities only feed sums held to a tolerance (the weights and the Jacobian: the reference's own SSE path computes them from 12-bit
+  // reciprocals); a fused multiply-add is one rounding and one instruction where the separate pair is two of each, and this loop is
+  // bound by instruction issue (profiles/r05_notes.md).  Everything above that decides a mask bit or a count is untouched.
   float pz2d = frcp((Wz * Wz) * d);
-  float g0 = (Wz * a.t[0] - Wx * a.t[2]) * pz2d;
-  float g1 = (Wz * a.t[1] - Wy * a.t[2]) * pz2d;
-  float drpdd = g0 * gx + g1 * gy;
-  float w_p = frcp(a.cameraPixelNoise2 + drpdd * (drpdd * (a.var_weight * var)));
+  float g0 = __builtin_fmaf(Wz, a.t[0], 0.0f - Wx * a.t[2]) * pz2d;
+  float g1 = __builtin_fmaf(Wz, a.t[1], 0.0f - Wy * a.t[2]) * pz2d;
+  float drpdd = __builtin_fmaf(g0, gx, g1 * gy);
+  float w_p = frcp(__builtin_fmaf(drpdd, drpdd * (a.var_weight * var), a.cameraPixelNoise2));
   float wr = residual * fsqrt(w_p);
   wr = fmaxf(wr, 0.0f - wr);
   float wh = (wr < a.huber_half) ? 1.0f : a.huber_half * frcp(wr);
   o.werr = wh * (wr * wr);
   o.w = wh * w_p;
 
-  // K3, SSE operation order
   o.J[0] = z * gx;
   o.J[1] = z * gy;
   float v1 = (Wx * gy) * z;
@@ -193,8 +195,8 @@ __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q
   v1 = (Wx * gx) * z2;
   v2 = (Wy * gy) * z2;
   o.J[2] = 0.0f - (v1 + v2);
-  o.J[3] = 0.0f - ((v2 * Wy) + (gy + v1 * Wy));
-  o.J[4] = (gx + v1 * Wx) + v2 * Wx;
+  o.J[3] = 0.0f - __builtin_fmaf(v2, Wy, __builtin_fmaf(v1, Wy, gy));
+  o.J[4] = __builtin_fmaf(v2, Wx, __builtin_fmaf(v1, Wx, gx));
 }
 // (px,py,pz) = reference point, I_ref / var = its colour and inverse-depth variance.
 __device__ __forceinline__ void eval_point(const EvalCtx& a, float px, float py, float pz, float I_ref, float var, PointOut& o) {
