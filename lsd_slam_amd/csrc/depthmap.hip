@@ -969,7 +969,7 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
                                                double* __restrict__ partials, const KfExtra* __restrict__ kx = nullptr) {
   constexpr int HALO = FILL ? 4 : 2;
   constexpr int TW = 32 + 2 * HALO, TH = 8 + 2 * HALO, TN = TW * TH;
-  // Per tile entry ONE 16-byte word (idepth, idepth_var, pk) with pk = validity_counter of a valid pixel (never negative), -1 for an
+  // Per tile entry ONE 16-byte word (idepth, idepth_var, (float)pk) with pk = validity_counter of a valid pixel (never negative), -1 for an
   // invalid one: a neighbour costs K6 one LDS round trip (round 4: two dependent ones — the validity word, then, behind the branch on
   // it, the hypothesis; rounds 1-3: four arrays).  s_pk0 is the pre-K5 snapshot of pk that K5 reads.
   __shared__ int s_pk0[TN];
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
       const int pk = (inb && v) ? vc : -1;
       s_pk0[e] = pk;
       s_created[e] = 0;
-      s_e[e] = rege{id, var, __int_as_float(pk), 0.f};
+      s_e[e] = rege{id, var, (float)pk, 0.f};             // (the counter as a float: K6 adds it to a float sum once per neighbour)
     }
   }
   // K5's gradient test reads the keyframe's maxGradients at the pixels of its region: issued with the tile loads (one memory round
@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
               idepthObs = unzero(idepthObs);
               s_created[e] = 1;
               // nobody reads these entries during K5 (their snapshot validity is 0)
-              s_e[e] = rege{idepthObs, VAR_RANDOM_INIT_INITIAL, __int_as_float(0), 0.f};
+              s_e[e] = rege{idepthObs, VAR_RANDOM_INIT_INITIAL, 0.f, 0.f};
             }
           }
         }
@@ -1081,7 +1081,7 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   const int idx = inImage ? x + y * w : 0;
   const bool created = FILL && s_created[e] != 0;
   const rege c_e = s_e[e];
-  const int c_pk = __float_as_int(c_e.z);
+  const int c_pk = (int)c_e.z;
   const uint8_t wasValid = c_pk >= 0 ? 1 : 0;
   uint8_t nowValid = wasValid;
   bool smoothed = false, blacklistDec = false;
@@ -1099,12 +1099,18 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     // The next neighbour's entry is requested before the current one is worked on (volatile: the read stays where it is written instead
     // of sinking below the branches to its first use), so an LDS round trip overlaps the arithmetic instead of preceding it.
     auto entry = [&](int k) { const int dx = k / 5 - 2, dy = k % 5 - 2; return *(const volatile __attribute__((address_space(3))) rege3*)&s_e[e + dx + dy * TW]; };
+    // the six distance terms (dx^2 + dy^2) * regDistVar of the 5x5 window and the reciprocal's class mask, once, in scalar registers: as
+    // literals inside the loop each costs a move (+ a multiply) per neighbour in a loop of ~17 vector instructions per neighbour
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float df0 = uni(0.0f * a.regDistVar), df1 = uni(1.0f * a.regDistVar), df2 = uni(2.0f * a.regDistVar), df4 = uni(4.0f * a.regDistVar),
+                df5 = uni(5.0f * a.regDistVar), df8 = uni(8.0f * a.regDistVar);
+    const int nmask = lsd_rcp_mask();
     rege3 ej = entry(0);
 #pragma unroll
     for (int k = 0; k < 25; k++) {
       const int dx = k / 5 - 2, dy = k % 5 - 2;     // dx outer, dy inner: the reference's order of the sums
       const rege3 en = entry(k < 24 ? k + 1 : 24);
-      const int vcj = __float_as_int(ej.z);
+      const float vcj = ej.z;                       // validity counter (small integer, exact) or -1
       const float s_idj = ej.x;
       const float s_varj = ej.y;
       ej = en;
@@ -1116,8 +1122,9 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
       }
       val_sum += vcj;
       if (OCC) numNotOccluding++;
-      const float distFac = (float)(dx * dx + dy * dy) * a.regDistVar;
-      const float ivar = lsd_rcp_exact(s_varj + distFac);
+      const int d2 = dx * dx + dy * dy;             // (float)(d2) * regDistVar, as the reference forms it
+      const float distFac = d2 == 0 ? df0 : (d2 == 1 ? df1 : (d2 == 2 ? df2 : (d2 == 4 ? df4 : (d2 == 5 ? df5 : df8))));
+      const float ivar = lsd_rcp_exact(s_varj + distFac, nmask);
       sum += s_idj * ivar;
       sumIvar += ivar;
     }

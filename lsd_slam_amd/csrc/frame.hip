@@ -856,7 +856,7 @@ __global__ void k_flag_set(int* flag, int value, unsigned* arrive) {
 }
 __global__ void k_flag_wait(const int* flag, int value, int* fail) {
   if (threadIdx.x != 0) return;
-  for (unsigned spins = 0; spins < (1u << 24); spins++) {          // ~2 s
+  for (unsigned spins = 0; spins < (1u << 26); spins++) {          // ~8 s (2 s proved too tight once for a peer process's first launches on a shared GPU)
     if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= value) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                // system scope: this XCD's L2 drops what it cached of foreign memory
       return;
