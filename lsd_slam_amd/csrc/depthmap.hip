@@ -1567,6 +1567,7 @@ static int alloc_planes(HypPlanes& p, size_t n, void** base_out) {
   size_t bytes = n * 29 + 8 * 256;
   HIPCHK(hipMalloc((void**)&base, bytes));
   HIPCHK(hipMemset(base, 0, bytes));
+  HIPCHK(hipStreamSynchronize(nullptr));   // (hipMemset runs on the null stream, which this library's non-blocking streams do not wait for)
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   size_t off = 0;
   p.blacklisted = lsd_g((int32_t*)(base + off)); off = up(off + n * 4);
@@ -1590,6 +1591,7 @@ static int depth_create_impl(lsdhip_ctx* c, lsdhip_depthmap* dm) {
   HIPCHK(hipMalloc((void**)&dm->d_validSnap, n));
   dm->bases[2] = dm->d_validSnap;
   HIPCHK(hipMemset(dm->d_validSnap, 0, n));
+  HIPCHK(hipStreamSynchronize(nullptr));
   HIPCHK(hipMalloc((void**)&dm->d_slotCount, n * 4));
   HIPCHK(hipMalloc((void**)&dm->d_slots, n * 4 * PROP_SLOT_CAP));
   HIPCHK(hipMalloc((void**)&dm->d_ovfHead, n * 4));

@@ -610,7 +610,7 @@ int lsd_pipe_dummy(lsdhip_ctx* c) {
   if (!g_pipeDummy || !c->pipeline) return LSDHIP_OK;
   static float* buf = nullptr;
   const size_t n = 8u << 20;
-  if (!buf) { HIPCHK(hipMalloc((void**)&buf, n * 4)); HIPCHK(hipMemset(buf, 0, n * 4)); }
+  if (!buf) { HIPCHK(hipMalloc((void**)&buf, n * 4)); HIPCHK(hipMemset(buf, 0, n * 4)); HIPCHK(hipStreamSynchronize(nullptr)); }
   for (int rep = 0; rep < 4; rep++) {
     if (g_pipeDummy == 1) hipLaunchKernelGGL(k_dummy_stream, dim3(2048), dim3(256), 0, c->mstream, buf, n);
     else if (g_pipeDummy == 2) hipLaunchKernelGGL(k_dummy_lds, dim3(1200), dim3(256), 0, c->mstream, buf);
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void k_trace_sum(const uint32_t* __restrict__ 
 }
 void lsd_trace_sum(lsdhip_ctx* c, hipStream_t s, int kind, int id, const void* p, size_t bytes) {
   if (!g_traceSums) return;
-  if (!c->d_sums) { if (hipMalloc((void**)&c->d_sums, LSD_TRACE_SLOTS * 8) != hipSuccess) return; (void)hipMemset(c->d_sums, 0, LSD_TRACE_SLOTS * 8); }
+  if (!c->d_sums) { if (hipMalloc((void**)&c->d_sums, LSD_TRACE_SLOTS * 8) != hipSuccess) return; (void)hipMemset(c->d_sums, 0, LSD_TRACE_SLOTS * 8); (void)hipStreamSynchronize(nullptr); }
   const size_t slot = c->sums_meta.size() / 2;
   if (slot >= LSD_TRACE_SLOTS) return;
   c->sums_meta.push_back(kind); c->sums_meta.push_back(id);
@@ -707,14 +707,14 @@ __global__ void k_gate_open(int* flag, int value) {
 }
 int lsd_gate_wait(lsdhip_ctx* c) {
   if (!g_pipeGate || !c->pipeline) return LSDHIP_OK;
-  if (!c->d_gate) { HIPCHK(hipMalloc((void**)&c->d_gate, 64)); HIPCHK(hipMemset(c->d_gate, 0, 64)); }
+  if (!c->d_gate) { HIPCHK(hipMalloc((void**)&c->d_gate, 64)); HIPCHK(hipMemset(c->d_gate, 0, 64)); HIPCHK(hipStreamSynchronize(nullptr)); }
   c->gateWaited = c->gateSeq + 1;
   hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, c->mstream, c->d_gate, c->gateWaited);
   return LSDHIP_OK;
 }
 int lsd_gate_open(lsdhip_ctx* c) {
   if (!g_pipeGate || !c->pipeline) return LSDHIP_OK;
-  if (!c->d_gate) { HIPCHK(hipMalloc((void**)&c->d_gate, 64)); HIPCHK(hipMemset(c->d_gate, 0, 64)); }
+  if (!c->d_gate) { HIPCHK(hipMalloc((void**)&c->d_gate, 64)); HIPCHK(hipMemset(c->d_gate, 0, 64)); HIPCHK(hipStreamSynchronize(nullptr)); }
   c->gateSeq++;
   hipLaunchKernelGGL(k_gate_open, dim3(1), dim3(64), 0, c->stream, c->d_gate, c->gateSeq);
   return LSDHIP_OK;
@@ -899,6 +899,10 @@ extern "C" int lsdhip_ctx_flag_set(lsdhip_ctx* c, int* flag_dev, int value) {
   if (!c->d_flagArrive) {
     HIPCHK(hipMalloc((void**)&c->d_flagArrive, 64));
     HIPCHK(hipMemset(c->d_flagArrive, 0, 64));
+    // the memset runs on the null stream, which the (non-blocking) streams of this library do not wait for: without this the first
+    // k_flag_set could count arrivals on top of whatever the allocation held, never reach its grid size and never raise its flag —
+    // every wait of both processes then times out at value 1 (seen twice on the GPU box, tests/test_bands_gpu.py)
+    HIPCHK(hipStreamSynchronize(nullptr));
   }
   // (sets of one context are stream-ordered, on either of its streams in turn: one arrival counter serves them all)
   hipLaunchKernelGGL(k_flag_set, dim3(LSD_FLAG_WGS), dim3(64), 0, lsd_transport_stream(c), flag_dev, value, c->d_flagArrive);
