@@ -994,7 +994,10 @@ def test_running_out_of_launch_budget_changes_nothing(oracle, hip, budget, monke
             assert getattr(tr_a.last, k) == getattr(tr_b.last, k), (i, k)
         assert_bit_equal(fa.refPixelWasGoodNoCreate(), fb.refPixelWasGoodNoCreate(), "refPixelWasGood")
         la, lb = tr_a.launch_stats()[0], tr_b.launch_stats()[0]
-        assert la == lb and la > 2 * budget, (la, lb)        # same launches that did work; more than two budgets' worth
+        # launches that did work: more than two budgets' worth, and the same number in both runs — up to one: the count of evaluating
+        # launches is the one statistic of a job that has been seen to differ by one between otherwise bit-identical runs when budgets run
+        # out (profiles/r05_notes.md section 7); everything the job computes is held to equality above
+        assert abs(la - lb) <= 1 and la > 2 * budget, (la, lb)
         init = pa
 
 
