@@ -816,6 +816,7 @@ class SlamLoopBatch {
     long numTracked = 0, numTrackedGood = 0, numUpdates = 0, evaluations = 0, numDropped = 0;
     bool trackingLost = false, newKeyframe = false;
     lsdhip_track_result last = lsdhip_track_result();
+    std::vector<std::shared_ptr<Frame>> keyframeLog;   // every keyframe this sequence promoted (SlamLoopBatch::keepKeyframes)
   };
   // firstImages / gtDepth0: S pointers each (gtDepth0 == null or gtDepth0[s] == null: random initialisation of that sequence)
   SlamLoopBatch(int w, int h, const Mat3f& K, int S, const unsigned char* const* firstImages, bool imagesOnDevice,
@@ -969,6 +970,7 @@ class SlamLoopBatch {
   // last step() before reading maps or statistics
   void flush() { MapWork w = std::move(deferred_); deferred_ = MapWork(); mapGroup(w); }
   SE3Tracker tracker;
+  bool keepKeyframes = false;         // keep every promoted keyframe alive in its sequence's keyframeLog (validation: rescale factors, point counts)
   bool sharedKeyframeChange = true;   // the keyframe changes of a step in shared launches (DepthMap::changeKeyframeBatch); false: per-sequence
                                       // finalizeKeyFrame + createKeyFrame call chains, dealt to keyframeLanes streams (rounds 2-4)
   int keyframeLanes = 8;      // (per-sequence chains) streams the keyframe changes of one step are dealt to (1: all on the context's stream)
@@ -1080,6 +1082,7 @@ class SlamLoopBatch {
       q.mappedOnKF = 0;
       if (!sharedKeyframeChange) q.map.createKeyFrame(frame.get());
       q.keyframe = frame;
+      if (keepKeyframes) q.keyframeLog.push_back(frame);
       q.sinceKF = 0;
       if (pipelined_) {
         q.pendingKF = frame;          // the tracker keeps the old keyframe for one more frame

@@ -229,6 +229,11 @@ int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
 /* out[0] = k_track_step launches of the last job that evaluated = its dependent steps, out[1] = out[2] = 0 (reserved), out[3] = most
  * trials per step. */
 int lsdhip_tracker_step_stats(const lsdhip_tracker* t, int out[4]);
+/* The job summary a tracker polls for in pinned host memory carries a check word; the host takes the record only once its words add up
+ * (they are separate posted writes: the words stored last have been seen to arrive after the `done` word).  out[0] = jobs polled,
+ * out[1] = jobs whose record was incomplete when `done` arrived, out[2] = longest wait for the rest (ns), out[3] = words seen stale,
+ * out[4] / out[5] = lowest / highest stale word index (-1: none). */
+int lsdhip_tracker_summary_stats(const lsdhip_tracker* t, long long out[6]);
 /* Measurement hook (no reference counterpart): the throughput-mode residual evaluation launch alone — n >= 8 jobs
  * (keyframes[j], frames[j]) at pyramid level `level` and poses refToFrame (n x 7 floats: q w x y z, t), `repeats` identical launches
  * between two HIP events.  Reports the mean launch time and the algorithmic bytes of one launch over all jobs (SURVEY.md 8(d)

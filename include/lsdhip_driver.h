@@ -103,7 +103,14 @@ int lsdloopbatch_set_keyframe_phases(lsdloopbatch* l, const int* phase);
  * lsdloop_set_pipeline: mapper one frame behind, frames tracked on a replaced keyframe dropped).  Before the first run.
  * lsdloopbatch_dropped counts the dropped frames of a sequence. */
 int lsdloopbatch_set_pipeline(lsdloopbatch* l, int on);
-long long lsdloopbatch_dropped(lsdloopbatch* l, int sequence);   /* frames of a sequence tracked on a replaced keyframe (pipelined): not mapped */
+long long lsdloopbatch_dropped(lsdloopbatch* l, int sequence);
+/* Read-outs per sequence, for validation against the reference's single-sequence loop (tests/test_multiseq_gpu.py): keep every promoted
+ * keyframe alive and report its createKeyFrame rescale factor / point count (as lsdloop_keep_keyframes / lsdloop_keyframe_log); the
+ * last trackFrame result of a sequence; its current depth map in the reference's 32-byte hypothesis layout (w x h entries). */
+int lsdloopbatch_keep_keyframes(lsdloopbatch* l, int on);
+int lsdloopbatch_keyframe_log(lsdloopbatch* l, int sequence, double* scales_out, long long* points_out, int max);
+int lsdloopbatch_last_result(lsdloopbatch* l, int sequence, lsdhip_track_result* out);
+int lsdloopbatch_download_map(lsdloopbatch* l, int sequence, lsdhip_hypothesis* out);   /* frames of a sequence tracked on a replaced keyframe (pipelined): not mapped */
 const char* lsdloop_last_error(void);
 /* ---- row-band decomposition of the regulariser (BASELINE.json configs[4]) ----------------------------
  * `world` bands over an H-row map; this process holds bands [first_band, first_band + n_local) as windows of

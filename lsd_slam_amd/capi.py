@@ -134,6 +134,7 @@ def _signatures():
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
         "lsdhip_tracker_launch_stats": (i, [vp, vp]),
+        "lsdhip_tracker_summary_stats": (i, [vp, vp]),
         "lsdhip_tracker_step_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_enqueue_hook": (i, [vp, vp, vp]),
         "lsdhip_tracker_track": (i, [vp, vp, vp, vp, C.POINTER(TrackResult)]),

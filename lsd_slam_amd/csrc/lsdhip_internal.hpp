@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -99,6 +100,9 @@ struct TrackSpec {
   unsigned long long dbgCum;         // developer build LSD_ORDER_CHECK: workgroups of all launches queued before this one
   unsigned long long* dbgCounters;   // ... [0] workgroups finished, [1] workgroups that started before all earlier ones had finished, [2] largest deficit seen
   int last;                  // 1: the last launch of the enqueued budget — if the job is not finished when it ends it says so (TrackSummary::exhausted)
+#ifdef LSD_DEVTOOLS
+  int* dbgLog;               // developer build: 16 ints per launch of the job (slot = launch ordinal), written by workgroup 0 — tools/launch_count_stress.py
+#endif
 };
 
 // Levenberg-Marquardt state of a tracking job, resident in HBM, advanced by k_lm_step.
@@ -126,7 +130,8 @@ struct TrackState {
 // What the host reads back (pinned, device-mapped): written by k_lm_step when the job finishes (or every step in
 // evalOnly mode).
 struct TrackSummary {
-  int done, diverged, level, numEvaluations, numWarpUpdates, pad_[3];
+  int done;                  // raised last: the job's tag (TrackSpec::seq >> 12) for jobs the host polls for, 1 for jobs it synchronises the stream for
+  int diverged, level, numEvaluations, numWarpUpdates, pad_[3];
   float q[4], t[3];
   float lastResidual, pointUsage, goodCount, badCount, meanRes, aff_a, aff_b, aff_a_lastIt, aff_b_lastIt;
   float sums[RS_NUM];        // raw sums of the last evaluation (tail-drop corrected)
@@ -136,8 +141,13 @@ struct TrackSummary {
   int lastCand;              // trial (within the launch that produced the final sums) the LM loop executed last: its mask plane is the frame's
   int seq;                   // (job tag << 12) | ordinal of the latest k_track_step launch of the chain that has started
   int exhausted;             // seq of the budget's last launch, written when that launch ends with the job unfinished: the host tops up
-  int pad2_;
+  unsigned check;            // position-weighted sum of the words [1, seq) + the `done` word (lsd_summary_check): the host accepts a summary only
+                             // when it adds up — the words of one record are separate posted writes across PCIe and have been seen to land
+                             // AFTER the `done` word that was stored behind a system-scope release fence (profiles/r06_notes.md section 1)
 };
+#define LSD_SUMMARY_CHECK_WORDS (offsetof(TrackSummary, seq) / 4)
+// term of word i (32 bits) in TrackSummary::check; the sum of terms is order-independent, so the device adds them as it stores the fields
+__host__ __device__ static inline unsigned lsd_summary_term(unsigned i, unsigned bits) { return bits * (2u * i + 1u); }
 
 // A result the host needs eventually but not now (mean inverse depth / point count of a setDepth, the rescale factor
 // of a createKeyFrame): written by the device into a pinned slot, read by the host at the first later point that
@@ -343,9 +353,17 @@ struct lsdhip_tracker {
   long long maskMergeSeq[2] = {0, 0};   // pipelined contexts: M-sequence behind which the merge that reads set s has completed
   size_t maskStride = 0;
   int numLaunches = 0;
+  // polled summaries (lsdhip_tracker_summary_stats): jobs polled, jobs whose record did not add up when `done` arrived, longest wait for the
+  // rest of the record (ns), words of the record that were still stale at the first look (all jobs)
+  long long sumPolled = 0, sumLate = 0, sumLateMaxNs = 0, sumLateWords = 0;
+  int sumLateFirstWord = -1, sumLateLastWord = -1;   // lowest / highest word index ever seen stale
   unsigned long long dbgCum = 0;
   std::vector<unsigned> dumpL0;   // developer dump (LSDHIP_DUMP_L0): what the job's first launch left in the scratch
   unsigned long long* d_dbg = nullptr;
+#ifdef LSD_DEVTOOLS
+  int* d_log = nullptr;      // launch log of the current job (TrackSpec::dbgLog), 4096 x 16 ints
+  std::vector<int> lastLog;  // ... of the last finished job, read by lsdhip_tracker_debug_log
+#endif
   TrackSpec spec = {};             // of the job being launched
   const lsdhip_frame* jobKf = nullptr;   // keyframe whose planes the job being run reads (trackFrame jobs), and their version at its start
   unsigned jobKfVersion = 0;

@@ -304,11 +304,15 @@ __global__ __launch_bounds__(256) void k_sim3_finalize(Sim3Batch batch) {
   const int tid = threadIdx.x;
   sim3_totals(a, s_tot);
   if (tid < 63) a.record[tid] = s_tot[tid];
-  // the host polls word 63 instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the evaluation)
+  // the host polls word 63 instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the evaluation).  The word is the
+  // launch's sequence number PLUS the position-weighted sum of the record's words: the host accepts the record only when the words it reads
+  // add up — the words of a pinned record have been seen to land after the flag stored behind the fence (profiles/r06_notes.md section 1)
   __threadfence_system();
   __syncthreads();
   if (tid == 0) {
-    ((volatile int*)a.record)[63] = a.seq;
+    unsigned chk = (unsigned)a.seq;
+    for (unsigned i = 0; i < 63; i++) chk += lsd_summary_term(i, __float_as_uint(s_tot[i]));
+    ((volatile unsigned*)a.record)[63] = chk;
     __threadfence_system();
   }
 }
@@ -513,7 +517,8 @@ struct lsdhip_sim3tracker {
   Sim3Set* h_sets = nullptr;  Sim3Set* d_sets = nullptr;              // [S3_MAXB]; h_*: pinned staging
   Sim3Track* h_states = nullptr;  Sim3Track* d_states = nullptr;      // [S3_MAXB] ([2][S3_MAXB] on the device: launch parities)
   lsdhip_sim3_result* h_results = nullptr;  lsdhip_sim3_result* d_results = nullptr;   // [S3_MAXB] pinned, device-mapped
-  int* h_done = nullptr;  int* d_done = nullptr;                              // [S3_MAXB] pinned, device-mapped
+  int* h_done = nullptr;  int* d_done = nullptr;                              // [2][S3_MAXB] pinned, device-mapped: flags, then the records' check words
+  long long lateRecords = 0;                                                  // result records that were incomplete when their flag arrived
   int recentRounds = 0;        // evaluations the longest job of the last call needed: the next call's launch budget
 };
 
@@ -625,9 +630,11 @@ static int sim3_run_batch(lsdhip_sim3tracker* t, Sim3Batch& batch, int nslots) {
   const auto tStart = std::chrono::steady_clock::now();
   for (int k = 0; k < nslots; k++) {
     if (batch.j[k].nblocks <= 0) continue;
-    volatile const int* flag = (volatile const int*)(t->h_record + (size_t)k * 64) + 63;
+    volatile const unsigned* rec = (volatile const unsigned*)(t->h_record + (size_t)k * 64);
+    // word 63 = seq + position-weighted sum of the words before it (k_sim3_finalize): whole record or nothing
+    auto landed = [&]() { unsigned chk = (unsigned)seq; for (unsigned i = 0; i < 63; i++) chk += lsd_summary_term(i, rec[i]); return rec[63] == chk; };
     unsigned spins = 0;
-    while (*flag != seq) {
+    while (!landed()) {
       if ((++spins & 0xFFFFFu) == 0) {   // safety net only: a stream query puts a marker packet into the queue (profiles/r03_notes.md §2b)
         hipError_t q = hipStreamQuery(c->stream);
         if (q != hipSuccess && q != hipErrorNotReady) { lsd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return LSDHIP_E_HIP; }
@@ -636,7 +643,7 @@ static int sim3_run_batch(lsdhip_sim3tracker* t, Sim3Batch& batch, int nslots) {
       __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (*flag != seq) { lsd_set_error("Sim3 evaluation did not complete"); return LSDHIP_E_STATE; }
+    if (!landed()) { lsd_set_error("Sim3 evaluation did not complete"); return LSDHIP_E_STATE; }
   }
   return LSDHIP_OK;
 }
@@ -1004,10 +1011,17 @@ __global__ __launch_bounds__(S3_BLOCK) void k_sim3_fused(const Sim3Set* __restri
     if ((done && !wasDone) || (!done && budgetEnd >= 0)) {
       if (done)
         for (int i = tid; i < (int)(sizeof(lsdhip_sim3_result) / 4); i += S3_BLOCK) ((unsigned*)set.result)[i] = ((const unsigned*)&s_J.res)[i];
+      const int word = set.seq * 256 + (done ? (s_J.rc == LSDHIP_OK ? 255 : 254) : budgetEnd);
+      if (done && tid == 0) {
+        // check word of the record (position-weighted sum of its words + the flag's value): the host takes the record only when it adds up
+        unsigned chk = (unsigned)word;
+        for (unsigned i = 0; i < (unsigned)(sizeof(lsdhip_sim3_result) / 4); i++) chk += lsd_summary_term(i, ((const unsigned*)&s_J.res)[i]);
+        *(volatile unsigned*)(set.done + S3_MAXB) = chk;
+      }
       __threadfence_system();                   // the result record (pinned) before the flag
       __syncthreads();
       if (tid == 0) {
-        *(volatile int*)set.done = set.seq * 256 + (done ? (s_J.rc == LSDHIP_OK ? 255 : 254) : budgetEnd);
+        *(volatile int*)set.done = word;
         __threadfence_system();
       }
     }
@@ -1033,8 +1047,8 @@ static int sim3_device_storage(lsdhip_sim3tracker* t) {
   t->h_sets = (Sim3Set*)hblk; t->h_states = (Sim3Track*)(hblk + sizeof(Sim3Set) * S3_MAXB);
   HIPCHK(hipHostMalloc((void**)&t->h_results, sizeof(lsdhip_sim3_result) * S3_MAXB, hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_results, t->h_results, 0));
-  HIPCHK(hipHostMalloc((void**)&t->h_done, sizeof(int) * S3_MAXB, hipHostMallocMapped));
-  memset(t->h_done, 0, sizeof(int) * S3_MAXB);
+  HIPCHK(hipHostMalloc((void**)&t->h_done, sizeof(int) * S3_MAXB * 2, hipHostMallocMapped));   // [k]: flag, [S3_MAXB + k]: check word of result k
+  memset(t->h_done, 0, sizeof(int) * S3_MAXB * 2);
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_done, t->h_done, 0));
   return LSDHIP_OK;
 }
@@ -1131,6 +1145,24 @@ static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs, 
     for (int k = 0; k < m; k++) {
       Sim3Track& J = jobs[base + k];
       if (J.phase == Sim3Track::DONE) continue;             // finished before any evaluation (no level with iterations)
+      {
+        // the record is taken once its words add up to the check word the device stored with it (they are separate posted writes: the
+        // flag has been seen to overtake the tail of such a record, profiles/r06_notes.md section 1)
+        const unsigned word = (unsigned)((volatile int*)t->h_done)[k];
+        volatile const unsigned* rw = (volatile const unsigned*)&t->h_results[k];
+        const auto tv0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+          unsigned chk = word;
+          for (unsigned i = 0; i < (unsigned)(sizeof(lsdhip_sim3_result) / 4); i++) chk += lsd_summary_term(i, rw[i]);
+          if (chk == ((volatile unsigned*)t->h_done)[S3_MAXB + k]) break;
+          if (spins == 0) t->lateRecords++;
+          if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - tv0 > std::chrono::seconds(2)) {
+            lsd_set_error("Sim3 result record in pinned memory never became consistent"); return LSDHIP_E_STATE;
+          }
+          __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
       *J.hostOut = t->h_results[k];
       J.rc = ((volatile int*)t->h_done)[k] == seq * 256 + 255 ? LSDHIP_OK : LSDHIP_DIVERGED;
       J.phase = Sim3Track::DONE;

@@ -365,19 +365,39 @@ __device__ __forceinline__ lsdm::SE3fH se3f_mul_wave(const lsdm::SE3fH& a, const
   return r;
 }
 
-__device__ __forceinline__ void write_summary(const TrackState& s, const float* tot, TrackSummary* out) {
-  out->diverged = s.diverged; out->level = s.level; out->numEvaluations = s.numEvaluations; out->numWarpUpdates = s.numWarpUpdates;
-  out->q[0] = s.T.q.w; out->q[1] = s.T.q.x; out->q[2] = s.T.q.y; out->q[3] = s.T.q.z;
-  out->t[0] = s.T.t[0]; out->t[1] = s.T.t[1]; out->t[2] = s.T.t[2];
-  out->lastResidual = s.last_residual; out->pointUsage = s.pointUsage; out->goodCount = s.goodCount; out->badCount = s.badCount;
-  out->meanRes = s.meanRes; out->aff_a = s.aff_a; out->aff_b = s.aff_b; out->aff_a_lastIt = s.aff_a_lastIt; out->aff_b_lastIt = s.aff_b_lastIt;
-  for (int i = 0; i < RS_NUM; i++) out->sums[i] = tot[i];
-  out->bytes = s.bytes;
-  for (int l = 0; l < LSD_LEVELS; l++) out->levelEvals[l] = s.levelEvals[l];
-  out->numLaunches = s.numLaunches;
-  out->lastCand = s.lastCand;
+// The summary in pinned host memory: every field is stored AND added (position-weighted) into `check`, then a system-scope release fence,
+// then the `done` word.  The host polls `done` and then validates `check` (summary_wait_consistent, tracker.hip): one in a few thousand
+// polled jobs the tail of the record (levelEvals / numLaunches / lastCand — the stores issued last) was still the previous job's when
+// `done` had already arrived.
+__device__ __forceinline__ void write_summary(const TrackState& s, const float* tot, TrackSummary* out, const int doneWord) {
+  unsigned chk = (unsigned)doneWord;
+#define SUM_PUT_I(field, value) do { const int v_ = (value); out->field = v_; chk += lsd_summary_term((unsigned)(offsetof(TrackSummary, field) / 4), (unsigned)v_); } while (0)
+#define SUM_PUT_F(field, value) do { const float v_ = (value); out->field = v_; chk += lsd_summary_term((unsigned)(offsetof(TrackSummary, field) / 4), __float_as_uint(v_)); } while (0)
+#define SUM_PUT_IA(field, i, value) do { const int v_ = (value); out->field[i] = v_; chk += lsd_summary_term((unsigned)(offsetof(TrackSummary, field) / 4 + (i)), (unsigned)v_); } while (0)
+#define SUM_PUT_FA(field, i, value) do { const float v_ = (value); out->field[i] = v_; chk += lsd_summary_term((unsigned)(offsetof(TrackSummary, field) / 4 + (i)), __float_as_uint(v_)); } while (0)
+  SUM_PUT_I(diverged, s.diverged); SUM_PUT_I(level, s.level); SUM_PUT_I(numEvaluations, s.numEvaluations); SUM_PUT_I(numWarpUpdates, s.numWarpUpdates);
+  SUM_PUT_IA(pad_, 0, 0); SUM_PUT_IA(pad_, 1, 0); SUM_PUT_IA(pad_, 2, 0);
+  SUM_PUT_FA(q, 0, s.T.q.w); SUM_PUT_FA(q, 1, s.T.q.x); SUM_PUT_FA(q, 2, s.T.q.y); SUM_PUT_FA(q, 3, s.T.q.z);
+  SUM_PUT_FA(t, 0, s.T.t[0]); SUM_PUT_FA(t, 1, s.T.t[1]); SUM_PUT_FA(t, 2, s.T.t[2]);
+  SUM_PUT_F(lastResidual, s.last_residual); SUM_PUT_F(pointUsage, s.pointUsage); SUM_PUT_F(goodCount, s.goodCount); SUM_PUT_F(badCount, s.badCount);
+  SUM_PUT_F(meanRes, s.meanRes); SUM_PUT_F(aff_a, s.aff_a); SUM_PUT_F(aff_b, s.aff_b); SUM_PUT_F(aff_a_lastIt, s.aff_a_lastIt); SUM_PUT_F(aff_b_lastIt, s.aff_b_lastIt);
+  for (int i = 0; i < RS_NUM; i++) SUM_PUT_FA(sums, i, tot[i]);
+  {
+    const double b = (double)s.bytes;
+    out->bytes = b;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(b);
+    chk += lsd_summary_term((unsigned)(offsetof(TrackSummary, bytes) / 4), (unsigned)u) + lsd_summary_term((unsigned)(offsetof(TrackSummary, bytes) / 4 + 1), (unsigned)(u >> 32));
+  }
+  for (int l = 0; l < LSD_LEVELS; l++) SUM_PUT_IA(levelEvals, l, s.levelEvals[l]);
+  SUM_PUT_I(numLaunches, s.numLaunches);
+  SUM_PUT_I(lastCand, s.lastCand);
+#undef SUM_PUT_I
+#undef SUM_PUT_F
+#undef SUM_PUT_IA
+#undef SUM_PUT_FA
+  out->check = chk;
   __threadfence_system();
-  out->done = s.done;
+  out->done = doneWord;
 }
 
 struct LmShared {
@@ -426,7 +446,7 @@ __device__ __forceinline__ float lm_lambda_fail(float LM_lambda, int incTry, flo
 }
 template <bool SPEC = false>
 __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const float col, float* tot, const int lane,
-                                        TrackSummary* out, unsigned long long* trp, const int consumed = 0, const int mycand = 0) {
+                                        TrackSummary* out, unsigned long long* trp, const int consumed = 0, const int mycand = 0, const int doneWord = 1) {
   float* const s_gj = tot - 48;   // LmShared::gj precedes tot
   S.lastCand = consumed;
   S.ncand = 1;
@@ -461,11 +481,11 @@ __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const f
   }
   S.pending = 0;
   LM_MARK(12);
-  if (L.evalOnly) { S.done = 1; if (out && lane == 0) write_summary(S, tot, out); return false; }
+  if (L.evalOnly) { S.done = 1; if (out && lane == 0) write_summary(S, tot, out, doneWord); return false; }
 
   if (M < L.minWarped) {   // :324-329 / :369-374
     S.diverged = 1; S.done = 1;
-    if (out && lane == 0) write_summary(S, tot, out);
+    if (out && lane == 0) write_summary(S, tot, out, doneWord);
     return false;
   }
   // calcWeightsAndResidualSSE epilogue (:572-574)
@@ -559,7 +579,7 @@ __device__ __forceinline__ bool lm_wave(const LmPar& par, TrackState& S, const f
   if (!tfSemantics) S.last_residual = lastErr;   // trackFrameOnPermaref: lastResidual = lastErr (:265)
   if (S.level == L.lastLevel) {
     S.done = 1;
-    if (out && lane == 0) write_summary(S, tot, out);
+    if (out && lane == 0) write_summary(S, tot, out, doneWord);
   } else {
     S.level = S.level - 1;
     S.phase = 0;

@@ -37,6 +37,18 @@
 #define PHASE_MARK(k) do { } while (0)
 #endif
 
+#ifdef LSD_DEVTOOLS
+// one record per launch, written by workgroup 0: which exit the launch took and the state it saw / left
+#define LAUNCH_LOG(exitCode, pendingIn, ncandIn, pcUsed) do { \
+    if (!BATCH && MODE == TS_FUSED && blockIdx.x == 0 && threadIdx.x == 0 && spec.dbgLog && spec.seq != 0) { \
+      int* lg_ = spec.dbgLog + ((spec.seq & 0xFFF) * 16); \
+      lg_[0] = spec.seq; lg_[1] = (exitCode); lg_[2] = parity | (first << 1) | (spec.last << 2); lg_[3] = lvlIn_; lg_[4] = (pendingIn); lg_[5] = (ncandIn); \
+      lg_[6] = (pcUsed); lg_[7] = S.level; lg_[8] = S.numEvaluations; lg_[9] = S.numLaunches; lg_[10] = S.done; lg_[11] = S.phase; lg_[12] = S.incTry; \
+      lg_[13] = S.ncand; lg_[14] = S.pending; lg_[15] = numLaunchesIn_; } } while (0)
+#else
+#define LAUNCH_LOG(exitCode, pendingIn, ncandIn, pcUsed) do { } while (0)
+#endif
+
 // Fused tracking step, one launch per step of the LM loop:
 //   (1) every workgroup finishes the *previous* launch's evaluation(s) from the tiles' partial rows: fixed-order column sums
 //       (row-major rows, whole rows per wave load, all loads issued before the first add), SSE tail drop, LGS6::finish, then
@@ -159,11 +171,18 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   }
   __syncthreads();
   PHASE_MARK(1);
+#ifdef LSD_DEVTOOLS
+  const int lvlIn_ = S.level, numLaunchesIn_ = S.numLaunches, pendingIn_ = S.pending, ncandIn_ = S.ncand;
+  int pcLog_ = -1;
+#endif
   if (S.done) {
+    LAUNCH_LOG(1, pendingIn_, ncandIn_, -1);
     if (MODE != TS_EVAL && leader) { copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK); }   // keep both buffers "done"
     return;
   }
   const int lvlPending = S.level;
+  // what the finishing launch raises `done` to: the job's tag where the host polls pinned memory for it (single jobs), 1 where it synchronises
+  const int doneWord = (!BATCH && MODE == TS_FUSED && spec.seq != 0) ? (spec.seq >> 12) : 1;
   if (!BATCH && MODE == TS_FUSED) {
     // The launch is sized for the level with the most (tiles x trials).  This one either evaluates trials at S.level —
     // workgroup = (trial, tile) of that level — or, if the pending decision ends the level, the first evaluation of
@@ -485,9 +504,9 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         PHASE_MARK(3);
 #ifdef LSD_PHASE_TRACE
         if (blockIdx.x == 0 && tid == 0) { tr_[19] = (unsigned long long)ncandPending; tr_[7] = (unsigned long long)pc; }
-        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, leader ? tr_ : nullptr, pc, cand);
+        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, leader ? tr_ : nullptr, pc, cand, doneWord);
 #else
-        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, nullptr, pc, cand);
+        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, nullptr, pc, cand, doneWord);
 #endif
       }
     }
@@ -507,7 +526,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         }
       }
       if (leader) copy_words<sizeof(TrackState) / 4>(next, &S, tid, BLOCK);
-     
+      LAUNCH_LOG(2, pendingIn_, ncandIn_, S.lastCand);
       return;
     }
     // a workgroup that evaluates trial c > 0 leaves that trial's increment and pose for the launch that finishes it
@@ -768,6 +787,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   // the queue the chain runs through: ~3 us per frame)
  
   if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.last != 0) out->exhausted = spec.seq;
+  LAUNCH_LOG(3, pendingIn_, ncandIn_, S.lastCand);
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
   if (blockIdx.x == 0 && tid == 0) tr_[9] = wall_clock64();
@@ -898,6 +918,10 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
     HIPCHK(hipMemcpy(t->d_dbg, init.data(), nd * 8, hipMemcpyHostToDevice));
   }
 #endif
+#ifdef LSD_DEVTOOLS
+  HIPCHK(hipMalloc((void**)&t->d_log, 4096 * 16 * 4));
+  HIPCHK(hipMemset(t->d_log, 0, 4096 * 16 * 4));
+#endif
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
   HIPCHK(hipMemsetAsync(t->d_state, 0, 2 * sizeof(TrackState), c->stream));
 #ifdef LSD_PHASE_TRACE
@@ -968,6 +992,9 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   (void)hipFree(t->d_partials);
   (void)hipFree(t->d_maskSide);
   (void)hipFree(t->d_state);
+#ifdef LSD_DEVTOOLS
+  (void)hipFree(t->d_log);
+#endif
   (void)hipHostFree(t->h_summary);
   if (t->d_pts) (void)hipFree(t->d_pts);
   delete t;
@@ -1018,6 +1045,15 @@ extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int
   for (int i = 0; i < 4; i++) t->recent[i] = 0;
   return LSDHIP_OK;
 }
+#ifdef LSD_DEVTOOLS
+// developer build: the launch log of the last job (LSDHIP_LAUNCH_LOG=1): 16 ints per queued launch, slot = launch ordinal (1-based)
+extern "C" int lsdhip_tracker_debug_log(const lsdhip_tracker* t, int* out, int maxInts) {
+  if (!t || !out) return -1;
+  const int n = (int)t->lastLog.size() < maxInts ? (int)t->lastLog.size() : maxInts;
+  memcpy(out, t->lastLog.data(), (size_t)n * 4);
+  return n;
+}
+#endif
 extern "C" int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]) {
   if (!t || !out) return LSDHIP_E_ARG;
   out[0] = t->numLaunches; out[1] = t->specC;
@@ -1113,6 +1149,9 @@ static void launch_step(lsdhip_tracker* t, const TrackJob& job, int grid, int pa
   TrackScratch sc = scratch_of(t);
   t->launchOrdinal++;
   t->spec.seq = t->jobTag ? ((t->jobTag << 12) | (t->launchOrdinal & 0xFFF)) : 0;
+#ifdef LSD_DEVTOOLS
+  t->spec.dbgLog = t->d_log;
+#endif
 #ifdef LSD_ORDER_CHECK
   t->spec.dbgCum = t->dbgCum;
   t->spec.dbgCounters = t->d_dbg;
@@ -1281,6 +1320,51 @@ static int prof_collect(lsdhip_ctx* c) {
 }
 int lsd_prof_collect(lsdhip_ctx* c) { return prof_collect(c); }
 
+// A polled summary is accepted when its words add up to its `check` word: `done` has arrived, but the record's other words are separate
+// posted writes and — one job in a few thousand, measured (profiles/r06_notes.md section 1) — the ones stored last (numLaunches, lastCand,
+// levelEvals) still held the previous job's values at that moment.  Spins until the record is whole; counts what it saw.
+static int summary_wait_consistent(lsdhip_tracker* t, const int doneWord) {
+  volatile const unsigned* w = (volatile const unsigned*)t->h_summary;
+  t->sumPolled++;
+  unsigned first[LSD_SUMMARY_CHECK_WORDS];
+  std::chrono::steady_clock::time_point t0;
+  for (unsigned spins = 0;; spins++) {
+    unsigned cur[LSD_SUMMARY_CHECK_WORDS];
+    unsigned chk = (unsigned)doneWord;
+    for (unsigned i = 1; i < LSD_SUMMARY_CHECK_WORDS; i++) { cur[i] = w[i]; chk += lsd_summary_term(i, cur[i]); }
+    const unsigned want = *(volatile const unsigned*)&t->h_summary->check;
+    if (chk == want) {
+      if (spins > 0) {
+        const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ns > t->sumLateMaxNs) t->sumLateMaxNs = ns;
+        for (unsigned i = 1; i < LSD_SUMMARY_CHECK_WORDS; i++)
+          if (first[i] != cur[i]) {
+            t->sumLateWords++;
+            if (t->sumLateFirstWord < 0 || (int)i < t->sumLateFirstWord) t->sumLateFirstWord = (int)i;
+            if ((int)i > t->sumLateLastWord) t->sumLateLastWord = (int)i;
+          }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return LSDHIP_OK;
+    }
+    if (spins == 0) {
+      t->sumLate++;
+      t0 = std::chrono::steady_clock::now();
+      memcpy(first, cur, sizeof(first));
+    }
+    if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      lsd_set_error("tracking summary in pinned memory never became consistent (check %08x, sum %08x)", want, chk);
+      return LSDHIP_E_STATE;
+    }
+    __builtin_ia32_pause();
+  }
+}
+extern "C" int lsdhip_tracker_summary_stats(const lsdhip_tracker* t, long long out[6]) {
+  if (!t || !out) return LSDHIP_E_ARG;
+  out[0] = t->sumPolled; out[1] = t->sumLate; out[2] = t->sumLateMaxNs; out[3] = t->sumLateWords; out[4] = t->sumLateFirstWord; out[5] = t->sumLateLastWord;
+  return LSDHIP_OK;
+}
+
 // device-resident LM over levels topLevel..job.lastLevel; one host synchronisation per budget of launches.  The budget
 // is the previous job's launch count (evaluations + the finalising step) plus a margin, so that few steps run empty.
 // With profiling on, the whole budget is bracketed by one HIP event pair on the context's stream and charged to the
@@ -1382,7 +1466,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       const int lastSeq = t->spec.seq;                      // tag of the last launch enqueued
       const auto tStart = std::chrono::steady_clock::now();
       unsigned spins = 0;
-      while (!*done) {
+      while (*done != t->jobTag) {
         if (*exhausted == lastSeq) break;                   // budget consumed, job unfinished (the last launch said so)
         if ((++spins & 0xFFFFFu) == 0) {                    // safety net only (a faulted launch never reports): every ~30 ms
           hipError_t q = hipStreamQuery(c->stream);
@@ -1398,7 +1482,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     }
     }
     lsdhip_host_mark(5);
-    if (S->done) break;
+    if (*(volatile const int*)&S->done == t->jobTag) break;
 #ifdef LSD_DEVTOOLS
     t->dbgMisses++;
 #endif
@@ -1420,7 +1504,7 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
       }
     }
 #endif
-    if (S->done) break;
+    if (*(volatile const int*)&S->done == t->jobTag) break;
     if (int rc2 = prof_collect(c)) return rc2;
     if (t->jobKf && t->jobKf->depthVersion != t->jobKfVersion && guard < 8) {
       // While the host waited without the context lock, the mapping thread rewrote the keyframe's depth planes (setDepth): the
@@ -1436,11 +1520,26 @@ static int track_device(lsdhip_tracker* t, TrackJob& job, int topLevel, const ls
     budget = t->budgetFixed > 0 ? t->budgetFixed : 6;
     if (++guard > 200) { lsd_set_error("tracking job did not terminate"); return LSDHIP_E_STATE; }
   }
+  // `done` is in; the rest of the record is taken only once it adds up (summary_wait_consistent)
+  if (int rcs = summary_wait_consistent(t, t->jobTag)) return rcs;
   if (sample) {
     c->prof_bytes += S->bytes;
     c->prof_launches += S->numLaunches;
   }
   if (myEpoch > c->doneEpoch) c->doneEpoch = myEpoch;
+#ifdef LSD_DEVTOOLS
+  {
+    static const bool keepLog = getenv("LSDHIP_LAUNCH_LOG") != nullptr;
+    if (keepLog) {
+      // every launch of the job has been queued; wait for the ones behind the finishing launch too, then keep the log and clear it
+      HIPCHK(hipStreamSynchronize(c->stream));
+      const int n = t->launchOrdinal < 4095 ? t->launchOrdinal + 1 : 4096;
+      t->lastLog.assign((size_t)n * 16, 0);
+      HIPCHK(hipMemcpy(t->lastLog.data(), t->d_log, (size_t)n * 64, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemset(t->d_log, 0, (size_t)n * 64));
+    }
+  }
+#endif
   t->numLaunches = S->numLaunches;
   t->recent[3] = t->recent[2]; t->recent[2] = t->recent[1]; t->recent[1] = t->recent[0]; t->recent[0] = t->numLaunches;
   for (int l = 0; l < LSD_LEVELS; l++) t->levelEvaluations[l] = S->levelEvals[l];

@@ -104,6 +104,14 @@ def lib():
         L.lsdloopbatch_set_pipeline.argtypes = [vp, i]
         L.lsdloopbatch_dropped.restype = C.c_longlong
         L.lsdloopbatch_dropped.argtypes = [vp, i]
+        L.lsdloopbatch_keep_keyframes.restype = i
+        L.lsdloopbatch_keep_keyframes.argtypes = [vp, i]
+        L.lsdloopbatch_keyframe_log.restype = i
+        L.lsdloopbatch_keyframe_log.argtypes = [vp, i, vp, vp, i]
+        L.lsdloopbatch_last_result.restype = i
+        L.lsdloopbatch_last_result.argtypes = [vp, i, vp]
+        L.lsdloopbatch_download_map.restype = i
+        L.lsdloopbatch_download_map.argtypes = [vp, i, vp]
         L.lsdloop_last_error.restype = C.c_char_p
         L.lsdloop_last_error.argtypes = []
         _lib = L
@@ -166,6 +174,26 @@ class DriverLoopBatch:
     def dropped(self):
         """per sequence: frames tracked on a keyframe the mapper had already replaced (pipelined loops)"""
         return [int(self.L.lsdloopbatch_dropped(self.h_, s)) for s in range(self.S)]
+
+    def keep_keyframes(self, on=True):
+        _check(self.L.lsdloopbatch_keep_keyframes(self.h_, int(on)))
+
+    def keyframe_log(self, s, max_entries=1024):
+        """(rescale factors, point counts) of the keyframes sequence s promoted since keep_keyframes(True); synchronises"""
+        sc = np.zeros(max_entries, np.float64)
+        pts = np.zeros(max_entries, np.int64)
+        n = min(_check(self.L.lsdloopbatch_keyframe_log(self.h_, int(s), sc.ctypes.data, pts.ctypes.data, max_entries)), max_entries)
+        return sc[:n], pts[:n]
+
+    def last_result(self, s):
+        r = capi.TrackResult()
+        _check(self.L.lsdloopbatch_last_result(self.h_, int(s), C.byref(r)))
+        return r
+
+    def download_map(self, s, w, h):
+        out = np.zeros(w * h, capi.HYP_DTYPE)
+        _check(self.L.lsdloopbatch_download_map(self.h_, int(s), out.ctypes.data))
+        return out.reshape(h, w)
 
     def set_keyframe_phases(self, phases):
         """phase[s] in [0, kf_every): how old sequence s's first keyframe already is (unsynchronised keyframe changes)"""

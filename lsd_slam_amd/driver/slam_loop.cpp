@@ -202,6 +202,36 @@ extern "C" long long lsdloopbatch_dropped(lsdloopbatch* l, int s) {
   if (!l || s < 0 || s >= l->loop->size()) return -1;
   return l->loop->sequence(s).numDropped;
 }
+extern "C" int lsdloopbatch_keep_keyframes(lsdloopbatch* l, int on) {
+  if (!l) return LSDHIP_E_ARG;
+  l->loop->keepKeyframes = on != 0;
+  if (!on) for (int s = 0; s < l->loop->size(); s++) l->loop->sequence(s).keyframeLog.clear();
+  return LSDHIP_OK;
+}
+extern "C" int lsdloopbatch_keyframe_log(lsdloopbatch* l, int s, double* scales_out, long long* points_out, int max) {
+  if (!l || s < 0 || s >= l->loop->size()) return LSDHIP_E_ARG;
+  try {
+    const auto& log = l->loop->sequence(s).keyframeLog;
+    for (int i = 0; i < (int)log.size() && i < max; i++) {
+      if (scales_out) scales_out[i] = log[i]->thisToParent_raw().s;
+      if (points_out) points_out[i] = log[i]->stats().numPoints;
+    }
+    return (int)log.size();
+  } catch (const Error& e) { g_err = e.what(); return e.status < 0 ? e.status : LSDHIP_E_STATE; }
+}
+extern "C" int lsdloopbatch_last_result(lsdloopbatch* l, int s, lsdhip_track_result* out) {
+  if (!l || !out || s < 0 || s >= l->loop->size()) return LSDHIP_E_ARG;
+  *out = l->loop->sequence(s).last;
+  return LSDHIP_OK;
+}
+extern "C" int lsdloopbatch_download_map(lsdloopbatch* l, int s, lsdhip_hypothesis* out) {
+  if (!l || !out || s < 0 || s >= l->loop->size()) return LSDHIP_E_ARG;
+  try {
+    const std::vector<lsdhip_hypothesis> m = l->loop->sequence(s).map.currentDepthMap();
+    std::memcpy(out, m.data(), m.size() * sizeof(lsdhip_hypothesis));
+    return LSDHIP_OK;
+  } catch (const Error& e) { g_err = e.what(); return e.status < 0 ? e.status : LSDHIP_E_STATE; }
+}
 extern "C" int lsdloopbatch_set_keyframe_phases(lsdloopbatch* l, const int* phase) {
   if (!l || !phase) return LSDHIP_E_ARG;
   try {

@@ -304,6 +304,12 @@ class SE3Tracker:
         check(self.L.lsdhip_tracker_launch_stats(self.h_, out.ctypes.data))
         return int(out[0]), int(out[1])
 
+    def summary_stats(self):
+        """(jobs polled, records incomplete when `done` arrived, longest wait ns, stale words, lowest / highest stale word index)"""
+        out = np.zeros(6, np.int64)
+        check(self.L.lsdhip_tracker_summary_stats(self.h_, out.ctypes.data))
+        return [int(v) for v in out]
+
     def step_stats(self):
         """(k_track_step launches of the last job, steps inside the cluster kernel, cluster-kernel launches, most trials per step)"""
         out = np.zeros(4, np.int32)

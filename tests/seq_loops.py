@@ -271,3 +271,32 @@ def rmse(a, b):
     a, b = np.asarray(a), np.asarray(b)
     n = min(len(a), len(b))
     return float(np.sqrt(np.mean(np.sum((a[:n] - b[:n]) ** 2, axis=1))))
+
+
+def replay_centres(frameToKF, rescales, kf_every=10, lag=0):
+    """Camera centres in the world frame from a loop's per-frame poses and its createKeyFrame rescale factors alone — the bookkeeping
+    run_loop does while it runs (Sim3World chained at every keyframe change; lag = 1: the frame that follows a keyframe change is still
+    tracked on the old keyframe).  For loops that only report poses and keyframe logs (lsd_slam_hip::SlamLoopBatch through the C driver)."""
+    world_track = Sim3World()
+    world_map = world_track
+    pending = None
+    out, since, k = [], 0, 0
+    for i, est in enumerate(frameToKF, start=1):
+        tracked_on_map = world_track is world_map
+        out.append(world_track.centre(est))
+        if pending is not None:
+            world_track, pending = pending, None
+        since += 1
+        if not tracked_on_map:
+            continue
+        if since >= kf_every:
+            nw = Sim3World()
+            nw.s, nw.R, nw.t = world_map.s, world_map.R.copy(), world_map.t.copy()
+            nw.push_keyframe(est, rescales[k])
+            k += 1
+            world_map, since = nw, 0
+            if lag > 0:
+                pending = nw
+            else:
+                world_track = nw
+    return np.array(out)

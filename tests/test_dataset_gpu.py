@@ -102,9 +102,9 @@ def test_cpp_loop_rccl_gather_single_rank():
 def test_cpp_loop_is_deterministic_run_to_run(pipelined):
     """The C++ track + map loop (asynchronous mapping behind tracking, next frame's pyramids queued by the enqueue hook, launch budgets
     from the recent jobs, top-ups) gives the same poses and evaluation counts, bit for bit, in every run: no result depends on
-    timing.  (The number of evaluating launches is a scheduling statistic: about one run in ten counts one launch more or less on one
-    frame of the 150 with every pose and evaluation count identical — also with the round-4 library, tools/determinism_chunks.py,
-    profiles/r05_notes.md — so it is held to 1 % here, not to equality.)  (An experiment that built the next frame's pyramids on a second stream with a pinned-memory flag instead of an event
+    timing.  The number of evaluating launches is held to equality as well (round 5 allowed 1 %: the count itself never differed — the
+    host read the previous job's `numLaunches` when the tail of the pinned summary landed after its `done` word; the record now carries a
+    check word, profiles/r06_notes.md section 1).  (An experiment that built the next frame's pyramids on a second stream with a pinned-memory flag instead of an event
     failed exactly this check once in five runs — profiles/r03_notes.md — and was dropped.)
     pipelined: tracking stream beside mapping stream with the mapper one frame behind (lsdloop_set_pipeline) — the hand-overs between
     the two streams are events, and the one-frame lag is part of the loop's definition, not of its timing."""
@@ -127,8 +127,7 @@ def test_cpp_loop_is_deterministic_run_to_run(pipelined):
         if base is None:
             base = sig
         else:
-            assert sig[2:] == base[2:], (rep, sig[1:], base[1:])
-            assert abs(sig[1] - base[1]) <= 0.01 * base[1], (rep, sig[1:], base[1:])
+            assert sig[1:] == base[1:], (rep, sig[1:], base[1:])
             assert sig[0] == base[0], "run %d: poses differ from run 0" % rep
 
 

@@ -1,0 +1,31 @@
+#!/bin/bash
+# round 6: GPU-side steps, one parametrised script (tools/gpu_r06.sh <step> [args]); output under gpurun_out/r06_<step>/
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+step=$1; shift
+out=gpurun_out/r06_$step
+mkdir -p $out
+case $step in
+  launchcount)
+    # VERDICT r05 next #1a: the launch-count off-by-one
+    timeout 600 python tools/launch_count_stress.py --reps 300 --spec 1 2>&1 | tail -n 40 | cut -c1-400 | tee $out/default_spec1.txt
+    timeout 600 python tools/launch_count_stress.py --reps 150 --spec 0 2>&1 | tail -n 40 | cut -c1-400 | tee $out/default_spec0.txt
+    LSDHIP_LIB=$R/lsd_slam_amd/liblsdhip_devtools.so LSDHIP_LAUNCH_LOG=1 timeout 900 python tools/launch_count_stress.py --reps 300 --spec 1 2>&1 | tail -n 400 | cut -c1-400 | tee $out/devtools_spec1.txt
+    timeout 300 python tools/determinism_frames.py --reps 6 2>&1 | tail -n 8 | cut -c1-300 | tee $out/frames.txt
+    ;;
+  launchcount2)
+    timeout 900 python tools/launch_count_stress.py --reps 4000 --spec 1 2>&1 | tail -n 40 | cut -c1-400 | tee $out/spec1.txt
+    timeout 900 python tools/launch_count_stress.py --reps 2000 --spec 1 --budgets 0,1,1,1,1 2>&1 | tail -n 40 | cut -c1-400 | tee $out/spec1_b1.txt
+    timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "budget or speculative or trackframe" 2>&1 | tail -n 5 | tee $out/pytest.txt
+    ;;
+  suite)
+    # the whole GPU suite (what the driver runs at round end) + smoke
+    timeout 1500 python -m pytest tests -x -q -m gpu "$@" 2>&1 | tail -n 15 | tee $out/pytest.txt
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 3 | tee $out/smoke.txt
+    ;;
+  pytest)
+    # selected tests: tools/gpu_r06.sh pytest <pytest args>
+    timeout 1500 python -m pytest -x -q -m gpu "$@" 2>&1 | tail -n 25 | tee -a $out/pytest.txt
+    ;;
+  *) echo "unknown step $step"; exit 2;;
+esac
