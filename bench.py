@@ -423,65 +423,76 @@ def bands_distributed(torch, dist, rank, world, local_rank, passes=20):
     return rec if rank == 0 else None
 
 
-def multi_seq(torch, w, h, K, d_frames, depth0, device, single_value, sizes=(8, 32), steps=30, warmup=10, regions=3):
+def multi_seq(torch, w, h, K, seeds, device, single_value, sizes=(8, 32, 64, 128), steps=30, warmup=10, regions=3):
     """BASELINE.json configs[3] with more sequences than GPUs: S independent sequences share this GPU (lsd_slam_hip::SlamLoopBatch — frame
-    creation, tracking jobs and updateKeyframe calls of all sequences in shared launches, keyframe changes as per-sequence call chains on
-    side streams).  Two execution models per S, as for the single sequence: pipelined (`frames_s`: the tracking batch of step t + 1
-    beside the mapping work of step t, per sequence the mapper one frame behind) and blockUntilMapped (`frames_s_block_until_mapped`).
-    The sequences are four camera motions over the bench scene (the closed camera loop forwards / backwards at one and two frames per
-    step, all starting on frame 0 with its ground-truth depth), each replicated S / 4 times with its own frames, keyframes and maps.
-    Replicas must come out bit-identical (same inputs through different z-slices of the same launches): checked here."""
+    creation, tracking jobs, updateKeyframe calls and keyframe changes of all sequences in shared launches).  Two execution models per S,
+    as for the single sequence: pipelined (`frames_s`: the tracking batch of step t + 1 beside the mapping work of step t, per sequence
+    the mapper one frame behind) and blockUntilMapped (`frames_s_block_until_mapped`).
+    `seeds`: 8 (device frames, ground-truth depth of frame 0) pairs — scene S1 rendered with the 8 seeds of SURVEY.md section 8(d)
+    ("Config 4 uses 8 sequence indices").  Sequence s plays seed s % 8 with camera motion (s // 8) % 4 (the closed camera loop forwards /
+    backwards at one and two frames per step); S = 8 is exactly the 8 seeds of configs[3], the configuration
+    tests/test_multiseq_gpu.py::test_batch_loop_8_seeds_640x480_against_the_oracle holds against the oracle sequence by sequence.  From
+    S = 64 on every (seed, motion) pair exists more than once: such replicas must come out bit-identical (same inputs through different
+    slices of the same launches) — checked here.  S = 64 / 128 say where frames/s saturates."""
     from lsd_slam_amd.driver import DriverLoopBatch
     from lsd_slam_amd import capi
-    n = d_frames.shape[0]
+    n = seeds[0][0].shape[0]
+    NS = len(seeds)
     motions = [(1, 1), (-1, 1), (1, 2), (-1, 2)]
-    out = {"workload": "S sequences x 640x480 track+map loop on one GPU (BASELINE.json configs[3], sequences > GPUs), 4 camera motions x S/4 replicas, "
-                       "new keyframe every %d frames (phases 0 / 2 / 5 / 7 by camera motion), %d timed steps (= frames per sequence)" % (KF_EVERY, steps)}
+    out = {"workload": "S sequences x 640x480 track+map loop on one GPU (BASELINE.json configs[3], sequences > GPUs): scene S1 with %d seeds x 4 camera "
+                       "motions (sequence s: seed s %% %d, motion (s // %d) %% 4; S = 8: the 8 seeds, camera forwards), new keyframe every %d frames (phases 0 / 2 / 5 / 7 "
+                       "by s %% 4), %d timed steps (= frames per sequence)" % (NS, NS, NS, KF_EVERY, steps)}
     L = capi.lib()
     for S in sizes:
-        idx = lambda s, t: (motions[s % 4][0] * motions[s % 4][1] * t) % n
-        ptrs = lambda t: [d_frames[idx(s, t)].data_ptr() for s in range(S)]
+        mo = lambda s: motions[(s // NS) % 4]
+        idx = lambda s, t: (mo(s)[0] * mo(s)[1] * t) % n
+        ptrs = lambda t: [seeds[s % NS][0][idx(s, t)].data_ptr() for s in range(S)]
         rec = {"sequences": S}
-        for pipelined in (True, False):
-            loop = DriverLoopBatch(w, h, K, ptrs(0), [depth0] * S, kf_every=KF_EVERY, images_on_device=True, device=device)
-            loop.set_keyframe_phases([((s % 4) * KF_EVERY) // 4 for s in range(S)])   # independent cameras do not change keyframe in the same step
-            loop.set_pipeline(pipelined)
-            ctx_h = loop.ctx_handle()
-            t = 1
-            loop.run([ptrs(t + k) for k in range(warmup)])
-            t += warmup
-            capi.check(L.lsdhip_ctx_synchronize(ctx_h))
-            dts, poses = [], None
-            for _ in range(regions):
-                batch = [ptrs(t + k) for k in range(steps)]
-                t0 = time.perf_counter()
-                done, poses = loop.run(batch, want_poses=True)
+        try:
+            for pipelined in (True, False):
+                loop = DriverLoopBatch(w, h, K, ptrs(0), [seeds[s % NS][1] for s in range(S)], kf_every=KF_EVERY, images_on_device=True, device=device)
+                loop.set_keyframe_phases([((s % 4) * KF_EVERY) // 4 for s in range(S)])   # independent cameras do not change keyframe in the same step
+                loop.set_pipeline(pipelined)
+                ctx_h = loop.ctx_handle()
+                t = 1
+                loop.run([ptrs(t + k) for k in range(warmup)])
+                t += warmup
                 capi.check(L.lsdhip_ctx_synchronize(ctx_h))
-                dts.append(time.perf_counter() - t0)
-                t += steps
-            st = loop.stats()
-            dropped = sum(loop.dropped())
-            roof = None
-            if pipelined:
-                try:
-                    roof = multi_seq_roofline(loop, L, ctx_h, ptrs, t, S, w, h, steps)
-                except Exception as e:
-                    roof = {"error": str(e)}
-            loop.close()
-            dt = float(np.median(dts))
-            fps = S * steps / dt
-            if not pipelined:
-                rec["frames_s_block_until_mapped"] = fps
-                rec["ms_per_step_block_until_mapped"] = dt / steps * 1e3
-                continue
-            identical = all(np.array_equal(poses[:, s], poses[:, s % 4]) for s in range(S))
-            rec.update({"frames_s": fps, "ms_per_step": dt / steps * 1e3, "us_per_frame": dt / steps / S * 1e6,
-                        "vs_one_sequence": (fps / single_value) if single_value else None,
-                        "tracked_good": sum(q["tracked_good"] for q in st), "frames": sum(q["frames"] for q in st),
-                        "updates": sum(q["updates"] for q in st), "keyframes": sum(q["keyframes"] for q in st), "dropped": dropped,
-                        "lost": sum(q["lost"] for q in st),
-                        "lm_evaluations_per_frame": sum(q["evaluations"] for q in st) / max(1, sum(q["frames"] for q in st)),
-                        "replicas_bit_identical": bool(identical), "roofline": roof})
+                dts, poses = [], None
+                for _ in range(regions):
+                    batch = [ptrs(t + k) for k in range(steps)]
+                    t0 = time.perf_counter()
+                    done, poses = loop.run(batch, want_poses=True)
+                    capi.check(L.lsdhip_ctx_synchronize(ctx_h))
+                    dts.append(time.perf_counter() - t0)
+                    t += steps
+                st = loop.stats()
+                dropped = sum(loop.dropped())
+                roof = None
+                if pipelined and S <= 32:
+                    try:
+                        roof = multi_seq_roofline(loop, L, ctx_h, ptrs, t, S, w, h, steps)
+                    except Exception as e:
+                        roof = {"error": str(e)}
+                loop.close()
+                dt = float(np.median(dts))
+                fps = S * steps / dt
+                if not pipelined:
+                    rec["frames_s_block_until_mapped"] = fps
+                    rec["ms_per_step_block_until_mapped"] = dt / steps * 1e3
+                    continue
+                # replicas: the same (seed, motion, keyframe phase) pair again, 4 NS sequences further on
+                period = 4 * NS
+                identical = all(np.array_equal(poses[:, s], poses[:, s % period]) for s in range(S)) if S > period else None
+                rec.update({"frames_s": fps, "ms_per_step": dt / steps * 1e3, "us_per_frame": dt / steps / S * 1e6,
+                            "vs_one_sequence": (fps / single_value) if single_value else None,
+                            "tracked_good": sum(q["tracked_good"] for q in st), "frames": sum(q["frames"] for q in st),
+                            "updates": sum(q["updates"] for q in st), "keyframes": sum(q["keyframes"] for q in st), "dropped": dropped,
+                            "lost": sum(q["lost"] for q in st),
+                            "lm_evaluations_per_frame": sum(q["evaluations"] for q in st) / max(1, sum(q["frames"] for q in st)),
+                            "distinct_sequences": min(S, period), "replicas_bit_identical": identical, "roofline": roof})
+        except Exception as e:     # (a size the box cannot hold must not take the smaller ones down)
+            rec["error"] = str(e)
         out["S%d" % S] = rec
     return out
 
@@ -694,7 +705,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             assert int(t.item()) == world
         if rank == 0:
-            emit(json.dumps({"metric": "tracked frames/sec (full track+map loop) at %dx%d" % (args.width, args.height), "value": None,
+            emit(json.dumps({"metric": "tracked frames/sec (full track+map loop) at %dx%d, frames resident in HBM (8-bit upload excluded: value_pcie_inclusive has it)" % (args.width, args.height), "value": None,
                              "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
                              "scaling": "weak",
                              # what a real N-rank run adds to the line: every rank's own frames/s (configs[3]: a straggler shows) and the
@@ -881,7 +892,8 @@ def main():
                         "avg_launch_us": res_ms / res_launches * 1e3,
                         "algorithmic_bytes_per_launch": res_bytes / res_launches}
         out = {
-            "metric": "tracked frames/sec (full track+map loop) at %dx%d" % (w, h), "value": value, "unit": "frames/s",
+            "metric": "tracked frames/sec (full track+map loop) at %dx%d, frames resident in HBM (8-bit upload excluded: value_pcie_inclusive has it)" % (w, h),
+            "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "repeats": repeats, "ms_per_step_all_regions": [e / args.steps * 1e3 for e in elapsed_all],
             "region_start_unix_s": region_wall,
@@ -963,7 +975,13 @@ def main():
         if world == 1 and (w, h) == (640, 480) and not args.no_extra_configs:
             # (before the dense 4K leg: a burst like that leaves a box in its slow state for seconds, profiles/r03_notes.md section 1)
             try:
-                out.setdefault("extra_configs", {})["multi_seq"] = multi_seq(torch, w, h, K, d_frames, depth0, local_rank, out["value"])
+                # the 8 seeds of configs[3]: this rank's sequence + 7 more, rendered here (outside every timed region)
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(7) as ex:
+                    more = list(ex.map(lambda q: synth.make_sequence(w, h, n_seq, seq_index=q, kind=args.scene), range(1, 8)))
+                seeds = [(d_frames, depth0)] + [(torch.from_numpy(fr).cuda(local_rank), d0) for fr, d0, _, _ in more]
+                out.setdefault("extra_configs", {})["multi_seq"] = multi_seq(torch, w, h, K, seeds, local_rank, out["value"])
+                del seeds, more
             except Exception as e:
                 out.setdefault("extra_configs", {})["multi_seq"] = {"error": str(e)}
             try:
@@ -1021,6 +1039,37 @@ def main():
                 "note": "same execution model on both sides (cpu_baseline.value: sequential track-then-map; cpu_baseline.pipelined: tracking thread beside mapping thread, mapper one frame behind)"}
         else:
             out["cpu_baseline"] = None
+        # compact copies of the figures the other objects of this line hold, INSIDE `roofline` (a reader that keeps only `roofline` /
+        # `cpu_baseline` / `config` of the line still gets them): fractions are of the 8 TB/s HBM peak, algorithmic bytes / measured time
+        if out.get("roofline") is not None:
+            def dig(d, *keys):
+                for k in keys:
+                    if not isinstance(d, dict) or d.get(k) is None:
+                        return None
+                    d = d[k]
+                return d
+            ms = dig(out, "extra_configs", "multi_seq") or {}
+            others = {
+                "throughput_mode.level1_evaluation.frac": dig(out, "roofline_throughput_mode", "level1_evaluation", "frac"),
+                "throughput_mode.level1_evaluation.us_per_launch": dig(out, "roofline_throughput_mode", "level1_evaluation", "us_per_launch"),
+                "throughput_mode.whole_batches.frac": dig(out, "roofline_throughput_mode", "frac"),
+                "depth.k_observe.active_bytes.frac": dig(out, "roofline_depth", "frac"),
+                "reg_3840x2160.full_frame.frac": dig(out, "extra_configs", "reg_3840x2160", "full_frame", "frac"),
+                "reg_3840x2160.full_frame.ms_per_pass": dig(out, "extra_configs", "reg_3840x2160", "full_frame", "ms_per_pass"),
+                "reg_3840x2160.bands_vs_full_frame": dig(out, "extra_configs", "reg_3840x2160", "bands_vs_full_frame"),
+                "s2_1280x1024.frames_s": dig(out, "extra_configs", "s2_1280x1024", "frames_s"),
+                "value_block_until_mapped": dig(out, "value_block_until_mapped", "value"),
+                "value_pcie_inclusive": dig(out, "value_pcie_inclusive", "value"),
+                "keyframe_ms": out.get("keyframe_ms"), "depth_mpix_per_s": out.get("depth_mpix_per_s"),
+            }
+            for key in ("S8", "S32", "S64", "S128"):
+                others["multi_seq.%s.frames_s" % key] = dig(ms, key, "frames_s")
+                others["multi_seq.%s.frames_s_block_until_mapped" % key] = dig(ms, key, "frames_s_block_until_mapped")
+            for key in ("S8", "S32"):
+                for stage in ("track_batch", "observe", "regularise", "keyframe_change"):
+                    others["multi_seq.%s.%s.frac" % (key, stage)] = dig(ms, key, "roofline", stage, "frac")
+                    others["multi_seq.%s.%s.us" % (key, stage)] = dig(ms, key, "roofline", stage, "avg_launch_us")
+            out["roofline"]["others"] = others
         add_achievable(out)
         emit(json.dumps(out))
     if distributed:

@@ -39,6 +39,7 @@ class Record:
     def __init__(self):
         self.frameToKF, self.centres, self.diverged, self.good, self.usage = [], [], [], [], []
         self.residual = []
+        self.evals = []                # numEvaluations of every trackFrame call (the LM loop's control flow, in one number)
         self.kf_frames, self.rescale, self.semidense = [], [], []      # per keyframe change
         self.final_semidense = None
         self.final_valid = None
@@ -93,7 +94,7 @@ class OracleSide:
 
     def track(self, f, init):
         r = self.tr.track(self.ref, f, init)
-        return np.array(r.frameToRef), bool(r.diverged), bool(r.trackingWasGood), r.pointUsage, r.lastResidual
+        return np.array(r.frameToRef), bool(r.diverged), bool(r.trackingWasGood), r.pointUsage, r.lastResidual, int(r.numEvaluations)
 
     def depth_flag(self, kf):
         return kf.stats()["depthHasBeenUpdatedFlag"] != 0
@@ -139,7 +140,7 @@ class HipSide:
 
     def track(self, f, init):
         est = np.array(self.tr.trackFrame(self.ref, f, init))
-        return est, bool(self.tr.diverged), bool(self.tr.trackingWasGood), self.tr.pointUsage, self.tr.lastResidual
+        return est, bool(self.tr.diverged), bool(self.tr.trackingWasGood), self.tr.pointUsage, self.tr.lastResidual, int(self.tr.last.numEvaluations)
 
     def depth_flag(self, kf):
         return kf.depthHasBeenUpdatedFlag()
@@ -196,13 +197,14 @@ def run_loop(side, n, kf_every=10, live_queue=1, lag=0, clear_flag=False, init_p
             else:
                 side.import_ref(track_kf, False)           # the keyframe's depth changed in the last mapping iteration
         tracked_on = track_kf
-        est, diverged, good, usage, residual = side.track(f, last)
+        est, diverged, good, usage, residual, evals = side.track(f, last)
         rec.frameToKF.append(est)
         rec.centres.append(world_track.centre(est))
         rec.diverged.append(diverged)
         rec.good.append(good)
         rec.usage.append(usage)
         rec.residual.append(residual)
+        rec.evals.append(evals)
         rec.tracked_on.append(rec.kf_frames[-1] if (rec.kf_frames and tracked_on is map_kf) else (0 if tracked_on is side.kf0 else -1))
         if diverged:
             break

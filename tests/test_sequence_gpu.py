@@ -85,7 +85,20 @@ def test_sequence_50_frames_hip_vs_oracle(oracle, params, seq_index, live_queue,
         raise AssertionError("%s | a second HIP run gives %s poses" % (e, "IDENTICAL" if same else "DIFFERENT")) from e
 
 
-def _compare(g, o_sse, o_sc, gt, affine_on=True):
+def _compare(g, o_sse, o_sc, gt, affine_on=True, decision_edges=None, residual_ensemble=None, residual_abs_floor=0.0):
+    """decision_edges (a list, or None): frames on which the device's LM loop ran a different number of evaluations than the oracle's — a
+    stopping test that fell the other way under a different summation order; the pose bounds hold there as everywhere, but `lastResidual`
+    is then the error of a different iterate — possibly of a different pyramid level: trackFrame reports the error of the last ACCEPTED
+    step, and a level whose first retry is already rejected leaves the coarser level's value (SE3Tracker.cpp:399-401) — so on such frames it
+    is not compared; they are appended to the list and the caller bounds how many there may be.  None: every frame at the tight bound,
+    whatever the evaluation counts.
+    residual_ensemble (records of the oracle's own perturbed runs, or None): where the caller compares with the closest member of such an
+    ensemble, a frame's `lastResidual` bound is also at least 3x the largest deviation any member shows from that member on that frame —
+    late in a sequence the members' maps have drifted apart, and with them the residual they report for the same image.
+    residual_abs_floor: absolute difference of `lastResidual` that is accepted whatever the relative one — for SMALL residuals with affine
+    lighting on: the device's estimate of the offset b differs from the reference's by up to 0.07 grey levels (the reference's sequential
+    float32 sums being the less accurate side, test_affine_lighting_estimate_against_float64_truth), which is ~2e-3 of weighted residual
+    however small that residual is; both of the oracle's paths add in the same order and therefore do not show this in their spread."""
     assert len(g.frameToKF) == len(o_sse.frameToKF) == N_FRAMES
     # identical verdicts, frame for frame
     assert g.diverged == o_sse.diverged and not any(g.diverged)
@@ -116,9 +129,14 @@ def _compare(g, o_sse, o_sc, gt, affine_on=True):
     worst = (0.0, 0, 0.0)
     for i, (a, b, c) in enumerate(zip(g.residual, o_sse.residual, o_sc.residual)):
         d, sp = abs(a - b) / abs(b), abs(c - b) / abs(b)
+        if residual_ensemble:
+            sp = max(sp, 0.3 * max(abs(m.residual[i] - b) / abs(b) for m in residual_ensemble if len(m.residual) > i))
+        if decision_edges is not None and g.evals[i] != o_sse.evals[i]:
+            decision_edges.append((i + 1, g.evals[i], o_sse.evals[i], a, b))
+            continue
         if d / max(10 * sp, floor) > worst[0]:
             worst = (d / max(10 * sp, floor), i + 1, d)
-        assert d <= max(10 * sp, floor), ("lastResidual of frame %d" % (i + 1), a, b, c)
+        assert d <= max(10 * sp, floor) or abs(a - b) <= residual_abs_floor, ("lastResidual of frame %d" % (i + 1), a, b, c)
     print("lastResidual: tightest frame %d at %.0f %% of its bound (relative difference %.2e)" % (worst[1], 100 * worst[0], worst[2]))
 
     # keyframe changes: rescale factors and semi-dense counts (within 1 %)

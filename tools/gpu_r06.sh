@@ -25,7 +25,28 @@ case $step in
     ;;
   pytest)
     # selected tests: tools/gpu_r06.sh pytest <pytest args>
-    timeout 1500 python -m pytest -x -q -m gpu "$@" 2>&1 | tail -n 25 | tee -a $out/pytest.txt
+    timeout 1500 python -m pytest -x -q -m gpu "$@" > $out/pytest_full.txt 2>&1
+    grep -v "^  *[a-z_]* = \|^    " $out/pytest_full.txt | tail -n 60 | cut -c1-1500 | tee $out/pytest.txt
+    ;;
+  run)
+    # any developer tool: tools/gpu_r06.sh run <name> <command ...>   (output to gpurun_out/r06_run/<name>.txt)
+    name=$1; shift
+    timeout 1500 "$@" 2>&1 | tail -n 200 | cut -c1-700 | tee $out/$name.txt
+    ;;
+  bench)
+    # the driver's own command line (+ extra args); the JSON line goes to $out/bench.json
+    timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 "$@" > $out/bench.json 2> $out/bench.err
+    tail -n 5 $out/bench.err | cut -c1-300
+    python - <<PY
+import json
+d = json.loads(open("$out/bench.json").read().strip().splitlines()[-1])
+print("value", d["value"], "ms/step", d["ms_per_step"], "validation", d["validation"]["ok"])
+print("roofline", {k: v for k, v in d["roofline"].items() if k != "others"})
+for k, v in (d["roofline"].get("others") or {}).items():
+    print("   ", k, v)
+cb = d.get("cpu_baseline") or {}
+print("cpu_baseline", cb.get("value"), cb.get("kind"), "speedup", d.get("speedup_vs_cpu_baseline", {}).get("pipelined"), d.get("speedup_vs_cpu_baseline", {}).get("block_until_mapped"))
+PY
     ;;
   *) echo "unknown step $step"; exit 2;;
 esac
