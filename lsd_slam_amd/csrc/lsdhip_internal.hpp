@@ -168,7 +168,7 @@ struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_OBS_WALK_WAVES 4096             // one-wave workgroups of the walk launch
 #define LSD_BATCH_THROUGHPUT_MIN_JOBS 8     // lsdhip_tracker_track_batch: throughput mode from this many jobs on
 #define LSD_BATCH_SPEC_MAX 4                // reject-chain speculation of batches in throughput mode: most trials per step (levels without a mask)
-#define LSD_BATCH_SPEC_PIXELS 1000000       // ... trials per step at a level = what keeps jobs x trials x pixels of the level within this
+#define LSD_BATCH_SPEC_PIXELS 500000        // ... trials per step at a level = what keeps jobs x trials x pixels of the level within this (1 M until round 5: 64-job batches lost 12 % to it)
 #define LSD_BATCH_STRIP_WORKGROUPS 768      // strips x jobs of a throughput-mode evaluation launch (3 workgroups per CU)
 struct lsdhip_frame;
 

@@ -107,7 +107,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   constexpr int CPP = (RS_END + NPASS - 1) / NPASS;      // columns per batch
   constexpr int RSLICE_ = BLOCK / CPP;
   __shared__ float s_sum[(NSLICE > RSLICE_ ? NSLICE : RSLICE_)][64];
-  __shared__ float s_red[CPP * (BLOCK + 1) + 8];
+  __shared__ __attribute__((aligned(16))) float s_red[CPP * (BLOCK + 1) + 8];
   __shared__ int s_wtop[WAVES][3];
   __shared__ int s_top[3];
   const int tid = threadIdx.x;
@@ -129,11 +129,15 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   constexpr int NSLOT = 16;                                  // row slots of the column sums: slot s adds rows s, s + 16, ...
   // trials a launch can finish: single jobs up to LSD_SPEC_MAX; batches in throughput mode up to LSD_BATCH_SPEC_MAX (the LM launch has one
   // workgroup per (trial, job): each proposes its own retry, as the trial groups of a single job's launch do); small batches one
-  constexpr int TRIALS_MAX = BATCH ? (MODE == TS_LM ? LSD_BATCH_SPEC_MAX : 1) : LSD_SPEC_MAX;
-  constexpr bool SPEC_LM = (!BATCH && MODE == TS_FUSED) || (BATCH && MODE == TS_LM);
-  __shared__ __attribute__((aligned(16))) float s_sumT[TRIALS_MAX][NSLOT][RS_COLS];    // per pending trial: column sums by row slot
-  __shared__ float s_subT[TRIALS_MAX][3][32];               // ... K2/K3 contributions of its (up to 3) tail points
-  __shared__ int s_nsubT[TRIALS_MAX];
+  constexpr int TRIALS_MAX = BATCH ? (MODE == TS_EVAL ? 1 : LSD_BATCH_SPEC_MAX) : LSD_SPEC_MAX;
+  constexpr bool SPEC_LM = MODE != TS_EVAL;
+  // The finishing phase's per-trial tables live in the reduction buffer s_red: neither the strip list nor the reduction is live before the
+  // barrier that ends the LM step, and nothing of these tables is read after it — so a launch that can finish four (batches) or six
+  // (single jobs) trials needs no more LDS than one that finishes one (three workgroups per CU stay three).
+  static_assert(TRIALS_MAX * (NSLOT * RS_COLS + 96 + 1) <= CPP * (BLOCK + 1) + 8, "the finishing phase's tables must fit the reduction buffer");
+  float (*const s_sumT)[NSLOT][RS_COLS] = (float (*)[NSLOT][RS_COLS])s_red;                        // per pending trial: column sums by row slot
+  float (*const s_subT)[3][32] = (float (*)[3][32])(s_red + TRIALS_MAX * NSLOT * RS_COLS);          // ... K2/K3 contributions of its (up to 3) tail points
+  int* const s_nsubT = (int*)(s_red + TRIALS_MAX * (NSLOT * RS_COLS + 96));
   __shared__ float s_rec[TRIALS_MAX][32];                   // ... increment [0..5], pose [6..12], R [13..21], t [22..24] (trials > 0)
 #ifdef LSD_PHASE_TRACE
   __shared__ unsigned long long* s_trp;
@@ -183,7 +187,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   const int lvlPending = S.level;
   // what the finishing launch raises `done` to: the job's tag where the host polls pinned memory for it (single jobs), 1 where it synchronises
   const int doneWord = (!BATCH && MODE == TS_FUSED && spec.seq != 0) ? (spec.seq >> 12) : 1;
-  if (!BATCH && MODE == TS_FUSED) {
+  if (MODE == TS_FUSED) {
     // The launch is sized for the level with the most (tiles x trials).  This one either evaluates trials at S.level —
     // workgroup = (trial, tile) of that level — or, if the pending decision ends the level, the first evaluation of
     // S.level - 1 (workgroup = tile).  Workgroups that have no work either way leave before the finishing phase (whose loads
@@ -556,7 +560,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   // the same CU could read 1, enter the finishing phase alone and pair its barriers with the others' reduction barriers: one
   // tile's sums came out as LDS residue.  Seen only with a second stream active, profiles/r04_notes.md.)
   const int nb = job.lv[level].nblocks;
-  if (!BATCH && MODE == TS_FUSED && level != lvlPending) { cand = 0; bx = (int)blockIdx.x; }   // first evaluation of the next level
+  if (MODE == TS_FUSED && level != lvlPending) { cand = 0; bx = (int)blockIdx.x; }   // first evaluation of the next level
   if (bx >= nb || cand >= S.ncand) return;   // workgroup 0 always has work: it publishes the state at the end
   sums_out += (size_t)cand * RS_COLS * max_rows;
   topkey_out += (size_t)cand * max_rows;
@@ -1813,6 +1817,7 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   static const int specMaxEnv = getenv("LSDHIP_BATCH_SPEC") ? atoi(getenv("LSDHIP_BATCH_SPEC")) : LSD_BATCH_SPEC_MAX;   // developer A/B (1: off)
   int specMax = specMaxEnv < 1 ? 1 : (specMaxEnv > LSD_BATCH_SPEC_MAX ? LSD_BATCH_SPEC_MAX : specMaxEnv);
   if (t->specC < specMax) specMax = t->specC;        // lsdhip_tracker_set_speculation(t, 1, 0): one evaluation per step, batches too
+  if (getenv("LSDHIP_BATCH_FUSED") && atoi(getenv("LSDHIP_BATCH_FUSED")) == 1) specMax = 1;   // developer A/B: the fused form without speculation
   if (split && specMax > 1) {
     for (int l = 0; l < LSD_LEVELS; l++) spec.trials[l] = 1;
     const TrackJob& j0 = t->h_bjobs[0];
@@ -1820,7 +1825,8 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
       bool ok = true;
       for (int j = 0; j < n; j++) ok = ok && t->h_bjobs[j].lv[l].tilePx > 0 && !t->h_bjobs[j].lv[l].writeMask && t->h_bjobs[j].lastLevel <= l && t->h_bjobs[j].topLevel >= l;
       if (!ok) continue;
-      long long tr = (long long)LSD_BATCH_SPEC_PIXELS / ((long long)j0.lv[l].w * j0.lv[l].h * n);
+      static const long long specPixels = getenv("LSDHIP_BATCH_SPEC_PIXELS") ? atoll(getenv("LSDHIP_BATCH_SPEC_PIXELS")) : LSD_BATCH_SPEC_PIXELS;   // developer sweep
+      long long tr = specPixels / ((long long)j0.lv[l].w * j0.lv[l].h * n);
       if (tr > specMax) tr = specMax;
       if (tr < 1) tr = 1;
       spec.trials[l] = (int)tr;
@@ -1846,10 +1852,14 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
     budget += 3;
   }
   int parity = 0, first = 1, guard = 0;
+  static const int fusedEnv = getenv("LSDHIP_BATCH_FUSED") ? atoi(getenv("LSDHIP_BATCH_FUSED")) : 2;   // developer A/B (round 6): 0 = LM launch + evaluation launch per round
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     for (int i = 0; i < budget; i++) {
-      if (split) {
+      if (split && fusedEnv) {
+        hipLaunchKernelGGL((k_track_step<256, true, TS_FUSED>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
+                           t->d_bstate, sc, d_sum, parity, first, spec);
+      } else if (split) {
         // throughput mode: one LM workgroup per (trial, job), then a pure evaluation launch over all jobs' (trial, strip) pairs
         hipLaunchKernelGGL((k_track_step<256, true, TS_LM>), dim3(lmGrid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, parity, first, spec);

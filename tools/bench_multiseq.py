@@ -15,9 +15,12 @@ ap.add_argument("--regions", type=int, default=3)
 ap.add_argument("--tag", type=str, default="")
 args = ap.parse_args()
 w, h = 640, 480
-frames, depth0, K, gt = synth.make_sequence(w, h, 50, seq_index=0, kind="S1")
-d_frames = torch.from_numpy(frames).cuda(0)
+from concurrent.futures import ThreadPoolExecutor
+with ThreadPoolExecutor(8) as ex:
+    seqs = list(ex.map(lambda q: synth.make_sequence(w, h, 50, seq_index=q, kind="S1"), range(8)))
+K = seqs[0][2]
+seeds = [(torch.from_numpy(q[0]).cuda(0), q[1]) for q in seqs]
 torch.cuda.synchronize()
-out = bench.multi_seq(torch, w, h, K, d_frames, depth0, 0, None, sizes=tuple(args.S), steps=args.steps, warmup=10, regions=args.regions)
+out = bench.multi_seq(torch, w, h, K, seeds, 0, None, sizes=tuple(args.S), steps=args.steps, warmup=10, regions=args.regions)
 out.pop("workload", None)
 print(json.dumps({"tag": args.tag, **out}))

@@ -48,5 +48,36 @@ cb = d.get("cpu_baseline") or {}
 print("cpu_baseline", cb.get("value"), cb.get("kind"), "speedup", d.get("speedup_vs_cpu_baseline", {}).get("pipelined"), d.get("speedup_vs_cpu_baseline", {}).get("block_until_mapped"))
 PY
     ;;
+  batchprof)
+    # rocprofv3 kernel trace of the S-sequence loop: timeline of the tracking batches + kernel statistics.  tools/gpu_r06.sh batchprof <tag> [S]
+    tag=${1:-base}; S=${2:-32}
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_$tag -- python $R/tools/bench_multiseq.py --S $S --steps 30 --regions 2 > $R/$out/${tag}_bench.json 2> $R/$out/${tag}_err.txt)
+    f=$(find $out/prof_$tag -name "*kernel_trace.csv" | head -1)
+    g=$(find $out/prof_$tag -name "*kernel_stats.csv" | head -1)
+    python tools/batch_timeline.py $f $S | cut -c1-1500 | tee $out/${tag}_timeline.txt
+    head -16 $g | cut -c1-170 | tee $out/${tag}_kernel_stats.csv
+    python -c "
+import json; d=json.loads(open('$out/${tag}_bench.json').read().strip().splitlines()[-1]); k='S$S'
+print(k, 'frames_s', d[k].get('frames_s'), 'block', d[k].get('frames_s_block_until_mapped'), 'track_batch us', ((d[k].get('roofline') or {}).get('track_batch') or {}).get('avg_launch_us'))"
+    rm -rf $out/prof_$tag
+    ;;
+  ab)
+    # A/B of environment switches on the pure tracking batches and the S-sequence loop, alternating: tools/gpu_r06.sh ab <tag> "ENV=1 ..." ["ENV2=..."]
+    tag=$1; shift
+    for rep in 1 2; do
+      i=0
+      for envs in "" "$@"; do
+        echo "== rep $rep arm $i: [$envs]" | tee -a $out/$tag.txt
+        env $envs timeout 300 python tools/bench_batch.py --batches 8,32,64 --rounds 20 2>/dev/null | cut -c1-200 | tee -a $out/$tag.txt
+        env $envs timeout 300 python tools/bench_multiseq.py --S 8 32 --steps 30 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k in ('S8','S32'):
+    r=(d[k].get('roofline') or {}).get('track_batch') or {}
+    print(k, 'frames_s %.0f block %.0f track_batch %.1f us frac %.4f' % (d[k]['frames_s'], d[k]['frames_s_block_until_mapped'], r.get('avg_launch_us') or 0, r.get('frac') or 0))" | tee -a $out/$tag.txt
+        i=$((i+1))
+      done
+    done
+    ;;
   *) echo "unknown step $step"; exit 2;;
 esac
