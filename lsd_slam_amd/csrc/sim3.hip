@@ -900,31 +900,50 @@ __device__ __forceinline__ void sim3_job_view(const Sim3Set& set, const Sim3Trac
   a.record = nullptr; a.seq = 0;
 }
 // 7x7 solve of the LM step with one element of the augmented 7x8 system per lane (lane = 8 i + j), pivot row / column read back through
-// LDS — gj6_solve_wave of the SE3 tracker (track_device.hpp) with one more row.  No pivoting: J^T W J (+ damping) is symmetric positive
-// definite; same solution as the reference's A.ldlt().solve(b) up to rounding (ldlt7_solve above stays as the CPU-checked form,
-// tests/test_host_math_cpu.py), which is what the trackFrameSim3 tests hold the poses to.
+// LDS — gj6_solve_wave of the SE3 tracker (track_device.hpp) with one more row and DIAGONAL PIVOTING: at every step the unused row with
+// the largest |diagonal| is the pivot (what Eigen's LDLT does, C/Tracking/Sim3Tracker.cpp:300 `A.ldlt().solve(b)`), and a pivot that is
+// exactly zero eliminates nothing and leaves its unknown at 0 (Eigen: the pseudo-inverse of D).  After an accepted step LM_lambda falls back
+// to 0 (Sim3Tracker.cpp:336-337), so the system is only positive SEMI-definite when the scale / depth rows are weakly constrained: the
+// unpivoted form of round 5 divided by whatever stood on the diagonal and returned inf / NaN increments there, i.e. a job
+// reported as diverged where the reference takes a finite step.  Same solution as the reference's factorisation up to rounding
+// (ldlt7_solve above stays as the CPU-checked form, tests/test_host_math_cpu.py); tests/test_sim3_gpu.py::test_sim3_weak_depth_constraints.
 __device__ __forceinline__ void gj7_solve_wave(const Sim3Track& J, Sim3Scratch& W, const int lane) {
   const int i = lane >> 3, j = lane & 7;
   const bool act = i < 7;
   const int ii = act ? i : 0;
   float m = sim3_damped_entry(J, ii, j);
+  unsigned used = 0;                       // rows that have been pivots (uniform)
 #pragma unroll
   for (int k = 0; k < 7; k++) {
     if (act) W.m[i][j] = m;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const float d = W.m[k][k], rk = W.m[k][j], ck = W.m[ii][k];
+    // the pivot: largest |diagonal| among the rows not used yet, lowest index first (all seven reads are issued together)
+    float dg[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) dg[r] = W.m[r][r];
+    int p = 0;
+    float best = -1.0f;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const float a = fabsf(dg[r]);
+      const bool take = !((used >> r) & 1u) && a > best;
+      best = take ? a : best;
+      p = take ? r : p;
+    }
+    used |= 1u << p;
+    const float d = W.m[p][p], rk = W.m[p][j], ck = W.m[ii][p];
     const float f = ck * lsd_rcp_exact(d);
     const float upd = m - f * rk;
-    m = (i == k) ? m : upd;
+    m = (i == p || d == 0.0f) ? m : upd;
     __builtin_amdgcn_wave_barrier();
   }
   if (act) W.m[i][j] = m;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (lane < 7) W.inc[lane] = W.m[lane][7] * lsd_rcp_exact(W.m[lane][lane]);
+  if (lane < 7) { const float d = W.m[lane][lane]; W.inc[lane] = d != 0.0f ? W.m[lane][7] * lsd_rcp_exact(d) : 0.0f; }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

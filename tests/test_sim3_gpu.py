@@ -81,28 +81,94 @@ def test_sim3_tail_drop_is_the_last_points_in_column_order(oracle, hip):
     assert seen - {0}, "no case with a tail"
 
 
+def _pose_delta(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return (float(np.linalg.norm(a[4:7] - b[4:7])), float(min(np.linalg.norm(a[:4] - b[:4]), np.linalg.norm(a[:4] + b[:4]))), float(abs(a[7] - b[7]) / abs(b[7])))
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
 @pytest.mark.parametrize("scale", [1.0, 1.25, 0.8])
 def test_sim3_track_recovers_pose_and_scale_like_the_oracle(oracle, hip, scale):
+    """Whole trackFrameSim3 calls AND prefixes of the Levenberg-Marquardt loop (the first n iterations of the coarsest level, then the
+    finer levels added) against the oracle's three arithmetic modes.  Since round 6 the device solves the damped 7x7 system with diagonal
+    pivoting like the reference's LDL^T, and the two loops stay in step: the NUMBER OF EVALUATIONS is equal at every prefix and for the
+    whole call.  The bounds are set from the reference's own spread, measured here in the same call (its SSE path with _mm_rcp_ps and its
+    scalar path against its SSE path with IEEE reciprocals, which is the arithmetic the device follows; tools/sim3_parity_probe.py,
+    profiles/r06_notes.md section 3): pose within 2e-5 / 5e-6 / 5e-6 (translation / quaternion / relative scale; round 5: 2e-3 / 1e-3 /
+    2e-3), residuals within 3x that spread with a floor of 5e-4 (round 5: 2e-2 / 5e-2), Hessian within 3x the spread, floor 1e-4 (3e-2)."""
     w, h = 320, 240
     P = pair(oracle, hip, w, h, 3, scale)
     init = P["exp"].copy()
     init[7] = 1.0
-    to = oracle.Sim3Tracker(w, h, P["K"], mode=oracle.SSE_EXACT_RCP)
-    ro = to.track(P["ra"], P["fb"], init, 3, 1)
     tg = hip.Sim3Tracker(P["ctx"])
-    got, rg = tg.trackFrameSim3(P["ga"], P["gb"], init, 3, 1)
+    full = [5, 20, 50, 100, 100]
+    schedules = [("level 3, %d iterations" % n, [0, 0, 0, n, 0], 3, 3) for n in (1, 2, 3, 4, 100)] + [("levels 3-2", full, 3, 2), ("levels 3-1", full, 3, 1)]
+    for name, its, first, last in schedules:
+        runs = {}
+        for mname, mode in (("exact", oracle.SSE_EXACT_RCP), ("sse", oracle.SSE), ("scalar", oracle.SCALAR)):
+            to = oracle.Sim3Tracker(w, h, P["K"], mode=mode)
+            to.set_max_its(its)
+            runs[mname] = to.track(P["ra"], P["fb"], init, first, last)
+        tg.setMaxItsPerLvl(its)
+        got, rg = tg.trackFrameSim3(P["ga"], P["gb"], init, first, last)
+        ro = runs["exact"]
+        want = np.array(ro.frameToRef)
+        assert not ro.diverged and not tg.diverged, name
+        assert rg.numEvaluations == ro.numEvaluations, (name, rg.numEvaluations, ro.numEvaluations)
+        dt, dq, ds = _pose_delta(got, want)
+        assert dt < 2e-5 and dq < 5e-6 and ds < 5e-6, (name, dt, dq, ds)
+
+        def spread(f):
+            return max(_rel(f(runs["sse"]), f(ro)), _rel(f(runs["scalar"]), f(ro)))
+        for fname, fg, fo in (("lastResidual", rg.lastResidual, lambda r: r.lastResidual), ("lastDepthResidual", rg.lastDepthResidual, lambda r: r.lastDepthResidual),
+                              ("lastPhotometricResidual", rg.lastPhotometricResidual, lambda r: r.lastPhotometricResidual)):
+            assert _rel(fg, fo(ro)) <= max(3 * spread(fo), 5e-4), (name, fname, fg, fo(ro), spread(fo))
+        Hg, Ho, Hs = np.array(rg.lastSim3Hessian).reshape(7, 7), np.array(ro.hessian).reshape(7, 7), np.array(runs["scalar"].hessian).reshape(7, 7)
+        assert np.allclose(Hg, Hg.T)
+        close(Hg, Ho, max(3 * np.abs(Hs - Ho).max() / np.abs(Ho).max(), 1e-4), "Hessian (%s)" % name)
+    assert got[7] == pytest.approx(scale, rel=2e-2)
+
+
+@pytest.mark.parametrize("case", ["no depth terms", "a 6x6 patch of depth"])
+def test_sim3_weak_depth_constraints(oracle, hip, case):
+    """After an accepted step LM_lambda falls back to 0 (Sim3Tracker.cpp:336-337), so the 7x7 system is only positive SEMI-definite when
+    the depth residual constrains it weakly: with no depth term at all, row / column 6 (the scale) is exactly zero.  The reference's
+    A.ldlt().solve(b) pivots on the largest diagonal and treats a zero pivot as 'no step in that unknown' — a finite increment; the
+    unpivoted Gauss-Jordan of round 5 divided by that zero and the job came back as diverged.  The device now pivots the same
+    way: same verdict, same number of evaluations, pose and scale as the oracle's."""
+    from lsd_slam_amd import synth
+    w, h = 320, 240
+    sc = synth.Scene(0)
+    K = synth.intrinsics(w, h)
+    imgA, depthA = sc.render(0, w, h)
+    imgB, depthB = sc.render(2, w, h)
+    sparse = np.zeros_like(depthB)
+    if case == "no depth terms":
+        sparse[0, 0] = depthB[0, 0]            # the frame "has depth", but no warped point ever lands on that pixel
+    else:
+        sparse[117:123, 157:163] = depthB[117:123, 157:163]
+    fa, fb = oracle.Frame(0, imgA, K), oracle.Frame(2, imgB, K)
+    fa.set_depth_gt(depthA); fb.set_depth_gt(sparse)
+    ra = oracle.TrackingReference(); ra.import_frame(fa)
+    ctx = hip.Context(w, h, K)
+    ga, gb = hip.Frame(ctx, 0, imgA), hip.Frame(ctx, 2, imgB)
+    ga.setDepthFromGroundTruth(depthA); gb.setDepthFromGroundTruth(sparse)
+    R, t = sc.frame_to_ref(2, 0)
+    init = np.concatenate([synth.rot_to_quat(R), t + np.array([0.003, -0.002, 0.001]), [1.0]])
+    ro = oracle.Sim3Tracker(w, h, K, mode=oracle.SSE_EXACT_RCP).track(ra, fb, init, 3, 1)
+    tg = hip.Sim3Tracker(ctx)
+    got, rg = tg.trackFrameSim3(ga, gb, init, 3, 1)
     want = np.array(ro.frameToRef)
-    assert not ro.diverged and not tg.diverged
-    assert got[7] == pytest.approx(scale, rel=2e-2) and got[7] == pytest.approx(want[7], rel=2e-3)
-    assert np.linalg.norm(got[4:7] - want[4:7]) < 2e-3
-    assert min(np.linalg.norm(got[:4] - want[:4]), np.linalg.norm(got[:4] + want[:4])) < 1e-3
-    assert rg.lastResidual == pytest.approx(ro.lastResidual, rel=2e-2)
-    assert rg.lastDepthResidual == pytest.approx(ro.lastDepthResidual, rel=5e-2)
-    assert rg.lastPhotometricResidual == pytest.approx(ro.lastPhotometricResidual, rel=2e-2)
-    assert abs(rg.numEvaluations - ro.numEvaluations) <= max(3, ro.numEvaluations // 5)
-    Hg, Ho = np.array(rg.lastSim3Hessian).reshape(7, 7), np.array(ro.hessian).reshape(7, 7)
-    assert np.allclose(Hg, Hg.T)
-    close(Hg, Ho, 3e-2, "Hessian")
+    assert bool(tg.diverged) == bool(ro.diverged), (case, tg.diverged, ro.diverged)
+    assert np.all(np.isfinite(got))
+    if not ro.diverged:
+        assert rg.numEvaluations == ro.numEvaluations, (case, rg.numEvaluations, ro.numEvaluations)
+        dt, dq, ds = _pose_delta(got, want)
+        assert dt < 1e-4 and dq < 2e-5 and ds < 1e-4, (case, dt, dq, ds)
+        print("%s: %d evaluations, pose delta (t, q, scale) %.1e %.1e %.1e, scale %.6f" % (case, rg.numEvaluations, dt, dq, ds, got[7]))
 
 
 def test_sim3_first_iteration_is_identical(oracle, hip):
