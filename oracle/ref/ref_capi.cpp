@@ -10,6 +10,8 @@
 // headers under oracle/ref/shim/ (each says what it stands in for).  Nothing here is copied from the reference: this
 // file only calls its classes.  Private members are reached with the usual test-harness `#define private public`.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -291,6 +293,7 @@ void orc_tracker_track(void* t, void* ref, void* frame, const double init_frameT
   ((FrameBox*)frame)->parent_keep = ((RefBox*)ref)->keep;
   fill_result(&b->tr, T, out);
 }
+#ifndef LSD_REF_HIP_BACKED
 #if defined(ENABLE_SSE)
 #define REF_CALL(function, arguments) function##SSE arguments
 #else
@@ -332,6 +335,11 @@ int orc_tracker_buffer(void* t, int which, float* out) {
   if (out) memcpy(out, bufs[which], sizeof(float) * tr->buf_warped_size);
   return tr->buf_warped_size;
 }
+#else
+// (hip-backed build, integration/hip_backed: SE3Tracker's members are defined over the C ABI — the private CPU stages do not exist)
+void orc_tracker_evaluate(void*, void*, void*, const float*, int, float, float, ResidualRecord*) { fprintf(stderr, "orc_tracker_evaluate: not part of the hip-backed build\n"); abort(); }
+int orc_tracker_buffer(void*, int, float*) { return -1; }
+#endif
 // the reference takes the permanent reference from the keyframe object (Frame::permaRef_*); the oracle's hook takes the
 // cloud: install it on a scratch frame of the right size
 static void install_permaref(Frame* fr, const float* pos, const float* colvar, int n) {
@@ -403,6 +411,7 @@ void orc_depth_get(void* d, void* out32) {
   static_assert(sizeof(DepthMapPixelHypothesis) == 32, "hypothesis must be 32 bytes");
   memcpy(out32, (void*)dm->currentDepthMap, 32 * (size_t)dm->width * dm->height);
 }
+#ifndef LSD_REF_HIP_BACKED
 void orc_depth_set(void* d, void* kf, const void* in32, int reactivated) {
   DepthBox* b = (DepthBox*)d;
   DepthMap* dm = &b->dm;
@@ -417,6 +426,9 @@ void orc_depth_set(void* d, void* kf, const void* in32, int reactivated) {
   dm->activeKeyFrameIsReactivated = reactivated != 0;
   memcpy((void*)dm->currentDepthMap, in32, 32 * (size_t)f->width(0) * f->height(0));
 }
+#else
+void orc_depth_set(void*, void*, const void*, int) { fprintf(stderr, "orc_depth_set: not part of the hip-backed build\n"); abort(); }
+#endif
 static std::deque<FramePtr> frames_in(void** frames, int n) {
   std::deque<FramePtr> q;
   for (int i = 0; i < n; i++) q.push_back(((FrameBox*)frames[i])->f);
@@ -444,6 +456,7 @@ void orc_depth_set_from_existing(void* d, void* f) {
 void orc_frame_take_reactivation(void* f, void* d) { fresh(); F(f)->takeReActivationData(D(d)->currentDepthMap); }
 void orc_frame_set_depth_from_map(void* f, void* d) { fresh(); F(f)->setDepth(D(d)->currentDepthMap); }
 
+#ifndef LSD_REF_HIP_BACKED
 // stage: 0 observe (needs frames), 1 fillHoles, 2 regularize(false,24), 3 regularize(true,24), 4 propagate(frames[0] = new KF)
 void orc_depth_stage(void* d, int stage, void** frames, int n) {
   fresh();
@@ -486,11 +499,16 @@ void orc_depth_stage(void* d, int stage, void** frames, int n) {
   }
 }
 
+#else
+void orc_depth_stage(void*, int, void**, int) { fprintf(stderr, "orc_depth_stage: not part of the hip-backed build\n"); abort(); }
+#endif
 double orc_now_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 const char* orc_ref_build_info() {
-#if defined(ENABLE_SSE)
+#if defined(LSD_REF_HIP_BACKED)
+  return "reference headers + Frame / TrackingReference / Sim3Tracker sources, with SE3Tracker and DepthMap defined over liblsdhip.so (integration/hip_backed)";
+#elif defined(ENABLE_SSE)
   return "reference sources (lsd_slam_core/src) compiled with -DENABLE_SSE against oracle/ref/shim stand-ins";
 #else
   return "reference sources (lsd_slam_core/src) compiled without ENABLE_SSE against oracle/ref/shim stand-ins";
@@ -499,6 +517,7 @@ const char* orc_ref_build_info() {
 
 }  // extern "C"
 
+#ifndef LSD_REF_HIP_BACKED
 // Per-pixel stereo hook: makeAndCheckEPL + doLineStereo for pixel (x, y) against frame `ref` with the search interval the
 // caller gives, nothing written to the map.  out: isGood, epx, epy, error, result_idepth, result_var, result_eplLength.
 // (doLineStereo is `inline` in DepthMap.cpp; the build keeps an out-of-line copy with -fkeep-inline-functions.)
@@ -517,6 +536,9 @@ extern "C" void orc_depth_line_stereo(void* d, void* ref, int x, int y, float mi
   out[4] = ri; out[5] = rv; out[6] = rl;
 }
 
+#else
+extern "C" void orc_depth_line_stereo(void*, void*, int, int, float, float, float, float*) { fprintf(stderr, "orc_depth_line_stereo: not part of the hip-backed build\n"); abort(); }
+#endif
 // ---- Sim3Tracker (C/Tracking/Sim3Tracker.{h,cpp}, compiled unchanged) --------------------------------------------------------
 // Sim3 as double[8] = (qw, qx, qy, qz, tx, ty, tz, scale); the stand-in Sophus::Sim3d keeps (unit quaternion, scale, translation).
 extern "C" {
