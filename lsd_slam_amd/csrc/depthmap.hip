@@ -964,11 +964,15 @@ struct KfExtra {
   LSD_G uint8_t* reactVal;
   PropArgs prop;         // (src unused)
 };
-template <bool FILL, bool OCC, bool SET, bool KF = false, bool SUMV = false>
+// PY: pixels per lane = units of 8 map rows a workgroup owns (owned tile 32 x 8 PY).  The taller tile loads (32 + 2 HALO) x (8 PY + 2 HALO)
+// entries for 256 PY owned pixels — 2.5x (PY = 1), 1.88x (2), 1.56x (4) with K5 — and recomputes K5 on 1.69x / 1.41x / 1.27x of them; the
+// per-pixel arithmetic does not know the tile it runs in, so every shape gives the same planes bit for bit (profiles/r06_notes.md section 5).
+template <bool FILL, bool OCC, bool SET, bool KF, bool SUMV, int PY>
 __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restrict__ id0, float* __restrict__ var0,
                                                double* __restrict__ partials, const KfExtra* __restrict__ kx = nullptr) {
   constexpr int HALO = FILL ? 4 : 2;
-  constexpr int TW = 32 + 2 * HALO, TH = 8 + 2 * HALO, TN = TW * TH;
+  constexpr int OH = 8 * PY;
+  constexpr int TW = 32 + 2 * HALO, TH = OH + 2 * HALO, TN = TW * TH;
   // Per tile entry ONE 16-byte word (idepth, idepth_var, (float)pk) with pk = validity_counter of a valid pixel (never negative), -1 for an
   // invalid one: a neighbour costs K6 one LDS round trip (round 4: two dependent ones — the validity word, then, behind the branch on
   // it, the hypothesis; rounds 1-3: four arrays).  s_pk0 is the pre-K5 snapshot of pk that K5 reads.
@@ -986,9 +990,12 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   const int nt = gridDim.x * gridDim.y;
   const int lin = blockIdx.x + blockIdx.y * gridDim.x;
   const int tIdx = (nt & 7) == 0 ? (lin & 7) * (nt >> 3) + (lin >> 3) : lin;
-  if (a.tileRows > 0 && tIdx / (int)gridDim.x >= a.tileRows) return;
-  const int tbx = tIdx % gridDim.x, tby = tIdx / gridDim.x + a.tileRow0;
-  const int x0 = tbx * 32 - HALO, y0 = tby * 8 - HALO;
+  // tile rows are counted in units of 8 map rows (the C ABI's unit, lsdhip_depth_stage_rows): this workgroup owns PY of them
+  const int unit0 = (tIdx / (int)gridDim.x) * PY;
+  if (a.tileRows > 0 && unit0 >= a.tileRows) return;
+  const int tbx = tIdx % gridDim.x;
+  const int x0 = tbx * 32 - HALO, y0 = (unit0 + a.tileRow0) * 8 - HALO;
+  const int ownedRows = a.tileRows > 0 ? (a.tileRows - unit0 < PY ? (a.tileRows - unit0) * 8 : OH) : OH;   // a part may end inside the tile
   const int w = a.w, h = a.h;
 
   // ---- tile load (unconditional, clamped addresses; out-of-image entries are invalid) ----
@@ -1073,11 +1080,21 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     __syncthreads();
   }
 
-  // ---- K6 on the owned 32x8 pixels ----
-  const int lx = HALO + (tid & 31), ly = HALO + (tid >> 5);
+  // ---- K6 on the owned 32 x (8 PY) pixels: lane (tid & 31, tid >> 5) takes rows tid >> 5, + 8, ... ----
+  // the six distance terms (dx^2 + dy^2) * regDistVar of the 5x5 window and the reciprocal's class mask, once, in scalar registers: as
+  // literals inside the loop each costs a move (+ a multiply) per neighbour in a loop of ~17 vector instructions per neighbour
+  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  const float df0 = uni(0.0f * a.regDistVar), df1 = uni(1.0f * a.regDistVar), df2 = uni(2.0f * a.regDistVar), df4 = uni(4.0f * a.regDistVar),
+              df5 = uni(5.0f * a.regDistVar), df8 = uni(8.0f * a.regDistVar);
+  const int nmask = lsd_rcp_mask();
+  double accS = 0;          // (sum, count) of this lane's pixels: createKeyFrame's rescale sums (SUMV) or Frame::setDepth's statistics (SET)
+  int accC = 0;
+#pragma unroll
+  for (int p = 0; p < PY; p++) {
+  const int lx = HALO + (tid & 31), ly = HALO + (tid >> 5) + 8 * p;
   const int e = lx + ly * TW;
   const int x = x0 + lx, y = y0 + ly;
-  const bool inImage = x < w && y < h;
+  const bool inImage = x < w && y < h && ly - HALO < ownedRows;
   const int idx = inImage ? x + y * w : 0;
   const bool created = FILL && s_created[e] != 0;
   const rege c_e = s_e[e];
@@ -1099,12 +1116,6 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     // The next neighbour's entry is requested before the current one is worked on (volatile: the read stays where it is written instead
     // of sinking below the branches to its first use), so an LDS round trip overlaps the arithmetic instead of preceding it.
     auto entry = [&](int k) { const int dx = k / 5 - 2, dy = k % 5 - 2; return *(const volatile __attribute__((address_space(3))) rege3*)&s_e[e + dx + dy * TW]; };
-    // the six distance terms (dx^2 + dy^2) * regDistVar of the 5x5 window and the reciprocal's class mask, once, in scalar registers: as
-    // literals inside the loop each costs a move (+ a multiply) per neighbour in a loop of ~17 vector instructions per neighbour
-    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-    const float df0 = uni(0.0f * a.regDistVar), df1 = uni(1.0f * a.regDistVar), df2 = uni(2.0f * a.regDistVar), df4 = uni(4.0f * a.regDistVar),
-                df5 = uni(5.0f * a.regDistVar), df8 = uni(8.0f * a.regDistVar);
-    const int nmask = lsd_rcp_mask();
     rege3 ej = entry(0);
 #pragma unroll
     for (int k = 0; k < 25; k++) {
@@ -1180,40 +1191,28 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
   }
   if (SUMV) {
     // createKeyFrame's rescale sums (DepthMap.cpp:1286-1294): idepth_smoothed over the valid pixels
-    double s = 0;
-    int c = 0;
-    if (inImage && nowValid) { s = ids; c = 1; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      s += __shfl_xor(s, off);
-      c += __shfl_xor(c, off);
-    }
-    if ((tid & 63) == 0) { s_sum[tid >> 6] = s; s_cnt[tid >> 6] = c; }
-    __syncthreads();
-    if (tid == 0) {
-      const int b = tIdx;
-      partials[2 * b] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
-      partials[2 * b + 1] = (double)(((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3]);
-    }
+    if (inImage && nowValid) { accS += ids; accC += 1; }
   }
-
   if (SET) {
-    // ---- K8: Frame::setDepth on the owned pixel + (sum, count) partials ----
-    double s = 0;
-    int c = 0;
+    // ---- K8: Frame::setDepth on the owned pixel ----
     if (inImage) {
       if (nowValid && (double)ids >= -0.05) {
         id0[idx] = ids;
         var0[idx] = vars;
-        s = ids;
-        c = 1;
+        accS += ids;
+        accC += 1;
       } else {
         id0[idx] = -1.f;
         var0[idx] = -1.f;
       }
     }
-    // (sum, count) of the workgroup: butterfly inside each wave, then four partials through LDS.  The sum of at most 256 floats
+  }
+  }   // pixels of this lane
+  if (SUMV || SET) {
+    // (sum, count) of the workgroup: butterfly inside each wave, then four partials through LDS.  The sum of at most 256 PY floats
     // of one sign and a dynamic range below 2^20 is exact in double, so its value does not depend on the order.
+    double s = accS;
+    int c = accC;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       s += __shfl_xor(s, off);
@@ -1228,10 +1227,10 @@ __device__ __forceinline__ void reg_fused_tile(const RegArgs& a, float* __restri
     }
   }
 }
-template <bool FILL, bool OCC, bool SET>
+template <bool FILL, bool OCC, bool SET, int PY>
 __global__ __launch_bounds__(256) void k_reg_fused(RegArgs a, float* __restrict__ id0, float* __restrict__ var0,
                                                     double* __restrict__ partials) {
-  reg_fused_tile<FILL, OCC, SET>(a, id0, var0, partials);
+  reg_fused_tile<FILL, OCC, SET, false, false, PY>(a, id0, var0, partials);
 }
 // the update-time pass (fill holes + regularise [+ setDepth]) over the maps of several sequences, blockIdx.z = map
 struct RegBatchItem {
@@ -1240,15 +1239,15 @@ struct RegBatchItem {
   LSD_G float* var0;
   LSD_G double* partials;
 };
-template <bool SET>
+template <bool SET, int PY>
 __global__ __launch_bounds__(256) void k_reg_fused_batch(const RegBatchItem* __restrict__ items) {
   const RegBatchItem& it = items[blockIdx.z];
   if (SET) {
     if (it.id0 == nullptr) return;
-    reg_fused_tile<true, false, true>(it.a, it.id0, it.var0, it.partials);
+    reg_fused_tile<true, false, true, false, false, PY>(it.a, it.id0, it.var0, it.partials);
   } else {
     if (it.id0 != nullptr) return;
-    reg_fused_tile<true, false, false>(it.a, nullptr, nullptr, nullptr);
+    reg_fused_tile<true, false, false, false, false, PY>(it.a, nullptr, nullptr, nullptr);
   }
 }
 
@@ -1267,14 +1266,15 @@ struct KfItem {
   LSD_G double* partials;
   KfExtra x;
 };
+template <int PY>
 __global__ __launch_bounds__(256) void k_kf_finalize_prop(const KfItem* __restrict__ items) {
   const KfItem& it = items[blockIdx.z];
-  reg_fused_tile<true, false, true, true, false>(it.a, it.id0, it.var0, it.partials, &it.x);
+  reg_fused_tile<true, false, true, true, false, PY>(it.a, it.id0, it.var0, it.partials, &it.x);
 }
-template <bool FILL, bool OCC>
+template <bool FILL, bool OCC, int PY>
 __global__ __launch_bounds__(256) void k_kf_reg(const RegBatchItem* __restrict__ items) {
   const RegBatchItem& it = items[blockIdx.z];
-  reg_fused_tile<FILL, OCC, false, false, FILL>(it.a, nullptr, nullptr, it.partials, nullptr);   // (the rescale sums ride on the second pass)
+  reg_fused_tile<FILL, OCC, false, false, FILL, PY>(it.a, nullptr, nullptr, it.partials, nullptr);   // (the rescale sums ride on the second pass)
 }
 struct RescaleItem {
   HypPlanes m;
@@ -1287,6 +1287,18 @@ struct RescaleItem {
   LSD_G double* statPartials;        // (sum, count) per workgroup of this launch
   int n;
 };
+// Tile height of a regulariser launch: workgroups that own 32 x 16 pixels (PY = 2) move a quarter less through LDS per owned pixel and
+// recompute a sixth less of K5 than 32 x 8 ones — where the launch has enough of them to fill the chip (several maps, large frames:
+// -19 % for the 32-map pass, -6 % at 3840x2160); one 640x480 map is 1200 short workgroups or 600 long ones on 256 CUs, and the short ones
+// win there (keyframe change 0.085 against 0.097 ms).  32 x 32 (PY = 4, 33.6 KB of LDS) lost everywhere.  profiles/r06_notes.md section 5.
+static inline int lsd_reg_py(long long workgroups_at_py1) {
+  static const int forced = getenv("LSDHIP_REG_PY") ? atoi(getenv("LSDHIP_REG_PY")) : 0;     // developer A/B
+  if (forced == 1 || forced == 2) return forced;
+  return workgroups_at_py1 >= 2048 ? 2 : 1;
+}
+// grid rows of a regulariser launch over `units` tile rows of 8 map rows each
+static inline int lsd_reg_grid_rows(int units, int py) { return (units + py - 1) / py; }
+#define LSD_REG_DISPATCH(py, ...) do { if ((py) == 2) { constexpr int PYV = 2; __VA_ARGS__; } else { constexpr int PYV = 1; __VA_ARGS__; } } while (0)
 #define LSD_RESCALE_PX 2048    // pixels per workgroup of k_kf_rescale_setdepth
 __global__ __launch_bounds__(256) void k_kf_rescale_setdepth(const RescaleItem* __restrict__ items) {
   const RescaleItem& it = items[blockIdx.y];
@@ -1349,9 +1361,10 @@ __global__ __launch_bounds__(256) void k_kf_rescale_setdepth(const RescaleItem* 
 
 // parts of the fused fill-holes + regularise pass of several maps in one launch (row-band decomposition: the windows of one process),
 // blockIdx.z = part
+template <int PY>
 __global__ __launch_bounds__(256) void k_reg_rows_batch(const RegBatchItem* __restrict__ items) {
   const RegBatchItem& it = items[blockIdx.z];
-  reg_fused_tile<true, false, false>(it.a, nullptr, nullptr, nullptr);
+  reg_fused_tile<true, false, false, false, false, PY>(it.a, nullptr, nullptr, nullptr);
 }
 
 // K8: Frame::setDepth (Frame.cpp:199-243) + per-workgroup (sum, count) partials for meanIdepth / numPoints
@@ -1737,9 +1750,11 @@ static int regularize(lsdhip_depthmap* dm, bool removeOcclusions, int validityTH
   lsdhip_ctx* c = dm->ctx;
   LSD_CTX_LOCK(c);
   RegArgs a = reg_args(dm, validityTH);
-  dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
-  if (removeOcclusions) hipLaunchKernelGGL((k_reg_fused<false, true, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
-  else hipLaunchKernelGGL((k_reg_fused<false, false, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
+  const int tx = (c->w + 31) / 32, units = (c->h + 7) / 8, py = lsd_reg_py((long long)tx * units);
+  dim3 grid(tx, lsd_reg_grid_rows(units, py));
+  LSD_REG_DISPATCH(py,
+    if (removeOcclusions) hipLaunchKernelGGL((k_reg_fused<false, true, false, PYV>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((k_reg_fused<false, false, false, PYV>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr));
   HIPCHK(hipGetLastError());
   swap_valid(dm);
   return LSDHIP_OK;
@@ -1750,11 +1765,13 @@ static int fill_regularize(lsdhip_depthmap* dm, int validityTH, bool setDepth) {
   LSD_CTX_LOCK(c);
   lsdhip_frame* kf = dm->activeKeyFrame;
   RegArgs a = reg_args(dm, validityTH);
-  dim3 grid((c->w + 31) / 32, (c->h + 7) / 8);
-  if (setDepth)
-    hipLaunchKernelGGL((k_reg_fused<true, false, true>), grid, dim3(256), 0, lsd_map_stream(c), a, lsd_depth_w(kf)[0], lsd_depthvar_w(kf)[0], dm->d_red + 16);
-  else
-    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
+  const int tx = (c->w + 31) / 32, units = (c->h + 7) / 8, py = lsd_reg_py((long long)tx * units);
+  dim3 grid(tx, lsd_reg_grid_rows(units, py));
+  LSD_REG_DISPATCH(py,
+    if (setDepth)
+      hipLaunchKernelGGL((k_reg_fused<true, false, true, PYV>), grid, dim3(256), 0, lsd_map_stream(c), a, lsd_depth_w(kf)[0], lsd_depthvar_w(kf)[0], dm->d_red + 16);
+    else
+      hipLaunchKernelGGL((k_reg_fused<true, false, false, PYV>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr));
   HIPCHK(hipGetLastError());
   swap_valid(dm);
   if (setDepth) return set_depth_finish(dm, (int)(grid.x * grid.y));
@@ -1774,8 +1791,10 @@ static int fill_regularize_rows(lsdhip_depthmap* dm, int validityTH, int tileRow
   if (nTileRows > 0) {
     RegArgs a = reg_args(dm, validityTH);
     a.tileRow0 = tileRow0;
-    dim3 grid((c->w + 31) / 32, nTileRows);
-    hipLaunchKernelGGL((k_reg_fused<true, false, false>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr);
+    a.tileRows = nTileRows;
+    const int tx = (c->w + 31) / 32, py = lsd_reg_py((long long)tx * nTileRows);
+    dim3 grid(tx, lsd_reg_grid_rows(nTileRows, py));
+    LSD_REG_DISPATCH(py, hipLaunchKernelGGL((k_reg_fused<true, false, false, PYV>), grid, dim3(256), 0, lsd_map_stream(c), a, nullptr, nullptr, nullptr));
     HIPCHK(hipGetLastError());
   }
   if (last) swap_valid(dm);
@@ -2275,11 +2294,13 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
   rc = lsd_bprof_end(c, bp, ms, mapPixels);
   if (rc) return rc;
   const RegBatchItem* dra = (const RegBatchItem*)((const uint8_t*)dev + obsBytes);
-  const dim3 rgrid((c->w + 31) / 32, (c->h + 7) / 8, n);
+  const int rpy = lsd_reg_py((long long)((c->w + 31) / 32) * ((c->h + 7) / 8) * n);
+  const dim3 rgrid((c->w + 31) / 32, lsd_reg_grid_rows((c->h + 7) / 8, rpy), n);
   bp = lsd_bprof_begin(c, 2, ms);
   if (bp < -1) return bp;
-  if (nSet > 0) hipLaunchKernelGGL((k_reg_fused_batch<true>), rgrid, dim3(256), 0, ms, dra);
-  if (nSet < n) hipLaunchKernelGGL((k_reg_fused_batch<false>), rgrid, dim3(256), 0, ms, dra);
+  LSD_REG_DISPATCH(rpy,
+    if (nSet > 0) hipLaunchKernelGGL((k_reg_fused_batch<true, PYV>), rgrid, dim3(256), 0, ms, dra);
+    if (nSet < n) hipLaunchKernelGGL((k_reg_fused_batch<false, PYV>), rgrid, dim3(256), 0, ms, dra));
   rc = lsd_bprof_end(c, bp, ms, mapPixels);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
@@ -2409,7 +2430,8 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   if (int rcb = lsd_m_begin(c)) return rcb;
   const hipStream_t ms = lsd_map_stream(c);
   const int npx = c->w * c->h;
-  const dim3 tgrid((c->w + 31) / 32, (c->h + 7) / 8, n);
+  const int tpy = lsd_reg_py((long long)((c->w + 31) / 32) * ((c->h + 7) / 8) * n);
+  const dim3 tgrid((c->w + 31) / 32, lsd_reg_grid_rows((c->h + 7) / 8, tpy), n);
   const int ntiles = (int)(tgrid.x * tgrid.y);
   const int nwg5 = (npx + LSD_RESCALE_PX - 1) / LSD_RESCALE_PX;
   for (int j = 0; j < n; j++) {
@@ -2517,10 +2539,10 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   const RegBatchItem* dOcc = (const RegBatchItem*)((const uint8_t*)dev + kfBytes);
   const RegBatchItem* dFill = (const RegBatchItem*)((const uint8_t*)dev + kfBytes + regBytes);
   const RescaleItem* dRes = (const RescaleItem*)((const uint8_t*)dev + kfBytes + 2 * regBytes);
-  hipLaunchKernelGGL(k_kf_finalize_prop, tgrid, dim3(256), 0, ms, dkf);
+  LSD_REG_DISPATCH(tpy, hipLaunchKernelGGL(k_kf_finalize_prop<PYV>, tgrid, dim3(256), 0, ms, dkf));
   hipLaunchKernelGGL(k_prop_resolve_batch, dim3((unsigned)((npx + 255) / 256), n), dim3(256), 0, ms, dkf);
-  hipLaunchKernelGGL((k_kf_reg<false, true>), tgrid, dim3(256), 0, ms, dOcc);
-  hipLaunchKernelGGL((k_kf_reg<true, false>), tgrid, dim3(256), 0, ms, dFill);
+  LSD_REG_DISPATCH(tpy, hipLaunchKernelGGL((k_kf_reg<false, true, PYV>), tgrid, dim3(256), 0, ms, dOcc));
+  LSD_REG_DISPATCH(tpy, hipLaunchKernelGGL((k_kf_reg<true, false, PYV>), tgrid, dim3(256), 0, ms, dFill));
   hipLaunchKernelGGL(k_kf_rescale_setdepth, dim3(nwg5, n), dim3(256), 0, ms, dRes);
   HIPCHK(hipGetLastError());
   rc = lsd_args_release(c, ms);
@@ -2732,7 +2754,10 @@ extern "C" int lsdhip_depth_stage_rows_batch(lsdhip_ctx* c, int n, lsdhip_depthm
   const hipStream_t ms = lsd_map_stream(c);
   rc = lsd_args_commit(c, ms);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_reg_rows_batch, dim3((c->w + 31) / 32, maxRows, n), dim3(256), 0, ms, (const RegBatchItem*)dev);
+  long long wg1 = 0;
+  for (int k = 0; k < n; k++) wg1 += (long long)((c->w + 31) / 32) * n_tile_rows[k];
+  const int bpy = lsd_reg_py(wg1);
+  LSD_REG_DISPATCH(bpy, hipLaunchKernelGGL(k_reg_rows_batch<PYV>, dim3((c->w + 31) / 32, lsd_reg_grid_rows(maxRows, bpy), n), dim3(256), 0, ms, (const RegBatchItem*)dev));
   HIPCHK(hipGetLastError());
   rc = lsd_args_release(c, ms);
   if (rc) return rc;

@@ -79,5 +79,28 @@ for k in ('S8','S32'):
       done
     done
     ;;
+  ablib)
+    # same-box A/B of builds of liblsdhip.so (lsd_slam_amd/liblsdhip_<name>.so, build.build_variant), alternating with the default library:
+    # tools/gpu_r06.sh ablib <tag> <name> [<name> ...]   — the 4K regulariser (full frame, 8 bands), the S = 32 loop and the bench loop's keyframe time
+    tag=$1; shift
+    for rep in 1 2; do
+      for name in default "$@"; do
+        if [ $name = default ]; then unset LD_PRELOAD LSDHIP_LIB; else export LD_PRELOAD=$R/lsd_slam_amd/liblsdhip_$name.so LSDHIP_LIB=$R/lsd_slam_amd/liblsdhip_$name.so; fi
+        echo "== rep $rep lib $name" | tee -a $out/$tag.txt
+        for b in 1 8; do timeout 300 python tools/bench_bands.py --native --bands $b --passes 20 2>/dev/null | tail -n 1 | cut -c1-220 | tee -a $out/$tag.txt; done
+        timeout 300 python tools/bench_multiseq.py --S 32 --steps 30 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k in ('S32',):
+    r=d[k].get('roofline') or {}
+    print(k, 'frames_s %.0f block %.0f' % (d[k]['frames_s'], d[k]['frames_s_block_until_mapped']), ' '.join('%s %.1f us' % (n, (r.get(n) or {}).get('avg_launch_us') or 0) for n in ('track_batch','observe','regularise','keyframe_change','idepth_pyramids','frame_pyramids')))" | tee -a $out/$tag.txt
+        timeout 300 python bench.py --no-cpu-baseline --no-throughput-mode --no-pcie-leg --no-extra-configs --steps 50 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('bench value %.0f keyframe_ms %.4f depth_mpix_per_s %.0f' % (d['value'], d['keyframe_ms'], d['depth_mpix_per_s']))" | tee -a $out/$tag.txt
+        unset LD_PRELOAD LSDHIP_LIB
+      done
+    done
+    ;;
   *) echo "unknown step $step"; exit 2;;
 esac
