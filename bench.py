@@ -382,44 +382,81 @@ def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
 
 def bands_distributed(torch, dist, rank, world, local_rank, passes=20):
     """BASELINE.json configs[4] across the ranks of this run: the 3840x2160 regulariser (fill holes + regularise fused per pass, scene S3)
-    cut into one row band per rank, halo rows packed and exchanged with ncclSend / ncclRecv inside the C++ band loop
-    (lsd_slam_amd/driver/slam_loop.cpp lsdband_run), with the exchange under the interior rows of the pass (overlap 1) and after the
-    pass (overlap 0).  Every rank calls this; rank 0 returns the record.  With one rank (LSD_FORCE_DIST=1) the one band is the full frame
-    and nothing is exchanged: the keys are there, the RCCL calls are not exercised."""
+    cut into one row band per rank, over BOTH transports of the C++ band loop (lsd_slam_amd/driver/slam_loop.cpp lsdband_run):
+      rccl — halo rows packed and exchanged with grouped ncclSend / ncclRecv on the loop's stream;
+      ipc  — rows packed straight into the neighbour's IPC-mapped mailbox (peer access over xGMI), ready / consumed flags as one-lane
+             kernels on the stream: no collective library in the pass at all.  A band's pass is ~17-19 us of compute at 8 GPUs, so the
+             latency of the exchange, not its 2 MB, decides which one the 8-GPU run should use.
+    Each with the exchange under the interior rows of the pass (overlap 1) and after the pass (overlap 0).  Every rank calls this; rank 0
+    returns the record.  With one rank (LSD_FORCE_DIST=1) the one band is the full frame and nothing is exchanged: the keys are there,
+    the exchange is not exercised."""
     from lsd_slam_amd.bands import NativeBandRegularizer, synth_s3
     from lsd_slam_amd.driver import DriverLoop
     W, H = 3840, 2160
     hyp, maxgrad = synth_s3(W, H)
-    uid = [DriverLoop.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    br = NativeBandRegularizer(W, H, world, [rank], device=local_rank)
-    br.comm_init(uid[0], world, rank, list(range(world)))
     rec = {"workload": "3840x2160 depth-map regularisation, one row band per rank (BASELINE.json configs[4]), %d passes, 64 algorithmic B/px per pass" % passes,
-           "transport": "rccl" if world > 1 else "none (one rank: the band is the full frame)", "bands": world,
-           "halo_bytes_per_pass": int(br.halo_bytes_per_pass())}
-    for overlap in (1, 0):
-        br.set_overlap(overlap)
-        br.load(hyp, maxgrad)
-        br.run(2)
-        br.synchronize()
-        dts = []
-        for _ in range(3):
+           "bands": world}
+
+    def measure(br):
+        out = {}
+        for overlap in (1, 0):
+            br.set_overlap(overlap)
             br.load(hyp, maxgrad)
+            br.run(2)
             br.synchronize()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            br.run(passes)
-            br.synchronize()
-            dist.barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dts.append(float(t.item()))
-        dt = float(np.median(dts))
-        ach = W * H * passes * 64.0 / dt / 1e9
-        rec["overlap_%d" % overlap] = {"ms_per_pass": dt / passes * 1e3, "mpix_per_s": W * H * passes / dt / 1e6, "achieved": ach,
-                                       "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world)}
-    br.close() if hasattr(br, "close") else None
+            dts = []
+            for _ in range(3):
+                br.load(hyp, maxgrad)
+                br.synchronize()
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                br.run(passes)
+                br.synchronize()
+                dist.barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dts.append(float(t.item()))
+            dt = float(np.median(dts))
+            ach = W * H * passes * 64.0 / dt / 1e9
+            out["overlap_%d" % overlap] = {"ms_per_pass": dt / passes * 1e3, "mpix_per_s": W * H * passes / dt / 1e6, "achieved": ach,
+                                           "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world)}
+        return out
+
+    for transport in ("rccl", "ipc"):
+        ok = torch.tensor([1], device="cuda")
+        tr = {"transport": transport if world > 1 else "none (one rank: the band is the full frame)"}
+        br = None
+        try:
+            br = NativeBandRegularizer(W, H, world, [rank], device=local_rank)
+            if transport == "rccl":
+                uid = [DriverLoop.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                br.comm_init(uid[0], world, rank, list(range(world)))
+            elif world > 1:
+                handle = br.ipc_init(world, rank, list(range(world)))
+                handles = [None] * world
+                dist.all_gather_object(handles, handle)
+                br.ipc_connect(handles)
+            tr["halo_bytes_per_pass"] = int(br.halo_bytes_per_pass())
+        except Exception as e:        # (a transport this node cannot set up must not take the other one, or the line, down)
+            tr["error"] = str(e)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                 # all ranks or none: nobody may wait in a barrier the others skip
+        if int(ok.item()) == 1:
+            tr.update(measure(br))
+            if transport == "ipc":
+                tr["flag_waits_failed"] = br.ipc_failed()
+        elif "error" not in tr:
+            tr["error"] = "another rank could not set this transport up"
+        if br is not None:
+            br.close()
+        rec[transport] = tr
+    # (round-5 readers: the RCCL record's keys at the top level as well)
+    for k in ("overlap_1", "overlap_0", "halo_bytes_per_pass"):
+        if k in rec["rccl"]:
+            rec[k] = rec["rccl"][k]
+    rec["transport"] = rec["rccl"]["transport"]
     return rec if rank == 0 else None
 
 
@@ -711,7 +748,7 @@ def main():
                              # what a real N-rank run adds to the line: every rank's own frames/s (configs[3]: a straggler shows) and the
                              # row-band regulariser over the ranks (configs[4], RCCL halo exchange inside the C++ loop)
                              "per_rank_frames_s": [None] * world if distributed else None,
-                             "extra_configs": {"reg_3840x2160_bands": None} if distributed else
+                             "extra_configs": {"reg_3840x2160_bands": {"rccl": None, "ipc": None}} if distributed else
                                               {"multi_seq": {"S32": {"frames_s": None, "roofline": {k: None for k in ("track_batch", "frame_pyramids", "observe", "regularise", "idepth_pyramids", "keyframe_change")}}}},
                              # like-for-like CPU comparison (one-GPU runs): the reference's sources in both execution models
                              "cpu_baseline": None if distributed else {"value": None, "updates_per_frame": None, "pipelined": {"value": None, "updates_per_frame": None}},

@@ -73,10 +73,11 @@ import torch.distributed as dist
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 from lsd_slam_amd.bands import BandPlan, BandRegularizer, DistComm, synth_s3
 from band_engines import OracleBandEngine
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
-w, H, passes = 160, 96, 3
+world = int(sys.argv[2])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=world)
+w, H, passes = 160, int(sys.argv[3]), 3
 hyp, maxgrad = synth_s3(w, H)
-plan = BandPlan(H, 2)
+plan = BandPlan(H, world)
 br = BandRegularizer(plan, [OracleBandEngine(w, plan.window_rows)], DistComm(), [dist.get_rank()])
 br.load(hyp, maxgrad)
 br.run(passes)
@@ -87,18 +88,21 @@ dist.destroy_process_group()
 """
 
 
-def test_banded_passes_two_gloo_ranks(oracle, tmp_path):
-    port = 29500 + os.getpid() % 2000
+@pytest.mark.parametrize("world,H", [(2, 96), (8, 256)])
+def test_banded_passes_over_gloo_ranks(oracle, tmp_path, world, H):
+    """one band per process, halo rows through torch.distributed point-to-point (gloo here, RCCL on GPUs): 2 ranks, and the 8 ranks
+    BASELINE.json configs[4] names (every interior band exchanges with two neighbours; the middle bands' windows overlap on both sides)"""
+    port = 29500 + (os.getpid() + 7 * world) % 2000
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, port=port, out=str(tmp_path)))
-    procs = [subprocess.Popen([sys.executable, str(script), str(r)]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(H)]) for r in range(world)]
     for p in procs:
-        assert p.wait(timeout=300) == 0
-    w, H, passes = 160, 96, 3
+        assert p.wait(timeout=600) == 0
+    w, passes = 160, 3
     hyp, maxgrad = synth_s3(w, H)
     ref = _full_frame(oracle, hyp, maxgrad, passes)
-    plan = BandPlan(H, 2)
-    for r in range(2):
+    plan = BandPlan(H, world)
+    for r in range(world):
         y0, y1 = plan.owned[r]
         _assert_rows_equal(np.load(tmp_path / ("band%d.npy" % r)), ref[y0:y1], "rank %d" % r)
 

@@ -72,25 +72,31 @@ def test_single_rank_is_a_noop_gather():
     assert kg.world == 1 and torch.equal(kg.collected[0][0], torch.full((2, 4, 4), 3.0))
 
 
-def test_bench_gpus_flag_starts_the_ranks_itself():
-    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one rank per GPU); the
-    --dry-run leg runs the same rendezvous / barrier / max-over-ranks plumbing on gloo and prints n_gpus == 2."""
+import pytest
+
+
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_gpus_flag_starts_the_ranks_itself(gpus):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU); the
+    --dry-run leg runs the same rendezvous / barrier / max-over-ranks plumbing on gloo and prints n_gpus == N — at 2 ranks and at
+    the 8 ranks the two sharded configurations of BASELINE.json name (configs[3], configs[4])."""
     import json
     import subprocess
     import sys
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-run", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
+    assert d["n_gpus"] == gpus and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
     # what an N-rank run adds to the line: one rate per rank (BASELINE.json configs[3]) and the row-band regulariser across the ranks
-    # (configs[4]: lsdband_run's RCCL halo exchange) — bench.py::bands_distributed
-    assert d["per_rank_frames_s"] == [None, None] and "reg_3840x2160_bands" in d["extra_configs"]
+    # over BOTH transports (configs[4]: lsdband_run's RCCL halo exchange, and the IPC mailboxes) — bench.py::bands_distributed
+    assert d["per_rank_frames_s"] == [None] * gpus
+    assert set(d["extra_configs"]["reg_3840x2160_bands"]) >= {"rccl", "ipc"}
 
 
 def test_bench_line_skeleton_of_a_one_gpu_run():
