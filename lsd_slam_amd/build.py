@@ -77,6 +77,13 @@ def build_variant(name, defines, verbose=False):
     return out
 
 
+def build_variant_if_stale(name, defines):
+    out = os.path.join(HERE, "liblsdhip_%s.so" % name)
+    if os.path.exists(out) and os.path.exists(OUT) and os.path.getmtime(out) >= os.path.getmtime(OUT):
+        return out
+    return build_variant(name, defines)
+
+
 DRIVER_OUT = os.path.join(HERE, "liblsdhip_driver.so")
 DRIVER_SRC = os.path.join(HERE, "driver", "slam_loop.cpp")
 

@@ -2304,7 +2304,7 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
   rc = lsd_bprof_end(c, bp, ms, mapPixels);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  rc = lsd_args_release(c, ms);
+  rc = lsd_args_release(c, dev, ms);
   if (rc) return rc;
   for (int j = 0; j < n; j++) swap_valid(maps[j]);
   // ---- Frame::setDepth's second half for the keyframes that were due -------------------------------------------------------------------
@@ -2434,6 +2434,40 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   const dim3 tgrid((c->w + 31) / 32, lsd_reg_grid_rows((c->h + 7) / 8, tpy), n);
   const int ntiles = (int)(tgrid.x * tgrid.y);
   const int nwg5 = (npx + LSD_RESCALE_PX - 1) / LSD_RESCALE_PX;
+  // Everything below edits host-side state of the maps, of both keyframes and of the context's slot ring while it builds the launches'
+  // arguments, and several steps can fail (a slot, the argument ring, a launch).  The edits are undone unless the call gets as far as its
+  // last launch: an error leaves every map on its old keyframe with its planes where they were, not half-way.
+  struct Txn {
+    lsdhip_ctx* c; int n; lsdhip_depthmap** maps; lsdhip_frame** nks;
+    struct M { HypPlanes cur, oth; uint8_t* snap; lsdhip_frame* kf; bool react; bool propClean; int oldStats; int nkRescale, nkStats; lsdm::Sim3dH nkPose; };
+    std::vector<M> m;
+    std::vector<int> slots;      // slots taken by this call
+    int slotNext; int ev = EV_SKIP; bool timing = false; bool done = false;
+    Txn(lsdhip_ctx* c_, int n_, lsdhip_depthmap** maps_, lsdhip_frame** nks_) : c(c_), n(n_), maps(maps_), nks(nks_), m((size_t)n_), slotNext(c_->slot_next) {
+      for (int j = 0; j < n; j++) {
+        lsdhip_depthmap* dm = maps[j];
+        m[j] = M{dm->cur, dm->oth, dm->d_validSnap, dm->activeKeyFrame, dm->activeKeyFrameIsReactivated, dm->propClean, dm->activeKeyFrame->pendStats,
+                 nks[j]->pendRescale, nks[j]->pendStats, nks[j]->thisToParent_raw};
+      }
+    }
+    ~Txn() {
+      if (done) return;
+      for (int s : slots) { c->slot_stats_owner[s] = nullptr; c->slot_rescale_owner[s] = nullptr; }
+      c->slot_next = slotNext;
+      for (int j = 0; j < n; j++) {
+        lsdhip_depthmap* dm = maps[j];
+        dm->cur = m[j].cur; dm->oth = m[j].oth; dm->d_validSnap = m[j].snap; dm->activeKeyFrame = m[j].kf; dm->activeKeyFrameIsReactivated = m[j].react;
+        dm->propClean = false;                       // (the K7 scratch may have been written: the next call clears it)
+        m[j].kf->pendStats = m[j].oldStats;
+        if (m[j].oldStats >= 0) c->slot_stats_owner[m[j].oldStats] = m[j].kf;
+        nks[j]->pendRescale = m[j].nkRescale; nks[j]->pendStats = m[j].nkStats;
+        if (m[j].nkRescale >= 0) c->slot_rescale_owner[m[j].nkRescale] = nks[j];
+        if (m[j].nkStats >= 0) c->slot_stats_owner[m[j].nkStats] = nks[j];
+        nks[j]->thisToParent_raw = m[j].nkPose;
+      }
+      if (timing) (void)timing_end(maps[0], ev);     // (keeps the event pair of the timing sample balanced)
+    }
+  } txn(c, n, maps, new_keyframes);
   for (int j = 0; j < n; j++) {
     lsdhip_depthmap* dm = maps[j];
     if (!dm->propClean) {     // (a single-call propagation, or a failed call, left the K7 scratch in use)
@@ -2445,6 +2479,7 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   }
   const int ev = timing_begin(maps[0], 1);
   if (ev < 0 && ev != EV_SKIP) return ev;
+  txn.ev = ev; txn.timing = true;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t kfBytes = up(sizeof(KfItem) * (size_t)n), regBytes = up(sizeof(RegBatchItem) * (size_t)n), resBytes = up(sizeof(RescaleItem) * (size_t)n);
   void* hostBlob = nullptr;
@@ -2478,6 +2513,7 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
     {
       const int slot = lsd_ctx_take_slot(c);
       if (slot < 0) return slot;
+      txn.slots.push_back(slot);
       if (old->pendStats >= 0) c->slot_stats_owner[old->pendStats] = nullptr;
       old->pendStats = slot;
       c->slot_stats_owner[slot] = old;
@@ -2502,6 +2538,7 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
     {
       const int slot = lsd_ctx_take_slot(c);
       if (slot < 0) return slot;
+      txn.slots.push_back(slot);
       if (nk->pendRescale >= 0) c->slot_rescale_owner[nk->pendRescale] = nullptr;
       nk->pendRescale = slot;
       c->slot_rescale_owner[slot] = nk;
@@ -2513,6 +2550,7 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
     {
       const int slot = lsd_ctx_take_slot(c);
       if (slot < 0) return slot;
+      txn.slots.push_back(slot);
       if (nk->pendStats >= 0) c->slot_stats_owner[nk->pendStats] = nullptr;
       nk->pendStats = slot;
       c->slot_stats_owner[slot] = nk;
@@ -2545,12 +2583,13 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   LSD_REG_DISPATCH(tpy, hipLaunchKernelGGL((k_kf_reg<true, false, PYV>), tgrid, dim3(256), 0, ms, dFill));
   hipLaunchKernelGGL(k_kf_rescale_setdepth, dim3(nwg5, n), dim3(256), 0, ms, dRes);
   HIPCHK(hipGetLastError());
-  rc = lsd_args_release(c, ms);
+  rc = lsd_args_release(c, dev, ms);
   if (rc) return rc;
   rc = lsd_frame_build_idepth_pyramid_batch(pyrFrames.data(), 2 * n, pyrParts.data(), 0, pyrOuts.data(), pyrN.data());
   if (rc) return rc;
   rc = lsd_bprof_end(c, bp, ms, (double)n * npx);
   if (rc) return rc;
+  txn.done = true;            // every launch of the change is queued: the new state stands
   for (int j = 0; j < n; j++) {
     maps[j]->propClean = true;
     pyrFrames[j]->depthHasBeenUpdatedFlag = true;
@@ -2759,7 +2798,7 @@ extern "C" int lsdhip_depth_stage_rows_batch(lsdhip_ctx* c, int n, lsdhip_depthm
   const int bpy = lsd_reg_py(wg1);
   LSD_REG_DISPATCH(bpy, hipLaunchKernelGGL(k_reg_rows_batch<PYV>, dim3((c->w + 31) / 32, lsd_reg_grid_rows(maxRows, bpy), n), dim3(256), 0, ms, (const RegBatchItem*)dev));
   HIPCHK(hipGetLastError());
-  rc = lsd_args_release(c, ms);
+  rc = lsd_args_release(c, dev, ms);
   if (rc) return rc;
   if (!c->async) HIPCHK(hipStreamSynchronize(ms));
   return LSDHIP_OK;

@@ -1212,11 +1212,18 @@ int lsd_args_commit(lsdhip_ctx* c, hipStream_t s) {
   r.used[i] = true;
   return LSDHIP_OK;
 }
-int lsd_args_release(lsdhip_ctx* c, hipStream_t s) {
+// `dev`: the device address lsd_args_begin / lsd_args_push handed out — the slot is identified by it, not by "the slot begun last": a
+// helper that pushes arguments of its own between a commit and its release (lsd_frame_build_idepth_pyramid_batch inside the keyframe
+// change) must not make the release guard the wrong slot
+int lsd_args_release(lsdhip_ctx* c, const void* dev, hipStream_t s) {
   LSD_CTX_LOCK(c);
   lsdhip_ctx::ArgRing& r = c->args;
-  if (r.cur < 0 || !r.used[r.cur]) return LSDHIP_OK;
-  HIPCHK(hipEventRecord(r.ev[r.cur], s));
+  constexpr int NS = lsdhip_ctx::ArgRing::NS;
+  const uint8_t* p = (const uint8_t*)dev;
+  if (!r.d || r.slotBytes == 0 || p < (const uint8_t*)r.d || p >= (const uint8_t*)r.d + r.slotBytes * NS) return LSDHIP_OK;   // (the ring was regrown since: the device was drained then)
+  const int i = (int)((size_t)(p - (const uint8_t*)r.d) / r.slotBytes);
+  if (!r.used[i]) return LSDHIP_OK;
+  HIPCHK(hipEventRecord(r.ev[i], s));
   return LSDHIP_OK;
 }
 int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out) {
@@ -1247,7 +1254,7 @@ int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double*
   if (rc) return rc;
   hipLaunchKernelGGL(k_idepth_pyramid_batch, dim3((c->w + 31) / 32, (c->h + 31) / 32 + 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
   HIPCHK(hipGetLastError());
-  rc = lsd_args_release(c, lsd_map_stream(c));
+  rc = lsd_args_release(c, dev, lsd_map_stream(c));
   if (rc) return rc;
   for (int j = 0; j < n; j++) {
     if (c->pipeline) { fs[j]->depthPending = true; fs[j]->depthPendingSeq = c->mSeq + 1; }
@@ -1384,7 +1391,7 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
   rc = lsd_bprof_end(c, bp, ms, (double)n * n0);
   if (rc) return fail(rc);
   if (hipGetLastError() != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: launch failed"); return fail(LSDHIP_E_HIP); }
-  rc = lsd_args_release(c, ms);
+  rc = lsd_args_release(c, dev, ms);
   if (rc) return fail(rc);
   const long long seq = lsd_m_record(c);
   if (seq < 0) return fail(LSDHIP_E_HIP);

@@ -520,7 +520,7 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
 int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out);
 int lsd_args_begin(lsdhip_ctx* c, size_t bytes, void** host_out, void** dev_out);
 int lsd_args_commit(lsdhip_ctx* c, hipStream_t s);
-int lsd_args_release(lsdhip_ctx* c, hipStream_t s);
+int lsd_args_release(lsdhip_ctx* c, const void* dev, hipStream_t s);
 // Frame::setDepth's second half for n keyframes in one launch (lsdhip_depth_update_batch)
 int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** f, int n, const double* const* redPartials, int redN, double* const* redOut,
                                          const int* redNs = nullptr);   // redNs: partial counts per frame (else redN for all)

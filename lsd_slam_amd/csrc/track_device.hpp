@@ -139,6 +139,13 @@ __device__ __forceinline__ void eval_fetch(const EvalCtx& a, const PointWarp& q,
 // K2's weights and K3's Jacobian (the reference's SSE path uses the 12-bit _mm_rcp_ps there, SE3Tracker.cpp:519-553), the usage and
 // affine-lighting statistics.  Everything that decides a mask bit or a count (the projection, the bilinear sample, isGood) stays
 // IEEE-exact: an IEEE division is a ~12-instruction dependent chain, and eleven of them made up a third of the evaluation.
+// LSD_EVAL_FMA (default 1): the multiply-adds of K2's weight and K3's Jacobian formulas fused (round 5).  They only feed sums held to a
+// tolerance — but the weighted error drives the LM loop's accept / reject test, so the reference's separately rounded order stays
+// buildable: lsd_slam_amd/build.py build_variant("nofma", ["LSD_EVAL_FMA=0"]), and tests/test_gpu_parity.py::test_unfused_build_holds_the_same_parity
+// runs the kernel-level and trackFrame parity tests on that build so that a regression can be bisected between the two.
+#ifndef LSD_EVAL_FMA
+#define LSD_EVAL_FMA 1
+#endif
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q, const PointTexels& t, float pz, float I_ref, float var,
@@ -176,10 +183,18 @@ __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q
   // reciprocals); a fused multiply-add is one rounding and one instruction where the separate pair is two of each, and this loop is
   // bound by instruction issue (profiles/r05_notes.md).  Everything above that decides a mask bit or a count is untouched.
   float pz2d = frcp((Wz * Wz) * d);
+#if LSD_EVAL_FMA
   float g0 = __builtin_fmaf(Wz, a.t[0], 0.0f - Wx * a.t[2]) * pz2d;
   float g1 = __builtin_fmaf(Wz, a.t[1], 0.0f - Wy * a.t[2]) * pz2d;
   float drpdd = __builtin_fmaf(g0, gx, g1 * gy);
   float w_p = frcp(__builtin_fmaf(drpdd, drpdd * (a.var_weight * var), a.cameraPixelNoise2));
+#else
+  // the reference's SSE operation order with every multiply and add rounded on its own (calcWeightsAndResidualSSE, SE3Tracker.cpp:519-553)
+  float g0 = (Wz * a.t[0] - Wx * a.t[2]) * pz2d;
+  float g1 = (Wz * a.t[1] - Wy * a.t[2]) * pz2d;
+  float drpdd = g0 * gx + g1 * gy;
+  float w_p = frcp(a.cameraPixelNoise2 + drpdd * (drpdd * (a.var_weight * var)));
+#endif
   float wr = residual * fsqrt(w_p);
   wr = fmaxf(wr, 0.0f - wr);
   float wh = (wr < a.huber_half) ? 1.0f : a.huber_half * frcp(wr);
@@ -195,8 +210,13 @@ __device__ __forceinline__ void eval_finish(const EvalCtx& a, const PointWarp& q
   v1 = (Wx * gx) * z2;
   v2 = (Wy * gy) * z2;
   o.J[2] = 0.0f - (v1 + v2);
+#if LSD_EVAL_FMA
   o.J[3] = 0.0f - __builtin_fmaf(v2, Wy, __builtin_fmaf(v1, Wy, gy));
   o.J[4] = __builtin_fmaf(v2, Wx, __builtin_fmaf(v1, Wx, gx));
+#else
+  o.J[3] = 0.0f - ((v2 * Wy) + (gy + v1 * Wy));        // calculateWarpUpdateSSE, SE3Tracker.cpp:1080-1104
+  o.J[4] = (gx + v1 * Wx) + v2 * Wx;
+#endif
 }
 // (px,py,pz) = reference point, I_ref / var = its colour and inverse-depth variance.
 __device__ __forceinline__ void eval_point(const EvalCtx& a, float px, float py, float pz, float I_ref, float var, PointOut& o) {

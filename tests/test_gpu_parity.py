@@ -2,6 +2,8 @@
 the same seeded inputs.  Bar: bit-exact for masks / integer state / per-pixel float results whose operation order
 is replicated; float32 reductions within 1e-5 of a float64 accumulation of the oracle's per-point float32 terms;
 function-level poses within the oracle's own scalar-vs-SSE spread."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1105,3 +1107,21 @@ def test_track_batch_speculation_is_bit_identical_to_one_trial_per_step(oracle, 
     for a, b in zip(m1, m0):
         assert np.array_equal(a, b)
     assert n0 < n1, (n0, n1)          # the reject chains collapsed: fewer rounds for the same evaluations
+
+
+@pytest.mark.gpu
+def test_unfused_build_holds_the_same_parity():
+    """eval_finish fuses the multiply-adds of K2's weights and K3's Jacobian (LSD_EVAL_FMA = 1, the default).  The build with
+    the reference's separately rounded operation order (liblsdhip_nofma.so: lsd_slam_amd/build.py build_variant("nofma", ["LSD_EVAL_FMA=0"]),
+    built by __graft_entry__.build()) runs the kernel-level residual parity and the trackFrame parity tests in a fresh interpreter:
+    both builds meet the same bounds, and a future regression in one of them can be bisected against the other."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lsd_slam_amd", "liblsdhip_nofma.so")
+    if not os.path.exists(lib):
+        pytest.skip("liblsdhip_nofma.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, LSDHIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "residual_kernel_fixed_pose or trackframe_parity or affine_lighting_estimate"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
