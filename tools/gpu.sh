@@ -1,5 +1,8 @@
 #!/bin/bash
-# round 6: GPU-side steps, one parametrised script (tools/gpu_r06.sh <step> [args]); output under gpurun_out/r06_<step>/
+# Every GPU-side step of a round, one parametrised script: gpurun -- 'bash tools/gpu.sh <step> [args]'; output under gpurun_out/r06_<step>/
+# steps: suite | pytest <args> | bench [args] | run <name> <cmd...> | ab <tag> "ENV=.."... | ablib <tag> <variant>... | batchprof <tag> [S] |
+#        profile <tag> (tools/gpu_profile.sh: bench line + rocprofv3 kernel stats + PMC traffic passes) | pmc <tag> (HBM traffic of the S = 32 loop: tools/gpu_pmc_multiseq.sh) |
+#        launchcount | launchcount2
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 step=$1; shift
@@ -24,12 +27,12 @@ case $step in
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 3 | tee $out/smoke.txt
     ;;
   pytest)
-    # selected tests: tools/gpu_r06.sh pytest <pytest args>
+    # selected tests: tools/gpu.sh pytest <pytest args>
     timeout 1500 python -m pytest -x -q -m gpu "$@" > $out/pytest_full.txt 2>&1
     grep -v "^  *[a-z_]* = \|^    " $out/pytest_full.txt | tail -n 60 | cut -c1-1500 | tee $out/pytest.txt
     ;;
   run)
-    # any developer tool: tools/gpu_r06.sh run <name> <command ...>   (output to gpurun_out/r06_run/<name>.txt)
+    # any developer tool: tools/gpu.sh run <name> <command ...>   (output to gpurun_out/r06_run/<name>.txt)
     name=$1; shift
     timeout 1500 "$@" 2>&1 | tail -n 200 | cut -c1-700 | tee $out/$name.txt
     ;;
@@ -49,7 +52,7 @@ print("cpu_baseline", cb.get("value"), cb.get("kind"), "speedup", d.get("speedup
 PY
     ;;
   batchprof)
-    # rocprofv3 kernel trace of the S-sequence loop: timeline of the tracking batches + kernel statistics.  tools/gpu_r06.sh batchprof <tag> [S]
+    # rocprofv3 kernel trace of the S-sequence loop: timeline of the tracking batches + kernel statistics.  tools/gpu.sh batchprof <tag> [S]
     tag=${1:-base}; S=${2:-32}
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_$tag -- python $R/tools/bench_multiseq.py --S $S --steps 30 --regions 2 > $R/$out/${tag}_bench.json 2> $R/$out/${tag}_err.txt)
     f=$(find $out/prof_$tag -name "*kernel_trace.csv" | head -1)
@@ -62,7 +65,7 @@ print(k, 'frames_s', d[k].get('frames_s'), 'block', d[k].get('frames_s_block_unt
     rm -rf $out/prof_$tag
     ;;
   ab)
-    # A/B of environment switches on the pure tracking batches and the S-sequence loop, alternating: tools/gpu_r06.sh ab <tag> "ENV=1 ..." ["ENV2=..."]
+    # A/B of environment switches on the pure tracking batches and the S-sequence loop, alternating: tools/gpu.sh ab <tag> "ENV=1 ..." ["ENV2=..."]
     tag=$1; shift
     for rep in 1 2; do
       i=0
@@ -81,7 +84,7 @@ for k in ('S8','S32'):
     ;;
   ablib)
     # same-box A/B of builds of liblsdhip.so (lsd_slam_amd/liblsdhip_<name>.so, build.build_variant), alternating with the default library:
-    # tools/gpu_r06.sh ablib <tag> <name> [<name> ...]   — the 4K regulariser (full frame, 8 bands), the S = 32 loop and the bench loop's keyframe time
+    # tools/gpu.sh ablib <tag> <name> [<name> ...]   — the 4K regulariser (full frame, 8 bands), the S = 32 loop and the bench loop's keyframe time
     tag=$1; shift
     for rep in 1 2; do
       for name in default "$@"; do
@@ -101,6 +104,14 @@ print('bench value %.0f keyframe_ms %.4f depth_mpix_per_s %.0f' % (d['value'], d
         unset LD_PRELOAD LSDHIP_LIB
       done
     done
+    ;;
+  profile)
+    # the round's profile set (bench line, rocprofv3 --kernel-trace --stats of the same command, FETCH_SIZE / WRITE_SIZE passes): tools/gpu_profile.sh
+    GRAFT_REPO_ROOT=$R bash tools/gpu_profile.sh ${1:-r06} 2>&1 | tail -n 40 | cut -c1-300
+    ;;
+  pmc)
+    # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) of the shared launches of the S = 32 loop against their durations
+    GRAFT_REPO_ROOT=$R bash tools/gpu_pmc_multiseq.sh ${1:-r06} 2>&1 | tail -n 60 | cut -c1-400
     ;;
   *) echo "unknown step $step"; exit 2;;
 esac
