@@ -113,5 +113,15 @@ print('bench value %.0f keyframe_ms %.4f depth_mpix_per_s %.0f' % (d['value'], d
     # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) of the shared launches of the S = 32 loop against their durations
     GRAFT_REPO_ROOT=$R bash tools/gpu_pmc_multiseq.sh ${1:-r06} 2>&1 | tail -n 60 | cut -c1-400
     ;;
+  repeat)
+    # the same tests N times in a row (fresh interpreter each time): tools/gpu.sh repeat <N> <pytest args>
+    n=$1; shift
+    ok=0
+    for i in $(seq 1 $n); do
+      if timeout 900 python -m pytest -x -q -m gpu "$@" > $out/run_$i.txt 2>&1; then ok=$((ok+1)); else echo "run $i FAILED"; tail -n 30 $out/run_$i.txt | cut -c1-300; fi
+      tail -n 1 $out/run_$i.txt
+    done
+    echo "repeat: $ok of $n runs green" | tee $out/summary.txt
+    ;;
   *) echo "unknown step $step"; exit 2;;
 esac
