@@ -135,7 +135,11 @@ int lsdhip_ctx_reserve_frames(lsdhip_ctx* ctx, int n);
 void lsdhip_frame_destroy(lsdhip_frame* f);
 int lsdhip_frame_id(lsdhip_frame* f);
 /* Frame::image/gradients/maxGradients/idepth/idepthVar(level) accessors (Frame.h:357-418), copied to host.
- * what: 0 image, 1 gradients (4 floats per pixel: gx,gy,I,0), 2 maxGradients (level 0), 3 idepth, 4 idepthVar */
+ * what: 0 image, 1 gradients (4 floats per pixel: gx,gy,I,0), 2 maxGradients (level 0), 3 idepth, 4 idepthVar,
+ * 5 (levels >= 1; not a member of the reference's Frame) the level's reference blocks as the tracker's throughput mode reads them: per 256
+ *   consecutive pixels the in-block offsets of the pixels TrackingReference::makePointCloud would take (TrackingReference.cpp:120-131),
+ *   compacted in pixel order (256 bytes per block; list slot s in byte (s mod 64) * 4 + s / 64), then one int32 count per block;
+ *   out_host holds ceil(pixels / 256) * 260 bytes */
 int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float* out_host);
 /* Frame::setDepthFromGroundTruth (Frame.cpp:245-293) */
 int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_host, float cov_scale);

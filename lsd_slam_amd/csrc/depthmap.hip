@@ -1930,7 +1930,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
     const size_t words = (size_t)((c->w + 31) / 32) * ((c->h + 7) / 8) * 16;
     if (!dm->d_obs_trace) HIPCHK(hipMalloc((void**)&dm->d_obs_trace, words * 8));
     HIPCHK(hipMemsetAsync(dm->d_obs_trace, 0, words * 8, lsd_map_stream(c)));
-    a.trace = dm->d_obs_trace;
+    a.trace = (decltype(a.trace))dm->d_obs_trace;
     dm->obs_trace_words = words;
   }
 #endif

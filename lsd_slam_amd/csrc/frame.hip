@@ -215,6 +215,7 @@ struct DepthPyrArgs {
   LSD_G const double* redPartials;
   int redN;
   LSD_G double* redOut;
+  LSD_G uint8_t* blk[LSD_LEVELS];   // reference blocks of levels >= 1 (k_ref_blocks)
 };
 
 // Levels 1..4 of (idepth, idepthVar) from level 0, one 32x32 level-0 tile per workgroup: every lane pools one 2x2 block of level 0
@@ -301,6 +302,70 @@ __global__ __launch_bounds__(256) void k_idepth_pyramid(DepthPyrArgs a) { idepth
 __global__ __launch_bounds__(256) void k_idepth_pyramid_batch(const DepthPyrArgs* __restrict__ items) {
   const DepthPyrArgs a = items[blockIdx.z];
   idepth_pyramid_tile(a);
+}
+
+// Reference blocks of the idepth pyramid's levels >= 1: which pixels of a level are reference points of a tracking job — inside the
+// one-pixel border, idepthVar > 0, idepth != 0: the test of TrackingReference::makePointCloud (C/Tracking/TrackingReference.cpp:120-131) —
+// depends on the keyframe's planes alone, and a throughput-mode batch asks it of every pixel in every evaluation (8 bytes per pixel, four
+// ballots per 1024 pixels, a barrier).  Answered once per pyramid instead: one wave per block of 256 consecutive pixels leaves the
+// in-block offsets of the block's valid pixels, in pixel order, in the block's 256 bytes (slot-interleaved, below), and the count in the table behind the blocks;
+// strips are multiples of 256 pixels, so a strip's list is the concatenation of its blocks' lists — no scan over the level.
+__device__ __forceinline__ void ref_blocks_tile(const DepthPyrArgs& a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int gb = blockIdx.x * 4 + wave;
+  int l = 1, w = a.w0 >> 1, h = a.h0 >> 1;
+  for (; l < LSD_LEVELS; l++) {
+    const int nb = (w * h + 255) >> 8;
+    if (gb < nb) break;
+    gb -= nb;
+    w >>= 1; h >>= 1;
+  }
+  if (l >= LSD_LEVELS) return;
+  const int work = w * h, nblk = (work + 255) >> 8;
+  const int i0 = gb * 256 + lane * 4;
+  LSD_G const float* id = nullptr;
+  LSD_G const float* var = nullptr;
+  LSD_G uint8_t* blk = nullptr;
+#pragma unroll
+  for (int q = 1; q < LSD_LEVELS; q++)          // (no dynamic index into the argument record: it would move to scratch memory)
+    if (q == l) { id = a.id[q]; var = a.var[q]; blk = a.blk[q]; }
+  unsigned m = 0;
+  int y = i0 / w, x = i0 - y * w;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = i0 + k;
+    if (i < work) {
+      const float vv = var[i], dd = id[i];
+      const bool ok = !(x < 1 || x >= w - 1 || y < 1 || y >= h - 1) && !(vv <= 0 || dd == 0);
+      m |= (ok ? 1u : 0u) << k;
+    }
+    if (++x >= w) { x = 0; y++; }
+  }
+  const int cnt = __popc(m);
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  LSD_G uint8_t* out = blk + (size_t)gb * 256;
+  // slot s of the block's list lives in byte (s mod 64) * 4 + s / 64: the reader's lane l takes one 4-byte word = slots l, l + 64, l + 128,
+  // l + 192, so the lanes of a wave fill consecutive list entries (no LDS bank conflicts)
+  int pos = incl - cnt;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if ((m >> k) & 1u) { out[((pos & 63) << 2) + (pos >> 6)] = (uint8_t)(lane * 4 + k); pos++; }
+  if (lane == 63) ((LSD_G int*)(blk + (size_t)nblk * 256))[gb] = incl;
+}
+__global__ __launch_bounds__(256) void k_ref_blocks(DepthPyrArgs a) { ref_blocks_tile(a); }
+__global__ __launch_bounds__(256) void k_ref_blocks_batch(const DepthPyrArgs* __restrict__ items) {
+  const DepthPyrArgs a = items[blockIdx.z];
+  ref_blocks_tile(a);
+}
+static int lsd_refblk_grid(const lsdhip_ctx* c) {
+  int nb = 0;
+  for (int l = 1; l < LSD_LEVELS; l++) nb += lsd_refblk_blocks(c->wl[l] * c->hl[l]);
+  return (nb + 3) / 4;
 }
 
 // Frame::setDepthFromGroundTruth
@@ -724,7 +789,7 @@ int lsd_gate_open(lsdhip_ctx* c) {
 // Frame::setDepth result of the mapping stream becomes what SE3Tracker jobs read.  A no-op on non-pipelined contexts.
 int lsd_frame_publish_depth(lsdhip_frame* f) {
   if (!f->depthPending) return LSDHIP_OK;
-  for (int l = 0; l < LSD_LEVELS; l++) { std::swap(f->d_idepth[l], f->d_idepthW[l]); std::swap(f->d_idepthVar[l], f->d_idepthVarW[l]); }
+  for (int l = 0; l < LSD_LEVELS; l++) { std::swap(f->d_idepth[l], f->d_idepthW[l]); std::swap(f->d_idepthVar[l], f->d_idepthVarW[l]); std::swap(f->d_refBlk[l], f->d_refBlkW[l]); }
   f->depthPending = false;
   f->depthSeq = f->depthPendingSeq;
   f->hasIDepth = true;
@@ -1102,6 +1167,8 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   take(n0);
   for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);   // second depth plane set (pipelined contexts)
   for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
+  for (int s2 = 0; s2 < 2; s2++)                                                 // reference blocks of levels >= 1, one set per depth plane set
+    for (int l = 1; l < LSD_LEVELS; l++) take(lsd_refblk_bytes(c->wl[l] * c->hl[l]));
   char* base = nullptr;
   c->arena_bytes = align_up(off, 256);
   if (!c->free_arenas.empty()) {
@@ -1125,6 +1192,8 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   f->d_validity_reAct = (uint8_t*)(base + offs[k++]);
   for (int l = 0; l < LSD_LEVELS; l++) f->d_idepthW[l] = (float*)(base + offs[k++]);
   for (int l = 0; l < LSD_LEVELS; l++) f->d_idepthVarW[l] = (float*)(base + offs[k++]);
+  for (int l = 1; l < LSD_LEVELS; l++) f->d_refBlk[l] = (uint8_t*)(base + offs[k++]);
+  for (int l = 1; l < LSD_LEVELS; l++) f->d_refBlkW[l] = (uint8_t*)(base + offs[k++]);
   *out = f;
   return LSDHIP_OK;
 }
@@ -1168,7 +1237,9 @@ int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, i
   for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = lsd_g(id[l]); a.var[l] = lsd_g(var[l]); }
   a.w0 = c->w; a.h0 = c->h;
   a.redPartials = lsd_g(redPartials); a.redN = redN; a.redOut = lsd_g(redOut);
+  for (int l = 0; l < LSD_LEVELS; l++) a.blk[l] = lsd_g(lsd_refblk_w(f)[l]);
   hipLaunchKernelGGL(k_idepth_pyramid, dim3((c->w + 31) / 32, (c->h + 31) / 32 + (redPartials ? 1 : 0)), dim3(256), 0, lsd_map_stream(c), a);
+  hipLaunchKernelGGL(k_ref_blocks, dim3(lsd_refblk_grid(c)), dim3(256), 0, lsd_map_stream(c), a);
   HIPCHK(hipGetLastError());
   if (c->pipeline) { f->depthPending = true; f->depthPendingSeq = c->mSeq + 1; }   // complete at the caller's record point
   else f->hasIDepth = true;
@@ -1248,11 +1319,13 @@ int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double*
     for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = lsd_g(id[l]); a.var[l] = lsd_g(var[l]); }
     a.w0 = c->w; a.h0 = c->h;
     a.redPartials = lsd_g(redPartials[j]); a.redN = redNs ? redNs[j] : redN; a.redOut = lsd_g(redOut[j]);
+    for (int l = 0; l < LSD_LEVELS; l++) a.blk[l] = lsd_g(lsd_refblk_w(f)[l]);
   }
   void* dev = nullptr;
   int rc = lsd_args_push(c, items.data(), sizeof(DepthPyrArgs) * (size_t)n, lsd_map_stream(c), &dev);
   if (rc) return rc;
   hipLaunchKernelGGL(k_idepth_pyramid_batch, dim3((c->w + 31) / 32, (c->h + 31) / 32 + 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
+  hipLaunchKernelGGL(k_ref_blocks_batch, dim3(lsd_refblk_grid(c), 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
   HIPCHK(hipGetLastError());
   rc = lsd_args_release(c, dev, lsd_map_stream(c));
   if (rc) return rc;
@@ -1438,6 +1511,14 @@ extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float
     // Frame::idepth / idepthVar: what the last Frame::setDepth left (on pipelined contexts possibly not yet published to the tracker)
     case 3: if (!f->hasIDepth && !f->depthPending) return LSDHIP_E_STATE; src = lsd_depth_latest(f)[level]; break;
     case 4: if (!f->hasIDepth && !f->depthPending) return LSDHIP_E_STATE; src = lsd_depthvar_latest(f)[level]; break;
+    // the level's reference blocks (k_ref_blocks), as bytes: ceil(pixels / 256) x 256 offsets, then one int32 count per block
+    case 5:
+      if (!f->hasIDepth && !f->depthPending) return LSDHIP_E_STATE;
+      if (level < 1) return LSDHIP_E_ARG;
+      src = (f->depthPending ? f->d_refBlkW : f->d_refBlk)[level];
+      HIPCHK(hipMemcpyAsync(out, src, lsd_refblk_bytes((int)n), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return LSDHIP_OK;
     default: return LSDHIP_E_ARG;
   }
   HIPCHK(hipMemcpyAsync(out, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));

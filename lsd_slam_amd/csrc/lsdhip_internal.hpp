@@ -55,6 +55,8 @@ struct TrackLevel {
   const float* kf_idepth;    // keyframe (reference) planes at this level
   const float* kf_idepthVar;
   const float* kf_image;
+  const uint8_t* kf_refBlk;  // reference blocks of the level (k_ref_blocks, frame.hip): per 256 consecutive pixels the in-block offsets of the valid
+                             // reference pixels, compacted in pixel order (256 bytes), and behind all of them one count per block
   const float4* fr_grad;     // tracked-frame texels (gx, gy, I, 0)
   const float* pts_pos;      // explicit point list (permaref path) instead of keyframe planes; npts < 0 => dense grid
   const float* pts_colvar;
@@ -100,6 +102,9 @@ struct TrackSpec {
   unsigned long long dbgCum;         // developer build LSD_ORDER_CHECK: workgroups of all launches queued before this one
   unsigned long long* dbgCounters;   // ... [0] workgroups finished, [1] workgroups that started before all earlier ones had finished, [2] largest deficit seen
   int last;                  // 1: the last launch of the enqueued budget — if the job is not finished when it ends it says so (TrackSummary::exhausted)
+#ifdef LSD_PHASE_TRACE
+  int traceWg;               // developer build: the workgroup (blockIdx.x of job 0) of a batch launch that leaves the per-phase timestamps
+#endif
 #ifdef LSD_DEVTOOLS
   int* dbgLog;               // developer build: 16 ints per launch of the job (slot = launch ordinal), written by workgroup 0 — tools/launch_count_stress.py
 #endif
@@ -295,6 +300,10 @@ struct lsdhip_frame {
   long long depthSeq = 0;               // M-sequence the published planes are complete at (0: written synchronously)
   long long readySeq = 0;               // M-sequence the image pyramids are complete at (0: built on `stream` / synchronously)
   unsigned depthVersion = 0;            // incremented whenever the idepth / idepthVar pyramids are rewritten (setDepth)
+  // reference blocks of levels >= 1, written behind every idepth pyramid (k_ref_blocks) and published with it: what the strips of a
+  // throughput-mode tracking batch read instead of scanning the level's validity (TrackLevel::kf_refBlk)
+  uint8_t* d_refBlk[LSD_LEVELS] = {};
+  uint8_t* d_refBlkW[LSD_LEVELS] = {};
   uint8_t* d_wasGood = nullptr;         // level-1 mask (lazily created, 0xFF)
   bool wasGoodValid = false;
   bool wasGoodPristine = false;         // the mask still holds the 0xFF fill of frame creation
@@ -499,6 +508,9 @@ inline void lsd_trace_val(lsdhip_ctx*, int, int, unsigned long long) {}
 // depth planes a Frame::setDepth writes / the most recently written ones (== d_idepth on non-pipelined contexts)
 inline float** lsd_depth_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthW : f->d_idepth; }
 inline float** lsd_depthvar_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthVarW : f->d_idepthVar; }
+inline uint8_t** lsd_refblk_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_refBlkW : f->d_refBlk; }
+inline int lsd_refblk_blocks(int pixels) { return (pixels + 255) >> 8; }
+inline size_t lsd_refblk_bytes(int pixels) { return (size_t)lsd_refblk_blocks(pixels) * (256 + 4); }
 inline float** lsd_depth_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthW : f->d_idepth; }
 inline float** lsd_depthvar_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthVarW : f->d_idepthVar; }
 int lsd_frame_publish_depth(lsdhip_frame* f);

@@ -32,7 +32,8 @@
 
 
 #ifdef LSD_PHASE_TRACE
-#define PHASE_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) tr_[k] = clock64(); } while (0)
+#define PHASE_MARK(k) do { if (trOn_ && threadIdx.x == 0) tr_[k] = clock64(); } while (0)
+#define LSD_TRACE_WORDS 32
 #else
 #define PHASE_MARK(k) do { } while (0)
 #endif
@@ -142,12 +143,15 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 #ifdef LSD_PHASE_TRACE
   __shared__ unsigned long long* s_trp;
   unsigned long long* tr_ = sc.trace;
-  if (blockIdx.x == 0 && tid == 0) {
+  // the traced workgroup: workgroup 0 (batches: workgroup LSDHIP_TRACE_WG of job 0; tools/phase_trace_batch.py)
+  const bool trOn_ = sc.trace != nullptr && (int)blockIdx.x == (BATCH ? spec.traceWg : 0) && (!BATCH || blockIdx.y == 0);
+  if (trOn_ && tid == 0) {
     unsigned long long n = sc.trace[0];
     sc.trace[0] = n + 1;
-    tr_ = sc.trace + 1 + (n % 4096) * 20;
-    for (int k = 0; k < 20; k++) tr_[k] = 0;
+    tr_ = sc.trace + 1 + (n % 4096) * LSD_TRACE_WORDS;
+    for (int k = 0; k < LSD_TRACE_WORDS; k++) tr_[k] = 0;
     tr_[8] = wall_clock64();
+    tr_[24] = (unsigned long long)gridDim.x; tr_[25] = (unsigned long long)gridDim.y;
     s_trp = tr_;
   }
 #endif
@@ -215,6 +219,35 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     bx = (int)blockIdx.x - cand * nbl;
   }
 
+  // Throughput-mode strips (batches): the strip's list is the concatenation of its reference blocks (k_ref_blocks, frame.hip).  The loads —
+  // one block count per lane (at most 32 blocks), one word of four offsets per lane and step — depend on the level alone, not on the pose:
+  // a (trial, strip) workgroup that is going to evaluate at the pending level (the usual case; a level ends three times per job) requests
+  // them at the head of the finishing phase, so they travel with the previous round's partial sums instead of behind the LM step.
+  constexpr int CHMAX = 8;                       // tilePx <= 8192 (fill_level): 32 blocks, 8 steps of 4 waves
+  int cntv = 0;
+  unsigned ow[CHMAX];
+  auto strip_request = [&](const int lvl, const int tile_) {
+    const TrackLevel& L = job.lv[lvl];
+    const int px = L.w * L.h;
+    const int base_ = tile_ * L.tilePx;
+    const int b0_ = base_ >> 8;
+    const int mblk_ = (min(base_ + L.tilePx, px) - base_ + 255) >> 8;
+    const gbyte* offs = (const gbyte*)L.kf_refBlk;
+    const __attribute__((address_space(1))) int* cnts = (const __attribute__((address_space(1))) int*)(offs + ((size_t)((px + 255) >> 8) << 8));
+    cntv = lane < mblk_ ? cnts[b0_ + lane] : 0;
+#pragma unroll
+    for (int c = 0; c < CHMAX; c++) {
+      const int blk = c * 4 + wave;
+      ow[c] = blk < mblk_ ? *(const __attribute__((address_space(1))) unsigned*)(offs + ((size_t)(b0_ + blk) << 8) + (lane << 2)) : 0u;
+    }
+  };
+  bool havePre = false;
+  if (BATCH && MODE == TS_FUSED && S.pending && job.lv[lvlPending].tilePx > 0) {
+    const int tr = (spec.specC > 1 && spec.trials[lvlPending] > 1) ? spec.trials[lvlPending] : 1;
+    havePre = cand < tr;
+    if (havePre) strip_request(lvlPending, xcd_tile(bx, job.lv[lvlPending].nblocks));
+  }
+
   if (MODE != TS_EVAL && S.pending) {
     // Finish the trials of the previous launch, in the order the LM loop would have run them.  All their partial sums, order
     // keys and tail contributions are fetched TOGETHER (one memory round trip, whatever the number of trials), then wave 0 walks
@@ -268,7 +301,9 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
             if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
           }
         };
-        const bool single = job.lv[level].singlePass != 0;
+        // the owners of the keys left their K2/K3 contributions next to them: single-pass levels (one point per lane) and the strips of
+        // a throughput-mode batch (the three largest keys of a strip are re-evaluated at the end of its launch)
+        const bool single = job.lv[level].singlePass != 0 || job.lv[level].tilePx > 0;
         const int j = lane & 31, rj = lane >> 5;
         int keysA[3], srcA[3], keysB[3], srcB[3];
         float a0 = 0.f, a2 = 0.f, b0 = 0.f, b2 = 0.f;
@@ -339,13 +374,70 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
           }
         }
       };
+      // Strips of a throughput-mode batch, at most 24 per job: a strip's launch leaves one 32-float row per candidate — its (up to) three
+      // largest keys' K2/K3 contributions [0..28] and the key itself [31] — so ALL rows of the job travel in the same round trip as the
+      // partial sums (NQ 16-byte loads per lane), the three largest keys are picked from the rows in registers, and their rows go to the
+      // tail table: no second, dependent round trip (the keys first, then the owners' contributions) in front of the LM step.
+      auto tail_rows = [&](const int ca, const int cb, auto nqn) {
+        constexpr int NQ = decltype(nqn)::value;   // NQ * 64 >= nb * 24 (16-byte words of the rows)
+        const int cbb = cb < 0 ? ca : cb;
+        const float4* ta = (const float4*)(topval_in0 + (size_t)ca * max_rows * 96);
+        const float4* tb = (const float4*)(topval_in0 + (size_t)cbb * max_rows * 96);
+        const int nf4 = nb * 24;
+        float4 va[NQ], vb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int f = q * 64 + lane;
+          va[q] = ta[f < nf4 ? f : 0];   // unconditional, issued together
+          vb[q] = tb[f < nf4 ? f : 0];
+        }
+        auto pick = [&](const float4 (&v)[NQ], const int c) {
+          int k0 = -1, k1 = -1, k2 = -1, e0 = 0, e1 = 0, e2 = 0;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const int f = q * 64 + lane;
+            const int k = ((lane & 7) == 7 && f < nf4) ? __float_as_int(v[q].w) : -1, ek = f >> 3;   // the row's key sits in its last word
+            const bool g0 = k > k0, g1 = k > k1, g2 = k > k2;
+            k2 = g1 ? k1 : (g2 ? k : k2); e2 = g1 ? e1 : (g2 ? ek : e2);
+            k1 = g0 ? k0 : (g1 ? k : k1); e1 = g0 ? e0 : (g1 ? ek : e1);
+            k0 = g0 ? k : k0; e0 = g0 ? ek : e0;
+          }
+          int nsub = 0;
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            const int m = __builtin_amdgcn_readlane(wave_max_to_lane63(k0), 63);
+            const unsigned long long own = __ballot(k0 == m && m >= 0);
+            const int owner = own ? (int)__ffsll((long long)own) - 1 : 0;
+            const int row = __builtin_amdgcn_readlane(e0, owner);
+            if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
+            if (m >= 0) {
+              nsub++;
+              // (written as a chain of selects: a store under `q == row / 8` becomes an indexed read of v[], i.e. scratch memory)
+              float4 w4 = v[0];
+#pragma unroll
+              for (int q = 1; q < NQ; q++) {
+                const bool here = ((q * 64 + lane) >> 3) == row;
+                w4.x = here ? v[q].x : w4.x; w4.y = here ? v[q].y : w4.y; w4.z = here ? v[q].z : w4.z; w4.w = here ? v[q].w : w4.w;
+              }
+              if ((lane >> 3) == (row & 7)) *(float4*)&s_subT[c][r][(lane & 7) * 4] = w4;
+            }
+          }
+          if (lane == 0) s_nsubT[c] = nsub;
+        };
+        pick(va, ca);
+        if (cb >= 0) pick(vb, cb);
+      };
     // this wave's share of the tail work, run between the issue of the column-sum loads and their additions
     auto wave_tail = [&]() {
       // trial c -> wave WAVES-1 - (c mod WAVES): the last wave first (it has no column sums to add)
       const int ca = WAVES - 1 - wave;
       const int cb = ca + WAVES < ncandPending ? ca + WAVES : -1;
       if (ca < ncandPending) {
-        if (nb <= 128) tail_two(ca, cb, std::integral_constant<int, 2>());
+        if (BATCH && job.lv[level].tilePx > 0 && nb <= 24) {
+          if (nb <= 5) tail_rows(ca, cb, std::integral_constant<int, 2>());
+          else if (nb <= 13) tail_rows(ca, cb, std::integral_constant<int, 5>());
+          else tail_rows(ca, cb, std::integral_constant<int, 9>());
+        } else if (nb <= 128) tail_two(ca, cb, std::integral_constant<int, 2>());
         else tail_two(ca, cb, std::integral_constant<int, 5>());
       }
     };
@@ -404,13 +496,13 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
         else if (K <= 10) { for (int base = 0; base < ncandPending; base += 3) colsum(std::integral_constant<int, 10>(), I3(), base); }
         else { for (int base = 0; base < ncandPending; base++) colsum(std::integral_constant<int, QMAX>(), I1(), base); }
 #ifdef LSD_PHASE_TRACE
-        if (blockIdx.x == 0 && tid == 0) tr_[17] = clock64();
+        if (trOn_ && tid == 0) tr_[17] = clock64();
 #endif
       }
     }
     wave_tail();
 #ifdef LSD_PHASE_TRACE
-    if (blockIdx.x == 0 && tid == SUMW * 64) s_trp[18] = clock64();
+    if (trOn_ && tid == SUMW * 64) s_trp[18] = clock64();
 #endif
     __syncthreads();
     PHASE_MARK(2);
@@ -507,8 +599,8 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 #endif
         PHASE_MARK(3);
 #ifdef LSD_PHASE_TRACE
-        if (blockIdx.x == 0 && tid == 0) { tr_[19] = (unsigned long long)ncandPending; tr_[7] = (unsigned long long)pc; }
-        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, leader ? tr_ : nullptr, pc, cand, doneWord);
+        if (trOn_ && tid == 0) { tr_[19] = (unsigned long long)ncandPending; tr_[7] = (unsigned long long)pc; }
+        lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, trOn_ ? tr_ : nullptr, pc, cand, doneWord);
 #else
         lm_wave<SPEC_LM>(s_par, S, s, sh.tot, tid, leader ? out : nullptr, nullptr, pc, cand, doneWord);
 #endif
@@ -588,71 +680,51 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     // compacts the strip's valid reference pixels (semi-dense: ~30 %) into an LDS list — fixed order: chunk, then pixel
     // slot, then lane, so the result is run-to-run deterministic — and then evaluates the list with all lanes busy.
     unsigned* s_list = (unsigned*)s_red;   // (x | y << 16); s_red is not live before the reduction
+    // The strip's list is the concatenation of its reference blocks (k_ref_blocks, frame.hip: per 256 consecutive pixels the offsets of the
+    // valid ones, compacted in pixel order, and a count): wave v takes block 4 c + v of the strip in step c, lane l its slots l, l + 64, ...;
+    // every wave derives the blocks' places in the list from the counts itself (at most 32 blocks: one lane each), so nothing is exchanged
+    // and the only barrier is the one in front of the evaluation.  (Until round 6 the strip streamed the level's validity planes, 8 bytes per
+    // pixel, and compacted them with four ballots per 1024 pixels in every evaluation: a quarter of a level-1 round at 64 jobs.)
     const int tilePx = job.lv[level].tilePx;
     const int base = tile * tilePx;
-    const int nchunk = (tilePx + 1023) >> 10;     // strips are multiples of 256 pixels: the last chunk may be partial
     const int stripEnd = min(base + tilePx, work);
+    const int b0 = base >> 8;                                  // strips are multiples of 256 pixels
+    const int mblk = (stripEnd - base + 255) >> 8;             // <= 32 (tilePx <= 8192, fill_level)
     const float inv_w = 1.0f / (float)a.w;
-    unsigned vmask = 0;      // 4 validity bits per chunk
-    int wcount = 0;          // valid pixels of this wave (uniform)
-    // all validity loads of the strip are issued together (one memory round trip instead of one per 1024-pixel chunk)
-    constexpr int CHMAX = 8;                       // tilePx <= 8192 (fill_level)
-    v4f v4s[CHMAX], d4s[CHMAX];
+    if (!(havePre && level == lvlPending)) strip_request(level, tile);   // (else: requested next to the state, at the head of the finishing phase)
+    int incl = cntv;
 #pragma unroll
-    for (int c = 0; c < CHMAX; c++) {
-      const int i0 = base + (c << 10) + (tid << 2);
-      // work is a multiple of 4 whenever the level width is (checked on the host): the 4 pixels exist together
-      const bool in = c < nchunk && i0 < stripEnd;
-      const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
-      v4s[c] = in ? *(gv4f*)(a.kf_idepthVar + i0) : zero4;
-      d4s[c] = in ? *(gv4f*)(a.kf_idepth + i0) : zero4;
+    for (int d = 1; d < 32; d <<= 1) {
+      const int tv = __shfl_up(incl, d);
+      if (lane >= d) incl += tv;
     }
+    const int total = __shfl(incl, 31);
+    PHASE_MARK(20);
 #pragma unroll
     for (int c = 0; c < CHMAX; c++) {
-      if (c < nchunk) {
-        const int i0 = base + (c << 10) + (tid << 2);
-        if (i0 < stripEnd) {
-          int y = (int)((float)i0 * inv_w);
-          int x = i0 - y * a.w;
-          if (x < 0) { y--; x += a.w; }
-          if (x >= a.w) { y++; x -= a.w; }
-          const float vv[4] = {v4s[c].x, v4s[c].y, v4s[c].z, v4s[c].w}, dd[4] = {d4s[c].x, d4s[c].y, d4s[c].z, d4s[c].w};
+      const int blk = c * 4 + wave;                            // wave-uniform
+      if (blk < mblk) {
+        const int cb = __shfl(cntv, blk);
+        const int pb = __shfl(incl, blk) - cb;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const bool ok = !(x < 1 || x >= a.w - 1 || y < 1 || y >= a.h - 1) && !(vv[k] <= 0 || dd[k] == 0);
-            vmask |= (ok ? 1u : 0u) << (c * 4 + k);
-            if (++x >= a.w) { x = 0; y++; }
+        for (int k = 0; k < 4; k++) {
+          const int sl = lane + 64 * k;                       // (the block's bytes are slot-interleaved: k_ref_blocks)
+          if (sl < cb) {
+            const int i = ((b0 + blk) << 8) + (int)((ow[c] >> (8 * k)) & 255u);
+            int y = (int)((float)i * inv_w);
+            int x = i - y * a.w;
+            if (x < 0) { y--; x += a.w; }
+            if (x >= a.w) { y++; x -= a.w; }
+            s_list[pb + sl] = (unsigned)x | ((unsigned)y << 16);
           }
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) wcount += __popcll(__ballot((vmask >> (c * 4 + k)) & 1u));
-      }
-    }
-    if (lane == 0) s_wtop[wave][0] = wcount;
-    __syncthreads();
-    int pos = 0, total = 0;
-#pragma unroll
-    for (int wv = 0; wv < WAVES; wv++) {
-      const int cw = s_wtop[wv][0];
-      if (wv < wave) pos += cw;
-      total += cw;
-    }
-    for (int c = 0; c < nchunk; c++) {
-      const int i0 = base + (c << 10) + (tid << 2);
-      int y = (int)((float)i0 * inv_w);
-      int x = i0 - y * a.w;
-      if (x < 0) { y--; x += a.w; }
-      if (x >= a.w) { y++; x -= a.w; }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const bool ok = (vmask >> (c * 4 + k)) & 1u;
-        const unsigned long long bal = __ballot(ok);
-        if (ok) s_list[pos + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned)x | ((unsigned)y << 16);
-        pos += __popcll(bal);
-        if (++x >= a.w) { x = 0; y++; }
       }
     }
     __syncthreads();
+    PHASE_MARK(21);
+#ifdef LSD_PHASE_TRACE
+    if (trOn_ && tid == 0) tr_[23] = (unsigned long long)total;
+#endif
     if (total > 0) {
       // three-stage software pipeline over the list entries tid, tid + BLOCK, ...: (A) list entry + keyframe planes,
       // (B) reference point, warp, texel fetch, (C) residual / weights / normal equations.  Stage A of entry r + 2 and
@@ -685,6 +757,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       stageA(tid, A1);
       stageB(A1, B0);
       stageA(tid + BLOCK, A1);
+      PHASE_MARK(22);
       auto stageC = [&](const StB& B) {
         if (B.live) {
           const int x_ = (int)(B.xy & 0xffffu), y_ = (int)(B.xy >> 16);
@@ -733,13 +806,38 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
 
   PHASE_MARK(5);
 #ifdef LSD_PHASE_TRACE
-  if (blockIdx.x == 0 && tid == 0) { tr_[10] = (unsigned long long)level; tr_[11] = (unsigned long long)nb; }
+  if (trOn_ && tid == 0) { tr_[10] = (unsigned long long)level; tr_[11] = (unsigned long long)nb; tr_[26] = (unsigned long long)lvlPending; }
 #endif
   // workgroup reduction through LDS: every lane parks its 41 accumulators in column `tid` of s_red (row stride
   // BLOCK + 1: conflict-free both ways), then thread (slice, k) adds a contiguous run of lanes of row k in lane order
   // and 41 threads add the slices — ~130 instructions per wave instead of 41 x 7 DPP steps
   constexpr int RSLICE = BLOCK / CPP;                  // slices per row
   constexpr int RRUN = (BLOCK + RSLICE - 1) / RSLICE;  // lanes per slice
+  // Strips of a throughput-mode batch: the (up to) three in-image points of the strip with the largest reference-order keys are
+  // candidates for the job's tail (the last M % 4 in-image points, which the SSE loops of the reference leave out): three lanes evaluate
+  // them once more, alone, and leave their K2/K3 contributions in the strip's candidate rows — the launch that finishes this evaluation
+  // then needs no evaluation of its own in front of the LM step (it used to: keys, reference point, texels = three dependent round
+  // trips).  The two round trips of this evaluation run under the barriers of the reduction.
+  const bool stripRows = BATCH && job.lv[level].tilePx > 0;
+  const bool candLane = tid >= BLOCK - 64 && tid < BLOCK - 61;   // lanes 0..2 of the LAST wave: wave 0 adds the slices and stores the sums meanwhile
+  int cKey = -1, cX = 0, cY = 0;
+  float cVar = 0.f, cId = 1.f, cImg = 0.f, cPz = 0.f;
+  PointWarp cq;
+  PointTexels ct;
+  if (stripRows) {
+    block_top3(key0, key1, key2, s_wtop, s_top);
+    if (candLane) {
+      cKey = s_top[tid - (BLOCK - 64)];
+      if (cKey >= 0) {
+        cX = cKey / a.h;
+        cY = cKey - cX * a.h;
+        const int ci = __mul24(cY, a.w) + cX;
+        cVar = a.kf_idepthVar[ci];
+        cId = a.kf_idepth[ci];
+        cImg = a.kf_image[ci];
+      }
+    }
+  }
 #pragma unroll
   for (int hp = 0; hp < NPASS; hp++) {
     if (hp > 0) __syncthreads();
@@ -748,6 +846,13 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       if (hp * CPP + k < RS_END) s_red[k * (BLOCK + 1) + tid] = acc[hp * CPP + k];
     __syncthreads();
     if (MODE == TS_FUSED && hp == 0 && tid == 0) { S.pending = 1; S.numLaunches = S.numLaunches + 1; }   // every wave is past its reads of S.pending
+    if (stripRows && hp == 0 && candLane && cKey >= 0) {
+      const float inv = lsd_rcp_exact(cId);                // (fetch_point's arithmetic)
+      const float px = inv * (a.fxi * cX + a.cxi), py = inv * (a.fyi * cY + a.cyi);
+      cPz = inv * 1.0f;
+      eval_warp(a, px, py, cPz, cq);
+      eval_fetch(a, cq, cq.in_image, ct);
+    }
     {
       const int slice = tid / CPP, k = tid - slice * CPP;
       if (slice < RSLICE) {
@@ -763,6 +868,26 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       }
     }
     __syncthreads();
+    if (stripRows && hp == 0 && candLane) {
+      float* row = topval_out + (size_t)(tile * 3 + (tid - (BLOCK - 64))) * 32;
+      if (cKey >= 0) {
+        PointOut o;
+        eval_finish(a, cq, ct, cPz, cImg, cVar, o);
+        row[0] = o.werr;
+        int k = 1;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) {
+          const float Jw = o.J[rr] * o.w;
+#pragma unroll
+          for (int cc = rr; cc < 6; cc++) row[k++] = Jw * o.J[cc];
+        }
+        const float resw = o.res * o.w;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) row[k++] = resw * o.J[rr];
+        row[k++] = resw * o.res;
+      }
+      ((int*)row)[31] = cKey;
+    }
     if (tid < CPP && hp * CPP + tid < RS_END) {
       float s = s_sum[0][tid];
 #pragma unroll
@@ -770,7 +895,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       sums_out[(size_t)tile * RS_COLS + (hp * CPP + tid)] = s;
     }
   }
-  block_top3(key0, key1, key2, s_wtop, s_top);
+  if (!stripRows) block_top3(key0, key1, key2, s_wtop, s_top);
   if (tid == 0) topkey_out[tile] = make_int4(s_top[0], s_top[1], s_top[2], -1);
   if (job.lv[level].singlePass && key0 >= 0) {
     // one point per lane: its accumulators are exactly its K2/K3 contributions (0 + x == x)
@@ -794,7 +919,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   LAUNCH_LOG(3, pendingIn_, ncandIn_, S.lastCand);
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
-  if (blockIdx.x == 0 && tid == 0) tr_[9] = wall_clock64();
+  if (trOn_ && tid == 0) tr_[9] = wall_clock64();
 #endif
 }
 
@@ -929,8 +1054,8 @@ extern "C" int lsdhip_tracker_create(lsdhip_ctx* c, lsdhip_tracker** out) {
   HIPCHK(hipMalloc((void**)&t->d_state, 2 * sizeof(TrackState)));
   HIPCHK(hipMemsetAsync(t->d_state, 0, 2 * sizeof(TrackState), c->stream));
 #ifdef LSD_PHASE_TRACE
-  HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * 20) * 8));
-  HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * 20) * 8, c->stream));
+  HIPCHK(hipMalloc((void**)&t->d_trace, (1 + 4096 * LSD_TRACE_WORDS) * 8));
+  HIPCHK(hipMemsetAsync(t->d_trace, 0, (1 + 4096 * LSD_TRACE_WORDS) * 8, c->stream));
 #endif
   HIPCHK(hipHostMalloc((void**)&t->h_summary, sizeof(TrackSummary), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&t->d_summary, t->h_summary, 0));
@@ -978,12 +1103,12 @@ extern "C" void lsdhip_tracker_destroy(lsdhip_tracker* t) {
   if (t->d_dbg) (void)hipFree(t->d_dbg);
 #ifdef LSD_PHASE_TRACE
   if (const char* path = getenv("LSDHIP_TRACE_FILE")) {
-    std::vector<unsigned long long> h(1 + 4096 * 20);
+    std::vector<unsigned long long> h(1 + 4096 * LSD_TRACE_WORDS);
     if (hipMemcpy(h.data(), t->d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
       if (FILE* f = fopen(path, "w")) {
         unsigned long long n = h[0] < 4096 ? h[0] : 4096;
         for (unsigned long long i = 0; i < n; i++) {
-          for (int k = 0; k < 20; k++) fprintf(f, "%llu ", h[1 + i * 20 + k]);
+          for (int k = 0; k < LSD_TRACE_WORDS; k++) fprintf(f, "%llu ", h[1 + i * LSD_TRACE_WORDS + k]);
           fprintf(f, "\n");
         }
         fclose(f);
@@ -1090,8 +1215,10 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   if (npts >= 0) {
     L.pts_pos = pts_pos; L.pts_colvar = pts_colvar; L.npts = npts;
     L.kf_idepth = L.kf_idepthVar = L.kf_image = nullptr;
+    L.kf_refBlk = nullptr;
   } else {
     L.kf_idepth = kf->d_idepth[level]; L.kf_idepthVar = kf->d_idepthVar[level]; L.kf_image = kf->d_image[level];
+    L.kf_refBlk = kf->d_refBlk[level];
     L.pts_pos = L.pts_colvar = nullptr; L.npts = -1;
   }
   int work = npts >= 0 ? npts : L.w * L.h;
@@ -1102,7 +1229,7 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   if (L.nblocks < 1) L.nblocks = 1;
   L.singlePass = (long long)L.nblocks * t->block >= work ? 1 : 0;
   L.tilePx = 0;
-  if (t->batch_jobs >= LSD_BATCH_THROUGHPUT_MIN_JOBS && npts < 0 && (L.w & 3) == 0) {
+  if (t->batch_jobs >= LSD_BATCH_THROUGHPUT_MIN_JOBS && npts < 0 && L.kf_refBlk != nullptr) {   // (levels >= 1: level 0 has no reference blocks)
     // throughput mode: strips of tilePx pixels, compacted in the workgroup; enough strips over all jobs to fill the chip
     static const int wgTarget = getenv("LSDHIP_BATCH_WGS") ? atoi(getenv("LSDHIP_BATCH_WGS")) : LSD_BATCH_STRIP_WORKGROUPS;   // developer sweep
     // strips x jobs = the chip's 768 workgroup slots (3 per CU) where the level is large enough: one full round of equal strips;
@@ -1779,7 +1906,7 @@ static TrackScratch batch_scratch(lsdhip_tracker* t, int cmax) {
   sc.max_rows = t->max_blocks;
   sc.cmax = cmax;
 #ifdef LSD_PHASE_TRACE
-  sc.trace = nullptr;
+  sc.trace = t->d_trace;
 #endif
   return sc;
 }
@@ -1813,6 +1940,9 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   // counts, fewer dependent rounds.  Per level as many trials as keep jobs x trials x pixels of the level within LSD_BATCH_SPEC_PIXELS
   // (a round must not cost more than the rounds it saves); one at the level that writes refPixelWasGood (no side planes in batches).
   TrackSpec spec = TrackSpec{};
+#ifdef LSD_PHASE_TRACE
+  spec.traceWg = getenv("LSDHIP_TRACE_WG") ? atoi(getenv("LSDHIP_TRACE_WG")) : 0;
+#endif
   int lmGrid = 1;
   static const int specMaxEnv = getenv("LSDHIP_BATCH_SPEC") ? atoi(getenv("LSDHIP_BATCH_SPEC")) : LSD_BATCH_SPEC_MAX;   // developer A/B (1: off)
   int specMax = specMaxEnv < 1 ? 1 : (specMaxEnv > LSD_BATCH_SPEC_MAX ? LSD_BATCH_SPEC_MAX : specMaxEnv);

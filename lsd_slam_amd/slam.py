@@ -168,6 +168,16 @@ class Frame:
     def idepthVar(self, level=0):
         return self._plane(4, level)
 
+    def referenceBlocks(self, level):
+        """(offsets uint8 [blocks, 256], counts int32 [blocks]) of the level's reference blocks (lsdhip_frame_download what = 5): per 256
+        consecutive pixels the in-block offsets of the valid reference pixels, compacted in pixel order (returned in list order: on the device
+        slot s of a block sits in byte (s mod 64) * 4 + s // 64, so that a lane's 4-byte word holds slots l, l + 64, l + 128, l + 192)."""
+        nblk = (self.width(level) * self.height(level) + 255) // 256
+        raw = np.zeros(nblk * 260, np.uint8)
+        check(self.L.lsdhip_frame_download(self.h_, 5, level, raw.ctypes.data), False)
+        offs = raw[:nblk * 256].reshape(nblk, 64, 4).transpose(0, 2, 1).reshape(nblk, 256)
+        return offs.copy(), raw[nblk * 256:].view(np.int32).copy()
+
     def setDepthFromGroundTruth(self, depth, cov_scale=1.0):
         d = np.ascontiguousarray(depth, dtype=np.float32)
         check(self.L.lsdhip_frame_set_depth_gt(self.h_, d.ctypes.data, cov_scale), False)

@@ -86,6 +86,40 @@ def test_idepth_pyramid_ragged_validity(oracle, hip):
         assert_bit_equal(fg.idepthVar(lvl), fo.plane("idepthVar", lvl), "idepthVar L%d" % lvl)
 
 
+@pytest.mark.parametrize("w,h", [(160, 128), (640, 480), (656, 496)])
+def test_reference_blocks_list_the_oracles_reference_pixels(oracle, hip, w, h):
+    """The blocks the throughput-mode strips read (k_ref_blocks, written behind every idepth pyramid): per 256 consecutive pixels exactly
+    the pixels the oracle's makePointCloud test takes — inside the one-pixel border, idepthVar > 0, idepth != 0 (TrackingReference.cpp:120-131)
+    — in pixel order; sizes with a ragged last block and an odd coarse width (656 / 16 = 41) included."""
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 1)
+    rng = np.random.default_rng(11)
+    idp = rng.uniform(-0.2, 2.0, (h, w)).astype(np.float32)
+    var = rng.uniform(1e-6, 0.25, (h, w)).astype(np.float32)
+    hole = rng.uniform(size=(h, w)) < 0.55
+    idp[hole] = -1
+    var[hole] = -1
+    idp[rng.uniform(size=(h, w)) < 0.02] = 0.0     # idepth == 0 with a positive variance: not a reference point
+    fo = oracle.Frame(0, frames[0], K)
+    fg = hip.Frame(ctx, 0, frames[0])
+    fo.set_depth_planes(idp, var)
+    fg.setDepthPlanes(idp, var)
+    for lvl in range(1, 5):
+        wl, hl = w >> lvl, h >> lvl
+        idl, varl = fo.plane("idepth", lvl), fo.plane("idepthVar", lvl)
+        ok = (varl > 0) & (idl != 0)
+        ok[0, :] = ok[-1, :] = False
+        ok[:, 0] = ok[:, -1] = False
+        flat = ok.reshape(-1)
+        offs, cnts = fg.referenceBlocks(lvl)
+        nblk = (wl * hl + 255) // 256
+        assert offs.shape == (nblk, 256) and cnts.shape == (nblk,)
+        for b in range(nblk):
+            want = np.flatnonzero(flat[b * 256:(b + 1) * 256])
+            assert cnts[b] == len(want), "level %d block %d: count" % (lvl, b)
+            assert np.array_equal(offs[b, :len(want)], want.astype(np.uint8)), "level %d block %d: offsets" % (lvl, b)
+        assert int(cnts.sum()) == int(flat.sum())
+
+
 def test_pointcloud_order_and_bits(oracle, hip):
     w, h = 320, 240
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Every GPU-side step of a round, one parametrised script: gpurun -- 'bash tools/gpu.sh <step> [args]'; output under gpurun_out/r06_<step>/
-# steps: suite | pytest <args> | bench [args] | run <name> <cmd...> | ab <tag> "ENV=.."... | ablib <tag> <variant>... | batchprof <tag> [S] |
+# steps: suite | pytest <args> | bench [args] | run <name> <cmd...> | ab <tag> "ENV=.."... | ablib <tag> <variant>... | ablibtrack <tag> <variant>... | batchprof <tag> [S] |
 #        profile <tag> (tools/gpu_profile.sh: bench line + rocprofv3 kernel stats + PMC traffic passes) | pmc <tag> (HBM traffic of the S = 32 loop: tools/gpu_pmc_multiseq.sh) |
 #        launchcount | launchcount2
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -101,6 +101,24 @@ for k in ('S32',):
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('bench value %.0f keyframe_ms %.4f depth_mpix_per_s %.0f' % (d['value'], d['keyframe_ms'], d['depth_mpix_per_s']))" | tee -a $out/$tag.txt
+        unset LD_PRELOAD LSDHIP_LIB
+      done
+    done
+    ;;
+  ablibtrack)
+    # same-box A/B of builds of liblsdhip.so on the tracking batches and the S-sequence loop: tools/gpu.sh ablibtrack <tag> <name> [<name> ...]
+    tag=$1; shift
+    for rep in 1 2; do
+      for name in default "$@"; do
+        if [ $name = default ]; then unset LD_PRELOAD LSDHIP_LIB; else export LD_PRELOAD=$R/lsd_slam_amd/liblsdhip_$name.so LSDHIP_LIB=$R/lsd_slam_amd/liblsdhip_$name.so; fi
+        echo "== rep $rep lib $name" | tee -a $out/$tag.txt
+        timeout 300 python tools/bench_batch.py --batches 8,32,64 --rounds 20 2>/dev/null | cut -c1-200 | tee -a $out/$tag.txt
+        timeout 300 python tools/bench_multiseq.py --S 8 32 64 --steps 30 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k in ('S8','S32','S64'):
+    r=(d[k].get('roofline') or {}).get('track_batch') or {}
+    print(k, 'frames_s %.0f block %.0f track_batch %.1f us frac %.4f' % (d[k]['frames_s'], d[k]['frames_s_block_until_mapped'], r.get('avg_launch_us') or 0, r.get('frac') or 0))" | tee -a $out/$tag.txt
         unset LD_PRELOAD LSDHIP_LIB
       done
     done
