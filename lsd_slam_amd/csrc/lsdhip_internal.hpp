@@ -390,6 +390,7 @@ struct lsdhip_tracker {
   TrackState* d_bstate = nullptr;     // [capacity][2]
   float* d_bscratch = nullptr;        // TrackScratch arena x capacity (sums | topkey | topval | recs, each [job][parity][trial][...])
   int batchRecent[4] = {0, 0, 0, 0};  // rounds the last batches needed: size the launch budget of the next one
+  int batchTag = 1;                   // what `done` of a polled batch's summaries is raised to (>= 2; 1 = a batch the host synchronises for)
   TrackSummary* h_bsummary = nullptr; // pinned, device-mapped
   float* d_pts = nullptr;         // permaref point upload
   int pts_capacity = 0;

@@ -190,7 +190,8 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   }
   const int lvlPending = S.level;
   // what the finishing launch raises `done` to: the job's tag where the host polls pinned memory for it (single jobs), 1 where it synchronises
-  const int doneWord = (!BATCH && MODE == TS_FUSED && spec.seq != 0) ? (spec.seq >> 12) : 1;
+  // (batches whose host polls: spec.seq is the batch's tag itself)
+  const int doneWord = (MODE == TS_FUSED && spec.seq != 0) ? (BATCH ? spec.seq : (spec.seq >> 12)) : 1;
   if (MODE == TS_FUSED) {
     // The launch is sized for the level with the most (tiles x trials).  This one either evaluates trials at S.level —
     // workgroup = (trial, tile) of that level — or, if the pending decision ends the level, the first evaluation of
@@ -915,7 +916,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   // appends launches — the stream order makes them follow; no hipStreamQuery in the wait loop (each one puts a marker packet into
   // the queue the chain runs through: ~3 us per frame)
  
-  if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.last != 0) out->exhausted = spec.seq;
+  if (MODE == TS_FUSED && leader && tid == 0 && spec.last != 0) out->exhausted = spec.seq;
   LAUNCH_LOG(3, pendingIn_, ncandIn_, S.lastCand);
   PHASE_MARK(6);
 #ifdef LSD_PHASE_TRACE
@@ -1454,8 +1455,9 @@ int lsd_prof_collect(lsdhip_ctx* c) { return prof_collect(c); }
 // A polled summary is accepted when its words add up to its `check` word: `done` has arrived, but the record's other words are separate
 // posted writes and — one job in a few thousand, measured (profiles/r06_notes.md section 1) — the ones stored last (numLaunches, lastCand,
 // levelEvals) still held the previous job's values at that moment.  Spins until the record is whole; counts what it saw.
-static int summary_wait_consistent(lsdhip_tracker* t, const int doneWord) {
-  volatile const unsigned* w = (volatile const unsigned*)t->h_summary;
+static int summary_wait_consistent(lsdhip_tracker* t, const int doneWord, const TrackSummary* rec = nullptr) {
+  if (!rec) rec = t->h_summary;
+  volatile const unsigned* w = (volatile const unsigned*)rec;
   t->sumPolled++;
   unsigned first[LSD_SUMMARY_CHECK_WORDS];
   std::chrono::steady_clock::time_point t0;
@@ -1463,7 +1465,7 @@ static int summary_wait_consistent(lsdhip_tracker* t, const int doneWord) {
     unsigned cur[LSD_SUMMARY_CHECK_WORDS];
     unsigned chk = (unsigned)doneWord;
     for (unsigned i = 1; i < LSD_SUMMARY_CHECK_WORDS; i++) { cur[i] = w[i]; chk += lsd_summary_term(i, cur[i]); }
-    const unsigned want = *(volatile const unsigned*)&t->h_summary->check;
+    const unsigned want = *(volatile const unsigned*)&rec->check;
     if (chk == want) {
       if (spins > 0) {
         const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -1983,9 +1985,22 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   }
   int parity = 0, first = 1, guard = 0;
   static const int fusedEnv = getenv("LSDHIP_BATCH_FUSED") ? atoi(getenv("LSDHIP_BATCH_FUSED")) : 2;   // developer A/B (round 6): 0 = LM launch + evaluation launch per round
+  // Fused rounds: the host polls the jobs' summaries in pinned memory (as lsdhip_tracker_track does for one job) instead of draining the
+  // stream: the budget's launches behind the last job's finishing step (~3 us each, a handful per batch) then run while the host is
+  // already reading the results and queueing what follows.  `done` carries the batch's tag, the record is taken once it adds up to its
+  // check word; the budget's last launch reports a job it leaves unfinished (`exhausted`).
+  static const bool pollEnv = !(getenv("LSDHIP_BATCH_POLL") && getenv("LSDHIP_BATCH_POLL")[0] == '0');   // developer A/B
+  const bool polled = split && fusedEnv && t->spinWait && pollEnv;
+  if (polled) {
+    t->batchTag = t->batchTag >= 0x3FFFFFFF ? 2 : t->batchTag + 1;
+    if (t->batchTag < 2) t->batchTag = 2;
+    spec.seq = t->batchTag;
+    for (int j = 0; j < n; j++) t->h_bsummary[j].exhausted = 0;
+  }
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     for (int i = 0; i < budget; i++) {
+      spec.last = (polled && i == budget - 1) ? 1 : 0;
       if (split && fusedEnv) {
         hipLaunchKernelGGL((k_track_step<256, true, TS_FUSED>), dim3(grid, n), dim3(256), 0, c->stream, t->h_bjobs[0], (const TrackJob*)t->d_bjobs,
                            t->d_bstate, sc, d_sum, parity, first, spec);
@@ -2006,9 +2021,33 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
     if (c->prof_on) { HIPCHK(hipEventRecord(c->ev_b, c->stream)); c->prof_pending = true; }
     // the batch's launches are queued: the place for everything the device can do beside them (lsdhip_tracker_set_enqueue_hook)
     if (callHook && guard == 0 && t->enqueueHook) t->enqueueHook(t->enqueueHookUser);
-    HIPCHK(hipStreamSynchronize(c->stream));
     bool all = true;
-    for (int j = 0; j < n; j++) all = all && t->h_bsummary[j].done;
+    if (polled) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int j = 0; j < n && all; j++) {
+        volatile const int* done = &t->h_bsummary[j].done;
+        volatile const int* exhausted = &t->h_bsummary[j].exhausted;
+        for (unsigned spins = 0;; spins++) {
+          if (*done == t->batchTag) break;
+          if (*exhausted == t->batchTag) { all = false; break; }
+          if ((spins & 0xFFFFu) == 0xFFFFu) {
+            // the stream may have stopped on an error, or (a budget cut short by a failed launch) nobody is left to report
+            if (hipStreamQuery(c->stream) != hipErrorNotReady) { all = *done == t->batchTag; if (!all) break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { lsd_set_error("tracking batch: no progress report from the device"); return LSDHIP_E_STATE; }
+          }
+          __builtin_ia32_pause();
+        }
+        if (all) { if (int rcs = summary_wait_consistent(t, t->batchTag, &t->h_bsummary[j])) return rcs; }
+      }
+      if (!all) {
+        HIPCHK(hipStreamSynchronize(c->stream));   // out of budget: rare
+        all = true;
+        for (int j = 0; j < n; j++) { all = all && t->h_bsummary[j].done == t->batchTag; t->h_bsummary[j].exhausted = 0; }
+      }
+    } else {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      for (int j = 0; j < n; j++) all = all && t->h_bsummary[j].done;
+    }
     if (all) break;
     if (int rc2 = prof_collect(c)) return rc2;
     budget = 6;
