@@ -535,14 +535,17 @@ def multi_seq(torch, w, h, K, seeds, device, single_value, sizes=(8, 32, 64, 128
 
 
 # algorithmic bytes per map pixel of the shared launches of the S-sequence loop (unique bytes read + written):
-#   frame pyramids : k_image_pyramid_batch (1 B in, five image levels 4 x 1.332 B, level-0 texels 16 B, |grad| 4 B) + k_gradients_max_batch
-#                    (image levels 1-4 in 1.33 B, texels of levels 1-4 out 5.31 B, |grad| in 4 B, maxGradients out 4 B)         = 41.0 B
+#   frame pyramids : k_image_pyramid_batch (1 B in, five image levels 4 x 1.332 B) + k_gradients_max_batch (image levels 1-4 in 1.33 B,
+#                    texels of levels 1-4 out 5.31 B)                                                                            = 13.0 B
+#                    (until round 6 also the level-0 texels 16 B, |grad| 4 + 4 B and maxGradients 4 B of EVERY frame = 41.0 B; these are
+#                    keyframe planes now, built when a frame becomes a DepthMap's keyframe — 32 B per pixel of a new keyframe, queued ahead
+#                    of the keyframe change's bracket and inside keyframe_ms)
 #   regularise     : K5 ~34 + K6 30 (+ K8 17 when the pass carries Frame::setDepth; counted without)                           = 64.0 B
 #   idepth pyramids: level-0 (idepth, var) in 8 B, levels 1-4 out 2.66 B                                                         = 10.7 B
 #   keyframe change: finalize pass 64 + setDepth 17 + re-activation data 9 + candidates 16 | merge 20 + 29 | regularise(occ) 30 | fill +
 #                    regularise 64 | rescale + setDepth 41 | two idepth pyramids 21.3                                            = 311 B
 #   observe        : 13 B per map pixel (the cheap rejections) + 57 B per searched pixel + 4 B per reference-image sample (steps + 4)
-MS_BYTES_PER_PX = {"frame_pyramids": 41.0, "regularise": 64.0, "idepth_pyramids": 10.7, "keyframe_change": 311.0}
+MS_BYTES_PER_PX = {"frame_pyramids": 13.0, "regularise": 64.0, "idepth_pyramids": 10.7, "keyframe_change": 311.0}
 
 
 def multi_seq_roofline(loop, L, ctx_h, ptrs, t0, S, w, h, steps):

@@ -2089,6 +2089,7 @@ extern "C" int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   lsdhip_ctx* c = dm->ctx;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
+  if (int rcl = lsd_frame_require_level0(kf)) return rcl;   // a DepthMap's keyframe is asked for gradients(0) / maxGradients(0)
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = false;
   int n = c->w * c->h;
@@ -2104,6 +2105,7 @@ extern "C" int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   lsdhip_ctx* c = dm->ctx;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
+  if (int rcl = lsd_frame_require_level0(kf)) return rcl;
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = false;
   // initializeRandomly (DepthMap.cpp:883-916) draws from the C library's rand() in pixel order: a host-side init path.
@@ -2140,6 +2142,7 @@ extern "C" int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame*
   lsdhip_ctx* c = dm->ctx;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
+  if (int rcl = lsd_frame_require_level0(kf)) return rcl;
   dm->activeKeyFrame = kf;
   kf->numMappedOnThis = 0;
   kf->numFramesTrackedOnThis = 0;
@@ -2366,6 +2369,7 @@ extern "C" int lsdhip_depth_create_keyframe(lsdhip_depthmap* dm, lsdhip_frame* n
   if (int rcb = lsd_m_begin(c)) return rcb;
   const int ev = timing_begin(dm, 1);
   if (ev < 0 && ev != EV_SKIP) return ev;
+  if (int rcl = lsd_frame_require_level0(nk)) return rcl;   // the new keyframe's maxGradients(0): propagateDepth reads it (DepthMap.cpp:758)
   int rc = propagate(dm, nk, false);
   if (rc) return rc;
   dm->msPropagate = ema(dm->msPropagate, now_ms() - t0);
@@ -2480,6 +2484,7 @@ extern "C" int lsdhip_depth_change_keyframe_batch(int n, lsdhip_depthmap** maps,
   const int ev = timing_begin(maps[0], 1);
   if (ev < 0 && ev != EV_SKIP) return ev;
   txn.ev = ev; txn.timing = true;
+  if (int rcl = lsd_frames_require_level0(new_keyframes, n)) return rcl;   // the new keyframes' gradients(0) / maxGradients(0), one launch pair
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t kfBytes = up(sizeof(KfItem) * (size_t)n), regBytes = up(sizeof(RegBatchItem) * (size_t)n), resBytes = up(sizeof(RescaleItem) * (size_t)n);
   void* hostBlob = nullptr;
@@ -2722,6 +2727,7 @@ extern "C" int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const 
   HIPCHK(hipMemcpyAsync(dm->cur.idepth_s, ids.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
   HIPCHK(hipMemcpyAsync(dm->cur.var_s, vars.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
   HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
+  if (int rcl = lsd_frame_require_level0(kf)) return rcl;
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = reactivated != 0;
   return LSDHIP_OK;
@@ -2742,7 +2748,8 @@ extern "C" int lsdhip_depth_stage(lsdhip_depthmap* dm, int stage, lsdhip_frame**
     case 3: rc = regularize(dm, true, VAL_SUM_MIN_FOR_KEEP); break;
     case 4:
       if (!refs || n < 1) return LSDHIP_E_ARG;
-      rc = propagate(dm, refs[0], true);
+      rc = lsd_frame_require_level0(refs[0]);
+      if (rc == LSDHIP_OK) rc = propagate(dm, refs[0], true);
       if (rc == LSDHIP_OK) { dm->activeKeyFrame = refs[0]; dm->activeKeyFrameIsReactivated = false; }
       break;
     case 5: rc = fill_regularize(dm, VAL_SUM_MIN_FOR_KEEP, false); break;

@@ -11,6 +11,7 @@
 //   Frame::setDepthFromGroundTruth Frame.cpp:245-293
 //   TrackingReference::makePointCloud C/Tracking/TrackingReference.cpp:96-147
 // Unwritten pool memory of the reference is defined as 0 here (rows 0 / h-1 of gradients etc.).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -42,15 +43,19 @@ __device__ __forceinline__ void image_pyramid_tile(const uint8_t* __restrict__ g
     i0[i] = v;
     s0[ty][tx] = v;
     // Frame::buildGradients (Frame.cpp:643-680): rows 1..h-2 by linear index, so x = 0 / w-1 wrap into the neighbouring rows
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool inner = (i >= w) && (i < w * (h - 1));
-    if (inner) {
-      g.x = 0.5f * ((float)gray[i + 1] - (float)gray[i - 1]);
-      g.y = 0.5f * ((float)gray[i + w] - (float)gray[i - w]);
-      g.z = v;
+    // (grad0 == nullptr — every frame since round 6: the level-0 gradients and maxGradients are keyframe planes, built when a frame
+    // becomes one: lsd_frames_require_level0 below)
+    if (grad0) {
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool inner = (i >= w) && (i < w * (h - 1));
+      if (inner) {
+        g.x = 0.5f * ((float)gray[i + 1] - (float)gray[i - 1]);
+        g.y = 0.5f * ((float)gray[i + w] - (float)gray[i - w]);
+        g.z = v;
+      }
+      grad0[i] = g;
+      absgrad0[i] = inner ? sqrtf(g.x * g.x + g.y * g.y) : 0.f;
     }
-    grad0[i] = g;
-    absgrad0[i] = inner ? sqrtf(g.x * g.x + g.y * g.y) : 0.f;
   }
   __syncthreads();
   if (tid < 64) {
@@ -135,6 +140,7 @@ __device__ __forceinline__ void gradients_max_block(const GradMaxArgs& a) {
     for (int k = 2; k < LSD_LEVELS; k++) if (b >= a.blk0[k]) l = k;
     const int w = a.w[l], h = a.h[l];
     const int i = (b - a.blk0[l]) * 256 + threadIdx.x;
+    if (l == 1 && i < a.nMaskWords) a.wasGoodWords[i] = 0xFFFFFFFFu;   // the frame's level-1 refPixelWasGood in its "never written" state
     if (i >= w * h) return;
     const float* __restrict__ img = a.img[l];
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -151,7 +157,6 @@ __device__ __forceinline__ void gradients_max_block(const GradMaxArgs& a) {
   const int w = a.w[0], h = a.h[0];
   const int i = (b - a.blk0[LSD_LEVELS]) * 256 + threadIdx.x;
   const int n = w * h;
-  if (i < a.nMaskWords) a.wasGoodWords[i] = 0xFFFFFFFFu;
   if (i >= n) return;
   const int lo = w + 1, hi = w * (h - 1) - 1;
   auto vmax = [&](int j) -> float {
@@ -181,6 +186,36 @@ __global__ __launch_bounds__(256) void k_gradients_max_batch(const GradMaxArgs* 
   for (int i = threadIdx.x; i < (int)(sizeof(GradMaxArgs) / 4); i += 256) ((int*)&s_a)[i] = src[i];
   __syncthreads();
   gradients_max_block(s_a);
+}
+
+// Level-0 gradients (gx, gy, I, 0) and |grad| from the level-0 float image (the exact conversion of the 8-bit source): the arithmetic the
+// image pyramid kernel did for every frame until round 6 (Frame::buildGradients, Frame.cpp:643-680, rows 1..h-2 by linear index).
+// The reference builds Frame::gradients(0) and maxGradients(0) on demand, and only keyframes are ever asked for them (DepthMap's
+// observe / regularise / propagate, setDepthFromGroundTruth); a tracked frame needs the levels >= 1.  So do we now: 7.3 of the 12.6 MB a
+// 640x480 frame's pyramids moved were these two planes and the |grad| scratch.
+struct Level0Item {
+  LSD_G const float* img0;
+  LSD_G float4* grad0;
+  LSD_G float* absgrad;
+};
+__device__ __forceinline__ void level0_gradients_px(const Level0Item& a, const int w, const int h) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w * h) return;
+  const float v = a.img0[i];
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool inner = (i >= w) && (i < w * (h - 1));
+  if (inner) {
+    g.x = 0.5f * (a.img0[i + 1] - a.img0[i - 1]);
+    g.y = 0.5f * (a.img0[i + w] - a.img0[i - w]);
+    g.z = v;
+  }
+  a.grad0[i] = g;
+  a.absgrad[i] = inner ? sqrtf(g.x * g.x + g.y * g.y) : 0.f;
+}
+__global__ __launch_bounds__(256) void k_level0_gradients(Level0Item a, int w, int h) { level0_gradients_px(a, w, h); }
+__global__ __launch_bounds__(256) void k_level0_gradients_batch(const Level0Item* __restrict__ items, int w, int h) {
+  const Level0Item a = items[blockIdx.y];
+  level0_gradients_px(a, w, h);
 }
 
 // inverse-variance pooling of one 2x2 block, children in the order idx, idx+1, idx+sw, idx+sw+1
@@ -1205,7 +1240,8 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
   dim3 grid(c->w / 16, c->h / 16);
   lsdhip_host_mark(21);
   hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
-                     f->d_image[3], f->d_image[4], c->w, c->h, f->d_grad[0], f->d_absgrad);
+                     f->d_image[3], f->d_image[4], c->w, c->h, (float4*)nullptr, (float*)nullptr);
+  f->level0Ready = false;
   GradMaxArgs ga;
   int nb = 0;
   for (int l = 0; l < LSD_LEVELS; l++) {
@@ -1216,12 +1252,75 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
   ga.blk0[LSD_LEVELS] = nb;
   ga.absg = lsd_g(f->d_absgrad); ga.maxgrad = lsd_g(f->d_maxgrad);
   ga.wasGoodWords = lsd_g((uint32_t*)f->d_wasGood); ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
-  int n0 = c->w * c->h;
   lsdhip_host_mark(22);
-  hipLaunchKernelGGL(k_gradients_max, dim3(nb + (n0 + 255) / 256), dim3(256), 0, stream, ga);
+  hipLaunchKernelGGL(k_gradients_max, dim3(nb), dim3(256), 0, stream, ga);   // the gradient blocks only: maxGradients is a keyframe plane (lsd_frames_require_level0)
   lsdhip_host_mark(23);
   HIPCHK(hipGetLastError());
   f->wasGoodPristine = true;
+  return LSDHIP_OK;
+}
+
+// Frame::gradients(0) / Frame::maxGradients(0) on demand (the reference's Frame::require, Frame.cpp:560-640): the level-0 gradient texels,
+// |grad| and its 3x3 maximum, for the frames that are asked for them — the keyframes of a DepthMap, a frame given a ground-truth depth,
+// a level-0 tracking job, a download.  Queued on the mapping stream (where the consumers are; a caller on the tracking stream moves the
+// frame's readySeq behind them).  One launch pair for all frames of the call that do not have the planes yet.
+int lsd_frames_require_level0(lsdhip_frame** fs, int n) {
+  if (n <= 0) return LSDHIP_OK;
+  lsdhip_ctx* c = fs[0]->ctx;
+  LSD_CTX_LOCK(c);
+  std::vector<lsdhip_frame*> todo;
+  for (int j = 0; j < n; j++)
+    if (fs[j] && !fs[j]->level0Ready && std::find(todo.begin(), todo.end(), fs[j]) == todo.end()) todo.push_back(fs[j]);
+  if (todo.empty()) return LSDHIP_OK;
+  const hipStream_t ms = lsd_map_stream(c);
+  const int n0 = c->w * c->h, m = (int)todo.size();
+  auto fill_max = [&](lsdhip_frame* f, GradMaxArgs& ga) {
+    memset((void*)&ga, 0, sizeof(ga));
+    for (int l = 0; l < LSD_LEVELS; l++) { ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l]; ga.blk0[l] = 0; }
+    ga.blk0[LSD_LEVELS] = 0;                   // no gradient blocks: every block is a maxGradients block
+    ga.absg = lsd_g(f->d_absgrad); ga.maxgrad = lsd_g(f->d_maxgrad);
+  };
+  if (m == 1) {
+    lsdhip_frame* f = todo[0];
+    Level0Item it;
+    it.img0 = lsd_g((const float*)f->d_image[0]); it.grad0 = lsd_g(f->d_grad[0]); it.absgrad = lsd_g(f->d_absgrad);
+    GradMaxArgs ga;
+    fill_max(f, ga);
+    hipLaunchKernelGGL(k_level0_gradients, dim3((n0 + 255) / 256), dim3(256), 0, ms, it, c->w, c->h);
+    hipLaunchKernelGGL(k_gradients_max, dim3((n0 + 255) / 256), dim3(256), 0, ms, ga);
+  } else {
+    const size_t itBytes = align_up(sizeof(Level0Item) * (size_t)m, 256);
+    std::vector<uint8_t> blob(itBytes + sizeof(GradMaxArgs) * (size_t)m);
+    for (int j = 0; j < m; j++) {
+      Level0Item& it = ((Level0Item*)blob.data())[j];
+      it.img0 = lsd_g((const float*)todo[j]->d_image[0]); it.grad0 = lsd_g(todo[j]->d_grad[0]); it.absgrad = lsd_g(todo[j]->d_absgrad);
+      fill_max(todo[j], ((GradMaxArgs*)(blob.data() + itBytes))[j]);
+    }
+    void* dev = nullptr;
+    if (int rc = lsd_args_push(c, blob.data(), blob.size(), ms, &dev)) return rc;
+    hipLaunchKernelGGL(k_level0_gradients_batch, dim3((n0 + 255) / 256, m), dim3(256), 0, ms, (const Level0Item*)dev, c->w, c->h);
+    hipLaunchKernelGGL(k_gradients_max_batch, dim3((n0 + 255) / 256, m), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + itBytes));
+    if (int rc = lsd_args_release(c, dev, ms)) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  for (lsdhip_frame* f : todo) f->level0Ready = true;
+  return LSDHIP_OK;
+}
+int lsd_frame_require_level0(lsdhip_frame* f) { return lsd_frames_require_level0(&f, 1); }
+// ... for a consumer on the tracking stream (a level-0 tracking / Sim3 job) or the host (a download): the frame's planes are complete at a
+// new point of the mapping stream
+int lsd_frame_require_level0_for_tracking(lsdhip_frame* f) {
+  if (f->level0Ready) return LSDHIP_OK;
+  lsdhip_ctx* c = f->ctx;
+  LSD_CTX_LOCK(c);
+  if (int rc = lsd_m_begin(c)) return rc;
+  if (int rc = lsd_frame_require_level0(f)) return rc;
+  if (c->pipeline) {
+    const long long seq = lsd_m_record(c);
+    if (seq < 0) return LSDHIP_E_HIP;
+    if (seq > f->readySeq) f->readySeq = seq;
+    if (int rc = lsd_t_wait_m(c, seq)) return rc;   // (the callers have already ordered the tracking stream behind the frame's older readySeq)
+  }
   return LSDHIP_OK;
 }
 
@@ -1436,7 +1535,8 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
     }
     pi[j].gray = lsd_g(images_on_device ? gray[j] : f->d_gray);
     for (int l = 0; l < LSD_LEVELS; l++) pi[j].img[l] = lsd_g(f->d_image[l]);
-    pi[j].grad0 = lsd_g(f->d_grad[0]); pi[j].absgrad0 = lsd_g(f->d_absgrad);
+    pi[j].grad0 = nullptr; pi[j].absgrad0 = nullptr;   // keyframe planes: lsd_frames_require_level0
+    f->level0Ready = false;
     GradMaxArgs& ga = gi[j];
     nb = 0;
     for (int l = 0; l < LSD_LEVELS; l++) {
@@ -1460,7 +1560,7 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
   if (bp < -1) return fail(bp);
   hipLaunchKernelGGL(k_image_pyramid_batch, dim3(c->w / 16, c->h / 16, n), dim3(256), 0, ms, (const ImagePyrItem*)dev, c->w, c->h);
   const int n0 = c->w * c->h;
-  hipLaunchKernelGGL(k_gradients_max_batch, dim3(nb + (n0 + 255) / 256, n), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + piBytes));
+  hipLaunchKernelGGL(k_gradients_max_batch, dim3(nb, n), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + piBytes));
   rc = lsd_bprof_end(c, bp, ms, (double)n * n0);
   if (rc) return fail(rc);
   if (hipGetLastError() != hipSuccess) { lsd_set_error("lsdhip_frame_create_batch: launch failed"); return fail(LSDHIP_E_HIP); }
@@ -1503,7 +1603,9 @@ extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float
   LSD_CTX_LOCK(c);
   size_t n = (size_t)c->wl[level] * c->hl[level];
   const void* src = nullptr;
+  if ((what == 1 && level == 0) || what == 2) { if (int rc = lsd_frame_require_level0_for_tracking(f)) return rc; }   // built on demand
   if (c->pipeline) { if (int rc = lsd_sync_all(c)) return rc; }
+  else if (lsd_map_stream(c) != c->stream) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));   // (an open lane region)
   switch (what) {
     case 0: src = f->d_image[level]; break;
     case 1: src = f->d_grad[level]; n *= 4; break;
@@ -1536,6 +1638,7 @@ extern "C" int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_hos
   float* d_depth = c->d_gtStage;
   if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
   const hipStream_t ms = lsd_map_stream(c);
+  if (int rcl = lsd_frame_require_level0(f)) return rcl;   // Frame::setDepthFromGroundTruth reads maxGradients(0) (Frame.cpp:259)
   HIPCHK(hipMemcpyAsync(d_depth, depth_host, (size_t)n0 * 4, hipMemcpyHostToDevice, ms));
   hipLaunchKernelGGL(k_set_depth_gt, dim3((n0 + 255) / 256), dim3(256), 0, ms, d_depth, f->d_maxgrad, lsd_depth_w(f)[0],
                      lsd_depthvar_w(f)[0], c->w, c->h, cov_scale, c->params.minUseGrad);
@@ -1565,7 +1668,9 @@ extern "C" int lsdhip_frame_set_maxgrad(lsdhip_frame* f, const float* maxgrad_ho
   lsdhip_ctx* c = f->ctx;
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
+  if (int rcl = lsd_frame_require_level0_for_tracking(f)) return rcl;   // (the planes count as built from here on: the overwrite below must be the last word)
   if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
+  else if (lsd_map_stream(c) != c->stream) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   HIPCHK(hipMemcpyAsync(f->d_maxgrad, maxgrad_host, (size_t)c->w * c->h * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;

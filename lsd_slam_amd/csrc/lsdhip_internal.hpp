@@ -291,6 +291,7 @@ struct lsdhip_frame {
   float* d_idepth[LSD_LEVELS] = {};     // the depth planes the TRACKING side reads (TrackingReference's view of the keyframe)
   float* d_idepthVar[LSD_LEVELS] = {};
   bool hasIDepth = false;
+  bool level0Ready = false;             // d_grad[0], d_absgrad, d_maxgrad are built (keyframe planes, on demand: lsd_frames_require_level0)
   // Pipelined contexts: Frame::setDepth on the mapping stream writes the second plane set while a tracking job may still read the
   // first; lsdhip_frame_publish_depth (= TrackingReference::importFrame) swaps them.  Non-pipelined contexts write d_idepth directly.
   float* d_idepthW[LSD_LEVELS] = {};
@@ -528,6 +529,9 @@ struct LsdTrackJobScope {
   ~LsdTrackJobScope() { if (c->pipeline && drain) (void)hipStreamSynchronize(c->stream); }
 };
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream);
+int lsd_frames_require_level0(lsdhip_frame** fs, int n);    // Frame::gradients(0) / maxGradients(0) on demand, on lsd_map_stream (frame.hip)
+int lsd_frame_require_level0(lsdhip_frame* f);
+int lsd_frame_require_level0_for_tracking(lsdhip_frame* f);
 // copies `bytes` of kernel-argument records to the device on `s` (stream-ordered) and returns the device address; lsd_args_release after
 // the launches that read them (frame.hip).  begin / commit: the same in two steps, for records that hold their own device address
 int lsd_args_push(lsdhip_ctx* c, const void* src, size_t bytes, hipStream_t s, void** dev_out);

@@ -562,6 +562,7 @@ static int sim3_build_job(lsdhip_sim3tracker* t, int slot, lsdhip_frame* kf, lsd
   lsdhip_ctx* c = t->ctx;
   LSD_CTX_LOCK(c);
   Sim3Job a;
+  if (level == 0) { (void)lsd_frame_require_level0_for_tracking(kf); (void)lsd_frame_require_level0_for_tracking(frame); }   // level-0 texels on demand
   a.kf_idepth = kf->d_idepth[level]; a.kf_idepthVar = kf->d_idepthVar[level]; a.kf_image = kf->d_image[level]; a.kf_grad = kf->d_grad[level];
   a.fr_grad = frame->d_grad[level]; a.fr_idepth = frame->d_idepth[level]; a.fr_idepthVar = frame->d_idepthVar[level];
   a.w = c->wl[level]; a.h = c->hl[level];
@@ -1101,6 +1102,7 @@ static int sim3_track_jobs(lsdhip_sim3tracker* t, std::vector<Sim3Track>& jobs, 
         Sim3Lvl& L = S.lv[l];
         lsdhip_frame* kf = frames[base + k].first;
         lsdhip_frame* fr = frames[base + k].second;
+        if (l == 0) { (void)lsd_frame_require_level0_for_tracking(kf); (void)lsd_frame_require_level0_for_tracking(fr); }
         L.kf_idepth = kf->d_idepth[l]; L.kf_idepthVar = kf->d_idepthVar[l]; L.kf_image = kf->d_image[l]; L.kf_grad = kf->d_grad[l];
         L.fr_grad = fr->d_grad[l]; L.fr_idepth = fr->d_idepth[l]; L.fr_idepthVar = fr->d_idepthVar[l];
         L.w = c->wl[l]; L.h = c->hl[l];

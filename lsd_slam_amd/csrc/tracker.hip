@@ -1213,6 +1213,7 @@ static void fill_level(lsdhip_tracker* t, TrackJob& job, int level, lsdhip_frame
   L.w = c->wl[level]; L.h = c->hl[level];
   L.fx = in.fx; L.fy = in.fy; L.cx = in.cx; L.cy = in.cy; L.fxi = in.fxi; L.fyi = in.fyi; L.cxi = in.cxi; L.cyi = in.cyi;
   L.fr_grad = frame->d_grad[level];
+  if (level == 0) (void)lsd_frame_require_level0_for_tracking(frame);   // (levels >= 1 are what a tracked frame has: the level-0 texels on demand)
   if (npts >= 0) {
     L.pts_pos = pts_pos; L.pts_colvar = pts_colvar; L.npts = npts;
     L.kf_idepth = L.kf_idepthVar = L.kf_image = nullptr;
