@@ -22,6 +22,10 @@ __device__ __forceinline__ int dpp_i(int v) {   // masked-off / out-of-row lanes
   return __builtin_amdgcn_update_dpp(-1, v, CTRL, ROW_MASK, BANK_MASK, false);
 }
 // wave64 max of non-negative keys (identity -1); result valid in lane 63
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_i0(int v) {   // masked-off / out-of-row lanes read 0 (the identity of a sum)
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
+}
 __device__ __forceinline__ int wave_max_to_lane63(int v) {
   int t = dpp_max_i(v, dpp_i<0x111, 0xf, 0xf>(v));
   t = dpp_max_i(t, dpp_i<0x112, 0xf, 0xf>(v));

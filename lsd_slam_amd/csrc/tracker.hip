@@ -413,14 +413,18 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
             if (k0 == m && m >= 0) { k0 = k1; e0 = e1; k1 = k2; e1 = e2; k2 = -1; }
             if (m >= 0) {
               nsub++;
-              // (written as a chain of selects: a store under `q == row / 8` becomes an indexed read of v[], i.e. scratch memory)
-              float4 w4 = v[0];
+              // the row's 16-byte words sit in v[row / 8] of lanes 8 (row % 8) ..: a scalar branch per q (row is uniform).  (The empty asm
+              // keeps the compiler from folding the branches into an indexed read of v[] — scratch memory; a chain of 4 (NQ - 1) selects
+              // per candidate was the first form.)
+              const int qsel = row >> 3;
 #pragma unroll
-              for (int q = 1; q < NQ; q++) {
-                const bool here = ((q * 64 + lane) >> 3) == row;
-                w4.x = here ? v[q].x : w4.x; w4.y = here ? v[q].y : w4.y; w4.z = here ? v[q].z : w4.z; w4.w = here ? v[q].w : w4.w;
+              for (int q = 0; q < NQ; q++) {
+                if (q == qsel) {
+                  float4 w4 = v[q];
+                  asm volatile("" : "+v"(w4.x), "+v"(w4.y), "+v"(w4.z), "+v"(w4.w));
+                  if ((lane >> 3) == (row & 7)) *(float4*)&s_subT[c][r][(lane & 7) * 4] = w4;
+                }
               }
-              if ((lane >> 3) == (row & 7)) *(float4*)&s_subT[c][r][(lane & 7) * 4] = w4;
             }
           }
           if (lane == 0) s_nsubT[c] = nsub;
@@ -660,7 +664,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   topval_out += (size_t)cand * max_rows * 96;
   const int tile = xcd_tile(bx, nb);
   EvalCtx a;
-  make_ctx_dev(job, S, level, a);
+  make_ctx_dev(job, S, level, a);   // (fetched beside the finishing phase for the pending level: measured, +-0 — the scalar loads are not what the step behind the LM waits for)
   if (BATCH && MODE == TS_EVAL && cand > 0) {
     // a retry further down the reject chain: its pose is in the record the LM workgroup that proposed it left
     const float* rec = sc.recs + ((size_t)parity * cmax + cand) * 32;
@@ -693,20 +697,23 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
     const int mblk = (stripEnd - base + 255) >> 8;             // <= 32 (tilePx <= 8192, fill_level)
     const float inv_w = 1.0f / (float)a.w;
     if (!(havePre && level == lvlPending)) strip_request(level, tile);   // (else: requested next to the state, at the head of the finishing phase)
-    int incl = cntv;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-      const int tv = __shfl_up(incl, d);
-      if (lane >= d) incl += tv;
-    }
-    const int total = __shfl(incl, 31);
+    // inclusive scan of the (at most 32) block counts over lanes 0..31 in six DPP additions, the blocks' entries through v_readlane (the
+    // wave index is uniform: readfirstlane tells the compiler so)
+    int incl = cntv + dpp_i0<0x111, 0xf, 0xf>(cntv);      // row_shr:1
+    incl += dpp_i0<0x112, 0xf, 0xf>(cntv);                // row_shr:2
+    incl += dpp_i0<0x113, 0xf, 0xf>(cntv);                // row_shr:3
+    incl += dpp_i0<0x114, 0xf, 0xe>(incl);                // row_shr:4 bank_mask:0xe
+    incl += dpp_i0<0x118, 0xf, 0xc>(incl);                // row_shr:8 bank_mask:0xc
+    incl += dpp_i0<0x142, 0xa, 0xf>(incl);                // row_bcast:15 row_mask:0xa
+    const int total = __builtin_amdgcn_readlane(incl, 31);
+    const int waveU = __builtin_amdgcn_readfirstlane(wave);
     PHASE_MARK(20);
 #pragma unroll
     for (int c = 0; c < CHMAX; c++) {
-      const int blk = c * 4 + wave;                            // wave-uniform
+      const int blk = c * 4 + waveU;
       if (blk < mblk) {
-        const int cb = __shfl(cntv, blk);
-        const int pb = __shfl(incl, blk) - cb;
+        const int cb = __builtin_amdgcn_readlane(cntv, blk);
+        const int pb = __builtin_amdgcn_readlane(incl, blk) - cb;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int sl = lane + 64 * k;                       // (the block's bytes are slot-interleaved: k_ref_blocks)
