@@ -139,7 +139,11 @@ int lsdhip_frame_id(lsdhip_frame* f);
  * 5 (levels >= 1; not a member of the reference's Frame) the level's reference blocks as the tracker's throughput mode reads them: per 256
  *   consecutive pixels the in-block offsets of the pixels TrackingReference::makePointCloud would take (TrackingReference.cpp:120-131),
  *   compacted in pixel order (256 bytes per block; list slot s in byte (s mod 64) * 4 + s / 64), then one int32 count per block;
- *   out_host holds ceil(pixels / 256) * 260 bytes */
+ *   out_host holds ceil(pixels / 256) * 260 bytes
+ * 6 (level 0; not a member of the reference's Frame) the gradient candidates the batched DepthMap update walks: per 1024 consecutive
+ *   pixels the in-group offsets (uint16, pixel order) of the pixels inside the 3-pixel border with maxGradients >= minUseGrad — the two
+ *   tests of DepthMap::observeDepthRow that depend on the keyframe alone (DepthMap.cpp:111-131) — then one uint16 count per group;
+ *   out_host holds ceil(pixels / 1024) * 1025 * 2 bytes */
 int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float* out_host);
 /* Frame::setDepthFromGroundTruth (Frame.cpp:245-293) */
 int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_host, float cov_scale);

@@ -103,6 +103,7 @@ struct ObserveArgs {
   LSD_G unsigned long long* counters;   // null, or (sampled launches while profiling) two words per wave: pixels that entered the search, walk steps
   LSD_G float4* queue;                  // batches, two-launch form: this map's search queue (pixel index bits, epx, epy, -) and its fill count
   LSD_G int* qcount;
+  LSD_G const uint16_t* gradCand;       // the keyframe's gradient candidates (lsdhip_frame::d_gradCand; k_observe_select_cand_batch)
   StereoRef one;   // nRefs == 1 (the blockUntilMapped case): the reference travels in the kernel arguments, no staging copy
 };
 
@@ -724,29 +725,37 @@ __device__ __forceinline__ void prop_candidate(const PropArgs& a, const int x, c
 // the pass is a chain of two dependent memory round trips per pixel, and a lane that keeps eight of them in flight needs a quarter of
 // the residency rounds (the one-pixel form ran at 1.7 TB/s: 0.84 of its wave cycles waiting, profiles/r05_notes.md).
 // Same tests in the same order as observe_front (incl. its one store: a hypothesis on a pixel below the gradient threshold is dropped).
-__device__ __forceinline__ void observe_front4(const ObserveArgs& a, const int x, const int y0, bool (&hit)[4], float (&epx)[4], float (&epy)[4]) {
+// CAND: the four pixels come from the keyframe's gradient candidates (k_observe_select_cand_batch): the border and gradient tests are
+// already answered (and no hypothesis sits below the threshold: lsdhip_depthmap::lowGradHypPossible), maxGradients is not read.
+template <bool CAND>
+__device__ __forceinline__ void observe_front4(const ObserveArgs& a, const int (&xs)[4], const int (&ys)[4], const bool (&in)[4], bool (&hit)[4],
+                                               float (&epx)[4], float (&epy)[4]) {
   const StereoRef& rf = a.one;
   const bool useMask = rf.parentIsKF && rf.wasGood != nullptr;
-  bool in[4], hyp[4];
+  bool hyp[4];
   int idx[4], bl[4];
   float mg[4], nid[4];
   uint8_t val[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int y = y0 + 4 * k;
-    in[k] = !(x < 3 || x >= a.w - 3 || y < 3 || y >= a.h - 3);
-    idx[k] = in[k] ? x + y * a.w : 0;
-    val[k] = a.m.valid[idx[k]];
-    mg[k] = a.kfMaxGrad[idx[k]];
-    bl[k] = a.m.blacklisted[idx[k]];
-    nid[k] = a.m.nextID[idx[k]];
+    idx[k] = in[k] ? xs[k] + ys[k] * a.w : 0;
+    if (CAND) {
+      // (a quarter of the slots of a group hold a candidate on a typical keyframe: only those request anything)
+      val[k] = 0; bl[k] = 0; nid[k] = 0.f; mg[k] = a.minUseGrad;
+      if (in[k]) { val[k] = a.m.valid[idx[k]]; bl[k] = a.m.blacklisted[idx[k]]; nid[k] = a.m.nextID[idx[k]]; }
+    } else {
+      val[k] = a.m.valid[idx[k]];
+      mg[k] = a.kfMaxGrad[idx[k]];
+      bl[k] = a.m.blacklisted[idx[k]];
+      nid[k] = a.m.nextID[idx[k]];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     hyp[k] = val[k] != 0;
     bool pass = in[k];
-    if (pass && hyp[k] && mg[k] < a.minUseGrad) { a.m.valid[idx[k]] = 0; pass = false; }
-    if (pass && (mg[k] < a.minUseGrad || bl[k] < MIN_BLACKLIST)) pass = false;
+    if (!CAND && pass && hyp[k] && mg[k] < a.minUseGrad) { a.m.valid[idx[k]] = 0; pass = false; }
+    if (pass && ((!CAND && mg[k] < a.minUseGrad) || bl[k] < MIN_BLACKLIST)) pass = false;
     if (pass && hyp[k] && !a.reactivated) {
       const int rel = (int)nid[k] - a.byIDOffset;
       if (rel >= a.nByID) pass = false;
@@ -757,19 +766,52 @@ __device__ __forceinline__ void observe_front4(const ObserveArgs& a, const int x
   float kR[4], kL[4], kD[4], kU[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int y = y0 + 4 * k;
+    const int x = xs[k], y = ys[k];
     const int j = hit[k] ? idx[k] : a.w + 1;                          // (a pixel with all four neighbours inside the plane)
-    good[k] = (useMask && hit[k]) ? rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)] : (uint8_t)1;
-    kR[k] = a.kfImage[j + 1]; kL[k] = a.kfImage[j - 1]; kD[k] = a.kfImage[j + a.w]; kU[k] = a.kfImage[j - a.w];
+    if (CAND) {
+      good[k] = 1; kR[k] = kL[k] = kD[k] = kU[k] = 0.f;
+      if (hit[k]) {
+        if (useMask) good[k] = rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)];
+        kR[k] = a.kfImage[j + 1]; kL[k] = a.kfImage[j - 1]; kD[k] = a.kfImage[j + a.w]; kU[k] = a.kfImage[j - a.w];
+      }
+    } else {
+      good[k] = (useMask && hit[k]) ? rf.wasGood[(x >> 1) + (a.w >> 1) * (y >> 1)] : (uint8_t)1;
+      kR[k] = a.kfImage[j + 1]; kL[k] = a.kfImage[j - 1]; kD[k] = a.kfImage[j + a.w]; kU[k] = a.kfImage[j - a.w];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     epx[k] = 0; epy[k] = 0;
     if (hit[k]) {
       if (!good[k]) hit[k] = false;
-      else hit[k] = make_and_check_epl(a, rf, x, y0 + 4 * k, kR[k], kL[k], kD[k], kU[k], &epx[k], &epy[k]);
+      else hit[k] = make_and_check_epl(a, rf, xs[k], ys[k], kR[k], kL[k], kD[k], kU[k], &epx[k], &epy[k]);
     }
   }
+}
+// the survivors of a workgroup's pixels, compacted, go to their map's queue (one atomic per workgroup and call)
+__device__ __forceinline__ void observe_queue_append(const ObserveArgs& a, const int (&xs)[4], const int (&ys)[4], const bool (&hit)[4],
+                                                     const float (&epx)[4], const float (&epy)[4], int* s_wcount, int* s_base) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  int rank[4], wc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned long long bal = __ballot(hit[k]);
+    rank[k] = wc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    wc += __popcll(bal);
+  }
+  if ((tid & 63) == 0) s_wcount[wave] = wc;
+  __syncthreads();
+  if (tid == 0) {
+    const int tot = (s_wcount[0] + s_wcount[1]) + (s_wcount[2] + s_wcount[3]);
+    *s_base = tot > 0 ? atomicAdd(a.qcount, tot) : 0;
+  }
+  __syncthreads();
+  int off = *s_base;
+#pragma unroll
+  for (int k = 0; k < 4; k++) off += k < wave ? s_wcount[k] : 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (hit[k]) a.queue[off + rank[k]] = make_float4(__int_as_float(xs[k] + ys[k] * a.w), epx[k], epy[k], 0.f);
 }
 __global__ __launch_bounds__(256) void k_observe_select_batch(const ObserveArgs* __restrict__ items) {
   const ObserveArgs& a = items[blockIdx.z];
@@ -778,29 +820,63 @@ __global__ __launch_bounds__(256) void k_observe_select_batch(const ObserveArgs*
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int x = blockIdx.x * 64 + lane;
   const int y0 = blockIdx.y * 16 + wave;                              // the lane's pixels: rows y0, y0 + 4, y0 + 8, y0 + 12 of the 64x16 tile
-  bool hit[4];
-  float epx[4], epy[4];
-  observe_front4(a, x, y0, hit, epx, epy);
-  int rank[4], wc = 0;
+  int xs[4], ys[4];
+  bool in[4], hit[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const unsigned long long bal = __ballot(hit[k]);
-    rank[k] = wc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-    wc += __popcll(bal);
+    xs[k] = x; ys[k] = y0 + 4 * k;
+    in[k] = !(x < 3 || x >= a.w - 3 || ys[k] < 3 || ys[k] >= a.h - 3);
   }
-  if (lane == 0) s_wcount[wave] = wc;
-  __syncthreads();
-  if (tid == 0) {
-    const int tot = (s_wcount[0] + s_wcount[1]) + (s_wcount[2] + s_wcount[3]);
-    s_base = tot > 0 ? atomicAdd(a.qcount, tot) : 0;
+  float epx[4], epy[4];
+  observe_front4<false>(a, xs, ys, in, hit, epx, epy);
+  observe_queue_append(a, xs, ys, hit, epx, epy, s_wcount, &s_base);
+}
+// The select pass over the keyframe's gradient candidates (round 6): the two tests that depend on the keyframe alone — the 3-pixel border
+// and maxGradients >= minUseGrad, which three pixels in four fail on a typical keyframe — were answered when the frame became a keyframe
+// (k_grad_candidates, frame.hip).  One wave per group of 1024 consecutive pixels walks the group's list, 256 candidates per trip, four per
+// lane with their loads in flight together (the entries of a trip are requested before the count is known: beyond it they are ignored):
+// a quarter of the waves of the every-pixel pass, each with one more (short) round trip, and only candidates request hypothesis planes.
+// Used when no map of the call can hold a hypothesis below the threshold (lsdhip_depthmap::lowGradHypPossible); same tests in the same
+// order on the same pixels otherwise, and the queue's order is immaterial: every plane bit-identical (tests/test_multiseq_gpu.py).
+__global__ __launch_bounds__(256) void k_observe_select_cand_batch(const ObserveArgs* __restrict__ items) {
+  const ObserveArgs& a = items[blockIdx.z];
+  __shared__ int s_wcount[4];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n0 = a.w * a.h, ngroups = (n0 + 1023) >> 10;
+  const int g = blockIdx.x * 4 + wave;
+  const bool live = g < ngroups;
+  LSD_G const uint16_t* list = a.gradCand + (size_t)(live ? g : 0) * 1024;
+  const int count = live ? (int)a.gradCand[(size_t)ngroups * 1024 + g] : 0;
+  int maxCount = count;                                                // (the workgroup's waves take the same number of trips: the appends hold barriers)
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int gq = blockIdx.x * 4 + q;
+    const int cq = gq < ngroups ? (int)a.gradCand[(size_t)ngroups * 1024 + gq] : 0;
+    maxCount = cq > maxCount ? cq : maxCount;
   }
-  __syncthreads();
-  int off = s_base;
+  const float inv_w = 1.0f / (float)a.w;
+  for (int e0 = 0; e0 < maxCount; e0 += 256) {
+    int xs[4], ys[4];
+    bool in[4], hit[4];
+    unsigned off[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) off += k < wave ? s_wcount[k] : 0;
+    for (int k = 0; k < 4; k++) off[k] = list[e0 + lane + 64 * k];      // (within the group's 1024 slots)
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (hit[k]) a.queue[off + rank[k]] = make_float4(__int_as_float(x + (y0 + 4 * k) * a.w), epx[k], epy[k], 0.f);
+    for (int k = 0; k < 4; k++) {
+      in[k] = e0 + lane + 64 * k < count;
+      const int i = (g << 10) + (int)off[k];
+      int y = (int)((float)i * inv_w);
+      int x = i - y * a.w;
+      if (x < 0) { y--; x += a.w; }
+      if (x >= a.w) { y++; x -= a.w; }
+      xs[k] = in[k] ? x : 3; ys[k] = in[k] ? y : 3;
+    }
+    float epx[4], epy[4];
+    observe_front4<true>(a, xs, ys, in, hit, epx, epy);
+    observe_queue_append(a, xs, ys, hit, epx, epy, s_wcount, &s_base);
+    __syncthreads();                                                   // (s_wcount / s_base are reused by the next trip)
+  }
 }
 // (144 registers, three waves per SIMD; capped at 128 — four waves, 32 bytes of scratch per lane — the 32-sequence loop ran the same:
 // profiles/r05_notes.md)
@@ -1963,6 +2039,7 @@ static int observe(lsdhip_depthmap* dm, lsdhip_frame** refs, int n) {
       if (n == 1) hipLaunchKernelGGL((k_observe<true, 2>), grid, dim3(64), 0, lsd_map_stream(c), a);
       else hipLaunchKernelGGL((k_observe<false, 2>), grid, dim3(64), 0, lsd_map_stream(c), a);
     }
+    dm->lowGradHypPossible = false;   // (the pass drops a hypothesis on a pixel below the gradient threshold: observe_front)
   }
   if (a.counters) hipLaunchKernelGGL(k_obs_count_sum, dim3(1), dim3(256), 0, lsd_map_stream(c), (const unsigned long long*)dm->d_obsCounters, dm->obsCounterWaves, dm->d_obsAcc);
   HIPCHK(hipGetLastError());
@@ -2090,6 +2167,7 @@ extern "C" int lsdhip_depth_init_gt(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   if (int rcl = lsd_frame_require_level0(kf)) return rcl;   // a DepthMap's keyframe is asked for gradients(0) / maxGradients(0)
+  dm->lowGradHypPossible = true;
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = false;
   int n = c->w * c->h;
@@ -2106,6 +2184,7 @@ extern "C" int lsdhip_depth_init_random(lsdhip_depthmap* dm, lsdhip_frame* kf) {
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   if (int rcl = lsd_frame_require_level0(kf)) return rcl;
+  dm->lowGradHypPossible = true;
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = false;
   // initializeRandomly (DepthMap.cpp:883-916) draws from the C library's rand() in pixel order: a host-side init path.
@@ -2143,6 +2222,7 @@ extern "C" int lsdhip_depth_set_from_existing(lsdhip_depthmap* dm, lsdhip_frame*
   LSD_CTX_LOCK(c);
   HIPCHK(hipSetDevice(c->device));
   if (int rcl = lsd_frame_require_level0(kf)) return rcl;
+  dm->lowGradHypPossible = true;
   dm->activeKeyFrame = kf;
   kf->numMappedOnThis = 0;
   kf->numFramesTrackedOnThis = 0;
@@ -2252,6 +2332,8 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
   int* qcountHost = (int*)((uint8_t*)hostBlob + obsBytes + regBytes);       // the queues' fill counts start from the zeros copied here
   int* qcountDev = (int*)((uint8_t*)dev + obsBytes + regBytes);
   int nSet = 0;
+  static const bool candOff = getenv("LSDHIP_OBS_CAND") && getenv("LSDHIP_OBS_CAND")[0] == '0';   // developer A/B (round 6)
+  bool candidates = !candOff;     // the select pass walks the keyframes' gradient candidates: every map of the call must qualify
   for (int j = 0; j < n; j++) {
     lsdhip_depthmap* dm = maps[j];
     lsdhip_frame* kf = dm->activeKeyFrame;
@@ -2265,6 +2347,8 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
 #endif
     a.queue = lsd_g(split ? dm->d_obsQueue : nullptr);
     a.qcount = lsd_g(qcountDev + j);
+    a.gradCand = lsd_g((const uint16_t*)kf->d_gradCand);
+    if (dm->lowGradHypPossible || kf->gradCandTh != a.minUseGrad) candidates = false;
     qcountHost[j] = 0;
     dm->d_refs = nullptr;
     dm->d_refByID = nullptr;
@@ -2289,7 +2373,8 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
       if (!c->d_obsBatchAcc) { HIPCHK(hipMalloc((void**)&c->d_obsBatchAcc, 66 * 8)); HIPCHK(hipMemsetAsync(c->d_obsBatchAcc, 0, 66 * 8, ms)); }
       acc = c->d_obsBatchAcc;
     }
-    hipLaunchKernelGGL(k_observe_select_batch, dim3((c->w + 63) / 64, (c->h + 15) / 16, n), dim3(256), 0, ms, (const ObserveArgs*)dev);
+    if (candidates) hipLaunchKernelGGL(k_observe_select_cand_batch, dim3((lsd_gradcand_groups(c->w * c->h) + 3) / 4, 1, n), dim3(256), 0, ms, (const ObserveArgs*)dev);
+    else hipLaunchKernelGGL(k_observe_select_batch, dim3((c->w + 63) / 64, (c->h + 15) / 16, n), dim3(256), 0, ms, (const ObserveArgs*)dev);
     hipLaunchKernelGGL(k_observe_walk_batch, dim3(walkWaves), dim3(64), 0, ms, (const ObserveArgs*)dev, (const int*)qcountDev, n, acc);
   } else {
     hipLaunchKernelGGL((k_observe_batch<2>), dim3((c->w + 31) / 32, (c->h + 1) / 2, n), dim3(64), 0, ms, (const ObserveArgs*)dev);
@@ -2309,7 +2394,7 @@ extern "C" int lsdhip_depth_update_batch(int n, lsdhip_depthmap** maps, lsdhip_f
   HIPCHK(hipGetLastError());
   rc = lsd_args_release(c, dev, ms);
   if (rc) return rc;
-  for (int j = 0; j < n; j++) swap_valid(maps[j]);
+  for (int j = 0; j < n; j++) { swap_valid(maps[j]); maps[j]->lowGradHypPossible = false; }   // (every form of the observe pass drops a hypothesis below the threshold)
   // ---- Frame::setDepth's second half for the keyframes that were due -------------------------------------------------------------------
   if (nSet > 0) {
     std::vector<lsdhip_frame*> kfs;
@@ -2728,6 +2813,7 @@ extern "C" int lsdhip_depth_upload(lsdhip_depthmap* dm, lsdhip_frame* kf, const 
   HIPCHK(hipMemcpyAsync(dm->cur.var_s, vars.data(), n * 4, hipMemcpyHostToDevice, lsd_map_stream(c)));
   HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   if (int rcl = lsd_frame_require_level0(kf)) return rcl;
+  dm->lowGradHypPossible = true;
   dm->activeKeyFrame = kf;
   dm->activeKeyFrameIsReactivated = reactivated != 0;
   return LSDHIP_OK;

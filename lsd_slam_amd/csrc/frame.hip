@@ -218,6 +218,50 @@ __global__ __launch_bounds__(256) void k_level0_gradients_batch(const Level0Item
   level0_gradients_px(a, w, h);
 }
 
+// Gradient candidates of a keyframe (lsdhip_frame::d_gradCand): one workgroup per group of 1024 consecutive pixels, four per lane; the
+// offsets of the group's candidates — inside the 3-pixel border, !(maxGradients < minUseGrad): the two tests of observeDepthRow that
+// depend on nothing but the keyframe (DepthMap.cpp:111-131) — compacted in pixel order, and their number.
+struct GradCandItem {
+  LSD_G const float* maxgrad;
+  LSD_G uint16_t* cand;
+};
+__device__ __forceinline__ void grad_cand_group(const GradCandItem& a, const int w, const int h, const float th) {
+  __shared__ int s_w[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n0 = w * h, g = blockIdx.x;
+  const int i0 = g * 1024 + tid * 4;
+  unsigned m = 0;
+  int y = i0 / w, x = i0 - y * w;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = i0 + k;
+    if (i < n0 && !(x < 3 || x >= w - 3 || y < 3 || y >= h - 3) && !(a.maxgrad[i] < th)) m |= 1u << k;
+    if (++x >= w) { x = 0; y++; }
+  }
+  const int cnt = __popc(m);
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int pos = incl - cnt;
+#pragma unroll
+  for (int q = 0; q < 4; q++) pos += q < wave ? s_w[q] : 0;
+  LSD_G uint16_t* out = a.cand + (size_t)g * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if ((m >> k) & 1u) out[pos++] = (uint16_t)(tid * 4 + k);
+  if (tid == 0) a.cand[(size_t)((n0 + 1023) >> 10) * 1024 + g] = (uint16_t)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+__global__ __launch_bounds__(256) void k_grad_candidates(GradCandItem a, int w, int h, float th) { grad_cand_group(a, w, h, th); }
+__global__ __launch_bounds__(256) void k_grad_candidates_batch(const GradCandItem* __restrict__ items, int w, int h, float th) {
+  const GradCandItem a = items[blockIdx.y];
+  grad_cand_group(a, w, h, th);
+}
+
 // inverse-variance pooling of one 2x2 block, children in the order idx, idx+1, idx+sw, idx+sw+1
 __device__ __forceinline__ void pool4(const float id[4], const float var[4], float& oid, float& ovar) {
   float idepthSumsSum = 0.f, ivarSumsSum = 0.f;
@@ -1204,6 +1248,7 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   for (int l = 0; l < LSD_LEVELS; l++) take((size_t)c->wl[l] * c->hl[l] * 4);
   for (int s2 = 0; s2 < 2; s2++)                                                 // reference blocks of levels >= 1, one set per depth plane set
     for (int l = 1; l < LSD_LEVELS; l++) take(lsd_refblk_bytes(c->wl[l] * c->hl[l]));
+  take(lsd_gradcand_bytes((int)n0));                                             // gradient candidates (keyframes)
   char* base = nullptr;
   c->arena_bytes = align_up(off, 256);
   if (!c->free_arenas.empty()) {
@@ -1229,6 +1274,7 @@ static int frame_alloc(lsdhip_ctx* c, int id, lsdhip_frame** out) {
   for (int l = 0; l < LSD_LEVELS; l++) f->d_idepthVarW[l] = (float*)(base + offs[k++]);
   for (int l = 1; l < LSD_LEVELS; l++) f->d_refBlk[l] = (uint8_t*)(base + offs[k++]);
   for (int l = 1; l < LSD_LEVELS; l++) f->d_refBlkW[l] = (uint8_t*)(base + offs[k++]);
+  f->d_gradCand = (uint16_t*)(base + offs[k++]);
   *out = f;
   return LSDHIP_OK;
 }
@@ -1241,7 +1287,7 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
   lsdhip_host_mark(21);
   hipLaunchKernelGGL(k_image_pyramid, grid, dim3(256), 0, stream, src ? src : f->d_gray, f->d_image[0], f->d_image[1], f->d_image[2],
                      f->d_image[3], f->d_image[4], c->w, c->h, (float4*)nullptr, (float*)nullptr);
-  f->level0Ready = false;
+  f->level0Ready = false; f->gradCandTh = -1.0f;
   GradMaxArgs ga;
   int nb = 0;
   for (int l = 0; l < LSD_LEVELS; l++) {
@@ -1286,24 +1332,31 @@ int lsd_frames_require_level0(lsdhip_frame** fs, int n) {
     it.img0 = lsd_g((const float*)f->d_image[0]); it.grad0 = lsd_g(f->d_grad[0]); it.absgrad = lsd_g(f->d_absgrad);
     GradMaxArgs ga;
     fill_max(f, ga);
+    GradCandItem gc;
+    gc.maxgrad = lsd_g((const float*)f->d_maxgrad); gc.cand = lsd_g(f->d_gradCand);
     hipLaunchKernelGGL(k_level0_gradients, dim3((n0 + 255) / 256), dim3(256), 0, ms, it, c->w, c->h);
     hipLaunchKernelGGL(k_gradients_max, dim3((n0 + 255) / 256), dim3(256), 0, ms, ga);
+    hipLaunchKernelGGL(k_grad_candidates, dim3(lsd_gradcand_groups(n0)), dim3(256), 0, ms, gc, c->w, c->h, c->params.minUseGrad);
   } else {
-    const size_t itBytes = align_up(sizeof(Level0Item) * (size_t)m, 256);
-    std::vector<uint8_t> blob(itBytes + sizeof(GradMaxArgs) * (size_t)m);
+    const size_t itBytes = align_up(sizeof(Level0Item) * (size_t)m, 256), gmBytes = align_up(sizeof(GradMaxArgs) * (size_t)m, 256);
+    std::vector<uint8_t> blob(itBytes + gmBytes + sizeof(GradCandItem) * (size_t)m);
     for (int j = 0; j < m; j++) {
       Level0Item& it = ((Level0Item*)blob.data())[j];
       it.img0 = lsd_g((const float*)todo[j]->d_image[0]); it.grad0 = lsd_g(todo[j]->d_grad[0]); it.absgrad = lsd_g(todo[j]->d_absgrad);
       fill_max(todo[j], ((GradMaxArgs*)(blob.data() + itBytes))[j]);
+      GradCandItem& gc = ((GradCandItem*)(blob.data() + itBytes + gmBytes))[j];
+      gc.maxgrad = lsd_g((const float*)todo[j]->d_maxgrad); gc.cand = lsd_g(todo[j]->d_gradCand);
     }
     void* dev = nullptr;
     if (int rc = lsd_args_push(c, blob.data(), blob.size(), ms, &dev)) return rc;
     hipLaunchKernelGGL(k_level0_gradients_batch, dim3((n0 + 255) / 256, m), dim3(256), 0, ms, (const Level0Item*)dev, c->w, c->h);
     hipLaunchKernelGGL(k_gradients_max_batch, dim3((n0 + 255) / 256, m), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + itBytes));
+    hipLaunchKernelGGL(k_grad_candidates_batch, dim3(lsd_gradcand_groups(n0), m), dim3(256), 0, ms,
+                       (const GradCandItem*)((const uint8_t*)dev + itBytes + gmBytes), c->w, c->h, c->params.minUseGrad);
     if (int rc = lsd_args_release(c, dev, ms)) return rc;
   }
   HIPCHK(hipGetLastError());
-  for (lsdhip_frame* f : todo) f->level0Ready = true;
+  for (lsdhip_frame* f : todo) { f->level0Ready = true; f->gradCandTh = c->params.minUseGrad; }
   return LSDHIP_OK;
 }
 int lsd_frame_require_level0(lsdhip_frame* f) { return lsd_frames_require_level0(&f, 1); }
@@ -1536,7 +1589,7 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
     pi[j].gray = lsd_g(images_on_device ? gray[j] : f->d_gray);
     for (int l = 0; l < LSD_LEVELS; l++) pi[j].img[l] = lsd_g(f->d_image[l]);
     pi[j].grad0 = nullptr; pi[j].absgrad0 = nullptr;   // keyframe planes: lsd_frames_require_level0
-    f->level0Ready = false;
+    f->level0Ready = false; f->gradCandTh = -1.0f;
     GradMaxArgs& ga = gi[j];
     nb = 0;
     for (int l = 0; l < LSD_LEVELS; l++) {
@@ -1603,7 +1656,7 @@ extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float
   LSD_CTX_LOCK(c);
   size_t n = (size_t)c->wl[level] * c->hl[level];
   const void* src = nullptr;
-  if ((what == 1 && level == 0) || what == 2) { if (int rc = lsd_frame_require_level0_for_tracking(f)) return rc; }   // built on demand
+  if ((what == 1 && level == 0) || what == 2 || what == 6) { if (int rc = lsd_frame_require_level0_for_tracking(f)) return rc; }   // built on demand
   if (c->pipeline) { if (int rc = lsd_sync_all(c)) return rc; }
   else if (lsd_map_stream(c) != c->stream) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));   // (an open lane region)
   switch (what) {
@@ -1619,6 +1672,12 @@ extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float
       if (level < 1) return LSDHIP_E_ARG;
       src = (f->depthPending ? f->d_refBlkW : f->d_refBlk)[level];
       HIPCHK(hipMemcpyAsync(out, src, lsd_refblk_bytes((int)n), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return LSDHIP_OK;
+    // the keyframe planes' gradient candidates (k_grad_candidates), as uint16: ceil(pixels / 1024) groups of 1024 offsets, then one count per group
+    case 6:
+      if (level != 0) return LSDHIP_E_ARG;
+      HIPCHK(hipMemcpyAsync(out, f->d_gradCand, lsd_gradcand_bytes((int)n), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       return LSDHIP_OK;
     default: return LSDHIP_E_ARG;
@@ -1672,6 +1731,12 @@ extern "C" int lsdhip_frame_set_maxgrad(lsdhip_frame* f, const float* maxgrad_ho
   if (c->pipeline) { if (int rcs = lsd_sync_all(c)) return rcs; }
   else if (lsd_map_stream(c) != c->stream) HIPCHK(hipStreamSynchronize(lsd_map_stream(c)));
   HIPCHK(hipMemcpyAsync(f->d_maxgrad, maxgrad_host, (size_t)c->w * c->h * 4, hipMemcpyHostToDevice, c->stream));
+  {
+    GradCandItem gc;     // the keyframe's gradient candidates follow the plane
+    gc.maxgrad = lsd_g((const float*)f->d_maxgrad); gc.cand = lsd_g(f->d_gradCand);
+    hipLaunchKernelGGL(k_grad_candidates, dim3(lsd_gradcand_groups(c->w * c->h)), dim3(256), 0, c->stream, gc, c->w, c->h, c->params.minUseGrad);
+    f->gradCandTh = c->params.minUseGrad;
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return LSDHIP_OK;
 }

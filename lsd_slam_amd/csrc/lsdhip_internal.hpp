@@ -292,6 +292,11 @@ struct lsdhip_frame {
   float* d_idepthVar[LSD_LEVELS] = {};
   bool hasIDepth = false;
   bool level0Ready = false;             // d_grad[0], d_absgrad, d_maxgrad are built (keyframe planes, on demand: lsd_frames_require_level0)
+  // gradient candidates of a keyframe (built with the level-0 planes): per group of 1024 consecutive pixels the in-group offsets (uint16,
+  // pixel order) of the pixels DepthMap::observeDepthRow can ever search — inside the 3-pixel border, maxGradients >= minUseGrad
+  // (DepthMap.cpp:111-131) — then one uint16 count per group.  The select pass of a batched update walks these lists instead of all pixels.
+  uint16_t* d_gradCand = nullptr;
+  float gradCandTh = -1.0f;             // the threshold the lists were built for (< 0: not built)
   // Pipelined contexts: Frame::setDepth on the mapping stream writes the second plane set while a tracking job may still read the
   // first; lsdhip_frame_publish_depth (= TrackingReference::importFrame) swaps them.  Non-pipelined contexts write d_idepth directly.
   float* d_idepthW[LSD_LEVELS] = {};
@@ -457,6 +462,11 @@ struct lsdhip_depthmap {
   double* d_red = nullptr;         // reduction scratch (sum, count)
   size_t redStride = 0;            // doubles per set of partials (three sets behind the first 16 doubles)
   bool propClean = false;          // slot counts / chain heads / flags of the K7 scratch are in their rest state
+  // A hypothesis on a pixel below the gradient threshold can only come from outside the update loop (ground-truth / random initialisation,
+  // an upload, re-activation data): propagateDepth and the hole filling create none (DepthMap.cpp:551, :565, :668), and the first
+  // observe pass drops them (:125).  While this is set the select pass of a batched update scans every pixel; afterwards the keyframe's
+  // gradient candidates.
+  bool lowGradHypPossible = true;
   double* h_red = nullptr;         // pinned
   // GPU-side timing of the mapping calls (events on the context's stream; read back lazily)
   hipEvent_t ev[8][2] = {};
@@ -511,6 +521,8 @@ inline void lsd_trace_val(lsdhip_ctx*, int, int, unsigned long long) {}
 inline float** lsd_depth_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthW : f->d_idepth; }
 inline float** lsd_depthvar_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_idepthVarW : f->d_idepthVar; }
 inline uint8_t** lsd_refblk_w(lsdhip_frame* f) { return f->ctx->pipeline ? f->d_refBlkW : f->d_refBlk; }
+inline int lsd_gradcand_groups(int pixels) { return (pixels + 1023) >> 10; }
+inline size_t lsd_gradcand_bytes(int pixels) { return ((size_t)lsd_gradcand_groups(pixels) * 1024 + (size_t)lsd_gradcand_groups(pixels)) * 2; }
 inline int lsd_refblk_blocks(int pixels) { return (pixels + 255) >> 8; }
 inline size_t lsd_refblk_bytes(int pixels) { return (size_t)lsd_refblk_blocks(pixels) * (256 + 4); }
 inline float** lsd_depth_latest(lsdhip_frame* f) { return f->depthPending ? f->d_idepthW : f->d_idepth; }

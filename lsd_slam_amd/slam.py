@@ -178,6 +178,13 @@ class Frame:
         offs = raw[:nblk * 256].reshape(nblk, 64, 4).transpose(0, 2, 1).reshape(nblk, 256)
         return offs.copy(), raw[nblk * 256:].view(np.int32).copy()
 
+    def gradientCandidates(self):
+        """(offsets uint16 [groups, 1024], counts uint16 [groups]) of the frame's gradient candidates (lsdhip_frame_download what = 6)."""
+        ng = (self.width(0) * self.height(0) + 1023) // 1024
+        raw = np.zeros(ng * 1025, np.uint16)
+        check(self.L.lsdhip_frame_download(self.h_, 6, 0, raw.ctypes.data), False)
+        return raw[:ng * 1024].reshape(ng, 1024).copy(), raw[ng * 1024:].copy()
+
     def setDepthFromGroundTruth(self, depth, cov_scale=1.0):
         d = np.ascontiguousarray(depth, dtype=np.float32)
         check(self.L.lsdhip_frame_set_depth_gt(self.h_, d.ctypes.data, cov_scale), False)

@@ -120,6 +120,37 @@ def test_reference_blocks_list_the_oracles_reference_pixels(oracle, hip, w, h):
         assert int(cnts.sum()) == int(flat.sum())
 
 
+@pytest.mark.parametrize("w,h", [(160, 128), (640, 480), (656, 496)])
+def test_gradient_candidates_are_the_pixels_observe_can_search(oracle, hip, w, h):
+    """The lists the batched update's select pass walks (k_grad_candidates, built with a keyframe's level-0 planes): per 1024 consecutive
+    pixels exactly the pixels inside the 3-pixel border whose maxGradients is not below minUseGrad (DepthMap.cpp:111-131), in pixel order;
+    also after the test hook has overwritten the plane."""
+    frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 1)
+    fg = hip.Frame(ctx, 0, frames[0])
+    th = 5.0     # lsdhip_default_params: minUseGrad
+
+    def check():
+        mg = fg.maxGradients(0)
+        ok = ~(mg < th)
+        ok[:3, :] = False; ok[-3:, :] = False; ok[:, :3] = False; ok[:, -3:] = False
+        flat = ok.reshape(-1)
+        offs, cnts = fg.gradientCandidates()
+        ng = (w * h + 1023) // 1024
+        assert offs.shape == (ng, 1024) and cnts.shape == (ng,)
+        for g in range(ng):
+            want = np.flatnonzero(flat[g * 1024:(g + 1) * 1024])
+            assert cnts[g] == len(want), "group %d: count" % g
+            assert np.array_equal(offs[g, :len(want)], want.astype(np.uint16)), "group %d: offsets" % g
+        return int(flat.sum())
+
+    n1 = check()
+    assert 0 < n1 < w * h
+    rng = np.random.default_rng(3)
+    fg.setMaxGradients(rng.uniform(0, 12, (h, w)).astype(np.float32))
+    n2 = check()
+    assert n2 != n1
+
+
 def test_pointcloud_order_and_bits(oracle, hip):
     w, h = 320, 240
     frames, depth0, K, gt, ctx = make_pair(oracle, hip, w, h, 1)
