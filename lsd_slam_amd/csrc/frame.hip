@@ -869,6 +869,7 @@ int lsd_gate_open(lsdhip_ctx* c) {
 int lsd_frame_publish_depth(lsdhip_frame* f) {
   if (!f->depthPending) return LSDHIP_OK;
   for (int l = 0; l < LSD_LEVELS; l++) { std::swap(f->d_idepth[l], f->d_idepthW[l]); std::swap(f->d_idepthVar[l], f->d_idepthVarW[l]); std::swap(f->d_refBlk[l], f->d_refBlkW[l]); }
+  std::swap(f->refBlkValid, f->refBlkValidW);
   f->depthPending = false;
   f->depthSeq = f->depthPendingSeq;
   f->hasIDepth = true;
@@ -1306,6 +1307,35 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
   return LSDHIP_OK;
 }
 
+// The reference blocks of the PUBLISHED depth planes of the keyframes of a throughput-mode tracking batch, where they are missing: a context
+// builds them behind every idepth pyramid only once it has run such a batch (a single-sequence loop never reads them and does not pay the
+// launch).  Queued on the caller's stream — the tracking stream, which is already ordered behind the planes.
+int lsd_frames_require_ref_blocks(lsdhip_frame** kfs, int n, hipStream_t stream) {
+  if (n <= 0) return LSDHIP_OK;
+  lsdhip_ctx* c = kfs[0]->ctx;
+  LSD_CTX_LOCK(c);
+  c->refBlocksWanted = true;
+  std::vector<lsdhip_frame*> todo;
+  for (int j = 0; j < n; j++)
+    if (kfs[j] && !kfs[j]->refBlkValid && std::find(todo.begin(), todo.end(), kfs[j]) == todo.end()) todo.push_back(kfs[j]);
+  if (todo.empty()) return LSDHIP_OK;
+  std::vector<DepthPyrArgs> items(todo.size());
+  for (size_t j = 0; j < todo.size(); j++) {
+    lsdhip_frame* f = todo[j];
+    DepthPyrArgs& a = items[j];
+    memset((void*)&a, 0, sizeof(a));
+    for (int l = 0; l < LSD_LEVELS; l++) { a.id[l] = lsd_g(f->d_idepth[l]); a.var[l] = lsd_g(f->d_idepthVar[l]); a.blk[l] = lsd_g(f->d_refBlk[l]); }
+    a.w0 = c->w; a.h0 = c->h;
+  }
+  void* dev = nullptr;
+  if (int rc = lsd_args_push(c, items.data(), sizeof(DepthPyrArgs) * items.size(), stream, &dev)) return rc;
+  hipLaunchKernelGGL(k_ref_blocks_batch, dim3(lsd_refblk_grid(c), 1, (unsigned)todo.size()), dim3(256), 0, stream, (const DepthPyrArgs*)dev);
+  HIPCHK(hipGetLastError());
+  if (int rc = lsd_args_release(c, dev, stream)) return rc;
+  for (lsdhip_frame* f : todo) f->refBlkValid = true;
+  return LSDHIP_OK;
+}
+
 // Frame::gradients(0) / Frame::maxGradients(0) on demand (the reference's Frame::require, Frame.cpp:560-640): the level-0 gradient texels,
 // |grad| and its 3x3 maximum, for the frames that are asked for them — the keyframes of a DepthMap, a frame given a ground-truth depth,
 // a level-0 tracking job, a download.  Queued on the mapping stream (where the consumers are; a caller on the tracking stream moves the
@@ -1391,7 +1421,8 @@ int lsd_frame_build_idepth_pyramid(lsdhip_frame* f, const double* redPartials, i
   a.redPartials = lsd_g(redPartials); a.redN = redN; a.redOut = lsd_g(redOut);
   for (int l = 0; l < LSD_LEVELS; l++) a.blk[l] = lsd_g(lsd_refblk_w(f)[l]);
   hipLaunchKernelGGL(k_idepth_pyramid, dim3((c->w + 31) / 32, (c->h + 31) / 32 + (redPartials ? 1 : 0)), dim3(256), 0, lsd_map_stream(c), a);
-  hipLaunchKernelGGL(k_ref_blocks, dim3(lsd_refblk_grid(c)), dim3(256), 0, lsd_map_stream(c), a);
+  if (c->refBlocksWanted) hipLaunchKernelGGL(k_ref_blocks, dim3(lsd_refblk_grid(c)), dim3(256), 0, lsd_map_stream(c), a);
+  (c->pipeline ? f->refBlkValidW : f->refBlkValid) = c->refBlocksWanted;
   HIPCHK(hipGetLastError());
   if (c->pipeline) { f->depthPending = true; f->depthPendingSeq = c->mSeq + 1; }   // complete at the caller's record point
   else f->hasIDepth = true;
@@ -1477,7 +1508,8 @@ int lsd_frame_build_idepth_pyramid_batch(lsdhip_frame** fs, int n, const double*
   int rc = lsd_args_push(c, items.data(), sizeof(DepthPyrArgs) * (size_t)n, lsd_map_stream(c), &dev);
   if (rc) return rc;
   hipLaunchKernelGGL(k_idepth_pyramid_batch, dim3((c->w + 31) / 32, (c->h + 31) / 32 + 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
-  hipLaunchKernelGGL(k_ref_blocks_batch, dim3(lsd_refblk_grid(c), 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
+  if (c->refBlocksWanted) hipLaunchKernelGGL(k_ref_blocks_batch, dim3(lsd_refblk_grid(c), 1, n), dim3(256), 0, lsd_map_stream(c), (const DepthPyrArgs*)dev);
+  for (int j = 0; j < n; j++) (c->pipeline ? fs[j]->refBlkValidW : fs[j]->refBlkValid) = c->refBlocksWanted;
   HIPCHK(hipGetLastError());
   rc = lsd_args_release(c, dev, lsd_map_stream(c));
   if (rc) return rc;
@@ -1670,7 +1702,21 @@ extern "C" int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float
     case 5:
       if (!f->hasIDepth && !f->depthPending) return LSDHIP_E_STATE;
       if (level < 1) return LSDHIP_E_ARG;
-      src = (f->depthPending ? f->d_refBlkW : f->d_refBlk)[level];
+      {
+        // of the newest planes (published or not), built here if the context has not been building them (everything is drained above)
+        const bool pend = f->depthPending;
+        bool& valid = pend ? f->refBlkValidW : f->refBlkValid;
+        uint8_t** blk = pend ? f->d_refBlkW : f->d_refBlk;
+        if (!valid) {
+          DepthPyrArgs pa;
+          memset((void*)&pa, 0, sizeof(pa));
+          for (int l = 0; l < LSD_LEVELS; l++) { pa.id[l] = lsd_g(lsd_depth_latest(f)[l]); pa.var[l] = lsd_g(lsd_depthvar_latest(f)[l]); pa.blk[l] = lsd_g(blk[l]); }
+          pa.w0 = c->w; pa.h0 = c->h;
+          hipLaunchKernelGGL(k_ref_blocks, dim3(lsd_refblk_grid(c)), dim3(256), 0, c->stream, pa);
+          valid = true;
+        }
+        src = blk[level];
+      }
       HIPCHK(hipMemcpyAsync(out, src, lsd_refblk_bytes((int)n), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       return LSDHIP_OK;

@@ -197,6 +197,7 @@ struct lsdhip_ctx {
   long long enqEpoch = 0, doneEpoch = 0;
   long long slot_epoch[LSD_NUM_SLOTS] = {};
   int w = 0, h = 0;
+  bool refBlocksWanted = false;          // set by the first throughput-mode tracking batch: from then on every idepth pyramid is followed by k_ref_blocks
   int wl[LSD_LEVELS], hl[LSD_LEVELS];
   LevelIntr intr[LSD_LEVELS];
   float K0[9], K0inv[9];
@@ -310,6 +311,8 @@ struct lsdhip_frame {
   // throughput-mode tracking batch read instead of scanning the level's validity (TrackLevel::kf_refBlk)
   uint8_t* d_refBlk[LSD_LEVELS] = {};
   uint8_t* d_refBlkW[LSD_LEVELS] = {};
+  bool refBlkValid = false, refBlkValidW = false;   // the set holds the blocks of its depth planes (contexts that have not run a throughput-mode
+                                                    // batch yet do not build them: lsdhip_ctx::refBlocksWanted, lsd_frames_require_ref_blocks)
   uint8_t* d_wasGood = nullptr;         // level-1 mask (lazily created, 0xFF)
   bool wasGoodValid = false;
   bool wasGoodPristine = false;         // the mask still holds the 0xFF fill of frame creation
@@ -541,6 +544,7 @@ struct LsdTrackJobScope {
   ~LsdTrackJobScope() { if (c->pipeline && drain) (void)hipStreamSynchronize(c->stream); }
 };
 int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t stream);
+int lsd_frames_require_ref_blocks(lsdhip_frame** kfs, int n, hipStream_t stream);   // the published planes' reference blocks, where missing (frame.hip)
 int lsd_frames_require_level0(lsdhip_frame** fs, int n);    // Frame::gradients(0) / maxGradients(0) on demand, on lsd_map_stream (frame.hip)
 int lsd_frame_require_level0(lsdhip_frame* f);
 int lsd_frame_require_level0_for_tracking(lsdhip_frame* f);

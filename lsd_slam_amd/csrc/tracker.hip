@@ -2106,6 +2106,7 @@ extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame
     }
     if (int rcw = lsd_t_wait_m(c, need)) return rcw;
   }
+  if (n >= LSD_BATCH_THROUGHPUT_MIN_JOBS) { if (int rcb = lsd_frames_require_ref_blocks(keyframes, n, c->stream)) return rcb; }   // the strips read them
   int rc = batch_reserve(t, n);
   if (rc) return rc;
   batch_begin(t, n);
@@ -2144,6 +2145,8 @@ extern "C" int lsdhip_tracker_eval_throughput(lsdhip_tracker* t, int n, lsdhip_f
   LsdTrackJobScope tjob_(c, true);
   if (tjob_.rc) return tjob_.rc;
   HIPCHK(hipSetDevice(c->device));
+  for (int j = 0; j < n; j++) if (!keyframes[j] || !frames[j] || !keyframes[j]->hasIDepth) return LSDHIP_E_ARG;
+  if (int rcb = lsd_frames_require_ref_blocks(keyframes, n, c->stream)) return rcb;
   int rc = batch_reserve(t, n);
   if (rc) return rc;
   batch_begin(t, n);
