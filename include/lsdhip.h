@@ -149,7 +149,8 @@ int lsdhip_frame_download(lsdhip_frame* f, int what, int level, float* out_host)
 int lsdhip_frame_set_depth_gt(lsdhip_frame* f, const float* depth_host, float cov_scale);
 /* raw level-0 idepth / idepthVar planes (what Frame::setDepth leaves behind, Frame.cpp:199-243) */
 int lsdhip_frame_set_depth_planes(lsdhip_frame* f, const float* idepth_host, const float* idepthVar_host);
-/* test / synthetic-benchmark hook: overwrite the level-0 maxGradients plane (Frame::maxGradients(0)) */
+/* test / synthetic-benchmark hook: overwrite the level-0 maxGradients plane (Frame::maxGradients(0)); the frame's gradient candidates
+ * follow.  Call it before the frame becomes a DepthMap's keyframe (a map that already uses it must be re-initialised / uploaded again). */
 int lsdhip_frame_set_maxgrad(lsdhip_frame* f, const float* maxgrad_host);
 /* Frame::refPixelWasGood() (Frame.h:421-437): level-1 mask, bytes 0xFF until the tracker writes 0/1.
  * returns 1 and fills out_host if the mask exists, 0 if it was never created / was cleared. */
