@@ -116,48 +116,21 @@ struct GradArgs {
   int w[LSD_LEVELS], h[LSD_LEVELS];
 };
 
-// Second launch of a new frame: the gradient planes of levels 1..4 (blocks [0, gradBlocks)) and the level-0 maxGradients
-// (the remaining blocks) — independent of each other, both depend on the first launch only.
-// Gradients: 4 B/px read (+ neighbours from L2), 16 B/px written.
-// maxGradients: separable 3x3 max of |grad| with the reference's linear-index validity ranges (see header comment); also
-// leaves the frame's level-1 refPixelWasGood mask in its "never written" state (0xFF), so that the tracker needs no separate
-// fill before its first use.
+// Second launch of a new frame: the gradient texels of levels 1..4 (4 B/px read + neighbours from L2, 16 B/px written); the level-1
+// blocks also leave the frame's refPixelWasGood mask in its "never written" state (0xFF), so that the tracker needs no separate fill
+// before its first use.  (Until round 6 the launch carried the level-0 maxGradients as extra blocks — hence the name; that plane is a
+// keyframe plane now: k_maxgrad_candidates.)
 struct GradMaxArgs {
   LSD_G const float* img[LSD_LEVELS];
   LSD_G float4* grad[LSD_LEVELS];
   int w[LSD_LEVELS], h[LSD_LEVELS];
   int blk0[LSD_LEVELS + 1];     // first block of level l's gradient range (levels 1..4); blk0[LSD_LEVELS] = gradBlocks
-  LSD_G const float* absg;
-  LSD_G float* maxgrad;
   LSD_G uint32_t* wasGoodWords;
   int nMaskWords;
 };
-__device__ __forceinline__ void gradients_max_block(const GradMaxArgs& a) {
-  const int b = blockIdx.x;
-  if (b < a.blk0[LSD_LEVELS]) {
-    int l = 1;
-#pragma unroll
-    for (int k = 2; k < LSD_LEVELS; k++) if (b >= a.blk0[k]) l = k;
-    const int w = a.w[l], h = a.h[l];
-    const int i = (b - a.blk0[l]) * 256 + threadIdx.x;
-    if (l == 1 && i < a.nMaskWords) a.wasGoodWords[i] = 0xFFFFFFFFu;   // the frame's level-1 refPixelWasGood in its "never written" state
-    if (i >= w * h) return;
-    const float* __restrict__ img = a.img[l];
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool inner = (i >= w) && (i < w * (h - 1));
-    if (inner) {
-      g.x = 0.5f * (img[i + 1] - img[i - 1]);
-      g.y = 0.5f * (img[i + w] - img[i - w]);
-      g.z = img[i];
-    }
-    a.grad[l][i] = g;
-    return;
-  }
-  const float* __restrict__ absg = a.absg;
-  const int w = a.w[0], h = a.h[0];
-  const int i = (b - a.blk0[LSD_LEVELS]) * 256 + threadIdx.x;
-  const int n = w * h;
-  if (i >= n) return;
+// Frame::buildMaxGradients (Frame.cpp:682-747) for one pixel: separable 3x3 maximum of |grad| with the reference's linear-index validity
+// ranges (the vertical pass covers [w + 1, w (h - 1) - 1), the horizontal pass the same range; the two border values it copies)
+__device__ __forceinline__ float max_gradient_at(LSD_G const float* __restrict__ absg, const int w, const int h, const int i) {
   const int lo = w + 1, hi = w * (h - 1) - 1;
   auto vmax = [&](int j) -> float {
     if (j < lo || j >= hi) return 0.f;
@@ -177,7 +150,28 @@ __device__ __forceinline__ void gradients_max_block(const GradMaxArgs& a) {
   } else if (i == w || i == hi) {
     out = absg[i];
   }
-  a.maxgrad[i] = out;
+  return out;
+}
+__device__ __forceinline__ void gradients_max_block(const GradMaxArgs& a) {
+  const int b = blockIdx.x;
+  if (b < a.blk0[LSD_LEVELS]) {
+    int l = 1;
+#pragma unroll
+    for (int k = 2; k < LSD_LEVELS; k++) if (b >= a.blk0[k]) l = k;
+    const int w = a.w[l], h = a.h[l];
+    const int i = (b - a.blk0[l]) * 256 + threadIdx.x;
+    if (l == 1 && i < a.nMaskWords) a.wasGoodWords[i] = 0xFFFFFFFFu;   // the frame's level-1 refPixelWasGood in its "never written" state
+    if (i >= w * h) return;
+    const float* __restrict__ img = a.img[l];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool inner = (i >= w) && (i < w * (h - 1));
+    if (inner) {
+      g.x = 0.5f * (img[i + 1] - img[i - 1]);
+      g.y = 0.5f * (img[i + w] - img[i - w]);
+      g.z = img[i];
+    }
+    a.grad[l][i] = g;
+  }
 }
 __global__ __launch_bounds__(256) void k_gradients_max(GradMaxArgs a) { gradients_max_block(a); }
 __global__ __launch_bounds__(256) void k_gradients_max_batch(const GradMaxArgs* __restrict__ items) {
@@ -260,6 +254,40 @@ __global__ __launch_bounds__(256) void k_grad_candidates(GradCandItem a, int w, 
 __global__ __launch_bounds__(256) void k_grad_candidates_batch(const GradCandItem* __restrict__ items, int w, int h, float th) {
   const GradCandItem a = items[blockIdx.y];
   grad_cand_group(a, w, h, th);
+}
+
+// maxGradients(0) and the gradient candidates in one launch (the keyframe planes' second launch): one workgroup of 1024 lanes per group of
+// 1024 consecutive pixels, one pixel per lane.
+struct MaxCandItem {
+  LSD_G const float* absg;
+  LSD_G float* maxgrad;
+  LSD_G uint16_t* cand;
+};
+__device__ __forceinline__ void maxgrad_cand_group(const MaxCandItem& a, const int w, const int h, const float th) {
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n0 = w * h, g = blockIdx.x;
+  const int i = g * 1024 + tid;
+  bool cand = false;
+  if (i < n0) {
+    const float mg = max_gradient_at(a.absg, w, h, i);
+    a.maxgrad[i] = mg;
+    const int y = i / w, x = i - y * w;
+    cand = !(x < 3 || x >= w - 3 || y < 3 || y >= h - 3) && !(mg < th);
+  }
+  const unsigned long long bal = __ballot(cand);
+  if (lane == 0) s_w[wave] = __popcll(bal);
+  __syncthreads();
+  int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)), total = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) { pos += q < wave ? s_w[q] : 0; total += s_w[q]; }
+  if (cand) a.cand[(size_t)g * 1024 + pos] = (uint16_t)tid;
+  if (tid == 0) a.cand[(size_t)((n0 + 1023) >> 10) * 1024 + g] = (uint16_t)total;
+}
+__global__ __launch_bounds__(1024) void k_maxgrad_candidates(MaxCandItem a, int w, int h, float th) { maxgrad_cand_group(a, w, h, th); }
+__global__ __launch_bounds__(1024) void k_maxgrad_candidates_batch(const MaxCandItem* __restrict__ items, int w, int h, float th) {
+  const MaxCandItem a = items[blockIdx.y];
+  maxgrad_cand_group(a, w, h, th);
 }
 
 // inverse-variance pooling of one 2x2 block, children in the order idx, idx+1, idx+sw, idx+sw+1
@@ -1297,7 +1325,6 @@ int lsd_frame_build_pyramids(lsdhip_frame* f, const uint8_t* src, hipStream_t st
     if (l >= 1) nb += (c->wl[l] * c->hl[l] + 255) / 256;
   }
   ga.blk0[LSD_LEVELS] = nb;
-  ga.absg = lsd_g(f->d_absgrad); ga.maxgrad = lsd_g(f->d_maxgrad);
   ga.wasGoodWords = lsd_g((uint32_t*)f->d_wasGood); ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
   lsdhip_host_mark(22);
   hipLaunchKernelGGL(k_gradients_max, dim3(nb), dim3(256), 0, stream, ga);   // the gradient blocks only: maxGradients is a keyframe plane (lsd_frames_require_level0)
@@ -1350,39 +1377,25 @@ int lsd_frames_require_level0(lsdhip_frame** fs, int n) {
   if (todo.empty()) return LSDHIP_OK;
   const hipStream_t ms = lsd_map_stream(c);
   const int n0 = c->w * c->h, m = (int)todo.size();
-  auto fill_max = [&](lsdhip_frame* f, GradMaxArgs& ga) {
-    memset((void*)&ga, 0, sizeof(ga));
-    for (int l = 0; l < LSD_LEVELS; l++) { ga.w[l] = c->wl[l]; ga.h[l] = c->hl[l]; ga.blk0[l] = 0; }
-    ga.blk0[LSD_LEVELS] = 0;                   // no gradient blocks: every block is a maxGradients block
-    ga.absg = lsd_g(f->d_absgrad); ga.maxgrad = lsd_g(f->d_maxgrad);
+  auto fill = [&](lsdhip_frame* f, Level0Item& it, MaxCandItem& mc) {
+    it.img0 = lsd_g((const float*)f->d_image[0]); it.grad0 = lsd_g(f->d_grad[0]); it.absgrad = lsd_g(f->d_absgrad);
+    mc.absg = lsd_g((const float*)f->d_absgrad); mc.maxgrad = lsd_g(f->d_maxgrad); mc.cand = lsd_g(f->d_gradCand);
   };
   if (m == 1) {
-    lsdhip_frame* f = todo[0];
     Level0Item it;
-    it.img0 = lsd_g((const float*)f->d_image[0]); it.grad0 = lsd_g(f->d_grad[0]); it.absgrad = lsd_g(f->d_absgrad);
-    GradMaxArgs ga;
-    fill_max(f, ga);
-    GradCandItem gc;
-    gc.maxgrad = lsd_g((const float*)f->d_maxgrad); gc.cand = lsd_g(f->d_gradCand);
+    MaxCandItem mc;
+    fill(todo[0], it, mc);
     hipLaunchKernelGGL(k_level0_gradients, dim3((n0 + 255) / 256), dim3(256), 0, ms, it, c->w, c->h);
-    hipLaunchKernelGGL(k_gradients_max, dim3((n0 + 255) / 256), dim3(256), 0, ms, ga);
-    hipLaunchKernelGGL(k_grad_candidates, dim3(lsd_gradcand_groups(n0)), dim3(256), 0, ms, gc, c->w, c->h, c->params.minUseGrad);
+    hipLaunchKernelGGL(k_maxgrad_candidates, dim3(lsd_gradcand_groups(n0)), dim3(1024), 0, ms, mc, c->w, c->h, c->params.minUseGrad);
   } else {
-    const size_t itBytes = align_up(sizeof(Level0Item) * (size_t)m, 256), gmBytes = align_up(sizeof(GradMaxArgs) * (size_t)m, 256);
-    std::vector<uint8_t> blob(itBytes + gmBytes + sizeof(GradCandItem) * (size_t)m);
-    for (int j = 0; j < m; j++) {
-      Level0Item& it = ((Level0Item*)blob.data())[j];
-      it.img0 = lsd_g((const float*)todo[j]->d_image[0]); it.grad0 = lsd_g(todo[j]->d_grad[0]); it.absgrad = lsd_g(todo[j]->d_absgrad);
-      fill_max(todo[j], ((GradMaxArgs*)(blob.data() + itBytes))[j]);
-      GradCandItem& gc = ((GradCandItem*)(blob.data() + itBytes + gmBytes))[j];
-      gc.maxgrad = lsd_g((const float*)todo[j]->d_maxgrad); gc.cand = lsd_g(todo[j]->d_gradCand);
-    }
+    const size_t itBytes = align_up(sizeof(Level0Item) * (size_t)m, 256);
+    std::vector<uint8_t> blob(itBytes + sizeof(MaxCandItem) * (size_t)m);
+    for (int j = 0; j < m; j++) fill(todo[j], ((Level0Item*)blob.data())[j], ((MaxCandItem*)(blob.data() + itBytes))[j]);
     void* dev = nullptr;
     if (int rc = lsd_args_push(c, blob.data(), blob.size(), ms, &dev)) return rc;
     hipLaunchKernelGGL(k_level0_gradients_batch, dim3((n0 + 255) / 256, m), dim3(256), 0, ms, (const Level0Item*)dev, c->w, c->h);
-    hipLaunchKernelGGL(k_gradients_max_batch, dim3((n0 + 255) / 256, m), dim3(256), 0, ms, (const GradMaxArgs*)((const uint8_t*)dev + itBytes));
-    hipLaunchKernelGGL(k_grad_candidates_batch, dim3(lsd_gradcand_groups(n0), m), dim3(256), 0, ms,
-                       (const GradCandItem*)((const uint8_t*)dev + itBytes + gmBytes), c->w, c->h, c->params.minUseGrad);
+    hipLaunchKernelGGL(k_maxgrad_candidates_batch, dim3(lsd_gradcand_groups(n0), m), dim3(1024), 0, ms,
+                       (const MaxCandItem*)((const uint8_t*)dev + itBytes), c->w, c->h, c->params.minUseGrad);
     if (int rc = lsd_args_release(c, dev, ms)) return rc;
   }
   HIPCHK(hipGetLastError());
@@ -1630,7 +1643,6 @@ extern "C" int lsdhip_frame_create_batch(lsdhip_ctx* c, int n, const int* ids, c
       if (l >= 1) nb += (c->wl[l] * c->hl[l] + 255) / 256;
     }
     ga.blk0[LSD_LEVELS] = nb;
-    ga.absg = lsd_g(f->d_absgrad); ga.maxgrad = lsd_g(f->d_maxgrad);
     ga.wasGoodWords = lsd_g((uint32_t*)f->d_wasGood); ga.nMaskWords = (c->wl[1] * c->hl[1] + 3) / 4;
     f->wasGoodPristine = true;
   }
