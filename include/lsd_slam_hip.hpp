@@ -369,6 +369,7 @@ class SE3Tracker {
   int levelEvaluations[LSDHIP_PYRAMID_LEVELS] = {0, 0, 0, 0, 0};   // evaluations of the last trackFrame per pyramid level
   int numLaunches = 0;                         // evaluating launches of the last job (< numEvaluations: retries share launches)
   void setSpeculation(int trials, int finestLevelWorkgroups = 0) { check(lsdhip_tracker_set_speculation(h_, trials, finestLevelWorkgroups), "lsdhip_tracker_set_speculation"); }
+  void setBatchCoarseMinJobs(int minJobs) { check(lsdhip_tracker_set_batch_coarse_min_jobs(h_, minJobs), "lsdhip_tracker_set_batch_coarse_min_jobs"); }
 
  private:
   void pushSettings() {   // the public `settings` member is plain data in the reference: hand it over before every job

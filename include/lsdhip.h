@@ -61,6 +61,7 @@ typedef struct lsdhip_build_defaults_t {
   int spec_workgroups, spec_workgroups_above_pixels;
   int spec_trials_max;                                  /* largest `trials` lsdhip_tracker_set_speculation accepts */
   int batch_throughput_min_jobs, batch_strip_workgroups;  /* lsdhip_tracker_track_batch: throughput mode */
+  int batch_coarse_min_jobs, batch_coarse_max_pixels, batch_coarse_max_points;   /* ... its coarse levels: lsdhip_tracker_set_batch_coarse_min_jobs */
 } lsdhip_build_defaults_t;
 void lsdhip_build_defaults(lsdhip_build_defaults_t* out);
 
@@ -232,6 +233,12 @@ int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
  * other values are rounded down to a multiple of 8 (one band of tiles per XCD), values below 8 up to 8.  The per-level overrides of
  * the environment (LSDHIP_SPEC_LEVELS) are cleared by this call. */
 int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups);
+/* Throughput-mode batches (lsdhip_tracker_track_batch): from `minJobs` jobs on, the levels of at most 8192 pixels and 5120 valid
+ * reference points that do not write refPixelWasGood (levels 4 and 3 of a 640x480 job) are walked by ONE workgroup per job — the level's
+ * points staged in LDS, the whole LM loop of the level in that workgroup — ahead of the lock-step rounds for the larger levels: same
+ * per-point arithmetic and LM decisions, sums in that workgroup's order.  Default 32 jobs (below, the jobs have the chip to themselves
+ * and the lock-step rounds are as fast); 0: never. */
+int lsdhip_tracker_set_batch_coarse_min_jobs(lsdhip_tracker* t, int minJobs);
 /* out[0] = k_track_step launches of the last job that evaluated (<= its numEvaluations), out[1] = most trials per step (the
  * per-level numbers follow the automatic policy above). */
 int lsdhip_tracker_launch_stats(const lsdhip_tracker* t, int out[2]);
@@ -266,8 +273,8 @@ int lsdhip_tracker_track(lsdhip_tracker* t, lsdhip_frame* keyframe, lsdhip_frame
                          const double frameToReference_initialEstimate[7], lsdhip_track_result* out);
 /* trackFrame for n independent (keyframe, frame) pairs in the same kernel launches (one job per blockIdx.y): the decisions and
  * per-point arithmetic of n lsdhip_tracker_track calls, sums in another order (fewer, fatter workgroups per job); n evaluations share
- * every launch.  From 8 jobs on the batch runs in throughput mode: a step = one LM launch (one workgroup per job) + one evaluation
- * launch whose strips x jobs fill the chip's 768 workgroup slots.  This is how several sequences share
+ * every launch.  From 8 jobs on the batch runs in throughput mode: a lock-step round = one launch whose (trial, strip) workgroups x jobs
+ * fill the chip's 768 workgroup slots, each repeating the LM decision in front of its evaluation.  This is how several sequences share
  * one GPU (BASELINE configs[3] with fewer GPUs than sequences) and how batches of keyframe candidates are checked
  * (SURVEY.md §8(f) N2).  inits: n x 7 doubles, results: n records.  Returns LSDHIP_DIVERGED if any job diverged. */
 int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,

@@ -103,6 +103,9 @@ int lsdloopbatch_set_keyframe_phases(lsdloopbatch* l, const int* phase);
  * lsdloop_set_pipeline: mapper one frame behind, frames tracked on a replaced keyframe dropped).  Before the first run.
  * lsdloopbatch_dropped counts the dropped frames of a sequence. */
 int lsdloopbatch_set_pipeline(lsdloopbatch* l, int on);
+/* lsdhip_tracker_set_batch_coarse_min_jobs of the loop's tracker (sequences per step from which the coarse pyramid levels of a tracking
+ * batch run in one workgroup per sequence; 0: never) */
+int lsdloopbatch_set_coarse_min_jobs(lsdloopbatch* l, int min_jobs);
 long long lsdloopbatch_dropped(lsdloopbatch* l, int sequence);
 /* Read-outs per sequence, for validation against the reference's single-sequence loop (tests/test_multiseq_gpu.py): keep every promoted
  * keyframe alive and report its createKeyFrame rescale factor / point count (as lsdloop_keep_keyframes / lsdloop_keyframe_log); the

@@ -21,7 +21,8 @@ assert HYP_DTYPE.itemsize == 32
 class BuildDefaults(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("ctx_async", "ctx_pipeline", "spec_trials_small", "spec_small_pixels", "spec_trials_mid", "spec_mid_pixels",
                                          "spec_workgroups", "spec_workgroups_above_pixels", "spec_trials_max", "batch_throughput_min_jobs",
-                                         "batch_strip_workgroups")]
+                                         "batch_strip_workgroups", "batch_coarse_min_jobs", "batch_coarse_max_pixels",
+                                         "batch_coarse_max_points")]
 
 
 class Params(C.Structure):
@@ -133,6 +134,7 @@ def _signatures():
         "lsdhip_depth_stage_rows_batch": (i, [vp, i, pvp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "lsdhip_tracker_exec_stats": (i, [vp, vp]),
         "lsdhip_tracker_set_speculation": (i, [vp, i, i]),
+        "lsdhip_tracker_set_batch_coarse_min_jobs": (i, [vp, i]),
         "lsdhip_tracker_launch_stats": (i, [vp, vp]),
         "lsdhip_tracker_summary_stats": (i, [vp, vp]),
         "lsdhip_tracker_step_stats": (i, [vp, vp]),

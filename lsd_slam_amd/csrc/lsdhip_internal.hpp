@@ -362,6 +362,7 @@ struct lsdhip_tracker {
   int cap_override = 0;           // batch tracking: per-job workgroup cap while the jobs of a batch are being described
   int recent[4] = {0, 0, 0, 0};   // evaluating launches of the last jobs: size the launch budget of the next one
   int specC = 6;                  // most trials per launch (LSDHIP_SPEC; 1 = no speculation)
+  int soloMinJobs = -1;           // batches of at least this many jobs walk their coarse levels in one workgroup per job (k_track_solo); 0: never; -1: build default
   bool specAuto = true;           // trials per level from the level's size (see track_device); false after set_speculation
   int specCaps[LSD_LEVELS] = {0, 0, 0, 0, 0};    // per-level workgroups per trial (LSDHIP_SPEC_CAPS; 0 = automatic)
   int specLevel[LSD_LEVELS] = {0, 0, 0, 0, 0};   // per-level trials (LSDHIP_SPEC_LEVELS = "l0,l1,l2,l3,l4"; 0 = automatic / specC)

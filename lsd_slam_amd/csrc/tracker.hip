@@ -951,6 +951,267 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 #endif
 }
 
+// ---- The coarse levels of a throughput-mode job inside ONE workgroup (round 6) --------------------------------------------------------
+// A lock-step round of a batch costs its latency chain (state, partial sums of other workgroups, the LM step, list, pipeline fill,
+// reduction: 11-13 us of workgroup time with 1.5-2.5 us of evaluation in it at levels 3 and 4, profiles/r06_notes.md section 9), every
+// job pays the rounds of the slowest, and every (trial, strip) workgroup repeats the finishing phase.  A level small enough to be one
+// strip (at most LSD_SOLO_MAX_PX pixels, at most LSD_SOLO_MAX_PTS valid reference points: levels 3 and 4 of a 640x480 job) needs none of
+// that: one workgroup per job runs the level's whole LM loop at its own pace and leaves the state at the first larger level for the
+// lock-step rounds (k_track_step<.., true, TS_FUSED> with first = 0).
+//   * What an evaluation needs of a reference point does not depend on the pose: the level's points are STAGED IN LDS once, when the
+//     workgroup enters the level — 16 bytes each: pixel (x | y << 16), 1 / idepth (= the point's z; x and y follow from it and the pixel
+//     with the two multiply-adds of makePointCloud, TrackingReference.cpp:128-138), colour, variance — from the keyframe's reference
+//     blocks (k_ref_blocks, pixel order).  An iteration then has ONE dependent global round trip per trip of 512 points (the four texels
+//     of the new frame) instead of two, and the three tail candidates come out of LDS as well.
+//   * Per iteration four barriers: park the upper half's sums / wave top-3 | fold halves, wave 0 merges the top-3 and requests the tail
+//     candidates' texels | runs of columns | wave 0: totals, tail, lm_wave on its own lanes (no barrier between them) | next iteration.
+// Same arithmetic per point, same LM step (lm_wave), the sums in this kernel's own fixed order; no speculation (a retry is one more
+// iteration of a few microseconds, not a launch).
+#define LSD_SOLO_MAX_PX 8192
+#define LSD_SOLO_MAX_PTS 5120
+// Worth it from this many jobs per batch: one workgroup per job walks its coarse levels in about the time the lock-step rounds take, on
+// n CUs instead of the chip — a gain where other work (the mapping stream of the S-sequence loop) wants the other CUs, a small loss for
+// a few jobs that have the chip to themselves (profiles/r06_notes.md section 21).
+#define LSD_SOLO_MIN_JOBS 32
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2, TrackSummary* __restrict__ outs,
+                                                      const int parity, const int doneWord) {
+  const TrackJob& job = jobs[blockIdx.x];
+  st2 += 2 * (size_t)blockIdx.x;
+  TrackSummary* out = outs + blockIdx.x;
+  constexpr int WAVES = BLOCK / 64;
+  constexpr int HALF = BLOCK / 2;
+  constexpr int CPP = RS_END;
+  constexpr int RSLICE = BLOCK / CPP;
+  constexpr int RRUN = (HALF + RSLICE - 1) / RSLICE;
+  static_assert(WAVES * 3 <= 64 && LSD_SOLO_MAX_PX <= 8192 && LSD_SOLO_MAX_PTS <= 8192, "top-3 merge in one wave; key and slot share a word");
+  __shared__ TrackState S;
+  __shared__ LmShared sh;
+  __shared__ LmPar s_par;
+  __shared__ __attribute__((aligned(16))) float s_red[CPP * (HALF + 1) + RRUN];
+  __shared__ float s_sum[RSLICE][64];
+  __shared__ float s_sub[3][32];
+  __shared__ int s_wtop[WAVES][3];
+  __shared__ uint4 s_pts[LSD_SOLO_MAX_PTS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) {
+    S.T = job.T0;
+    set_eval_pose(S, job.T0);
+    S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
+    S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
+    S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
+    S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
+    S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
+    S.bytes = 0;
+    for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
+    S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
+  }
+  if (tid < 36) S.A[tid] = 0;
+  if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
+  __syncthreads();
+  int listLevel = -1, total = 0;
+  EvalCtx a;
+  for (int guard = 0; guard < 4096; guard++) {
+    const int level = S.level;
+    if (S.done) break;
+    const TrackLevel& L = job.lv[level];
+    const int work = L.w * L.h;
+    if (L.tilePx <= 0 || work > LSD_SOLO_MAX_PX || L.writeMask) break;     // the larger levels (and the one that writes refPixelWasGood): lock-step rounds of strips
+    if (level != listLevel) {
+      make_ctx_dev(job, S, level, a);
+      if (tid == BLOCK - 1) stage_lm_par(job, level, s_par, 1);
+      // the level's points: its reference blocks in pixel order (as a strip of the lock-step rounds builds its list), staged with
+      // everything of the keyframe an evaluation reads
+      const int mblk = (work + 255) >> 8;                   // <= 32
+      const gbyte* offs = (const gbyte*)L.kf_refBlk;
+      const __attribute__((address_space(1))) int* cnts = (const __attribute__((address_space(1))) int*)(offs + ((size_t)mblk << 8));
+      const int cntv = lane < mblk ? cnts[lane] : 0;
+      int incl = cntv + dpp_i0<0x111, 0xf, 0xf>(cntv);
+      incl += dpp_i0<0x112, 0xf, 0xf>(cntv);
+      incl += dpp_i0<0x113, 0xf, 0xf>(cntv);
+      incl += dpp_i0<0x114, 0xf, 0xe>(incl);
+      incl += dpp_i0<0x118, 0xf, 0xc>(incl);
+      incl += dpp_i0<0x142, 0xa, 0xf>(incl);
+      total = __builtin_amdgcn_readlane(incl, 31);
+      if (total > LSD_SOLO_MAX_PTS) break;                  // (every wave computes the same total) more points than the stage holds: strips
+      const int waveU = __builtin_amdgcn_readfirstlane(wave);
+      const float inv_w = 1.0f / (float)a.w;
+      for (int blk = waveU; blk < mblk; blk += WAVES) {
+        const int cb = __builtin_amdgcn_readlane(cntv, blk);
+        const int pb = __builtin_amdgcn_readlane(incl, blk) - cb;
+        const unsigned ow = *(const __attribute__((address_space(1))) unsigned*)(offs + ((size_t)blk << 8) + (lane << 2));
+        unsigned xy[4];
+        float var[4], id[4], img[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int sl = lane + 64 * k;
+          const int i = sl < cb ? (blk << 8) + (int)((ow >> (8 * k)) & 255u) : 0;
+          int y = (int)((float)i * inv_w);
+          int x = i - y * a.w;
+          if (x < 0) { y--; x += a.w; }
+          if (x >= a.w) { y++; x -= a.w; }
+          xy[k] = (unsigned)x | ((unsigned)y << 16);
+          var[k] = a.kf_idepthVar[i];
+          id[k] = a.kf_idepth[i];
+          img[k] = a.kf_image[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int sl = lane + 64 * k;
+          if (sl < cb) {
+            const float inv = lsd_rcp_exact(id[k]);
+            s_pts[pb + sl] = make_uint4(xy[k], __float_as_uint(inv * 1.0f), __float_as_uint(img[k]), __float_as_uint(var[k]));
+          }
+        }
+      }
+      listLevel = level;
+      __syncthreads();
+    } else {
+      // the pose under evaluation (the LM step of the previous iteration left it in S)
+#pragma unroll
+      for (int i = 0; i < 9; i++) a.R[i] = S.R[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) a.t[i] = S.t[i];
+      a.aff_a = S.aff_a; a.aff_b = S.aff_b;
+    }
+    float acc[RS_END];
+#pragma unroll
+    for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
+    int key0 = -1, key1 = -1, key2 = -1;
+    struct StB { int p; unsigned xy; float pz, I_ref, var; PointWarp q; PointTexels t; bool live; };
+    auto stageB = [&](const int p, StB& B) {
+      B.live = p < total;
+      B.p = p;
+      const uint4 e = s_pts[B.live ? p : 0];
+      B.xy = e.x;
+      B.pz = __uint_as_float(e.y); B.I_ref = __uint_as_float(e.z); B.var = __uint_as_float(e.w);
+      const int bx_ = (int)(e.x & 0xffffu), by_ = (int)(e.x >> 16);
+      const float px = B.pz * (a.fxi * bx_ + a.cxi), py = B.pz * (a.fyi * by_ + a.cyi);
+      eval_warp(a, px, py, B.pz, B.q);
+      eval_fetch(a, B.q, B.live && B.q.in_image, B.t);
+    };
+    if (total > 0) {
+      // two trips of texel fetches in flight ahead of the trip being finished
+      auto stageC = [&](const StB& B) {
+        if (B.live) {
+          acc[RS_NREF] += 1.f;
+          if (B.q.in_image) {
+            PointOut o;
+            eval_finish(a, B.q, B.t, B.pz, B.I_ref, B.var, o);
+            // reference order of the point (x h + y, TrackingReference.cpp:128-138) | its slot in the stage
+            top3_insert(((__mul24((int)(B.xy & 0xffffu), a.h) + (int)(B.xy >> 16)) << 13) | B.p, key0, key1, key2);
+            accumulate_point(o, acc);
+          }
+        }
+      };
+      const int rounds = (total + BLOCK - 1) / BLOCK;
+      StB B0, B1, B2;
+      stageB(tid, B0);
+      stageB(tid + BLOCK, B1);
+      for (int r = 0; r < rounds; r += 3) {
+        stageB(tid + (r + 2) * BLOCK, B2);
+        stageC(B0);
+        stageB(tid + (r + 3) * BLOCK, B0);
+        stageC(B1);
+        stageB(tid + (r + 4) * BLOCK, B1);
+        stageC(B2);
+      }
+    }
+    // each wave's three largest keys; the upper half parks its sums
+    {
+      int c0 = key0, c1 = key1, c2 = key2;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int m = __builtin_amdgcn_readlane(wave_max_to_lane63(c0), 63);
+        if (lane == 0) s_wtop[wave][r] = m;
+        if (c0 == m && m >= 0) { c0 = c1; c1 = c2; c2 = -1; }
+      }
+    }
+    if (tid >= HALF) {
+#pragma unroll
+      for (int k = 0; k < CPP; k++) s_red[k * (HALF + 1) + tid - HALF] = acc[k];
+    }
+    __syncthreads();
+    // wave 0: the level's three largest keys = the candidates for the tail (the last M % 4 in-image points in reference order); lanes
+    // 0..2 evaluate them once more out of the stage — their texels travel under the next two barriers
+    int cKey = -1;
+    StB cB;
+    if (wave == 0) {
+      int v = lane < WAVES * 3 ? s_wtop[lane / 3][lane - 3 * (lane / 3)] : -1;
+      int top[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        top[r] = __builtin_amdgcn_readlane(wave_max_to_lane63(v), 63);
+        if (v == top[r]) v = -1;
+      }
+      cKey = lane == 0 ? top[0] : (lane == 1 ? top[1] : (lane == 2 ? top[2] : -1));
+      if (cKey >= 0) stageB(cKey & 8191, cB);
+    }
+    if (tid < HALF) {
+#pragma unroll
+      for (int k = 0; k < CPP; k++) s_red[k * (HALF + 1) + tid] = acc[k] + s_red[k * (HALF + 1) + tid];
+    }
+    __syncthreads();
+    {
+      const int slice = tid / CPP, k = tid - slice * CPP;
+      if (slice < RSLICE) {
+        const float* row = s_red + k * (HALF + 1);
+        const int j0 = slice * RRUN;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < RRUN; j++) { const float v = row[j0 + j]; sacc += (j0 + j < HALF) ? v : 0.f; }
+        s_sum[slice][k] = sacc;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float sv = 0.f;
+      if (lane < CPP) {
+        sv = s_sum[0][lane];
+#pragma unroll
+        for (int sl = 1; sl < RSLICE; sl++) sv += s_sum[sl][lane];
+      }
+      if (cKey >= 0) {
+        PointOut o;
+        eval_finish(a, cB.q, cB.t, cB.pz, cB.I_ref, cB.var, o);
+        float* row = s_sub[lane];
+        row[0] = o.werr;
+        int k = 1;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) {
+          const float Jw = o.J[rr] * o.w;
+#pragma unroll
+          for (int cc = rr; cc < 6; cc++) row[k++] = Jw * o.J[cc];
+        }
+        const float resw = o.res * o.w;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) row[k++] = resw * o.J[rr];
+        row[k++] = resw * o.res;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int M = (int)rl(sv, RS_M);
+      const int nsub = (__builtin_amdgcn_readlane(cKey, 0) >= 0) + (__builtin_amdgcn_readlane(cKey, 1) >= 0) + (__builtin_amdgcn_readlane(cKey, 2) >= 0);
+      int need = M & 3;
+      if (need > nsub) need = nsub;
+      // RS_WERR -> 0, RS_A0.. -> 1..21, RS_B0.. -> 22..27, RS_ERR -> 28
+      const int subIdx = (lane == RS_WERR) ? 0 : ((lane >= RS_A0 && lane < RS_B0) ? 1 + lane - RS_A0 : ((lane >= RS_B0 && lane < RS_ERR) ? 22 + lane - RS_B0 : (lane == RS_ERR ? 28 : -1)));
+      if (subIdx >= 0) {
+        if (need > 0) sv -= s_sub[0][subIdx];
+        if (need > 1) sv -= s_sub[1][subIdx];
+        if (need > 2) sv -= s_sub[2][subIdx];
+      }
+      if (lane < RS_NUM) sh.tot[lane] = sv;
+      lm_wave<false>(s_par, S, sv, sh.tot, lane, out, nullptr, 0, 0, doneWord);
+    }
+    __syncthreads();
+  }
+  // what the lock-step rounds load (they read st2[parity of their launch]; a finished job keeps both buffers "done")
+  copy_words<sizeof(TrackState) / 4>(st2 + (1 - parity), &S, tid, BLOCK);
+  if (S.done) copy_words<sizeof(TrackState) / 4>(st2 + parity, &S, tid, BLOCK);
+}
+
 // Pipelined contexts: the frame's refPixelWasGood is what the LAST trial the LM loop executed wrote.  Trial 0 of every launch writes the
 // frame's own plane, trials > 0 write side planes — at the same pixels (the valid reference points do not depend on the pose), so the
 // pixels the job visited are those whose byte in the frame's plane is no longer the 0xFF of frame creation: there the side plane's byte
@@ -1180,6 +1441,12 @@ extern "C" int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int
   if (finestLevelWorkgroups > 0) t->specCap = finestLevelWorkgroups < 8 ? 8 : (finestLevelWorkgroups & ~7);   // multiples of 8 (one tile band per XCD), at least 8
   for (int l = 0; l < LSD_LEVELS; l++) t->specLevel[l] = 0;
   for (int i = 0; i < 4; i++) t->recent[i] = 0;
+  return LSDHIP_OK;
+}
+extern "C" int lsdhip_tracker_set_batch_coarse_min_jobs(lsdhip_tracker* t, int minJobs) {
+  if (!t || minJobs < 0) { lsd_set_error("lsdhip_tracker_set_batch_coarse_min_jobs: minJobs must be >= 0"); return LSDHIP_E_ARG; }
+  LSD_CTX_LOCK(t->ctx);
+  t->soloMinJobs = minJobs;
   return LSDHIP_OK;
 }
 #ifdef LSD_DEVTOOLS
@@ -2005,8 +2272,19 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
     spec.seq = t->batchTag;
     for (int j = 0; j < n; j++) t->h_bsummary[j].exhausted = 0;
   }
+  // the coarse levels of every job inside one workgroup (k_track_solo), then lock-step rounds for the rest
+  static const int soloMinEnv = getenv("LSDHIP_BATCH_SOLO_MIN") ? atoi(getenv("LSDHIP_BATCH_SOLO_MIN")) : LSD_SOLO_MIN_JOBS;   // developer A/B (0: never)
+  const int soloMin = t->soloMinJobs >= 0 ? t->soloMinJobs : soloMinEnv;     // lsdhip_tracker_set_batch_coarse_min_jobs
+  bool soloDue = split && fusedEnv && soloMin > 0 && n >= soloMin;
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    if (soloDue) {
+      soloDue = false;
+      const int dw = polled ? t->batchTag : 1;
+      hipLaunchKernelGGL(k_track_solo<512>, dim3(n), dim3(512), 0, c->stream, (const TrackJob*)t->d_bjobs, t->d_bstate, d_sum, parity, dw);
+      first = 0;
+      parity ^= 1;
+    }
     for (int i = 0; i < budget; i++) {
       spec.last = (polled && i == budget - 1) ? 1 : 0;
       if (split && fusedEnv) {
@@ -2084,6 +2362,7 @@ extern "C" void lsdhip_build_defaults(lsdhip_build_defaults_t* out) {
   out->spec_workgroups = LSD_SPEC_CAP_WORKGROUPS; out->spec_workgroups_above_pixels = LSD_SPEC_CAP_ABOVE_PX;
   out->spec_trials_max = LSD_SPEC_MAX;
   out->batch_throughput_min_jobs = LSD_BATCH_THROUGHPUT_MIN_JOBS; out->batch_strip_workgroups = LSD_BATCH_STRIP_WORKGROUPS;
+  out->batch_coarse_min_jobs = LSD_SOLO_MIN_JOBS; out->batch_coarse_max_pixels = LSD_SOLO_MAX_PX; out->batch_coarse_max_points = LSD_SOLO_MAX_PTS;
 }
 
 extern "C" int lsdhip_tracker_track_batch(lsdhip_tracker* t, int n, lsdhip_frame** keyframes, lsdhip_frame** frames,

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = ["lsdloop_create", "lsdloop_destroy", "lsdloop_run", "lsdloop
                     "lsdloop_last_error", "lsdloop_keep_keyframes", "lsdloop_keyframe_log", "lsdloop_set_live_queue", "lsdloop_set_pipeline", "lsdloop_set_speculation", "lsdloop_observe_time", "lsdloop_comm_unique_id", "lsdloop_comm_init", "lsdloop_comm_destroy",
                     "lsdloop_gather_keyframes", "lsdband_create", "lsdband_destroy", "lsdband_window_rows", "lsdband_layout", "lsdband_load",
                     "lsdband_get", "lsdband_comm_init", "lsdband_run", "lsdband_synchronize", "lsdband_halo_bytes_per_pass", "lsdband_set_packed_exchange", "lsdband_set_overlap", "lsdband_tile_runs", "lsdband_plan", "lsdband_ipc_init", "lsdband_ipc_connect", "lsdband_ipc_failed", "lsdloop_gather_counts", "lsdloop_ipc_init", "lsdloop_ipc_connect", "lsdloop_ipc_result", "lsdloop_observe_work",
-                    "lsdloopbatch_create", "lsdloopbatch_destroy", "lsdloopbatch_run", "lsdloopbatch_get_stats", "lsdloopbatch_ctx", "lsdloopbatch_set_keyframe_phases", "lsdloopbatch_set_pipeline", "lsdloopbatch_dropped",
+                    "lsdloopbatch_create", "lsdloopbatch_destroy", "lsdloopbatch_run", "lsdloopbatch_get_stats", "lsdloopbatch_ctx", "lsdloopbatch_set_keyframe_phases", "lsdloopbatch_set_pipeline", "lsdloopbatch_set_coarse_min_jobs", "lsdloopbatch_dropped",
                     "lsdloopbatch_keep_keyframes", "lsdloopbatch_keyframe_log", "lsdloopbatch_last_result", "lsdloopbatch_download_map"]
 
 
@@ -103,6 +103,8 @@ def lib():
         L.lsdloopbatch_set_keyframe_phases.argtypes = [vp, vp]
         L.lsdloopbatch_set_pipeline.restype = i
         L.lsdloopbatch_set_pipeline.argtypes = [vp, i]
+        L.lsdloopbatch_set_coarse_min_jobs.restype = i
+        L.lsdloopbatch_set_coarse_min_jobs.argtypes = [vp, i]
         L.lsdloopbatch_dropped.restype = C.c_longlong
         L.lsdloopbatch_dropped.argtypes = [vp, i]
         L.lsdloopbatch_keep_keyframes.restype = i
@@ -167,6 +169,10 @@ class DriverLoopBatch:
 
     def ctx_handle(self):
         return C.c_void_p(self.L.lsdloopbatch_ctx(self.h_))
+
+    def set_coarse_min_jobs(self, min_jobs):
+        """sequences per step from which a tracking batch walks its coarse levels in one workgroup per sequence (0: never)"""
+        _check(self.L.lsdloopbatch_set_coarse_min_jobs(self.h_, int(min_jobs)))
 
     def set_pipeline(self, on=True):
         """tracking beside mapping for all sequences, the mapper one frame behind (before the first run)"""

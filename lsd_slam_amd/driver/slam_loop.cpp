@@ -188,6 +188,11 @@ extern "C" int lsdloopbatch_get_stats(lsdloopbatch* l, long long* out) {
   return LSDHIP_OK;
 }
 extern "C" void* lsdloopbatch_ctx(lsdloopbatch* l) { return l ? (void*)l->ctx->handle() : nullptr; }
+extern "C" int lsdloopbatch_set_coarse_min_jobs(lsdloopbatch* l, int min_jobs) {
+  if (!l) return LSDHIP_E_ARG;
+  try { l->loop->tracker.setBatchCoarseMinJobs(min_jobs); return LSDHIP_OK; }
+  catch (const Error& e) { g_err = e.what(); return e.status < 0 ? e.status : LSDHIP_E_STATE; }
+}
 extern "C" int lsdloopbatch_set_pipeline(lsdloopbatch* l, int on) {
   if (!l) return LSDHIP_E_ARG;
   try {

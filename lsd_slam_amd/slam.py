@@ -315,6 +315,10 @@ class SE3Tracker:
         """LM retries evaluated per launch (1 = one evaluation per launch); see include/lsdhip.h"""
         check(self.L.lsdhip_tracker_set_speculation(self.h_, int(trials), int(finest_level_workgroups)))
 
+    def set_batch_coarse_min_jobs(self, min_jobs):
+        """throughput-mode batches of at least `min_jobs` jobs walk their coarse levels in one workgroup per job (0: never); see include/lsdhip.h"""
+        check(self.L.lsdhip_tracker_set_batch_coarse_min_jobs(self.h_, int(min_jobs)))
+
     def launch_stats(self):
         """(evaluating launches of the last job, trials per launch)"""
         out = np.zeros(2, np.int32)

@@ -187,6 +187,9 @@ def test_header_prose_states_the_built_defaults(built_lib):
     assert "`trials` (1..%d)" % d.spec_trials_max in spec and "(default %d)" % d.spec_workgroups in spec
     batch = comment_before("int lsdhip_tracker_track_batch(")
     assert "From %d jobs on" % d.batch_throughput_min_jobs in batch and "%d workgroup slots" % d.batch_strip_workgroups in batch
+    coarse = comment_before("int lsdhip_tracker_set_batch_coarse_min_jobs(")
+    assert "Default %d jobs" % d.batch_coarse_min_jobs in coarse
+    assert "at most %d pixels and %d valid reference points" % (d.batch_coarse_max_pixels, d.batch_coarse_max_points) in coarse
     # and the defaults the wrappers document
     assert d.ctx_async == 0 and d.ctx_pipeline == 0
 

@@ -352,8 +352,8 @@ def _s8_inputs():
     return _S8["seqs"]
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_batch_loop_8_seeds_640x480_against_the_oracle(hip, pipelined):
+@pytest.mark.parametrize("pipelined,coarse", [(False, None), (True, None), (True, 1)])
+def test_batch_loop_8_seeds_640x480_against_the_oracle(hip, pipelined, coarse):
     """lsd_slam_hip::SlamLoopBatch at the BASELINE configuration — 640x480, S = 8 sequences with 8 DISTINCT seeds, throughput mode of the
     tracker on (>= 8 jobs), shared updateKeyframe / keyframe-change launches, both execution models — with every sequence held against the
     ORACLE's run of the single-sequence loop (tests/seq_loops.py: C/SlamSystem.cpp:890-1040 + :542-614, Frame::setDepth in every
@@ -366,7 +366,9 @@ def test_batch_loop_8_seeds_640x480_against_the_oracle(hip, pipelined):
     Python-driven single loop take the device's path there (tools/s8_debug.py).
     Where a sequence sits on one of the loop's decision edges (the oracle itself moves
     by ~3e-4 under a 1e-6 perturbation of the first estimate there), it is compared with the closest member of the oracle's own ensemble,
-    exactly as test_sequence_50_frames_hip_vs_oracle does for this loop."""
+    exactly as test_sequence_50_frames_hip_vs_oracle does for this loop.
+    coarse = 1: the same with levels 4 and 3 of every tracking batch walked by one workgroup per sequence (k_track_solo: the default from
+    32 sequences per step, lsdhip_tracker_set_batch_coarse_min_jobs), held to the same bounds."""
     from concurrent.futures import ThreadPoolExecutor
     import oracle.pyoracle as po
     import seq_loops as sl
@@ -383,6 +385,8 @@ def test_batch_loop_8_seeds_640x480_against_the_oracle(hip, pipelined):
         bl = DriverLoopBatch(w, h, K, [imgs[s][0].ctypes.data for s in range(S)], [seqs[s][1] for s in range(S)], kf_every=10, images_on_device=False)
         bl.keep_keyframes(True)
         bl.set_pipeline(pipelined)
+        if coarse is not None:
+            bl.set_coarse_min_jobs(coarse)
         recs = [sl.Record() for _ in range(S)]
         kfs = [0] * S
         for t in range(1, n + 1):

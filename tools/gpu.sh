@@ -71,11 +71,11 @@ print(k, 'frames_s', d[k].get('frames_s'), 'block', d[k].get('frames_s_block_unt
       i=0
       for envs in "" "$@"; do
         echo "== rep $rep arm $i: [$envs]" | tee -a $out/$tag.txt
-        env $envs timeout 300 python tools/bench_batch.py --batches 8,32,64 --rounds 20 2>/dev/null | cut -c1-200 | tee -a $out/$tag.txt
-        env $envs timeout 300 python tools/bench_multiseq.py --S 8 32 --steps 30 2>/dev/null | python -c "
+        env $envs timeout 300 python tools/bench_batch.py --batches ${ABB:-8,32,64} --rounds 20 2>/dev/null | cut -c1-200 | tee -a $out/$tag.txt
+        env $envs timeout 300 python tools/bench_multiseq.py --S ${ABS:-8 32} --steps 30 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-for k in ('S8','S32'):
+for k in [k for k in d if k[:1] == 'S' and k[1:].isdigit()]:
     r=(d[k].get('roofline') or {}).get('track_batch') or {}
     print(k, 'frames_s %.0f block %.0f track_batch %.1f us frac %.4f' % (d[k]['frames_s'], d[k]['frames_s_block_until_mapped'], r.get('avg_launch_us') or 0, r.get('frac') or 0))" | tee -a $out/$tag.txt
         i=$((i+1))
