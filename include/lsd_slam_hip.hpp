@@ -826,6 +826,7 @@ class SlamLoopBatch {
     if (S <= 0 || kfEvery <= 0) throw Error(LSDHIP_E_ARG, "SlamLoopBatch: S > 0 sequences, a fixed keyframe interval > 0");
     const int its[LSDHIP_PYRAMID_LEVELS] = {5, 20, 50, 100, 0};
     std::memcpy(tracker.settings.maxItsPerLvl, its, sizeof(its));
+    tracker.setBatchCoarseMinJobs(coarseMinJobs(false));
     std::vector<int> ids((size_t)S);
     for (int s = 0; s < S; s++) ids[s] = idOf(s, 0);
     std::vector<std::shared_ptr<Frame>> first = Frame::createBatch(w, h, K, ids, firstImages, imagesOnDevice);
@@ -865,10 +866,19 @@ class SlamLoopBatch {
   // (SlamSystem.cpp:559-566), the first frame on a new keyframe starts from se3FromSim3(newKeyframe^-1 * lastTrackedFrame) (:913-920).
   // The tracking batch of step t + 1 — a chain of small latency-bound launches — runs beside the shared updateKeyframe launches and the
   // keyframe changes of step t.  Call before the first step().
+  // One workgroup per sequence for the coarse levels of a tracking batch (lsdhip_tracker_set_batch_coarse_min_jobs) frees the chip for the
+  // mapping launches beside it: worth it from the library's default (32 sequences) where tracking runs beside mapping, from twice as
+  // many where nothing runs beside the batch (measured: profiles/r06_notes.md section 21).  tracker.setBatchCoarseMinJobs overrides.
+  static int coarseMinJobs(bool pipelined) {
+    lsdhip_build_defaults_t d;
+    lsdhip_build_defaults(&d);
+    return pipelined ? d.batch_coarse_min_jobs : 2 * d.batch_coarse_min_jobs;
+  }
   void setPipelined(bool on) {
     if (frameId_ != 0) throw Error(LSDHIP_E_STATE, "SlamLoopBatch::setPipelined: switch before the first step");
     Context::get(w_, h_, K_)->setPipeline(on);
     pipelined_ = on;
+    tracker.setBatchCoarseMinJobs(coarseMinJobs(on));
     for (auto& q : seqs_) { q->trackKF = q->keyframe; q->pendingKF.reset(); }
     if (on) tracker.setEnqueueHook([this]() {
       // the tracking batch's launches are queued: now the mapping work of the previous step, then the next step's frames
