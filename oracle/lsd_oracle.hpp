@@ -15,8 +15,9 @@
 // whole trackFrameSim3 calls) — all BIT-EXACT.  What is NOT the reference's own
 // code in that build, and therefore still rests on restatement: the Eigen fixed-size arithmetic
 // (3x3 products / inverse, 6x6 LDL^T) and the Sophus SE3 / Sim3 group operations, which oracle/_ref
-// shares with this oracle (orc_math.hpp); Sophus exp / log are checked against the element list of the
-// reference's own sophus/test_se3.cpp (tests/test_oracle_cpu.py); Sim3::exp (orc_sim3_exp.hpp), the 7x7 LDL^T and
+// shares with this oracle (orc_math.hpp); SE3 exp / log and Sim3::exp pass Sophus' own expMapTest / expLogTest on the vectors of the
+// reference's thirdparty/Sophus/sophus/test_se3.cpp / test_sim3.cpp at Sophus' thresholds, and the 6x6 LDL^T agrees with LAPACK
+// (tests/test_oracle_cpu.py; Sophus itself is vendored there but needs Eigen, which this image lacks); the 7x7 LDL^T and
 // Quaternionf::setFromTwoVectors are shared stand-in algebra in the same sense.
 //
 // Conventions: unwritten pool memory is defined as 0 (the reference recycles FrameMemory buffers,

@@ -235,7 +235,7 @@ template <typename T> static inline void se3_log(const SE3<T>& s, T out[6]) {
   Om.m[2][0] = -omega[1]; Om.m[2][1] = omega[0];  Om.m[2][2] = 0;
   Mat3<T> Om2 = matmat(Om, Om);
   Mat3<T> Vinv;
-  if (theta < sophus_eps<T>()) {
+  if (std::abs(theta) < sophus_eps<T>()) {   // se3.hpp:566 (theta is negative for quaternions with w < 0: rotations beyond pi)
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
       Vinv.m[i][j] = (i == j ? T(1) : T(0)) - T(0.5) * Om.m[i][j] + T(1. / 12.) * Om2.m[i][j];
   } else {

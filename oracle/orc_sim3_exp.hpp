@@ -1,5 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  Sophus Sim3::exp restated (sophus/sim3.hpp:585-650, absent dependency; published closed
-// form), shared by the oracle's Sim3Tracker (orc_sim3.cpp) and by the stand-in Sophus header the reference build uses
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Sophus Sim3::exp restated (thirdparty/Sophus/sophus/sim3.hpp:585-650: vendored with the reference,
+// but it needs Eigen, which this image lacks; held to Sophus' own expMapTest vectors in tests/test_oracle_cpu.py), shared by the oracle's Sim3Tracker (orc_sim3.cpp) and by the stand-in Sophus header the reference build uses
 // (oracle/ref/shim/sophus/sim3.hpp): like the SE3 algebra, this arithmetic is common to both sides of the pin.
 #pragma once
 #include <cmath>

@@ -290,3 +290,116 @@ def test_sim3_sse_drops_tail_and_counts_constraints(oracle):
     assert rc.num_constraints == 2 * rc.warped_size
     # raw (undivided) systems agree up to the <= 3 dropped points of ~1000 and the reassociated sums
     assert np.allclose(np.array(rs.A), np.array(rc.A), rtol=2e-2, atol=5e-3 * np.abs(np.array(rc.A)).max())
+
+
+def _hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], float)
+
+
+# tangent vectors of the reference's own Sophus tests (thirdparty/Sophus/sophus/test_se3.cpp:69-81, test_sim3.cpp:73-85): (v, w[, sigma])
+SOPHUS_SE3_TANGENTS = [(0, 0, 0, 0, 0, 0), (1, 0, 0, 0, 0, 0), (0, 1, 0, 1, 0, 0), (0, -5, 10, 0, 0, 0), (-1, 1, 0, 0, 0, 1), (20, -1, 0, -1, 1, 0),
+                       (30, 5, -1, 20, -1, 0)]
+SOPHUS_SIM3_TANGENTS = [(0, 0, 0, 0, 0, 0, 0), (1, 0, 0, 0, 0, 0, 0), (0, 1, 0, 1, 0, 0, 0.1), (0, 0, 1, 0, 1, 0, 0.1), (-1, 1, 0, 0, 0, 1, -0.1),
+                        (20, -1, 0, -1, 1, 0, -0.1), (30, 5, -1, 20, -1, 0, 1.5)]
+
+
+def _se3_matrix(oracle, p):
+    M = np.eye(4); M[:3, :3] = oracle.quat_to_rot(p[:4]); M[:3, 3] = p[4:7]
+    return M
+
+
+def _sim3_matrix(oracle, T):
+    M = np.eye(4); M[:3, :3] = T[7] * oracle.quat_to_rot(T[:4]); M[:3, 3] = T[4:7]
+    return M
+
+
+def _twist_matrix(a):
+    M = np.zeros((4, 4)); M[:3, :3] = _hat(a[3:6]) + (a[6] if len(a) > 6 else 0.0) * np.eye(3); M[:3, 3] = a[:3]
+    return M
+
+
+def test_exp_maps_pass_the_references_sophus_tests(oracle):
+    """The oracle and oracle/_ref share the builder's stand-ins for Sophus (SE3::exp / log, Sim3::exp) — the one part of the pin that is
+    not the reference's own source (Sophus is vendored under thirdparty/, Eigen is not in this image, so it cannot be compiled).  The
+    reference ships Sophus' own tests: expMapTest (thirdparty/Sophus/sophus/tests.hpp:90-110) demands ||exp(x).matrix() - expm(hat(x))||_F
+    <= 10 epsilon (epsilon = 1e-10 for double) on the tangent vectors of test_se3.cpp / test_sim3.cpp, expLogTest (:70-88)
+    ||T - exp(log(T))|| <= epsilon.  The stand-ins are held to exactly those vectors and thresholds, with scipy.linalg.expm as Eigen's
+    MatrixFunctions."""
+    from scipy.linalg import expm
+    eps = 1e-10
+    for a in SOPHUS_SE3_TANGENTS:
+        a = np.array(a, float)
+        T = _se3_matrix(oracle, oracle.se3_exp(a))
+        assert np.linalg.norm(T - expm(_twist_matrix(a))) <= 10 * eps, a
+        # (beyond the reference's list: the exponentials of its tangent vectors as group elements — (30, 5, -1, 20, -1, 0) turns by 20 rad,
+        # its quaternion has w < 0 and log's theta is negative: the stand-in tested `theta < epsilon` where se3.hpp:566 tests |theta|,
+        # found by this test and fixed)
+        T2 = _se3_matrix(oracle, oracle.se3_exp(oracle.se3_log(oracle.se3_exp(a))))
+        assert np.linalg.norm(T - T2) <= 10 * eps, a
+    # expLogTest on the group elements of test_se3.cpp:40-66 (rotation vector, translation; the two products spelled out)
+    rot = lambda w: oracle.se3_exp(np.concatenate([[0, 0, 0], w]))
+    def elem(w, t):
+        p = rot(np.array(w, float)); p[4:7] = t
+        return p
+    pi = np.pi
+    group = [elem((0.2, 0.5, 0.0), (0, 0, 0)), elem((0.2, 0.5, -1.0), (10, 0, 0)), elem((0, 0, 0), (0, 100, 5)), elem((0, 0, 0.00001), (0, 0, 0)),
+             elem((0, 0, 0.00001), (0, -0.00000001, 0.0000000001)), elem((0, 0, 0.00001), (0.01, 0, 0)), elem((pi, 0, 0), (4, -5, 0)),
+             oracle.se3_mul(oracle.se3_mul(elem((0.2, 0.5, 0.0), (0, 0, 0)), elem((pi, 0, 0), (0, 0, 0))), elem((-0.2, -0.5, -0.0), (0, 0, 0))),
+             oracle.se3_mul(oracle.se3_mul(elem((0.3, 0.5, 0.1), (2, 0, -7)), elem((pi, 0, 0), (0, 0, 0))), elem((-0.3, -0.5, -0.1), (0, 6, 0)))]
+    for g in group:
+        T1 = _se3_matrix(oracle, g)
+        T2 = _se3_matrix(oracle, oracle.se3_exp(oracle.se3_log(g)))
+        assert np.linalg.norm(T1 - T2) <= eps, g
+    for a in SOPHUS_SIM3_TANGENTS:
+        a = np.array(a, float)
+        assert np.linalg.norm(_sim3_matrix(oracle, oracle.sim3_exp(a)) - expm(_twist_matrix(a))) <= 10 * eps, a
+
+
+def test_exp_maps_against_the_matrix_exponential(oracle):
+    """Beyond the reference's seven vectors per group: random twists over nine decades and the branch switches of the closed forms
+    (rotation / scale below Sophus' epsilon, one of them only), against the matrix exponential in float64.  Bounds: relative 1e-11,
+    plus what the published closed forms themselves lose to cancellation — (1 - cos theta) / theta^2 and (e^sigma - 1) / sigma carry
+    eps_double / theta resp. eps_double / sigma of relative error into the translation (the reference's arithmetic, restated as is:
+    3e-11 |v| at theta = 2e-7, 1e-7 |v| at sigma = 1e-9), and V = R below theta = 1e-10 is off by theta |v| / 2."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(11)
+    twists = [rng.standard_normal(7) * sc for sc in (1e-9, 1e-5, 1e-2, 0.3, 1.5) for _ in range(6)]
+    twists.append(np.array([0.1, -0.2, 0.3, 0, 0, 0, 0.0]))              # pure translation
+    twists.append(np.array([0, 0, 0, 0, 0, 0, 0.4]))                     # pure scale
+    twists.append(np.array([0.3, 0.1, -0.2, 1e-7, -2e-7, 1e-7, 0.2]))    # small rotation, ordinary scale
+    twists.append(np.array([0.3, 0.1, -0.2, 1e-11, -2e-11, 1e-11, 0.2]))  # rotation below the small-angle switch
+    twists.append(np.array([0.3, 0.1, -0.2, 0.5, -0.4, 0.2, 1e-9]))      # small scale, ordinary rotation
+    twists.append(np.array([0.3, 0.1, -0.2, 0.5, -0.4, 0.2, 1e-11]))     # scale below its switch
+    tiny = 4e-16
+    for a in twists:
+        v, theta, sigma = np.linalg.norm(a[:3]), np.linalg.norm(a[3:6]), abs(a[6])
+        lost_rot = tiny / theta if theta >= 1e-10 else 0.5 * theta
+        lost_scale = tiny / sigma if sigma >= 1e-10 else 0.5 * sigma
+        p = oracle.se3_exp(a[:6])
+        E = expm(_twist_matrix(a[:6]))
+        assert np.allclose(oracle.quat_to_rot(p[:4]), E[:3, :3], rtol=0, atol=1e-12), a
+        assert np.allclose(p[4:7], E[:3, 3], rtol=1e-11, atol=1e-13 + v * lost_rot), a
+        assert np.allclose(oracle.se3_log(p), a[:6], rtol=1e-9, atol=1e-12 + 10 * v * lost_rot), a
+        T = oracle.sim3_exp(a)
+        E = expm(_twist_matrix(a))
+        assert np.allclose(T[7] * oracle.quat_to_rot(T[:4]), E[:3, :3], rtol=1e-11, atol=1e-12), a
+        assert np.allclose(T[4:7], E[:3, 3], rtol=1e-11, atol=1e-13 + v * (lost_rot + lost_scale)), a
+
+
+def test_ldlt_stand_ins_against_numpy(oracle):
+    """Eigen's A.ldlt().solve(b) (LGSX.h:411-443 call sites) is restated by the builder for oracle and oracle/_ref alike: on symmetric
+    positive definite systems of the LM loop's kind — J^T W J (1 + lambda on the diagonal) over four decades of conditioning — the 6x6
+    solve agrees with LAPACK (numpy.linalg.solve in float64 on the same float32 matrix) to float32 solve accuracy."""
+    rng = np.random.default_rng(5)
+    L = oracle.lib()
+    for cond in (1e1, 1e2, 1e3, 1e4):
+        for _ in range(10):
+            Q, _r = np.linalg.qr(rng.standard_normal((6, 6)))
+            ev = np.geomspace(1.0, cond, 6)
+            A = ((Q * ev) @ Q.T).astype(np.float32)
+            A = ((A + A.T) * 0.5).astype(np.float32)
+            b = rng.standard_normal(6).astype(np.float32)
+            x = np.zeros(6, np.float32)
+            L.orc_ldlt6_solve(np.ascontiguousarray(A.ravel()), b, x)
+            want = np.linalg.solve(A.astype(np.float64), b.astype(np.float64))
+            assert np.linalg.norm(x - want) <= 4e-7 * cond * np.linalg.norm(want) + 1e-7, (cond, x, want)
