@@ -169,7 +169,9 @@ struct DeferredSlot { double sum, count, flag, pad; };
 #define LSD_SPEC_MID_PX 90112
 #define LSD_SPEC_CAP_WORKGROUPS 80          // workgroups per trial on speculating levels above LSD_SPEC_CAP_ABOVE_PX pixels
 #define LSD_SPEC_CAP_ABOVE_PX 24576
+#ifndef LSD_OBS_SPLIT_MIN_MAPS
 #define LSD_OBS_SPLIT_MIN_MAPS 4             // lsdhip_depth_update_batch: select + walk launches from this many maps on
+#endif
 #define LSD_OBS_WALK_WAVES 4096             // one-wave workgroups of the walk launch
 #define LSD_BATCH_THROUGHPUT_MIN_JOBS 8     // lsdhip_tracker_track_batch: throughput mode from this many jobs on
 #define LSD_BATCH_SPEC_MAX 4                // reject-chain speculation of batches in throughput mode: most trials per step (levels without a mask)
