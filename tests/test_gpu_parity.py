@@ -906,6 +906,44 @@ def test_track_batch_throughput_mode_matches_single_calls(oracle, hip, coarse):
     assert np.array_equal(poses, poses2)
 
 
+@pytest.mark.gpu
+def test_track_batch_coarse_levels_fall_back_to_strips_when_the_stage_overflows(oracle, hip):
+    """k_track_solo stages at most 5120 reference points of a level in LDS.  At 752x480 level 3 is 94x60 = 5640 pixels (<= 8192: the
+    one-workgroup form takes it) and a dense keyframe gives it 5336 valid points: the workgroup walks level 4, finds level 3 too large for
+    its stage, and hands the job — state at level 3, nothing pending — to the lock-step rounds.  Same bounds against single calls as the
+    other batch tests."""
+    w, h = 752, 480
+    seqs = [sequence(w, h, 3, seq_index=s) for s in range(4)]
+    ctx = hip.Context(w, h, seqs[0][2])
+    tr = hip.SE3Tracker(ctx)
+    tr.set_maxItsPerLvl(ODOMETRY_ITS)
+    tr.set_batch_coarse_min_jobs(1)
+    refs, frs, want = [], [], []
+    for s, (frames, depth0, K, gt) in enumerate(seqs):
+        for k in (1, 2):
+            pair = []
+            for copy in range(2):
+                kf = hip.Frame(ctx, 100 * s + 10 * k, frames[0])
+                depth = depth0.copy()
+                depth[~(depth > 0)] = np.median(depth0[depth0 > 0])
+                kf.setDepthPlanes(1.0 / depth, np.full_like(depth, 1e-4))     # a hypothesis on every pixel
+                ref = hip.TrackingReference()
+                ref.importFrame(kf)
+                pair.append((ref, hip.Frame(ctx, 100 * s + 10 * k + 1, frames[k])))
+            assert int((pair[0][0].keyframe.idepthVar(3)[1:-1, 1:-1] > 0).sum()) > 5120     # the stage does overflow
+            pose = tr.trackFrame(pair[0][0], pair[0][1], IDENT7)
+            want.append((pose, tr.last.numEvaluations, tr.lastResidual, pair[0][1].refPixelWasGoodNoCreate()))
+            refs.append(pair[1][0]); frs.append(pair[1][1])
+    poses, recs = tr.trackFrameBatch(refs, frs, np.tile(IDENT7, (8, 1)))
+    for j in range(8):
+        sp, sev, sres, smask = want[j]
+        dtj, drj = pose_distance(poses[j], sp, oracle)
+        assert max(dtj, drj) < 2e-4, (j, dtj, drj)
+        assert abs(recs[j].numEvaluations - sev) <= 2
+        assert recs[j].lastResidual == pytest.approx(sres, rel=5e-2)
+        assert (frs[j].refPixelWasGoodNoCreate() != smask).mean() < 2e-3
+
+
 def test_permaref_batch_matches_single_and_oracle(oracle, hip):
     """several keyframes' permanent references (level-4 clouds) tracked against one new frame in the same
     launches give what single trackFrameOnPermaref calls and the oracle give."""
