@@ -2256,7 +2256,8 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   if (split && t->batchRecent[0] > 0) {
     budget = 0;
     for (int i = 0; i < 4; i++) if (t->batchRecent[i] > budget) budget = t->batchRecent[i];
-    budget += 3;
+    static const int marginEnv = getenv("LSDHIP_BATCH_MARGIN") ? atoi(getenv("LSDHIP_BATCH_MARGIN")) : 3;   // developer sweep
+    budget += marginEnv;
   }
   int parity = 0, first = 1, guard = 0;
   static const int fusedEnv = getenv("LSDHIP_BATCH_FUSED") ? atoi(getenv("LSDHIP_BATCH_FUSED")) : 2;   // developer A/B (round 6): 0 = LM launch + evaluation launch per round
