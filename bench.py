@@ -331,8 +331,8 @@ def other_execution_model(DriverLoop, capi, w, h, K, ptr, depth0, device, pipeli
 
 def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
     """The same residual evaluation with enough independent work per launch: `jobs` trackFrame jobs (frames 1..5 of the
-    sequence against the keyframe with ground-truth depth) share every launch (lsdhip_tracker_track_batch, throughput mode:
-    LM launch + evaluation launch per step).  Reports the algorithmic bandwidth of the step kernels over ALL launches of the
+    sequence against the keyframe with ground-truth depth) share every launch (lsdhip_tracker_track_batch, throughput mode: the
+    coarse levels in one workgroup per job — k_track_solo, from 32 jobs on —, then one fused launch per lock-step round).  Reports the algorithmic bandwidth of the step kernels over ALL launches of the
     jobs, HIP events around each batch; the level-1 evaluation launches alone run ~2.3x higher (profiles/r01_sizes.md).
     An extra, not the bench metric: the single-sequence loop above is what `value` and `roofline` describe."""
     ctx = la.Context(w, h, K, device=device)
@@ -364,7 +364,7 @@ def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
     achieved = nbytes / (ms * 1e-3) / 1e9
     out = {"bound": "hbm", "jobs_per_launch": jobs, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "evaluations": int(n_eval), "stream_ms": ms,
-           "kernel": "k_track_step<TS_LM> + k_track_step<TS_EVAL>, all launches of %d rounds of %d jobs (LM launches and the small pyramid levels carry almost no bytes)" % (rounds, jobs)}
+           "kernel": "k_track_solo (levels 4, 3: one workgroup per job) + k_track_step<256, true, TS_FUSED> (one launch per lock-step round), all launches of %d batches of %d jobs (the small pyramid levels carry almost no bytes)" % (rounds, jobs)}
     # the residual evaluation launch alone, per pyramid level, at fixed poses (lsdhip_tracker_eval_throughput: 20 identical launches
     # between two HIP events): level 1 is where the bytes are
     T = np.zeros((jobs, 7), np.float32)
