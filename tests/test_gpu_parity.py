@@ -917,6 +917,8 @@ def test_track_batch_coarse_levels_fall_back_to_strips_when_the_stage_overflows(
     ctx = hip.Context(w, h, seqs[0][2])
     tr = hip.SE3Tracker(ctx)
     tr.set_maxItsPerLvl(ODOMETRY_ITS)
+    with pytest.raises(hip.LsdHipError):
+        tr.set_batch_coarse_min_jobs(-1)
     tr.set_batch_coarse_min_jobs(1)
     refs, frs, want = [], [], []
     for s, (frames, depth0, K, gt) in enumerate(seqs):
