@@ -233,10 +233,11 @@ int lsdhip_tracker_exec_stats(const lsdhip_tracker* t, int out[8]);
  * other values are rounded down to a multiple of 8 (one band of tiles per XCD), values below 8 up to 8.  The per-level overrides of
  * the environment (LSDHIP_SPEC_LEVELS) are cleared by this call. */
 int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLevelWorkgroups);
-/* Throughput-mode batches (lsdhip_tracker_track_batch): from `minJobs` jobs on, the levels of at most 8192 pixels and 5120 valid
- * reference points that do not write refPixelWasGood (levels 4 and 3 of a 640x480 job) are walked by ONE workgroup per job — the level's
- * points staged in LDS, the whole LM loop of the level in that workgroup — ahead of the lock-step rounds for the larger levels: same
- * per-point arithmetic and LM decisions, sums in that workgroup's order.  Default 32 jobs (below, the jobs have the chip to themselves
+/* Throughput-mode batches (lsdhip_tracker_track_batch): from `minJobs` jobs on, the levels of at most 4800 pixels and 4608 valid
+ * reference points that do not write refPixelWasGood (levels 4 and 3 of a 640x480 job) are walked by ONE workgroup per job — the tracked
+ * frame's texel plane of the level staged in LDS (the tile of the bilinear taps), the level's reference points in registers, the whole LM
+ * loop of the level in that workgroup — ahead of the lock-step rounds for the larger levels: same per-point arithmetic and LM decisions,
+ * sums in that workgroup's order.  Default 32 jobs (below, the jobs have the chip to themselves
  * and the lock-step rounds are as fast); 0: never. */
 int lsdhip_tracker_set_batch_coarse_min_jobs(lsdhip_tracker* t, int minJobs);
 /* out[0] = k_track_step launches of the last job that evaluated (<= its numEvaluations), out[1] = most trials per step (the

@@ -955,27 +955,33 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 // A lock-step round of a batch costs its latency chain (state, partial sums of other workgroups, the LM step, list, pipeline fill,
 // reduction: 11-13 us of workgroup time with 1.5-2.5 us of evaluation in it at levels 3 and 4, profiles/r06_notes.md section 9), every
 // job pays the rounds of the slowest, and every (trial, strip) workgroup repeats the finishing phase.  A level small enough to be one
-// strip (at most LSD_SOLO_MAX_PX pixels, at most LSD_SOLO_MAX_PTS valid reference points: levels 3 and 4 of a 640x480 job) needs none of
-// that: one workgroup per job runs the level's whole LM loop at its own pace and leaves the state at the first larger level for the
-// lock-step rounds (k_track_step<.., true, TS_FUSED> with first = 0).
-//   * What an evaluation needs of a reference point does not depend on the pose: the level's points are STAGED IN LDS once, when the
-//     workgroup enters the level — 16 bytes each: pixel (x | y << 16), 1 / idepth (= the point's z; x and y follow from it and the pixel
-//     with the two multiply-adds of makePointCloud, TrackingReference.cpp:128-138), colour, variance — from the keyframe's reference
-//     blocks (k_ref_blocks, pixel order).  An iteration then has ONE dependent global round trip per trip of 512 points (the four texels
-//     of the new frame) instead of two, and the three tail candidates come out of LDS as well.
-//   * Per iteration four barriers: park the upper half's sums / wave top-3 | fold halves, wave 0 merges the top-3 and requests the tail
-//     candidates' texels | runs of columns | wave 0: totals, tail, lm_wave on its own lanes (no barrier between them) | next iteration.
-// Same arithmetic per point, same LM step (lm_wave), the sums in this kernel's own fixed order; no speculation (a retry is one more
-// iteration of a few microseconds, not a launch).
-#define LSD_SOLO_MAX_PX 8192
-#define LSD_SOLO_MAX_PTS 5120
+// strip and one LDS tile (at most LSD_SOLO_MAX_PX pixels: levels 3 and 4 of a 640x480 job) needs none of that: one workgroup per job runs
+// the level's whole LM loop at its own pace and leaves the state at the first larger level for the lock-step rounds
+// (k_track_step<.., true, TS_FUSED> with first = 0).  Everything an iteration reads is staged when the workgroup enters the level:
+//   * the TRACKED FRAME'S TEXEL PLANE in LDS (gx, gy, I, 0: 16 bytes per pixel, 76.8 KB at 80x60) — the form BASELINE.json's north_star
+//     names: LDS-staged image tiles for the bilinear taps (getInterpolatedElement43, C/util/globalFuncs.h:63-77); the tile is the level;
+//   * the level's REFERENCE POINTS in registers: lane t owns points t, t + 512, ... of the level's list (the keyframe's reference blocks
+//     in pixel order, as a strip of the lock-step rounds builds its own), at most LSD_SOLO_TRIPS of them, 3 registers each: pixel,
+//     1 / idepth (= the point's z; x and y follow with the two multiply-adds of makePointCloud, TrackingReference.cpp:128-138), colour
+//     (the variance, read once per point and iteration, sits in LDS beside the tile) — none of it depends on the pose.
+// An LM iteration then touches no global memory: warp from registers, four 16-byte taps from LDS, finish, accumulate; the pose in scalar
+// registers.  Four barriers per iteration: the upper half parks its sums and
+// every wave its top-3 keys | the halves fold, wave 0 merges the top-3 and requests the three tail candidates' reference pixels (the only
+// loads of the iteration, three lanes, under two barriers) | runs of columns | wave 0: totals, the candidates from the tile, tail drop,
+// lm_wave on its own lanes (no barrier between them) | next iteration.  Same arithmetic per point, same LM step, the sums in this
+// kernel's own fixed order; no speculation (a retry is one more iteration of a few microseconds, not a launch).
+// Measured (profiles/r06_notes.md section 21): the tile neither gains nor costs against gathering the taps from L2 / HBM — the iteration
+// is bound by what one CU can issue — and the launch takes about what the ten rounds it replaces took, on n CUs instead of the chip.
+#define LSD_SOLO_MAX_PX 4800
+#define LSD_SOLO_TRIPS 9          // x 512 lanes = 4608 points >= the (w - 2)(h - 2) interior of any level of at most 4800 pixels
+#define LSD_SOLO_MAX_PTS (LSD_SOLO_TRIPS * 512)
 // Worth it from this many jobs per batch: one workgroup per job walks its coarse levels in about the time the lock-step rounds take, on
 // n CUs instead of the chip — a gain where other work (the mapping stream of the S-sequence loop) wants the other CUs, a small loss for
 // a few jobs that have the chip to themselves (profiles/r06_notes.md section 21).
 #define LSD_SOLO_MIN_JOBS 32
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2, TrackSummary* __restrict__ outs,
-                                                      const int parity, const int doneWord) {
+                                                          const int parity, const int doneWord) {
   const TrackJob& job = jobs[blockIdx.x];
   st2 += 2 * (size_t)blockIdx.x;
   TrackSummary* out = outs + blockIdx.x;
@@ -984,7 +990,9 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
   constexpr int CPP = RS_END;
   constexpr int RSLICE = BLOCK / CPP;
   constexpr int RRUN = (HALF + RSLICE - 1) / RSLICE;
-  static_assert(WAVES * 3 <= 64 && LSD_SOLO_MAX_PX <= 8192 && LSD_SOLO_MAX_PTS <= 8192, "top-3 merge in one wave; key and slot share a word");
+  constexpr int TRIPS = LSD_SOLO_TRIPS;
+  static_assert(WAVES * 3 <= 64, "top-3 merge in one wave");
+  static_assert((size_t)TRIPS * BLOCK * 4 <= sizeof(float) * (CPP * (HALF + 1) + RRUN), "the level's list borrows the reduction buffer");
   __shared__ TrackState S;
   __shared__ LmShared sh;
   __shared__ LmPar s_par;
@@ -992,7 +1000,8 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
   __shared__ float s_sum[RSLICE][64];
   __shared__ float s_sub[3][32];
   __shared__ int s_wtop[WAVES][3];
-  __shared__ uint4 s_pts[LSD_SOLO_MAX_PTS];
+  __shared__ v4f s_tex[LSD_SOLO_MAX_PX];
+  __shared__ float s_var[LSD_SOLO_TRIPS * BLOCK];     // the points' variances: [trip][lane] (the registers hold the rest of a point)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) {
     S.T = job.T0;
@@ -1011,6 +1020,18 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
   __syncthreads();
   int listLevel = -1, total = 0;
   EvalCtx a;
+  // this lane's reference points of the level (trip r: point tid + r BLOCK of the list)
+  unsigned pXY[TRIPS];
+  float pZ[TRIPS], pI[TRIPS];
+  // the four taps of getInterpolatedElement43 (C/util/globalFuncs.h:63-77) out of the tile; `fetch` = false reads texel 0 instead
+  auto taps = [&](const PointWarp& q, const bool fetch, PointTexels& t) {
+    const int ix = fetch ? (int)q.u_new : 0;
+    const int iy = fetch ? (int)q.v_new : 0;
+    const v4f* bp = s_tex + (ix + __mul24(iy, a.w));
+    const v4f v00 = bp[0], v10 = bp[1], v01 = bp[a.w], v11 = bp[a.w + 1];
+    t.t00 = Texel3{v00.x, v00.y, v00.z}; t.t10 = Texel3{v10.x, v10.y, v10.z};
+    t.t01 = Texel3{v01.x, v01.y, v01.z}; t.t11 = Texel3{v11.x, v11.y, v11.z};
+  };
   for (int guard = 0; guard < 4096; guard++) {
     const int level = S.level;
     if (S.done) break;
@@ -1020,9 +1041,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
     if (level != listLevel) {
       make_ctx_dev(job, S, level, a);
       if (tid == BLOCK - 1) stage_lm_par(job, level, s_par, 1);
-      // the level's points: its reference blocks in pixel order (as a strip of the lock-step rounds builds its list), staged with
-      // everything of the keyframe an evaluation reads
-      const int mblk = (work + 255) >> 8;                   // <= 32
+      const int mblk = (work + 255) >> 8;                   // <= 19
       const gbyte* offs = (const gbyte*)L.kf_refBlk;
       const __attribute__((address_space(1))) int* cnts = (const __attribute__((address_space(1))) int*)(offs + ((size_t)mblk << 8));
       const int cntv = lane < mblk ? cnts[lane] : 0;
@@ -1033,39 +1052,55 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
       incl += dpp_i0<0x118, 0xf, 0xc>(incl);
       incl += dpp_i0<0x142, 0xa, 0xf>(incl);
       total = __builtin_amdgcn_readlane(incl, 31);
-      if (total > LSD_SOLO_MAX_PTS) break;                  // (every wave computes the same total) more points than the stage holds: strips
+      if (total > TRIPS * BLOCK) break;                     // (every wave computes the same total) cannot happen below 4800 pixels; strips if it does
+      // the tile: the level's texel plane, 16 bytes per lane and step
+      {
+        gv4f* src = (gv4f*)a.fr_grad;
+        for (int i = tid; i < work; i += BLOCK) s_tex[i] = src[i];
+      }
+      // the level's list (pixel order, as a strip of the lock-step rounds builds its own) in the reduction buffer
+      unsigned* s_list = (unsigned*)s_red;
       const int waveU = __builtin_amdgcn_readfirstlane(wave);
       const float inv_w = 1.0f / (float)a.w;
       for (int blk = waveU; blk < mblk; blk += WAVES) {
         const int cb = __builtin_amdgcn_readlane(cntv, blk);
         const int pb = __builtin_amdgcn_readlane(incl, blk) - cb;
         const unsigned ow = *(const __attribute__((address_space(1))) unsigned*)(offs + ((size_t)blk << 8) + (lane << 2));
-        unsigned xy[4];
-        float var[4], id[4], img[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int sl = lane + 64 * k;
-          const int i = sl < cb ? (blk << 8) + (int)((ow >> (8 * k)) & 255u) : 0;
-          int y = (int)((float)i * inv_w);
-          int x = i - y * a.w;
-          if (x < 0) { y--; x += a.w; }
-          if (x >= a.w) { y++; x -= a.w; }
-          xy[k] = (unsigned)x | ((unsigned)y << 16);
-          var[k] = a.kf_idepthVar[i];
-          id[k] = a.kf_idepth[i];
-          img[k] = a.kf_image[i];
-        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int sl = lane + 64 * k;
           if (sl < cb) {
-            const float inv = lsd_rcp_exact(id[k]);
-            s_pts[pb + sl] = make_uint4(xy[k], __float_as_uint(inv * 1.0f), __float_as_uint(img[k]), __float_as_uint(var[k]));
+            const int i = (blk << 8) + (int)((ow >> (8 * k)) & 255u);
+            int y = (int)((float)i * inv_w);
+            int x = i - y * a.w;
+            if (x < 0) { y--; x += a.w; }
+            if (x >= a.w) { y++; x -= a.w; }
+            s_list[pb + sl] = (unsigned)x | ((unsigned)y << 16);
           }
         }
       }
-      listLevel = level;
       __syncthreads();
+      // this lane's points: everything of the keyframe an evaluation reads, once per level
+      {
+        float var[TRIPS], id[TRIPS];
+#pragma unroll
+        for (int r = 0; r < TRIPS; r++) {
+          const int p = tid + r * BLOCK;
+          const unsigned xy = s_list[p < total ? p : 0];
+          const int i = __mul24((int)(xy >> 16), a.w) + (int)(xy & 0xffffu);
+          pXY[r] = xy;
+          var[r] = a.kf_idepthVar[i];
+          id[r] = a.kf_idepth[i];
+          pI[r] = a.kf_image[i];
+        }
+#pragma unroll
+        for (int r = 0; r < TRIPS; r++) {
+          s_var[r * BLOCK + tid] = var[r];
+          pZ[r] = (tid + r * BLOCK < total) ? lsd_rcp_exact(id[r]) * 1.0f : 1.0f;
+        }
+      }
+      listLevel = level;
+      __syncthreads();                                      // the list's words become the reduction buffer again
     } else {
       // the pose under evaluation (the LM step of the previous iteration left it in S)
 #pragma unroll
@@ -1074,47 +1109,44 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
       for (int i = 0; i < 3; i++) a.t[i] = S.t[i];
       a.aff_a = S.aff_a; a.aff_b = S.aff_b;
     }
+    // (the pose is the same in every lane: scalar registers — the lane's points and the 41 running sums want the vector ones)
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.R[i] = uni(a.R[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) a.t[i] = uni(a.t[i]);
+    a.aff_a = uni(a.aff_a); a.aff_b = uni(a.aff_b);
     float acc[RS_END];
 #pragma unroll
     for (int k = 0; k < RS_END; k++) acc[k] = 0.f;
     int key0 = -1, key1 = -1, key2 = -1;
-    struct StB { int p; unsigned xy; float pz, I_ref, var; PointWarp q; PointTexels t; bool live; };
-    auto stageB = [&](const int p, StB& B) {
-      B.live = p < total;
-      B.p = p;
-      const uint4 e = s_pts[B.live ? p : 0];
-      B.xy = e.x;
-      B.pz = __uint_as_float(e.y); B.I_ref = __uint_as_float(e.z); B.var = __uint_as_float(e.w);
-      const int bx_ = (int)(e.x & 0xffffu), by_ = (int)(e.x >> 16);
-      const float px = B.pz * (a.fxi * bx_ + a.cxi), py = B.pz * (a.fyi * by_ + a.cyi);
-      eval_warp(a, px, py, B.pz, B.q);
-      eval_fetch(a, B.q, B.live && B.q.in_image, B.t);
-    };
-    if (total > 0) {
-      // two trips of texel fetches in flight ahead of the trip being finished
-      auto stageC = [&](const StB& B) {
-        if (B.live) {
+    {
+      const int rounds = (total + BLOCK - 1) / BLOCK;
+      struct StT { PointWarp q; PointTexels t; };
+      StT T0;
+      auto stageB = [&](const int r, StT& T) {
+        const bool live = tid + r * BLOCK < total;
+        const int bx_ = (int)(pXY[r] & 0xffffu), by_ = (int)(pXY[r] >> 16);
+        const float px = pZ[r] * (a.fxi * bx_ + a.cxi), py = pZ[r] * (a.fyi * by_ + a.cyi);
+        eval_warp(a, px, py, pZ[r], T.q);
+        taps(T.q, live && T.q.in_image, T.t);
+      };
+      auto stageC = [&](const int r, const StT& T) {
+        if (tid + r * BLOCK < total) {
           acc[RS_NREF] += 1.f;
-          if (B.q.in_image) {
+          if (T.q.in_image) {
             PointOut o;
-            eval_finish(a, B.q, B.t, B.pz, B.I_ref, B.var, o);
-            // reference order of the point (x h + y, TrackingReference.cpp:128-138) | its slot in the stage
-            top3_insert(((__mul24((int)(B.xy & 0xffffu), a.h) + (int)(B.xy >> 16)) << 13) | B.p, key0, key1, key2);
+            eval_finish(a, T.q, T.t, pZ[r], pI[r], s_var[r * BLOCK + tid], o);
+            top3_insert(__mul24((int)(pXY[r] & 0xffffu), a.h) + (int)(pXY[r] >> 16), key0, key1, key2);   // reference order (x h + y, TrackingReference.cpp:128-138)
             accumulate_point(o, acc);
           }
         }
       };
-      const int rounds = (total + BLOCK - 1) / BLOCK;
-      StB B0, B1, B2;
-      stageB(tid, B0);
-      stageB(tid + BLOCK, B1);
-      for (int r = 0; r < rounds; r += 3) {
-        stageB(tid + (r + 2) * BLOCK, B2);
-        stageC(B0);
-        stageB(tid + (r + 3) * BLOCK, B0);
-        stageC(B1);
-        stageB(tid + (r + 4) * BLOCK, B1);
-        stageC(B2);
+#pragma unroll
+      for (int r = 0; r < TRIPS; r++) {
+        // (uniform branch: every lane sees the same `rounds`.  Requesting the taps of trip r + 1 before trip r is finished — two points in
+        // flight — pushed the kernel over its 256 registers; the LDS round trip hides behind the SIMD's other wave)
+        if (r < rounds) { stageB(r, T0); stageC(r, T0); }
       }
     }
     // each wave's three largest keys; the upper half parks its sums
@@ -1133,9 +1165,9 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
     }
     __syncthreads();
     // wave 0: the level's three largest keys = the candidates for the tail (the last M % 4 in-image points in reference order); lanes
-    // 0..2 evaluate them once more out of the stage — their texels travel under the next two barriers
-    int cKey = -1;
-    StB cB;
+    // 0..2 evaluate them once more — their reference pixel travels under the next two barriers, the taps come out of the tile
+    int cKey = -1, cX = 0, cY = 0;
+    float cVar = 0.f, cId = 1.f, cImg = 0.f;
     if (wave == 0) {
       int v = lane < WAVES * 3 ? s_wtop[lane / 3][lane - 3 * (lane / 3)] : -1;
       int top[3];
@@ -1145,7 +1177,14 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
         if (v == top[r]) v = -1;
       }
       cKey = lane == 0 ? top[0] : (lane == 1 ? top[1] : (lane == 2 ? top[2] : -1));
-      if (cKey >= 0) stageB(cKey & 8191, cB);
+      if (cKey >= 0) {
+        cX = cKey / a.h;
+        cY = cKey - cX * a.h;
+        const int ci = __mul24(cY, a.w) + cX;
+        cVar = a.kf_idepthVar[ci];
+        cId = a.kf_idepth[ci];
+        cImg = a.kf_image[ci];
+      }
     }
     if (tid < HALF) {
 #pragma unroll
@@ -1172,8 +1211,15 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
         for (int sl = 1; sl < RSLICE; sl++) sv += s_sum[sl][lane];
       }
       if (cKey >= 0) {
+        const float inv = lsd_rcp_exact(cId);                // (fetch_point's arithmetic)
+        const float px = inv * (a.fxi * cX + a.cxi), py = inv * (a.fyi * cY + a.cyi);
+        const float cPz = inv * 1.0f;
+        PointWarp cq;
+        PointTexels ct;
+        eval_warp(a, px, py, cPz, cq);
+        taps(cq, cq.in_image, ct);
         PointOut o;
-        eval_finish(a, cB.q, cB.t, cB.pz, cB.I_ref, cB.var, o);
+        eval_finish(a, cq, ct, cPz, cImg, cVar, o);
         float* row = s_sub[lane];
         row[0] = o.werr;
         int k = 1;

@@ -864,8 +864,8 @@ def test_track_batch_equals_single_calls(oracle, hip):
 def test_track_batch_throughput_mode_matches_single_calls(oracle, hip, coarse):
     """>= 8 jobs switch the batch to its throughput mode (strips of the keyframe level compacted to their valid pixels in
     LDS, tail points re-evaluated): same points, same per-point arithmetic, another summation order.
-    coarse = 1: the levels of at most 8192 pixels (here 4, 3 and 2) walked by one workgroup per job with the level's points staged in LDS
-    (k_track_solo, the default from 32 jobs per batch): the same bounds."""
+    coarse = 1: the levels of at most 4800 pixels (here 4, 3 and 2) walked by one workgroup per job with the level's texel plane staged in
+    LDS (k_track_solo, the default from 32 jobs per batch): the same bounds."""
     w, h = 320, 240
     seqs = [sequence(w, h, 4, seq_index=s) for s in range(3)]
     ctx = hip.Context(w, h, seqs[0][2])
@@ -907,11 +907,11 @@ def test_track_batch_throughput_mode_matches_single_calls(oracle, hip, coarse):
 
 
 @pytest.mark.gpu
-def test_track_batch_coarse_levels_fall_back_to_strips_when_the_stage_overflows(oracle, hip):
-    """k_track_solo stages at most 5120 reference points of a level in LDS.  At 752x480 level 3 is 94x60 = 5640 pixels (<= 8192: the
-    one-workgroup form takes it) and a dense keyframe gives it 5336 valid points: the workgroup walks level 4, finds level 3 too large for
-    its stage, and hands the job — state at level 3, nothing pending — to the lock-step rounds.  Same bounds against single calls as the
-    other batch tests."""
+def test_track_batch_coarse_levels_fall_back_to_strips_when_a_level_does_not_fit(oracle, hip):
+    """k_track_solo holds the texel plane of a level of at most 4800 pixels in LDS and at most 4608 of its reference points in registers.
+    At 752x480 level 4 (47x30) fits and level 3 (94x60 = 5640 pixels, 5336 valid points on a dense keyframe) does not: the workgroup walks
+    level 4 and hands the job — state at level 3, nothing pending — to the lock-step rounds.  Same bounds against single calls as the other
+    batch tests."""
     w, h = 752, 480
     seqs = [sequence(w, h, 3, seq_index=s) for s in range(4)]
     ctx = hip.Context(w, h, seqs[0][2])
@@ -932,7 +932,7 @@ def test_track_batch_coarse_levels_fall_back_to_strips_when_the_stage_overflows(
                 ref = hip.TrackingReference()
                 ref.importFrame(kf)
                 pair.append((ref, hip.Frame(ctx, 100 * s + 10 * k + 1, frames[k])))
-            assert int((pair[0][0].keyframe.idepthVar(3)[1:-1, 1:-1] > 0).sum()) > 5120     # the stage does overflow
+            assert pair[0][0].keyframe.idepthVar(3).size > 4800 and int((pair[0][0].keyframe.idepthVar(3)[1:-1, 1:-1] > 0).sum()) > 4608     # too large either way
             pose = tr.trackFrame(pair[0][0], pair[0][1], IDENT7)
             want.append((pose, tr.last.numEvaluations, tr.lastResidual, pair[0][1].refPixelWasGoodNoCreate()))
             refs.append(pair[1][0]); frs.append(pair[1][1])
