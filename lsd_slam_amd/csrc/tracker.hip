@@ -71,6 +71,39 @@
 // once per workgroup): TS_FUSED = finish + evaluate as described above; TS_LM = finish the pending evaluation and publish the
 // state (grid.x = 1); TS_EVAL = evaluate the published state (reads st2[parity], writes scratch[parity]; no state change).
 enum { TS_FUSED = 0, TS_LM = 1, TS_EVAL = 2 };
+// the state a job's first launch starts from (SE3Tracker.cpp:280-320: the initial estimate, affine parameters of the settings, the top level)
+__device__ __forceinline__ void track_state_begin(TrackState& S, const TrackJob& job, const int tid) {
+  if (tid == 0) {
+    S.T = job.T0;
+    set_eval_pose(S, job.T0);
+    S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
+    S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
+    S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
+    S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
+    S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
+    S.bytes = 0;
+    for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
+    S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
+  }
+  if (tid < 36) S.A[tid] = 0;
+  if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
+}
+// one point's K2 / K3 contributions as the 29-float row the tail drop subtracts: werr | the 21 upper-triangular J J^T w | the 6 J r w | r^2 w
+__device__ __forceinline__ void tail_row(const PointOut& o, float* row) {
+  row[0] = o.werr;
+  int k = 1;
+#pragma unroll
+  for (int rr = 0; rr < 6; rr++) {
+    const float Jw = o.J[rr] * o.w;
+#pragma unroll
+    for (int cc = rr; cc < 6; cc++) row[k++] = Jw * o.J[cc];
+  }
+  const float resw = o.res * o.w;
+#pragma unroll
+  for (int rr = 0; rr < 6; rr++) row[k++] = resw * o.J[rr];
+  row[k++] = resw * o.res;
+}
+
 template <int BLOCK, bool BATCH, int MODE>
 __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2,
                                                 TrackScratch sc, TrackSummary* __restrict__ out, int parity, int first, const TrackSpec& spec) {
@@ -159,20 +192,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
   if (!BATCH && MODE == TS_FUSED && !first && !leader && st2[parity].done) return;   // launches queued behind the finishing one
   if (!BATCH && MODE == TS_FUSED && leader && tid == 0 && spec.seq != 0) out->seq = spec.seq;   // pinned host memory: fire and forget
   if (first) {
-    if (tid == 0) {
-      S.T = job.T0;
-      set_eval_pose(S, job.T0);
-      S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
-      S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
-      S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
-      S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
-      S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
-      S.bytes = 0;
-      for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
-      S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
-    }
-    if (tid < 36) S.A[tid] = 0;
-    if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
+    track_state_begin(S, job, tid);
   } else {
     copy_words<sizeof(TrackState) / 4>(&S, st2 + parity, tid, BLOCK);
     if (SPEC_LM && cmax > 1 && tid < 32 * TRIALS_MAX) (&s_rec[0][0])[tid] = sc.recs[(size_t)parity * cmax * 32 + (tid < 32 * cmax ? tid : 0)];
@@ -881,18 +901,7 @@ __device__ __forceinline__ void track_step_impl(const TrackJob& jobv, const Trac
       if (cKey >= 0) {
         PointOut o;
         eval_finish(a, cq, ct, cPz, cImg, cVar, o);
-        row[0] = o.werr;
-        int k = 1;
-#pragma unroll
-        for (int rr = 0; rr < 6; rr++) {
-          const float Jw = o.J[rr] * o.w;
-#pragma unroll
-          for (int cc = rr; cc < 6; cc++) row[k++] = Jw * o.J[cc];
-        }
-        const float resw = o.res * o.w;
-#pragma unroll
-        for (int rr = 0; rr < 6; rr++) row[k++] = resw * o.J[rr];
-        row[k++] = resw * o.res;
+        tail_row(o, row);
       }
       ((int*)row)[31] = cKey;
     }
@@ -961,9 +970,9 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 //   * the TRACKED FRAME'S TEXEL PLANE in LDS (gx, gy, I, 0: 16 bytes per pixel, 76.8 KB at 80x60) — the form BASELINE.json's north_star
 //     names: LDS-staged image tiles for the bilinear taps (getInterpolatedElement43, C/util/globalFuncs.h:63-77); the tile is the level;
 //   * the level's REFERENCE POINTS in registers: lane t owns points t, t + 512, ... of the level's list (the keyframe's reference blocks
-//     in pixel order, as a strip of the lock-step rounds builds its own), at most LSD_SOLO_TRIPS of them, 3 registers each: pixel,
-//     1 / idepth (= the point's z; x and y follow with the two multiply-adds of makePointCloud, TrackingReference.cpp:128-138), colour
-//     (the variance, read once per point and iteration, sits in LDS beside the tile) — none of it depends on the pose.
+//     in pixel order, as a strip of the lock-step rounds builds its own), at most LSD_SOLO_TRIPS of them, 2 registers each: pixel,
+//     1 / idepth (= the point's z; x and y follow with the two multiply-adds of makePointCloud, TrackingReference.cpp:128-138); colour and
+//     variance, read once per point and iteration, sit in LDS beside the tile — none of it depends on the pose.
 // An LM iteration then touches no global memory: warp from registers, four 16-byte taps from LDS, finish, accumulate; the pose in scalar
 // registers.  Four barriers per iteration: the upper half parks its sums and
 // every wave its top-3 keys | the halves fold, wave 0 merges the top-3 and requests the three tail candidates' reference pixels (the only
@@ -975,6 +984,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 #define LSD_SOLO_MAX_PX 4800
 #define LSD_SOLO_TRIPS 9          // x 512 lanes = 4608 points >= the (w - 2)(h - 2) interior of any level of at most 4800 pixels
 #define LSD_SOLO_MAX_PTS (LSD_SOLO_TRIPS * 512)
+#define LSD_SOLO_LDS_PTS 4544     // (w - 2)(h - 2) <= w h - 4 sqrt(w h) + 4 <= 4527 interior pixels of a level of at most 4800
 // Worth it from this many jobs per batch: one workgroup per job walks its coarse levels in about the time the lock-step rounds take, on
 // n CUs instead of the chip — a gain where other work (the mapping stream of the S-sequence loop) wants the other CUs, a small loss for
 // a few jobs that have the chip to themselves (profiles/r06_notes.md section 21).
@@ -1001,28 +1011,15 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
   __shared__ float s_sub[3][32];
   __shared__ int s_wtop[WAVES][3];
   __shared__ v4f s_tex[LSD_SOLO_MAX_PX];
-  __shared__ float s_var[LSD_SOLO_TRIPS * BLOCK];     // the points' variances: [trip][lane] (the registers hold the rest of a point)
+  __shared__ float s_var[LSD_SOLO_LDS_PTS], s_img[LSD_SOLO_LDS_PTS];     // the points' variances and colours, list order (the registers hold the rest of a point)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid == 0) {
-    S.T = job.T0;
-    set_eval_pose(S, job.T0);
-    S.aff_a = job.aff_a0; S.aff_b = job.aff_b0; S.aff_a_lastIt = job.aff_a0; S.aff_b_lastIt = job.aff_b0;
-    S.lastErr = 0; S.LM_lambda = 0; S.last_residual = 0;
-    S.level = job.topLevel; S.iteration = 0; S.incTry = 0; S.phase = 0; S.pending = 0;
-    S.done = 0; S.diverged = 0; S.numEvaluations = 0; S.numWarpUpdates = 0;
-    S.pointUsage = 0; S.goodCount = 0; S.badCount = 0; S.meanRes = 0;
-    S.bytes = 0;
-    for (int l = 0; l < LSD_LEVELS; l++) S.levelEvals[l] = 0;
-    S.ncand = 1; S.lastCand = 0; S.numLaunches = 0;
-  }
-  if (tid < 36) S.A[tid] = 0;
-  if (tid < 6) { S.b[tid] = 0; S.inc[tid] = 0; }
+  track_state_begin(S, job, tid);
   __syncthreads();
   int listLevel = -1, total = 0;
   EvalCtx a;
   // this lane's reference points of the level (trip r: point tid + r BLOCK of the list)
   unsigned pXY[TRIPS];
-  float pZ[TRIPS], pI[TRIPS];
+  float pZ[TRIPS];
   // the four taps of getInterpolatedElement43 (C/util/globalFuncs.h:63-77) out of the tile; `fetch` = false reads texel 0 instead
   auto taps = [&](const PointWarp& q, const bool fetch, PointTexels& t) {
     const int ix = fetch ? (int)q.u_new : 0;
@@ -1052,7 +1049,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
       incl += dpp_i0<0x118, 0xf, 0xc>(incl);
       incl += dpp_i0<0x142, 0xa, 0xf>(incl);
       total = __builtin_amdgcn_readlane(incl, 31);
-      if (total > TRIPS * BLOCK) break;                     // (every wave computes the same total) cannot happen below 4800 pixels; strips if it does
+      if (total > LSD_SOLO_LDS_PTS) break;                  // (every wave computes the same total) cannot happen below 4800 pixels; strips if it does
       // the tile: the level's texel plane, 16 bytes per lane and step
       {
         gv4f* src = (gv4f*)a.fr_grad;
@@ -1082,7 +1079,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
       __syncthreads();
       // this lane's points: everything of the keyframe an evaluation reads, once per level
       {
-        float var[TRIPS], id[TRIPS];
+        float var[TRIPS], id[TRIPS], img[TRIPS];
 #pragma unroll
         for (int r = 0; r < TRIPS; r++) {
           const int p = tid + r * BLOCK;
@@ -1091,12 +1088,13 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
           pXY[r] = xy;
           var[r] = a.kf_idepthVar[i];
           id[r] = a.kf_idepth[i];
-          pI[r] = a.kf_image[i];
+          img[r] = a.kf_image[i];
         }
 #pragma unroll
         for (int r = 0; r < TRIPS; r++) {
-          s_var[r * BLOCK + tid] = var[r];
-          pZ[r] = (tid + r * BLOCK < total) ? lsd_rcp_exact(id[r]) * 1.0f : 1.0f;
+          const int p = tid + r * BLOCK;
+          if (p < total) { s_var[p] = var[r]; s_img[p] = img[r]; }
+          pZ[r] = (p < total) ? lsd_rcp_exact(id[r]) * 1.0f : 1.0f;
         }
       }
       listLevel = level;
@@ -1136,7 +1134,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
           acc[RS_NREF] += 1.f;
           if (T.q.in_image) {
             PointOut o;
-            eval_finish(a, T.q, T.t, pZ[r], pI[r], s_var[r * BLOCK + tid], o);
+            eval_finish(a, T.q, T.t, pZ[r], s_img[tid + r * BLOCK], s_var[tid + r * BLOCK], o);
             top3_insert(__mul24((int)(pXY[r] & 0xffffu), a.h) + (int)(pXY[r] >> 16), key0, key1, key2);   // reference order (x h + y, TrackingReference.cpp:128-138)
             accumulate_point(o, acc);
           }
@@ -1221,18 +1219,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict
         PointOut o;
         eval_finish(a, cq, ct, cPz, cImg, cVar, o);
         float* row = s_sub[lane];
-        row[0] = o.werr;
-        int k = 1;
-#pragma unroll
-        for (int rr = 0; rr < 6; rr++) {
-          const float Jw = o.J[rr] * o.w;
-#pragma unroll
-          for (int cc = rr; cc < 6; cc++) row[k++] = Jw * o.J[cc];
-        }
-        const float resw = o.res * o.w;
-#pragma unroll
-        for (int rr = 0; rr < 6; rr++) row[k++] = resw * o.J[rr];
-        row[k++] = resw * o.res;
+        tail_row(o, row);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
