@@ -2310,6 +2310,15 @@ static int batch_run(lsdhip_tracker* t, int n, bool callHook = false) {
   static const int soloMinEnv = getenv("LSDHIP_BATCH_SOLO_MIN") ? atoi(getenv("LSDHIP_BATCH_SOLO_MIN")) : LSD_SOLO_MIN_JOBS;   // developer A/B (0: never)
   const int soloMin = t->soloMinJobs >= 0 ? t->soloMinJobs : soloMinEnv;     // lsdhip_tracker_set_batch_coarse_min_jobs
   bool soloDue = split && fusedEnv && soloMin > 0 && n >= soloMin;
+  if (soloDue) {
+    // (nothing to walk if no job's top level fits the tile — 1280x1024: level 4 is 80x64 = 5120 pixels —: the launch would only copy states)
+    bool any = false;
+    for (int j = 0; j < n && !any; j++) {
+      const TrackLevel& L = t->h_bjobs[j].lv[t->h_bjobs[j].topLevel];
+      any = L.tilePx > 0 && !L.writeMask && (long long)L.w * L.h <= LSD_SOLO_MAX_PX;
+    }
+    soloDue = any;
+  }
   while (true) {
     if (c->prof_on) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     if (soloDue) {
