@@ -66,6 +66,7 @@ print(k, 'frames_s', d[k].get('frames_s'), 'block', d[k].get('frames_s_block_unt
     ;;
   ab)
     # A/B of environment switches on the pure tracking batches and the S-sequence loop, alternating: tools/gpu.sh ab <tag> "ENV=1 ..." ["ENV2=..."]
+    # (ABB="8,32,64" batch sizes of the pure batches, ABS="8 32" sequence counts of the loop)
     tag=$1; shift
     for rep in 1 2; do
       i=0
