@@ -332,7 +332,7 @@ def other_execution_model(DriverLoop, capi, w, h, K, ptr, depth0, device, pipeli
 def throughput_mode(la, w, h, K, d_frames, depth0, device, jobs=64, rounds=3):
     """The same residual evaluation with enough independent work per launch: `jobs` trackFrame jobs (frames 1..5 of the
     sequence against the keyframe with ground-truth depth) share every launch (lsdhip_tracker_track_batch, throughput mode: the
-    coarse levels in one workgroup per job — k_track_solo, from 32 jobs on —, then one fused launch per lock-step round).  Reports the algorithmic bandwidth of the step kernels over ALL launches of the
+    coarse levels in one workgroup per job — k_track_solo, from 24 jobs on —, then one fused launch per lock-step round).  Reports the algorithmic bandwidth of the step kernels over ALL launches of the
     jobs, HIP events around each batch; the level-1 evaluation launches alone run ~2.3x higher (profiles/r01_sizes.md).
     An extra, not the bench metric: the single-sequence loop above is what `value` and `roofline` describe."""
     ctx = la.Context(w, h, K, device=device)
@@ -490,6 +490,8 @@ def multi_seq(torch, w, h, K, seeds, device, single_value, sizes=(8, 32, 64, 128
                 loop = DriverLoopBatch(w, h, K, ptrs(0), [seeds[s % NS][1] for s in range(S)], kf_every=KF_EVERY, images_on_device=True, device=device)
                 loop.set_keyframe_phases([((s % 4) * KF_EVERY) // 4 for s in range(S)])   # independent cameras do not change keyframe in the same step
                 loop.set_pipeline(pipelined)
+                if os.environ.get("LSD_COARSE_MIN_JOBS"):      # developer A/B (tools/bench_multiseq.py): sequences per step from which the coarse levels run in one workgroup each
+                    loop.set_coarse_min_jobs(int(os.environ["LSD_COARSE_MIN_JOBS"]))
                 ctx_h = loop.ctx_handle()
                 t = 1
                 loop.run([ptrs(t + k) for k in range(warmup)])

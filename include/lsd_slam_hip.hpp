@@ -867,7 +867,7 @@ class SlamLoopBatch {
   // The tracking batch of step t + 1 — a chain of small latency-bound launches — runs beside the shared updateKeyframe launches and the
   // keyframe changes of step t.  Call before the first step().
   // One workgroup per sequence for the coarse levels of a tracking batch (lsdhip_tracker_set_batch_coarse_min_jobs) frees the chip for the
-  // mapping launches beside it: worth it from the library's default (32 sequences) where tracking runs beside mapping, from twice as
+  // mapping launches beside it: worth it from the library's default (24 sequences) where tracking runs beside mapping, from twice as
   // many where nothing runs beside the batch (measured: profiles/r06_notes.md section 21).  tracker.setBatchCoarseMinJobs overrides.
   static int coarseMinJobs(bool pipelined) {
     lsdhip_build_defaults_t d;

@@ -237,7 +237,7 @@ int lsdhip_tracker_set_speculation(lsdhip_tracker* t, int trials, int finestLeve
  * reference points that do not write refPixelWasGood (levels 4 and 3 of a 640x480 job) are walked by ONE workgroup per job — the tracked
  * frame's texel plane of the level staged in LDS (the tile of the bilinear taps), the level's reference points in registers, the whole LM
  * loop of the level in that workgroup — ahead of the lock-step rounds for the larger levels: same per-point arithmetic and LM decisions,
- * sums in that workgroup's order.  Default 32 jobs (below, the jobs have the chip to themselves
+ * sums in that workgroup's order.  Default 24 jobs (below, the jobs have the chip to themselves
  * and the lock-step rounds are as fast); 0: never. */
 int lsdhip_tracker_set_batch_coarse_min_jobs(lsdhip_tracker* t, int minJobs);
 /* out[0] = k_track_step launches of the last job that evaluated (<= its numEvaluations), out[1] = most trials per step (the

@@ -988,7 +988,7 @@ __global__ __launch_bounds__(BLOCK) void k_track_step(TrackJob jobv, const Track
 // Worth it from this many jobs per batch: one workgroup per job walks its coarse levels in about the time the lock-step rounds take, on
 // n CUs instead of the chip — a gain where other work (the mapping stream of the S-sequence loop) wants the other CUs, a small loss for
 // a few jobs that have the chip to themselves (profiles/r06_notes.md section 21).
-#define LSD_SOLO_MIN_JOBS 32
+#define LSD_SOLO_MIN_JOBS 24
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_track_solo(const TrackJob* __restrict__ jobs, TrackState* __restrict__ st2, TrackSummary* __restrict__ outs,
                                                           const int parity, const int doneWord) {

@@ -865,7 +865,7 @@ def test_track_batch_throughput_mode_matches_single_calls(oracle, hip, coarse):
     """>= 8 jobs switch the batch to its throughput mode (strips of the keyframe level compacted to their valid pixels in
     LDS, tail points re-evaluated): same points, same per-point arithmetic, another summation order.
     coarse = 1: the levels of at most 4800 pixels (here 4, 3 and 2) walked by one workgroup per job with the level's texel plane staged in
-    LDS (k_track_solo, the default from 32 jobs per batch): the same bounds."""
+    LDS (k_track_solo, the default from 24 jobs per batch): the same bounds."""
     w, h = 320, 240
     seqs = [sequence(w, h, 4, seq_index=s) for s in range(3)]
     ctx = hip.Context(w, h, seqs[0][2])

@@ -368,7 +368,7 @@ def test_batch_loop_8_seeds_640x480_against_the_oracle(hip, pipelined, coarse):
     by ~3e-4 under a 1e-6 perturbation of the first estimate there), it is compared with the closest member of the oracle's own ensemble,
     exactly as test_sequence_50_frames_hip_vs_oracle does for this loop.
     coarse = 1: the same with levels 4 and 3 of every tracking batch walked by one workgroup per sequence (k_track_solo: the default from
-    32 sequences per step, lsdhip_tracker_set_batch_coarse_min_jobs), held to the same bounds."""
+    24 sequences per step, lsdhip_tracker_set_batch_coarse_min_jobs), held to the same bounds."""
     from concurrent.futures import ThreadPoolExecutor
     import oracle.pyoracle as po
     import seq_loops as sl
