@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """The S-sequence leg of bench.py alone (bench.multi_seq: lsd_slam_hip::SlamLoopBatch, pipelined and blockUntilMapped), for A/B runs
-under environment switches.  Prints one JSON line.   python tools/bench_multiseq.py [--S 32] [--steps 30] [--tag name]"""
+under environment switches (LSD_COARSE_MIN_JOBS=n: lsdloopbatch_set_coarse_min_jobs of every loop).  Prints one JSON line.
+    python tools/bench_multiseq.py [--S 32] [--steps 30] [--tag name]"""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
